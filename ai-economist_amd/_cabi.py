@@ -1,0 +1,140 @@
+"""ctypes mirror of include/aie.h (the C ABI of the batched env.step()).
+
+Only plain C types cross this boundary: pointers, sizes, ints, doubles.  torch is used
+by env.py purely as the owner of device memory / streams.
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+MAX_AGENTS = 64
+MAX_COMPONENTS = 8
+MAX_BRACKETS = 16
+MAX_RATES = 64
+N_RES = 2
+MT_N = 624
+
+COMP_BUILD, COMP_CDA, COMP_GATHER, COMP_TAX = 1, 2, 3, 4
+SKILL = {"none": 0, "pareto": 1, "lognormal": 2}
+TAX_MODEL = {
+    "model_wrapper": 0,
+    "us-federal-single-filer-2018-scaled": 1,
+    "fixed-bracket-rates": 2,
+}
+WARMUP = {"decay": 0, "auto": 1}
+PLANNER_REWARD = {
+    "coin_eq_times_productivity": 0,
+    "inv_income_weighted_coin_endowments": 1,
+    "inv_income_weighted_utility": 2,
+}
+
+E_INVALID, E_NOTFOUND, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5
+
+DTYPES = ["uint8", "int8", "int16", "int32", "uint32", "float32", "float64"]
+
+
+class AieConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("n_envs", C.c_int32),
+        ("n_agents", C.c_int32),
+        ("world_h", C.c_int32),
+        ("world_w", C.c_int32),
+        ("episode_length", C.c_int32),
+        ("multi_action_mode_agents", C.c_int32),
+        ("multi_action_mode_planner", C.c_int32),
+        ("allow_observation_scaling", C.c_int32),
+        ("n_components", C.c_int32),
+        ("components", C.c_int32 * MAX_COMPONENTS),
+        ("has_water", C.c_int32),
+        ("shared_layout", C.c_int32),
+        ("planner_gets_spatial_info", C.c_int32),
+        ("full_observability", C.c_int32),
+        ("obs_range", C.c_int32),
+        ("fixed_four_skill_and_loc", C.c_int32),
+        ("energy_warmup_method", C.c_int32),
+        ("planner_reward_type", C.c_int32),
+        ("regen_halfwidth", C.c_int32 * N_RES),
+        ("max_health", C.c_int32 * N_RES),
+        ("regen_weight", C.c_double * N_RES),
+        ("starting_agent_coin", C.c_double),
+        ("isoelastic_eta", C.c_double),
+        ("energy_cost", C.c_double),
+        ("energy_warmup_constant", C.c_double),
+        ("mixing_weight_gini_vs_coin", C.c_double),
+        ("ranked_locs", (C.c_int32 * 2) * MAX_AGENTS),
+        ("avg_ranked_skill", C.c_double * MAX_AGENTS),
+        ("build_payment", C.c_int32),
+        ("build_payment_max_skill_multiplier", C.c_int32),
+        ("build_skill_dist", C.c_int32),
+        ("build_labor", C.c_double),
+        ("gather_skill_dist", C.c_int32),
+        ("move_labor", C.c_double),
+        ("collect_labor", C.c_double),
+        ("cda_max_bid_ask", C.c_int32),
+        ("cda_order_duration", C.c_int32),
+        ("cda_max_num_orders", C.c_int32),
+        ("cda_order_labor", C.c_double),
+        ("tax_disable", C.c_int32),
+        ("tax_model", C.c_int32),
+        ("tax_period", C.c_int32),
+        ("tax_n_brackets", C.c_int32),
+        ("tax_n_disc_rates", C.c_int32),
+        ("tax_bracket_cutoffs", C.c_double * MAX_BRACKETS),
+        ("tax_disc_rates", C.c_double * MAX_RATES),
+        ("tax_fixed_rates", C.c_double * MAX_BRACKETS),
+    ]
+
+
+class AieTensorDesc(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 64),
+        ("data", C.c_void_p),
+        ("dtype", C.c_int32),
+        ("ndim", C.c_int32),
+        ("shape", C.c_int64 * 6),
+        ("stride", C.c_int64 * 6),
+        ("arena_offset", C.c_int64),
+    ]
+
+
+def bind(lib):
+    """Declares the prototypes of every symbol include/aie.h exports."""
+    vp = C.c_void_p
+    lib.aie_arena_bytes.restype = C.c_int64
+    lib.aie_arena_bytes.argtypes = [C.POINTER(AieConfig)]
+    lib.aie_create.restype = C.c_int
+    lib.aie_create.argtypes = [C.POINTER(AieConfig), C.c_int, vp, C.c_int64, C.POINTER(vp)]
+    lib.aie_destroy.restype = C.c_int
+    lib.aie_destroy.argtypes = [vp]
+    lib.aie_last_error.restype = C.c_char_p
+    lib.aie_last_error.argtypes = [vp]
+    lib.aie_num_tensors.restype = C.c_int
+    lib.aie_num_tensors.argtypes = [vp]
+    lib.aie_tensor_at.restype = C.c_int
+    lib.aie_tensor_at.argtypes = [vp, C.c_int, C.POINTER(AieTensorDesc)]
+    lib.aie_get_tensor.restype = C.c_int
+    lib.aie_get_tensor.argtypes = [vp, C.c_char_p, C.POINTER(AieTensorDesc)]
+    lib.aie_upload.restype = C.c_int
+    lib.aie_upload.argtypes = [vp, C.c_char_p, vp, C.c_int64]
+    lib.aie_download.restype = C.c_int
+    lib.aie_download.argtypes = [vp, C.c_char_p, vp, C.c_int64]
+    lib.aie_set_layout.restype = C.c_int
+    lib.aie_set_layout.argtypes = [vp, vp, vp, vp]
+    lib.aie_seed.restype = C.c_int
+    lib.aie_seed.argtypes = [vp, C.c_uint32, vp]
+    lib.aie_set_rng_state.restype = C.c_int
+    lib.aie_set_rng_state.argtypes = [vp, vp, vp]
+    lib.aie_reset.restype = C.c_int
+    lib.aie_reset.argtypes = [vp, vp, vp]
+    lib.aie_step.restype = C.c_int
+    lib.aie_step.argtypes = [vp, vp, vp, vp]
+    lib.aie_sample_random_actions.restype = C.c_int
+    lib.aie_sample_random_actions.argtypes = [vp, C.c_uint64, C.c_int64, vp, vp, vp]
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "aie_arena_bytes", "aie_create", "aie_destroy", "aie_last_error", "aie_num_tensors",
+    "aie_tensor_at", "aie_get_tensor", "aie_upload", "aie_download", "aie_set_layout",
+    "aie_seed", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
+]

@@ -1,0 +1,471 @@
+/*
+ * aie_layout.h -- single source of truth for (a) the per-replica state record that
+ * lives in HBM, (b) the dense observation / reward tensors, (c) the action-space and
+ * flat-observation bookkeeping that the reference derives at construction time.
+ *
+ * Plain C99 (also included from HIP C++).  Included by the HIP library
+ * (aie_capi.hip / aie_kernels.hip) and by the CPU restatement oracle/aie_oracle.c so
+ * that both step byte-identical records.
+ *
+ * Reference logic restated here:
+ *   action subspace registration order + single-action map
+ *       F/base/base_agent.py:97-169  (_incorporate_component / register_components)
+ *   per-component action counts
+ *       F/components/build.py:88-98, move.py:69-79,
+ *       continuous_double_auction.py:411-431, redistribution.py:920-939
+ *   flat observation = concatenation in SORTED key order
+ *       F/base/base_env.py:561-612 (_build_packager/_package), keys prefixed with
+ *       "<Component.name>-" / "world-" at base_env.py:644-673
+ *   flattened masks  F/base/base_agent.py:440-460
+ *   map key order    F/base/world.py:59-93 (resources first, then sorted landmarks,
+ *                    then <Res>SourceBlock appended at :66)
+ */
+#ifndef AIE_LAYOUT_H_
+#define AIE_LAYOUT_H_
+
+#include <stdio.h>
+#include <string.h>
+
+#include "aie.h"
+
+#define AIE_MAX_TENSORS 64
+
+/* internal action-subspace slots of a mobile agent */
+enum {
+  AIE_SUB_BUILD = 0,
+  AIE_SUB_BUY0 = 1,  /* Buy_Stone  */
+  AIE_SUB_SELL0 = 2, /* Sell_Stone */
+  AIE_SUB_BUY1 = 3,  /* Buy_Wood   */
+  AIE_SUB_SELL1 = 4, /* Sell_Wood  */
+  AIE_SUB_GATHER = 5,
+  AIE_N_SUB_SLOTS = 6
+};
+
+/* Everything a kernel needs, passed BY VALUE as the kernel argument. */
+typedef struct aie_params {
+  aie_config c;
+
+  /* dims */
+  int32_t E, n, H, W, HW;
+  int32_t P;        /* price levels = max_bid_ask + 1                                  */
+  int32_t NB;       /* tax brackets                                                    */
+  int32_t M;        /* order-book capacity per commodity side = n * max_num_orders     */
+  int32_t CM;       /* map channels in Maps.state: 5 (no water) or 6                   */
+  int32_t WV;       /* egocentric window edge = 2*obs_range + 1                        */
+  int32_t has_build, has_cda, has_gather, has_tax;
+  int32_t planner_acts; /* 1 if the planner has tax action subspaces                   */
+
+  /* action spaces */
+  int32_t n_sub_a;                      /* registered agent subspaces, in order        */
+  int32_t sub_a_slot[AIE_MAX_SUBSPACES];/* -> AIE_SUB_*                                */
+  int32_t sub_a_dim[AIE_MAX_SUBSPACES]; /* number of non-NO-OP actions                 */
+  int32_t sub_a_base[AIE_MAX_SUBSPACES];/* first single-action index of the subspace   */
+  int32_t A;                            /* single-action mode: total actions incl NO-OP */
+  int32_t n_sub_p;                      /* planner subspaces (NB or 0)                 */
+  int32_t sub_p_dim;
+  int32_t act_a_width;                  /* ints per agent in d_actions_a               */
+  int32_t act_p_width;                  /* ints per replica in d_actions_p             */
+
+  /* flat observation sizes and fragment offsets (in f32 elements) */
+  int32_t FA, FP, FPA;                  /* agent flat, planner flat, planner p{i}      */
+  int32_t fa_build, fa_cda, fa_gather, fa_tax, fa_time, fa_world;
+  int32_t fp_cda, fp_tax, fp_time, fp_world;
+  int32_t fpa_tax, fpa_world;
+  int32_t MA, MP;                       /* flattened mask sizes                        */
+
+  /* per-replica record: byte offsets */
+  int32_t rec_bytes;
+  int32_t o_cells;  /* u32 [HW]: byte0 stone, byte1 wood, byte2 house owner (i8, -1 none),
+                       byte3 static flags (AIE_CELL_WATER | _STONE_SRC | _WOOD_SRC)        */
+  int32_t o_loc_r, o_loc_c, o_inv_res, o_esc_res;
+  int32_t o_inv_coin, o_esc_coin, o_labor, o_build_payment, o_build_skill, o_bonus_gather_prob;
+  int32_t o_util;
+  int32_t o_cda_n_bids, o_cda_n_asks, o_cda_bids, o_cda_asks, o_cda_n_orders;
+  int32_t o_cda_bid_hist, o_cda_ask_hist, o_cda_price_history;
+  int32_t o_tax_cycle_pos, o_tax_rate_idx, o_tax_last_coin, o_tax_last_income;
+  int32_t o_tax_last_marginal_rate, o_tax_total_collected;
+  int32_t o_timestep, o_completions, o_auto_warmup;
+  int32_t o_mt, o_mt_pos, o_mt_has_gauss, o_mt_gauss;
+
+  /* arena: byte offsets of the dense regions */
+  int64_t a_records;
+  int64_t a_obs_a_map, a_obs_a_idx, a_obs_a_flat, a_obs_a_mask, a_obs_a_time;
+  int64_t a_obs_p_map, a_obs_p_idx, a_obs_p_flat, a_obs_p_mask, a_obs_p_time, a_obs_p_agents;
+  int64_t a_rew_a, a_rew_p, a_done;
+  int64_t arena_bytes;
+} aie_params;
+
+typedef struct aie_tensor_table {
+  int32_t n;
+  aie_tensor_desc t[AIE_MAX_TENSORS];
+} aie_tensor_table;
+
+static inline int64_t aie__align(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+static inline int aie__dtype_size(int dt) {
+  switch (dt) {
+    case AIE_U8: case AIE_I8: return 1;
+    case AIE_I16: return 2;
+    case AIE_I32: case AIE_U32: case AIE_F32: return 4;
+    default: return 8;
+  }
+}
+
+static inline int aie__has(const aie_config* c, int comp) {
+  for (int i = 0; i < c->n_components; ++i)
+    if (c->components[i] == comp) return 1;
+  return 0;
+}
+
+#define AIE__FAIL(...)                                   \
+  do {                                                   \
+    if (err) snprintf(err, errlen, __VA_ARGS__);         \
+    return AIE_E_INVALID;                                \
+  } while (0)
+
+/* record field allocator */
+static inline int32_t aie__rec(int32_t* cur, int32_t bytes, int32_t align) {
+  int32_t o = (int32_t)aie__align(*cur, align);
+  *cur = o + bytes;
+  return o;
+}
+
+static inline void aie__add(aie_tensor_table* tt, const char* name, int dtype, int64_t off,
+                            int64_t env_stride, int ndim_inner, int64_t d0, int64_t d1,
+                            int64_t d2, int64_t d3, int64_t E) {
+  if (!tt || tt->n >= AIE_MAX_TENSORS) return;
+  aie_tensor_desc* d = &tt->t[tt->n++];
+  memset(d, 0, sizeof(*d));
+  snprintf(d->name, sizeof(d->name), "%s", name);
+  d->dtype = dtype;
+  d->ndim = 1 + ndim_inner;
+  int64_t dims[4] = {d0, d1, d2, d3};
+  d->shape[0] = E;
+  d->stride[0] = env_stride;
+  int64_t st = aie__dtype_size(dtype);
+  for (int i = ndim_inner - 1; i >= 0; --i) {
+    d->shape[1 + i] = dims[i];
+    d->stride[1 + i] = st;
+    st *= dims[i];
+  }
+  d->arena_offset = off;
+  d->data = NULL;
+}
+
+/* Validates the config (mirrors the reference's constructor asserts) and derives
+ * every dimension / offset.  `tt` may be NULL. */
+static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tensor_table* tt,
+                                   char* err, size_t errlen) {
+  memset(p, 0, sizeof(*p));
+  if (tt) tt->n = 0;
+  if (c->abi_version != AIE_ABI_VERSION) AIE__FAIL("abi_version %d != %d", c->abi_version, AIE_ABI_VERSION);
+  if (c->n_envs < 1) AIE__FAIL("n_envs must be >= 1");
+  if (c->n_agents < 2) AIE__FAIL("n_agents must be >= 2 (base_env.py:223)");
+  if (c->n_agents > AIE_MAX_AGENTS - 2) AIE__FAIL("n_agents > %d unsupported", AIE_MAX_AGENTS - 2);
+  if (c->world_h < 1 || c->world_w < 1 || c->world_h > 255 || c->world_w > 255)
+    AIE__FAIL("world_size out of range");
+  if (c->episode_length < 1) AIE__FAIL("episode_length must be >= 1 (base_env.py:254)");
+  if (c->n_components < 0 || c->n_components > AIE_MAX_COMPONENTS) AIE__FAIL("bad n_components");
+  for (int i = 0; i < c->n_components; ++i) {
+    int k = c->components[i];
+    if (k < AIE_COMP_BUILD || k > AIE_COMP_TAX) AIE__FAIL("unknown component id %d", k);
+    for (int j = 0; j < i; ++j)
+      if (c->components[j] == k) AIE__FAIL("component %d listed twice", k);
+  }
+  if (c->full_observability) {
+    if (err) snprintf(err, errlen, "full_observability=True is not supported yet");
+    return AIE_E_UNSUPPORTED;
+  }
+  if (c->obs_range < 0 || c->obs_range > 15) AIE__FAIL("mobile_agent_observation_range out of range");
+  for (int r = 0; r < AIE_N_RES; ++r) {
+    if (c->regen_halfwidth[r] != 0) {
+      if (err) snprintf(err, errlen, "regen_halfwidth > 0 is not supported (bit-exact guarantee is for 0)");
+      return AIE_E_UNSUPPORTED;
+    }
+    if (!(c->regen_weight[r] >= 0.0 && c->regen_weight[r] <= 1.0)) AIE__FAIL("regen_weight not in [0,1]");
+    if (c->max_health[r] < 1 || c->max_health[r] > 255) AIE__FAIL("max_health out of range");
+  }
+  if (!(c->starting_agent_coin >= 0.0)) AIE__FAIL("starting_agent_coin must be >= 0");
+  if (!(c->isoelastic_eta >= 0.0 && c->isoelastic_eta <= 1.0)) AIE__FAIL("isoelastic_eta not in [0,1]");
+  if (!(c->energy_cost >= 0.0)) AIE__FAIL("energy_cost must be >= 0");
+  if (!(c->energy_warmup_constant >= 0.0)) AIE__FAIL("energy_warmup_constant must be >= 0");
+  if (!(c->mixing_weight_gini_vs_coin >= 0.0 && c->mixing_weight_gini_vs_coin <= 1.0))
+    AIE__FAIL("mixing_weight_gini_vs_coin not in [0,1]");
+
+  p->c = *c;
+  p->E = c->n_envs;
+  p->n = c->n_agents;
+  p->H = c->world_h;
+  p->W = c->world_w;
+  p->HW = c->world_h * c->world_w;
+  p->has_build = aie__has(c, AIE_COMP_BUILD);
+  p->has_cda = aie__has(c, AIE_COMP_CDA);
+  p->has_gather = aie__has(c, AIE_COMP_GATHER);
+  p->has_tax = aie__has(c, AIE_COMP_TAX);
+  p->CM = c->has_water ? 6 : 5;
+  p->WV = 2 * c->obs_range + 1;
+
+  if (p->has_build) {
+    if (c->build_payment < 0) AIE__FAIL("Build.payment must be >= 0");
+    if (c->build_payment_max_skill_multiplier < 1) AIE__FAIL("Build.payment_max_skill_multiplier must be >= 1");
+    if (!(c->build_labor >= 0.0)) AIE__FAIL("Build.build_labor must be >= 0");
+    if (c->build_skill_dist < 0 || c->build_skill_dist > 2) AIE__FAIL("Build.skill_dist invalid");
+  }
+  if (p->has_gather) {
+    if (!(c->move_labor >= 0.0) || !(c->collect_labor >= 0.0)) AIE__FAIL("Gather labor must be >= 0");
+    if (c->gather_skill_dist < 0 || c->gather_skill_dist > 2) AIE__FAIL("Gather.skill_dist invalid");
+  }
+  if (c->fixed_four_skill_and_loc && !(p->has_build && c->build_skill_dist == AIE_SKILL_PARETO))
+    AIE__FAIL("fixed_four_skill_and_loc requires Build with skill_dist='pareto' (layout_from_file.py:177-178)");
+  if (p->has_cda) {
+    if (c->cda_max_bid_ask < 1 || c->cda_max_bid_ask > 126) AIE__FAIL("CDA.max_bid_ask out of range");
+    if (c->cda_order_duration < 1 || c->cda_order_duration > 32000) AIE__FAIL("CDA.order_duration out of range");
+    if (c->cda_max_num_orders < 1 || c->cda_max_num_orders > 255) AIE__FAIL("CDA.max_num_orders out of range");
+    if (!(c->cda_order_labor >= 0.0)) AIE__FAIL("CDA.order_labor must be >= 0");
+    p->P = c->cda_max_bid_ask + 1;
+    p->M = c->n_agents * c->cda_max_num_orders;
+  }
+  if (p->has_tax) {
+    if (c->tax_period < 1) AIE__FAIL("Tax.period must be > 0");
+    if (c->tax_n_brackets < 2 || c->tax_n_brackets > AIE_MAX_BRACKETS) AIE__FAIL("Tax.n_brackets out of range");
+    if (c->tax_model < AIE_TAX_MODEL_WRAPPER || c->tax_model > AIE_TAX_FIXED) {
+      if (err) snprintf(err, errlen, "tax_model not supported (saez is host-side episodic numerics)");
+      return AIE_E_UNSUPPORTED;
+    }
+    if (c->tax_bracket_cutoffs[0] != 0.0) AIE__FAIL("bracket_cutoffs[0] must be 0 (redistribution.py:243)");
+    if (c->tax_model == AIE_TAX_MODEL_WRAPPER && !c->tax_disable) {
+      if (c->tax_n_disc_rates < 2 || c->tax_n_disc_rates > AIE_MAX_RATES) AIE__FAIL("Tax.n_disc_rates out of range");
+      p->planner_acts = 1;
+    } else if (c->tax_model == AIE_TAX_MODEL_WRAPPER) {
+      if (c->tax_n_disc_rates < 1 || c->tax_n_disc_rates > AIE_MAX_RATES) AIE__FAIL("Tax.n_disc_rates out of range");
+    }
+    p->NB = c->tax_n_brackets;
+  }
+
+  /* ---- action subspaces, registration order = component order ----------------- */
+  int ns = 0, base = 1;
+  for (int i = 0; i < c->n_components; ++i) {
+    switch (c->components[i]) {
+      case AIE_COMP_BUILD:
+        p->sub_a_slot[ns] = AIE_SUB_BUILD; p->sub_a_dim[ns] = 1; ns++; break;
+      case AIE_COMP_CDA:
+        for (int r = 0; r < AIE_N_RES; ++r) {
+          p->sub_a_slot[ns] = r ? AIE_SUB_BUY1 : AIE_SUB_BUY0; p->sub_a_dim[ns] = p->P; ns++;
+          p->sub_a_slot[ns] = r ? AIE_SUB_SELL1 : AIE_SUB_SELL0; p->sub_a_dim[ns] = p->P; ns++;
+        }
+        break;
+      case AIE_COMP_GATHER:
+        p->sub_a_slot[ns] = AIE_SUB_GATHER; p->sub_a_dim[ns] = 4; ns++; break;
+      default: break;
+    }
+  }
+  p->n_sub_a = ns;
+  for (int s = 0; s < ns; ++s) { p->sub_a_base[s] = base; base += p->sub_a_dim[s]; }
+  p->A = base;
+  if (c->multi_action_mode_agents) {
+    if (ns == 0) { p->act_a_width = 1; }      /* PassiveAgentPlaceholder, base_agent.py:158-161 */
+    else p->act_a_width = ns;
+  } else {
+    p->act_a_width = 1;
+  }
+  p->n_sub_p = p->planner_acts ? p->NB : 0;
+  p->sub_p_dim = p->planner_acts ? c->tax_n_disc_rates : 0;
+  if (c->multi_action_mode_planner) p->act_p_width = p->n_sub_p ? p->n_sub_p : 1;
+  else p->act_p_width = 1;
+
+  /* ---- flattened masks (base_agent.py:440-460) -------------------------------- */
+  if (c->multi_action_mode_agents) {
+    p->MA = 0;
+    for (int s = 0; s < ns; ++s) p->MA += 1 + p->sub_a_dim[s];
+    if (ns == 0) p->MA = 1;
+  } else {
+    p->MA = p->A;
+  }
+  if (c->multi_action_mode_planner) p->MP = p->n_sub_p ? p->n_sub_p * (1 + p->sub_p_dim) : 1;
+  else p->MP = 1 + p->n_sub_p * p->sub_p_dim;
+
+  /* ---- flat observations: sorted keys ----------------------------------------- */
+  {
+    int f = 0;
+    p->fa_build = f;  if (p->has_build) f += 2;
+    p->fa_cda = f;    if (p->has_cda) f += 10 * p->P + 2;
+    p->fa_gather = f; if (p->has_gather) f += 1;
+    p->fa_tax = f;    if (p->has_tax) f += p->NB + p->n + 4;
+    p->fa_time = f;   f += 1;
+    p->fa_world = f;  f += 5; /* inventory-Coin,-Stone,-Wood, loc-col, loc-row */
+    p->FA = f;
+    f = 0;
+    p->fp_cda = f;    if (p->has_cda) f += 6 * p->P + 2;
+    p->fp_tax = f;    if (p->has_tax) f += p->NB + p->n + 3;
+    p->fp_time = f;   f += 1;
+    p->fp_world = f;  f += 3;
+    p->FP = f;
+    f = 0;
+    p->fpa_tax = f;   if (p->has_tax) f += 3;
+    p->fpa_world = f; f += 3 + (c->planner_gets_spatial_info ? 2 : 0);
+    p->FPA = f;
+  }
+
+  /* ---- per-replica record ------------------------------------------------------ */
+  const int n = p->n, HW = p->HW, R = AIE_N_RES;
+  int32_t cur = 0;
+  p->o_cells = aie__rec(&cur, 4 * HW, 16);
+  p->o_inv_coin = aie__rec(&cur, 8 * n, 8);
+  p->o_esc_coin = aie__rec(&cur, 8 * n, 8);
+  p->o_labor = aie__rec(&cur, 8 * n, 8);
+  p->o_build_payment = aie__rec(&cur, 8 * n, 8);
+  p->o_build_skill = aie__rec(&cur, 8 * n, 8);
+  p->o_bonus_gather_prob = aie__rec(&cur, 8 * n, 8);
+  p->o_util = aie__rec(&cur, 8 * (n + 1), 8);
+  p->o_loc_r = aie__rec(&cur, 4 * n, 4);
+  p->o_loc_c = aie__rec(&cur, 4 * n, 4);
+  p->o_inv_res = aie__rec(&cur, 4 * R * n, 4);
+  p->o_esc_res = aie__rec(&cur, 4 * R * n, 4);
+  if (p->has_cda) {
+    p->o_cda_price_history = aie__rec(&cur, 8 * R * n * p->P, 8);
+    p->o_cda_n_bids = aie__rec(&cur, 4 * R, 4);
+    p->o_cda_n_asks = aie__rec(&cur, 4 * R, 4);
+    p->o_cda_bids = aie__rec(&cur, 4 * R * p->M, 4);
+    p->o_cda_asks = aie__rec(&cur, 4 * R * p->M, 4);
+    p->o_cda_n_orders = aie__rec(&cur, 4 * R * n, 4);
+    p->o_cda_bid_hist = aie__rec(&cur, R * n * p->P, 4);
+    p->o_cda_ask_hist = aie__rec(&cur, R * n * p->P, 4);
+  }
+  if (p->has_tax) {
+    p->o_tax_last_coin = aie__rec(&cur, 8 * n, 8);
+    p->o_tax_last_income = aie__rec(&cur, 8 * n, 8);
+    p->o_tax_last_marginal_rate = aie__rec(&cur, 8 * n, 8);
+    p->o_tax_total_collected = aie__rec(&cur, 8, 8);
+    p->o_tax_cycle_pos = aie__rec(&cur, 4, 4);
+    p->o_tax_rate_idx = aie__rec(&cur, 4 * p->NB, 4);
+  }
+  p->o_timestep = aie__rec(&cur, 4, 4);
+  p->o_completions = aie__rec(&cur, 4, 4);
+  p->o_auto_warmup = aie__rec(&cur, 4, 4);
+  p->o_mt_gauss = aie__rec(&cur, 8, 8);
+  p->o_mt_pos = aie__rec(&cur, 4, 4);
+  p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
+  p->o_mt = aie__rec(&cur, 4 * AIE_MT_N, 16);
+  p->rec_bytes = (int32_t)aie__align(cur, 16);
+
+  /* ---- arena ------------------------------------------------------------------- */
+  const int64_t E = p->E;
+  int64_t a = 0;
+  p->a_records = a; a = aie__align(a + E * (int64_t)p->rec_bytes, 256);
+  const int64_t wv2 = (int64_t)p->WV * p->WV;
+  p->a_obs_a_map = a;  a = aie__align(a + E * n * (p->CM + 1) * wv2 * 4, 256);
+  p->a_obs_a_idx = a;  a = aie__align(a + E * n * 2 * wv2 * 2, 256);
+  p->a_obs_a_flat = a; a = aie__align(a + E * n * p->FA * 4, 256);
+  p->a_obs_a_mask = a; a = aie__align(a + E * n * p->MA * 4, 256);
+  p->a_obs_a_time = a; a = aie__align(a + E * n * 4, 256);
+  if (c->planner_gets_spatial_info) {
+    p->a_obs_p_map = a; a = aie__align(a + E * p->CM * HW * 4, 256);
+    p->a_obs_p_idx = a; a = aie__align(a + E * 2 * HW * 2, 256);
+  }
+  p->a_obs_p_flat = a;   a = aie__align(a + E * p->FP * 4, 256);
+  p->a_obs_p_mask = a;   a = aie__align(a + E * p->MP * 4, 256);
+  p->a_obs_p_time = a;   a = aie__align(a + E * 4, 256);
+  p->a_obs_p_agents = a; a = aie__align(a + E * n * p->FPA * 4, 256);
+  p->a_rew_a = a; a = aie__align(a + E * n * 4, 256);
+  p->a_rew_p = a; a = aie__align(a + E * 4, 256);
+  p->a_done = a;  a = aie__align(a + E, 256);
+  p->arena_bytes = a;
+
+  /* ---- tensor table ------------------------------------------------------------ */
+  if (tt) {
+    const int64_t rs = p->rec_bytes, r0 = p->a_records;
+#define REC(name, dt, off, nd, d0, d1, d2) aie__add(tt, name, dt, r0 + (off), rs, nd, d0, d1, d2, 0, E)
+    REC("cells", AIE_U32, p->o_cells, 2, p->H, p->W, 0);
+    /* byte-plane views into the packed cell words (element stride 4) */
+    {
+      static const char* nm[4] = {"stone", "wood", "house_owner", "cell_flags"};
+      for (int b = 0; b < 4; ++b) {
+        REC(nm[b], b == 2 ? AIE_I8 : AIE_U8, p->o_cells + b, 2, p->H, p->W, 0);
+        aie_tensor_desc* d = &tt->t[tt->n - 1];
+        d->stride[2] = 4;
+        d->stride[1] = 4 * (int64_t)p->W;
+      }
+    }
+    REC("loc_r", AIE_I32, p->o_loc_r, 1, n, 0, 0);
+    REC("loc_c", AIE_I32, p->o_loc_c, 1, n, 0, 0);
+    REC("inv_res", AIE_I32, p->o_inv_res, 2, R, n, 0);
+    REC("esc_res", AIE_I32, p->o_esc_res, 2, R, n, 0);
+    REC("inv_coin", AIE_F64, p->o_inv_coin, 1, n, 0, 0);
+    REC("esc_coin", AIE_F64, p->o_esc_coin, 1, n, 0, 0);
+    REC("labor", AIE_F64, p->o_labor, 1, n, 0, 0);
+    REC("build_payment", AIE_F64, p->o_build_payment, 1, n, 0, 0);
+    REC("build_skill", AIE_F64, p->o_build_skill, 1, n, 0, 0);
+    REC("bonus_gather_prob", AIE_F64, p->o_bonus_gather_prob, 1, n, 0, 0);
+    REC("util", AIE_F64, p->o_util, 1, n + 1, 0, 0);
+    if (p->has_cda) {
+      REC("cda_n_bids", AIE_I32, p->o_cda_n_bids, 1, R, 0, 0);
+      REC("cda_n_asks", AIE_I32, p->o_cda_n_asks, 1, R, 0, 0);
+      REC("cda_bids", AIE_I32, p->o_cda_bids, 2, R, p->M, 0);
+      REC("cda_asks", AIE_I32, p->o_cda_asks, 2, R, p->M, 0);
+      REC("cda_n_orders", AIE_I32, p->o_cda_n_orders, 2, R, n, 0);
+      REC("cda_bid_hist", AIE_U8, p->o_cda_bid_hist, 3, R, n, p->P);
+      REC("cda_ask_hist", AIE_U8, p->o_cda_ask_hist, 3, R, n, p->P);
+      REC("cda_price_history", AIE_F64, p->o_cda_price_history, 3, R, n, p->P);
+    }
+    if (p->has_tax) {
+      REC("tax_cycle_pos", AIE_I32, p->o_tax_cycle_pos, 0, 0, 0, 0);
+      REC("tax_rate_idx", AIE_I32, p->o_tax_rate_idx, 1, p->NB, 0, 0);
+      REC("tax_last_coin", AIE_F64, p->o_tax_last_coin, 1, n, 0, 0);
+      REC("tax_last_income", AIE_F64, p->o_tax_last_income, 1, n, 0, 0);
+      REC("tax_last_marginal_rate", AIE_F64, p->o_tax_last_marginal_rate, 1, n, 0, 0);
+      REC("tax_total_collected", AIE_F64, p->o_tax_total_collected, 0, 0, 0, 0);
+    }
+    REC("timestep", AIE_I32, p->o_timestep, 0, 0, 0, 0);
+    REC("completions", AIE_I32, p->o_completions, 0, 0, 0, 0);
+    REC("auto_warmup", AIE_I32, p->o_auto_warmup, 0, 0, 0, 0);
+    REC("mt", AIE_U32, p->o_mt, 1, AIE_MT_N, 0, 0);
+    REC("mt_pos", AIE_I32, p->o_mt_pos, 0, 0, 0, 0);
+    REC("mt_has_gauss", AIE_I32, p->o_mt_has_gauss, 0, 0, 0, 0);
+    REC("mt_gauss", AIE_F64, p->o_mt_gauss, 0, 0, 0, 0);
+#undef REC
+#define DENSE(name, dt, off, nd, d0, d1, d2, d3)                                            \
+  do {                                                                                      \
+    int64_t dd[4] = {d0, d1, d2, d3};                                                       \
+    int64_t es = aie__dtype_size(dt);                                                       \
+    for (int q = 0; q < nd; ++q) es *= dd[q];                                               \
+    aie__add(tt, name, dt, off, es, nd, d0, d1, d2, d3, E);                                 \
+  } while (0)
+    DENSE("obs_a_world-map", AIE_F32, p->a_obs_a_map, 4, n, p->CM + 1, p->WV, p->WV);
+    DENSE("obs_a_world-idx_map", AIE_I16, p->a_obs_a_idx, 4, n, 2, p->WV, p->WV);
+    DENSE("obs_a_flat", AIE_F32, p->a_obs_a_flat, 2, n, p->FA, 0, 0);
+    DENSE("obs_a_action_mask", AIE_F32, p->a_obs_a_mask, 2, n, p->MA, 0, 0);
+    DENSE("obs_a_time", AIE_F32, p->a_obs_a_time, 2, n, 1, 0, 0);
+    if (c->planner_gets_spatial_info) {
+      DENSE("obs_p_world-map", AIE_F32, p->a_obs_p_map, 3, p->CM, p->H, p->W, 0);
+      DENSE("obs_p_world-idx_map", AIE_I16, p->a_obs_p_idx, 3, 2, p->H, p->W, 0);
+    }
+    DENSE("obs_p_flat", AIE_F32, p->a_obs_p_flat, 1, p->FP, 0, 0, 0);
+    DENSE("obs_p_action_mask", AIE_F32, p->a_obs_p_mask, 1, p->MP, 0, 0, 0);
+    DENSE("obs_p_time", AIE_F32, p->a_obs_p_time, 1, 1, 0, 0, 0);
+    DENSE("obs_p_agents", AIE_F32, p->a_obs_p_agents, 2, n, p->FPA, 0, 0);
+    DENSE("rewards_a", AIE_F32, p->a_rew_a, 1, n, 0, 0, 0);
+    DENSE("rewards_p", AIE_F32, p->a_rew_p, 0, 0, 0, 0, 0);
+    DENSE("done", AIE_U8, p->a_done, 0, 0, 0, 0, 0);
+#undef DENSE
+  }
+  return AIE_OK;
+}
+
+/* packed map cell */
+#define AIE_CELL_WATER 1u
+#define AIE_CELL_STONE_SRC 2u
+#define AIE_CELL_WOOD_SRC 4u
+#define AIE_CELL_STONE(w) ((w) & 0xffu)
+#define AIE_CELL_WOOD(w) (((w) >> 8) & 0xffu)
+#define AIE_CELL_OWNER(w) ((int)(int8_t)(((w) >> 16) & 0xffu))
+#define AIE_CELL_FLAGS(w) (((w) >> 24) & 0xffu)
+#define AIE_CELL_PACK(st, wd, own, fl) \
+  ((uint32_t)(st) | ((uint32_t)(wd) << 8) | (((uint32_t)(own) & 0xffu) << 16) | ((uint32_t)(fl) << 24))
+
+/* order word packing: agent | price << 8 | lifetime << 16 */
+#define AIE_ORD_AGENT(o) ((o) & 0xff)
+#define AIE_ORD_PRICE(o) (((o) >> 8) & 0xff)
+#define AIE_ORD_LIFE(o) (((o) >> 16) & 0xffff)
+#define AIE_ORD_PACK(a, p, l) ((int32_t)((a) | ((p) << 8) | ((l) << 16)))
+
+#endif /* AIE_LAYOUT_H_ */

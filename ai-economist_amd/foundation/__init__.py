@@ -1,0 +1,25 @@
+"""Host-side mirror of `ai_economist.foundation` for the MI355X batched backend.
+
+Same entry points as the reference package (F/__init__.py:7-18):
+
+    from ai_economist_amd import foundation
+    env = foundation.make_env_instance("layout_from_file/simple_wood_and_stone",
+                                       n_envs=4096, **same_kwargs_as_the_reference)
+    obs = env.reset(); obs, rew, done, info = env.step(actions)
+
+`foundation.scenarios / components / agents / resources / landmarks / endogenous`
+are the registries; register your own Scenario/Component spec classes with
+`@foundation.scenarios.add` / `@foundation.components.add`.
+"""
+from .components import component_registry as components
+from .entities import agent_registry as agents
+from .entities import endogenous_registry as endogenous
+from .entities import landmark_registry as landmarks
+from .entities import resource_registry as resources
+from .scenarios import scenario_registry as scenarios
+
+
+def make_env_instance(scenario_name, **kwargs):
+    """Looks the scenario up by name and constructs it (F/__init__.py:16-18)."""
+    scenario_class = scenarios.get(scenario_name)
+    return scenario_class(**kwargs)

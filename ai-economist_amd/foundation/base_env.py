@@ -1,0 +1,266 @@
+"""BaseEnvironment: the Gym-style reset()/step() surface, batched over E replicas.
+
+Mirrors the constructor contract, properties and call order of the reference's
+`BaseEnvironment` (F/base/base_env.py:24-1120) but every replica-level computation is
+a HIP kernel behind the C ABI (include/aie.h); this class only validates kwargs,
+builds the `aie_config`, and hands out batched torch views.
+
+Differences that come with batching (documented in INTEGRATION.md):
+  * obs / rew / done are batched tensors keyed "a" (all mobile agents, leading dims
+    [E, n_agents]) and "p" (planner, leading dim [E]) -- the layout the reference uses
+    with collate_agent_step_and_reset_data=True, with the agent axis FIRST;
+    `as_reference_dicts(e)` rebuilds the reference's exact per-replica dict.
+  * randomness is one legacy-NumPy MT19937 stream PER replica (replica e of
+    `seed(s)` == the reference after `env.seed(s + e)`), not the process-global stream.
+"""
+import ctypes
+
+import numpy as np
+
+from .. import _cabi
+from .components import component_registry
+from .entities import endogenous_registry, landmark_registry, resource_registry
+from .registrar import Registry
+
+
+class BaseEnvironment:
+    name = ""
+    agent_subclasses = []
+    required_entities = None
+
+    def __init__(self, components=None, n_agents=None, world_size=None, episode_length=1000,
+                 multi_action_mode_agents=False, multi_action_mode_planner=True,
+                 flatten_observations=True, flatten_masks=True,
+                 allow_observation_scaling=True, dense_log_frequency=None,
+                 world_dense_log_frequency=50, collate_agent_step_and_reset_data=False,
+                 seed=None, n_envs=1, device=None, env_offset=0):
+        assert self.name
+        assert isinstance(self.agent_subclasses, (tuple, list)) and len(self.agent_subclasses) > 0
+        assert isinstance(self.required_entities, (tuple, list))
+        assert isinstance(world_size, (tuple, list)) and len(world_size) == 2
+        self.world_size = list(world_size)
+        assert isinstance(n_agents, int) and n_agents >= 2
+        self.n_agents = n_agents
+        self.num_agents = n_agents + 1  # + planner, as in base_env.py:227-230
+        assert isinstance(components, (tuple, list))
+
+        def spec_is_valid(spec):
+            if isinstance(spec, (tuple, list)):
+                return len(spec) == 2 and isinstance(spec[0], str) and isinstance(spec[1], dict)
+            if isinstance(spec, dict):
+                return (len(spec) == 1 and isinstance(list(spec.keys())[0], str)
+                        and isinstance(list(spec.values())[0], dict))
+            return False
+
+        assert all(spec_is_valid(c) for c in components)
+        self._episode_length = int(episode_length)
+        assert self._episode_length >= 1
+        self.multi_action_mode_agents = bool(multi_action_mode_agents)
+        self.multi_action_mode_planner = bool(multi_action_mode_planner)
+        self._allow_observation_scaling = bool(allow_observation_scaling)
+        if not flatten_observations or not flatten_masks:
+            raise NotImplementedError(
+                "the batched backend always produces flattened observations and masks")
+        if dense_log_frequency is not None:
+            raise NotImplementedError("dense logs are not produced by the batched backend yet")
+        self.collate_agent_step_and_reset_data = True
+        self.n_envs = int(n_envs)
+        assert self.n_envs >= 1
+        self.env_offset = int(env_offset)  # global index of replica 0 (multi-GPU sharding)
+        self._device = device
+
+        self._entities = {"resources": ["Coin"], "landmarks": [], "endogenous": ["Labor"]}
+        self._register_entities(self.required_entities)
+        self._components = []
+        self._components_dict = {}
+        self._shorthand_lookup = {}
+        for spec in components:
+            if isinstance(spec, (tuple, list)):
+                cname, ckw = spec
+            else:
+                cname, ckw = list(spec.keys())[0], list(spec.values())[0]
+            ccls = component_registry.get(cname)
+            self._register_entities(ccls.required_entities)
+            obj = ccls(self.n_agents, self._episode_length, inventory_scale=self.inv_scale, **ckw)
+            if obj.name in self._components_dict:
+                raise ValueError("component {} listed twice".format(obj.name))
+            self._components.append(obj)
+            self._components_dict[obj.name] = obj
+            self._shorthand_lookup[obj.shorthand] = obj
+
+        self._completions = 0
+        self._backend = None
+        self._pending_seed = None if seed is None else int(seed)
+        if seed is not None:
+            assert isinstance(seed, (int, float)) and int(seed) > 0
+
+    # ---- entity bookkeeping (base_env.py:368-408) ----
+    def _register_entities(self, entities):
+        for entity in entities:
+            if resource_registry.has(entity):
+                if entity not in self._entities["resources"]:
+                    self._entities["resources"].append(entity)
+            elif landmark_registry.has(entity):
+                if entity not in self._entities["landmarks"]:
+                    self._entities["landmarks"].append(entity)
+            elif endogenous_registry.has(entity):
+                if entity not in self._entities["endogenous"]:
+                    self._entities["endogenous"].append(entity)
+            else:
+                raise KeyError("Unknown entity: {}".format(entity))
+
+    @property
+    def episode_length(self):
+        return int(self._episode_length)
+
+    @property
+    def inv_scale(self):
+        return 0.01 if self._allow_observation_scaling else 1
+
+    @property
+    def resources(self):
+        return sorted(self._entities["resources"])
+
+    @property
+    def landmarks(self):
+        return sorted(self._entities["landmarks"])
+
+    @property
+    def endogenous(self):
+        return sorted(self._entities["endogenous"])
+
+    @property
+    def components(self):
+        return self._components
+
+    def get_component(self, component_name):
+        if component_name not in self._components_dict:
+            if component_name not in self._shorthand_lookup:
+                raise KeyError(
+                    "No component with name or shorthand name {} found; registered "
+                    "components are:\n\t".format(component_name)
+                    + "\n\t".join(self._components_dict.keys()))
+            return self._shorthand_lookup[component_name]
+        return self._components_dict[component_name]
+
+    # ---- C-ABI config ----
+    def fill_scenario_config(self, cfg):
+        raise NotImplementedError
+
+    def layout_planes(self):
+        """Returns (stone_src, wood_src, water) uint8 [H, W] (or [E, H, W]) planes."""
+        raise NotImplementedError
+
+    def build_config(self):
+        cfg = _cabi.AieConfig()
+        ctypes.memset(ctypes.byref(cfg), 0, ctypes.sizeof(cfg))
+        cfg.abi_version = _cabi.ABI_VERSION
+        cfg.n_envs = self.n_envs
+        cfg.n_agents = self.n_agents
+        cfg.world_h, cfg.world_w = int(self.world_size[0]), int(self.world_size[1])
+        cfg.episode_length = self._episode_length
+        cfg.multi_action_mode_agents = int(self.multi_action_mode_agents)
+        cfg.multi_action_mode_planner = int(self.multi_action_mode_planner)
+        cfg.allow_observation_scaling = int(self._allow_observation_scaling)
+        if len(self._components) > _cabi.MAX_COMPONENTS:
+            raise ValueError("too many components")
+        cfg.n_components = len(self._components)
+        for i, c in enumerate(self._components):
+            cfg.components[i] = c.comp_id
+            c.fill_config(cfg)
+        self.fill_scenario_config(cfg)
+        return cfg
+
+    # ---- device backend ----
+    @property
+    def backend(self):
+        if self._backend is None:
+            from ..env import DeviceBackend  # needs torch + the HIP library; fails loudly
+
+            self._backend = DeviceBackend(self.build_config(), self.layout_planes(),
+                                          device=self._device)
+            if self._pending_seed is not None:
+                self._backend.seed(self._pending_seed + self.env_offset)
+        return self._backend
+
+    def seed(self, seed):
+        """Replica e gets the NumPy legacy stream of `np.random.seed(seed + env_offset + e)`
+        (reference: BaseEnvironment.seed, base_env.py:481-494)."""
+        assert isinstance(seed, (int, float))
+        seed = int(seed)
+        assert seed > 0
+        self._pending_seed = seed
+        if self._backend is not None:
+            self._backend.seed(seed + self.env_offset)
+
+    def set_rng_state(self, keys, pos):
+        """Injects raw MT19937 states (reference: reset/step(seed_state=...))."""
+        self.backend.set_rng_state(keys, pos)
+
+    def tensor(self, name):
+        return self.backend.tensors[name]
+
+    @property
+    def tensors(self):
+        return self.backend.tensors
+
+    def _obs(self):
+        t = self.backend.tensors
+        obs = {"a": {}, "p": {}}
+        for k, v in t.items():
+            if k.startswith("obs_a_"):
+                obs["a"][k[6:]] = v
+            elif k.startswith("obs_p_"):
+                obs["p"][k[6:]] = v
+        return obs
+
+    def reset(self, env_mask=None):
+        """Resets all replicas (or those selected by the uint8/bool device tensor
+        `env_mask`, e.g. the `done` tensor) and returns batched observations."""
+        if self._backend is None and self._pending_seed is None:
+            # the reference falls back on whatever the global NumPy stream holds;
+            # here an unseeded env is seeded from the OS once.
+            self._pending_seed = int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31 - 1)) + 1
+        self.backend.reset(env_mask)
+        return self._obs()
+
+    def step(self, actions=None):
+        """actions: None (all NO-OP), or {"a": int32 [E, n_agents(, n_subspaces)],
+        "p": int32 [E, n_planner_subspaces]} device tensors.  Returns the batched
+        (obs, rew, done, info) of base_env.py:929-1032."""
+        a = p = None
+        if actions is not None:
+            assert isinstance(actions, dict)
+            a = actions.get("a")
+            p = actions.get("p")
+        self.backend.step(a, p)
+        t = self.backend.tensors
+        rew = {"a": t["rewards_a"], "p": t["rewards_p"]}
+        done = {"__all__": t["done"]}
+        info = {"a": {}, "p": {}}
+        return self._obs(), rew, done, info
+
+    def as_reference_dicts(self, e):
+        """Rebuilds the reference's per-replica observation dict
+        ({"0": {...}, ..., "p": {..., "p0": ...}}) for replica e as NumPy arrays."""
+        t = self.backend.tensors
+        out = {}
+        for i in range(self.n_agents):
+            d = {}
+            for k, v in t.items():
+                if k.startswith("obs_a_"):
+                    d[k[6:]] = v[e, i].cpu().numpy()
+            out[str(i)] = d
+        d = {}
+        for k, v in t.items():
+            if k == "obs_p_agents":
+                arr = v[e].cpu().numpy()
+                for i in range(self.n_agents):
+                    d["p%d" % i] = arr[i]
+            elif k.startswith("obs_p_"):
+                d[k[6:]] = v[e].cpu().numpy()
+        out["p"] = d
+        return out
+
+
+scenario_registry = Registry(BaseEnvironment)

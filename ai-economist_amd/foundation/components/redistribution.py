@@ -1,0 +1,118 @@
+"""`PeriodicBracketTax` (reference: F/components/redistribution.py:78-346, 920-939;
+dynamics -> tax_component_step / tax_enact in csrc/aie_kernels.hip).
+
+Supported tax models: "model_wrapper" (planner picks discretised rates),
+"us-federal-single-filer-2018-scaled", "fixed-bracket-rates".  The Saez model
+(redistribution.py:436-823) is episodic host-side numerics and is listed under
+"next" in DESIGN.md.
+"""
+import numpy as np
+
+from ... import _cabi
+from .base import BaseComponent, component_registry
+
+
+@component_registry.add
+class PeriodicBracketTax(BaseComponent):
+    name = "PeriodicBracketTax"
+    component_type = "PeriodicTax"
+    required_entities = ["Coin"]
+    agent_subclasses = ["BasicMobileAgent", "BasicPlanner"]
+    comp_id = _cabi.COMP_TAX
+
+    US_FEDERAL_2018 = [0.1, 0.12, 0.22, 0.24, 0.32, 0.35, 0.37]
+
+    def __init__(self, *base_args, disable_taxes=False, tax_model="model_wrapper",
+                 period=100, rate_min=0.0, rate_max=1.0, rate_disc=0.05, n_brackets=5,
+                 top_bracket_cutoff=100, usd_scaling=1000.0, bracket_spacing="us-federal",
+                 fixed_bracket_rates=None, pareto_weight_type="inverse_income",
+                 saez_fixed_elas=None, tax_annealing_schedule=None, **base_kwargs):
+        super().__init__(*base_args, **base_kwargs)
+        self.disable_taxes = bool(disable_taxes)
+        self.tax_model = tax_model
+        assert self.tax_model in ["model_wrapper", "us-federal-single-filer-2018-scaled",
+                                  "saez", "fixed-bracket-rates"]
+        if self.tax_model == "saez":
+            raise NotImplementedError(
+                "tax_model='saez' is not implemented by the MI355X backend yet")
+        if tax_annealing_schedule is not None:
+            raise NotImplementedError("tax_annealing_schedule is not implemented yet")
+        self.period = int(period)
+        assert self.period > 0
+        self.rate_min = 0.0 if self.disable_taxes else float(rate_min)
+        self.rate_max = 0.0 if self.disable_taxes else float(rate_max)
+        assert 0 <= self.rate_min <= self.rate_max <= 1.0
+        self.rate_disc = float(rate_disc)
+        self.use_discretized_rates = self.tax_model == "model_wrapper"
+        if self.use_discretized_rates:
+            self.disc_rates = np.arange(self.rate_min, self.rate_max + self.rate_disc,
+                                        self.rate_disc)
+            self.disc_rates = self.disc_rates[self.disc_rates <= self.rate_max]
+            assert len(self.disc_rates) > 1 or self.disable_taxes
+            self.n_disc_rates = len(self.disc_rates)
+        else:
+            self.disc_rates = None
+            self.n_disc_rates = 0
+
+        self.n_brackets = int(n_brackets)
+        assert self.n_brackets >= 2
+        self.top_bracket_cutoff = float(top_bracket_cutoff)
+        assert self.top_bracket_cutoff >= 10
+        self.usd_scale = float(usd_scaling)
+        assert self.usd_scale > 0
+        self.bracket_spacing = bracket_spacing.lower()
+        assert self.bracket_spacing in ["linear", "log", "us-federal"]
+        if self.bracket_spacing == "linear":
+            self.bracket_cutoffs = np.linspace(0, self.top_bracket_cutoff, self.n_brackets)
+        elif self.bracket_spacing == "log":
+            b0_max = self.top_bracket_cutoff / (2 ** (self.n_brackets - 2))
+            self.bracket_cutoffs = np.concatenate(
+                [[0], 2 ** np.linspace(np.log2(b0_max), np.log2(self.top_bracket_cutoff),
+                                       n_brackets - 1)])
+        else:
+            self.bracket_cutoffs = (
+                np.array([0, 9700, 39475, 84200, 160725, 204100, 510300]) / self.usd_scale)
+            self.n_brackets = len(self.bracket_cutoffs)
+            self.top_bracket_cutoff = float(self.bracket_cutoffs[-1])
+        assert self.bracket_cutoffs[0] == 0
+
+        if self.tax_model == "us-federal-single-filer-2018-scaled":
+            assert self.bracket_spacing == "us-federal"
+        if self.tax_model == "fixed-bracket-rates":
+            assert isinstance(fixed_bracket_rates, (tuple, list))
+            assert np.min(fixed_bracket_rates) >= 0
+            assert np.max(fixed_bracket_rates) <= 1
+            assert len(fixed_bracket_rates) == self.n_brackets
+            self._fixed_bracket_rates = np.array(fixed_bracket_rates, dtype=np.float64)
+        else:
+            self._fixed_bracket_rates = None
+
+    def get_n_actions(self, agent_cls_name):
+        if agent_cls_name == "BasicPlanner":
+            if self.tax_model == "model_wrapper" and not self.disable_taxes:
+                return [("TaxIndexBracket_{:03d}".format(int(r)), self.n_disc_rates)
+                        for r in self.bracket_cutoffs]
+        return 0
+
+    def fill_config(self, cfg):
+        if self.n_brackets > _cabi.MAX_BRACKETS:
+            raise ValueError("n_brackets > {}".format(_cabi.MAX_BRACKETS))
+        cfg.tax_disable = int(self.disable_taxes)
+        cfg.tax_model = _cabi.TAX_MODEL[self.tax_model]
+        cfg.tax_period = self.period
+        cfg.tax_n_brackets = self.n_brackets
+        for i, v in enumerate(self.bracket_cutoffs):
+            cfg.tax_bracket_cutoffs[i] = float(v)
+        if self.use_discretized_rates:
+            if self.n_disc_rates > _cabi.MAX_RATES:
+                raise ValueError("more than {} discretised rates".format(_cabi.MAX_RATES))
+            cfg.tax_n_disc_rates = self.n_disc_rates
+            for i, v in enumerate(self.disc_rates):
+                cfg.tax_disc_rates[i] = float(v)
+        else:
+            cfg.tax_n_disc_rates = 0
+            base = (self.US_FEDERAL_2018
+                    if self.tax_model == "us-federal-single-filer-2018-scaled"
+                    else self._fixed_bracket_rates)
+            for i, v in enumerate(np.minimum(np.array(base, dtype=np.float64), self.rate_max)):
+                cfg.tax_fixed_rates[i] = float(v)

@@ -1,0 +1,211 @@
+/*
+ * aie.h -- C ABI of the MI355X-native batched Foundation env.step().
+ *
+ * One `aie_env` owns E independent replicas of one Foundation environment on one
+ * GPU.  The reference has no such seam for gather-trade-build; the closest thing it
+ * has is the WarpDrive wrapper used by the COVID scenario, and every entry point below
+ * cites the reference interface it stands in for (paths relative to the reference
+ * tree, F/ = ai_economist/foundation/):
+ *
+ *   aie_create            F/__init__.py:16-18 (make_env_instance) +
+ *                         F/base/base_env.py:178-366 (BaseEnvironment.__init__) +
+ *                         F/env_wrapper.py:96-265 (FoundationEnvWrapper.__init__)
+ *   aie_seed              F/base/base_env.py:481-494 (BaseEnvironment.seed ->
+ *                         np.random.seed), one legacy MT19937 stream PER replica
+ *   aie_set_rng_state     F/base/base_env.py:871-881 / 968-978 (seed_state injection)
+ *   aie_reset             F/base/base_env.py:852-927 (reset) +
+ *                         F/env_wrapper.py:267-353 (reset_all_envs/reset_only_done_envs)
+ *   aie_step              F/base/base_env.py:929-1032 (step) +
+ *                         F/env_wrapper.py:355-377 (step_all_envs)
+ *   aie_get_tensor        F/env_wrapper.py:297-326 (get_data_dictionary /
+ *                         get_tensor_dictionary -> CUDADataManager.push_data_to_device,
+ *                         torch_accessible=True)
+ *   aie_upload/_download  F/env_wrapper.py:291-329 (one-time host -> device push)
+ *
+ * Conventions: every function returns 0 on success or a negative AIE_E_* code;
+ * aie_last_error() gives the message.  The library owns all state / observation /
+ * reward buffers (one arena, optionally caller-provided so that it can be a
+ * torch-owned allocation); the caller owns action buffers.  All kernels are enqueued
+ * asynchronously on the caller's HIP stream; there are no hidden synchronisations
+ * except in aie_upload/aie_download/aie_destroy.  Calls on one handle are not
+ * thread-safe; distinct handles are independent.  No process-global RNG.
+ */
+#ifndef AIE_H_
+#define AIE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIE_ABI_VERSION 1
+
+#define AIE_MAX_AGENTS 64      /* mobile agents per replica (one lane each)            */
+#define AIE_MAX_COMPONENTS 8
+#define AIE_MAX_BRACKETS 16
+#define AIE_MAX_RATES 64       /* discretised tax rates per bracket                     */
+#define AIE_MAX_SUBSPACES 16   /* action subspaces per agent class                      */
+#define AIE_N_RES 2            /* collectible resources, sorted: 0 = Stone, 1 = Wood    */
+#define AIE_MT_N 624
+
+/* ---- error codes ---------------------------------------------------------------- */
+#define AIE_OK 0
+#define AIE_E_INVALID (-1)     /* bad argument / config (reference: assert/ValueError)  */
+#define AIE_E_NOTFOUND (-2)    /* unknown tensor name (reference: KeyError)             */
+#define AIE_E_HIP (-3)         /* HIP runtime error                                     */
+#define AIE_E_NOMEM (-4)
+#define AIE_E_UNSUPPORTED (-5)
+
+/* ---- component ids (registry names in the reference, F/components/*.py) -------- */
+enum {
+  AIE_COMP_BUILD = 1,          /* "Build"                     F/components/build.py:15        */
+  AIE_COMP_CDA = 2,            /* "ContinuousDoubleAuction"   F/components/continuous_double_auction.py:16 */
+  AIE_COMP_GATHER = 3,         /* "Gather"                    F/components/move.py:16         */
+  AIE_COMP_TAX = 4             /* "PeriodicBracketTax"        F/components/redistribution.py:78 */
+};
+
+enum { AIE_SKILL_NONE = 0, AIE_SKILL_PARETO = 1, AIE_SKILL_LOGNORMAL = 2 };
+enum {
+  AIE_TAX_MODEL_WRAPPER = 0,   /* "model_wrapper": planner actions pick the rates       */
+  AIE_TAX_US_FEDERAL = 1,      /* "us-federal-single-filer-2018-scaled"                 */
+  AIE_TAX_FIXED = 2            /* "fixed-bracket-rates"                                 */
+};
+enum { AIE_WARMUP_DECAY = 0, AIE_WARMUP_AUTO = 1 };
+enum {
+  AIE_PLANNER_REW_COIN_EQ_TIMES_PROD = 0,
+  AIE_PLANNER_REW_INV_INCOME_COIN = 1,
+  AIE_PLANNER_REW_INV_INCOME_UTIL = 2
+};
+
+enum {
+  AIE_U8 = 0, AIE_I8 = 1, AIE_I16 = 2, AIE_I32 = 3, AIE_U32 = 4, AIE_F32 = 5, AIE_F64 = 6
+};
+
+/* ---- configuration: the kwargs of make_env_instance + component kwargs ---------- */
+typedef struct aie_config {
+  int32_t abi_version;
+  int32_t n_envs;                    /* E replicas on this device                      */
+  int32_t n_agents;                  /* base_env.py:221-224 (>= 2)                      */
+  int32_t world_h, world_w;          /* base_env.py:215-219                             */
+  int32_t episode_length;            /* base_env.py:253                                 */
+  int32_t multi_action_mode_agents;  /* base_env.py:258                                 */
+  int32_t multi_action_mode_planner; /* base_env.py:259                                 */
+  int32_t allow_observation_scaling; /* base_env.py:262 -> inv_scale 0.01 / time scale  */
+  int32_t n_components;
+  int32_t components[AIE_MAX_COMPONENTS]; /* AIE_COMP_*, in config order (=dynamics order) */
+
+  /* scenario: layout_from_file / uniform simple_wood_and_stone
+   * (F/scenarios/simple_wood_and_stone/layout_from_file.py:68-167) */
+  int32_t has_water;                 /* "Water" landmark registered (LayoutFromFile)    */
+  int32_t shared_layout;             /* 1: source/water planes identical in all replicas */
+  int32_t planner_gets_spatial_info;
+  int32_t full_observability;
+  int32_t obs_range;                 /* mobile_agent_observation_range                  */
+  int32_t fixed_four_skill_and_loc;
+  int32_t energy_warmup_method;
+  int32_t planner_reward_type;
+  int32_t regen_halfwidth[AIE_N_RES];/* must be 0 (bit-exact guarantee)  */
+  int32_t max_health[AIE_N_RES];
+  double regen_weight[AIE_N_RES];
+  double starting_agent_coin;
+  double isoelastic_eta;
+  double energy_cost;
+  double energy_warmup_constant;
+  double mixing_weight_gini_vs_coin;
+  int32_t ranked_locs[AIE_MAX_AGENTS][2]; /* fixed_four_skill_and_loc, :196-247         */
+  double avg_ranked_skill[AIE_MAX_AGENTS];/* already multiplied by Build.payment, :192  */
+
+  /* Build (F/components/build.py:41-68) */
+  int32_t build_payment;
+  int32_t build_payment_max_skill_multiplier;
+  int32_t build_skill_dist;
+  double build_labor;
+
+  /* Gather (F/components/move.py:41-64) */
+  int32_t gather_skill_dist;
+  double move_labor, collect_labor;
+
+  /* ContinuousDoubleAuction (continuous_double_auction.py:42-77) */
+  int32_t cda_max_bid_ask;
+  int32_t cda_order_duration;
+  int32_t cda_max_num_orders;
+  double cda_order_labor;
+
+  /* PeriodicBracketTax (redistribution.py:137-346) */
+  int32_t tax_disable;
+  int32_t tax_model;
+  int32_t tax_period;
+  int32_t tax_n_brackets;
+  int32_t tax_n_disc_rates;
+  double tax_bracket_cutoffs[AIE_MAX_BRACKETS];
+  double tax_disc_rates[AIE_MAX_RATES];       /* np.arange(rate_min, rate_max+disc, disc) */
+  double tax_fixed_rates[AIE_MAX_BRACKETS];   /* us-federal / fixed models, <= rate_max  */
+} aie_config;
+
+/* ---- tensor descriptor ---------------------------------------------------------- */
+typedef struct aie_tensor_desc {
+  char name[64];
+  void* data;            /* device pointer of element [0,...,0] (NULL before aie_create)*/
+  int32_t dtype;         /* AIE_U8 ...                                                  */
+  int32_t ndim;          /* includes the leading env dimension                         */
+  int64_t shape[6];
+  int64_t stride[6];     /* in BYTES (state fields live in per-env records => strided)  */
+  int64_t arena_offset;  /* byte offset of element [0,...] inside the arena             */
+} aie_tensor_desc;
+
+typedef struct aie_env aie_env;
+
+/* Validates cfg and returns the arena size in bytes (> 0) or a negative error code. */
+int64_t aie_arena_bytes(const aie_config* cfg);
+
+/* Creates E replicas on HIP device `device`.  If `arena` is non-NULL it must be a
+ * device allocation of at least aie_arena_bytes(cfg) bytes, 256-byte aligned, that
+ * outlives the env (e.g. a torch uint8 tensor); otherwise the library hipMallocs it. */
+int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_bytes,
+               aie_env** out);
+int aie_destroy(aie_env* env);
+const char* aie_last_error(const aie_env* env /* NULL: last create error */);
+
+/* Number of exported tensors and their descriptors (index or name lookup). */
+int aie_num_tensors(const aie_env* env);
+int aie_tensor_at(const aie_env* env, int index, aie_tensor_desc* out);
+int aie_get_tensor(const aie_env* env, const char* name, aie_tensor_desc* out);
+
+/* Host <-> device copies of one named tensor (dense, C-order, leading dim = E).
+ * Synchronous; meant for initial state injection and parity dumps. */
+int aie_upload(aie_env* env, const char* name, const void* host, int64_t bytes);
+int aie_download(aie_env* env, const char* name, void* host, int64_t bytes);
+
+/* Source-block / water planes (HOST pointers, u8 [H*W] each; with shared_layout=1 one
+ * replica's planes which are broadcast, else E of them).  They are packed into the
+ * static flag byte of every map cell (layout_from_file.py:103-112, 323-334). */
+int aie_set_layout(aie_env* env, const uint8_t* stone_src, const uint8_t* wood_src,
+                   const uint8_t* water);
+
+/* Replica e gets the stream np.random.seed(base_seed + e) would give. */
+int aie_seed(aie_env* env, uint32_t base_seed, void* stream);
+/* Raw legacy-MT19937 state per replica: key[E][624], pos[E] (np.random.get_state()). */
+int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos);
+
+/* Resets the replicas whose env_mask byte is non-zero (NULL = all); env_mask is a
+ * DEVICE pointer [E] u8 (e.g. the `done` tensor).  Writes reset observations. */
+int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream);
+
+/* One env.step() for all replicas.  d_actions_a: device int32 [E, n_agents]
+ * (single-action mode) or [E, n_agents, n_subspaces] (multi-action mode);
+ * d_actions_p: device int32 [E, n_planner_subspaces] (multi-action planner) or [E].
+ * Either may be NULL (= all NO-OP, base_env.py:964-966). */
+int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p,
+             void* stream);
+
+/* Fills caller-owned action buffers with the bench's synthetic uniform random policy:
+ * counter RNG keyed (seed, global env id, t, agent) -- SURVEY.md section 8(d). */
+int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_offset,
+                              int32_t* d_actions_a, int32_t* d_actions_p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIE_H_ */

@@ -1,0 +1,1033 @@
+/*
+ * aie_oracle.c -- TEST INFRASTRUCTURE.  A plain-C, single-replica-at-a-time CPU
+ * restatement of the reference Foundation env.reset()/env.step() for the
+ * gather-trade-build family.  It is the checker for the HIP path: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product
+ * (ai-economist_amd/) never calls into this file.
+ *
+ * Parity status: PINNED.  This restatement is itself checked, step by step, against
+ * (a) the live reference Python (tests/test_oracle_vs_reference.py, only where
+ * /root/reference exists) and (b) the committed fixtures in tests/golden/ that
+ * oracle/gen_golden.py produced by running the unmodified reference.
+ *
+ * It steps the SAME byte records / dense tensors that the device uses
+ * (ai-economist_amd/csrc/aie_layout.h), so a parity check is a byte compare for all
+ * integer state and a tolerance compare for f64/f32 fields.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference tree; F/ = ai_economist/foundation/).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../ai-economist_amd/csrc/aie_layout.h"
+
+typedef struct {
+  const aie_params* p;
+  uint8_t* rec;              /* this replica's record                                 */
+  uint8_t* arena;
+  int e;
+  int act[AIE_MAX_AGENTS][AIE_N_SUB_SLOTS]; /* decoded per-subspace actions           */
+  int act_p[AIE_MAX_BRACKETS];
+} ctx_t;
+
+#define F64(c, off) ((double*)((c)->rec + (c)->p->off))
+#define I32(c, off) ((int32_t*)((c)->rec + (c)->p->off))
+#define U8(c, off) ((uint8_t*)((c)->rec + (c)->p->off))
+#define I8(c, off) ((int8_t*)((c)->rec + (c)->p->off))
+#define CELLS(c) ((uint32_t*)((c)->rec + (c)->p->o_cells))
+/* byte lanes of the packed cell word (little endian): stone, wood, owner, flags */
+#define CB(c, cell, b) (((uint8_t*)CELLS(c))[4 * (cell) + (b)])
+#define C_STONE(c, cell) CB(c, cell, 0)
+#define C_WOOD(c, cell) CB(c, cell, 1)
+#define C_OWNER(c, cell) (((int8_t*)CELLS(c))[4 * (cell) + 2])
+#define C_FLAGS(c, cell) CB(c, cell, 3)
+
+/* ------------------------------------------------------------------------------- */
+/* NumPy legacy RandomState (MT19937) -- third-party dependency of the reference,  */
+/* numpy (any version: the legacy stream is frozen); algorithms restated from the  */
+/* published MT19937 reference code and numpy/random/src/{mt19937,legacy,distributions}. */
+/* Used by the reference through np.random.* (F/base/base_env.py:493,              */
+/* F/base/world.py:420, F/components/move.py:138, layout_from_file.py:361-366,400). */
+/* ------------------------------------------------------------------------------- */
+static void mt_twist(uint32_t* mt) {
+  const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAT = 0x9908b0dfu;
+  int i;
+  uint32_t y;
+  for (i = 0; i < 624 - 397; i++) {
+    y = (mt[i] & UPPER) | (mt[i + 1] & LOWER);
+    mt[i] = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
+  }
+  for (; i < 623; i++) {
+    y = (mt[i] & UPPER) | (mt[i + 1] & LOWER);
+    mt[i] = mt[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
+  }
+  y = (mt[623] & UPPER) | (mt[0] & LOWER);
+  mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
+}
+
+static uint32_t rng_u32(ctx_t* c) {
+  uint32_t* mt = (uint32_t*)(c->rec + c->p->o_mt);
+  int32_t* pos = I32(c, o_mt_pos);
+  if (*pos >= 624) {
+    mt_twist(mt);
+    *pos = 0;
+  }
+  uint32_t y = mt[(*pos)++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+/* legacy random_sample: 53-bit double from two words */
+static double rng_double(ctx_t* c) {
+  uint32_t a = rng_u32(c) >> 5, b = rng_u32(c) >> 6;
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+/* random_interval(max): masked rejection on 32-bit words (max <= 0xffffffff) */
+static uint32_t rng_interval(ctx_t* c, uint32_t max) {
+  if (max == 0) return 0;
+  uint32_t mask = max, v;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  while ((v = (rng_u32(c) & mask)) > max) {}
+  return v;
+}
+
+/* np.random.randint(0, high) legacy (int64 default, masked rejection, rng = high-1) */
+static int rng_randint(ctx_t* c, int high) { return (int)rng_interval(c, (uint32_t)(high - 1)); }
+
+static double rng_gauss(ctx_t* c) {
+  int32_t* has = I32(c, o_mt_has_gauss);
+  double* g = F64(c, o_mt_gauss);
+  if (*has) {
+    double t = *g;
+    *has = 0;
+    *g = 0.0;
+    return t;
+  }
+  double f, x1, x2, r2;
+  do {
+    x1 = 2.0 * rng_double(c) - 1.0;
+    x2 = 2.0 * rng_double(c) - 1.0;
+    r2 = x1 * x1 + x2 * x2;
+  } while (r2 >= 1.0 || r2 == 0.0);
+  f = sqrt(-2.0 * log(r2) / r2);
+  *g = f * x1;
+  *has = 1;
+  return f * x2;
+}
+static double rng_std_exponential(ctx_t* c) { return -log(1.0 - rng_double(c)); }
+static double rng_pareto(ctx_t* c, double a) { return exp(rng_std_exponential(c) / a) - 1.0; }
+static double rng_lognormal(ctx_t* c, double mean, double sigma) {
+  return exp(mean + sigma * rng_gauss(c));
+}
+
+/* np.random.permutation(n) == shuffle(arange(n)), Fisher-Yates from the top.
+ * F/base/world.py:418-422 (World.get_random_order_agents). */
+static void rng_permutation(ctx_t* c, int n, int* out) {
+  for (int i = 0; i < n; ++i) out[i] = i;
+  for (int i = n - 1; i >= 1; --i) {
+    int j = (int)rng_interval(c, (uint32_t)i);
+    int t = out[i]; out[i] = out[j]; out[j] = t;
+  }
+}
+
+/* np.random.seed(int): init_genrand; pos = 624 (first draw twists) */
+void aie_oracle_seed_one(uint32_t* mt, uint32_t seed) {
+  mt[0] = seed;
+  for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+}
+
+/* numpy float64 add.reduce over a contiguous run: pairwise summation
+ * (numpy/_core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum). */
+static double np_sum(const double* a, int n) {
+  if (n < 8) {
+    double res = -0.0;
+    for (int i = 0; i < n; ++i) res += a[i];
+    return res;
+  } else if (n <= 128) {
+    double r[8];
+    int i;
+    for (i = 0; i < 8; ++i) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  } else {
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_sum(a, n2) + np_sum(a + n2, n - n2);
+  }
+}
+
+/* ------------------------------------------------------------------------------- */
+/* World helpers: F/base/world.py                                                   */
+/* ------------------------------------------------------------------------------- */
+static int occupied_by_other(ctx_t* c, int r, int col, int self) {
+  const int32_t *lr = I32(c, o_loc_r), *lc = I32(c, o_loc_c);
+  for (int j = 0; j < c->p->n; ++j)
+    if (j != self && lr[j] == r && lc[j] == col) return 1;
+  return 0;
+}
+
+/* World.can_agent_occupy (world.py:424-440): in bounds, accessible (no Water; House
+ * only if owner, world.py:213-217,256-258,300-305) and unoccupied. */
+static int accessible(ctx_t* c, int r, int col, int agent) {
+  const aie_params* p = c->p;
+  if (r < 0 || r >= p->H || col < 0 || col >= p->W) return 0;
+  int cell = r * p->W + col;
+  if (C_FLAGS(c, cell) & AIE_CELL_WATER) return 0;
+  int8_t o = C_OWNER(c, cell);
+  return o < 0 || o == agent;
+}
+static int can_agent_occupy(ctx_t* c, int r, int col, int agent) {
+  return accessible(c, r, col, agent) && !occupied_by_other(c, r, col, agent);
+}
+
+/* ------------------------------------------------------------------------------- */
+/* Build: F/components/build.py                                                     */
+/* ------------------------------------------------------------------------------- */
+/* Build.agent_can_build, build.py:70-83 (+ world.py:284-293) */
+static int agent_can_build(ctx_t* c, int i) {
+  const aie_params* p = c->p;
+  const int32_t* inv = I32(c, o_inv_res);
+  if (inv[1 * p->n + i] < 1 || inv[0 * p->n + i] < 1) return 0;
+  int cell = I32(c, o_loc_r)[i] * p->W + I32(c, o_loc_c)[i];
+  if (C_STONE(c, cell) > 0 || C_WOOD(c, cell) > 0) return 0;
+  if (C_OWNER(c, cell) >= 0) return 0;
+  if (C_FLAGS(c, cell) & (AIE_CELL_WATER | AIE_CELL_STONE_SRC | AIE_CELL_WOOD_SRC)) return 0;
+  return 1;
+}
+
+/* Build.component_step, build.py:112-161 */
+static void build_step(ctx_t* c) {
+  const aie_params* p = c->p;
+  int order[AIE_MAX_AGENTS];
+  rng_permutation(c, p->n, order); /* drawn even if nobody builds (build.py:121) */
+  for (int k = 0; k < p->n; ++k) {
+    int i = order[k];
+    if (c->act[i][AIE_SUB_BUILD] != 1) continue;
+    if (!agent_can_build(c, i)) continue;
+    I32(c, o_inv_res)[1 * p->n + i] -= 1;
+    I32(c, o_inv_res)[0 * p->n + i] -= 1;
+    int cell = I32(c, o_loc_r)[i] * p->W + I32(c, o_loc_c)[i];
+    C_OWNER(c, cell) = (int8_t)i; /* world.py:474-479, 240-259 */
+    F64(c, o_inv_coin)[i] += F64(c, o_build_payment)[i];
+    F64(c, o_labor)[i] += p->c.build_labor;
+  }
+}
+
+/* ------------------------------------------------------------------------------- */
+/* Gather: F/components/move.py                                                     */
+/* ------------------------------------------------------------------------------- */
+/* Gather.component_step, move.py:93-153 */
+static void gather_step(ctx_t* c) {
+  const aie_params* p = c->p;
+  int order[AIE_MAX_AGENTS];
+  rng_permutation(c, p->n, order);
+  int32_t *lr = I32(c, o_loc_r), *lc = I32(c, o_loc_c);
+  for (int k = 0; k < p->n; ++k) {
+    int i = order[k];
+    int a = c->act[i][AIE_SUB_GATHER];
+    int r = lr[i], col = lc[i], nr = r, nc = col;
+    if (a != 0) {
+      if (a == 1) nc = col - 1;       /* Left  */
+      else if (a == 2) nc = col + 1;  /* Right */
+      else if (a == 3) nr = r - 1;    /* Up    */
+      else nr = r + 1;                /* Down  */
+      if (can_agent_occupy(c, nr, nc, i)) { /* world.py:454-460 */
+        lr[i] = nr; lc[i] = nc;
+      } else {
+        nr = r; nc = col;
+      }
+      if (nr != r || nc != col) F64(c, o_labor)[i] += p->c.move_labor;
+    }
+    /* collect on the landing tile -- also on a NO-OP (move.py:112-113,136).
+     * location_resources is evaluated once, before any consumption (world.py:284-288) */
+    int cell = nr * p->W + nc;
+    int health[2] = {C_STONE(c, cell), C_WOOD(c, cell)};
+    for (int rsrc = 0; rsrc < 2; ++rsrc) {
+      if (health[rsrc] >= 1) {
+        /* rand() is consumed even if bonus_gather_prob == 0 (move.py:138) */
+        int n_gathered = 1 + (rng_double(c) < F64(c, o_bonus_gather_prob)[i] ? 1 : 0);
+        I32(c, o_inv_res)[rsrc * p->n + i] += n_gathered;
+        CB(c, cell, rsrc) -= 1; /* consume_resource, world.py:481-483 */
+        F64(c, o_labor)[i] += p->c.collect_labor;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------- */
+/* ContinuousDoubleAuction: F/components/continuous_double_auction.py               */
+/* ------------------------------------------------------------------------------- */
+/* create_bid :168-198 / create_ask :200-229 */
+static void cda_create_bid(ctx_t* c, int r, int i, int price) {
+  const aie_params* p = c->p;
+  int32_t* no = I32(c, o_cda_n_orders) + r * p->n;
+  if (!(no[i] < p->c.cda_max_num_orders) || F64(c, o_inv_coin)[i] < (double)price) return;
+  int32_t* nb = I32(c, o_cda_n_bids) + r;
+  I32(c, o_cda_bids)[r * p->M + *nb] = AIE_ORD_PACK(i, price, 0);
+  (*nb)++;
+  U8(c, o_cda_bid_hist)[(r * p->n + i) * p->P + price] += 1;
+  no[i] += 1;
+  /* inventory_to_escrow("Coin", price), base_agent.py:279-299 */
+  double inv = F64(c, o_inv_coin)[i];
+  double tr = inv < (double)price ? inv : (double)price;
+  F64(c, o_inv_coin)[i] -= tr;
+  F64(c, o_esc_coin)[i] += tr;
+  F64(c, o_labor)[i] += p->c.cda_order_labor;
+}
+static void cda_create_ask(ctx_t* c, int r, int i, int price) {
+  const aie_params* p = c->p;
+  int32_t* no = I32(c, o_cda_n_orders) + r * p->n;
+  int32_t* inv = I32(c, o_inv_res) + r * p->n;
+  if (!(no[i] < p->c.cda_max_num_orders && inv[i] > 0)) return;
+  int32_t* na = I32(c, o_cda_n_asks) + r;
+  I32(c, o_cda_asks)[r * p->M + *na] = AIE_ORD_PACK(i, price, 0);
+  (*na)++;
+  U8(c, o_cda_ask_hist)[(r * p->n + i) * p->P + price] += 1;
+  no[i] += 1;
+  inv[i] -= 1;
+  I32(c, o_esc_res)[r * p->n + i] += 1;
+  F64(c, o_labor)[i] += p->c.cda_order_labor;
+}
+
+/* stable insertion sorts reproducing Python's sorted(..., key, reverse) (:249-256) */
+static int bid_before(int32_t a, int32_t b) { /* (bid, lifetime) descending */
+  int pa = AIE_ORD_PRICE(a), pb = AIE_ORD_PRICE(b);
+  if (pa != pb) return pa > pb;
+  return AIE_ORD_LIFE(a) > AIE_ORD_LIFE(b);
+}
+static int ask_before(int32_t a, int32_t b) { /* (ask, -lifetime) ascending */
+  int pa = AIE_ORD_PRICE(a), pb = AIE_ORD_PRICE(b);
+  if (pa != pb) return pa < pb;
+  return AIE_ORD_LIFE(a) > AIE_ORD_LIFE(b);
+}
+static void stable_sort(int32_t* v, int n, int (*before)(int32_t, int32_t)) {
+  for (int i = 1; i < n; ++i) {
+    int32_t x = v[i];
+    int j = i - 1;
+    while (j >= 0 && before(x, v[j])) { v[j + 1] = v[j]; --j; }
+    v[j + 1] = x;
+  }
+}
+static void list_pop(int32_t* v, int* n, int idx) {
+  for (int k = idx; k + 1 < *n; ++k) v[k] = v[k + 1];
+  (*n)--;
+}
+
+/* match_orders :231-350 -- literal restatement of the restart loop */
+static void cda_match(ctx_t* c) {
+  const aie_params* p = c->p;
+  for (int r = 0; r < AIE_N_RES; ++r) {
+    int possible[AIE_MAX_AGENTS];
+    for (int i = 0; i < p->n; ++i) possible[i] = 1;
+    int keep_checking = 1;
+    int32_t* bids = I32(c, o_cda_bids) + r * p->M;
+    int32_t* asks = I32(c, o_cda_asks) + r * p->M;
+    int nb = I32(c, o_cda_n_bids)[r], na = I32(c, o_cda_n_asks)[r];
+    stable_sort(bids, nb, bid_before);
+    stable_sort(asks, na, ask_before);
+    for (;;) {
+      int any = 0;
+      for (int i = 0; i < p->n; ++i) any |= possible[i];
+      if (!(any && keep_checking)) break;
+      int ib = 0, ia = 0;
+      for (;;) {
+        if (ib >= nb) { keep_checking = 0; break; }
+        int buyer = AIE_ORD_AGENT(bids[ib]);
+        if (!possible[buyer]) { ib++; }
+        else if (ia >= na) { possible[buyer] = 0; break; }
+        else if (AIE_ORD_AGENT(asks[ia]) == buyer) { ia++; }
+        else if (AIE_ORD_PRICE(bids[ib]) < AIE_ORD_PRICE(asks[ia])) { possible[buyer] = 0; break; }
+        else {
+          int32_t bid = bids[ib], ask = asks[ia];
+          list_pop(bids, &nb, ib);
+          list_pop(asks, &na, ia);
+          int seller = AIE_ORD_AGENT(ask);
+          int bprice = AIE_ORD_PRICE(bid), aprice = AIE_ORD_PRICE(ask);
+          int price = (AIE_ORD_LIFE(bid) <= AIE_ORD_LIFE(ask)) ? aprice : bprice; /* :297-304 */
+          U8(c, o_cda_bid_hist)[(r * p->n + buyer) * p->P + bprice] -= 1;
+          U8(c, o_cda_ask_hist)[(r * p->n + seller) * p->P + aprice] -= 1;
+          I32(c, o_cda_n_orders)[r * p->n + seller] -= 1;
+          I32(c, o_cda_n_orders)[r * p->n + buyer] -= 1;
+          F64(c, o_cda_price_history)[(r * p->n + seller) * p->P + price] += 1.0;
+          I32(c, o_esc_res)[r * p->n + seller] -= 1;
+          I32(c, o_inv_res)[r * p->n + buyer] += 1;
+          F64(c, o_esc_coin)[buyer] -= (double)bprice;
+          F64(c, o_inv_coin)[seller] += (double)price;
+          F64(c, o_inv_coin)[buyer] += (double)(bprice - price);
+          break;
+        }
+      }
+    }
+    I32(c, o_cda_n_bids)[r] = nb;
+    I32(c, o_cda_n_asks)[r] = na;
+  }
+}
+
+/* remove_expired_orders :352-406 */
+static void cda_expire(ctx_t* c) {
+  const aie_params* p = c->p;
+  for (int r = 0; r < AIE_N_RES; ++r) {
+    int32_t* bids = I32(c, o_cda_bids) + r * p->M;
+    int nb = I32(c, o_cda_n_bids)[r], k = 0;
+    for (int q = 0; q < nb; ++q) {
+      int32_t o = bids[q];
+      int life = AIE_ORD_LIFE(o) + 1, ag = AIE_ORD_AGENT(o), pr = AIE_ORD_PRICE(o);
+      if (life <= p->c.cda_order_duration) bids[k++] = AIE_ORD_PACK(ag, pr, life);
+      else {
+        double esc = F64(c, o_esc_coin)[ag];
+        double tr = esc < (double)pr ? esc : (double)pr; /* escrow_to_inventory */
+        F64(c, o_esc_coin)[ag] -= tr;
+        F64(c, o_inv_coin)[ag] += tr;
+        U8(c, o_cda_bid_hist)[(r * p->n + ag) * p->P + pr] -= 1;
+        I32(c, o_cda_n_orders)[r * p->n + ag] -= 1;
+      }
+    }
+    I32(c, o_cda_n_bids)[r] = k;
+    int32_t* asks = I32(c, o_cda_asks) + r * p->M;
+    int na = I32(c, o_cda_n_asks)[r];
+    k = 0;
+    for (int q = 0; q < na; ++q) {
+      int32_t o = asks[q];
+      int life = AIE_ORD_LIFE(o) + 1, ag = AIE_ORD_AGENT(o), pr = AIE_ORD_PRICE(o);
+      if (life <= p->c.cda_order_duration) asks[k++] = AIE_ORD_PACK(ag, pr, life);
+      else {
+        I32(c, o_esc_res)[r * p->n + ag] -= 1;
+        I32(c, o_inv_res)[r * p->n + ag] += 1;
+        U8(c, o_cda_ask_hist)[(r * p->n + ag) * p->P + pr] -= 1;
+        I32(c, o_cda_n_orders)[r * p->n + ag] -= 1;
+      }
+    }
+    I32(c, o_cda_n_asks)[r] = k;
+  }
+}
+
+/* ContinuousDoubleAuction.component_step :440-489 */
+static void cda_step(ctx_t* c) {
+  const aie_params* p = c->p;
+  for (int r = 0; r < AIE_N_RES; ++r) {
+    for (int i = 0; i < p->n; ++i) {
+      double* ph = F64(c, o_cda_price_history) + (r * p->n + i) * p->P;
+      for (int k = 0; k < p->P; ++k) ph[k] *= 0.995; /* :451 */
+      int a = c->act[i][r ? AIE_SUB_BUY1 : AIE_SUB_BUY0];
+      if (a > 0) cda_create_bid(c, r, i, a - 1);
+      a = c->act[i][r ? AIE_SUB_SELL1 : AIE_SUB_SELL0];
+      if (a > 0) cda_create_ask(c, r, i, a - 1);
+    }
+  }
+  cda_match(c);
+  cda_expire(c);
+}
+
+/* ------------------------------------------------------------------------------- */
+/* PeriodicBracketTax: F/components/redistribution.py                               */
+/* ------------------------------------------------------------------------------- */
+/* curr_marginal_rates :396-417 */
+static double tax_rate(ctx_t* c, int b) {
+  const aie_params* p = c->p;
+  if (p->c.tax_model == AIE_TAX_MODEL_WRAPPER) return p->c.tax_disc_rates[I32(c, o_tax_rate_idx)[b]];
+  return p->c.tax_fixed_rates[b];
+}
+/* marginal_rate :837-844 */
+static double tax_marginal_rate(ctx_t* c, double income) {
+  const aie_params* p = c->p;
+  if (income < 0) return 0.0;
+  for (int b = 0; b < p->NB; ++b) {
+    double lo = p->c.tax_bracket_cutoffs[b];
+    double hi = (b + 1 < p->NB) ? p->c.tax_bracket_cutoffs[b + 1] : INFINITY;
+    if (income >= lo && income < hi) return tax_rate(c, b);
+  }
+  return tax_rate(c, 0); /* argmax of all-False == 0 */
+}
+/* taxes_due :846-851 */
+static double tax_due(ctx_t* c, double income) {
+  const aie_params* p = c->p;
+  double bt[AIE_MAX_BRACKETS];
+  for (int b = 0; b < p->NB; ++b) {
+    double cut = p->c.tax_bracket_cutoffs[b];
+    double size = (b + 1 < p->NB) ? p->c.tax_bracket_cutoffs[b + 1] - cut : INFINITY;
+    double past = income - cut;
+    if (past < 0) past = 0;
+    double bin = size < past ? size : past;
+    bt[b] = tax_rate(c, b) * bin;
+  }
+  return np_sum(bt, p->NB);
+}
+/* enact_taxes :853-915 */
+static void tax_enact(ctx_t* c) {
+  const aie_params* p = c->p;
+  double net = 0;
+  for (int i = 0; i < p->n; ++i) {
+    double income = (F64(c, o_inv_coin)[i] + F64(c, o_esc_coin)[i]) - F64(c, o_tax_last_coin)[i];
+    double due = tax_due(c, income);
+    double inv = F64(c, o_inv_coin)[i];
+    double eff = inv < due ? inv : due; /* don't take from escrow */
+    double mr = tax_marginal_rate(c, income);
+    F64(c, o_inv_coin)[i] -= eff;
+    net += eff;
+    F64(c, o_tax_last_income)[i] = income;
+    F64(c, o_tax_last_marginal_rate)[i] = mr;
+  }
+  *F64(c, o_tax_total_collected) += net;
+  double lump = net / p->n;
+  for (int i = 0; i < p->n; ++i) {
+    F64(c, o_inv_coin)[i] += lump;
+    F64(c, o_tax_last_coin)[i] = F64(c, o_inv_coin)[i] + F64(c, o_esc_coin)[i];
+  }
+}
+/* component_step :945-972 (+ set_new_period_rates_model :419-434) */
+static void tax_step(ctx_t* c) {
+  const aie_params* p = c->p;
+  int32_t* pos = I32(c, o_tax_cycle_pos);
+  if (*pos == 1 && p->c.tax_model == AIE_TAX_MODEL_WRAPPER && !p->c.tax_disable) {
+    for (int b = 0; b < p->NB; ++b) {
+      int a = c->act_p[b];
+      if (a > 0 && a <= p->c.tax_n_disc_rates) I32(c, o_tax_rate_idx)[b] = a - 1;
+    }
+  }
+  if (*pos >= p->c.tax_period) {
+    tax_enact(c);
+    *pos = 0;
+  }
+  *pos += 1;
+}
+
+/* ------------------------------------------------------------------------------- */
+/* Scenario: F/scenarios/simple_wood_and_stone/layout_from_file.py                  */
+/* ------------------------------------------------------------------------------- */
+/* scenario_step :372-410, regen_halfwidth == 0 (1x1 kernel): p = w * max(map, src);
+ * spawnable reduces to "is a source block"; rand(H,W) is drawn for Wood, then Stone. */
+static void scenario_step(ctx_t* c) {
+  const aie_params* p = c->p;
+  for (int q = 0; q < 2; ++q) {
+    int rsrc = q == 0 ? 1 : 0; /* ["Wood", "Stone"] */
+    unsigned srcbit = rsrc ? AIE_CELL_WOOD_SRC : AIE_CELL_STONE_SRC;
+    double w = p->c.regen_weight[rsrc];
+    int mh = p->c.max_health[rsrc];
+    for (int cell = 0; cell < p->HW; ++cell) {
+      double u = rng_double(c);
+      int m = CB(c, cell, rsrc), src = (C_FLAGS(c, cell) & srcbit) ? 1 : 0;
+      int health = m > src ? m : src;
+      int respawn = (u < w * (double)health) && src > 0;
+      int v = m + respawn;
+      CB(c, cell, rsrc) = (uint8_t)(v < mh ? v : mh);
+    }
+  }
+}
+
+/* energy_weight :249-267 */
+static double energy_weight(ctx_t* c) {
+  const aie_params* p = c->p;
+  if (p->c.energy_warmup_constant <= 0.0) return 1.0;
+  if (p->c.energy_warmup_method == AIE_WARMUP_DECAY)
+    return 1.0 - exp(-(double)(*I32(c, o_completions)) / p->c.energy_warmup_constant);
+  return 1.0 - exp(-(double)(*I32(c, o_auto_warmup)) / p->c.energy_warmup_constant);
+}
+
+/* social_metrics.get_gini, F/scenarios/utils/social_metrics.py:10-46 */
+static double get_gini(const double* e, int n) {
+  if (n < 30) {
+    double d[AIE_MAX_AGENTS * AIE_MAX_AGENTS];
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) d[i * n + j] = fabs(e[i] - e[j]);
+    double diff = np_sum(d, n * n);
+    double norm = 2 * n * np_sum(e, n);
+    double unscaled = diff / (norm + 1e-10);
+    return unscaled / ((double)(n - 1) / (double)n);
+  }
+  double s[AIE_MAX_AGENTS], cs[AIE_MAX_AGENTS];
+  memcpy(s, e, sizeof(double) * n);
+  for (int i = 1; i < n; ++i) { /* np.sort */
+    double x = s[i]; int j = i - 1;
+    while (j >= 0 && s[j] > x) { s[j + 1] = s[j]; --j; }
+    s[j + 1] = x;
+  }
+  double tot = np_sum(s, n) + 1e-10, run = 0;
+  for (int i = 0; i < n; ++i) { run += s[i]; cs[i] = run / tot; }
+  return 1 - (2.0 / (n + 1)) * np_sum(cs, n);
+}
+
+/* get_current_optimization_metrics :269-318 (rewards.py:12-48, 84-133) */
+static void current_metrics(ctx_t* c, double* out /* n+1 */) {
+  const aie_params* p = c->p;
+  const int n = p->n;
+  double coin[AIE_MAX_AGENTS];
+  double lc = energy_weight(c) * p->c.energy_cost;
+  double eta = p->c.isoelastic_eta;
+  for (int i = 0; i < n; ++i) {
+    coin[i] = F64(c, o_inv_coin)[i] + F64(c, o_esc_coin)[i];
+    double util_c;
+    if (eta == 1.0) util_c = log(coin[i] > 1 ? coin[i] : 1); /* rewards.py:37 ("dangerous") */
+    else util_c = (pow(coin[i], 1 - eta) - 1) / (1 - eta);
+    out[i] = util_c - F64(c, o_labor)[i] * lc;
+  }
+  if (p->c.planner_reward_type == AIE_PLANNER_REW_COIN_EQ_TIMES_PROD) {
+    double ew = 1 - p->c.mixing_weight_gini_vs_coin;
+    double prod = np_sum(coin, n) / n;
+    double equality = ew * (1 - get_gini(coin, n)) + (1 - ew);
+    out[n] = equality * prod;
+  } else {
+    double w[AIE_MAX_AGENTS], t[AIE_MAX_AGENTS];
+    for (int i = 0; i < n; ++i) w[i] = 1 / (coin[i] > 1 ? coin[i] : 1);
+    double sw = np_sum(w, n);
+    for (int i = 0; i < n; ++i) {
+      w[i] = w[i] / sw;
+      t[i] = (p->c.planner_reward_type == AIE_PLANNER_REW_INV_INCOME_COIN ? coin[i] : out[i]) * w[i];
+    }
+    out[n] = np_sum(t, n);
+  }
+}
+
+/* ------------------------------------------------------------------------------- */
+/* Observations, masks, rewards                                                     */
+/* ------------------------------------------------------------------------------- */
+static double inv_scale(const aie_params* p) { return p->c.allow_observation_scaling ? 0.01 : 1.0; }
+
+/* LayoutFromFile.generate_observations :412-517 + component obs + _package */
+static void write_obs(ctx_t* c) {
+  const aie_params* p = c->p;
+  const int n = p->n, H = p->H, W = p->W, HW = p->HW, w = p->c.obs_range, WV = p->WV, CM = p->CM;
+  const int e = c->e;
+  const uint32_t* cells = CELLS(c);
+  const int32_t *lr = I32(c, o_loc_r), *lc = I32(c, o_loc_c);
+  const double isc = inv_scale(p);
+  int16_t locmap[255 * 255];
+  for (int k = 0; k < HW; ++k) locmap[k] = 0;
+  for (int i = 0; i < n; ++i) locmap[lr[i] * W + lc[i]] = (int16_t)(i + 2); /* world.py:406-416, +2 */
+
+  /* channel k of Maps.state, key order world.py:59-93 */
+  #define FL(cell, bit) ((AIE_CELL_FLAGS(cells[cell]) & (bit)) ? 1 : 0)
+  #define CHAN(k, cell) ((k) == 0 ? (int)AIE_CELL_STONE(cells[cell]) : (k) == 1 ? (int)AIE_CELL_WOOD(cells[cell]) : \
+      (k) == 2 ? (AIE_CELL_OWNER(cells[cell]) >= 0) : \
+      (p->c.has_water ? ((k) == 3 ? FL(cell, AIE_CELL_WATER) : (k) == 4 ? FL(cell, AIE_CELL_STONE_SRC) : FL(cell, AIE_CELL_WOOD_SRC)) \
+                      : ((k) == 3 ? FL(cell, AIE_CELL_STONE_SRC) : FL(cell, AIE_CELL_WOOD_SRC))))
+  #define OWN(cell) AIE_CELL_OWNER(cells[cell])
+
+  float* amap = (float*)(c->arena + p->a_obs_a_map) + (int64_t)e * n * (CM + 1) * WV * WV;
+  int16_t* aidx = (int16_t*)(c->arena + p->a_obs_a_idx) + (int64_t)e * n * 2 * WV * WV;
+  for (int i = 0; i < n; ++i) {
+    for (int dr = 0; dr < WV; ++dr)
+      for (int dc = 0; dc < WV; ++dc) {
+        int r = lr[i] - w + dr, col = lc[i] - w + dc;
+        int in = (r >= 0 && r < H && col >= 0 && col < W);
+        int cell = r * W + col;
+        for (int k = 0; k < CM; ++k)
+          amap[((i * (CM + 1) + k) * WV + dr) * WV + dc] = in ? (float)CHAN(k, cell) : 0.0f;
+        amap[((i * (CM + 1) + CM) * WV + dr) * WV + dc] = in ? 1.0f : 0.0f; /* :480-485 */
+        int16_t v0 = in ? (int16_t)(OWN(cell) >= 0 ? OWN(cell) + 2 : 0) : 0;
+        int16_t v1 = in ? locmap[cell] : 0;
+        if (v0 == i + 2) v0 = 1; /* :503 */
+        if (v1 == i + 2) v1 = 1;
+        aidx[((i * 2 + 0) * WV + dr) * WV + dc] = v0;
+        aidx[((i * 2 + 1) * WV + dr) * WV + dc] = v1;
+      }
+  }
+  if (p->c.planner_gets_spatial_info) {
+    float* pmap = (float*)(c->arena + p->a_obs_p_map) + (int64_t)e * CM * HW;
+    int16_t* pidx = (int16_t*)(c->arena + p->a_obs_p_idx) + (int64_t)e * 2 * HW;
+    for (int k = 0; k < CM; ++k)
+      for (int cell = 0; cell < HW; ++cell) pmap[k * HW + cell] = (float)CHAN(k, cell);
+    for (int cell = 0; cell < HW; ++cell) {
+      pidx[cell] = (int16_t)(OWN(cell) >= 0 ? OWN(cell) + 2 : 0);
+      pidx[HW + cell] = locmap[cell];
+    }
+  }
+  #undef CHAN
+  #undef FL
+  #undef OWN
+
+  const int t = *I32(c, o_timestep);
+  const double time_scale = p->c.allow_observation_scaling ? (double)p->c.episode_length : 1.0;
+  const double tval = (double)t / time_scale;
+
+  /* ---- CDA shared quantities (continuous_double_auction.py:491-542) ---- */
+  double market_rate[2] = {0, 0};
+  double net_ph[2][128];
+  double full_asks[2][128], full_bids[2][128];
+  if (p->has_cda) {
+    for (int r = 0; r < 2; ++r) {
+      for (int k = 0; k < p->P; ++k) {
+        double s = 0; /* np.sum(np.stack(...), axis=0): row-by-row accumulation */
+        double fa = 0, fb = 0;
+        for (int i = 0; i < n; ++i) {
+          double v = F64(c, o_cda_price_history)[(r * n + i) * p->P + k];
+          s = (i == 0) ? v : s + v;
+          fa += U8(c, o_cda_ask_hist)[(r * n + i) * p->P + k];
+          fb += U8(c, o_cda_bid_hist)[(r * n + i) * p->P + k];
+        }
+        net_ph[r][k] = s; full_asks[r][k] = fa; full_bids[r][k] = fb;
+      }
+      double dot = 0;
+      for (int k = 0; k < p->P; ++k) dot += (double)k * net_ph[r][k];
+      double tot = np_sum(net_ph[r], p->P);
+      market_rate[r] = dot / (tot > 0.001 ? tot : 0.001);
+    }
+  }
+  /* ---- tax shared quantities (redistribution.py:974-1023) ---- */
+  double is_tax_day = 0, is_first_day = 0, tax_phase = 0, sorted_inc[AIE_MAX_AGENTS];
+  if (p->has_tax) {
+    int pos = *I32(c, o_tax_cycle_pos);
+    is_tax_day = pos >= p->c.tax_period ? 1.0 : 0.0;
+    is_first_day = pos == 1 ? 1.0 : 0.0;
+    tax_phase = (double)pos / (double)p->c.tax_period;
+    for (int i = 0; i < n; ++i) sorted_inc[i] = F64(c, o_tax_last_income)[i] / (double)p->c.tax_period;
+    for (int i = 1; i < n; ++i) {
+      double x = sorted_inc[i]; int j = i - 1;
+      while (j >= 0 && sorted_inc[j] > x) { sorted_inc[j + 1] = sorted_inc[j]; --j; }
+      sorted_inc[j + 1] = x;
+    }
+  }
+
+  float* aflat = (float*)(c->arena + p->a_obs_a_flat) + (int64_t)e * n * p->FA;
+  float* atime = (float*)(c->arena + p->a_obs_a_time) + (int64_t)e * n;
+  float* pag = (float*)(c->arena + p->a_obs_p_agents) + (int64_t)e * n * p->FPA;
+  for (int i = 0; i < n; ++i) {
+    float* f = aflat + i * p->FA;
+    if (p->has_build) { /* build.py:163-178 */
+      f[p->fa_build + 0] = (float)(F64(c, o_build_payment)[i] / (double)p->c.build_payment);
+      f[p->fa_build + 1] = (float)F64(c, o_build_skill)[i];
+    }
+    if (p->has_cda) {
+      float* g = f + p->fa_cda;
+      const int P = p->P;
+      for (int r = 0; r < 2; ++r)
+        for (int k = 0; k < P; ++k) {
+          double mya = U8(c, o_cda_ask_hist)[(r * n + i) * P + k];
+          double myb = U8(c, o_cda_bid_hist)[(r * n + i) * P + k];
+          g[0 * P + r * P + k] = (float)(full_asks[r][k] - mya);          /* available_asks */
+          g[2 * P + r * P + k] = (float)(full_bids[r][k] - myb);          /* available_bids */
+          g[4 * P + 2 + r * P + k] = (float)mya;                          /* my_asks        */
+          g[6 * P + 2 + r * P + k] = (float)myb;                          /* my_bids        */
+          g[8 * P + 2 + r * P + k] = (float)(net_ph[r][k] * isc);         /* price_history  */
+        }
+      g[4 * P + 0] = (float)market_rate[0];
+      g[4 * P + 1] = (float)market_rate[1];
+    }
+    if (p->has_gather) f[p->fa_gather] = (float)F64(c, o_bonus_gather_prob)[i]; /* move.py:155-165 */
+    double cmr = 0;
+    if (p->has_tax) {
+      float* g = f + p->fa_tax;
+      for (int b = 0; b < p->NB; ++b) g[b] = (float)tax_rate(c, b);
+      g[p->NB + 0] = (float)is_first_day;
+      g[p->NB + 1] = (float)is_tax_day;
+      for (int k = 0; k < n; ++k) g[p->NB + 2 + k] = (float)sorted_inc[k];
+      cmr = tax_marginal_rate(c, (F64(c, o_inv_coin)[i] + F64(c, o_esc_coin)[i]) - F64(c, o_tax_last_coin)[i]);
+      g[p->NB + 2 + n] = (float)cmr;
+      g[p->NB + 3 + n] = (float)tax_phase;
+    }
+    f[p->fa_time] = (float)tval;
+    f[p->fa_world + 0] = (float)(F64(c, o_inv_coin)[i] * isc);
+    f[p->fa_world + 1] = (float)((double)I32(c, o_inv_res)[0 * n + i] * isc);
+    f[p->fa_world + 2] = (float)((double)I32(c, o_inv_res)[1 * n + i] * isc);
+    f[p->fa_world + 3] = (float)((double)lc[i] / (double)W);
+    f[p->fa_world + 4] = (float)((double)lr[i] / (double)H);
+    atime[i] = (float)tval;
+    /* planner's per-agent view p{i} */
+    float* q = pag + i * p->FPA;
+    if (p->has_tax) {
+      q[p->fpa_tax + 0] = (float)cmr;
+      q[p->fpa_tax + 1] = (float)(F64(c, o_tax_last_income)[i] / (double)p->c.tax_period);
+      q[p->fpa_tax + 2] = (float)F64(c, o_tax_last_marginal_rate)[i];
+    }
+    q[p->fpa_world + 0] = f[p->fa_world + 0];
+    q[p->fpa_world + 1] = f[p->fa_world + 1];
+    q[p->fpa_world + 2] = f[p->fa_world + 2];
+    if (p->c.planner_gets_spatial_info) {
+      q[p->fpa_world + 3] = f[p->fa_world + 3];
+      q[p->fpa_world + 4] = f[p->fa_world + 4];
+    }
+  }
+  /* planner flat */
+  float* pf = (float*)(c->arena + p->a_obs_p_flat) + (int64_t)e * p->FP;
+  if (p->has_cda) {
+    float* g = pf + p->fp_cda;
+    const int P = p->P;
+    for (int r = 0; r < 2; ++r)
+      for (int k = 0; k < P; ++k) {
+        g[0 * P + r * P + k] = (float)full_asks[r][k];
+        g[2 * P + r * P + k] = (float)full_bids[r][k];
+        g[4 * P + 2 + r * P + k] = (float)(net_ph[r][k] * isc);
+      }
+    g[4 * P + 0] = (float)market_rate[0];
+    g[4 * P + 1] = (float)market_rate[1];
+  }
+  if (p->has_tax) {
+    float* g = pf + p->fp_tax;
+    for (int b = 0; b < p->NB; ++b) g[b] = (float)tax_rate(c, b);
+    g[p->NB + 0] = (float)is_first_day;
+    g[p->NB + 1] = (float)is_tax_day;
+    for (int k = 0; k < n; ++k) g[p->NB + 2 + k] = (float)sorted_inc[k];
+    g[p->NB + 2 + n] = (float)tax_phase;
+  }
+  pf[p->fp_time] = (float)tval;
+  pf[p->fp_world + 0] = 0.0f; /* the planner's own inventory is always empty */
+  pf[p->fp_world + 1] = 0.0f;
+  pf[p->fp_world + 2] = 0.0f;
+  ((float*)(c->arena + p->a_obs_p_time))[e] = (float)tval;
+}
+
+/* _generate_masks base_env.py:706-756 + flatten_masks base_agent.py:440-460 */
+static void write_masks(ctx_t* c) {
+  const aie_params* p = c->p;
+  const int n = p->n, e = c->e;
+  const int32_t *lr = I32(c, o_loc_r), *lc = I32(c, o_loc_c);
+  float* am = (float*)(c->arena + p->a_obs_a_mask) + (int64_t)e * n * p->MA;
+  const int multi = p->c.multi_action_mode_agents;
+  for (int i = 0; i < n; ++i) {
+    float* m = am + i * p->MA;
+    int o = 0;
+    if (!multi || p->n_sub_a == 0) m[o++] = 1.0f;
+    for (int s = 0; s < p->n_sub_a; ++s) {
+      if (multi) m[o++] = 1.0f;
+      int slot = p->sub_a_slot[s];
+      if (slot == AIE_SUB_BUILD) {
+        m[o++] = agent_can_build(c, i) ? 1.0f : 0.0f; /* build.py:180-193 */
+      } else if (slot == AIE_SUB_GATHER) {
+        /* move.py:167-188: L, R, U, D neighbours free and accessible */
+        static const int ro[4] = {0, 0, -1, 1}, co[4] = {-1, 1, 0, 0};
+        for (int k = 0; k < 4; ++k) m[o++] = can_agent_occupy(c, lr[i] + ro[k], lc[i] + co[k], i) ? 1.0f : 0.0f;
+      } else {
+        /* continuous_double_auction.py:544-580 */
+        int r = (slot == AIE_SUB_BUY1 || slot == AIE_SUB_SELL1) ? 1 : 0;
+        int is_buy = (slot == AIE_SUB_BUY0 || slot == AIE_SUB_BUY1);
+        int quota = I32(c, o_cda_n_orders)[r * n + i] < p->c.cda_max_num_orders;
+        for (int k = 0; k < p->P; ++k) {
+          float v;
+          if (is_buy) v = (quota && (double)k <= F64(c, o_inv_coin)[i]) ? 1.0f : 0.0f;
+          else v = (quota && I32(c, o_inv_res)[r * n + i] > 0) ? 1.0f : 0.0f;
+          m[o++] = v;
+        }
+      }
+    }
+  }
+  /* planner: redistribution.py:1025-1104 (no annealing) */
+  float* pm = (float*)(c->arena + p->a_obs_p_mask) + (int64_t)e * p->MP;
+  int o = 0;
+  const int pmulti = p->c.multi_action_mode_planner;
+  if (!pmulti || p->n_sub_p == 0) pm[o++] = 1.0f;
+  if (p->n_sub_p) {
+    float v = (*I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
+    for (int b = 0; b < p->n_sub_p; ++b) {
+      if (pmulti) pm[o++] = 1.0f;
+      for (int k = 0; k < p->sub_p_dim; ++k) pm[o++] = v;
+    }
+  }
+}
+
+/* compute_reward layout_from_file.py:519-559 */
+static void write_rewards(ctx_t* c) {
+  const aie_params* p = c->p;
+  const int n = p->n, e = c->e;
+  double cur[AIE_MAX_AGENTS + 1], rew[AIE_MAX_AGENTS + 1];
+  double* util = F64(c, o_util);
+  current_metrics(c, cur);
+  for (int i = 0; i <= n; ++i) { rew[i] = cur[i] - util[i]; util[i] = cur[i]; }
+  double avg = np_sum(rew, n) / n;
+  if (avg > 0) *I32(c, o_auto_warmup) += 1;
+  float* ra = (float*)(c->arena + p->a_rew_a) + (int64_t)e * n;
+  for (int i = 0; i < n; ++i) ra[i] = (float)rew[i];
+  ((float*)(c->arena + p->a_rew_p))[e] = (float)rew[n];
+}
+
+/* parse_actions base_env.py:552-556 -> base_agent.py:407-438 */
+static void decode_actions(ctx_t* c, const int32_t* aa, const int32_t* ap) {
+  const aie_params* p = c->p;
+  memset(c->act, 0, sizeof(c->act));
+  memset(c->act_p, 0, sizeof(c->act_p));
+  if (aa) {
+    for (int i = 0; i < p->n; ++i) {
+      const int32_t* a = aa + ((int64_t)c->e * p->n + i) * p->act_a_width;
+      if (p->c.multi_action_mode_agents) {
+        for (int s = 0; s < p->n_sub_a; ++s)
+          if (a[s] >= 0 && a[s] <= p->sub_a_dim[s]) c->act[i][p->sub_a_slot[s]] = a[s];
+      } else {
+        int v = a[0];
+        for (int s = 0; s < p->n_sub_a; ++s)
+          if (v >= p->sub_a_base[s] && v < p->sub_a_base[s] + p->sub_a_dim[s])
+            c->act[i][p->sub_a_slot[s]] = v - p->sub_a_base[s] + 1;
+      }
+    }
+  }
+  if (ap && p->n_sub_p) {
+    const int32_t* a = ap + (int64_t)c->e * p->act_p_width;
+    if (p->c.multi_action_mode_planner) {
+      for (int b = 0; b < p->n_sub_p; ++b) c->act_p[b] = a[b];
+    } else {
+      int v = a[0];
+      if (v >= 1 && v < 1 + p->n_sub_p * p->sub_p_dim) {
+        int b = (v - 1) / p->sub_p_dim;
+        c->act_p[b] = (v - 1) % p->sub_p_dim + 1;
+      }
+    }
+  }
+}
+
+static void make_ctx(ctx_t* c, const aie_params* p, uint8_t* arena, int e) {
+  c->p = p;
+  c->arena = arena;
+  c->e = e;
+  c->rec = arena + p->a_records + (int64_t)e * p->rec_bytes;
+}
+
+/* BaseEnvironment.step, base_env.py:929-1032 */
+static void step_one(const aie_params* p, uint8_t* arena, int e, const int32_t* aa, const int32_t* ap) {
+  ctx_t c;
+  make_ctx(&c, p, arena, e);
+  decode_actions(&c, aa, ap);
+  *I32(&c, o_timestep) += 1;
+  for (int k = 0; k < p->c.n_components; ++k) {
+    switch (p->c.components[k]) {
+      case AIE_COMP_BUILD: build_step(&c); break;
+      case AIE_COMP_CDA: cda_step(&c); break;
+      case AIE_COMP_GATHER: gather_step(&c); break;
+      case AIE_COMP_TAX: tax_step(&c); break;
+    }
+  }
+  scenario_step(&c);
+  write_obs(&c);
+  write_masks(&c);
+  write_rewards(&c);
+  int done = *I32(&c, o_timestep) >= p->c.episode_length;
+  (arena + p->a_done)[e] = (uint8_t)done;
+  if (done) *I32(&c, o_completions) += 1;
+}
+
+/* BaseEnvironment.reset, base_env.py:852-927, with LayoutFromFile
+ * reset_starting_layout/reset_agent_states/additional_reset_steps
+ * (layout_from_file.py:323-370, 564-593) and the component resets
+ * (build.py:224-254, move.py:193-210, continuous_double_auction.py:643-668,
+ * redistribution.py:1109-1139). */
+static void reset_one(const aie_params* p, uint8_t* arena, int e) {
+  ctx_t c;
+  make_ctx(&c, p, arena, e);
+  const int n = p->n, HW = p->HW;
+  *I32(&c, o_timestep) = 0;
+  for (int cell = 0; cell < HW; ++cell) { /* layout_from_file.py:323-334 */
+    unsigned fl = C_FLAGS(&c, cell);
+    CELLS(&c)[cell] = AIE_CELL_PACK((fl & AIE_CELL_STONE_SRC) ? 1 : 0, (fl & AIE_CELL_WOOD_SRC) ? 1 : 0, -1, fl);
+  }
+  for (int i = 0; i < n; ++i) {
+    I32(&c, o_inv_res)[i] = I32(&c, o_inv_res)[n + i] = 0;
+    I32(&c, o_esc_res)[i] = I32(&c, o_esc_res)[n + i] = 0;
+    F64(&c, o_inv_coin)[i] = p->c.starting_agent_coin;
+    F64(&c, o_esc_coin)[i] = 0;
+    F64(&c, o_labor)[i] = 0;
+    I32(&c, o_loc_r)[i] = -1;
+    I32(&c, o_loc_c)[i] = -1;
+  }
+  for (int i = 0; i < n; ++i) {
+    int r = rng_randint(&c, p->H), col = rng_randint(&c, p->W), tries = 0;
+    while (!can_agent_occupy(&c, r, col, i)) {
+      r = rng_randint(&c, p->H);
+      col = rng_randint(&c, p->W);
+      if (++tries > 200) break; /* reference raises TimeoutError */
+    }
+    I32(&c, o_loc_r)[i] = r;
+    I32(&c, o_loc_c)[i] = col;
+  }
+  for (int k = 0; k < p->c.n_components; ++k) {
+    switch (p->c.components[k]) {
+      case AIE_COMP_BUILD:
+        for (int i = 0; i < n; ++i) {
+          double skill = 1, pay = 1, pm = (double)p->c.build_payment_max_skill_multiplier;
+          if (p->c.build_skill_dist == AIE_SKILL_PARETO) {
+            skill = rng_pareto(&c, 4.0);
+            pay = (pm - 1) * skill + 1; if (pm < pay) pay = pm;
+          } else if (p->c.build_skill_dist == AIE_SKILL_LOGNORMAL) {
+            skill = rng_lognormal(&c, -1.0, 0.5);
+            pay = (pm - 1) * skill + 1; if (pm < pay) pay = pm;
+          }
+          F64(&c, o_build_payment)[i] = pay * (double)p->c.build_payment;
+          F64(&c, o_build_skill)[i] = skill;
+        }
+        break;
+      case AIE_COMP_GATHER:
+        for (int i = 0; i < n; ++i) {
+          double b = 0.0;
+          if (p->c.gather_skill_dist == AIE_SKILL_PARETO) { b = rng_pareto(&c, 3.0); b = (b < 2 ? b : 2) / 2; }
+          else if (p->c.gather_skill_dist == AIE_SKILL_LOGNORMAL) { b = rng_lognormal(&c, -2.022, 0.938); b = (b < 2 ? b : 2) / 2; }
+          F64(&c, o_bonus_gather_prob)[i] = b;
+        }
+        break;
+      case AIE_COMP_CDA:
+        memset(I32(&c, o_cda_n_bids), 0, 8);
+        memset(I32(&c, o_cda_n_asks), 0, 8);
+        memset(I32(&c, o_cda_bids), 0, 4 * 2 * p->M);
+        memset(I32(&c, o_cda_asks), 0, 4 * 2 * p->M);
+        memset(I32(&c, o_cda_n_orders), 0, 4 * 2 * n);
+        memset(U8(&c, o_cda_bid_hist), 0, 2 * n * p->P);
+        memset(U8(&c, o_cda_ask_hist), 0, 2 * n * p->P);
+        memset(F64(&c, o_cda_price_history), 0, 8 * 2 * n * p->P);
+        break;
+      case AIE_COMP_TAX:
+        for (int b = 0; b < p->NB; ++b) I32(&c, o_tax_rate_idx)[b] = 0;
+        *I32(&c, o_tax_cycle_pos) = 1;
+        for (int i = 0; i < n; ++i) {
+          F64(&c, o_tax_last_coin)[i] = F64(&c, o_inv_coin)[i] + F64(&c, o_esc_coin)[i];
+          F64(&c, o_tax_last_income)[i] = 0;
+          F64(&c, o_tax_last_marginal_rate)[i] = 0;
+        }
+        *F64(&c, o_tax_total_collected) = 0;
+        break;
+    }
+  }
+  if (!p->has_build) for (int i = 0; i < n; ++i) { F64(&c, o_build_payment)[i] = 0; F64(&c, o_build_skill)[i] = 0; }
+  if (!p->has_gather) for (int i = 0; i < n; ++i) F64(&c, o_bonus_gather_prob)[i] = 0;
+  if (p->c.fixed_four_skill_and_loc) { /* layout_from_file.py:582-586 */
+    int order[AIE_MAX_AGENTS];
+    for (int i = 0; i < n; ++i) { I32(&c, o_loc_r)[i] = -1; I32(&c, o_loc_c)[i] = -1; }
+    rng_permutation(&c, n, order);
+    for (int k = 0; k < n; ++k) {
+      int i = order[k];
+      int r = p->c.ranked_locs[k][0], col = p->c.ranked_locs[k][1];
+      if (can_agent_occupy(&c, r, col, i)) { I32(&c, o_loc_r)[i] = r; I32(&c, o_loc_c)[i] = col; }
+      F64(&c, o_build_payment)[i] = p->c.avg_ranked_skill[k];
+    }
+  }
+  current_metrics(&c, F64(&c, o_util));
+  write_obs(&c);
+  write_masks(&c);
+  float* ra = (float*)(arena + p->a_rew_a) + (int64_t)e * n;
+  for (int i = 0; i < n; ++i) ra[i] = 0;
+  ((float*)(arena + p->a_rew_p))[e] = 0;
+  (arena + p->a_done)[e] = 0;
+}
+
+/* ---- exported entry points (ctypes) ---------------------------------------------- */
+int aie_oracle_params(const aie_config* cfg, aie_params* out, aie_tensor_table* tt, char* err, int errlen) {
+  return aie_build_params(cfg, out, tt, err, (size_t)errlen);
+}
+int aie_oracle_sizeof_params(void) { return (int)sizeof(aie_params); }
+int aie_oracle_sizeof_table(void) { return (int)sizeof(aie_tensor_table); }
+
+void aie_oracle_step(const aie_params* p, uint8_t* arena, const int32_t* aa, const int32_t* ap, int e0, int e1) {
+  for (int e = e0; e < e1; ++e) step_one(p, arena, e, aa, ap);
+}
+void aie_oracle_reset(const aie_params* p, uint8_t* arena, const uint8_t* mask, int e0, int e1) {
+  for (int e = e0; e < e1; ++e)
+    if (!mask || mask[e]) reset_one(p, arena, e);
+}
+void aie_oracle_seed(const aie_params* p, uint8_t* arena, uint32_t base_seed) {
+  for (int e = 0; e < p->E; ++e) {
+    uint8_t* rec = arena + p->a_records + (int64_t)e * p->rec_bytes;
+    aie_oracle_seed_one((uint32_t*)(rec + p->o_mt), base_seed + (uint32_t)e);
+    *(int32_t*)(rec + p->o_mt_pos) = 624;
+    *(int32_t*)(rec + p->o_mt_has_gauss) = 0;
+    *(double*)(rec + p->o_mt_gauss) = 0.0;
+  }
+}
+/* multi-threaded step for the cpu_baseline leg of bench.py */
+void aie_oracle_step_mt(const aie_params* p, uint8_t* arena, const int32_t* aa, const int32_t* ap, int nthreads) {
+  int E = p->E;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (int e = 0; e < E; ++e) step_one(p, arena, e, aa, ap);
+}

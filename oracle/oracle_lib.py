@@ -1,0 +1,136 @@
+"""Test infrastructure ONLY: ctypes wrapper of oracle/aie_oracle.c (the CPU
+restatement).  Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ai_economist_amd import _cabi  # noqa: E402
+
+_LIB = None
+NP_DTYPES = [np.uint8, np.int8, np.int16, np.int32, np.uint32, np.float32, np.float64]
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", HERE], check=True)
+    return os.path.join(HERE, "_build", "libaie_oracle.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(HERE, "_build", "libaie_oracle.so")
+        src = os.path.join(HERE, "aie_oracle.c")
+        hdr = os.path.join(ROOT, "ai-economist_amd", "csrc", "aie_layout.h")
+        if (not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src)
+                or os.path.getmtime(path) < os.path.getmtime(hdr)):
+            path = build()
+        L = C.CDLL(path)
+        vp = C.c_void_p
+        L.aie_oracle_params.restype = C.c_int
+        L.aie_oracle_params.argtypes = [C.POINTER(_cabi.AieConfig), vp, vp, C.c_char_p, C.c_int]
+        L.aie_oracle_sizeof_params.restype = C.c_int
+        L.aie_oracle_sizeof_table.restype = C.c_int
+        L.aie_oracle_step.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int]
+        L.aie_oracle_step.restype = None
+        L.aie_oracle_step_mt.argtypes = [vp, vp, vp, vp, C.c_int]
+        L.aie_oracle_step_mt.restype = None
+        L.aie_oracle_reset.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+        L.aie_oracle_reset.restype = None
+        L.aie_oracle_seed.argtypes = [vp, vp, C.c_uint32]
+        L.aie_oracle_seed.restype = None
+        _LIB = L
+    return _LIB
+
+
+class TensorTable(C.Structure):
+    _fields_ = [("n", C.c_int32), ("_pad", C.c_int32), ("t", _cabi.AieTensorDesc * 64)]
+
+
+class OracleEnv:
+    """E replicas stepped on the CPU by the C restatement, in a NumPy arena with the
+    device's exact byte layout."""
+
+    def __init__(self, cfg, layout_planes=None):
+        L = lib()
+        self.cfg = cfg
+        assert L.aie_oracle_sizeof_table() == C.sizeof(TensorTable), (
+            L.aie_oracle_sizeof_table(), C.sizeof(TensorTable))
+        self._params = C.create_string_buffer(L.aie_oracle_sizeof_params())
+        self._table = TensorTable()
+        err = C.create_string_buffer(256)
+        rc = L.aie_oracle_params(C.byref(cfg), self._params, C.byref(self._table), err, 256)
+        if rc != 0:
+            raise ValueError("aie_build_params failed (%d): %s" % (rc, err.value.decode()))
+        self.E = cfg.n_envs
+        self.n = cfg.n_agents
+        self.descs = {}
+        arena_bytes = 0
+        for i in range(self._table.n):
+            d = self._table.t[i]
+            self.descs[d.name.decode()] = d
+        # arena size = end of the last dense tensor, rounded up like the library does
+        d = self.descs["done"]
+        arena_bytes = (d.arena_offset + self.E + 255) // 256 * 256
+        self.arena = np.zeros(arena_bytes, np.uint8)
+        self.t = {name: self._view(d) for name, d in self.descs.items()}
+        self.t["house_owner"][...] = -1
+        if layout_planes is not None:
+            self.set_layout(*layout_planes)
+
+    def _view(self, d):
+        dt = np.dtype(NP_DTYPES[d.dtype])
+        shape = tuple(d.shape[i] for i in range(d.ndim))
+        strides = tuple(d.stride[i] for i in range(d.ndim))
+        return np.ndarray(shape=shape, dtype=dt, buffer=self.arena.data,
+                          offset=d.arena_offset, strides=strides)
+
+    def set_layout(self, stone_src, wood_src, water):
+        fl = (np.asarray(water, np.uint8) * 1 + np.asarray(stone_src, np.uint8) * 2
+              + np.asarray(wood_src, np.uint8) * 4).astype(np.uint8)
+        self.t["cell_flags"][...] = fl  # broadcasts [H,W] -> [E,H,W]
+
+    def load_state(self, state, e=None):
+        """state: {field: array without env dim}; e=None broadcasts to all replicas."""
+        for k, v in state.items():
+            if k in ("stone_src", "wood_src", "water"):
+                continue
+            if k not in self.t:
+                continue
+            if e is None:
+                self.t[k][...] = v
+            else:
+                self.t[k][e] = v
+        if "stone_src" in state:
+            fl = (np.asarray(state["water"], np.uint8) + 2 * np.asarray(state["stone_src"], np.uint8)
+                  + 4 * np.asarray(state["wood_src"], np.uint8)).astype(np.uint8)
+            if e is None:
+                self.t["cell_flags"][...] = fl
+            else:
+                self.t["cell_flags"][e] = fl
+
+    def seed(self, base_seed):
+        lib().aie_oracle_seed(self._params, self.arena.ctypes.data, base_seed)
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).ctypes.data
+        lib().aie_oracle_reset(self._params, self.arena.ctypes.data, m, 0, self.E)
+
+    def step(self, actions_a=None, actions_p=None, nthreads=1):
+        a = None if actions_a is None else np.ascontiguousarray(actions_a, np.int32)
+        p = None if actions_p is None else np.ascontiguousarray(actions_p, np.int32)
+        pa = None if a is None else a.ctypes.data
+        pp = None if p is None or p.size == 0 else p.ctypes.data
+        if nthreads > 1:
+            lib().aie_oracle_step_mt(self._params, self.arena.ctypes.data, pa, pp, nthreads)
+        else:
+            lib().aie_oracle_step(self._params, self.arena.ctypes.data, pa, pp, 0, self.E)
