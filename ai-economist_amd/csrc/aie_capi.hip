@@ -1,0 +1,280 @@
+// aie_capi.hip -- the C ABI declared in include/aie.h: handle management, tensor table,
+// host<->device staging, and the kernel launches.  No torch types anywhere.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "aie_kernels.hip"
+
+struct aie_env {
+  aie_params P;
+  aie_tensor_table tt;
+  uint8_t* arena;
+  bool owns_arena;
+  int device;
+  size_t lds;
+  int64_t sample_t;
+  char err[512];
+};
+
+static thread_local char g_create_err[512] = "";
+
+#define AIE_HIP_CHECK(env, expr)                                                          \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      snprintf((env)->err, sizeof((env)->err), "%s failed: %s", #expr, hipGetErrorString(_e)); \
+      return AIE_E_HIP;                                                                   \
+    }                                                                                     \
+  } while (0)
+
+// cells start with "no house" (owner byte 0xff); everything else zero
+__global__ void aie_init_cells_kernel(const aie_params P, uint8_t* __restrict__ arena) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (int64_t)P.E * P.HW) return;
+  const int e = (int)(q / P.HW), cell = (int)(q - (int64_t)e * P.HW);
+  reinterpret_cast<uint32_t*>(arena + P.a_records + (int64_t)e * P.rec_bytes + P.o_cells)[cell] = 0x00ff0000u;
+}
+
+// packs the static layout flags into byte 3 of every cell word
+__global__ void aie_set_flags_kernel(const aie_params P, uint8_t* __restrict__ arena,
+                                     const uint8_t* __restrict__ flags, int shared) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (int64_t)P.E * P.HW) return;
+  const int e = (int)(q / P.HW), cell = (int)(q - (int64_t)e * P.HW);
+  uint32_t* w = reinterpret_cast<uint32_t*>(arena + P.a_records + (int64_t)e * P.rec_bytes + P.o_cells) + cell;
+  const uint32_t fl = flags[shared ? cell : q];
+  *w = (*w & 0x00ffffffu) | (fl << 24);
+}
+
+extern "C" {
+
+int64_t aie_arena_bytes(const aie_config* cfg) {
+  aie_params P;
+  int rc = aie_build_params(cfg, &P, nullptr, g_create_err, sizeof(g_create_err));
+  if (rc != AIE_OK) return rc;
+  return P.arena_bytes;
+}
+
+int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_bytes, aie_env** out) {
+  if (!cfg || !out) {
+    snprintf(g_create_err, sizeof(g_create_err), "null argument");
+    return AIE_E_INVALID;
+  }
+  aie_env* env = new aie_env();
+  memset(env, 0, sizeof(*env));
+  int rc = aie_build_params(cfg, &env->P, &env->tt, g_create_err, sizeof(g_create_err));
+  if (rc != AIE_OK) { delete env; return rc; }
+  env->device = device;
+  env->lds = aie::lds_bytes(env->P);
+  if (env->lds > 64 * 1024) {
+    snprintf(g_create_err, sizeof(g_create_err),
+             "per-replica working set (%zu B of LDS) exceeds 64 KiB: reduce max_num_orders / world size", env->lds);
+    delete env;
+    return AIE_E_UNSUPPORTED;
+  }
+  hipError_t he = hipSetDevice(device);
+  if (he != hipSuccess) {
+    snprintf(g_create_err, sizeof(g_create_err), "hipSetDevice(%d): %s", device, hipGetErrorString(he));
+    delete env;
+    return AIE_E_HIP;
+  }
+  if (arena) {
+    if (arena_bytes < env->P.arena_bytes || (reinterpret_cast<uintptr_t>(arena) & 255u)) {
+      snprintf(g_create_err, sizeof(g_create_err), "arena too small (%lld < %lld) or not 256-byte aligned",
+               (long long)arena_bytes, (long long)env->P.arena_bytes);
+      delete env;
+      return AIE_E_INVALID;
+    }
+    env->arena = static_cast<uint8_t*>(arena);
+    env->owns_arena = false;
+  } else {
+    he = hipMalloc(reinterpret_cast<void**>(&env->arena), (size_t)env->P.arena_bytes);
+    if (he != hipSuccess) {
+      snprintf(g_create_err, sizeof(g_create_err), "hipMalloc(%lld): %s", (long long)env->P.arena_bytes,
+               hipGetErrorString(he));
+      delete env;
+      return AIE_E_NOMEM;
+    }
+    env->owns_arena = true;
+  }
+  he = hipMemset(env->arena, 0, (size_t)env->P.arena_bytes);
+  if (he == hipSuccess) {
+    const int64_t tot = (int64_t)env->P.E * env->P.HW;
+    hipLaunchKernelGGL(aie_init_cells_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, env->P, env->arena);
+    he = hipDeviceSynchronize();
+  }
+  if (he != hipSuccess) {
+    snprintf(g_create_err, sizeof(g_create_err), "arena init: %s", hipGetErrorString(he));
+    if (env->owns_arena) (void)hipFree(env->arena);
+    delete env;
+    return AIE_E_HIP;
+  }
+  for (int i = 0; i < env->tt.n; ++i) env->tt.t[i].data = env->arena + env->tt.t[i].arena_offset;
+  *out = env;
+  return AIE_OK;
+}
+
+int aie_destroy(aie_env* env) {
+  if (!env) return AIE_OK;
+  (void)hipSetDevice(env->device);
+  (void)hipDeviceSynchronize();
+  if (env->owns_arena && env->arena) (void)hipFree(env->arena);
+  delete env;
+  return AIE_OK;
+}
+
+const char* aie_last_error(const aie_env* env) { return env ? env->err : g_create_err; }
+
+int aie_num_tensors(const aie_env* env) { return env ? env->tt.n : AIE_E_INVALID; }
+
+int aie_tensor_at(const aie_env* env, int index, aie_tensor_desc* out) {
+  if (!env || !out || index < 0 || index >= env->tt.n) return AIE_E_INVALID;
+  *out = env->tt.t[index];
+  return AIE_OK;
+}
+
+static const aie_tensor_desc* find_tensor(const aie_env* env, const char* name) {
+  for (int i = 0; i < env->tt.n; ++i)
+    if (strcmp(env->tt.t[i].name, name) == 0) return &env->tt.t[i];
+  return nullptr;
+}
+
+int aie_get_tensor(const aie_env* env, const char* name, aie_tensor_desc* out) {
+  if (!env || !name || !out) return AIE_E_INVALID;
+  const aie_tensor_desc* d = find_tensor(env, name);
+  if (!d) {
+    snprintf(const_cast<aie_env*>(env)->err, sizeof(env->err), "no tensor named '%s'", name);
+    return AIE_E_NOTFOUND;
+  }
+  *out = *d;
+  return AIE_OK;
+}
+
+// Generic strided host<->device copy of one tensor through a host bounce buffer.
+static int copy_tensor(aie_env* env, const char* name, void* host, int64_t bytes, bool upload) {
+  if (!env || !name || !host) return AIE_E_INVALID;
+  const aie_tensor_desc* d = find_tensor(env, name);
+  if (!d) {
+    snprintf(env->err, sizeof(env->err), "no tensor named '%s'", name);
+    return AIE_E_NOTFOUND;
+  }
+  const int es = aie__dtype_size(d->dtype);
+  int64_t count = 1, span = es;
+  for (int i = 0; i < d->ndim; ++i) {
+    count *= d->shape[i];
+    span += (d->shape[i] - 1) * d->stride[i];
+  }
+  if (bytes != count * es) {
+    snprintf(env->err, sizeof(env->err), "'%s': expected %lld bytes, got %lld", name, (long long)(count * es),
+             (long long)bytes);
+    return AIE_E_INVALID;
+  }
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  std::vector<uint8_t> tmp((size_t)span);
+  uint8_t* dev = env->arena + d->arena_offset;
+  AIE_HIP_CHECK(env, hipDeviceSynchronize());
+  AIE_HIP_CHECK(env, hipMemcpy(tmp.data(), dev, (size_t)span, hipMemcpyDeviceToHost));
+  int64_t idx[6] = {0, 0, 0, 0, 0, 0};
+  uint8_t* h = static_cast<uint8_t*>(host);
+  for (int64_t k = 0; k < count; ++k) {
+    int64_t off = 0;
+    for (int i = 0; i < d->ndim; ++i) off += idx[i] * d->stride[i];
+    if (upload) memcpy(tmp.data() + off, h + k * es, (size_t)es);
+    else memcpy(h + k * es, tmp.data() + off, (size_t)es);
+    for (int i = d->ndim - 1; i >= 0; --i) {
+      if (++idx[i] < d->shape[i]) break;
+      idx[i] = 0;
+    }
+  }
+  if (upload) AIE_HIP_CHECK(env, hipMemcpy(dev, tmp.data(), (size_t)span, hipMemcpyHostToDevice));
+  return AIE_OK;
+}
+
+int aie_upload(aie_env* env, const char* name, const void* host, int64_t bytes) {
+  return copy_tensor(env, name, const_cast<void*>(host), bytes, true);
+}
+int aie_download(aie_env* env, const char* name, void* host, int64_t bytes) {
+  return copy_tensor(env, name, host, bytes, false);
+}
+
+int aie_set_layout(aie_env* env, const uint8_t* stone_src, const uint8_t* wood_src, const uint8_t* water) {
+  if (!env || !stone_src || !wood_src) return AIE_E_INVALID;
+  const aie_params& P = env->P;
+  const int shared = P.c.shared_layout ? 1 : 0;
+  const int64_t cnt = (shared ? 1 : (int64_t)P.E) * P.HW;
+  std::vector<uint8_t> fl((size_t)cnt);
+  for (int64_t q = 0; q < cnt; ++q)
+    fl[(size_t)q] = (uint8_t)(((water && water[q]) ? AIE_CELL_WATER : 0u) | (stone_src[q] ? AIE_CELL_STONE_SRC : 0u) |
+                              (wood_src[q] ? AIE_CELL_WOOD_SRC : 0u));
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  uint8_t* dfl = nullptr;
+  AIE_HIP_CHECK(env, hipMalloc(reinterpret_cast<void**>(&dfl), (size_t)cnt));
+  AIE_HIP_CHECK(env, hipMemcpy(dfl, fl.data(), (size_t)cnt, hipMemcpyHostToDevice));
+  const int64_t tot = (int64_t)P.E * P.HW;
+  hipLaunchKernelGGL(aie_set_flags_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, P, env->arena, dfl, shared);
+  AIE_HIP_CHECK(env, hipGetLastError());
+  AIE_HIP_CHECK(env, hipDeviceSynchronize());
+  AIE_HIP_CHECK(env, hipFree(dfl));
+  return AIE_OK;
+}
+
+int aie_seed(aie_env* env, uint32_t base_seed, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  hipLaunchKernelGGL(aie_seed_kernel, dim3((unsigned)((env->P.E + 63) / 64)), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), env->P, env->arena, base_seed);
+  AIE_HIP_CHECK(env, hipGetLastError());
+  return AIE_OK;
+}
+
+int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos) {
+  if (!env || !key || !pos) return AIE_E_INVALID;
+  const int64_t E = env->P.E;
+  int rc = aie_upload(env, "mt", key, E * AIE_MT_N * 4);
+  if (rc != AIE_OK) return rc;
+  rc = aie_upload(env, "mt_pos", pos, E * 4);
+  if (rc != AIE_OK) return rc;
+  std::vector<int32_t> z((size_t)E, 0);
+  std::vector<double> zd((size_t)E, 0.0);
+  rc = aie_upload(env, "mt_has_gauss", z.data(), E * 4);
+  if (rc != AIE_OK) return rc;
+  return aie_upload(env, "mt_gauss", zd.data(), E * 8);
+}
+
+int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+                     static_cast<hipStream_t>(stream), env->P, env->arena, d_env_mask);
+  AIE_HIP_CHECK(env, hipGetLastError());
+  return AIE_OK;
+}
+
+int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+                     static_cast<hipStream_t>(stream), env->P, env->arena, d_actions_a, d_actions_p);
+  AIE_HIP_CHECK(env, hipGetLastError());
+  return AIE_OK;
+}
+
+int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_offset, int32_t* d_actions_a,
+                              int32_t* d_actions_p, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  const aie_params& P = env->P;
+  const int64_t tot = (int64_t)P.E * (P.n * P.act_a_width + P.act_p_width);
+  hipLaunchKernelGGL(aie_sample_actions_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), P, seed, global_env_offset, env->sample_t, d_actions_a,
+                     d_actions_p);
+  env->sample_t += 1;
+  AIE_HIP_CHECK(env, hipGetLastError());
+  return AIE_OK;
+}
+
+}  // extern "C"

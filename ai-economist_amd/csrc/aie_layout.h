@@ -451,6 +451,23 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   return AIE_OK;
 }
 
+/* Counter-based RNG of the benchmark's synthetic uniform random policy
+ * (SURVEY.md 8(d)): splitmix64 finaliser over (seed, global replica id, t, slot). */
+#if defined(__HIPCC__)
+#define AIE_HD __host__ __device__
+#else
+#define AIE_HD
+#endif
+AIE_HD static inline uint32_t aie_counter_rng(uint64_t seed, uint64_t env, uint64_t t, uint64_t slot) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env + 1ull);
+  z ^= (t + 1ull) * 0xBF58476D1CE4E5B9ull;
+  z ^= (slot + 1ull) * 0x94D049BB133111EBull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+
 /* packed map cell */
 #define AIE_CELL_WATER 1u
 #define AIE_CELL_STONE_SRC 2u

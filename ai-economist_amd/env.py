@@ -1,0 +1,202 @@
+"""Device backend: owns the arena (a torch uint8 CUDA/HIP tensor), the `aie_env` handle
+and zero-copy torch views of every exported tensor.  torch is plumbing here (memory,
+streams, distributed); all compute happens in the HIP kernels behind the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi, _native
+
+_TORCH_DTYPES = None
+
+
+def _torch():
+    import torch
+
+    global _TORCH_DTYPES
+    if _TORCH_DTYPES is None:
+        _TORCH_DTYPES = [torch.uint8, torch.int8, torch.int16, torch.int32, torch.int32,
+                         torch.float32, torch.float64]  # uint32 exposed as int32 bits
+    return torch
+
+
+class AieError(RuntimeError):
+    pass
+
+
+class DeviceBackend:
+    def __init__(self, cfg, layout_planes, device=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise AieError("no HIP device visible: the batched env has no CPU fallback")
+        self.lib = _native.lib()
+        self.cfg = cfg
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        nbytes = self.lib.aie_arena_bytes(C.byref(cfg))
+        if nbytes < 0:
+            raise self._err(None, nbytes)
+        self.arena = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
+        h = C.c_void_p()
+        rc = self.lib.aie_create(C.byref(cfg), self.device.index or 0, self.arena.data_ptr(),
+                                 int(nbytes), C.byref(h))
+        if rc != 0:
+            raise self._err(None, rc)
+        self.handle = h
+        self.E = cfg.n_envs
+        self.n = cfg.n_agents
+        self.descs = {}
+        self.tensors = {}
+        d = _cabi.AieTensorDesc()
+        for i in range(self.lib.aie_num_tensors(self.handle)):
+            self.lib.aie_tensor_at(self.handle, i, C.byref(d))
+            name = d.name.decode()
+            self.descs[name] = (d.dtype, tuple(d.shape[: d.ndim]), tuple(d.stride[: d.ndim]),
+                                d.arena_offset)
+            self.tensors[name] = self._view(*self.descs[name])
+        stone_src, wood_src, water = [np.ascontiguousarray(p, np.uint8) for p in layout_planes]
+        self._check(self.lib.aie_set_layout(self.handle, stone_src.ctypes.data,
+                                            wood_src.ctypes.data, water.ctypes.data))
+        self.act_a_shape = (self.E, self.n) if not cfg.multi_action_mode_agents else None
+        self._rand_a = None
+        self._rand_p = None
+
+    # ---- plumbing ----
+    def _err(self, handle, rc):
+        msg = self.lib.aie_last_error(handle)
+        msg = msg.decode() if msg else ""
+        if rc == _cabi.E_NOTFOUND:
+            return KeyError(msg)
+        if rc == _cabi.E_INVALID:
+            return ValueError(msg)
+        if rc == _cabi.E_UNSUPPORTED:
+            return NotImplementedError(msg)
+        return AieError("aie error %d: %s" % (rc, msg))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise self._err(self.handle, rc)
+
+    def _view(self, dtype, shape, stride, offset):
+        torch = _torch()
+        tdt = _TORCH_DTYPES[dtype]
+        es = torch.empty(0, dtype=tdt).element_size()
+        base = self.arena[offset:]
+        usable = (base.numel() // es) * es
+        typed = base[:usable].view(tdt)
+        assert all(s % es == 0 for s in stride)
+        return torch.as_strided(typed, shape, tuple(s // es for s in stride))
+
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _ptr(self, t, dtype, what):
+        torch = _torch()
+        if t is None:
+            return None
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t), device=self.device)
+        if t.device != self.device:
+            t = t.to(self.device)
+        if t.dtype != dtype:
+            t = t.to(dtype)
+        t = t.contiguous()
+        self._keep = getattr(self, "_keep", [])
+        self._keep = self._keep[-8:] + [t]  # keep alive until the stream has consumed it
+        return C.c_void_p(t.data_ptr())
+
+    # ---- API ----
+    def seed(self, base_seed):
+        self._check(self.lib.aie_seed(self.handle, C.c_uint32(base_seed & 0xFFFFFFFF), self._stream()))
+
+    def set_rng_state(self, keys, pos):
+        keys = np.ascontiguousarray(keys, np.uint32).reshape(self.E, _cabi.MT_N)
+        pos = np.ascontiguousarray(pos, np.int32).reshape(self.E)
+        self._check(self.lib.aie_set_rng_state(self.handle, keys.ctypes.data, pos.ctypes.data))
+
+    def reset(self, env_mask=None):
+        torch = _torch()
+        m = self._ptr(env_mask, torch.uint8, "env_mask")
+        self._check(self.lib.aie_reset(self.handle, m, self._stream()))
+
+    def step(self, actions_a=None, actions_p=None):
+        torch = _torch()
+        a = self._ptr(actions_a, torch.int32, "actions_a")
+        p = self._ptr(actions_p, torch.int32, "actions_p")
+        self._check(self.lib.aie_step(self.handle, a, p, self._stream()))
+
+    def sample_random_actions(self, seed, env_offset=0):
+        """Fills (and returns) library-independent, caller-owned action buffers with the
+        benchmark's uniform random policy."""
+        torch = _torch()
+        if self._rand_a is None:
+            wa = 1 if not self.cfg.multi_action_mode_agents else max(1, self._n_sub_a())
+            wp = self._act_p_width()
+            self._rand_a = torch.zeros((self.E, self.n, wa), dtype=torch.int32, device=self.device)
+            self._rand_p = torch.zeros((self.E, wp), dtype=torch.int32, device=self.device)
+        self._check(self.lib.aie_sample_random_actions(
+            self.handle, C.c_uint64(seed), C.c_int64(env_offset),
+            C.c_void_p(self._rand_a.data_ptr()), C.c_void_p(self._rand_p.data_ptr()), self._stream()))
+        return self._rand_a, self._rand_p
+
+    def _n_sub_a(self):
+        comps = list(self.cfg.components)[: self.cfg.n_components]
+        return sum({_cabi.COMP_BUILD: 1, _cabi.COMP_CDA: 4, _cabi.COMP_GATHER: 1}.get(c, 0) for c in comps)
+
+    def _act_p_width(self):
+        has_planner_actions = (
+            _cabi.COMP_TAX in list(self.cfg.components)[: self.cfg.n_components]
+            and self.cfg.tax_model == 0 and not self.cfg.tax_disable)
+        if self.cfg.multi_action_mode_planner and has_planner_actions:
+            return self.cfg.tax_n_brackets
+        return 1
+
+    def upload(self, name, array):
+        dtype, shape, _, _ = self.descs[name]
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(array), shape), np.dtype(_cabi.DTYPES[dtype]))
+        self._check(self.lib.aie_upload(self.handle, name.encode(), arr.ctypes.data, arr.nbytes))
+
+    def download(self, name):
+        dtype, shape, _, _ = self.descs[name]
+        arr = np.empty(shape, np.dtype(_cabi.DTYPES[dtype]))
+        self._check(self.lib.aie_download(self.handle, name.encode(), arr.ctypes.data, arr.nbytes))
+        return arr
+
+    def load_state(self, state, e=None):
+        """Injects a host state ({field: array without env dim}) into replica e (or all)."""
+        torch = _torch()
+        for k, v in state.items():
+            if k in ("stone_src", "wood_src", "water"):
+                continue
+            if k not in self.tensors:
+                continue
+            t = self.tensors[k]
+            arr = np.asarray(v)
+            if k == "mt":
+                arr = arr.astype(np.uint32).view(np.int32)
+            src = torch.as_tensor(arr, device=self.device).to(t.dtype)
+            if e is None:
+                t[...] = src
+            else:
+                t[e] = src
+        if "stone_src" in state:
+            fl = (np.asarray(state["water"], np.uint8) + 2 * np.asarray(state["stone_src"], np.uint8)
+                  + 4 * np.asarray(state["wood_src"], np.uint8)).astype(np.uint8)
+            src = torch.as_tensor(fl, device=self.device)
+            if e is None:
+                self.tensors["cell_flags"][...] = src
+            else:
+                self.tensors["cell_flags"][e] = src
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.aie_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

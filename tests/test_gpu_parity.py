@@ -1,0 +1,231 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against
+(1) the committed reference golden vectors, (2) the CPU oracle on seeded random
+rollouts, (3) size-independent properties at the full BASELINE batch size."""
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import (F64_FIELDS, INT_FIELDS, compare_state, golden_names, load_golden, make_env,
+                     state_from_golden)
+
+pytestmark = pytest.mark.gpu
+
+OBS_TOL = 2e-6   # f32 observations (f64 in the reference, rounded once to f32)
+REW_TOL = 1e-5   # BASELINE.json north_star: coin-utility reward floats within 1e-5
+
+GTB = [["Build", {}], ["ContinuousDoubleAuction", {"max_num_orders": 5}], ["Gather", {}],
+       ["PeriodicBracketTax", {}]]
+C2 = dict(scenario_name="layout_from_file/simple_wood_and_stone", n_agents=4, world_size=[25, 25],
+          episode_length=1000, components=GTB, starting_agent_coin=10,
+          env_layout_file="quadrant_25x25_20each_30clump.txt")
+
+
+def _replica(be, e):
+    out = {}
+    for k, t in be.tensors.items():
+        v = t[e].cpu().numpy()
+        if k == "mt":
+            v = v.view(np.uint32)
+        out[k] = v
+    return out
+
+
+def _obs_check(be, g, k, where, e=0):
+    for name in [x for x in g.keys() if x.startswith("ob_")]:
+        t = name[3:]
+        want = g[name][k]
+        got = be.tensors[t][e].cpu().numpy()
+        if want.dtype.kind in "iu":
+            assert np.array_equal(got, want), "%s: obs %s differs" % (where, t)
+        else:
+            np.testing.assert_allclose(got, want, rtol=OBS_TOL, atol=OBS_TOL, err_msg="%s: obs %s" % (where, t))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_step_matches_reference_golden(name):
+    import torch
+
+    g = load_golden(name)
+    E = 3  # replicas 0 and 2 carry the golden state; replica 1 runs something else
+    env = make_env(g["cfg"], n_envs=E, device="cuda:0")
+    env.seed(77)
+    env.reset()
+    be = env.backend
+    s0 = state_from_golden(g, "s0_")
+    be.load_state(s0, e=0)
+    be.load_state(s0, e=2)
+    T = g["actions_a"].shape[0]
+    obs_steps = list(g["obs_steps"])
+    resets = {int(t): i for i, t in enumerate(g.get("reset_at", []))}
+    n = env.n_agents
+    for t in range(T):
+        a = np.zeros((E, n), np.int32)
+        a[0] = a[2] = g["actions_a"][t]
+        a[1] = (g["actions_a"][t] * 7 + t) % 6
+        act = {"a": torch.as_tensor(a, device="cuda:0")}
+        if g["actions_p"].shape[1]:
+            p = np.zeros((E, g["actions_p"].shape[1]), np.int32)
+            p[0] = p[2] = g["actions_p"][t]
+            act["p"] = torch.as_tensor(p, device="cuda:0")
+        env.step(act)
+        want = state_from_golden(g, "st_", t)
+        for e in (0, 2):
+            got = _replica(be, e)
+            compare_state(got, want, where="%s step %d replica %d" % (name, t + 1, e))
+            assert zlib.crc32(got["mt"].tobytes()) == int(g["st_mt_crc"][t])
+            rew = np.concatenate([got["rewards_a"], got["rewards_p"][None]])
+            np.testing.assert_allclose(rew, g["rew"][t], rtol=0, atol=REW_TOL)
+            assert int(got["done"]) == int(g["done"][t])
+        if (t + 1) in obs_steps:
+            _obs_check(be, g, obs_steps.index(t + 1), "%s step %d" % (name, t + 1), e=2)
+        if (t + 1) in resets:
+            env.reset(be.tensors["done"])
+            compare_state(_replica(be, 0), state_from_golden(g, "rs_", resets[t + 1]),
+                          where="%s reset after step %d" % (name, t + 1))
+    assert np.array_equal(_replica(be, 0)["mt"], g["final_mt"])
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_reset_matches_reference_golden(name):
+    g = load_golden(name)
+    E = 2
+    env = make_env(g["cfg"], n_envs=E, device="cuda:0")
+    be = env.backend
+    keys = np.stack([g["pre_reset_mt"]] * E)
+    be.set_rng_state(keys, np.full(E, int(g["pre_reset_pos"]), np.int32))
+    env.reset()
+    want = state_from_golden(g, "s0_")
+    for e in range(E):
+        got = _replica(be, e)
+        compare_state(got, want, where="%s reset replica %d" % (name, e))
+        assert np.array_equal(got["mt"], want["mt"])
+    if 0 in list(g["obs_steps"]):
+        _obs_check(be, g, list(g["obs_steps"]).index(0), name + " reset obs", e=1)
+
+
+def _compare_all(be, oracle, where, fields=None):
+    for k in INT_FIELDS + ["mt"]:
+        if k in be.tensors and k in oracle.t:
+            got = be.tensors[k].cpu().numpy()
+            if k == "mt":
+                got = got.view(np.uint32)
+            assert np.array_equal(got, oracle.t[k]), "%s: %s differs" % (where, k)
+    for r in range(2):
+        for side in ("bids", "asks"):
+            if "cda_" + side not in be.tensors:
+                continue
+            nn = oracle.t["cda_n_" + side][:, r]
+            got = be.tensors["cda_" + side][:, r].cpu().numpy()
+            want = oracle.t["cda_" + side][:, r]
+            msk = np.arange(got.shape[1])[None, :] < nn[:, None]
+            assert np.array_equal(got[msk], want[msk]), "%s: %s book differs" % (where, side)
+    for k in F64_FIELDS:
+        if k in be.tensors and k in oracle.t:
+            np.testing.assert_allclose(be.tensors[k].cpu().numpy(), oracle.t[k], rtol=1e-9, atol=1e-9,
+                                       err_msg="%s: %s" % (where, k))
+    for k in be.tensors:
+        if k.startswith("obs_") or k.startswith("rewards") or k == "done":
+            got = be.tensors[k].cpu().numpy()
+            want = oracle.t[k]
+            if got.dtype.kind in "iu":
+                assert np.array_equal(got, want), "%s: %s differs" % (where, k)
+            else:
+                np.testing.assert_allclose(got, want, rtol=OBS_TOL, atol=OBS_TOL, err_msg="%s: %s" % (where, k))
+
+
+@pytest.mark.parametrize("n_agents,E,T", [(4, 256, 230), (10, 128, 120)])
+def test_hip_matches_oracle_on_random_rollouts(n_agents, E, T):
+    """Seeded uniform-random rollouts (the bench's policy), every replica, every field,
+    every 10 steps, across a tax day and an episode boundary."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    cfg = dict(C2, n_agents=n_agents, episode_length=200, starting_agent_coin=15,
+               resource_regen_prob=0.05, env_layout_file="uniform_25x25_25each_65clump.txt")
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(5)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(5)
+    oracle.reset()
+    _compare_all(be, oracle, "after reset")
+    for t in range(T):
+        a, p = be.sample_random_actions(seed=99)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+        if (t + 1) % 10 == 0 or t + 1 == 200:
+            _compare_all(be, oracle, "step %d" % (t + 1))
+        if t + 1 == 200:
+            assert bool(be.tensors["done"].all())
+            env.reset(be.tensors["done"])
+            oracle.reset(oracle.t["done"].copy())
+            _compare_all(be, oracle, "after episode reset")
+
+
+def test_full_batch_properties_c2_4096():
+    """BASELINE configs[1] at full size (4096 replicas): determinism, shard invariance
+    (a replica's trajectory depends only on its global id), coin conservation."""
+    import torch
+
+    E, T = 4096, 120
+    env = make_env(dict(C2, resource_regen_prob=0.05, env_layout_file="uniform_25x25_25each_65clump.txt"),
+                   n_envs=E, device="cuda:0")
+    env.seed(11)
+    env.reset()
+    be = env.backend
+    for t in range(T):
+        a, p = be.sample_random_actions(seed=7)
+        env.step({"a": a, "p": p})
+    torch.cuda.synchronize()
+    snap = be.arena.clone()
+    # determinism
+    env2 = make_env(dict(C2, resource_regen_prob=0.05, env_layout_file="uniform_25x25_25each_65clump.txt"),
+                    n_envs=E, device="cuda:0")
+    env2.seed(11)
+    env2.reset()
+    for t in range(T):
+        a, p = env2.backend.sample_random_actions(seed=7)
+        env2.step({"a": a, "p": p})
+    torch.cuda.synchronize()
+    assert torch.equal(snap, env2.backend.arena)
+    # shard invariance: replicas [1024, 1024+64) run alone as a 64-replica shard
+    off, Es = 1024, 64
+    env3 = make_env(dict(C2, resource_regen_prob=0.05, env_layout_file="uniform_25x25_25each_65clump.txt"),
+                    n_envs=Es, device="cuda:0", env_offset=off)
+    env3.seed(11)
+    env3.reset()
+    for t in range(T):
+        a, p = env3.backend.sample_random_actions(seed=7, env_offset=off)
+        env3.step({"a": a, "p": p})
+    torch.cuda.synchronize()
+    for k in ("cells", "loc_r", "loc_c", "inv_res", "inv_coin", "labor", "mt", "obs_a_flat", "rewards_a"):
+        assert torch.equal(be.tensors[k][off:off + Es], env3.backend.tensors[k]), k
+    # coin conservation: trades and taxes move coin around, only building mints it
+    coin = (be.tensors["inv_coin"] + be.tensors["esc_coin"]).sum(dim=1).cpu().numpy()
+    houses = (be.tensors["house_owner"] >= 0).sum(dim=(1, 2)).cpu().numpy()
+    np.testing.assert_allclose(coin, 4 * 10.0 + 10.0 * houses, rtol=0, atol=1e-9)
+    assert houses.sum() > 0
+    # resource bookkeeping never goes negative; order books stay within quota
+    assert int(be.tensors["inv_res"].min()) >= 0 and int(be.tensors["esc_res"].min()) >= 0
+    assert int(be.tensors["cda_n_orders"].max()) <= 5
+    assert int(be.tensors["timestep"].min()) == T and int(be.tensors["timestep"].max()) == T
+
+
+def test_error_behaviour_through_cabi():
+    import ctypes
+
+    from ai_economist_amd import _cabi
+
+    env = make_env(C2, n_envs=4, device="cuda:0")
+    be = env.backend
+    with pytest.raises(KeyError):
+        be.download("no_such_tensor")
+    buf = np.zeros(3, np.int32)
+    rc = be.lib.aie_upload(be.handle, b"loc_r", buf.ctypes.data, buf.nbytes)  # wrong size
+    assert rc == _cabi.E_INVALID and b"expected" in be.lib.aie_last_error(be.handle)
+    d = _cabi.AieTensorDesc()
+    assert be.lib.aie_get_tensor(be.handle, b"obs_a_world-map", ctypes.byref(d)) == 0
+    assert tuple(d.shape[:5]) == (4, 4, 7, 11, 11) and d.dtype == 5
