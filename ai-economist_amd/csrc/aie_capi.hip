@@ -277,4 +277,11 @@ int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_of
   return AIE_OK;
 }
 
+// Development aid (not part of include/aie.h): phases of the step kernel to skip.
+int aie_dev_set_skip_mask(aie_env* env, int mask) {
+  if (!env) return AIE_E_INVALID;
+  env->P.dev_skip_mask = mask;
+  return AIE_OK;
+}
+
 }  // extern "C"

@@ -154,6 +154,26 @@ __device__ uint32_t rng_u32(const Ctx& c) {
 __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
+// numpy float64 add.reduce over n <= 128 contiguous values (pairwise summation with an
+// 8-way unrolled head, numpy/_core/src/umath/loops_utils.h.src): decisions such as
+// "mean agent reward > 0" (layout_from_file.py:554-557) depend on this exact order.
+__device__ double np_sum_small(const double* a, int n) {
+  if (n < 8) {
+    double res = -0.0;
+    for (int i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+    r0 += a[i + 0]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+    r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+  }
+  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (; i < n; ++i) res += a[i];
+  return res;
+}
+
 __device__ double rng_double(const Ctx& c) {
   uint32_t a = rng_u32(c);
   uint32_t b = rng_u32(c);
@@ -640,8 +660,7 @@ __device__ void current_metrics(const Ctx& c) {
     }
     __syncthreads();
     if (i == 0) {
-      double tot = 0;
-      for (int j = 0; j < n; ++j) tot += coin[j];
+      const double tot = np_sum_small(coin, n);
       double gini;
       if (n < 30) {
         double diff = 0;
@@ -657,8 +676,9 @@ __device__ void current_metrics(const Ctx& c) {
           while (b >= 0 && s[b] > x) { s[b + 1] = s[b]; --b; }
           s[b + 1] = x;
         }
+        const double tots = np_sum_small(s, n);
         double run = 0, acc = 0;
-        for (int j = 0; j < n; ++j) { run += s[j]; acc += run / (tot + 1e-10); }
+        for (int j = 0; j < n; ++j) { run += s[j]; acc += run / (tots + 1e-10); }
         gini = 1 - (2.0 / (n + 1)) * acc;
       }
       const double ew = 1 - c.P.c.mixing_weight_gini_vs_coin;
@@ -695,9 +715,7 @@ __device__ void compute_rewards(const Ctx& c, uint8_t* __restrict__ arena) {
   }
   __syncthreads();
   if (i == 0) {
-    double s = 0;
-    for (int j = 0; j < n; ++j) s += rew[j];
-    if (s / n > 0) *R_I32(c, o_auto_warmup) += 1;
+    if (np_sum_small(rew, n) / n > 0) *R_I32(c, o_auto_warmup) += 1;
   }
 }
 
@@ -1049,25 +1067,28 @@ aie_step_kernel(const aie_params P, uint8_t* __restrict__ arena, const int32_t* 
   rebuild_locmap(c);
   if (P.has_cda) cda_decay_price_history(c);
   __syncthreads();
+  const int skip = P.dev_skip_mask;
   if (c.tid == 0) {
     *R_I32(c, o_timestep) += 1;
-    for (int k = 0; k < P.c.n_components; ++k) {
-      switch (P.c.components[k]) {
-        case AIE_COMP_BUILD: build_component_step(c); break;
-        case AIE_COMP_CDA: cda_component_step(c); break;
-        case AIE_COMP_GATHER: gather_component_step(c); break;
-        case AIE_COMP_TAX: tax_component_step(c); break;
-        default: break;
+    if (!(skip & 1)) {
+      for (int k = 0; k < P.c.n_components; ++k) {
+        switch (P.c.components[k]) {
+          case AIE_COMP_BUILD: build_component_step(c); break;
+          case AIE_COMP_CDA: cda_component_step(c); break;
+          case AIE_COMP_GATHER: gather_component_step(c); break;
+          case AIE_COMP_TAX: tax_component_step(c); break;
+          default: break;
+        }
       }
     }
   }
   __syncthreads();
-  scenario_step_regen(c);
+  if (!(skip & 2)) scenario_step_regen(c);
   __syncthreads();
-  write_spatial_observations(c, arena);
-  write_flat_observations_and_masks(c, arena);
+  if (!(skip & 4)) write_spatial_observations(c, arena);
+  if (!(skip & 8)) write_flat_observations_and_masks(c, arena);
   __syncthreads();
-  compute_rewards(c, arena);
+  if (!(skip & 16)) compute_rewards(c, arena);
   __syncthreads();
   if (c.tid == 0) {
     const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
@@ -1075,7 +1096,7 @@ aie_step_kernel(const aie_params P, uint8_t* __restrict__ arena, const int32_t* 
     if (done) *R_I32(c, o_completions) += 1;
   }
   __syncthreads();
-  store_record(c, arena);
+  if (!(skip & 32)) store_record(c, arena);
 }
 
 // BaseEnvironment.reset, F/base/base_env.py:852-927, with LayoutFromFile

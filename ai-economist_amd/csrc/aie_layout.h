@@ -93,6 +93,11 @@ typedef struct aie_params {
   int64_t a_obs_p_map, a_obs_p_idx, a_obs_p_flat, a_obs_p_mask, a_obs_p_time, a_obs_p_agents;
   int64_t a_rew_a, a_rew_p, a_done;
   int64_t arena_bytes;
+
+  /* development only: phases of the step kernel to skip when profiling
+   * (tools/phase_profile.py); always 0 in normal operation */
+  int32_t dev_skip_mask;
+  int32_t dev_pad;
 } aie_params;
 
 typedef struct aie_tensor_table {
