@@ -11,6 +11,7 @@
 
 struct aie_env {
   aie_params P;
+  aie_params* d_params;  // device copy of P (kernel parameter block)
   aie_tensor_table tt;
   uint8_t* arena;
   bool owns_arena;
@@ -113,6 +114,14 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
     delete env;
     return AIE_E_HIP;
   }
+  he = hipMalloc(reinterpret_cast<void**>(&env->d_params), sizeof(aie_params));
+  if (he == hipSuccess) he = hipMemcpy(env->d_params, &env->P, sizeof(aie_params), hipMemcpyHostToDevice);
+  if (he != hipSuccess) {
+    snprintf(g_create_err, sizeof(g_create_err), "parameter block: %s", hipGetErrorString(he));
+    if (env->owns_arena) (void)hipFree(env->arena);
+    delete env;
+    return AIE_E_HIP;
+  }
   for (int i = 0; i < env->tt.n; ++i) env->tt.t[i].data = env->arena + env->tt.t[i].arena_offset;
   *out = env;
   return AIE_OK;
@@ -123,6 +132,7 @@ int aie_destroy(aie_env* env) {
   (void)hipSetDevice(env->device);
   (void)hipDeviceSynchronize();
   if (env->owns_arena && env->arena) (void)hipFree(env->arena);
+  if (env->d_params) (void)hipFree(env->d_params);
   delete env;
   return AIE_OK;
 }
@@ -249,7 +259,7 @@ int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
   if (!env) return AIE_E_INVALID;
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
-                     static_cast<hipStream_t>(stream), env->P, env->arena, d_env_mask);
+                     static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
 }
@@ -258,7 +268,7 @@ int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_
   if (!env) return AIE_E_INVALID;
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
-                     static_cast<hipStream_t>(stream), env->P, env->arena, d_actions_a, d_actions_p);
+                     static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
 }
@@ -281,6 +291,9 @@ int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_of
 int aie_dev_set_skip_mask(aie_env* env, int mask) {
   if (!env) return AIE_E_INVALID;
   env->P.dev_skip_mask = mask;
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  AIE_HIP_CHECK(env, hipDeviceSynchronize());
+  AIE_HIP_CHECK(env, hipMemcpy(env->d_params, &env->P, sizeof(aie_params), hipMemcpyHostToDevice));
   return AIE_OK;
 }
 

@@ -2,16 +2,19 @@
 // env.step() / env.reset() of the gather-trade-build family.
 //
 // Execution model: ONE WAVEFRONT (64 lanes) PER ENV REPLICA, one replica per workgroup.
-//   1. the replica's state record (map cells, agents, order book, tax trackers, MT19937
-//      state; layout in aie_layout.h) is streamed HBM -> LDS with 16-byte lane loads,
-//   2. component dynamics run out of LDS: inherently sequential parts (random agent
-//      order, order matching) on lane 0, everything else (price-history decay, resource
-//      regeneration incl. the MT19937 twist, observation crops, masks, utilities)
-//      across the 64 lanes,
-//   3. observations are written straight to their dense [E, ...] tensors with
-//      lane-contiguous (coalesced) stores; small vectors are staged in LDS and
-//      streamed out 4 bytes/lane contiguous,
-//   4. the record is streamed back LDS -> HBM.
+//   * the replica's state record (layout in aie_layout.h) is streamed HBM -> LDS with
+//     16-byte lane loads; its MT19937 key (624 words) goes HBM -> REGISTERS instead
+//     (10 VGPRs: lane l of row j holds word 64*j + l),
+//   * agent i's scalars (location, inventories, coin, labor, decoded action) live in the
+//     registers of lane i; "agent j acts next" is a v_readlane broadcast, never an LDS
+//     round trip; random agent orders are lane-distributed permutations,
+//   * the order book is matched with wave ballots: "best bid of a not-yet-flagged buyer"
+//     and "best ask of another agent" are find-first-set over 64 book slots at a time,
+//     insertions / removals / expiry compaction are one-instruction lane shifts,
+//   * the MT19937 twist is 10 register rows x (3 ds_bpermute + ~10 VALU) with no memory
+//     traffic and no barriers; np.random.rand(H, W) is consumed straight from the rows,
+//   * observations are written to their dense [E, ...] tensors with lane-contiguous
+//     (coalesced) stores; small vectors are staged in LDS and streamed out.
 // The path is integer / branchy and HBM-bound on the observation writes: no MFMA.
 //
 // Each __device__ function cites the reference function it implements (paths relative
@@ -22,18 +25,24 @@
 #include "aie_layout.h"
 
 #define AIE_NT 64  // threads per replica (one wavefront)
+#define AIE_SRC_CAP 256  // source-block doubles handled by the gather regen (else row regen)
 
 namespace aie {
 
+// NOTE: every __device__ function below is __forceinline__: a non-inlined call that takes
+// `const aie_params&` forces the compiler to copy the whole by-value kernel argument
+// (2.7 KB) to scratch memory on every launch -- measured 5x slower.
+
 struct Ctx {
   const aie_params& P;
-  uint8_t* rec;      // LDS copy of the record
-  int32_t* act;      // LDS [n][AIE_N_SUB_SLOTS] decoded agent actions
+  uint8_t* rec;      // LDS copy of the record (everything before the MT19937 key)
   int32_t* act_p;    // LDS [AIE_MAX_BRACKETS] decoded planner actions
-  int32_t* perm;     // LDS [AIE_MAX_AGENTS] random agent order
   uint8_t* locmap;   // LDS [HW] 0 = empty, i+1 = agent i
   double* fscr;      // LDS f64 scratch
-  float* stage;      // LDS staging of the small observation vectors
+  float* stage;      // LDS staging of the small observation vectors (also: MT word dump during regen)
+  uint16_t* srcl;    // LDS [AIE_SRC_CAP] regen doubles that target a source block
+  int32_t* srcn;     // LDS [1] number of source doubles found (may exceed AIE_SRC_CAP)
+  int32_t* mflags;   // LDS [n] per-agent mask bits
   int tid;
   int e;
 };
@@ -43,60 +52,147 @@ struct Ctx {
 #define R_U8(c, off) (reinterpret_cast<uint8_t*>((c).rec + (c).P.off))
 #define R_CELLS(c) (reinterpret_cast<uint32_t*>((c).rec + (c).P.o_cells))
 
-// f64 scratch slots
-__device__ __forceinline__ double* scr_net_ph(const Ctx& c) { return c.fscr; }                       // [2][P]
-__device__ __forceinline__ double* scr_market(const Ctx& c) { return c.fscr + 2 * 128; }             // [2]
-__device__ __forceinline__ double* scr_sorted_inc(const Ctx& c) { return c.fscr + 2 * 128 + 2; }     // [n]
-__device__ __forceinline__ double* scr_cmr(const Ctx& c) { return c.fscr + 2 * 128 + 2 + 64; }       // [n]
-__device__ __forceinline__ double* scr_coin(const Ctx& c) { return c.fscr + 2 * 128 + 2 + 128; }     // [n]
-__device__ __forceinline__ double* scr_part(const Ctx& c) { return c.fscr + 2 * 128 + 2 + 192; }     // [n+1]
-#define AIE_FSCR_DOUBLES (2 * 128 + 2 + 192 + 66)
+// f64 scratch slots: net price history [2][P], then four per-agent vectors
+__device__ __forceinline__ double* scr_net_ph(const Ctx& c) { return c.fscr; }
+__device__ __forceinline__ double* scr_sorted_inc(const Ctx& c) { return c.fscr + 2 * c.P.P; }
+__device__ __forceinline__ double* scr_cmr(const Ctx& c) { return c.fscr + 2 * c.P.P + c.P.n; }
+__device__ __forceinline__ double* scr_coin(const Ctx& c) { return c.fscr + 2 * c.P.P + 2 * c.P.n; }
+__device__ __forceinline__ double* scr_part(const Ctx& c) { return c.fscr + 2 * c.P.P + 3 * c.P.n; }  // [n+1]
+__host__ __device__ inline int fscr_doubles(const aie_params& P) { return 2 * P.P + 4 * P.n + 2; }
+
+// The LDS image of the record stops where the MT19937 key starts (it lives in VGPRs).
+__host__ __device__ inline int rec_lds_bytes(const aie_params& P) { return P.o_mt; }
+
+// staging area: small observation vectors; reused as the 624-word MT19937 dump of regen
+__host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline size_t stage_bytes(const aie_params& P) {
+  size_t b = (size_t)(pad4(P.n * P.FA) + pad4(P.n * P.MA) + pad4(P.n * P.FPA) + pad4(P.FP) + pad4(P.MP)) * 4;
+  if (b < AIE_MT_N * 4) b = AIE_MT_N * 4;
+  return (b + 15) / 16 * 16;
+}
 
 __host__ __device__ inline size_t lds_bytes(const aie_params& P) {
-  size_t b = (size_t)P.rec_bytes;
-  b += (size_t)P.n * AIE_N_SUB_SLOTS * 4 + AIE_MAX_BRACKETS * 4 + AIE_MAX_AGENTS * 4;
+  size_t b = (size_t)rec_lds_bytes(P);
+  b += AIE_MAX_BRACKETS * 4;
   b = (b + 15) / 16 * 16;
   b += ((size_t)P.HW + 15) / 16 * 16;
-  b += AIE_FSCR_DOUBLES * 8;
-  b += ((size_t)P.n * (P.FA + P.MA + P.FPA) + P.FP + P.MP) * 4 + 64;
+  b += (size_t)fscr_doubles(P) * 8;
+  b += stage_bytes(P);
+  b += AIE_SRC_CAP * 2 + 16 + (size_t)P.n * 4;
   return (b + 15) / 16 * 16;
 }
 
 __device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e, int tid) {
-  uint8_t* q = lds + P.rec_bytes;
-  int32_t* act = reinterpret_cast<int32_t*>(q);
-  q += P.n * AIE_N_SUB_SLOTS * 4;
+  uint8_t* q = lds + rec_lds_bytes(P);
   int32_t* act_p = reinterpret_cast<int32_t*>(q);
   q += AIE_MAX_BRACKETS * 4;
-  int32_t* perm = reinterpret_cast<int32_t*>(q);
-  q += AIE_MAX_AGENTS * 4;
   q = lds + ((q - lds) + 15) / 16 * 16;
   uint8_t* locmap = q;
   q += (P.HW + 15) / 16 * 16;
   double* fscr = reinterpret_cast<double*>(q);
-  q += AIE_FSCR_DOUBLES * 8;
+  q += fscr_doubles(P) * 8;
   float* stage = reinterpret_cast<float*>(q);
-  return Ctx{P, lds, act, act_p, perm, locmap, fscr, stage, tid, e};
+  q += stage_bytes(P);
+  uint16_t* srcl = reinterpret_cast<uint16_t*>(q);
+  q += AIE_SRC_CAP * 2;
+  int32_t* srcn = reinterpret_cast<int32_t*>(q);
+  q += 16;
+  int32_t* mflags = reinterpret_cast<int32_t*>(q);
+  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, tid, e};
 }
 
 // ------------------------------------------------------------------------------------
-// record streaming HBM <-> LDS (16 B per lane, fully coalesced)
+// wave helpers
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restrict__ arena) {
-  const uint4* src = reinterpret_cast<const uint4*>(arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes);
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ double bcast(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// 16 bytes with dword alignment: global dwordx4 accesses need no more on gfx950
+struct __attribute__((packed, aligned(4))) f32x4_a4 { float x, y, z, w; };
+
+// LDS (16-byte aligned) -> global (dword aligned) copy of `count` floats
+__device__ __forceinline__ void stream_out(const float* __restrict__ lds_src, float* __restrict__ dst, int count, int tid) {
+  const int n4 = count >> 2;
+  for (int q = tid; q < n4; q += AIE_NT) {
+    const float4 v = reinterpret_cast<const float4*>(lds_src)[q];
+    f32x4_a4 o = {v.x, v.y, v.z, v.w};
+    reinterpret_cast<f32x4_a4*>(dst)[q] = o;
+  }
+  for (int q = 4 * n4 + tid; q < count; q += AIE_NT) dst[q] = lds_src[q];
+}
+
+// q / d for a run-time constant d with host-computed magic (aie_layout.h: aie__magic)
+__device__ __forceinline__ int udiv(int q, int d, uint32_t magic) {
+  return d == 1 ? q : (int)__umulhi((uint32_t)q, magic);
+}
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// ------------------------------------------------------------------------------------
+// record streaming HBM <-> LDS (16 B per lane, fully coalesced); MT key HBM <-> VGPRs
+// ------------------------------------------------------------------------------------
+struct MT {
+  uint32_t r[10];  // word 64*j + lane (row 9: lanes 0..47)
+  int pos;         // wave-uniform index of the next unused word (624 = twist first)
+};
+
+// Also collects, with LDS atomics, the list of regeneration draws that matter: double d of
+// the step's 2*H*W np.random.rand values targets Wood cell d (d < HW) or Stone cell d-HW,
+// and only source-block cells can respawn (layout_from_file.py:394-403).
+// *c.srcn must have been zeroed (and a barrier passed) before the call.
+__device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {
+  const uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
+  const uint4* src = reinterpret_cast<const uint4*>(g);
   uint4* dst = reinterpret_cast<uint4*>(c.rec);
-  const int nq = c.P.rec_bytes >> 4;
-  for (int q = c.tid; q < nq; q += AIE_NT) dst[q] = src[q];
+  const int nq = rec_lds_bytes(c.P) >> 4;
+  const int HW = c.P.HW;
+  for (int q = c.tid; q < nq; q += AIE_NT) {
+    const uint4 v = src[q];
+    dst[q] = v;
+    const int cell0 = 4 * q - (c.P.o_cells >> 2);
+    if (cell0 >= 0 && cell0 < HW) {
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t fl = w[k] >> 24;
+        if ((fl & (AIE_CELL_STONE_SRC | AIE_CELL_WOOD_SRC)) && cell0 + k < HW) {
+          if (fl & AIE_CELL_WOOD_SRC) {
+            const int slot = atomicAdd(c.srcn, 1);
+            if (slot < AIE_SRC_CAP) c.srcl[slot] = (uint16_t)(cell0 + k);
+          }
+          if (fl & AIE_CELL_STONE_SRC) {
+            const int slot = atomicAdd(c.srcn, 1);
+            if (slot < AIE_SRC_CAP) c.srcl[slot] = (uint16_t)(HW + cell0 + k);
+          }
+        }
+      }
+    }
+  }
+  const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
+  m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
 }
-__device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__ arena) {
-  uint4* dst = reinterpret_cast<uint4*>(arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes);
+__device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m) {
+  uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
+  uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
-  const int nq = c.P.rec_bytes >> 4;
+  const int nq = rec_lds_bytes(c.P) >> 4;
   for (int q = c.tid; q < nq; q += AIE_NT) dst[q] = src[q];
+  uint32_t* key = reinterpret_cast<uint32_t*>(g + c.P.o_mt);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
+  if (c.tid < 48) key[576 + c.tid] = m.r[9];
 }
 
 // ------------------------------------------------------------------------------------
-// NumPy legacy RandomState stream (MT19937), one per replica, state in the record.
+// NumPy legacy RandomState stream (MT19937), one per replica.
 // The reference draws from the process-global np.random (F/base/base_env.py:493,
 // F/base/world.py:420, F/components/move.py:138, layout_from_file.py:361-366,400).
 // ------------------------------------------------------------------------------------
@@ -111,53 +207,88 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   y ^= (y >> 18);
   return y;
 }
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, int src_lane) { return (uint32_t)__shfl((int)v, src_lane, 64); }
 
-// Whole-wave twist: word k of the next state needs words k, k+1 and k+397 (mod 624);
-// 64 consecutive words are independent of each other because the recurrence distance
-// is 227 > 64, so the state is regenerated in ten 64-lane slices, in place.
-__device__ void mt_twist_wave(const Ctx& c) {
-  uint32_t* mt = reinterpret_cast<uint32_t*>(c.rec + c.P.o_mt);
-  for (int base = 0; base < AIE_MT_N; base += AIE_NT) {
-    const int k = base + c.tid;
-    uint32_t v = 0;
-    if (k < AIE_MT_N) {
-      const int k1 = (k + 1 == AIE_MT_N) ? 0 : k + 1;
-      const int km = (k + 397 >= AIE_MT_N) ? k + 397 - AIE_MT_N : k + 397;
-      v = mt_mix(mt[k], mt[k1], mt[km]);
-    }
-    __syncthreads();
-    if (k < AIE_MT_N) mt[k] = v;
-    __syncthreads();
+// Whole-state twist in registers.  Word k = 64*J + l of the next state needs words k,
+// k+1 and k+397 (mod 624, with the sequential in-place semantics: indices that wrap
+// refer to ALREADY UPDATED words).  k+397 = 64*(J+6) + l+13 and k-227 = 64*(J-4) + l+29,
+// so every row is two lane rotations (by 13 or by 29) of two other rows.
+#define AIE_MT_ROW(J, ROT, SPLIT, ROW_LO, ROW_HI, NEXT0)                                      \
+  {                                                                                          \
+    const uint32_t a = m.r[J];                                                               \
+    uint32_t b = lane_get(a, (lane + 1) & 63);                                               \
+    b = (lane == ((J) == 9 ? 47 : 63)) ? (NEXT0) : b;                                        \
+    const uint32_t x_lo = lane_get(ROW_LO, (lane + (ROT)) & 63);                             \
+    const uint32_t x_hi = lane_get(ROW_HI, (lane + (ROT)) & 63);                             \
+    m.r[J] = mt_mix(a, b, lane < (SPLIT) ? x_lo : x_hi);                                     \
   }
-}
-// Single-lane twist for the (rare) case where the sequential draws of lane 0 run off
-// the end of the current state block.
-__device__ void mt_twist_serial(uint32_t* mt) {
-  int i;
-  for (i = 0; i < AIE_MT_N - 397; i++) mt[i] = mt_mix(mt[i], mt[i + 1], mt[i + 397]);
-  for (; i < AIE_MT_N - 1; i++) mt[i] = mt_mix(mt[i], mt[i + 1], mt[i + 397 - AIE_MT_N]);
-  mt[AIE_MT_N - 1] = mt_mix(mt[AIE_MT_N - 1], mt[0], mt[396]);
-}
-// sequential draws (lane 0 only)
-__device__ uint32_t rng_u32(const Ctx& c) {
-  uint32_t* mt = reinterpret_cast<uint32_t*>(c.rec + c.P.o_mt);
-  int32_t* pos = R_I32(c, o_mt_pos);
-  int p = *pos;
-  if (p >= AIE_MT_N) {
-    mt_twist_serial(mt);
-    p = 0;
+__device__ __forceinline__ void mt_twist_body(MT& m, int lane) {
+  // rows 0..2: old[k+397] from rows J+6 (l < 51) / J+7 (l >= 51), rotation 13
+  AIE_MT_ROW(0, 13, 51, m.r[6], m.r[7], bcast(m.r[1], 0))
+  AIE_MT_ROW(1, 13, 51, m.r[7], m.r[8], bcast(m.r[2], 0))
+  AIE_MT_ROW(2, 13, 51, m.r[8], m.r[9], bcast(m.r[3], 0))
+  {  // row 3: l < 35 old row 9 (rotation 13), l >= 35 NEW row 0 (rotation 29)
+    const uint32_t a = m.r[3];
+    uint32_t b = lane_get(a, (lane + 1) & 63);
+    b = (lane == 63) ? bcast(m.r[4], 0) : b;
+    const uint32_t x_lo = lane_get(m.r[9], (lane + 13) & 63);
+    const uint32_t x_hi = lane_get(m.r[0], (lane + 29) & 63);
+    m.r[3] = mt_mix(a, b, lane < 35 ? x_lo : x_hi);
   }
-  uint32_t y = mt[p];
-  *pos = p + 1;
-  return mt_temper(y);
+  // rows 4..9: NEW[k-227] from rows J-4 (l < 35) / J-3 (l >= 35), rotation 29
+  AIE_MT_ROW(4, 29, 35, m.r[0], m.r[1], bcast(m.r[5], 0))
+  AIE_MT_ROW(5, 29, 35, m.r[1], m.r[2], bcast(m.r[6], 0))
+  AIE_MT_ROW(6, 29, 35, m.r[2], m.r[3], bcast(m.r[7], 0))
+  AIE_MT_ROW(7, 29, 35, m.r[3], m.r[4], bcast(m.r[8], 0))
+  AIE_MT_ROW(8, 29, 35, m.r[4], m.r[5], bcast(m.r[9], 0))
+  AIE_MT_ROW(9, 29, 35, m.r[5], m.r[6], bcast(m.r[0], 0))  // word 623 pairs with NEW word 0
+}
+
+// One out-of-line copy of the twist (rows travel in VGPRs by value): it is reached from
+// every draw site, and inlining ~150 instructions x 8 sites would overflow the I-cache.
+struct MTRows { uint32_t r[10]; };
+__device__ __attribute__((noinline)) MTRows mt_twist_rows(MTRows in, int lane) {
+  MT m;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) m.r[j] = in.r[j];
+  m.pos = 0;
+  mt_twist_body(m, lane);
+  MTRows out;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) out.r[j] = m.r[j];
+  return out;
+}
+__device__ __forceinline__ void mt_twist(MT& m, int lane) {
+  MTRows t;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) t.r[j] = m.r[j];
+  t = mt_twist_rows(t, lane);
+#pragma unroll
+  for (int j = 0; j < 10; ++j) m.r[j] = t.r[j];
+}
+
+// sequential draws (wave-uniform: every lane gets the same value)
+__device__ __forceinline__ uint32_t rng_u32(MT& m, int lane) {
+  if (m.pos >= AIE_MT_N) {
+    mt_twist(m, lane);
+    m.pos = 0;
+  }
+  const int row = m.pos >> 6;
+  uint32_t v = m.r[0];
+#pragma unroll
+  for (int j = 1; j < 10; ++j) v = (row == j) ? m.r[j] : v;
+  const uint32_t w = bcast(v, m.pos & 63);
+  m.pos += 1;
+  return mt_temper(w);
 }
 __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
+
 // numpy float64 add.reduce over n <= 128 contiguous values (pairwise summation with an
 // 8-way unrolled head, numpy/_core/src/umath/loops_utils.h.src): decisions such as
 // "mean agent reward > 0" (layout_from_file.py:554-557) depend on this exact order.
-__device__ double np_sum_small(const double* a, int n) {
+__device__ __forceinline__ double np_sum_small(const double* a, int n) {
   if (n < 8) {
     double res = -0.0;
     for (int i = 0; i < n; ++i) res += a[i];
@@ -174,40 +305,43 @@ __device__ double np_sum_small(const double* a, int n) {
   return res;
 }
 
-__device__ double rng_double(const Ctx& c) {
-  uint32_t a = rng_u32(c);
-  uint32_t b = rng_u32(c);
+__device__ __forceinline__ double rng_double(MT& m, int lane) {
+  const uint32_t a = rng_u32(m, lane);
+  const uint32_t b = rng_u32(m, lane);
   return u53(a, b);
 }
 // random_interval(max): masked rejection on 32-bit words
-__device__ uint32_t rng_interval(const Ctx& c, uint32_t max) {
+__device__ __forceinline__ uint32_t rng_interval(MT& m, int lane, uint32_t max) {
   if (max == 0) return 0;
   uint32_t mask = max, v;
   mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-  while ((v = (rng_u32(c) & mask)) > max) {}
+  while ((v = (rng_u32(m, lane) & mask)) > max) {}
   return v;
 }
-// np.random.permutation(n): World.get_random_order_agents, F/base/world.py:418-422
-__device__ void rng_permutation(const Ctx& c, int n, int32_t* out) {
-  for (int i = 0; i < n; ++i) out[i] = i;
+// np.random.permutation(n): World.get_random_order_agents, F/base/world.py:418-422.
+// Returned lane-distributed: lane k holds the k-th agent of the random order.
+__device__ __forceinline__ int rng_permutation(MT& m, int lane, int n) {
+  int p = lane;
   for (int i = n - 1; i >= 1; --i) {
-    int j = (int)rng_interval(c, (uint32_t)i);
-    int t = out[i]; out[i] = out[j]; out[j] = t;
+    const int j = (int)rng_interval(m, lane, (uint32_t)i);
+    const int vi = bcast(p, i), vj = bcast(p, j);
+    p = (lane == i) ? vj : ((lane == j) ? vi : p);
   }
+  return p;
 }
-__device__ double rng_gauss(const Ctx& c) {  // legacy_gauss (polar Box-Muller, cached)
+__device__ __forceinline__ double rng_gauss(const Ctx& c, MT& m) {  // legacy_gauss (polar Box-Muller, cached)
   int32_t* has = R_I32(c, o_mt_has_gauss);
   double* g = R_F64(c, o_mt_gauss);
   if (*has) {
-    double t = *g;
+    const double t = *g;
     *has = 0;
     *g = 0.0;
     return t;
   }
   double f, x1, x2, r2;
   do {
-    x1 = 2.0 * rng_double(c) - 1.0;
-    x2 = 2.0 * rng_double(c) - 1.0;
+    x1 = 2.0 * rng_double(m, c.tid) - 1.0;
+    x2 = 2.0 * rng_double(m, c.tid) - 1.0;
     r2 = x1 * x1 + x2 * x2;
   } while (r2 >= 1.0 || r2 == 0.0);
   f = sqrt(-2.0 * log(r2) / r2);
@@ -215,8 +349,8 @@ __device__ double rng_gauss(const Ctx& c) {  // legacy_gauss (polar Box-Muller, 
   *has = 1;
   return f * x2;
 }
-__device__ double rng_pareto(const Ctx& c, double a) { return exp(-log(1.0 - rng_double(c)) / a) - 1.0; }
-__device__ double rng_lognormal(const Ctx& c, double mean, double sigma) { return exp(mean + sigma * rng_gauss(c)); }
+__device__ __forceinline__ double rng_pareto(MT& m, int lane, double a) { return exp(-log(1.0 - rng_double(m, lane)) / a) - 1.0; }
+__device__ __forceinline__ double rng_lognormal(const Ctx& c, MT& m, double mean, double sigma) { return exp(mean + sigma * rng_gauss(c, m)); }
 
 // ------------------------------------------------------------------------------------
 // World helpers (F/base/world.py)
@@ -245,70 +379,174 @@ __device__ __forceinline__ bool agent_can_build(const Ctx& c, int i) {
 }
 
 // ------------------------------------------------------------------------------------
-// Build.component_step, F/components/build.py:112-161 (lane 0)
+// Agent state in registers: lane i < n holds agent i.
 // ------------------------------------------------------------------------------------
-__device__ void build_component_step(const Ctx& c) {
-  const int n = c.P.n;
-  int32_t* order = c.perm;
-  rng_permutation(c, n, order);  // drawn even if nobody builds (build.py:121)
-  for (int k = 0; k < n; ++k) {
-    const int i = order[k];
-    if (c.act[i * AIE_N_SUB_SLOTS + AIE_SUB_BUILD] != 1) continue;
-    if (!agent_can_build(c, i)) continue;
-    R_I32(c, o_inv_res)[n + i] -= 1;
-    R_I32(c, o_inv_res)[i] -= 1;
-    const int cell = R_I32(c, o_loc_r)[i] * c.P.W + R_I32(c, o_loc_c)[i];
-    uint32_t w = R_CELLS(c)[cell];
-    R_CELLS(c)[cell] = (w & 0xff00ffffu) | ((uint32_t)i << 16);  // world.py:474-479
-    R_F64(c, o_inv_coin)[i] += R_F64(c, o_build_payment)[i];
-    R_F64(c, o_labor)[i] += c.P.c.build_labor;
+struct Agents {
+  int lr, lc;            // location
+  int inv0, inv1;        // Stone, Wood in inventory
+  int esc0, esc1;        // Stone, Wood in escrow
+  int no0, no1;          // open orders per commodity (CDA n_orders)
+  uint32_t act;          // bit 0 build | gather << 1 (3 bits) | buy0 << 4 | sell0 << 11 | buy1 << 18 | sell1 << 25
+  double coin, esc_coin, labor;
+};
+#define AIE_ACT_BUILD(a) ((a) & 1u)
+#define AIE_ACT_GATHER(a) (((a) >> 1) & 7u)
+#define AIE_ACT_BUY(a, r) (((a) >> (4 + 14 * (r))) & 0x7fu)
+#define AIE_ACT_SELL(a, r) (((a) >> (11 + 14 * (r))) & 0x7fu)
+
+__device__ __forceinline__ void agents_load(const Ctx& c, Agents& A) {
+  const int n = c.P.n, i = c.tid < n ? c.tid : 0;
+  A.lr = R_I32(c, o_loc_r)[i];
+  A.lc = R_I32(c, o_loc_c)[i];
+  A.inv0 = R_I32(c, o_inv_res)[i];
+  A.inv1 = R_I32(c, o_inv_res)[n + i];
+  A.esc0 = R_I32(c, o_esc_res)[i];
+  A.esc1 = R_I32(c, o_esc_res)[n + i];
+  A.no0 = c.P.has_cda ? R_I32(c, o_cda_n_orders)[i] : 0;
+  A.no1 = c.P.has_cda ? R_I32(c, o_cda_n_orders)[n + i] : 0;
+  A.coin = R_F64(c, o_inv_coin)[i];
+  A.esc_coin = R_F64(c, o_esc_coin)[i];
+  A.labor = R_F64(c, o_labor)[i];
+}
+__device__ __forceinline__ void agents_store(const Ctx& c, const Agents& A) {
+  const int n = c.P.n, i = c.tid;
+  if (i < n) {
+    R_I32(c, o_loc_r)[i] = A.lr;
+    R_I32(c, o_loc_c)[i] = A.lc;
+    R_I32(c, o_inv_res)[i] = A.inv0;
+    R_I32(c, o_inv_res)[n + i] = A.inv1;
+    R_I32(c, o_esc_res)[i] = A.esc0;
+    R_I32(c, o_esc_res)[n + i] = A.esc1;
+    if (c.P.has_cda) {
+      R_I32(c, o_cda_n_orders)[i] = A.no0;
+      R_I32(c, o_cda_n_orders)[n + i] = A.no1;
+    }
+    R_F64(c, o_inv_coin)[i] = A.coin;
+    R_F64(c, o_esc_coin)[i] = A.esc_coin;
+    R_F64(c, o_labor)[i] = A.labor;
+  }
+}
+
+// parse_actions base_env.py:552-556 -> base_agent.py:407-438: lane i decodes agent i's
+// action into its packed per-subspace word; lane b decodes planner bracket b.
+__device__ __forceinline__ void decode_actions(const Ctx& c, Agents& A, const int32_t* __restrict__ aa,
+                               const int32_t* __restrict__ ap) {
+  const aie_params& P = c.P;
+  const int i = c.tid;
+  uint32_t act = 0;
+  if (i < P.n && aa) {
+    const int32_t* a = aa + ((int64_t)c.e * P.n + i) * P.act_a_width;
+    static const int shift[AIE_N_SUB_SLOTS] = {0, 4, 11, 18, 25, 1};
+    if (P.c.multi_action_mode_agents) {
+      for (int s = 0; s < P.n_sub_a; ++s) {
+        const int v = a[s];
+        if (v >= 0 && v <= P.sub_a_dim[s]) act |= (uint32_t)v << shift[P.sub_a_slot[s]];
+      }
+    } else {
+      const int v = a[0];
+      for (int s = 0; s < P.n_sub_a; ++s)
+        if (v >= P.sub_a_base[s] && v < P.sub_a_base[s] + P.sub_a_dim[s])
+          act |= (uint32_t)(v - P.sub_a_base[s] + 1) << shift[P.sub_a_slot[s]];
+    }
+  }
+  A.act = act;
+  if (i < AIE_MAX_BRACKETS) {
+    int v = 0;
+    if (ap && i < P.n_sub_p) {
+      const int32_t* a = ap + (int64_t)c.e * P.act_p_width;
+      if (P.c.multi_action_mode_planner) v = a[i];
+      else {
+        const int x = a[0];
+        if (x >= 1 && x < 1 + P.n_sub_p * P.sub_p_dim && (x - 1) / P.sub_p_dim == i) v = (x - 1) % P.sub_p_dim + 1;
+      }
+    }
+    c.act_p[i] = v;
   }
 }
 
 // ------------------------------------------------------------------------------------
-// Gather.component_step, F/components/move.py:93-153 (lane 0)
+// Build.component_step, F/components/build.py:112-161.  Wave-uniform control flow; the
+// builders are found with one ballot, so the common "nobody builds" step costs only the
+// permutation draw (which the reference consumes regardless, build.py:121).
 // ------------------------------------------------------------------------------------
-__device__ void gather_component_step(const Ctx& c) {
-  const int n = c.P.n, W = c.P.W;
-  int32_t* order = c.perm;
-  rng_permutation(c, n, order);
-  int32_t *lr = R_I32(c, o_loc_r), *lc = R_I32(c, o_loc_c);
+__device__ __forceinline__ void build_component_step(const Ctx& c, MT& m, Agents& A) {
+  const int n = c.P.n, lane = c.tid;
+  const int perm = rng_permutation(m, lane, n);
+  const uint64_t builders = __ballot(lane < n && AIE_ACT_BUILD(A.act));
+  if (builders == 0) return;
+  uint32_t* cells = R_CELLS(c);
   for (int k = 0; k < n; ++k) {
-    const int i = order[k];
-    const int a = c.act[i * AIE_N_SUB_SLOTS + AIE_SUB_GATHER];
-    const int r = lr[i], col = lc[i];
-    int nr = r, nc = col;
+    const int i = bcast(perm, k);
+    if (!((builders >> i) & 1ull)) continue;
+    // agent_can_build, build.py:70-83 (+ world.py:284-293)
+    const int cell = bcast(A.lr, i) * c.P.W + bcast(A.lc, i);
+    const uint32_t w = cells[cell];
+    const bool ok = bcast(A.inv0, i) >= 1 && bcast(A.inv1, i) >= 1 && (w & 0xffffu) == 0 &&
+                    ((w >> 16) & 0xffu) == 0xffu && (w >> 24) == 0;
+    if (!ok) continue;
+    if (lane == i) {
+      A.inv0 -= 1;
+      A.inv1 -= 1;
+      A.coin += R_F64(c, o_build_payment)[i];
+      A.labor += c.P.c.build_labor;
+    }
+    cells[cell] = (w & 0xff00ffffu) | ((uint32_t)i << 16);  // world.py:474-479 (every lane, same value)
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Gather.component_step, F/components/move.py:93-153 (wave-uniform control flow)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void gather_component_step(const Ctx& c, MT& m, Agents& A) {
+  const int n = c.P.n, W = c.P.W, H = c.P.H, lane = c.tid;
+  const int perm = rng_permutation(m, lane, n);
+  uint32_t* cells = R_CELLS(c);
+  for (int k = 0; k < n; ++k) {
+    const int i = bcast(perm, k);
+    const int a = (int)AIE_ACT_GATHER(bcast(A.act, i));
+    const int r = bcast(A.lr, i), col = bcast(A.lc, i);
+    int land = r * W + col;
     if (a != 0) {
-      if (a == 1) nc = col - 1;       // Left
-      else if (a == 2) nc = col + 1;  // Right
-      else if (a == 3) nr = r - 1;    // Up
-      else nr = r + 1;                // Down
-      if (can_agent_occupy(c, nr, nc, i)) {  // world.py:454-460
-        c.locmap[r * W + col] = 0;
-        c.locmap[nr * W + nc] = (uint8_t)(i + 1);
-        lr[i] = nr;
-        lc[i] = nc;
-        R_F64(c, o_labor)[i] += c.P.c.move_labor;
-      } else {
-        nr = r;
-        nc = col;
+      // 1 Left, 2 Right, 3 Up, 4 Down (move.py:116-123)
+      const int nr = r + (a == 3 ? -1 : a == 4 ? 1 : 0);
+      const int nc = col + (a == 1 ? -1 : a == 2 ? 1 : 0);
+      if (nr >= 0 && nr < H && nc >= 0 && nc < W) {
+        // World.can_agent_occupy, world.py:424-440
+        const int tcell = nr * W + nc;
+        const uint32_t tw = cells[tcell];
+        const int occ = c.locmap[tcell];
+        const int own = AIE_CELL_OWNER(tw);
+        if (!(AIE_CELL_FLAGS(tw) & AIE_CELL_WATER) && (own < 0 || own == i) && occ == 0) {
+          c.locmap[land] = 0;
+          c.locmap[tcell] = (uint8_t)(i + 1);
+          if (lane == i) {
+            A.lr = nr;
+            A.lc = nc;
+            A.labor += c.P.c.move_labor;
+          }
+          land = tcell;
+        }
       }
     }
     // collect on the landing tile, also on a NO-OP (move.py:112-113,136)
-    const int cell = nr * W + nc;
-    uint32_t w = R_CELLS(c)[cell];
-    const int health[2] = {(int)AIE_CELL_STONE(w), (int)AIE_CELL_WOOD(w)};
+    uint32_t w = cells[land];
+    if ((w & 0xffffu) != 0) {
+      const int health[2] = {(int)AIE_CELL_STONE(w), (int)AIE_CELL_WOOD(w)};
+      const double bonus = R_F64(c, o_bonus_gather_prob)[i];
 #pragma unroll
-    for (int rs = 0; rs < 2; ++rs) {
-      if (health[rs] >= 1) {
-        // rand() is consumed even when bonus_gather_prob == 0 (move.py:138)
-        const int got = 1 + (rng_double(c) < R_F64(c, o_bonus_gather_prob)[i] ? 1 : 0);
-        R_I32(c, o_inv_res)[rs * n + i] += got;
-        w -= (1u << (8 * rs));  // consume_resource, world.py:481-483
-        R_F64(c, o_labor)[i] += c.P.c.collect_labor;
+      for (int rs = 0; rs < 2; ++rs) {
+        if (health[rs] >= 1) {
+          // rand() is consumed even when bonus_gather_prob == 0 (move.py:138)
+          const int got = 1 + (rng_double(m, lane) < bonus ? 1 : 0);
+          if (lane == i) {
+            if (rs == 0) A.inv0 += got; else A.inv1 += got;
+            A.labor += c.P.c.collect_labor;
+          }
+          w -= (1u << (8 * rs));  // consume_resource, world.py:481-483
+        }
       }
+      cells[land] = w;
     }
-    R_CELLS(c)[cell] = w;
   }
 }
 
@@ -316,169 +554,210 @@ __device__ void gather_component_step(const Ctx& c) {
 // ContinuousDoubleAuction, F/components/continuous_double_auction.py
 // ------------------------------------------------------------------------------------
 // price_history *= 0.995 for every (commodity, agent, price) -- :451, all lanes
-__device__ void cda_decay_price_history(const Ctx& c) {
+__device__ __forceinline__ void cda_decay_price_history(const Ctx& c) {
   double* ph = R_F64(c, o_cda_price_history);
   const int tot = 2 * c.P.n * c.P.P;
   for (int q = c.tid; q < tot; q += AIE_NT) ph[q] *= 0.995;
 }
 
-// create_bid :168-198 / create_ask :200-229 (lane 0)
-__device__ void cda_create_bid(const Ctx& c, int r, int i, int price) {
-  const int n = c.P.n;
-  int32_t* no = R_I32(c, o_cda_n_orders) + r * n;
-  if (!(no[i] < c.P.c.cda_max_num_orders) || R_F64(c, o_inv_coin)[i] < (double)price) return;
-  int32_t* nb = R_I32(c, o_cda_n_bids) + r;
-  R_I32(c, o_cda_bids)[r * c.P.M + *nb] = AIE_ORD_PACK(i, price, 0);
-  *nb += 1;
-  R_U8(c, o_cda_bid_hist)[(r * n + i) * c.P.P + price] += 1;
-  no[i] += 1;
-  const double inv = R_F64(c, o_inv_coin)[i];
-  const double tr = inv < (double)price ? inv : (double)price;  // base_agent.py:279-299
-  R_F64(c, o_inv_coin)[i] -= tr;
-  R_F64(c, o_esc_coin)[i] += tr;
-  R_F64(c, o_labor)[i] += c.P.c.cda_order_labor;
-}
-__device__ void cda_create_ask(const Ctx& c, int r, int i, int price) {
-  const int n = c.P.n;
-  int32_t* no = R_I32(c, o_cda_n_orders) + r * n;
-  int32_t* inv = R_I32(c, o_inv_res) + r * n;
-  if (!(no[i] < c.P.c.cda_max_num_orders && inv[i] > 0)) return;
-  int32_t* na = R_I32(c, o_cda_n_asks) + r;
-  R_I32(c, o_cda_asks)[r * c.P.M + *na] = AIE_ORD_PACK(i, price, 0);
-  *na += 1;
-  R_U8(c, o_cda_ask_hist)[(r * n + i) * c.P.P + price] += 1;
-  no[i] += 1;
-  inv[i] -= 1;
-  R_I32(c, o_esc_res)[r * n + i] += 1;
-  R_F64(c, o_labor)[i] += c.P.c.cda_order_labor;
-}
-
 // Sort keys: bids by (price desc, lifetime desc, book position asc), asks by
 // (price asc, lifetime desc, book position asc) == Python's stable sorted() at :249-256.
-__device__ __forceinline__ bool bid_before(int32_t a, int32_t b) {
-  const int pa = AIE_ORD_PRICE(a), pb = AIE_ORD_PRICE(b);
-  if (pa != pb) return pa > pb;
-  return AIE_ORD_LIFE(a) > AIE_ORD_LIFE(b);
-}
-__device__ __forceinline__ bool ask_before(int32_t a, int32_t b) {
-  const int pa = AIE_ORD_PRICE(a), pb = AIE_ORD_PRICE(b);
-  if (pa != pb) return pa < pb;
-  return AIE_ORD_LIFE(a) > AIE_ORD_LIFE(b);
-}
 template <bool BIDS>
-__device__ void book_insertion_sort(int32_t* v, int n) {
-  for (int i = 1; i < n; ++i) {
-    const int32_t x = v[i];
-    int j = i - 1;
-    while (j >= 0 && (BIDS ? bid_before(x, v[j]) : ask_before(x, v[j]))) {
-      v[j + 1] = v[j];
-      --j;
-    }
-    v[j + 1] = x;
-  }
+__device__ __forceinline__ bool order_before(int32_t a, int32_t b) {
+  const int pa = AIE_ORD_PRICE(a), pb = AIE_ORD_PRICE(b);
+  if (pa != pb) return BIDS ? pa > pb : pa < pb;
+  return AIE_ORD_LIFE(a) > AIE_ORD_LIFE(b);
 }
 
-// match_orders :231-350 (lane 0): best remaining bid of a not-yet-flagged buyer against
-// the best ask of another agent; trade at the older order's price; restart.
-__device__ void cda_match_orders(const Ctx& c) {
-  const int n = c.P.n, M = c.P.M, P = c.P.P;
+// Inserts v[q] into the sorted prefix v[0..q): one ballot per 64 slots finds the
+// insertion point, one lane shift per 64 slots makes room (high slices first).
+template <bool BIDS>
+__device__ __forceinline__ void book_insert(int32_t* v, int q, int lane) {
+  const int32_t x = v[q];
+  int p = 0;
+  for (int base = 0; base < q; base += AIE_NT) {
+    const int idx = base + lane;
+    const bool stays = idx < q && !order_before<BIDS>(x, v[idx < q ? idx : 0]);
+    p += __popcll(__ballot(stays));
+  }
+  if (p == q) return;
+  for (int base = ((q - 1) / AIE_NT) * AIE_NT; base >= 0; base -= AIE_NT) {
+    const int idx = base + lane;
+    const bool mv = idx >= p && idx < q;
+    const int32_t t = mv ? v[idx] : 0;
+    if (mv) v[idx + 1] = t;
+  }
+  v[p] = x;
+}
+// Removes slot `at` from v[0..len): lane shift towards the front, low slices first.
+__device__ __forceinline__ void book_remove(int32_t* v, int len, int at, int lane) {
+  for (int base = (at / AIE_NT) * AIE_NT; base < len; base += AIE_NT) {
+    const int idx = base + lane;
+    const bool mv = idx > at && idx < len;
+    const int32_t t = mv ? v[idx] : 0;
+    if (mv) v[idx - 1] = t;
+  }
+}
+// First slot of v[0..len) whose order satisfies pred (wave ballot + find-first-set).
+template <typename Pred>
+__device__ __forceinline__ int book_find_first(const int32_t* v, int len, int lane, Pred pred) {
+  for (int base = 0; base < len; base += AIE_NT) {
+    const int idx = base + lane;
+    const uint64_t hit = __ballot(idx < len && pred(v[idx < len ? idx : 0]));
+    if (hit) return base + __ffsll((unsigned long long)hit) - 1;
+  }
+  return -1;
+}
+
+// ContinuousDoubleAuction.component_step :440-489 (decay of :451 already applied)
+__device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
+  const int n = c.P.n, M = c.P.M, P = c.P.P, lane = c.tid;
+  const int maxo = c.P.c.cda_max_num_orders, dur = c.P.c.cda_order_duration;
+  uint8_t* bid_hist = R_U8(c, o_cda_bid_hist);
+  uint8_t* ask_hist = R_U8(c, o_cda_ask_hist);
+  int nb[2] = {uni(R_I32(c, o_cda_n_bids)[0]), uni(R_I32(c, o_cda_n_bids)[1])};
+  int na[2] = {uni(R_I32(c, o_cda_n_asks)[0]), uni(R_I32(c, o_cda_n_asks)[1])};
+  const int nb0[2] = {nb[0], nb[1]}, na0[2] = {na[0], na[1]};
+
+  // ---- create_bid :168-198 / create_ask :200-229, commodity-major, agents in index order
+#pragma unroll
   for (int r = 0; r < AIE_N_RES; ++r) {
     int32_t* bids = R_I32(c, o_cda_bids) + r * M;
     int32_t* asks = R_I32(c, o_cda_asks) + r * M;
-    int nb = R_I32(c, o_cda_n_bids)[r], na = R_I32(c, o_cda_n_asks)[r];
-    book_insertion_sort<true>(bids, nb);
-    book_insertion_sort<false>(asks, na);
+    const uint32_t buy = AIE_ACT_BUY(A.act, r), sell = AIE_ACT_SELL(A.act, r);
+    const uint64_t mb = __ballot(lane < n && buy > 0), ms = __ballot(lane < n && sell > 0);
+    uint64_t mm = mb | ms;
+    while (mm) {
+      const int i = __ffsll((unsigned long long)mm) - 1;
+      mm &= mm - 1;
+      const int no = bcast(r ? A.no1 : A.no0, i);
+      if ((mb >> i) & 1ull) {
+        const int price = (int)bcast(buy, i) - 1;
+        if (no < maxo && !(bcast(A.coin, i) < (double)price)) {
+          bids[nb[r]] = AIE_ORD_PACK(i, price, 0);
+          nb[r] += 1;
+          bid_hist[(r * n + i) * P + price] += 1;
+          if (lane == i) {
+            if (r) A.no1 += 1; else A.no0 += 1;
+            const double tr = A.coin < (double)price ? A.coin : (double)price;  // base_agent.py:279-299
+            A.coin -= tr;
+            A.esc_coin += tr;
+            A.labor += c.P.c.cda_order_labor;
+          }
+        }
+      }
+      if ((ms >> i) & 1ull) {
+        const int price = (int)bcast(sell, i) - 1;
+        const int no2 = bcast(r ? A.no1 : A.no0, i);
+        if (no2 < maxo && bcast(r ? A.inv1 : A.inv0, i) > 0) {
+          asks[na[r]] = AIE_ORD_PACK(i, price, 0);
+          na[r] += 1;
+          ask_hist[(r * n + i) * P + price] += 1;
+          if (lane == i) {
+            if (r) { A.no1 += 1; A.inv1 -= 1; A.esc1 += 1; }
+            else { A.no0 += 1; A.inv0 -= 1; A.esc0 += 1; }
+            A.labor += c.P.c.cda_order_labor;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- match_orders :231-350
+#pragma unroll
+  for (int r = 0; r < AIE_N_RES; ++r) {
+    int32_t* bids = R_I32(c, o_cda_bids) + r * M;
+    int32_t* asks = R_I32(c, o_cda_asks) + r * M;
+    // the book is kept sorted; only this step's new orders (appended) need inserting
+    // Without a new order nothing can match: last step's loop ended with every buyer's
+    // best bid below the cheapest ask of another agent, and expiry only removes orders.
+    if (nb[r] == nb0[r] && na[r] == na0[r]) continue;
+    for (int q = nb0[r]; q < nb[r]; ++q) book_insert<true>(bids, q, lane);
+    for (int q = na0[r]; q < na[r]; ++q) book_insert<false>(asks, q, lane);
+    if (nb[r] == 0 || na[r] == 0) continue;
     uint64_t possible = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    bool keep_checking = true;
-    while (possible != 0 && keep_checking) {
-      int ib = 0, ia = 0;
-      for (;;) {
-        if (ib >= nb) { keep_checking = false; break; }
-        const int buyer = AIE_ORD_AGENT(bids[ib]);
-        if (!((possible >> buyer) & 1ull)) { ib++; continue; }
-        if (ia >= na) { possible &= ~(1ull << buyer); break; }
-        if (AIE_ORD_AGENT(asks[ia]) == buyer) { ia++; continue; }
-        if (AIE_ORD_PRICE(bids[ib]) < AIE_ORD_PRICE(asks[ia])) { possible &= ~(1ull << buyer); break; }
-        // TRADE
-        const int32_t bid = bids[ib], ask = asks[ia];
-        for (int k = ib; k + 1 < nb; ++k) bids[k] = bids[k + 1];
-        nb--;
-        for (int k = ia; k + 1 < na; ++k) asks[k] = asks[k + 1];
-        na--;
-        const int seller = AIE_ORD_AGENT(ask);
-        const int bprice = AIE_ORD_PRICE(bid), aprice = AIE_ORD_PRICE(ask);
-        const int price = (AIE_ORD_LIFE(bid) <= AIE_ORD_LIFE(ask)) ? aprice : bprice;  // :297-304
-        R_U8(c, o_cda_bid_hist)[(r * n + buyer) * P + bprice] -= 1;
-        R_U8(c, o_cda_ask_hist)[(r * n + seller) * P + aprice] -= 1;
-        R_I32(c, o_cda_n_orders)[r * n + seller] -= 1;
-        R_I32(c, o_cda_n_orders)[r * n + buyer] -= 1;
-        R_F64(c, o_cda_price_history)[(r * n + seller) * P + price] += 1.0;
-        R_I32(c, o_esc_res)[r * n + seller] -= 1;
-        R_I32(c, o_inv_res)[r * n + buyer] += 1;
-        R_F64(c, o_esc_coin)[buyer] -= (double)bprice;
-        R_F64(c, o_inv_coin)[seller] += (double)price;
-        R_F64(c, o_inv_coin)[buyer] += (double)(bprice - price);
-        break;
+    while (possible) {
+      const uint64_t poss = possible;
+      const int ib = book_find_first(bids, nb[r], lane, [poss](int32_t o) { return ((poss >> AIE_ORD_AGENT(o)) & 1ull) != 0; });
+      if (ib < 0) break;  // out of bids to check (:262-264)
+      const int32_t bid = uni(bids[ib]);
+      const int buyer = AIE_ORD_AGENT(bid), bprice = AIE_ORD_PRICE(bid);
+      const int ia = book_find_first(asks, na[r], lane, [buyer](int32_t o) { return AIE_ORD_AGENT(o) != buyer; });
+      int32_t ask = 0;
+      if (ia >= 0) ask = uni(asks[ia]);
+      if (ia < 0 || bprice < AIE_ORD_PRICE(ask)) {  // :273-286
+        possible &= ~(1ull << buyer);
+        continue;
+      }
+      // TRADE :289-346
+      book_remove(bids, nb[r], ib, lane);
+      nb[r] -= 1;
+      book_remove(asks, na[r], ia, lane);
+      na[r] -= 1;
+      const int seller = AIE_ORD_AGENT(ask), aprice = AIE_ORD_PRICE(ask);
+      const int price = (AIE_ORD_LIFE(bid) <= AIE_ORD_LIFE(ask)) ? aprice : bprice;  // :297-304
+      bid_hist[(r * n + buyer) * P + bprice] -= 1;
+      ask_hist[(r * n + seller) * P + aprice] -= 1;
+      R_F64(c, o_cda_price_history)[(r * n + seller) * P + price] += 1.0;
+      if (lane == seller) {
+        if (r) { A.no1 -= 1; A.esc1 -= 1; } else { A.no0 -= 1; A.esc0 -= 1; }
+        A.coin += (double)price;
+      }
+      if (lane == buyer) {
+        if (r) { A.no1 -= 1; A.inv1 += 1; } else { A.no0 -= 1; A.inv0 += 1; }
+        A.esc_coin -= (double)bprice;
+        A.coin += (double)(bprice - price);
       }
     }
-    R_I32(c, o_cda_n_bids)[r] = nb;
-    R_I32(c, o_cda_n_asks)[r] = na;
   }
-}
 
-// remove_expired_orders :352-406 (lane 0)
-__device__ void cda_remove_expired(const Ctx& c) {
-  const int n = c.P.n, M = c.P.M, P = c.P.P, dur = c.P.c.cda_order_duration;
+  // ---- remove_expired_orders :352-406: lifetime += 1 everywhere, compaction by ballot
+#pragma unroll
   for (int r = 0; r < AIE_N_RES; ++r) {
-    int32_t* bids = R_I32(c, o_cda_bids) + r * M;
-    const int nb = R_I32(c, o_cda_n_bids)[r];
-    int k = 0;
-    for (int q = 0; q < nb; ++q) {
-      const int32_t o = bids[q];
-      const int life = AIE_ORD_LIFE(o) + 1, ag = AIE_ORD_AGENT(o), pr = AIE_ORD_PRICE(o);
-      if (life <= dur) bids[k++] = AIE_ORD_PACK(ag, pr, life);
-      else {
-        const double esc = R_F64(c, o_esc_coin)[ag];
-        const double tr = esc < (double)pr ? esc : (double)pr;
-        R_F64(c, o_esc_coin)[ag] -= tr;
-        R_F64(c, o_inv_coin)[ag] += tr;
-        R_U8(c, o_cda_bid_hist)[(r * n + ag) * P + pr] -= 1;
-        R_I32(c, o_cda_n_orders)[r * n + ag] -= 1;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      int32_t* v = (side == 0 ? R_I32(c, o_cda_bids) : R_I32(c, o_cda_asks)) + r * M;
+      const int len = side == 0 ? nb[r] : na[r];
+      int kept = 0;
+      for (int base = 0; base < len; base += AIE_NT) {
+        const int idx = base + lane;
+        const bool valid = idx < len;
+        const int32_t o = valid ? v[idx] : 0;
+        const int life = AIE_ORD_LIFE(o) + 1;
+        const bool keep = valid && life <= dur;
+        const uint64_t km = __ballot(keep);
+        uint64_t em = __ballot(valid && !keep);
+        if (keep) v[kept + __popcll(km & lanemask_lt(lane))] = AIE_ORD_PACK(AIE_ORD_AGENT(o), AIE_ORD_PRICE(o), life);
+        kept += __popcll(km);
+        while (em) {  // expiries are rare: handled one by one, in book order
+          const int q = __ffsll((unsigned long long)em) - 1;
+          em &= em - 1;
+          const int32_t eo = bcast(o, q);
+          const int ag = AIE_ORD_AGENT(eo), pr = AIE_ORD_PRICE(eo);
+          if (side == 0) {
+            bid_hist[(r * n + ag) * P + pr] -= 1;
+            if (lane == ag) {
+              const double tr = A.esc_coin < (double)pr ? A.esc_coin : (double)pr;  // escrow_to_inventory
+              A.esc_coin -= tr;
+              A.coin += tr;
+              if (r) A.no1 -= 1; else A.no0 -= 1;
+            }
+          } else {
+            ask_hist[(r * n + ag) * P + pr] -= 1;
+            if (lane == ag) {
+              if (r) { A.esc1 -= 1; A.inv1 += 1; A.no1 -= 1; }
+              else { A.esc0 -= 1; A.inv0 += 1; A.no0 -= 1; }
+            }
+          }
+        }
       }
-    }
-    R_I32(c, o_cda_n_bids)[r] = k;
-    int32_t* asks = R_I32(c, o_cda_asks) + r * M;
-    const int na = R_I32(c, o_cda_n_asks)[r];
-    k = 0;
-    for (int q = 0; q < na; ++q) {
-      const int32_t o = asks[q];
-      const int life = AIE_ORD_LIFE(o) + 1, ag = AIE_ORD_AGENT(o), pr = AIE_ORD_PRICE(o);
-      if (life <= dur) asks[k++] = AIE_ORD_PACK(ag, pr, life);
-      else {
-        R_I32(c, o_esc_res)[r * n + ag] -= 1;
-        R_I32(c, o_inv_res)[r * n + ag] += 1;
-        R_U8(c, o_cda_ask_hist)[(r * n + ag) * P + pr] -= 1;
-        R_I32(c, o_cda_n_orders)[r * n + ag] -= 1;
-      }
-    }
-    R_I32(c, o_cda_n_asks)[r] = k;
-  }
-}
-
-// ContinuousDoubleAuction.component_step :440-489, sequential part (lane 0); the
-// price-history decay of :451 has already been applied by all lanes.
-__device__ void cda_component_step(const Ctx& c) {
-  const int n = c.P.n;
-  for (int r = 0; r < AIE_N_RES; ++r) {
-    for (int i = 0; i < n; ++i) {
-      int a = c.act[i * AIE_N_SUB_SLOTS + (r ? AIE_SUB_BUY1 : AIE_SUB_BUY0)];
-      if (a > 0) cda_create_bid(c, r, i, a - 1);
-      a = c.act[i * AIE_N_SUB_SLOTS + (r ? AIE_SUB_SELL1 : AIE_SUB_SELL0)];
-      if (a > 0) cda_create_ask(c, r, i, a - 1);
+      if (side == 0) nb[r] = kept; else na[r] = kept;
     }
   }
-  cda_match_orders(c);
-  cda_remove_expired(c);
+  R_I32(c, o_cda_n_bids)[0] = nb[0];
+  R_I32(c, o_cda_n_bids)[1] = nb[1];
+  R_I32(c, o_cda_n_asks)[0] = na[0];
+  R_I32(c, o_cda_n_asks)[1] = na[1];
 }
 
 // ------------------------------------------------------------------------------------
@@ -488,7 +767,7 @@ __device__ __forceinline__ double tax_rate(const Ctx& c, int b) {  // curr_margi
   if (c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER) return c.P.c.tax_disc_rates[R_I32(c, o_tax_rate_idx)[b]];
   return c.P.c.tax_fixed_rates[b];
 }
-__device__ double tax_marginal_rate(const Ctx& c, double income) {  // marginal_rate :837-844
+__device__ __forceinline__ double tax_marginal_rate(const Ctx& c, double income) {  // marginal_rate :837-844
   if (income < 0) return 0.0;
   const int NB = c.P.NB;
   for (int b = 0; b < NB; ++b) {
@@ -506,7 +785,7 @@ __device__ __forceinline__ double tax_bin(const Ctx& c, double income, int b) {
   if (past < 0) past = 0;
   return tax_rate(c, b) * (size < past ? size : past);
 }
-__device__ double tax_due(const Ctx& c, double income) {  // taxes_due :846-851
+__device__ __forceinline__ double tax_due(const Ctx& c, double income) {  // taxes_due :846-851
   const int NB = c.P.NB;
   // np.sum of NB values (pairwise summation, loops_utils.h.src)
   if (NB < 8) {
@@ -528,100 +807,165 @@ __device__ double tax_due(const Ctx& c, double income) {  // taxes_due :846-851
   for (; b < NB; ++b) res += tax_bin(c, income, b);
   return res;
 }
-__device__ void tax_enact(const Ctx& c) {  // enact_taxes :853-915 (lane 0)
-  const int n = c.P.n;
-  double net = 0;
-  for (int i = 0; i < n; ++i) {
-    const double income = (R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i]) - R_F64(c, o_tax_last_coin)[i];
+// enact_taxes :853-915: lane i computes agent i's income / tax; the revenue is summed
+// in agent order (the reference's running `net_tax_revenue +=`).
+__device__ __forceinline__ void tax_enact(const Ctx& c, Agents& A) {
+  const int n = c.P.n, i = c.tid;
+  double eff = 0;
+  if (i < n) {
+    const double income = (A.coin + A.esc_coin) - R_F64(c, o_tax_last_coin)[i];
     const double due = tax_due(c, income);
-    const double inv = R_F64(c, o_inv_coin)[i];
-    const double eff = inv < due ? inv : due;  // escrow is not taxed
+    eff = A.coin < due ? A.coin : due;  // escrow is not taxed
     R_F64(c, o_tax_last_marginal_rate)[i] = tax_marginal_rate(c, income);
-    R_F64(c, o_inv_coin)[i] = inv - eff;
-    net += eff;
     R_F64(c, o_tax_last_income)[i] = income;
+    A.coin -= eff;
   }
+  double net = 0;
+  for (int j = 0; j < n; ++j) net += bcast(eff, j);
   *R_F64(c, o_tax_total_collected) += net;
   const double lump = net / (double)n;
-  for (int i = 0; i < n; ++i) {
-    const double v = R_F64(c, o_inv_coin)[i] + lump;
-    R_F64(c, o_inv_coin)[i] = v;
-    R_F64(c, o_tax_last_coin)[i] = v + R_F64(c, o_esc_coin)[i];
+  if (i < n) {
+    A.coin += lump;
+    R_F64(c, o_tax_last_coin)[i] = A.coin + A.esc_coin;
   }
 }
-// component_step :945-972 + set_new_period_rates_model :419-434 (lane 0)
-__device__ void tax_component_step(const Ctx& c) {
-  int32_t* pos = R_I32(c, o_tax_cycle_pos);
-  if (*pos == 1 && c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER && !c.P.c.tax_disable) {
-    for (int b = 0; b < c.P.NB; ++b) {
-      const int a = c.act_p[b];
-      if (a > 0 && a <= c.P.c.tax_n_disc_rates) R_I32(c, o_tax_rate_idx)[b] = a - 1;
+// component_step :945-972 + set_new_period_rates_model :419-434
+__device__ __forceinline__ void tax_component_step(const Ctx& c, Agents& A) {
+  int pos = uni(*R_I32(c, o_tax_cycle_pos));
+  if (pos == 1 && c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER && !c.P.c.tax_disable) {
+    if (c.tid < c.P.NB) {
+      const int a = c.act_p[c.tid];
+      if (a > 0 && a <= c.P.c.tax_n_disc_rates) R_I32(c, o_tax_rate_idx)[c.tid] = a - 1;
     }
+    __syncthreads();
   }
-  if (*pos >= c.P.c.tax_period) {
-    tax_enact(c);
-    *pos = 0;
+  if (pos >= c.P.c.tax_period) {
+    tax_enact(c, A);
+    pos = 0;
   }
-  *pos += 1;
+  *R_I32(c, o_tax_cycle_pos) = pos + 1;
 }
 
 // ------------------------------------------------------------------------------------
-// LayoutFromFile.scenario_step, layout_from_file.py:372-410 (all lanes)
+// LayoutFromFile.scenario_step, layout_from_file.py:372-410.
 // regen_halfwidth == 0: p = regen_weight * max(map, src); only source blocks spawn.
-// np.random.rand(H, W) is consumed for Wood, then for Stone: 2*H*W doubles = 4*H*W
-// MT19937 words per step, produced 64 doubles at a time by the whole wave.
+// np.random.rand(H, W) is consumed for Wood, then for Stone: 4*H*W MT19937 words per
+// step, read row by row straight from the state registers (pairs of adjacent lanes
+// form one 53-bit double); a double that straddles a twist is carried over.
 // ------------------------------------------------------------------------------------
-__device__ void scenario_step_regen(const Ctx& c) {
-  uint32_t* mt = reinterpret_cast<uint32_t*>(c.rec + c.P.o_mt);
-  uint32_t* cells = R_CELLS(c);
-  int pos = *R_I32(c, o_mt_pos);  // wave-uniform
+__device__ __forceinline__ void regen_cell(const Ctx& c, uint32_t ta, uint32_t tb, int d) {
   const int HW = c.P.HW;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int rs = pass == 0 ? 1 : 0;  // ["Wood", "Stone"]
-    const uint32_t srcbit = (rs ? AIE_CELL_WOOD_SRC : AIE_CELL_STONE_SRC) << 24;
-    const double w = c.P.c.regen_weight[rs];
-    const uint32_t mh = (uint32_t)c.P.c.max_health[rs];
-    for (int base = 0; base < HW; base += AIE_NT) {
-      const int cnt = (HW - base) < AIE_NT ? (HW - base) : AIE_NT;
-      const int need = 2 * cnt;
-      const bool active = c.tid < cnt;
-      const int qa = 2 * c.tid, qb = qa + 1;
-      uint32_t a = 0, b = 0;
-      if (pos + need <= AIE_MT_N) {
-        if (active) { a = mt[pos + qa]; b = mt[pos + qb]; }
-        pos += need;
-      } else {
-        const int rem = AIE_MT_N - pos;
-        if (active && qa < rem) a = mt[pos + qa];
-        if (active && qb < rem) b = mt[pos + qb];
-        __syncthreads();
-        mt_twist_wave(c);
-        if (active && qa >= rem) a = mt[qa - rem];
-        if (active && qb >= rem) b = mt[qb - rem];
-        pos = need - rem;
-      }
-      if (active) {
-        const double u = u53(mt_temper(a), mt_temper(b));
-        const int cell = base + c.tid;
-        uint32_t cw = cells[cell];
-        const uint32_t m = (cw >> (8 * rs)) & 0xffu;
-        const uint32_t src = (cw & srcbit) ? 1u : 0u;
-        const uint32_t health = m > src ? m : src;
-        const uint32_t respawn = (src && (u < w * (double)health)) ? 1u : 0u;
-        uint32_t v = m + respawn;
-        v = v < mh ? v : mh;
-        cells[cell] = (cw & ~(0xffu << (8 * rs))) | (v << (8 * rs));
+  const int rs = d >= HW ? 0 : 1;  // first H*W doubles are Wood's, then Stone's
+  const int cell = d - (d >= HW ? HW : 0);
+  uint8_t* cb = reinterpret_cast<uint8_t*>(R_CELLS(c)) + 4 * cell;
+  const uint32_t fl = cb[3];
+  if (fl & (rs ? AIE_CELL_WOOD_SRC : AIE_CELL_STONE_SRC)) {
+    const uint32_t mval = cb[rs];
+    const uint32_t health = mval > 1u ? mval : 1u;  // max(map, source block = 1)
+    const double u = u53(ta, tb);
+    if (u < c.P.c.regen_weight[rs] * (double)health && mval < (uint32_t)c.P.c.max_health[rs]) cb[rs] = (uint8_t)(mval + 1);
+  }
+}
+__device__ __forceinline__ void scenario_step_regen_rows(const Ctx& c, MT& m) {
+  const int lane = c.tid;
+  const int total = 4 * c.P.HW;  // words to consume
+  int done = 0;
+  bool carry = false;
+  uint32_t carry_t = 0;
+  int carry_d = 0;
+  while (true) {
+    if (m.pos >= AIE_MT_N) {
+      mt_twist(m, lane);
+      m.pos = 0;
+    }
+    const int pos = m.pos;
+    if (carry) {  // second half of a double whose first word was word 623 of the old state
+      if (lane == 0) regen_cell(c, carry_t, mt_temper(m.r[0]), carry_d);
+      carry = false;
+    }
+#pragma unroll
+    for (int J = 0; J < 10; ++J) {
+      if (64 * J + 63 < pos) continue;              // row fully consumed already
+      if (done + (64 * J - pos) >= total) continue;  // row entirely beyond this step's needs
+      const int a_idx = 64 * J + lane;
+      const int q = done + (a_idx - pos);           // regen-relative word number
+      const uint32_t t = mt_temper(m.r[J]);
+      uint32_t tn = lane_get(t, (lane + 1) & 63);
+      if (J < 9) tn = (lane == 63) ? mt_temper(bcast(m.r[J + 1], 0)) : tn;
+      const bool first = a_idx >= pos && a_idx < AIE_MT_N - 1 && (q & 1) == 0 && q < total;
+      if (first) regen_cell(c, t, tn, q >> 1);
+    }
+    const int avail = AIE_MT_N - pos;
+    const int take = (total - done) < avail ? (total - done) : avail;
+    if (take == avail) {  // consumed word 623: is it the first half of a double?
+      const int q623 = done + (AIE_MT_N - 1 - pos);
+      if ((q623 & 1) == 0 && q623 < total) {
+        carry = true;
+        carry_t = mt_temper(bcast(m.r[9], 47));
+        carry_d = q623 >> 1;
       }
     }
+    done += take;
+    m.pos = pos + take;
+    if (done >= total) break;
   }
-  __syncthreads();
-  if (c.tid == 0) *R_I32(c, o_mt_pos) = pos;
+}
+
+// Sparse variant (the normal case: a few dozen source blocks): lane j owns source double
+// d_j and needs stream words pos+2*d_j, +1.  The state is advanced window by window (one
+// twist each); in every window the 624 raw words are dumped to LDS and each lane picks the
+// word(s) that fall into it.  ~800 instructions per step instead of ~2200.
+__device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
+  const int S = uni(*c.srcn);
+  if (S > AIE_SRC_CAP) {
+    scenario_step_regen_rows(c, m);
+    return;
+  }
+  const int lane = c.tid;
+  const int total = 4 * c.P.HW;
+  uint32_t* buf = reinterpret_cast<uint32_t*>(c.stage);
+  const int pos0 = m.pos;  // <= 624
+  const int nchunk = (S + AIE_NT - 1) / AIE_NT;
+  int off_a[AIE_SRC_CAP / AIE_NT];
+  uint32_t wa[AIE_SRC_CAP / AIE_NT], wb[AIE_SRC_CAP / AIE_NT];
+#pragma unroll
+  for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
+    const int j = k * AIE_NT + lane;
+    off_a[k] = (k < nchunk && j < S) ? pos0 + 2 * (int)c.srcl[j] : -16;  // stream offset of word A
+    wa[k] = wb[k] = 0;
+  }
+  const int last_win = (pos0 + total - 1) / AIE_MT_N;
+  for (int w = 0; w <= last_win; ++w) {
+    if (w > 0) mt_twist(m, lane);
+    const int lo = w * AIE_MT_N;
+    bool need = false;
+#pragma unroll
+    for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k)
+      need |= (off_a[k] + 1 >= lo) && (off_a[k] < lo + AIE_MT_N);
+    if (__ballot(need) == 0) continue;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 9; ++j) buf[64 * j + lane] = m.r[j];
+    if (lane < 48) buf[576 + lane] = m.r[9];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
+      const int ia = off_a[k] - lo, ib = ia + 1;
+      if (ia >= 0 && ia < AIE_MT_N) wa[k] = buf[ia];
+      if (off_a[k] >= 0 && ib >= 0 && ib < AIE_MT_N) wb[k] = buf[ib];
+    }
+  }
+  m.pos = pos0 + total - last_win * AIE_MT_N;
+#pragma unroll
+  for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k)
+    if (off_a[k] >= 0) regen_cell(c, mt_temper(wa[k]), mt_temper(wb[k]), (off_a[k] - pos0) >> 1);
+  __syncthreads();  // the dump area is the observation staging area
 }
 
 // ------------------------------------------------------------------------------------
 // Utilities / rewards
 // ------------------------------------------------------------------------------------
-__device__ double energy_weight(const Ctx& c) {  // layout_from_file.py:249-267
+__device__ __forceinline__ double energy_weight(const Ctx& c) {  // layout_from_file.py:249-267
   if (c.P.c.energy_warmup_constant <= 0.0) return 1.0;
   const int v = c.P.c.energy_warmup_method == AIE_WARMUP_DECAY ? *R_I32(c, o_completions) : *R_I32(c, o_auto_warmup);
   return 1.0 - exp(-(double)v / c.P.c.energy_warmup_constant);
@@ -633,7 +977,7 @@ __device__ double energy_weight(const Ctx& c) {  // layout_from_file.py:249-267
 // social_metrics.get_gini (social_metrics.py:10-46).
 // Lane i < n computes agent i's utility; lane 0 finishes the planner's.
 // Results are left in scr_part()[0..n]; must be followed by __syncthreads().
-__device__ void current_metrics(const Ctx& c) {
+__device__ __forceinline__ void current_metrics(const Ctx& c) {
   const int n = c.P.n, i = c.tid;
   double* coin = scr_coin(c);
   double* out = scr_part(c);
@@ -699,7 +1043,7 @@ __device__ void current_metrics(const Ctx& c) {
 }
 
 // compute_reward layout_from_file.py:519-559
-__device__ void compute_rewards(const Ctx& c, uint8_t* __restrict__ arena) {
+__device__ __forceinline__ void compute_rewards(const Ctx& c, uint8_t* __restrict__ arena) {
   const int n = c.P.n, i = c.tid;
   current_metrics(c);
   __syncthreads();
@@ -722,52 +1066,55 @@ __device__ void compute_rewards(const Ctx& c, uint8_t* __restrict__ arena) {
 // ------------------------------------------------------------------------------------
 // Observations
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ float chan_value(uint32_t w, int k, bool has_water) {
-  // channel order of Maps.state (world.py:59-93): Stone, Wood, House, [Water],
-  // StoneSourceBlock, WoodSourceBlock
-  switch (k) {
-    case 0: return (float)AIE_CELL_STONE(w);
-    case 1: return (float)AIE_CELL_WOOD(w);
-    case 2: return (((w >> 16) & 0xffu) != 0xffu) ? 1.0f : 0.0f;
-    default: break;
-  }
+// Channels of Maps.state (world.py:59-93): Stone, Wood, House, [Water], StoneSourceBlock,
+// WoodSourceBlock.  `ch[]` receives CM values for one packed cell word.
+template <bool WATER>
+__device__ __forceinline__ void cell_channels(uint32_t w, float* ch) {
   const uint32_t fl = w >> 24;
-  if (has_water) {
-    if (k == 3) return (fl & AIE_CELL_WATER) ? 1.0f : 0.0f;
-    k -= 1;
-  }
-  return (fl & (k == 3 ? AIE_CELL_STONE_SRC : AIE_CELL_WOOD_SRC)) ? 1.0f : 0.0f;
+  ch[0] = (float)AIE_CELL_STONE(w);
+  ch[1] = (float)AIE_CELL_WOOD(w);
+  ch[2] = (((w >> 16) & 0xffu) != 0xffu) ? 1.0f : 0.0f;
+  int k = 3;
+  if (WATER) ch[k++] = (fl & AIE_CELL_WATER) ? 1.0f : 0.0f;
+  ch[k++] = (fl & AIE_CELL_STONE_SRC) ? 1.0f : 0.0f;
+  ch[k++] = (fl & AIE_CELL_WOOD_SRC) ? 1.0f : 0.0f;
 }
 
 // LayoutFromFile.generate_observations layout_from_file.py:412-517: the egocentric
-// (2w+1)^2 crop for every agent and the full map for the planner.  One lane per
-// (agent, window cell): one LDS word read, CM+1 coalesced f32 stores, 2 i16 stores.
-__device__ void write_spatial_observations(const Ctx& c, uint8_t* __restrict__ arena) {
-  const int n = c.P.n, H = c.P.H, W = c.P.W, HW = c.P.HW, WV = c.P.WV, CM = c.P.CM;
+// (2w+1)^2 crop for every agent and the full map for the planner.
+//   crop:    one lane per (agent, window cell): one LDS word read feeds CM+1 coalesced f32
+//            stores and 2 i16 stores (the out-of-world ring: all 0, in-bounds channel 0);
+//   planner: one lane per 4 consecutive cells: one 16-byte LDS read feeds CM 16-byte
+//            stores and two 8-byte stores.
+template <bool WATER>
+__device__ __forceinline__ void write_spatial_observations_t(const Ctx& c, uint8_t* __restrict__ arena) {
+  constexpr int CM = WATER ? 6 : 5;
+  const int n = c.P.n, H = c.P.H, W = c.P.W, HW = c.P.HW, WV = c.P.WV;
   const int w = c.P.c.obs_range;
   const int WV2 = WV * WV;
-  const bool has_water = c.P.c.has_water != 0;
   const uint32_t* cells = R_CELLS(c);
   const int32_t *lr = R_I32(c, o_loc_r), *lc = R_I32(c, o_loc_c);
   float* amap = reinterpret_cast<float*>(arena + c.P.a_obs_a_map) + (int64_t)c.e * n * (CM + 1) * WV2;
   int16_t* aidx = reinterpret_cast<int16_t*>(arena + c.P.a_obs_a_idx) + (int64_t)c.e * n * 2 * WV2;
   const int tot = n * WV2;
   for (int q = c.tid; q < tot; q += AIE_NT) {
-    const int i = q / WV2;
+    const int i = udiv(q, WV2, c.P.mg_WV2);
     const int d = q - i * WV2;
-    const int dr = d / WV, dc = d - dr * WV;
+    const int dr = udiv(d, WV, c.P.mg_WV), dc = d - dr * WV;
     const int r = lr[i] - w + dr, col = lc[i] - w + dc;
     const bool in = (r >= 0) & (r < H) & (col >= 0) & (col < W);
     const int cell = in ? r * W + col : 0;
-    // out of the world: all channels 0, owner none, in-bounds channel 0 (:480-485)
-    const uint32_t cw = in ? cells[cell] : 0x00ff0000u;
+    const uint32_t cw = in ? cells[cell] : 0x00ff0000u;  // :480-485
+    float ch[6];
+    cell_channels<WATER>(cw, ch);
     float* o = amap + (int64_t)i * (CM + 1) * WV2 + d;
-    for (int k = 0; k < CM; ++k) o[k * WV2] = chan_value(cw, k, has_water);
+#pragma unroll
+    for (int k = 0; k < CM; ++k) o[k * WV2] = ch[k];
     o[CM * WV2] = in ? 1.0f : 0.0f;
     const int own = AIE_CELL_OWNER(cw);
     int v0 = own >= 0 ? own + 2 : 0;
     int v1 = in ? (int)c.locmap[cell] : 0;
-    v1 = v1 ? v1 + 1 : 0;  // agent k -> k + 2
+    v1 = v1 ? v1 + 1 : 0;     // agent k -> k + 2
     if (v0 == i + 2) v0 = 1;  // :503
     if (v1 == i + 2) v1 = 1;
     int16_t* oi = aidx + (int64_t)i * 2 * WV2 + d;
@@ -777,155 +1124,138 @@ __device__ void write_spatial_observations(const Ctx& c, uint8_t* __restrict__ a
   if (c.P.c.planner_gets_spatial_info) {
     float* pmap = reinterpret_cast<float*>(arena + c.P.a_obs_p_map) + (int64_t)c.e * CM * HW;
     int16_t* pidx = reinterpret_cast<int16_t*>(arena + c.P.a_obs_p_idx) + (int64_t)c.e * 2 * HW;
-    for (int cell = c.tid; cell < HW; cell += AIE_NT) {
-      const uint32_t cw = cells[cell];
-      for (int k = 0; k < CM; ++k) pmap[k * HW + cell] = chan_value(cw, k, has_water);
-      const int own = AIE_CELL_OWNER(cw);
+    // f32 channel planes: 4 consecutive cells per lane -> CM 16-byte stores.  The planes
+    // are only dword-aligned (H*W need not be a multiple of 4): global dwordx4 stores need
+    // no more than that on gfx950.
+    const int nq4 = HW >> 2;
+    for (int q = c.tid; q < nq4; q += AIE_NT) {
+      const uint4 cw = reinterpret_cast<const uint4*>(cells)[q];
+      float ch[4][6];
+      cell_channels<WATER>(cw.x, ch[0]);
+      cell_channels<WATER>(cw.y, ch[1]);
+      cell_channels<WATER>(cw.z, ch[2]);
+      cell_channels<WATER>(cw.w, ch[3]);
+#pragma unroll
+      for (int k = 0; k < CM; ++k) {
+        f32x4_a4 v = {ch[0][k], ch[1][k], ch[2][k], ch[3][k]};
+        *reinterpret_cast<f32x4_a4*>(pmap + k * HW + 4 * q) = v;
+      }
+    }
+    for (int cell = 4 * nq4 + c.tid; cell < HW; cell += AIE_NT) {  // tail cells
+      float ch[6];
+      cell_channels<WATER>(cells[cell], ch);
+#pragma unroll
+      for (int k = 0; k < CM; ++k) pmap[k * HW + cell] = ch[k];
+    }
+    for (int cell = c.tid; cell < HW; cell += AIE_NT) {  // i16 owner / location planes
+      const int own = AIE_CELL_OWNER(cells[cell]);
       const int occ = c.locmap[cell];
       pidx[cell] = (int16_t)(own >= 0 ? own + 2 : 0);
       pidx[HW + cell] = (int16_t)(occ ? occ + 1 : 0);
     }
   }
 }
+__device__ __forceinline__ void write_spatial_observations(const Ctx& c, uint8_t* __restrict__ arena) {
+  if (c.P.c.has_water) write_spatial_observations_t<true>(c, arena);
+  else write_spatial_observations_t<false>(c, arena);
+}
 
 // Component + scalar observations, packed in SORTED key order (base_env.py:561-612):
 // Build (build.py:163-178), CDA (continuous_double_auction.py:491-542), Gather
 // (move.py:155-165), PeriodicBracketTax (redistribution.py:974-1023), time, world-*.
 // Built in LDS (c.stage) then streamed out.
-__device__ void write_flat_observations_and_masks(const Ctx& c, uint8_t* __restrict__ arena) {
+__device__ __forceinline__ void write_flat_observations_and_masks(const Ctx& c, uint8_t* __restrict__ arena) {
   const aie_params& P = c.P;
   const int n = P.n, tid = c.tid, Pp = P.P, NB = P.NB;
   const double isc = P.c.allow_observation_scaling ? 0.01 : 1.0;
   float* s_aflat = c.stage;
-  float* s_amask = s_aflat + n * P.FA;
-  float* s_pag = s_amask + n * P.MA;
-  float* s_pflat = s_pag + n * P.FPA;
-  float* s_pmask = s_pflat + P.FP;
+  float* s_amask = s_aflat + pad4(n * P.FA);
+  float* s_pag = s_amask + pad4(n * P.MA);
+  float* s_pflat = s_pag + pad4(n * P.FPA);
+  float* s_pmask = s_pflat + pad4(P.FP);
+  const int t = *R_I32(c, o_timestep);
+  const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)P.c.episode_length : 1.0));
 
-  // ---- shared CDA quantities: lanes over (commodity, price) ----
-  if (P.has_cda) {
+  const int skip = P.dev_skip_mask;
+  // ================= stage A: per-(commodity, price) sums, per-agent scalars ===========
+  if (P.has_cda && !(skip & 64)) {
+    // lanes over (commodity r, price k): net price history and full bid / ask histograms
     double* net_ph = scr_net_ph(c);
     for (int q = tid; q < 2 * Pp; q += AIE_NT) {
-      const int r = q / Pp, k = q - r * Pp;
+      const int r = q >= Pp ? 1 : 0, k = q - r * Pp;
       double s = 0;
       int fa = 0, fb = 0;
       for (int i = 0; i < n; ++i) {
         const double v = R_F64(c, o_cda_price_history)[(r * n + i) * Pp + k];
-        s = (i == 0) ? v : s + v;
+        s = (i == 0) ? v : s + v;  // np.sum(np.stack(...), axis=0): row by row
         fa += R_U8(c, o_cda_ask_hist)[(r * n + i) * Pp + k];
         fb += R_U8(c, o_cda_bid_hist)[(r * n + i) * Pp + k];
       }
-      net_ph[r * 128 + k] = s;
-      const float ph = (float)(s * isc);
-      // planner: full_asks, full_bids, price_history
-      float* g = s_pflat + P.fp_cda;
+      net_ph[q] = s;
+      float* g = s_pflat + P.fp_cda;  // planner: full_asks, full_bids, price_history
       g[0 * Pp + q] = (float)fa;
       g[2 * Pp + q] = (float)fb;
-      g[4 * Pp + 2 + q] = ph;
-      for (int i = 0; i < n; ++i) {
-        float* f = s_aflat + i * P.FA + P.fa_cda;
-        const int mya = R_U8(c, o_cda_ask_hist)[(r * n + i) * Pp + k];
-        const int myb = R_U8(c, o_cda_bid_hist)[(r * n + i) * Pp + k];
-        f[0 * Pp + q] = (float)(fa - mya);  // available_asks
-        f[2 * Pp + q] = (float)(fb - myb);  // available_bids
-        f[4 * Pp + 2 + q] = (float)mya;     // my_asks
-        f[6 * Pp + 2 + q] = (float)myb;     // my_bids
-        f[8 * Pp + 2 + q] = ph;             // price_history
-      }
-    }
-    __syncthreads();
-    if (tid < 2) {
-      const int r = tid;
-      const double* a = net_ph + r * 128;
-      double dot = 0;
-      for (int k = 0; k < Pp; ++k) dot += (double)k * a[k];
-      // np.sum (pairwise) of P values
-      double tot;
-      if (Pp < 8) {
-        tot = -0.0;
-        for (int k = 0; k < Pp; ++k) tot += a[k];
-      } else {
-        double rr[8];
-        int k;
-        for (k = 0; k < 8; ++k) rr[k] = a[k];
-        for (k = 8; k < Pp - (Pp % 8); k += 8)
-          for (int j = 0; j < 8; ++j) rr[j] += a[k + j];
-        tot = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
-        for (; k < Pp; ++k) tot += a[k];
-      }
-      const float mr = (float)(dot / (tot > 0.001 ? tot : 0.001));
-      s_pflat[P.fp_cda + 4 * Pp + r] = mr;
-      for (int i = 0; i < n; ++i) s_aflat[i * P.FA + P.fa_cda + 4 * Pp + r] = mr;
+      g[4 * Pp + 2 + q] = (float)(s * isc);
     }
   }
-
-  // ---- shared tax quantities ----
-  double is_tax_day = 0, is_first_day = 0, tax_phase = 0;
-  if (P.has_tax) {
-    const int pos = *R_I32(c, o_tax_cycle_pos);
-    is_tax_day = pos >= P.c.tax_period ? 1.0 : 0.0;
-    is_first_day = pos == 1 ? 1.0 : 0.0;
-    tax_phase = (double)pos / (double)P.c.tax_period;
-    if (tid < n) {
-      // last_incomes sorted ascending (redistribution.py:908-911): rank by counting
-      const double per = (double)P.c.tax_period;
-      const double x = R_F64(c, o_tax_last_income)[tid] / per;
-      int rank = 0;
-      for (int j = 0; j < n; ++j) {
-        const double y = R_F64(c, o_tax_last_income)[j] / per;
-        rank += (y < x || (y == x && j < tid)) ? 1 : 0;
-      }
-      scr_sorted_inc(c)[rank] = x;
-      scr_cmr(c)[tid] = tax_marginal_rate(
-          c, (R_F64(c, o_inv_coin)[tid] + R_F64(c, o_esc_coin)[tid]) - R_F64(c, o_tax_last_coin)[tid]);
-    }
-    __syncthreads();
-    // lanes over (agent or planner, element of the tax fragment)
-    const int fragA = NB + n + 4, fragP = NB + n + 3;
-    for (int q = tid; q < n * fragA + fragP; q += AIE_NT) {
-      const bool planner = q >= n * fragA;
-      const int i = planner ? 0 : q / fragA;
-      const int j = planner ? q - n * fragA : q - i * fragA;
-      float v;
-      if (j < NB) v = (float)tax_rate(c, j);
-      else if (j == NB) v = (float)is_first_day;
-      else if (j == NB + 1) v = (float)is_tax_day;
-      else if (j < NB + 2 + n) v = (float)scr_sorted_inc(c)[j - NB - 2];
-      else if (!planner && j == NB + 2 + n) v = (float)scr_cmr(c)[i];
-      else v = (float)tax_phase;
-      if (planner) s_pflat[P.fp_tax + j] = v;
-      else s_aflat[i * P.FA + P.fa_tax + j] = v;
-    }
-  }
-
-  // ---- per-agent scalars ----
-  const int t = *R_I32(c, o_timestep);
-  const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)P.c.episode_length : 1.0));
-  if (tid < n) {
+  if (tid < n && !(skip & 64)) {
     const int i = tid;
     float* f = s_aflat + i * P.FA;
-    if (P.has_build) {
+    const double coin = R_F64(c, o_inv_coin)[i];
+    const int inv0 = R_I32(c, o_inv_res)[i], inv1 = R_I32(c, o_inv_res)[n + i];
+    const int lr = R_I32(c, o_loc_r)[i], lc = R_I32(c, o_loc_c)[i];
+    if (P.has_build) {  // build.py:163-178
       f[P.fa_build + 0] = (float)(R_F64(c, o_build_payment)[i] / (double)P.c.build_payment);
       f[P.fa_build + 1] = (float)R_F64(c, o_build_skill)[i];
     }
-    if (P.has_gather) f[P.fa_gather] = (float)R_F64(c, o_bonus_gather_prob)[i];
+    if (P.has_gather) f[P.fa_gather] = (float)R_F64(c, o_bonus_gather_prob)[i];  // move.py:155-165
     f[P.fa_time] = tval;
-    const float w0 = (float)(R_F64(c, o_inv_coin)[i] * isc);
-    const float w1 = (float)((double)R_I32(c, o_inv_res)[i] * isc);
-    const float w2 = (float)((double)R_I32(c, o_inv_res)[n + i] * isc);
-    const float w3 = (float)((double)R_I32(c, o_loc_c)[i] / (double)P.W);
-    const float w4 = (float)((double)R_I32(c, o_loc_r)[i] / (double)P.H);
+    const float w0 = (float)(coin * isc);
+    const float w1 = (float)((double)inv0 * isc);
+    const float w2 = (float)((double)inv1 * isc);
+    const float w3 = (float)((double)lc / (double)P.W);
+    const float w4 = (float)((double)lr / (double)P.H);
     f[P.fa_world + 0] = w0; f[P.fa_world + 1] = w1; f[P.fa_world + 2] = w2;
     f[P.fa_world + 3] = w3; f[P.fa_world + 4] = w4;
     float* q = s_pag + i * P.FPA;
-    if (P.has_tax) {
-      q[P.fpa_tax + 0] = (float)scr_cmr(c)[i];
-      q[P.fpa_tax + 1] = (float)(R_F64(c, o_tax_last_income)[i] / (double)P.c.tax_period);
-      q[P.fpa_tax + 2] = (float)R_F64(c, o_tax_last_marginal_rate)[i];
-    }
     q[P.fpa_world + 0] = w0; q[P.fpa_world + 1] = w1; q[P.fpa_world + 2] = w2;
     if (P.c.planner_gets_spatial_info) { q[P.fpa_world + 3] = w3; q[P.fpa_world + 4] = w4; }
     reinterpret_cast<float*>(arena + P.a_obs_a_time)[(int64_t)c.e * n + i] = tval;
+    if (P.has_tax) {
+      // last_incomes sorted ascending (redistribution.py:908-911): rank by counting
+      const double per = (double)P.c.tax_period;
+      const double x = R_F64(c, o_tax_last_income)[i] / per;
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const double y = R_F64(c, o_tax_last_income)[j] / per;
+        rank += (y < x || (y == x && j < i)) ? 1 : 0;
+      }
+      scr_sorted_inc(c)[rank] = x;
+      const double cmr = tax_marginal_rate(c, (coin + R_F64(c, o_esc_coin)[i]) - R_F64(c, o_tax_last_coin)[i]);
+      f[P.fa_tax + NB + 2 + n] = (float)cmr;
+      q[P.fpa_tax + 0] = (float)cmr;
+      q[P.fpa_tax + 1] = (float)x;
+      q[P.fpa_tax + 2] = (float)R_F64(c, o_tax_last_marginal_rate)[i];
+    }
+    // mask bits: Build build.py:180-193, Gather move.py:167-188, CDA :544-580
+    uint32_t mf = 0;
+    if (P.has_build) mf |= agent_can_build(c, i) ? 1u : 0u;
+    if (P.has_gather) {
+      mf |= can_agent_occupy(c, lr, lc - 1, i) ? 2u : 0u;
+      mf |= can_agent_occupy(c, lr, lc + 1, i) ? 4u : 0u;
+      mf |= can_agent_occupy(c, lr - 1, lc, i) ? 8u : 0u;
+      mf |= can_agent_occupy(c, lr + 1, lc, i) ? 16u : 0u;
+    }
+    if (P.has_cda) {
+      int kmax = coin >= (double)(Pp - 1) ? Pp - 1 : (int)coin;  // price k is affordable iff k <= coin
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bool quota = R_I32(c, o_cda_n_orders)[r * n + i] < P.c.cda_max_num_orders;
+        if (quota && (r ? inv1 : inv0) > 0) mf |= 32u << r;
+        if (quota) mf |= (uint32_t)(kmax + 1) << (8 + 8 * r);
+      }
+    }
+    c.mflags[i] = (int32_t)mf;
   }
   if (tid == 0) {
     s_pflat[P.fp_time] = tval;
@@ -934,71 +1264,122 @@ __device__ void write_flat_observations_and_masks(const Ctx& c, uint8_t* __restr
     s_pflat[P.fp_world + 2] = 0.0f;
     reinterpret_cast<float*>(arena + P.a_obs_p_time)[c.e] = tval;
   }
+  __syncthreads();
 
-  // ---- masks: _generate_masks base_env.py:706-756 + flatten_masks base_agent.py:440-460
-  // Gather move.py:167-188, Build build.py:180-193, CDA :544-580, Tax :1025-1104 ----
-  {
+  // ================= stage B: fill the vectors, one lane per element =====================
+  if (P.has_cda && !(skip & 128)) {
+    // continuous_double_auction.py:491-542
+    if (tid < 2) {
+      const int r = tid;
+      const double* a = scr_net_ph(c) + r * Pp;
+      double dot = 0;
+      for (int k = 0; k < Pp; ++k) dot += (double)k * a[k];
+      const double tot = np_sum_small(a, Pp);
+      const float mr = (float)(dot / (tot > 0.001 ? tot : 0.001));
+      s_pflat[P.fp_cda + 4 * Pp + r] = mr;
+      for (int i = 0; i < n; ++i) s_aflat[i * P.FA + P.fa_cda + 4 * Pp + r] = mr;
+    }
+    const float* g = s_pflat + P.fp_cda;
+    for (int it = tid; it < n * 2 * Pp; it += AIE_NT) {
+      const int i = udiv(it, 2 * Pp, P.mg_2P);
+      const int q = it - i * 2 * Pp;  // (commodity, price)
+      const int r = q >= Pp ? 1 : 0, k = q - r * Pp;
+      const float mya = (float)R_U8(c, o_cda_ask_hist)[(r * n + i) * Pp + k];
+      const float myb = (float)R_U8(c, o_cda_bid_hist)[(r * n + i) * Pp + k];
+      float* f = s_aflat + i * P.FA + P.fa_cda;
+      f[0 * Pp + q] = g[0 * Pp + q] - mya;  // available_asks
+      f[2 * Pp + q] = g[2 * Pp + q] - myb;  // available_bids
+      f[4 * Pp + 2 + q] = mya;              // my_asks
+      f[6 * Pp + 2 + q] = myb;              // my_bids
+      f[8 * Pp + 2 + q] = g[4 * Pp + 2 + q];  // price_history
+    }
+  }
+  if (P.has_tax && !(skip & 256)) {
+    // redistribution.py:974-1023; lanes over (agent or planner, element of the fragment)
+    const int pos = *R_I32(c, o_tax_cycle_pos);
+    const float is_tax_day = pos >= P.c.tax_period ? 1.0f : 0.0f;
+    const float is_first_day = pos == 1 ? 1.0f : 0.0f;
+    const float tax_phase = (float)((double)pos / (double)P.c.tax_period);
+    const int fragA = NB + n + 4;
+    for (int q = tid; q < (n + 1) * fragA; q += AIE_NT) {
+      const int i = udiv(q, fragA, P.mg_taxA);
+      const int j = q - i * fragA;
+      const bool planner = i == n;
+      if (j == NB + 2 + n) {  // marginal_rate: written in stage A (agents), absent for the planner
+        if (planner) s_pflat[P.fp_tax + NB + 2 + n] = tax_phase;
+        continue;
+      }
+      if (planner && j == NB + 3 + n) continue;
+      float v;
+      if (j < NB) v = (float)tax_rate(c, j);
+      else if (j == NB) v = is_first_day;
+      else if (j == NB + 1) v = is_tax_day;
+      else if (j < NB + 2 + n) v = (float)scr_sorted_inc(c)[j - NB - 2];
+      else v = tax_phase;
+      if (planner) s_pflat[P.fp_tax + j] = v;
+      else s_aflat[i * P.FA + P.fa_tax + j] = v;
+    }
+  }
+
+  // ---- masks: _generate_masks base_env.py:706-756 + flatten_masks base_agent.py:440-460,
+  // planner PeriodicBracketTax.generate_masks redistribution.py:1025-1104 ----
+  if (!(skip & 512)) {
     const bool multi = P.c.multi_action_mode_agents != 0;
-    const int32_t *lr = R_I32(c, o_loc_r), *lc = R_I32(c, o_loc_c);
-    for (int q = tid; q < n * P.MA; q += AIE_NT) {
-      const int i = q / P.MA;
-      int m = q - i * P.MA;
-      float v = 1.0f;
-      if (!multi) m -= 1;  // leading NO-OP entry
-      if (m >= 0 && P.n_sub_a > 0) {
-        int s = 0;
-        for (; s < P.n_sub_a; ++s) {
-          const int len = P.sub_a_dim[s] + (multi ? 1 : 0);
-          if (m < len) break;
-          m -= len;
+    // Element m of the flattened mask means the same thing for every agent: classify it
+    // once per lane (wave-uniform walk over the registered subspaces), then evaluate it
+    // against each agent's mask bits.
+    for (int m0 = 0; m0 < P.MA; m0 += AIE_NT) {
+      const int m = m0 + tid;
+      const int mm = m - (multi ? 0 : 1);  // skip the leading NO-OP entry
+      int kind = -1, loc = 0;              // -1: constant 1 (a NO-OP entry)
+      int base = 0;
+      for (int sub = 0; sub < P.n_sub_a; ++sub) {
+        const int len = P.sub_a_dim[sub] + (multi ? 1 : 0);
+        const int l = mm - base - (multi ? 1 : 0);
+        if (mm >= base && mm < base + len && l >= 0) {
+          kind = P.sub_a_slot[sub];
+          loc = l;
         }
-        if (multi) m -= 1;  // per-subspace NO-OP entry
-        if (m >= 0) {
-          const int slot = P.sub_a_slot[s];
-          if (slot == AIE_SUB_BUILD) v = agent_can_build(c, i) ? 1.0f : 0.0f;
-          else if (slot == AIE_SUB_GATHER) {
-            const int ro = (m == 2) ? -1 : (m == 3) ? 1 : 0;
-            const int co = (m == 0) ? -1 : (m == 1) ? 1 : 0;
-            v = can_agent_occupy(c, lr[i] + ro, lc[i] + co, i) ? 1.0f : 0.0f;
-          } else {
-            const int r = (slot == AIE_SUB_BUY1 || slot == AIE_SUB_SELL1) ? 1 : 0;
-            const bool is_buy = (slot == AIE_SUB_BUY0 || slot == AIE_SUB_BUY1);
-            const bool quota = R_I32(c, o_cda_n_orders)[r * n + i] < P.c.cda_max_num_orders;
-            if (is_buy) v = (quota && (double)m <= R_F64(c, o_inv_coin)[i]) ? 1.0f : 0.0f;
-            else v = (quota && R_I32(c, o_inv_res)[r * n + i] > 0) ? 1.0f : 0.0f;
-          }
+        base += len;
+      }
+      if (m < P.MA) {
+        for (int i = 0; i < n; ++i) {
+          const uint32_t mf = (uint32_t)c.mflags[i];
+          bool ok = true;
+          if (kind == AIE_SUB_BUILD) ok = mf & 1u;
+          else if (kind == AIE_SUB_GATHER) ok = (mf >> (1 + loc)) & 1u;
+          else if (kind == AIE_SUB_SELL0) ok = (mf >> 5) & 1u;
+          else if (kind == AIE_SUB_SELL1) ok = (mf >> 6) & 1u;
+          else if (kind == AIE_SUB_BUY0) ok = (uint32_t)loc < ((mf >> 8) & 0xffu);
+          else if (kind == AIE_SUB_BUY1) ok = (uint32_t)loc < ((mf >> 16) & 0xffu);
+          s_amask[i * P.MA + m] = ok ? 1.0f : 0.0f;
         }
       }
-      s_amask[q] = v;
     }
     const bool pmulti = P.c.multi_action_mode_planner != 0;
     const float open = (P.n_sub_p && *R_I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
     for (int q = tid; q < P.MP; q += AIE_NT) {
       float v;
       if (P.n_sub_p == 0) v = 1.0f;
-      else if (pmulti) v = (q % (1 + P.sub_p_dim) == 0) ? 1.0f : open;
+      else if (pmulti) v = (q - udiv(q, 1 + P.sub_p_dim, P.mg_sub_p) * (1 + P.sub_p_dim) == 0) ? 1.0f : open;
       else v = (q == 0) ? 1.0f : open;
       s_pmask[q] = v;
     }
   }
   __syncthreads();
 
-  // ---- stream the staged vectors out (lane-contiguous 4-byte stores) ----
-  {
-    float* g = reinterpret_cast<float*>(arena + P.a_obs_a_flat) + (int64_t)c.e * n * P.FA;
-    for (int q = tid; q < n * P.FA; q += AIE_NT) g[q] = s_aflat[q];
-    g = reinterpret_cast<float*>(arena + P.a_obs_a_mask) + (int64_t)c.e * n * P.MA;
-    for (int q = tid; q < n * P.MA; q += AIE_NT) g[q] = s_amask[q];
-    g = reinterpret_cast<float*>(arena + P.a_obs_p_agents) + (int64_t)c.e * n * P.FPA;
-    for (int q = tid; q < n * P.FPA; q += AIE_NT) g[q] = s_pag[q];
-    g = reinterpret_cast<float*>(arena + P.a_obs_p_flat) + (int64_t)c.e * P.FP;
-    for (int q = tid; q < P.FP; q += AIE_NT) g[q] = s_pflat[q];
-    g = reinterpret_cast<float*>(arena + P.a_obs_p_mask) + (int64_t)c.e * P.MP;
-    for (int q = tid; q < P.MP; q += AIE_NT) g[q] = s_pmask[q];
+  // ---- stream the staged vectors out: 16-byte LDS reads, dword-aligned 16-byte stores ----
+  if (!(skip & 1024)) {
+    stream_out(s_aflat, reinterpret_cast<float*>(arena + P.a_obs_a_flat) + (int64_t)c.e * n * P.FA, n * P.FA, tid);
+    stream_out(s_amask, reinterpret_cast<float*>(arena + P.a_obs_a_mask) + (int64_t)c.e * n * P.MA, n * P.MA, tid);
+    stream_out(s_pag, reinterpret_cast<float*>(arena + P.a_obs_p_agents) + (int64_t)c.e * n * P.FPA, n * P.FPA, tid);
+    stream_out(s_pflat, reinterpret_cast<float*>(arena + P.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
+    stream_out(s_pmask, reinterpret_cast<float*>(arena + P.a_obs_p_mask) + (int64_t)c.e * P.MP, P.MP, tid);
   }
 }
 
-__device__ void rebuild_locmap(const Ctx& c) {
+
+__device__ __forceinline__ void rebuild_locmap(const Ctx& c) {
   uint32_t* lm = reinterpret_cast<uint32_t*>(c.locmap);
   const int nw = (c.P.HW + 3) >> 2;
   for (int q = c.tid; q < nw; q += AIE_NT) lm[q] = 0;
@@ -1010,43 +1391,6 @@ __device__ void rebuild_locmap(const Ctx& c) {
   __syncthreads();
 }
 
-// parse_actions base_env.py:552-556 -> base_agent.py:407-438 (lane i decodes agent i)
-__device__ void decode_actions(const Ctx& c, const int32_t* __restrict__ aa, const int32_t* __restrict__ ap) {
-  const aie_params& P = c.P;
-  const int i = c.tid;
-  if (i < P.n) {
-    int32_t* act = c.act + i * AIE_N_SUB_SLOTS;
-#pragma unroll
-    for (int s = 0; s < AIE_N_SUB_SLOTS; ++s) act[s] = 0;
-    if (aa) {
-      const int32_t* a = aa + ((int64_t)c.e * P.n + i) * P.act_a_width;
-      if (P.c.multi_action_mode_agents) {
-        for (int s = 0; s < P.n_sub_a; ++s) {
-          const int v = a[s];
-          if (v >= 0 && v <= P.sub_a_dim[s]) act[P.sub_a_slot[s]] = v;
-        }
-      } else {
-        const int v = a[0];
-        for (int s = 0; s < P.n_sub_a; ++s)
-          if (v >= P.sub_a_base[s] && v < P.sub_a_base[s] + P.sub_a_dim[s])
-            act[P.sub_a_slot[s]] = v - P.sub_a_base[s] + 1;
-      }
-    }
-  }
-  if (i < AIE_MAX_BRACKETS) {
-    int v = 0;
-    if (ap && i < P.n_sub_p) {
-      const int32_t* a = ap + (int64_t)c.e * P.act_p_width;
-      if (P.c.multi_action_mode_planner) v = a[i];
-      else {
-        const int x = a[0];
-        if (x >= 1 && x < 1 + P.n_sub_p * P.sub_p_dim && (x - 1) / P.sub_p_dim == i) v = (x - 1) % P.sub_p_dim + 1;
-      }
-    }
-    c.act_p[i] = v;
-  }
-}
-
 }  // namespace aie
 
 // ======================================================================================
@@ -1056,34 +1400,42 @@ __device__ void decode_actions(const Ctx& c, const int32_t* __restrict__ aa, con
 // BaseEnvironment.step, F/base/base_env.py:929-1032: parse actions, timestep += 1,
 // components in list order, scenario_step, observations, masks, rewards, done.
 extern "C" __global__ void __launch_bounds__(AIE_NT)
-aie_step_kernel(const aie_params P, uint8_t* __restrict__ arena, const int32_t* __restrict__ act_a,
-                const int32_t* __restrict__ act_p) {
+aie_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   using namespace aie;
+  // The parameter block lives in device memory (uniform scalar loads).  Passing the 2.7 KB
+  // struct by value made the compiler copy it to scratch on every launch (5x slower).
+  const aie_params& P = *params;
   const Ctx c = make_ctx(P, lds, (int)blockIdx.x, (int)threadIdx.x);
-  load_record(c, arena);
-  decode_actions(c, act_a, act_p);
+  MT m;
+  Agents A;
+  if (c.tid == 0) *c.srcn = 0;
   __syncthreads();
+  load_record(c, arena, m);
+  decode_actions(c, A, act_a, act_p);
+  __syncthreads();
+  m.pos = uni(*R_I32(c, o_mt_pos));
+  agents_load(c, A);
   rebuild_locmap(c);
-  if (P.has_cda) cda_decay_price_history(c);
-  __syncthreads();
   const int skip = P.dev_skip_mask;
-  if (c.tid == 0) {
-    *R_I32(c, o_timestep) += 1;
-    if (!(skip & 1)) {
-      for (int k = 0; k < P.c.n_components; ++k) {
-        switch (P.c.components[k]) {
-          case AIE_COMP_BUILD: build_component_step(c); break;
-          case AIE_COMP_CDA: cda_component_step(c); break;
-          case AIE_COMP_GATHER: gather_component_step(c); break;
-          case AIE_COMP_TAX: tax_component_step(c); break;
-          default: break;
-        }
+  if (P.has_cda && !(skip & 1)) cda_decay_price_history(c);
+  __syncthreads();
+  if (c.tid == 0) *R_I32(c, o_timestep) += 1;
+  if (!(skip & 1)) {
+    for (int k = 0; k < P.c.n_components; ++k) {
+      switch (P.c.components[k]) {
+        case AIE_COMP_BUILD: if (!(skip & 2048)) build_component_step(c, m, A); break;
+        case AIE_COMP_CDA: if (!(skip & 4096)) cda_component_step(c, A); break;
+        case AIE_COMP_GATHER: if (!(skip & 8192)) gather_component_step(c, m, A); break;
+        case AIE_COMP_TAX: if (!(skip & 16384)) tax_component_step(c, A); break;
+        default: break;
       }
     }
   }
-  __syncthreads();
-  if (!(skip & 2)) scenario_step_regen(c);
+  agents_store(c, A);
+  if (!(skip & 2)) scenario_step_regen(c, m);
+  if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
   __syncthreads();
   if (!(skip & 4)) write_spatial_observations(c, arena);
   if (!(skip & 8)) write_flat_observations_and_masks(c, arena);
@@ -1096,23 +1448,30 @@ aie_step_kernel(const aie_params P, uint8_t* __restrict__ arena, const int32_t* 
     if (done) *R_I32(c, o_completions) += 1;
   }
   __syncthreads();
-  if (!(skip & 32)) store_record(c, arena);
+  if (!(skip & 32)) store_record(c, arena, m);
 }
 
 // BaseEnvironment.reset, F/base/base_env.py:852-927, with LayoutFromFile
 // reset_starting_layout / reset_agent_states / additional_reset_steps
 // (layout_from_file.py:323-370, 564-593) and the component resets (build.py:224-254,
 // move.py:193-210, continuous_double_auction.py:643-668, redistribution.py:1109-1139).
+// Runs once per episode: the sequential part is executed wave-uniformly out of LDS.
 extern "C" __global__ void __launch_bounds__(AIE_NT)
-aie_reset_kernel(const aie_params P, uint8_t* __restrict__ arena, const uint8_t* __restrict__ mask) {
+aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                 const uint8_t* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   using namespace aie;
+  const aie_params& P = *params;
   const int e = (int)blockIdx.x;
   if (mask && !mask[e]) return;
   const Ctx c = make_ctx(P, lds, e, (int)threadIdx.x);
   const int n = P.n, HW = P.HW, tid = c.tid;
-  load_record(c, arena);
+  MT m;
+  if (tid == 0) *c.srcn = 0;
   __syncthreads();
+  load_record(c, arena, m);
+  __syncthreads();
+  m.pos = uni(*R_I32(c, o_mt_pos));
   {  // layout_from_file.py:323-334: resources back on every source block, no houses
     uint32_t* cells = R_CELLS(c);
     for (int q = tid; q < HW; q += AIE_NT) {
@@ -1142,77 +1501,76 @@ aie_reset_kernel(const aie_params P, uint8_t* __restrict__ arena, const uint8_t*
   }
   __syncthreads();
   rebuild_locmap(c);  // all agents off the board
-  if (tid == 0) {
-    *R_I32(c, o_timestep) = 0;
-    for (int i = 0; i < n; ++i) {  // layout_from_file.py:360-370
-      int r = (int)rng_interval(c, (uint32_t)(P.H - 1)), col = (int)rng_interval(c, (uint32_t)(P.W - 1)), tries = 0;
-      while (!can_agent_occupy(c, r, col, i)) {
-        r = (int)rng_interval(c, (uint32_t)(P.H - 1));
-        col = (int)rng_interval(c, (uint32_t)(P.W - 1));
-        if (++tries > 200) break;  // the reference raises TimeoutError
-      }
-      R_I32(c, o_loc_r)[i] = r;
-      R_I32(c, o_loc_c)[i] = col;
-      c.locmap[r * P.W + col] = (uint8_t)(i + 1);
+  // ---- wave-uniform sequential part (every lane performs the same LDS updates) ----
+  *R_I32(c, o_timestep) = 0;
+  for (int i = 0; i < n; ++i) {  // layout_from_file.py:360-370
+    int r = (int)rng_interval(m, tid, (uint32_t)(P.H - 1)), col = (int)rng_interval(m, tid, (uint32_t)(P.W - 1)), tries = 0;
+    while (!can_agent_occupy(c, r, col, i)) {
+      r = (int)rng_interval(m, tid, (uint32_t)(P.H - 1));
+      col = (int)rng_interval(m, tid, (uint32_t)(P.W - 1));
+      if (++tries > 200) break;  // the reference raises TimeoutError
     }
-    for (int k = 0; k < P.c.n_components; ++k) {
-      switch (P.c.components[k]) {
-        case AIE_COMP_BUILD:
-          for (int i = 0; i < n; ++i) {
-            double skill = 1, pay = 1;
-            const double pm = (double)P.c.build_payment_max_skill_multiplier;
-            if (P.c.build_skill_dist == AIE_SKILL_PARETO) {
-              skill = rng_pareto(c, 4.0);
-              pay = (pm - 1) * skill + 1; if (pm < pay) pay = pm;
-            } else if (P.c.build_skill_dist == AIE_SKILL_LOGNORMAL) {
-              skill = rng_lognormal(c, -1.0, 0.5);
-              pay = (pm - 1) * skill + 1; if (pm < pay) pay = pm;
-            }
-            R_F64(c, o_build_payment)[i] = pay * (double)P.c.build_payment;
-            R_F64(c, o_build_skill)[i] = skill;
+    R_I32(c, o_loc_r)[i] = r;
+    R_I32(c, o_loc_c)[i] = col;
+    c.locmap[r * P.W + col] = (uint8_t)(i + 1);
+  }
+  for (int k = 0; k < P.c.n_components; ++k) {
+    switch (P.c.components[k]) {
+      case AIE_COMP_BUILD:
+        for (int i = 0; i < n; ++i) {
+          double skill = 1, pay = 1;
+          const double pm = (double)P.c.build_payment_max_skill_multiplier;
+          if (P.c.build_skill_dist == AIE_SKILL_PARETO) {
+            skill = rng_pareto(m, tid, 4.0);
+            pay = (pm - 1) * skill + 1; if (pm < pay) pay = pm;
+          } else if (P.c.build_skill_dist == AIE_SKILL_LOGNORMAL) {
+            skill = rng_lognormal(c, m, -1.0, 0.5);
+            pay = (pm - 1) * skill + 1; if (pm < pay) pay = pm;
           }
-          break;
-        case AIE_COMP_GATHER:
-          for (int i = 0; i < n; ++i) {
-            double b = 0.0;
-            if (P.c.gather_skill_dist == AIE_SKILL_PARETO) { b = rng_pareto(c, 3.0); b = (b < 2 ? b : 2) / 2; }
-            else if (P.c.gather_skill_dist == AIE_SKILL_LOGNORMAL) { b = rng_lognormal(c, -2.022, 0.938); b = (b < 2 ? b : 2) / 2; }
-            R_F64(c, o_bonus_gather_prob)[i] = b;
-          }
-          break;
-        case AIE_COMP_TAX:
-          for (int b = 0; b < P.NB; ++b) R_I32(c, o_tax_rate_idx)[b] = 0;
-          *R_I32(c, o_tax_cycle_pos) = 1;
-          for (int i = 0; i < n; ++i) {
-            R_F64(c, o_tax_last_coin)[i] = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
-            R_F64(c, o_tax_last_income)[i] = 0;
-            R_F64(c, o_tax_last_marginal_rate)[i] = 0;
-          }
-          *R_F64(c, o_tax_total_collected) = 0;
-          break;
-        default: break;
-      }
-    }
-    if (P.c.fixed_four_skill_and_loc) {  // layout_from_file.py:582-586
-      int32_t* order = c.perm;
-      for (int i = 0; i < n; ++i) {
-        c.locmap[R_I32(c, o_loc_r)[i] * P.W + R_I32(c, o_loc_c)[i]] = 0;
-        R_I32(c, o_loc_r)[i] = -1;
-        R_I32(c, o_loc_c)[i] = -1;
-      }
-      rng_permutation(c, n, order);
-      for (int k = 0; k < n; ++k) {
-        const int i = order[k];
-        const int r = P.c.ranked_locs[k][0], col = P.c.ranked_locs[k][1];
-        if (can_agent_occupy(c, r, col, i)) {
-          R_I32(c, o_loc_r)[i] = r;
-          R_I32(c, o_loc_c)[i] = col;
-          c.locmap[r * P.W + col] = (uint8_t)(i + 1);
+          R_F64(c, o_build_payment)[i] = pay * (double)P.c.build_payment;
+          R_F64(c, o_build_skill)[i] = skill;
         }
-        R_F64(c, o_build_payment)[i] = P.c.avg_ranked_skill[k];
-      }
+        break;
+      case AIE_COMP_GATHER:
+        for (int i = 0; i < n; ++i) {
+          double b = 0.0;
+          if (P.c.gather_skill_dist == AIE_SKILL_PARETO) { b = rng_pareto(m, tid, 3.0); b = (b < 2 ? b : 2) / 2; }
+          else if (P.c.gather_skill_dist == AIE_SKILL_LOGNORMAL) { b = rng_lognormal(c, m, -2.022, 0.938); b = (b < 2 ? b : 2) / 2; }
+          R_F64(c, o_bonus_gather_prob)[i] = b;
+        }
+        break;
+      case AIE_COMP_TAX:
+        for (int b = 0; b < P.NB; ++b) R_I32(c, o_tax_rate_idx)[b] = 0;
+        *R_I32(c, o_tax_cycle_pos) = 1;
+        for (int i = 0; i < n; ++i) {
+          R_F64(c, o_tax_last_coin)[i] = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
+          R_F64(c, o_tax_last_income)[i] = 0;
+          R_F64(c, o_tax_last_marginal_rate)[i] = 0;
+        }
+        *R_F64(c, o_tax_total_collected) = 0;
+        break;
+      default: break;
     }
   }
+  if (P.c.fixed_four_skill_and_loc) {  // layout_from_file.py:582-586
+    for (int i = 0; i < n; ++i) {
+      c.locmap[R_I32(c, o_loc_r)[i] * P.W + R_I32(c, o_loc_c)[i]] = 0;
+      R_I32(c, o_loc_r)[i] = -1;
+      R_I32(c, o_loc_c)[i] = -1;
+    }
+    const int perm = rng_permutation(m, tid, n);
+    for (int k = 0; k < n; ++k) {
+      const int i = bcast(perm, k);
+      const int r = P.c.ranked_locs[k][0], col = P.c.ranked_locs[k][1];
+      if (can_agent_occupy(c, r, col, i)) {
+        R_I32(c, o_loc_r)[i] = r;
+        R_I32(c, o_loc_c)[i] = col;
+        c.locmap[r * P.W + col] = (uint8_t)(i + 1);
+      }
+      R_F64(c, o_build_payment)[i] = P.c.avg_ranked_skill[k];
+    }
+  }
+  *R_I32(c, o_mt_pos) = m.pos;
   __syncthreads();
   current_metrics(c);
   __syncthreads();
@@ -1226,7 +1584,7 @@ aie_reset_kernel(const aie_params P, uint8_t* __restrict__ arena, const uint8_t*
     (arena + P.a_done)[e] = 0;
   }
   __syncthreads();
-  store_record(c, arena);
+  store_record(c, arena, m);
 }
 
 // np.random.seed(base_seed + e): init_genrand (Knuth LCG), pos = 624.

@@ -94,6 +94,10 @@ typedef struct aie_params {
   int64_t a_rew_a, a_rew_p, a_done;
   int64_t arena_bytes;
 
+  /* exact unsigned division by run-time constants: q / d == __umulhi(q, mg_d) for
+   * q < 2^32 / d (d >= 2); see aie__magic() */
+  uint32_t mg_WV2, mg_WV, mg_MA, mg_FA, mg_P, mg_2P, mg_taxA, mg_HW, mg_W, mg_sub_p;
+
   /* development only: phases of the step kernel to skip when profiling
    * (tools/phase_profile.py); always 0 in normal operation */
   int32_t dev_skip_mask;
@@ -104,6 +108,10 @@ typedef struct aie_tensor_table {
   int32_t n;
   aie_tensor_desc t[AIE_MAX_TENSORS];
 } aie_tensor_table;
+
+static inline uint32_t aie__magic(int64_t d) {
+  return d <= 1 ? 0u : (uint32_t)((0x100000000ll + d - 1) / d);
+}
 
 static inline int64_t aie__align(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -310,6 +318,17 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     p->fpa_world = f; f += 3 + (c->planner_gets_spatial_info ? 2 : 0);
     p->FPA = f;
   }
+
+  p->mg_WV2 = aie__magic((int64_t)p->WV * p->WV);
+  p->mg_WV = aie__magic(p->WV);
+  p->mg_MA = aie__magic(p->MA);
+  p->mg_FA = aie__magic(p->FA);
+  p->mg_P = aie__magic(p->P);
+  p->mg_2P = aie__magic(2 * p->P);
+  p->mg_taxA = aie__magic(p->NB + p->n + 4);
+  p->mg_HW = aie__magic(p->HW);
+  p->mg_W = aie__magic(p->W);
+  p->mg_sub_p = aie__magic(1 + p->sub_p_dim);
 
   /* ---- per-replica record ------------------------------------------------------ */
   const int n = p->n, HW = p->HW, R = AIE_N_RES;

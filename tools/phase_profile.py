@@ -48,6 +48,8 @@ def timeit(mask, n=200):
 names = {0: "full", 1: "-serial components", 2: "-regen", 4: "-spatial obs", 8: "-flat obs+masks",
          16: "-rewards", 32: "-record store", 63: "only load+decode+locmap+decay",
          62: "only serial", 61: "only regen", 59: "only spatial", 55: "only flat", 47: "only rewards"}
+names.update({64: "-flat stageA", 128: "-flat cda fill", 256: "-flat tax fill", 512: "-flat masks",
+              1024: "-flat copy-out", 2048: "-build", 4096: "-cda", 8192: "-gather", 16384: "-tax"})
 full = timeit(0)
 for m, nm in names.items():
     t = timeit(m)
