@@ -61,6 +61,19 @@ def algorithmic_bytes_per_env_step(be):
     return dict(obs=obs, state_rw=2 * rec, act=act, rew_done=rew, total=obs + 2 * rec + act + rew)
 
 
+def measured_traffic(envs_per_gpu):
+    """HBM bytes per aie_step_kernel launch from the committed rocprofv3 PMC summary
+    (profiles/*_pmc.json, made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE
+    passes of this same command).  Only valid for the default batch size."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files or envs_per_gpu != ENVS_PER_GPU:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+
+
 def usable_cores():
     try:
         n = len(os.sched_getaffinity(0))
@@ -202,8 +215,9 @@ def main():
         b = algorithmic_bytes_per_env_step(be)
         bytes_per_launch = b["total"] * E
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(E)
         roof = dict(bound="hbm", kernel="aie_step_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=bytes_per_launch,
                     algorithmic_bytes_per_agent_step=b["total"] / n, bytes_breakdown_per_env_step=b,
                     avg_launch_ms=avg_ms, median_launch_ms=durs[len(durs) // 2], launches_timed=nk)

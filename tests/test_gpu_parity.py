@@ -236,3 +236,42 @@ def test_error_behaviour_through_cabi():
     d = _cabi.AieTensorDesc()
     assert be.lib.aie_get_tensor(be.handle, b"obs_a_world-map", ctypes.byref(d)) == 0
     assert tuple(d.shape[:5]) == (4, 4, 7, 11, 11) and d.dtype == 5
+
+
+def _variant_names():
+    from test_oracle_vs_reference import VARIANTS
+
+    return sorted(VARIANTS)
+
+
+@pytest.mark.parametrize("variant", _variant_names())
+def test_hip_matches_oracle_on_config_variants(variant):
+    """Configuration variants that tests/test_oracle_vs_reference.py pins against the live
+    reference (multi-action agents, single-action planner, no observation scaling, other
+    planner rewards, component orders, tax models, 6 agents on 40x40): HIP vs oracle."""
+    import torch
+    from oracle_lib import OracleEnv
+    from test_oracle_vs_reference import BASE, VARIANTS
+
+    cfg = dict(BASE)
+    cfg.update(VARIANTS[variant])
+    E, T = 48, 170
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(3)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(3)
+    oracle.reset()
+    _compare_all(be, oracle, variant + " reset")
+    for t in range(T):
+        a, p = be.sample_random_actions(seed=17)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+        if (t + 1) % 10 == 0:
+            _compare_all(be, oracle, "%s step %d" % (variant, t + 1))
+        if bool(be.tensors["done"][0]):
+            env.reset(be.tensors["done"])
+            oracle.reset(oracle.t["done"].copy())
+            _compare_all(be, oracle, "%s reset after step %d" % (variant, t + 1))

@@ -1,0 +1,132 @@
+"""CPU tests that need the live reference (/root/reference, skipped elsewhere): the C
+restatement is stepped side by side with the UNMODIFIED reference env on configurations
+the committed fixtures do not cover (multi-action agents, single-action planner, no
+observation scaling, other planner reward types, other component orders, fixed tax
+models, disabled taxes...)."""
+import numpy as np
+import pytest
+
+from helpers import compare_state, make_env
+
+pytestmark = pytest.mark.reference
+
+BASE = dict(scenario_name="layout_from_file/simple_wood_and_stone", n_agents=4, world_size=[25, 25],
+            episode_length=80, starting_agent_coin=12, resource_regen_prob=0.08,
+            env_layout_file="uniform_25x25_25each_65clump.txt")
+GTB = [["Build", {}], ["ContinuousDoubleAuction", {"max_num_orders": 4, "order_duration": 15}],
+       ["Gather", {}], ["PeriodicBracketTax", {"period": 20}]]
+
+VARIANTS = {
+    "multi_action_agents": dict(components=GTB, multi_action_mode_agents=True),
+    "single_action_planner": dict(components=GTB, multi_action_mode_planner=False),
+    "no_obs_scaling": dict(components=GTB, allow_observation_scaling=False),
+    "inv_income_utility": dict(components=GTB, planner_reward_type="inv_income_weighted_utility"),
+    "inv_income_coin": dict(components=GTB, planner_reward_type="inv_income_weighted_coin_endowments",
+                            mixing_weight_gini_vs_coin=0.3),
+    "order_gather_first": dict(components=[GTB[2], GTB[1], GTB[0], GTB[3]]),
+    "us_federal_fixed": dict(components=GTB[:3] + [["PeriodicBracketTax", {
+        "period": 10, "tax_model": "us-federal-single-filer-2018-scaled"}]]),
+    "fixed_bracket_linear": dict(components=GTB[:3] + [["PeriodicBracketTax", {
+        "period": 10, "tax_model": "fixed-bracket-rates", "bracket_spacing": "linear", "n_brackets": 4,
+        "top_bracket_cutoff": 30, "fixed_bracket_rates": [0.0, 0.1, 0.3, 0.6]}]]),
+    "taxes_disabled": dict(components=GTB[:3] + [["PeriodicBracketTax", {"period": 10, "disable_taxes": True}]]),
+    "log_brackets_wrapper": dict(components=GTB[:3] + [["PeriodicBracketTax", {
+        "period": 10, "bracket_spacing": "log", "n_brackets": 5, "top_bracket_cutoff": 40, "rate_disc": 0.1}]]),
+    "no_cda_obs_range3": dict(components=[GTB[0], GTB[2], GTB[3]], mobile_agent_observation_range=3),
+    "energy_decay_warmup": dict(components=GTB, energy_warmup_constant=3, energy_warmup_method="decay",
+                                 isoelastic_eta=0.5),
+    "six_agents_40x40": dict(components=GTB, n_agents=6, world_size=[40, 40],
+                             env_layout_file="quadrant_40x40_50each.txt"),
+}
+
+
+def _ref_env(cfg):
+    from ref_harness import load_reference_foundation
+
+    foundation = load_reference_foundation()
+    kw = dict(cfg)
+    name = kw.pop("scenario_name")
+    kw["components"] = [tuple(c) for c in kw["components"]]
+    return foundation.make_env_instance(name, **kw)
+
+
+def _random_actions(env, rng, multi_a, multi_p):
+    ag = env.world.agents[0]
+    acts = {}
+    n = env.n_agents
+    if multi_a:
+        dims = [ag.action_dim[nm] for nm in ag._action_names]
+        arr = np.zeros((n, len(dims)), np.int32)
+        for i in range(n):
+            # mostly one sub-action at a time, sometimes several (incl. Buy and Sell together)
+            for s, d in enumerate(dims):
+                if rng.rand() < 0.3:
+                    arr[i, s] = rng.randint(0, d)
+            acts[str(i)] = [int(x) for x in arr[i]]
+    else:
+        A = ag.action_spaces
+        arr = np.zeros((n, 1), np.int32)
+        for i in range(n):
+            u = rng.rand()
+            a = rng.randint(A - 4, A) if (u < 0.45 and "Gather" in ag._action_names) else rng.randint(0, A)
+            arr[i, 0] = a
+            acts[str(i)] = int(a)
+    pl = env.world.planner
+    names = [nm for nm in pl._action_names if nm != "PassiveAgentPlaceholder"]
+    if names:
+        d = pl.action_dim[names[0]]
+        if multi_p:
+            pa = rng.randint(0, d, size=len(names)).astype(np.int32)
+            acts["p"] = [int(x) for x in pa]
+        else:
+            pa = np.array([rng.randint(0, pl.action_spaces)], np.int32)
+            acts["p"] = int(pa[0])
+    else:
+        pa = np.zeros(1, np.int32)
+    return acts, arr, pa
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_oracle_tracks_live_reference(variant):
+    from oracle_lib import OracleEnv
+    from ref_extract import extract_obs, extract_state, rewards_array
+
+    cfg = dict(BASE)
+    cfg.update(VARIANTS[variant])
+    ref = _ref_env(cfg)
+    host = make_env(cfg)
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    np.random.seed(31)
+    st = np.random.get_state()
+    o.t["mt"][0] = st[1]
+    o.t["mt_pos"][0] = st[2]
+    obs = ref.reset()
+    o.reset()
+    rng = np.random.RandomState(5)
+    multi_a = bool(cfg.get("multi_action_mode_agents", False))
+    multi_p = bool(cfg.get("multi_action_mode_planner", True))
+
+    def check(where, obs, rew=None):
+        compare_state({k: v[0] for k, v in o.t.items()}, extract_state(ref), where=where, f64_tol=1e-9)
+        assert np.array_equal(o.t["mt"][0], np.random.get_state()[1]), where + ": MT19937 state"
+        for k, want in extract_obs(ref, obs).items():
+            got = o.t[k][0]
+            if want.dtype.kind in "iu":
+                assert np.array_equal(got, want), "%s: obs %s" % (where, k)
+            else:
+                np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6, err_msg="%s: obs %s" % (where, k))
+        if rew is not None:
+            got = np.concatenate([o.t["rewards_a"][0], o.t["rewards_p"][[0]]])
+            np.testing.assert_allclose(got, rewards_array(ref, rew), rtol=0, atol=1e-5, err_msg=where)
+
+    check(variant + " reset", obs)
+    for t in range(170):
+        acts, aa, pa = _random_actions(ref, rng, multi_a, multi_p)
+        obs, rew, done, _ = ref.step(acts)
+        o.step(aa[None], pa[None])
+        check("%s step %d" % (variant, t + 1), obs, rew)
+        assert bool(o.t["done"][0]) == bool(done["__all__"])
+        if done["__all__"]:
+            obs = ref.reset()
+            o.reset()
+            check("%s reset after step %d" % (variant, t + 1), obs)

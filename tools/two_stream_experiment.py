@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Experiment: does splitting the 4096 replicas into S independent shards stepped on S
+HIP streams (so that one shard's compute phase overlaps another's store phase) help?"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from helpers import make_env  # noqa: E402
+
+E = 4096
+for S in (1, 2, 4):
+    envs, streams = [], []
+    for s in range(S):
+        env = make_env(bench.WORKLOAD, n_envs=E // S, device="cuda:0", env_offset=s * (E // S))
+        env.seed(1)
+        env.reset()
+        envs.append(env)
+        streams.append(torch.cuda.Stream())
+    torch.cuda.synchronize()
+
+    def step_all():
+        for env, st in zip(envs, streams):
+            with torch.cuda.stream(st):
+                a, p = env.backend.sample_random_actions(1234, env.env_offset)
+                env.backend.step(a, p)
+
+    for _ in range(200):
+        step_all()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 1500
+    for _ in range(K):
+        step_all()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("shards=%d  %.1f us/step  %.1f M agent-steps/s" % (S, dt / K * 1e6, E * 4 * K / dt / 1e6))
+    del envs
