@@ -5,15 +5,18 @@ by env.py purely as the owner of device memory / streams.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_AGENTS = 64
+MAX_AGENTS_WIDE = 128
 MAX_COMPONENTS = 8
 MAX_BRACKETS = 16
 MAX_RATES = 64
 N_RES = 2
 MT_N = 624
 
-COMP_BUILD, COMP_CDA, COMP_GATHER, COMP_TAX = 1, 2, 3, 4
+COMP_BUILD, COMP_CDA, COMP_GATHER, COMP_TAX, COMP_SIMPLE_LABOR = 1, 2, 3, 4, 5
+SCN_GTB, SCN_ONE_STEP_ECONOMY = 0, 1
+AGENT_REWARD = {"coin_minus_labor_cost": 0, "isoelastic_coin_minus_labor": 1}
 SKILL = {"none": 0, "pareto": 1, "lognormal": 2}
 TAX_MODEL = {
     "model_wrapper": 0,
@@ -82,6 +85,14 @@ class AieConfig(C.Structure):
         ("tax_bracket_cutoffs", C.c_double * MAX_BRACKETS),
         ("tax_disc_rates", C.c_double * MAX_RATES),
         ("tax_fixed_rates", C.c_double * MAX_BRACKETS),
+        ("scenario", C.c_int32),
+        ("ose_agent_reward_type", C.c_int32),
+        ("ose_labor_exponent", C.c_double),
+        ("ose_labor_cost", C.c_double),
+        ("labor_mask_first_step", C.c_int32),
+        ("labor_num_hours", C.c_int32),
+        ("labor_pmsm", C.c_double),
+        ("labor_skills", C.c_double * MAX_AGENTS_WIDE),
     ]
 
 

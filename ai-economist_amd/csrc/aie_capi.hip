@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "aie_kernels.hip"
+#include "aie_kernels_ose.hip"
 
 struct aie_env {
   aie_params P;
@@ -70,7 +71,8 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
   int rc = aie_build_params(cfg, &env->P, &env->tt, g_create_err, sizeof(g_create_err));
   if (rc != AIE_OK) { delete env; return rc; }
   env->device = device;
-  env->lds = aie::lds_bytes(env->P);
+  const bool ose = cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY;
+  env->lds = ose ? aie::ose_lds_bytes(env->P) : aie::lds_bytes(env->P);
   if (env->lds > 64 * 1024) {
     snprintf(g_create_err, sizeof(g_create_err),
              "per-replica working set (%zu B of LDS) exceeds 64 KiB: reduce max_num_orders / world size", env->lds);
@@ -103,7 +105,7 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
     env->owns_arena = true;
   }
   he = hipMemset(env->arena, 0, (size_t)env->P.arena_bytes);
-  if (he == hipSuccess) {
+  if (he == hipSuccess && !ose) {
     const int64_t tot = (int64_t)env->P.E * env->P.HW;
     hipLaunchKernelGGL(aie_init_cells_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, env->P, env->arena);
     he = hipDeviceSynchronize();
@@ -212,7 +214,9 @@ int aie_download(aie_env* env, const char* name, void* host, int64_t bytes) {
 }
 
 int aie_set_layout(aie_env* env, const uint8_t* stone_src, const uint8_t* wood_src, const uint8_t* water) {
-  if (!env || !stone_src || !wood_src) return AIE_E_INVALID;
+  if (!env) return AIE_E_INVALID;
+  if (env->P.c.scenario != AIE_SCN_GTB) return AIE_OK;  // map-less scenario: nothing to set
+  if (!stone_src || !wood_src) return AIE_E_INVALID;
   const aie_params& P = env->P;
   const int shared = P.c.shared_layout ? 1 : 0;
   const int64_t cnt = (shared ? 1 : (int64_t)P.E) * P.HW;
@@ -258,8 +262,12 @@ int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos) {
 int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
   if (!env) return AIE_E_INVALID;
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
-  hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
-                     static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
+  if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
+    hipLaunchKernelGGL(aie_ose_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
+  else
+    hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
 }
@@ -267,8 +275,12 @@ int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
 int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream) {
   if (!env) return AIE_E_INVALID;
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
-  hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
-                     static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
+  if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
+    hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
+  else
+    hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
 }

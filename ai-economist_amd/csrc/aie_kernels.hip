@@ -19,6 +19,7 @@
 //
 // Each __device__ function cites the reference function it implements (paths relative
 // to the reference tree, F/ = ai_economist/foundation/).
+#pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -131,6 +132,15 @@ __device__ __forceinline__ void stream_out(const float* __restrict__ lds_src, fl
 // q / d for a run-time constant d with host-computed magic (aie_layout.h: aie__magic)
 __device__ __forceinline__ int udiv(int q, int d, uint32_t magic) {
   return d == 1 ? q : (int)__umulhi((uint32_t)q, magic);
+}
+// XCD-aware workgroup -> replica mapping.  The dispatcher places workgroup b on XCD b % 8
+// (observed, used for speed only): give every XCD a CONTIGUOUS range of replicas so that
+// the 128-byte lines shared by neighbouring replicas in the env-major tensors (rewards,
+// done, flat vectors whose per-replica size is not a multiple of 128 B) are completed
+// inside one L2 instead of being written back as partial lines by two of them.
+__device__ __forceinline__ int replica_of_block(int b, int E) {
+  if (E & 7) return b;
+  return (b & 7) * (E >> 3) + (b >> 3);
 }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
@@ -436,7 +446,7 @@ __device__ __forceinline__ void decode_actions(const Ctx& c, Agents& A, const in
   uint32_t act = 0;
   if (i < P.n && aa) {
     const int32_t* a = aa + ((int64_t)c.e * P.n + i) * P.act_a_width;
-    static const int shift[AIE_N_SUB_SLOTS] = {0, 4, 11, 18, 25, 1};
+    static const int shift[AIE_N_SUB_SLOTS] = {0, 4, 11, 18, 25, 1, 0};
     if (P.c.multi_action_mode_agents) {
       for (int s = 0; s < P.n_sub_a; ++s) {
         const int v = a[s];
@@ -1407,7 +1417,7 @@ aie_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ are
   // The parameter block lives in device memory (uniform scalar loads).  Passing the 2.7 KB
   // struct by value made the compiler copy it to scratch on every launch (5x slower).
   const aie_params& P = *params;
-  const Ctx c = make_ctx(P, lds, (int)blockIdx.x, (int)threadIdx.x);
+  const Ctx c = make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)threadIdx.x);
   MT m;
   Agents A;
   if (c.tid == 0) *c.srcn = 0;
@@ -1462,7 +1472,7 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   using namespace aie;
   const aie_params& P = *params;
-  const int e = (int)blockIdx.x;
+  const int e = replica_of_block((int)blockIdx.x, P.E);
   if (mask && !mask[e]) return;
   const Ctx c = make_ctx(P, lds, e, (int)threadIdx.x);
   const int n = P.n, HW = P.HW, tid = c.tid;

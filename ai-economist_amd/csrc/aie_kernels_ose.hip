@@ -1,0 +1,423 @@
+// aie_kernels_ose.hip -- "one-step-economy" + SimpleLabor + PeriodicBracketTax
+// (BASELINE configs[4]): a map-less scenario with up to 128 agents per replica.
+//
+// One wavefront per replica; agents are strided over the 64 lanes (lane l owns agents
+// l and l + 64).  State is a few f64 vectors in LDS; the step is dominated by writing the
+// observations (each agent's flat vector repeats the shared tax fragment: ~88 KB per
+// replica-step at n = 100), so the shared part is built once in LDS and streamed out.
+//
+// Reference: F/scenarios/one_step_economy/one_step_economy.py,
+// F/components/simple_labor.py, F/components/redistribution.py.
+#include "aie_kernels.hip"
+
+namespace aie {
+
+struct OseScratch {
+  int32_t* act;      // [n] SimpleLabor action per agent
+  double* sorted;    // [n] sorted incomes / sorted coin
+  double* coin;      // [n]
+  double* tmp;       // [n]
+  double* part;      // [n + 1]
+  float* tmpl_a;     // [FA] shared part of an agent's flat vector
+  float* tmpl_p;     // [FP]
+};
+
+__host__ __device__ inline size_t ose_lds_bytes(const aie_params& P) {
+  size_t b = (size_t)rec_lds_bytes(P);
+  b += AIE_MAX_BRACKETS * 4 + (size_t)P.n * 4;
+  b = (b + 15) / 16 * 16;
+  b += (size_t)(4 * P.n + 2) * 8;
+  b += (size_t)(pad4(P.FA) + pad4(P.FP)) * 4;
+  return (b + 15) / 16 * 16;
+}
+
+__device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, int e, int tid, OseScratch& s) {
+  uint8_t* q = lds + rec_lds_bytes(P);
+  int32_t* act_p = reinterpret_cast<int32_t*>(q);
+  q += AIE_MAX_BRACKETS * 4;
+  s.act = reinterpret_cast<int32_t*>(q);
+  q += P.n * 4;
+  q = lds + ((q - lds) + 15) / 16 * 16;
+  s.sorted = reinterpret_cast<double*>(q);
+  s.coin = s.sorted + P.n;
+  s.tmp = s.coin + P.n;
+  s.part = s.tmp + P.n;
+  q += (4 * P.n + 2) * 8;
+  s.tmpl_a = reinterpret_cast<float*>(q);
+  s.tmpl_p = s.tmpl_a + pad4(P.FA);
+  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tid, e};
+}
+
+__device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {
+  const uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
+  const uint4* src = reinterpret_cast<const uint4*>(g);
+  uint4* dst = reinterpret_cast<uint4*>(c.rec);
+  const int nq = rec_lds_bytes(c.P) >> 4;
+  for (int q = c.tid; q < nq; q += AIE_NT) dst[q] = src[q];
+  const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
+  m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
+}
+
+// SimpleLabor.component_step simple_labor.py:105-126.  The random agent order
+// (world.py:418-422) is drawn -- it advances the stream -- but the result does not depend
+// on it, so the update itself runs one lane per agent.
+__device__ __forceinline__ void labor_component_step(const Ctx& c, const OseScratch& s, MT& m) {
+  const int n = c.P.n;
+  for (int i = n - 1; i >= 1; --i) (void)rng_interval(m, c.tid, (uint32_t)i);
+  for (int i = c.tid; i < n; i += AIE_NT) {
+    const int a = s.act[i];
+    if (a != 0) {
+      R_F64(c, o_labor)[i] = (double)a;  // hours worked this step (set, not accumulated)
+      const double payoff = (double)a * R_F64(c, o_skill)[i];
+      R_F64(c, o_production)[i] += payoff;
+      R_F64(c, o_inv_coin)[i] += payoff;
+    }
+  }
+  __syncthreads();
+}
+
+// PeriodicBracketTax.component_step :945-972 with enact_taxes :853-915
+__device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseScratch& s) {
+  const int n = c.P.n;
+  int pos = uni(*R_I32(c, o_tax_cycle_pos));
+  if (pos == 1 && c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER && !c.P.c.tax_disable) {
+    if (c.tid < c.P.NB) {
+      const int a = c.act_p[c.tid];
+      if (a > 0 && a <= c.P.c.tax_n_disc_rates) R_I32(c, o_tax_rate_idx)[c.tid] = a - 1;
+    }
+    __syncthreads();
+  }
+  if (pos >= c.P.c.tax_period) {
+    for (int i = c.tid; i < n; i += AIE_NT) {
+      const double coin = R_F64(c, o_inv_coin)[i];
+      const double income = (coin + R_F64(c, o_esc_coin)[i]) - R_F64(c, o_tax_last_coin)[i];
+      const double due = tax_due(c, income);
+      const double eff = coin < due ? coin : due;
+      R_F64(c, o_tax_last_marginal_rate)[i] = tax_marginal_rate(c, income);
+      R_F64(c, o_tax_last_income)[i] = income;
+      R_F64(c, o_inv_coin)[i] = coin - eff;
+      s.tmp[i] = eff;
+    }
+    __syncthreads();
+    double net = 0;  // running sum in agent order, as the reference accumulates it
+    for (int j = 0; j < n; ++j) net += s.tmp[j];
+    const double lump = net / (double)n;
+    for (int i = c.tid; i < n; i += AIE_NT) {
+      const double v = R_F64(c, o_inv_coin)[i] + lump;
+      R_F64(c, o_inv_coin)[i] = v;
+      R_F64(c, o_tax_last_coin)[i] = v + R_F64(c, o_esc_coin)[i];
+    }
+    if (c.tid == 0) *R_F64(c, o_tax_total_collected) += net;
+    pos = 0;
+    __syncthreads();
+  }
+  if (c.tid == 0) *R_I32(c, o_tax_cycle_pos) = pos + 1;
+  __syncthreads();
+}
+
+// ascending sort of src[0..n) into dst by counting ranks (one lane per element)
+__device__ __forceinline__ void rank_sort(const double* src, double* dst, int n, int tid) {
+  for (int i = tid; i < n; i += AIE_NT) {
+    const double x = src[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const double y = src[j];
+      rank += (y < x || (y == x && j < i)) ? 1 : 0;
+    }
+    dst[rank] = x;
+  }
+}
+
+// social_metrics.get_gini (social_metrics.py:10-46) of s.coin; lane 0 only, sorted copy
+// must be in s.sorted for n >= 30.
+__device__ __forceinline__ double ose_gini(const OseScratch& s, double* cs, int n) {
+  if (n < 30) {
+    double diff = 0;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) diff += fabs(s.coin[i] - s.coin[j]);
+    const double unscaled = diff / (2 * n * np_sum_small(s.coin, n) + 1e-10);
+    return unscaled / ((double)(n - 1) / (double)n);
+  }
+  const double tot = np_sum_small(s.sorted, n) + 1e-10;
+  double run = 0;
+  for (int i = 0; i < n; ++i) {
+    run += s.sorted[i];
+    cs[i] = run / tot;
+  }
+  return 1 - (2.0 / (n + 1)) * np_sum_small(cs, n);
+}
+
+// get_current_optimization_metrics one_step_economy.py:280-336 -> s.part[0..n]
+__device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s) {
+  const aie_params& P = c.P;
+  const int n = P.n;
+  for (int i = c.tid; i < n; i += AIE_NT) {
+    const double coin = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
+    const double labor = R_F64(c, o_labor)[i];
+    s.coin[i] = coin;
+    double u;
+    if (P.c.ose_agent_reward_type == AIE_AGENT_REW_ISOELASTIC) {
+      const double eta = P.c.isoelastic_eta;
+      const double uc = (eta == 1.0) ? log(coin > 1 ? coin : 1) : (pow(coin, 1 - eta) - 1) / (1 - eta);
+      u = uc - labor * P.c.ose_labor_cost;
+    } else {
+      u = coin - pow(labor, P.c.ose_labor_exponent) * P.c.ose_labor_cost;
+    }
+    s.part[i] = u;
+  }
+  __syncthreads();
+  const int prt = P.c.planner_reward_type;
+  if (prt == AIE_PLANNER_REW_COIN_EQ_TIMES_PROD) {
+    if (n >= 30) rank_sort(s.coin, s.sorted, n, c.tid);
+    __syncthreads();
+    if (c.tid == 0) {
+      const double ew = 1 - P.c.mixing_weight_gini_vs_coin;
+      const double prod = np_sum_small(s.coin, n) / n;
+      s.part[n] = (ew * (1 - ose_gini(s, s.tmp, n)) + (1 - ew)) * prod;
+    }
+  } else {
+    const bool use_util = prt == AIE_PLANNER_REW_INV_INCOME_UTIL;
+    for (int i = c.tid; i < n; i += AIE_NT) {
+      const double base = use_util ? R_F64(c, o_production)[i] : s.coin[i];
+      s.tmp[i] = 1 / (base > 1 ? base : 1);
+    }
+    __syncthreads();
+    const double sw = np_sum_small(s.tmp, n);  // every lane, same value
+    for (int i = c.tid; i < n; i += AIE_NT) s.sorted[i] = (use_util ? s.part[i] : s.coin[i]) * (s.tmp[i] / sw);
+    __syncthreads();
+    if (c.tid == 0) s.part[n] = np_sum_small(s.sorted, n);
+  }
+  __syncthreads();
+}
+
+// Observations + masks (one_step_economy.py:120-176, simple_labor.py:97-103,128-134,
+// redistribution.py:974-1104), flat vectors in sorted-key order (base_env.py:561-612).
+__device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseScratch& s, uint8_t* __restrict__ arena) {
+  const aie_params& P = c.P;
+  const int n = P.n, NB = P.NB, tid = c.tid;
+  const int t = *R_I32(c, o_timestep);
+  const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)P.c.episode_length : 1.0));
+  // ---- shared quantities ----
+  if (P.has_tax) {
+    const double per = (double)P.c.tax_period;
+    for (int i = tid; i < n; i += AIE_NT) s.tmp[i] = R_F64(c, o_tax_last_income)[i] / per;
+    __syncthreads();
+    rank_sort(s.tmp, s.sorted, n, tid);
+    __syncthreads();
+    const int pos = *R_I32(c, o_tax_cycle_pos);
+    for (int j = tid; j < NB + n + 4; j += AIE_NT) {
+      float v;
+      if (j < NB) v = (float)tax_rate(c, j);
+      else if (j == NB) v = pos == 1 ? 1.0f : 0.0f;               // is_first_day
+      else if (j == NB + 1) v = pos >= P.c.tax_period ? 1.0f : 0.0f;  // is_tax_day
+      else if (j < NB + 2 + n) v = (float)s.sorted[j - NB - 2];   // last_incomes (sorted)
+      else v = (float)((double)pos / per);                        // tax_phase
+      if (j != NB + 2 + n) s.tmpl_a[P.fa_tax + j] = v;            // [NB+2+n] = marginal_rate: per agent
+      if (j < NB + 2 + n) s.tmpl_p[P.fp_tax + j] = v;
+      else if (j == NB + 3 + n) s.tmpl_p[P.fp_tax + NB + 2 + n] = v;
+    }
+  }
+  for (int i = tid; i < n; i += AIE_NT) {
+    const double coin = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
+    s.coin[i] = coin;
+    if (P.has_tax) s.tmp[i] = tax_marginal_rate(c, coin - R_F64(c, o_tax_last_coin)[i]);
+  }
+  if (tid == 0) {
+    s.tmpl_a[P.fa_time] = tval;
+    s.tmpl_p[P.fp_time] = tval;
+    reinterpret_cast<float*>(arena + P.a_obs_p_time)[c.e] = tval;
+  }
+  __syncthreads();
+  // planner world-equality / world-normalized_per_capita_productivity (:161-172)
+  if (n >= 30) rank_sort(s.coin, s.sorted, n, tid);
+  __syncthreads();
+  if (tid == 0) {
+    // s.part is free here (rewards are computed afterwards)
+    s.tmpl_p[P.fp_world + 0] = (float)(1 - ose_gini(s, s.part, n));
+    s.tmpl_p[P.fp_world + 1] = (float)(np_sum_small(s.coin, n) / n / 1000);
+  }
+  __syncthreads();
+  // ---- agent flat vectors: the shared template with two per-agent entries ----
+  {
+    float* g = reinterpret_cast<float*>(arena + P.a_obs_a_flat) + (int64_t)c.e * n * P.FA;
+    const int i_mr = P.has_tax ? P.fa_tax + NB + 2 + n : -1;
+    const int i_sk = P.has_labor ? P.fa_labor : -1;
+    for (int q = tid; q < n * P.FA; q += AIE_NT) {
+      const int i = udiv(q, P.FA, P.mg_FA);
+      const int j = q - i * P.FA;
+      float v = s.tmpl_a[j];
+      if (j == i_mr) v = (float)s.tmp[i];
+      if (j == i_sk) v = (float)(R_F64(c, o_skill)[i] / P.c.labor_pmsm);
+      g[q] = v;
+    }
+    float* gt = reinterpret_cast<float*>(arena + P.a_obs_a_time) + (int64_t)c.e * n;
+    for (int i = tid; i < n; i += AIE_NT) gt[i] = tval;
+    if (P.FPA) {
+      float* gp = reinterpret_cast<float*>(arena + P.a_obs_p_agents) + (int64_t)c.e * n * P.FPA;
+      for (int i = tid; i < n; i += AIE_NT) {
+        gp[i * 3 + 0] = (float)s.tmp[i];
+        gp[i * 3 + 1] = (float)(R_F64(c, o_tax_last_income)[i] / (double)P.c.tax_period);
+        gp[i * 3 + 2] = (float)R_F64(c, o_tax_last_marginal_rate)[i];
+      }
+    }
+    stream_out(s.tmpl_p, reinterpret_cast<float*>(arena + P.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
+  }
+  // ---- masks ----
+  {
+    float on = 1.0f;
+    if (P.has_labor) {
+      const int first = *R_I32(c, o_first_step);
+      if (first && P.c.labor_mask_first_step) on = 0.0f;
+    }
+    const bool multi = P.c.multi_action_mode_agents != 0;
+    float* g = reinterpret_cast<float*>(arena + P.a_obs_a_mask) + (int64_t)c.e * n * P.MA;
+    for (int q = tid; q < n * P.MA; q += AIE_NT) {
+      const int i = udiv(q, P.MA, P.mg_MA);
+      const int mm = q - i * P.MA;
+      // single-action: [NO-OP, hours...]; multi-action: [NO-OP, hours...] of the only subspace
+      g[q] = (mm == 0 || P.n_sub_a == 0) ? 1.0f : on;
+      (void)multi;
+    }
+    const bool pmulti = P.c.multi_action_mode_planner != 0;
+    const float open = (P.n_sub_p && *R_I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
+    float* gp = reinterpret_cast<float*>(arena + P.a_obs_p_mask) + (int64_t)c.e * P.MP;
+    for (int q = tid; q < P.MP; q += AIE_NT) {
+      float v;
+      if (P.n_sub_p == 0) v = 1.0f;
+      else if (pmulti) v = (q - udiv(q, 1 + P.sub_p_dim, P.mg_sub_p) * (1 + P.sub_p_dim) == 0) ? 1.0f : open;
+      else v = (q == 0) ? 1.0f : open;
+      gp[q] = v;
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && P.has_labor) *R_I32(c, o_first_step) = 0;
+}
+
+__device__ __forceinline__ void ose_store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m) {
+  uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
+  uint4* dst = reinterpret_cast<uint4*>(g);
+  const uint4* src = reinterpret_cast<const uint4*>(c.rec);
+  const int nq = rec_lds_bytes(c.P) >> 4;
+  for (int q = c.tid; q < nq; q += AIE_NT) dst[q] = src[q];
+  uint32_t* key = reinterpret_cast<uint32_t*>(g + c.P.o_mt);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
+  if (c.tid < 48) key[576 + c.tid] = m.r[9];
+}
+
+}  // namespace aie
+
+// BaseEnvironment.step (base_env.py:929-1032) for the one-step-economy scenario
+extern "C" __global__ void __launch_bounds__(AIE_NT)
+aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  using namespace aie;
+  const aie_params& P = *params;
+  OseScratch s;
+  const Ctx c = ose_make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)threadIdx.x, s);
+  const int n = P.n, tid = c.tid;
+  MT m;
+  ose_load_record(c, arena, m);
+  // parse_actions (base_agent.py:407-438)
+  for (int i = tid; i < n; i += AIE_NT) {
+    int a = 0;
+    if (act_a && P.n_sub_a) {
+      const int v = act_a[((int64_t)c.e * n + i) * P.act_a_width];
+      if (P.c.multi_action_mode_agents) a = (v >= 0 && v <= P.sub_a_dim[0]) ? v : 0;
+      else a = (v >= 1 && v < 1 + P.sub_a_dim[0]) ? v : 0;
+    }
+    s.act[i] = a;
+  }
+  if (tid < AIE_MAX_BRACKETS) {
+    int v = 0;
+    if (act_p && tid < P.n_sub_p) {
+      const int32_t* a = act_p + (int64_t)c.e * P.act_p_width;
+      if (P.c.multi_action_mode_planner) v = a[tid];
+      else {
+        const int x = a[0];
+        if (x >= 1 && x < 1 + P.n_sub_p * P.sub_p_dim && (x - 1) / P.sub_p_dim == tid) v = (x - 1) % P.sub_p_dim + 1;
+      }
+    }
+    c.act_p[tid] = v;
+  }
+  __syncthreads();
+  m.pos = uni(*R_I32(c, o_mt_pos));
+  if (tid == 0) *R_I32(c, o_timestep) += 1;
+  for (int k = 0; k < P.c.n_components; ++k) {
+    if (P.c.components[k] == AIE_COMP_SIMPLE_LABOR) labor_component_step(c, s, m);
+    else if (P.c.components[k] == AIE_COMP_TAX) ose_tax_component_step(c, s);
+  }
+  if (tid == 0) *R_I32(c, o_mt_pos) = m.pos;
+  __syncthreads();
+  ose_write_observations(c, s, arena);
+  __syncthreads();
+  // compute_reward one_step_economy.py:195-222
+  ose_metrics(c, s);
+  {
+    double* util = R_F64(c, o_util);
+    for (int i = tid; i <= n; i += AIE_NT) {
+      const double r = s.part[i] - util[i];
+      util[i] = s.part[i];
+      if (i < n) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)c.e * n + i] = (float)r;
+      else reinterpret_cast<float*>(arena + P.a_rew_p)[c.e] = (float)r;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
+    (arena + P.a_done)[c.e] = (uint8_t)done;
+    if (done) *R_I32(c, o_completions) += 1;
+  }
+  __syncthreads();
+  ose_store_record(c, arena, m);
+}
+
+// reset: one_step_economy.py:99-118 + simple_labor.py:76-95 + redistribution.py:1109-1139
+// + additional_reset_steps :224-241.  No random draws.
+extern "C" __global__ void __launch_bounds__(AIE_NT)
+aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                     const uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  using namespace aie;
+  const aie_params& P = *params;
+  const int e = replica_of_block((int)blockIdx.x, P.E);
+  if (mask && !mask[e]) return;
+  OseScratch s;
+  const Ctx c = ose_make_ctx(P, lds, e, (int)threadIdx.x, s);
+  const int n = P.n, tid = c.tid;
+  MT m;
+  ose_load_record(c, arena, m);
+  __syncthreads();
+  for (int i = tid; i < n; i += AIE_NT) {
+    R_F64(c, o_inv_coin)[i] = 0; R_F64(c, o_esc_coin)[i] = 0; R_F64(c, o_labor)[i] = 0;
+    R_F64(c, o_skill)[i] = P.has_labor ? P.c.labor_skills[i] : 0;
+    R_F64(c, o_production)[i] = 0;
+    if (P.has_tax) {
+      R_F64(c, o_tax_last_coin)[i] = 0; R_F64(c, o_tax_last_income)[i] = 0; R_F64(c, o_tax_last_marginal_rate)[i] = 0;
+    }
+  }
+  if (tid == 0) {
+    *R_I32(c, o_timestep) = 0;
+    *R_I32(c, o_first_step) = 1;
+    if (P.has_tax) {
+      *R_I32(c, o_tax_cycle_pos) = 1;
+      *R_F64(c, o_tax_total_collected) = 0;
+    }
+  }
+  if (P.has_tax && tid < P.NB) R_I32(c, o_tax_rate_idx)[tid] = 0;
+  __syncthreads();
+  ose_metrics(c, s);
+  for (int i = tid; i <= n; i += AIE_NT) R_F64(c, o_util)[i] = s.part[i];
+  __syncthreads();
+  ose_write_observations(c, s, arena);
+  for (int i = tid; i < n; i += AIE_NT) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + i] = 0.0f;
+  if (tid == 0) {
+    reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.0f;
+    (arena + P.a_done)[e] = 0;
+  }
+  __syncthreads();
+  ose_store_record(c, arena, m);
+}

@@ -38,7 +38,8 @@ enum {
   AIE_SUB_BUY1 = 3,  /* Buy_Wood   */
   AIE_SUB_SELL1 = 4, /* Sell_Wood  */
   AIE_SUB_GATHER = 5,
-  AIE_N_SUB_SLOTS = 6
+  AIE_SUB_LABOR = 6, /* SimpleLabor (one-step-economy) */
+  AIE_N_SUB_SLOTS = 7
 };
 
 /* Everything a kernel needs, passed BY VALUE as the kernel argument. */
@@ -52,7 +53,7 @@ typedef struct aie_params {
   int32_t M;        /* order-book capacity per commodity side = n * max_num_orders     */
   int32_t CM;       /* map channels in Maps.state: 5 (no water) or 6                   */
   int32_t WV;       /* egocentric window edge = 2*obs_range + 1                        */
-  int32_t has_build, has_cda, has_gather, has_tax;
+  int32_t has_build, has_cda, has_gather, has_tax, has_labor;
   int32_t planner_acts; /* 1 if the planner has tax action subspaces                   */
 
   /* action spaces */
@@ -71,6 +72,7 @@ typedef struct aie_params {
   int32_t fa_build, fa_cda, fa_gather, fa_tax, fa_time, fa_world;
   int32_t fp_cda, fp_tax, fp_time, fp_world;
   int32_t fpa_tax, fpa_world;
+  int32_t fa_labor;                     /* one-step-economy: SimpleLabor-skill            */
   int32_t MA, MP;                       /* flattened mask sizes                        */
 
   /* per-replica record: byte offsets */
@@ -85,6 +87,7 @@ typedef struct aie_params {
   int32_t o_tax_cycle_pos, o_tax_rate_idx, o_tax_last_coin, o_tax_last_income;
   int32_t o_tax_last_marginal_rate, o_tax_total_collected;
   int32_t o_timestep, o_completions, o_auto_warmup;
+  int32_t o_skill, o_production, o_first_step; /* one-step-economy / SimpleLabor           */
   int32_t o_mt, o_mt_pos, o_mt_has_gauss, o_mt_gauss;
 
   /* arena: byte offsets of the dense regions */
@@ -165,6 +168,120 @@ static inline void aie__add(aie_tensor_table* tt, const char* name, int dtype, i
   d->data = NULL;
 }
 
+/* one-step-economy (F/scenarios/one_step_economy/one_step_economy.py): no map, agents
+ * hold coin / labor / skill / production; flat observations in sorted-key order:
+ *   agent   PeriodicBracketTax-{curr_rates,is_first_day,is_tax_day,last_incomes,
+ *           marginal_rate,tax_phase}, SimpleLabor-skill, time
+ *   planner PeriodicBracketTax-{curr_rates,is_first_day,is_tax_day,last_incomes,tax_phase},
+ *           time, world-equality, world-normalized_per_capita_productivity
+ *   p{i}    PeriodicBracketTax-{curr_marginal_rate,last_income,last_marginal_rate}      */
+static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p, aie_tensor_table* tt) {
+  const int n = p->n;
+  int f = 0;
+  p->fa_tax = f;   if (p->has_tax) f += p->NB + n + 4;
+  p->fa_labor = f; if (p->has_labor) f += 1;
+  p->fa_time = f;  f += 1;
+  p->fa_world = f;
+  p->FA = f;
+  f = 0;
+  p->fp_tax = f;   if (p->has_tax) f += p->NB + n + 3;
+  p->fp_time = f;  f += 1;
+  p->fp_world = f; f += 2;
+  p->FP = f;
+  p->fpa_tax = 0;
+  p->fpa_world = p->has_tax ? 3 : 0;
+  p->FPA = p->has_tax ? 3 : 0;
+  p->mg_FA = aie__magic(p->FA);
+  p->mg_MA = aie__magic(p->MA);
+
+  int32_t cur = 0;
+  p->o_inv_coin = aie__rec(&cur, 8 * n, 16);
+  p->o_esc_coin = aie__rec(&cur, 8 * n, 8);
+  p->o_labor = aie__rec(&cur, 8 * n, 8);
+  p->o_skill = aie__rec(&cur, 8 * n, 8);
+  p->o_production = aie__rec(&cur, 8 * n, 8);
+  p->o_util = aie__rec(&cur, 8 * (n + 1), 8);
+  if (p->has_tax) {
+    p->o_tax_last_coin = aie__rec(&cur, 8 * n, 8);
+    p->o_tax_last_income = aie__rec(&cur, 8 * n, 8);
+    p->o_tax_last_marginal_rate = aie__rec(&cur, 8 * n, 8);
+    p->o_tax_total_collected = aie__rec(&cur, 8, 8);
+    p->o_tax_cycle_pos = aie__rec(&cur, 4, 4);
+    p->o_tax_rate_idx = aie__rec(&cur, 4 * p->NB, 4);
+  }
+  p->o_timestep = aie__rec(&cur, 4, 4);
+  p->o_completions = aie__rec(&cur, 4, 4);
+  p->o_auto_warmup = aie__rec(&cur, 4, 4);
+  p->o_first_step = aie__rec(&cur, 4, 4);
+  p->o_mt_gauss = aie__rec(&cur, 8, 8);
+  p->o_mt_pos = aie__rec(&cur, 4, 4);
+  p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
+  p->o_mt = aie__rec(&cur, 4 * AIE_MT_N, 16);
+  p->rec_bytes = (int32_t)aie__align(cur, 16);
+
+  const int64_t E = p->E;
+  int64_t a = 0;
+  p->a_records = a;      a = aie__align(a + E * (int64_t)p->rec_bytes, 256);
+  p->a_obs_a_flat = a;   a = aie__align(a + E * n * p->FA * 4, 256);
+  p->a_obs_a_mask = a;   a = aie__align(a + E * n * p->MA * 4, 256);
+  p->a_obs_a_time = a;   a = aie__align(a + E * n * 4, 256);
+  p->a_obs_p_flat = a;   a = aie__align(a + E * p->FP * 4, 256);
+  p->a_obs_p_mask = a;   a = aie__align(a + E * p->MP * 4, 256);
+  p->a_obs_p_time = a;   a = aie__align(a + E * 4, 256);
+  p->a_obs_p_agents = a; a = aie__align(a + E * n * (p->FPA ? p->FPA : 1) * 4, 256);
+  p->a_rew_a = a; a = aie__align(a + E * n * 4, 256);
+  p->a_rew_p = a; a = aie__align(a + E * 4, 256);
+  p->a_done = a;  a = aie__align(a + E, 256);
+  p->arena_bytes = a;
+
+  if (tt) {
+    const int64_t rs = p->rec_bytes, r0 = p->a_records;
+#define REC(name, dt, off, nd, d0) aie__add(tt, name, dt, r0 + (off), rs, nd, d0, 0, 0, 0, E)
+    REC("inv_coin", AIE_F64, p->o_inv_coin, 1, n);
+    REC("esc_coin", AIE_F64, p->o_esc_coin, 1, n);
+    REC("labor", AIE_F64, p->o_labor, 1, n);
+    REC("skill", AIE_F64, p->o_skill, 1, n);
+    REC("production", AIE_F64, p->o_production, 1, n);
+    REC("util", AIE_F64, p->o_util, 1, n + 1);
+    if (p->has_tax) {
+      REC("tax_cycle_pos", AIE_I32, p->o_tax_cycle_pos, 0, 0);
+      REC("tax_rate_idx", AIE_I32, p->o_tax_rate_idx, 1, p->NB);
+      REC("tax_last_coin", AIE_F64, p->o_tax_last_coin, 1, n);
+      REC("tax_last_income", AIE_F64, p->o_tax_last_income, 1, n);
+      REC("tax_last_marginal_rate", AIE_F64, p->o_tax_last_marginal_rate, 1, n);
+      REC("tax_total_collected", AIE_F64, p->o_tax_total_collected, 0, 0);
+    }
+    REC("timestep", AIE_I32, p->o_timestep, 0, 0);
+    REC("completions", AIE_I32, p->o_completions, 0, 0);
+    REC("labor_first_step", AIE_I32, p->o_first_step, 0, 0);
+    REC("mt", AIE_U32, p->o_mt, 1, AIE_MT_N);
+    REC("mt_pos", AIE_I32, p->o_mt_pos, 0, 0);
+    REC("mt_has_gauss", AIE_I32, p->o_mt_has_gauss, 0, 0);
+    REC("mt_gauss", AIE_F64, p->o_mt_gauss, 0, 0);
+#undef REC
+#define DENSE(name, dt, off, nd, d0, d1)                                                    \
+  do {                                                                                      \
+    int64_t dd[2] = {d0, d1};                                                               \
+    int64_t es = aie__dtype_size(dt);                                                       \
+    for (int q = 0; q < nd; ++q) es *= dd[q];                                               \
+    aie__add(tt, name, dt, off, es, nd, d0, d1, 0, 0, E);                                   \
+  } while (0)
+    DENSE("obs_a_flat", AIE_F32, p->a_obs_a_flat, 2, n, p->FA);
+    DENSE("obs_a_action_mask", AIE_F32, p->a_obs_a_mask, 2, n, p->MA);
+    DENSE("obs_a_time", AIE_F32, p->a_obs_a_time, 2, n, 1);
+    DENSE("obs_p_flat", AIE_F32, p->a_obs_p_flat, 1, p->FP, 0);
+    DENSE("obs_p_action_mask", AIE_F32, p->a_obs_p_mask, 1, p->MP, 0);
+    DENSE("obs_p_time", AIE_F32, p->a_obs_p_time, 1, 1, 0);
+    if (p->FPA) DENSE("obs_p_agents", AIE_F32, p->a_obs_p_agents, 2, n, p->FPA);
+    DENSE("rewards_a", AIE_F32, p->a_rew_a, 1, n, 0);
+    DENSE("rewards_p", AIE_F32, p->a_rew_p, 0, 0, 0);
+    DENSE("done", AIE_U8, p->a_done, 0, 0, 0);
+#undef DENSE
+  }
+  (void)c;
+  return AIE_OK;
+}
+
 /* Validates the config (mirrors the reference's constructor asserts) and derives
  * every dimension / offset.  `tt` may be NULL. */
 static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tensor_table* tt,
@@ -174,23 +291,32 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   if (c->abi_version != AIE_ABI_VERSION) AIE__FAIL("abi_version %d != %d", c->abi_version, AIE_ABI_VERSION);
   if (c->n_envs < 1) AIE__FAIL("n_envs must be >= 1");
   if (c->n_agents < 2) AIE__FAIL("n_agents must be >= 2 (base_env.py:223)");
-  if (c->n_agents > AIE_MAX_AGENTS - 2) AIE__FAIL("n_agents > %d unsupported", AIE_MAX_AGENTS - 2);
+  if (c->scenario != AIE_SCN_GTB && c->scenario != AIE_SCN_ONE_STEP_ECONOMY) AIE__FAIL("unknown scenario %d", c->scenario);
+  if (c->scenario == AIE_SCN_GTB && c->n_agents > AIE_MAX_AGENTS - 2)
+    AIE__FAIL("n_agents > %d unsupported for spatial scenarios", AIE_MAX_AGENTS - 2);
+  if (c->scenario == AIE_SCN_ONE_STEP_ECONOMY && c->n_agents > AIE_MAX_AGENTS_WIDE)
+    AIE__FAIL("n_agents > %d unsupported for one-step-economy", AIE_MAX_AGENTS_WIDE);
   if (c->world_h < 1 || c->world_w < 1 || c->world_h > 255 || c->world_w > 255)
     AIE__FAIL("world_size out of range");
   if (c->episode_length < 1) AIE__FAIL("episode_length must be >= 1 (base_env.py:254)");
   if (c->n_components < 0 || c->n_components > AIE_MAX_COMPONENTS) AIE__FAIL("bad n_components");
   for (int i = 0; i < c->n_components; ++i) {
     int k = c->components[i];
-    if (k < AIE_COMP_BUILD || k > AIE_COMP_TAX) AIE__FAIL("unknown component id %d", k);
+    if (k < AIE_COMP_BUILD || k > AIE_COMP_SIMPLE_LABOR) AIE__FAIL("unknown component id %d", k);
+    if (c->scenario == AIE_SCN_GTB && k == AIE_COMP_SIMPLE_LABOR)
+      AIE__FAIL("SimpleLabor is only supported with the one-step-economy scenario");
+    if (c->scenario == AIE_SCN_ONE_STEP_ECONOMY && k != AIE_COMP_SIMPLE_LABOR && k != AIE_COMP_TAX)
+      AIE__FAIL("one-step-economy supports SimpleLabor and PeriodicBracketTax only");
     for (int j = 0; j < i; ++j)
       if (c->components[j] == k) AIE__FAIL("component %d listed twice", k);
   }
-  if (c->full_observability) {
+  const int gtb = c->scenario == AIE_SCN_GTB;
+  if (gtb && c->full_observability) {
     if (err) snprintf(err, errlen, "full_observability=True is not supported yet");
     return AIE_E_UNSUPPORTED;
   }
-  if (c->obs_range < 0 || c->obs_range > 15) AIE__FAIL("mobile_agent_observation_range out of range");
-  for (int r = 0; r < AIE_N_RES; ++r) {
+  if (gtb && (c->obs_range < 0 || c->obs_range > 15)) AIE__FAIL("mobile_agent_observation_range out of range");
+  for (int r = 0; gtb && r < AIE_N_RES; ++r) {
     if (c->regen_halfwidth[r] != 0) {
       if (err) snprintf(err, errlen, "regen_halfwidth > 0 is not supported (bit-exact guarantee is for 0)");
       return AIE_E_UNSUPPORTED;
@@ -200,8 +326,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   }
   if (!(c->starting_agent_coin >= 0.0)) AIE__FAIL("starting_agent_coin must be >= 0");
   if (!(c->isoelastic_eta >= 0.0 && c->isoelastic_eta <= 1.0)) AIE__FAIL("isoelastic_eta not in [0,1]");
-  if (!(c->energy_cost >= 0.0)) AIE__FAIL("energy_cost must be >= 0");
-  if (!(c->energy_warmup_constant >= 0.0)) AIE__FAIL("energy_warmup_constant must be >= 0");
+  if (gtb && !(c->energy_cost >= 0.0)) AIE__FAIL("energy_cost must be >= 0");
+  if (gtb && !(c->energy_warmup_constant >= 0.0)) AIE__FAIL("energy_warmup_constant must be >= 0");
   if (!(c->mixing_weight_gini_vs_coin >= 0.0 && c->mixing_weight_gini_vs_coin <= 1.0))
     AIE__FAIL("mixing_weight_gini_vs_coin not in [0,1]");
 
@@ -215,6 +341,17 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->has_cda = aie__has(c, AIE_COMP_CDA);
   p->has_gather = aie__has(c, AIE_COMP_GATHER);
   p->has_tax = aie__has(c, AIE_COMP_TAX);
+  p->has_labor = aie__has(c, AIE_COMP_SIMPLE_LABOR);
+  if (p->has_labor) {
+    if (c->labor_num_hours < 1 || c->labor_num_hours > 1000) AIE__FAIL("SimpleLabor.num_labor_hours out of range");
+    if (!(c->labor_pmsm > 0.0)) AIE__FAIL("SimpleLabor.payment_max_skill_multiplier must be > 0");
+  }
+  if (!gtb) {
+    if (c->ose_agent_reward_type == AIE_AGENT_REW_COIN_MINUS_LABOR_COST && !(c->ose_labor_exponent > 1.0))
+      AIE__FAIL("labor_exponent must be > 1 (rewards.py:69)");
+    if (c->ose_agent_reward_type != AIE_AGENT_REW_COIN_MINUS_LABOR_COST && c->ose_agent_reward_type != AIE_AGENT_REW_ISOELASTIC)
+      AIE__FAIL("unknown agent_reward_type");
+  }
   p->CM = c->has_water ? 6 : 5;
   p->WV = 2 * c->obs_range + 1;
 
@@ -269,6 +406,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
         break;
       case AIE_COMP_GATHER:
         p->sub_a_slot[ns] = AIE_SUB_GATHER; p->sub_a_dim[ns] = 4; ns++; break;
+      case AIE_COMP_SIMPLE_LABOR:
+        p->sub_a_slot[ns] = AIE_SUB_LABOR; p->sub_a_dim[ns] = c->labor_num_hours; ns++; break;
       default: break;
     }
   }
@@ -329,6 +468,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->mg_HW = aie__magic(p->HW);
   p->mg_W = aie__magic(p->W);
   p->mg_sub_p = aie__magic(1 + p->sub_p_dim);
+
+  if (!gtb) return aie__build_one_step_economy(c, p, tt);
 
   /* ---- per-replica record ------------------------------------------------------ */
   const int n = p->n, HW = p->HW, R = AIE_N_RES;

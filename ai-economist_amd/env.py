@@ -143,7 +143,8 @@ class DeviceBackend:
 
     def _n_sub_a(self):
         comps = list(self.cfg.components)[: self.cfg.n_components]
-        return sum({_cabi.COMP_BUILD: 1, _cabi.COMP_CDA: 4, _cabi.COMP_GATHER: 1}.get(c, 0) for c in comps)
+        return sum({_cabi.COMP_BUILD: 1, _cabi.COMP_CDA: 4, _cabi.COMP_GATHER: 1,
+                    _cabi.COMP_SIMPLE_LABOR: 1}.get(c, 0) for c in comps)
 
     def _act_p_width(self):
         has_planner_actions = (

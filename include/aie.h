@@ -40,9 +40,10 @@
 extern "C" {
 #endif
 
-#define AIE_ABI_VERSION 1
+#define AIE_ABI_VERSION 2
 
-#define AIE_MAX_AGENTS 64      /* mobile agents per replica (one lane each)            */
+#define AIE_MAX_AGENTS 64      /* mobile agents per replica, spatial scenarios (one lane each) */
+#define AIE_MAX_AGENTS_WIDE 128 /* mobile agents per replica, map-less one-step-economy        */
 #define AIE_MAX_COMPONENTS 8
 #define AIE_MAX_BRACKETS 16
 #define AIE_MAX_RATES 64       /* discretised tax rates per bracket                     */
@@ -63,8 +64,16 @@ enum {
   AIE_COMP_BUILD = 1,          /* "Build"                     F/components/build.py:15        */
   AIE_COMP_CDA = 2,            /* "ContinuousDoubleAuction"   F/components/continuous_double_auction.py:16 */
   AIE_COMP_GATHER = 3,         /* "Gather"                    F/components/move.py:16         */
-  AIE_COMP_TAX = 4             /* "PeriodicBracketTax"        F/components/redistribution.py:78 */
+  AIE_COMP_TAX = 4,            /* "PeriodicBracketTax"        F/components/redistribution.py:78 */
+  AIE_COMP_SIMPLE_LABOR = 5    /* "SimpleLabor"               F/components/simple_labor.py:15  */
 };
+
+/* ---- scenario families (registry names in the reference, F/scenarios) ----------- */
+enum {
+  AIE_SCN_GTB = 0,             /* "layout_from_file/simple_wood_and_stone" (+ uniform: next)   */
+  AIE_SCN_ONE_STEP_ECONOMY = 1 /* "one-step-economy"  F/scenarios/one_step_economy/one_step_economy.py:15 */
+};
+enum { AIE_AGENT_REW_COIN_MINUS_LABOR_COST = 0, AIE_AGENT_REW_ISOELASTIC = 1 };
 
 enum { AIE_SKILL_NONE = 0, AIE_SKILL_PARETO = 1, AIE_SKILL_LOGNORMAL = 2 };
 enum {
@@ -142,6 +151,18 @@ typedef struct aie_config {
   double tax_bracket_cutoffs[AIE_MAX_BRACKETS];
   double tax_disc_rates[AIE_MAX_RATES];       /* np.arange(rate_min, rate_max+disc, disc) */
   double tax_fixed_rates[AIE_MAX_BRACKETS];   /* us-federal / fixed models, <= rate_max  */
+
+  /* scenario family + one-step-economy (one_step_economy.py:55-78) */
+  int32_t scenario;                  /* AIE_SCN_*                                       */
+  int32_t ose_agent_reward_type;     /* AIE_AGENT_REW_*                                 */
+  double ose_labor_exponent;
+  double ose_labor_cost;
+
+  /* SimpleLabor (F/components/simple_labor.py:41-74) */
+  int32_t labor_mask_first_step;
+  int32_t labor_num_hours;           /* 100                                             */
+  double labor_pmsm;                 /* payment_max_skill_multiplier                    */
+  double labor_skills[AIE_MAX_AGENTS_WIDE]; /* per-agent skill (sorted Pareto means, :66-74) */
 } aie_config;
 
 /* ---- tensor descriptor ---------------------------------------------------------- */

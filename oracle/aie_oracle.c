@@ -31,6 +31,7 @@ typedef struct {
   int e;
   int act[AIE_MAX_AGENTS][AIE_N_SUB_SLOTS]; /* decoded per-subspace actions           */
   int act_p[AIE_MAX_BRACKETS];
+  int act_wide[AIE_MAX_AGENTS_WIDE]; /* one-step-economy: SimpleLabor action per agent */
 } ctx_t;
 
 #define F64(c, off) ((double*)((c)->rec + (c)->p->off))
@@ -556,6 +557,21 @@ static double get_gini(const double* e, int n) {
   return 1 - (2.0 / (n + 1)) * np_sum(cs, n);
 }
 
+/* same for up to AIE_MAX_AGENTS_WIDE agents (one-step-economy) */
+static double get_gini_wide(const double* e, int n) {
+  if (n < 30) return get_gini(e, n);
+  double s[AIE_MAX_AGENTS_WIDE], cs[AIE_MAX_AGENTS_WIDE];
+  memcpy(s, e, sizeof(double) * n);
+  for (int i = 1; i < n; ++i) { /* np.sort */
+    double x = s[i]; int j = i - 1;
+    while (j >= 0 && s[j] > x) { s[j + 1] = s[j]; --j; }
+    s[j + 1] = x;
+  }
+  double tot = np_sum(s, n) + 1e-10, run = 0;
+  for (int i = 0; i < n; ++i) { run += s[i]; cs[i] = run / tot; }
+  return 1 - (2.0 / (n + 1)) * np_sum(cs, n);
+}
+
 /* get_current_optimization_metrics :269-318 (rewards.py:12-48, 84-133) */
 static void current_metrics(ctx_t* c, double* out /* n+1 */) {
   const aie_params* p = c->p;
@@ -1002,6 +1018,234 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
   (arena + p->a_done)[e] = 0;
 }
 
+/* =================================================================================== */
+/* one-step-economy + SimpleLabor (BASELINE configs[4])                                 */
+/* F/scenarios/one_step_economy/one_step_economy.py, F/components/simple_labor.py       */
+/* =================================================================================== */
+/* SimpleLabor.component_step simple_labor.py:105-126.  The random agent order is drawn
+ * (world.py:418-422) although the result does not depend on it. */
+static void labor_step(ctx_t* c) {
+  const aie_params* p = c->p;
+  int order[AIE_MAX_AGENTS_WIDE];
+  for (int i = 0; i < p->n; ++i) order[i] = i;
+  for (int i = p->n - 1; i >= 1; --i) {
+    int j = (int)rng_interval(c, (uint32_t)i);
+    int t = order[i]; order[i] = order[j]; order[j] = t;
+  }
+  for (int k = 0; k < p->n; ++k) {
+    int i = order[k];
+    int a = c->act_wide[i];
+    if (a == 0) continue;
+    F64(c, o_labor)[i] = (double)a; /* hours worked this step (set, not accumulated) */
+    double payoff = (double)a * F64(c, o_skill)[i];
+    F64(c, o_production)[i] += payoff;
+    F64(c, o_inv_coin)[i] += payoff;
+  }
+}
+
+/* rewards.coin_minus_labor_cost rewards.py:51-81 / isoelastic :12-48; planner SWFs
+ * one_step_economy.py:300-336 (pretax incomes = production for the inverse-income SWF) */
+static void ose_metrics(ctx_t* c, double* out) {
+  const aie_params* p = c->p;
+  const int n = p->n;
+  double coin[AIE_MAX_AGENTS_WIDE];
+  for (int i = 0; i < n; ++i) {
+    coin[i] = F64(c, o_inv_coin)[i] + F64(c, o_esc_coin)[i];
+    double labor = F64(c, o_labor)[i];
+    if (p->c.ose_agent_reward_type == AIE_AGENT_REW_ISOELASTIC) {
+      double eta = p->c.isoelastic_eta;
+      double uc = (eta == 1.0) ? log(coin[i] > 1 ? coin[i] : 1) : (pow(coin[i], 1 - eta) - 1) / (1 - eta);
+      out[i] = uc - labor * p->c.ose_labor_cost;
+    } else {
+      out[i] = coin[i] - pow(labor, p->c.ose_labor_exponent) * p->c.ose_labor_cost;
+    }
+  }
+  if (p->c.planner_reward_type == AIE_PLANNER_REW_COIN_EQ_TIMES_PROD) {
+    double ew = 1 - p->c.mixing_weight_gini_vs_coin;
+    double prod = np_sum(coin, n) / n;
+    out[n] = (ew * (1 - get_gini_wide(coin, n)) + (1 - ew)) * prod;
+  } else {
+    double w[AIE_MAX_AGENTS_WIDE], t[AIE_MAX_AGENTS_WIDE];
+    const int use_util = p->c.planner_reward_type == AIE_PLANNER_REW_INV_INCOME_UTIL;
+    for (int i = 0; i < n; ++i) {
+      /* inv_income_weighted_utility is fed pretax incomes (production); the coin variant
+       * is fed coin endowments (one_step_economy.py:317-333) */
+      double base = use_util ? F64(c, o_production)[i] : coin[i];
+      w[i] = 1 / (base > 1 ? base : 1);
+    }
+    double sw = np_sum(w, n);
+    for (int i = 0; i < n; ++i) {
+      w[i] = w[i] / sw;
+      t[i] = (use_util ? out[i] : coin[i]) * w[i];
+    }
+    out[n] = np_sum(t, n);
+  }
+}
+
+static void ose_write_obs(ctx_t* c) {
+  const aie_params* p = c->p;
+  const int n = p->n, e = c->e, NB = p->NB;
+  const int t = *I32(c, o_timestep);
+  const double time_scale = p->c.allow_observation_scaling ? (double)p->c.episode_length : 1.0;
+  const float tval = (float)((double)t / time_scale);
+  double is_tax_day = 0, is_first_day = 0, tax_phase = 0, sorted_inc[AIE_MAX_AGENTS_WIDE];
+  if (p->has_tax) {
+    int pos = *I32(c, o_tax_cycle_pos);
+    is_tax_day = pos >= p->c.tax_period ? 1.0 : 0.0;
+    is_first_day = pos == 1 ? 1.0 : 0.0;
+    tax_phase = (double)pos / (double)p->c.tax_period;
+    for (int i = 0; i < n; ++i) sorted_inc[i] = F64(c, o_tax_last_income)[i] / (double)p->c.tax_period;
+    for (int i = 1; i < n; ++i) {
+      double x = sorted_inc[i]; int j = i - 1;
+      while (j >= 0 && sorted_inc[j] > x) { sorted_inc[j + 1] = sorted_inc[j]; --j; }
+      sorted_inc[j + 1] = x;
+    }
+  }
+  float* aflat = (float*)(c->arena + p->a_obs_a_flat) + (int64_t)e * n * p->FA;
+  float* atime = (float*)(c->arena + p->a_obs_a_time) + (int64_t)e * n;
+  float* pag = (float*)(c->arena + p->a_obs_p_agents) + (int64_t)e * n * p->FPA;
+  double coin[AIE_MAX_AGENTS_WIDE];
+  for (int i = 0; i < n; ++i) {
+    float* f = aflat + i * p->FA;
+    coin[i] = F64(c, o_inv_coin)[i] + F64(c, o_esc_coin)[i];
+    if (p->has_tax) {
+      float* g = f + p->fa_tax;
+      for (int b = 0; b < NB; ++b) g[b] = (float)tax_rate(c, b);
+      g[NB + 0] = (float)is_first_day;
+      g[NB + 1] = (float)is_tax_day;
+      for (int k = 0; k < n; ++k) g[NB + 2 + k] = (float)sorted_inc[k];
+      double cmr = tax_marginal_rate(c, coin[i] - F64(c, o_tax_last_coin)[i]);
+      g[NB + 2 + n] = (float)cmr;
+      g[NB + 3 + n] = (float)tax_phase;
+      float* q = pag + i * p->FPA;
+      q[0] = (float)cmr;
+      q[1] = (float)(F64(c, o_tax_last_income)[i] / (double)p->c.tax_period);
+      q[2] = (float)F64(c, o_tax_last_marginal_rate)[i];
+    }
+    if (p->has_labor) f[p->fa_labor] = (float)(F64(c, o_skill)[i] / p->c.labor_pmsm); /* simple_labor.py:128-134 */
+    f[p->fa_time] = tval;
+    atime[i] = tval;
+  }
+  float* pf = (float*)(c->arena + p->a_obs_p_flat) + (int64_t)e * p->FP;
+  if (p->has_tax) {
+    float* g = pf + p->fp_tax;
+    for (int b = 0; b < NB; ++b) g[b] = (float)tax_rate(c, b);
+    g[NB + 0] = (float)is_first_day;
+    g[NB + 1] = (float)is_tax_day;
+    for (int k = 0; k < n; ++k) g[NB + 2 + k] = (float)sorted_inc[k];
+    g[NB + 2 + n] = (float)tax_phase;
+  }
+  pf[p->fp_time] = tval;
+  /* one_step_economy.py:161-172: equality, productivity / n / 1000 */
+  pf[p->fp_world + 0] = (float)(1 - get_gini_wide(coin, n));
+  pf[p->fp_world + 1] = (float)(np_sum(coin, n) / n / 1000);
+  ((float*)(c->arena + p->a_obs_p_time))[e] = tval;
+
+  /* masks: SimpleLabor.generate_masks simple_labor.py:97-103 (all-off on the first call
+   * after a reset when mask_first_step), planner tax masks redistribution.py:1025-1104 */
+  float* am = (float*)(c->arena + p->a_obs_a_mask) + (int64_t)e * n * p->MA;
+  const int multi = p->c.multi_action_mode_agents;
+  float on = 1.0f;
+  if (p->has_labor) {
+    int32_t* first = I32(c, o_first_step);
+    if (*first) { *first = 0; if (p->c.labor_mask_first_step) on = 0.0f; }
+  }
+  for (int i = 0; i < n; ++i) {
+    float* m = am + i * p->MA;
+    int o = 0;
+    if (!multi || p->n_sub_a == 0) m[o++] = 1.0f;
+    for (int s = 0; s < p->n_sub_a; ++s) {
+      if (multi) m[o++] = 1.0f;
+      for (int k = 0; k < p->sub_a_dim[s]; ++k) m[o++] = on;
+    }
+  }
+  float* pm = (float*)(c->arena + p->a_obs_p_mask) + (int64_t)e * p->MP;
+  int o = 0;
+  const int pmulti = p->c.multi_action_mode_planner;
+  if (!pmulti || p->n_sub_p == 0) pm[o++] = 1.0f;
+  if (p->n_sub_p) {
+    float v = (*I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
+    for (int b = 0; b < p->n_sub_p; ++b) {
+      if (pmulti) pm[o++] = 1.0f;
+      for (int k = 0; k < p->sub_p_dim; ++k) pm[o++] = v;
+    }
+  }
+}
+
+static void ose_decode_actions(ctx_t* c, const int32_t* aa, const int32_t* ap) {
+  const aie_params* p = c->p;
+  memset(c->act_wide, 0, sizeof(c->act_wide));
+  memset(c->act_p, 0, sizeof(c->act_p));
+  if (aa && p->n_sub_a) {
+    for (int i = 0; i < p->n; ++i) {
+      int v = aa[((int64_t)c->e * p->n + i) * p->act_a_width];
+      if (p->c.multi_action_mode_agents) { if (v >= 0 && v <= p->sub_a_dim[0]) c->act_wide[i] = v; }
+      else if (v >= 1 && v < 1 + p->sub_a_dim[0]) c->act_wide[i] = v;
+    }
+  }
+  if (ap && p->n_sub_p) {
+    const int32_t* a = ap + (int64_t)c->e * p->act_p_width;
+    if (p->c.multi_action_mode_planner) { for (int b = 0; b < p->n_sub_p; ++b) c->act_p[b] = a[b]; }
+    else {
+      int v = a[0];
+      if (v >= 1 && v < 1 + p->n_sub_p * p->sub_p_dim) c->act_p[(v - 1) / p->sub_p_dim] = (v - 1) % p->sub_p_dim + 1;
+    }
+  }
+}
+
+static void ose_step_one(const aie_params* p, uint8_t* arena, int e, const int32_t* aa, const int32_t* ap) {
+  ctx_t c;
+  make_ctx(&c, p, arena, e);
+  ose_decode_actions(&c, aa, ap);
+  *I32(&c, o_timestep) += 1;
+  for (int k = 0; k < p->c.n_components; ++k) {
+    if (p->c.components[k] == AIE_COMP_SIMPLE_LABOR) labor_step(&c);
+    else if (p->c.components[k] == AIE_COMP_TAX) tax_step(&c);
+  }
+  ose_write_obs(&c);
+  /* compute_reward one_step_economy.py:195-222 */
+  const int n = p->n;
+  double cur[AIE_MAX_AGENTS_WIDE + 1];
+  double* util = F64(&c, o_util);
+  ose_metrics(&c, cur);
+  float* ra = (float*)(arena + p->a_rew_a) + (int64_t)e * n;
+  for (int i = 0; i < n; ++i) { ra[i] = (float)(cur[i] - util[i]); util[i] = cur[i]; }
+  ((float*)(arena + p->a_rew_p))[e] = (float)(cur[n] - util[n]);
+  util[n] = cur[n];
+  int done = *I32(&c, o_timestep) >= p->c.episode_length;
+  (arena + p->a_done)[e] = (uint8_t)done;
+  if (done) *I32(&c, o_completions) += 1;
+}
+
+/* reset: one_step_economy.py:99-118 + simple_labor.py:76-95 + redistribution.py:1109-1139
+ * + additional_reset_steps :224-241.  No random draws. */
+static void ose_reset_one(const aie_params* p, uint8_t* arena, int e) {
+  ctx_t c;
+  make_ctx(&c, p, arena, e);
+  const int n = p->n;
+  *I32(&c, o_timestep) = 0;
+  for (int i = 0; i < n; ++i) {
+    F64(&c, o_inv_coin)[i] = 0; F64(&c, o_esc_coin)[i] = 0; F64(&c, o_labor)[i] = 0;
+    F64(&c, o_skill)[i] = p->has_labor ? p->c.labor_skills[i] : 0;
+    F64(&c, o_production)[i] = 0;
+  }
+  *I32(&c, o_first_step) = 1;
+  if (p->has_tax) {
+    for (int b = 0; b < p->NB; ++b) I32(&c, o_tax_rate_idx)[b] = 0;
+    *I32(&c, o_tax_cycle_pos) = 1;
+    for (int i = 0; i < n; ++i) {
+      F64(&c, o_tax_last_coin)[i] = 0; F64(&c, o_tax_last_income)[i] = 0; F64(&c, o_tax_last_marginal_rate)[i] = 0;
+    }
+    *F64(&c, o_tax_total_collected) = 0;
+  }
+  ose_metrics(&c, F64(&c, o_util));
+  ose_write_obs(&c);
+  float* ra = (float*)(arena + p->a_rew_a) + (int64_t)e * n;
+  for (int i = 0; i < n; ++i) ra[i] = 0;
+  ((float*)(arena + p->a_rew_p))[e] = 0;
+  (arena + p->a_done)[e] = 0;
+}
+
 /* ---- exported entry points (ctypes) ---------------------------------------------- */
 int aie_oracle_params(const aie_config* cfg, aie_params* out, aie_tensor_table* tt, char* err, int errlen) {
   return aie_build_params(cfg, out, tt, err, (size_t)errlen);
@@ -1010,11 +1254,17 @@ int aie_oracle_sizeof_params(void) { return (int)sizeof(aie_params); }
 int aie_oracle_sizeof_table(void) { return (int)sizeof(aie_tensor_table); }
 
 void aie_oracle_step(const aie_params* p, uint8_t* arena, const int32_t* aa, const int32_t* ap, int e0, int e1) {
-  for (int e = e0; e < e1; ++e) step_one(p, arena, e, aa, ap);
+  for (int e = e0; e < e1; ++e) {
+    if (p->c.scenario == AIE_SCN_ONE_STEP_ECONOMY) ose_step_one(p, arena, e, aa, ap);
+    else step_one(p, arena, e, aa, ap);
+  }
 }
 void aie_oracle_reset(const aie_params* p, uint8_t* arena, const uint8_t* mask, int e0, int e1) {
   for (int e = e0; e < e1; ++e)
-    if (!mask || mask[e]) reset_one(p, arena, e);
+    if (!mask || mask[e]) {
+      if (p->c.scenario == AIE_SCN_ONE_STEP_ECONOMY) ose_reset_one(p, arena, e);
+      else reset_one(p, arena, e);
+    }
 }
 void aie_oracle_seed(const aie_params* p, uint8_t* arena, uint32_t base_seed) {
   for (int e = 0; e < p->E; ++e) {
@@ -1029,5 +1279,8 @@ void aie_oracle_seed(const aie_params* p, uint8_t* arena, uint32_t base_seed) {
 void aie_oracle_step_mt(const aie_params* p, uint8_t* arena, const int32_t* aa, const int32_t* ap, int nthreads) {
   int E = p->E;
 #pragma omp parallel for num_threads(nthreads) schedule(static)
-  for (int e = 0; e < E; ++e) step_one(p, arena, e, aa, ap);
+  for (int e = 0; e < E; ++e) {
+    if (p->c.scenario == AIE_SCN_ONE_STEP_ECONOMY) ose_step_one(p, arena, e, aa, ap);
+    else step_one(p, arena, e, aa, ap);
+  }
 }

@@ -44,7 +44,9 @@ def sample_actions(env, rng, t_steps, p_move=0.45, p_build=0.12, p_trade=0.33):
     A = base
     acts = np.zeros((t_steps, n), np.int32)
     trade_names = [nm for nm in names if nm.startswith("ContinuousDoubleAuction")]
-    for t in range(t_steps):
+    if names == ["SimpleLabor"]:
+        acts = rng.randint(0, A, size=(t_steps, n)).astype(np.int32)
+    for t in range(t_steps if names != ["SimpleLabor"] else 0):
         for i in range(n):
             u = rng.rand()
             if u < p_move and "Gather" in ranges:
@@ -75,6 +77,7 @@ def run_case(name, cfg, seed, t_steps, obs_steps, action_seed=123, action_kw=Non
     kwargs = dict(cfg)
     scenario = kwargs.pop("scenario_name")
     kwargs["components"] = [tuple(c) for c in kwargs["components"]]
+    np.random.seed(seed + 1000)  # SimpleLabor draws its skills from the global stream at construction
     env = foundation.make_env_instance(scenario, **kwargs)
     np.random.seed(seed)
     st = np.random.get_state()
@@ -139,6 +142,9 @@ def run_case(name, cfg, seed, t_steps, obs_steps, action_seed=123, action_kw=Non
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
+    if scenario == "one-step-economy":
+        print("%-28s %7.1f KB  A=%d" % (name, os.path.getsize(path) / 1024.0, A))
+        return
     print("%-28s %7.1f KB  A=%d  gathers=%d builds=%d trades=%d" % (
         name, os.path.getsize(path) / 1024.0, A,
         sum(len(g) for g in env.get_component("Gather").gathers) if _has(env, "Gather") else -1,
@@ -159,6 +165,13 @@ GTB = [
 ]
 
 CASES = {
+    # BASELINE configs[4] (C5) at 1 replica: one-step-economy, 100 agents, 2-step episodes
+    "c5_one_step_economy_100ag": dict(
+        cfg=dict(scenario_name="one-step-economy", n_agents=100, world_size=[1, 1], episode_length=2,
+                 components=[["SimpleLabor", {}],
+                             ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+                                                     "tax_model": "model_wrapper"}]]),
+        seed=13, t_steps=8, obs_steps=[0, 1, 2, 3, 4, 8]),
     # BASELINE configs[1] (C2) at 1 replica: quadrant layout, 4 agents, Build+CDA+Gather+Tax
     "c2_quadrant_4ag": dict(
         cfg=dict(scenario_name="layout_from_file/simple_wood_and_stone", n_agents=4,

@@ -83,8 +83,9 @@ class OracleEnv:
         arena_bytes = (d.arena_offset + self.E + 255) // 256 * 256
         self.arena = np.zeros(arena_bytes, np.uint8)
         self.t = {name: self._view(d) for name, d in self.descs.items()}
-        self.t["house_owner"][...] = -1
-        if layout_planes is not None:
+        if "house_owner" in self.t:
+            self.t["house_owner"][...] = -1
+        if layout_planes is not None and "cell_flags" in self.t:
             self.set_layout(*layout_planes)
 
     def _view(self, d):

@@ -16,8 +16,43 @@ def pack_order(agent, price, lifetime):
     return np.int32(int(agent) | (int(price) << 8) | (int(lifetime) << 16))
 
 
+def extract_state_one_step_economy(env):
+    w = env.world
+    ag = w.agents
+    s = {}
+    s["inv_coin"] = np.array([a.inventory["Coin"] for a in ag], np.float64)
+    s["esc_coin"] = np.array([a.escrow["Coin"] for a in ag], np.float64)
+    s["labor"] = np.array([a.endogenous["Labor"] for a in ag], np.float64)
+    s["skill"] = np.array([a.state.get("skill", 0.0) for a in ag], np.float64)
+    s["production"] = np.array([a.state.get("production", 0.0) for a in ag], np.float64)
+    com = env.curr_optimization_metrics
+    s["util"] = np.array([com.get(a.idx, com.get(str(a.idx), 0.0)) for a in ag]
+                         + [com.get(w.planner.idx, 0.0)], np.float64)
+    comps = {c.name: c for c in env.components}
+    if "PeriodicBracketTax" in comps:
+        c = comps["PeriodicBracketTax"]
+        s["tax_cycle_pos"] = np.array(c.tax_cycle_pos, np.int32)
+        s["tax_rate_idx"] = np.array(c.curr_rate_indices, np.int32)
+        s["tax_last_coin"] = np.array(c.last_coin, np.float64)
+        s["tax_last_income"] = np.array(c.last_income, np.float64)
+        s["tax_last_marginal_rate"] = np.array(c.last_marginal_rate, np.float64)
+        s["tax_total_collected"] = np.array(c.total_collected_taxes, np.float64)
+    if "SimpleLabor" in comps:
+        s["labor_first_step"] = np.array(int(comps["SimpleLabor"].is_first_step), np.int32)
+    s["timestep"] = np.array(w.timestep, np.int32)
+    s["completions"] = np.array(env._completions, np.int32)
+    st = np.random.get_state()
+    s["mt"] = np.array(st[1], np.uint32)
+    s["mt_pos"] = np.array(st[2], np.int32)
+    s["mt_has_gauss"] = np.array(st[3], np.int32)
+    s["mt_gauss"] = np.array(st[4], np.float64)
+    return s
+
+
 def extract_state(env):
     """Returns {field_name: ndarray} for ONE reference env (no leading env dim)."""
+    if env.name == "one-step-economy":
+        return extract_state_one_step_economy(env)
     w = env.world
     n = env.n_agents
     H, W = env.world_size

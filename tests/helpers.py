@@ -10,10 +10,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 INT_FIELDS = ["stone", "wood", "house_owner", "loc_r", "loc_c", "inv_res", "esc_res",
               "cda_n_bids", "cda_n_asks", "cda_n_orders", "cda_bid_hist", "cda_ask_hist",
-              "tax_cycle_pos", "tax_rate_idx", "timestep", "completions", "auto_warmup", "mt_pos"]
+              "tax_cycle_pos", "tax_rate_idx", "timestep", "completions", "auto_warmup", "mt_pos",
+              "labor_first_step"]
 F64_FIELDS = ["inv_coin", "esc_coin", "labor", "build_payment", "build_skill",
               "bonus_gather_prob", "util", "cda_price_history", "tax_last_coin",
-              "tax_last_income", "tax_last_marginal_rate", "tax_total_collected"]
+              "tax_last_income", "tax_last_marginal_rate", "tax_total_collected", "skill",
+              "production"]
 
 
 def golden_names():
@@ -24,6 +26,12 @@ def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
         g = {k: z[k] for k in z.files}
     g["cfg"] = json.loads(str(g["cfg_json"]))
+    if "s0_skill" in g:
+        # SimpleLabor estimates its skills from the GLOBAL NumPy stream at construction
+        # (simple_labor.py:66-74); the fixture carries the values the reference drew.
+        for comp in g["cfg"]["components"]:
+            if comp[0] == "SimpleLabor":
+                comp[1]["skills"] = [float(x) for x in g["s0_skill"]]
     return g
 
 

@@ -75,7 +75,7 @@ def test_hip_step_matches_reference_golden(name):
             compare_state(got, want, where="%s step %d replica %d" % (name, t + 1, e))
             assert zlib.crc32(got["mt"].tobytes()) == int(g["st_mt_crc"][t])
             rew = np.concatenate([got["rewards_a"], got["rewards_p"][None]])
-            np.testing.assert_allclose(rew, g["rew"][t], rtol=0, atol=REW_TOL)
+            np.testing.assert_allclose(rew, g["rew"][t], rtol=2e-7, atol=REW_TOL)  # f32 storage
             assert int(got["done"]) == int(g["done"][t])
         if (t + 1) in obs_steps:
             _obs_check(be, g, obs_steps.index(t + 1), "%s step %d" % (name, t + 1), e=2)
@@ -106,12 +106,14 @@ def test_hip_reset_matches_reference_golden(name):
 
 def _compare_all(be, oracle, where, fields=None):
     for k in INT_FIELDS + ["mt"]:
-        if k == "auto_warmup":
+        if k == "auto_warmup" and k in be.tensors:
             # counts steps whose MEAN REWARD is > 0; when an order expires the coin total
             # moves by one ulp and the sign of the resulting ~1e-16 reward depends on the
             # last bit of pow() (glibc vs the device libm).  Float-derived => tolerance.
             d = np.abs(be.tensors[k].cpu().numpy() - oracle.t[k])
             assert d.max() <= 3 and (d > 0).mean() < 0.1, "%s: auto_warmup drifted" % where
+            continue
+        if k == "auto_warmup":
             continue
         if k in be.tensors and k in oracle.t:
             got = be.tensors[k].cpu().numpy()
@@ -271,6 +273,52 @@ def test_hip_matches_oracle_on_config_variants(variant):
         oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
         if (t + 1) % 10 == 0:
             _compare_all(be, oracle, "%s step %d" % (variant, t + 1))
+        if bool(be.tensors["done"][0]):
+            env.reset(be.tensors["done"])
+            oracle.reset(oracle.t["done"].copy())
+            _compare_all(be, oracle, "%s reset after step %d" % (variant, t + 1))
+
+
+OSE_VARIANTS = {
+    "c5_default_100ag": dict(n_agents=100),
+    "coin_eq_40ag": dict(n_agents=40, planner_reward_type="coin_eq_times_productivity",
+                         mixing_weight_gini_vs_coin=0.25),
+    "isoelastic_12ag_coin_eq": dict(n_agents=12, agent_reward_type="isoelastic_coin_minus_labor",
+                                     planner_reward_type="coin_eq_times_productivity", isoelastic_eta=0.4),
+    "no_first_step_mask_128ag": dict(n_agents=128, labor_kw=dict(mask_first_step=False)),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(OSE_VARIANTS))
+def test_hip_matches_oracle_one_step_economy(variant):
+    """BASELINE configs[4] family: one-step-economy + SimpleLabor + PeriodicBracketTax."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    kw = dict(OSE_VARIANTS[variant])
+    labor_kw = kw.pop("labor_kw", {})
+    rs = np.random.RandomState(4)
+    n = kw["n_agents"]
+    labor_kw["skills"] = [float(x) for x in np.sort(1 + rs.rand(n) * 2)]
+    cfg = dict(scenario_name="one-step-economy", world_size=[1, 1], episode_length=2,
+               components=[["SimpleLabor", labor_kw],
+                           ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+                                                   "tax_model": "model_wrapper"}]], **kw)
+    E, T = 96, 12
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(9)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(9)
+    oracle.reset()
+    _compare_all(be, oracle, variant + " reset")
+    for t in range(T):
+        a, p = be.sample_random_actions(seed=23)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+        _compare_all(be, oracle, "%s step %d" % (variant, t + 1))
         if bool(be.tensors["done"][0]):
             env.reset(be.tensors["done"])
             oracle.reset(oracle.t["done"].copy())

@@ -130,3 +130,67 @@ def test_oracle_tracks_live_reference(variant):
             obs = ref.reset()
             o.reset()
             check("%s reset after step %d" % (variant, t + 1), obs)
+
+
+OSE_VARIANTS = {
+    "c5_default": dict(n_agents=100),
+    "coin_eq_40": dict(n_agents=40, planner_reward_type="coin_eq_times_productivity", mixing_weight_gini_vs_coin=0.25),
+    "isoelastic_12_coin_eq": dict(n_agents=12, agent_reward_type="isoelastic_coin_minus_labor",
+                                  planner_reward_type="coin_eq_times_productivity", isoelastic_eta=0.4),
+    "single_action_planner_25": dict(n_agents=25, multi_action_mode_planner=False, labor_cost=0.5, labor_exponent=1.5),
+    "no_first_step_mask": dict(n_agents=30, labor_kw=dict(mask_first_step=False), episode_length=3),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(OSE_VARIANTS))
+def test_oracle_tracks_live_reference_one_step_economy(variant):
+    from oracle_lib import OracleEnv
+    from ref_extract import extract_obs, extract_state, rewards_array
+
+    kw = dict(OSE_VARIANTS[variant])
+    labor_kw = kw.pop("labor_kw", {})
+    cfg = dict(scenario_name="one-step-economy", world_size=[1, 1], episode_length=kw.pop("episode_length", 2),
+               components=[["SimpleLabor", dict(labor_kw)],
+                           ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+                                                   "tax_model": "model_wrapper"}]], **kw)
+    np.random.seed(77)
+    ref = _ref_env(cfg)
+    cfg["components"][0][1]["skills"] = [float(x) for x in ref.get_component("SimpleLabor").skills]
+    host = make_env(cfg)
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    np.random.seed(5)
+    st = np.random.get_state()
+    o.t["mt"][0] = st[1]
+    o.t["mt_pos"][0] = st[2]
+    obs = ref.reset()
+    o.reset()
+    rng = np.random.RandomState(8)
+    n = cfg["n_agents"]
+    multi_p = bool(cfg.get("multi_action_mode_planner", True))
+
+    def check(where, obs, rew=None):
+        compare_state({k: v[0] for k, v in o.t.items()}, extract_state(ref), where=where, f64_tol=1e-9)
+        assert np.array_equal(o.t["mt"][0], np.random.get_state()[1]), where + ": MT19937 state"
+        for k, want in extract_obs(ref, obs).items():
+            np.testing.assert_allclose(o.t[k][0], want, rtol=2e-6, atol=2e-6, err_msg="%s: obs %s" % (where, k))
+        if rew is not None:
+            got = np.concatenate([o.t["rewards_a"][0], o.t["rewards_p"][[0]]])
+            np.testing.assert_allclose(got, rewards_array(ref, rew), rtol=2e-7, atol=1e-5, err_msg=where)
+
+    check(variant + " reset", obs)
+    for t in range(9):
+        aa = rng.randint(0, 101, size=(n, 1)).astype(np.int32)
+        acts = {str(i): int(aa[i, 0]) for i in range(n)}
+        if multi_p:
+            pa = rng.randint(0, 22, size=7).astype(np.int32)
+            acts["p"] = [int(x) for x in pa]
+        else:
+            pa = np.array([rng.randint(0, ref.world.planner.action_spaces)], np.int32)
+            acts["p"] = int(pa[0])
+        obs, rew, done, _ = ref.step(acts)
+        o.step(aa[None], pa[None])
+        check("%s step %d" % (variant, t + 1), obs, rew)
+        if done["__all__"]:
+            obs = ref.reset()
+            o.reset()
+            check("%s reset after step %d" % (variant, t + 1), obs)
