@@ -54,6 +54,7 @@ class AieConfig(C.Structure):
         ("full_observability", C.c_int32),
         ("obs_range", C.c_int32),
         ("fixed_four_skill_and_loc", C.c_int32),
+        ("reset_random_order", C.c_int32),
         ("energy_warmup_method", C.c_int32),
         ("planner_reward_type", C.c_int32),
         ("regen_halfwidth", C.c_int32 * N_RES),

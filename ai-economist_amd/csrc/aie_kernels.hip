@@ -1513,7 +1513,11 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   rebuild_locmap(c);  // all agents off the board
   // ---- wave-uniform sequential part (every lane performs the same LDS updates) ----
   *R_I32(c, o_timestep) = 0;
-  for (int i = 0; i < n; ++i) {  // layout_from_file.py:360-370
+  // layout_from_file.py:360-370 places agents in index order, dynamic_layout.py:420-431
+  // (uniform/...) in a random order
+  const int place_perm = P.c.reset_random_order ? rng_permutation(m, tid, n) : tid;
+  for (int k = 0; k < n; ++k) {
+    const int i = bcast(place_perm, k);
     int r = (int)rng_interval(m, tid, (uint32_t)(P.H - 1)), col = (int)rng_interval(m, tid, (uint32_t)(P.W - 1)), tries = 0;
     while (!can_agent_occupy(c, r, col, i)) {
       r = (int)rng_interval(m, tid, (uint32_t)(P.H - 1));

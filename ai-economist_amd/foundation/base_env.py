@@ -221,8 +221,14 @@ class BaseEnvironment:
             # the reference falls back on whatever the global NumPy stream holds;
             # here an unseeded env is seeded from the OS once.
             self._pending_seed = int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31 - 1)) + 1
+        self.host_pre_reset(env_mask)
         self.backend.reset(env_mask)
         return self._obs()
+
+    def host_pre_reset(self, env_mask):
+        """Hook for scenarios whose reset has a host-side part (e.g. uniform/...: a fresh
+        random layout per episode).  Default: nothing."""
+        return None
 
     def step(self, actions=None):
         """actions: None (all NO-OP), or {"a": int32 [E, n_agents(, n_subspaces)],

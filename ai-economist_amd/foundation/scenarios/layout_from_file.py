@@ -60,7 +60,7 @@ class LayoutFromFile(BaseEnvironment):
                 with open(env_layout_file, "r") as f:
                     grid = parse_layout_string(f.read())
             elif ";" in env_layout_file:
-                grid = parse_layout_string(env_layout_file)
+                grid = parse_layout_string(env_layout_file)[: self.world_size[0], : self.world_size[1]]
             else:
                 raise FileNotFoundError("unknown env_layout_file {!r}".format(env_layout_file))
         H, W = self.world_size

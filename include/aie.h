@@ -113,6 +113,8 @@ typedef struct aie_config {
   int32_t full_observability;
   int32_t obs_range;                 /* mobile_agent_observation_range                  */
   int32_t fixed_four_skill_and_loc;
+  int32_t reset_random_order;        /* agents are placed in a random order at reset
+                                      * (uniform/..., dynamic_layout.py:420-431)        */
   int32_t energy_warmup_method;
   int32_t planner_reward_type;
   int32_t regen_halfwidth[AIE_N_RES];/* must be 0 (bit-exact guarantee)  */

@@ -940,7 +940,11 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
     I32(&c, o_loc_r)[i] = -1;
     I32(&c, o_loc_c)[i] = -1;
   }
-  for (int i = 0; i < n; ++i) {
+  int place_order[AIE_MAX_AGENTS];
+  if (p->c.reset_random_order) rng_permutation(&c, n, place_order); /* dynamic_layout.py:420 */
+  else for (int i = 0; i < n; ++i) place_order[i] = i;
+  for (int k = 0; k < n; ++k) {
+    const int i = place_order[k];
     int r = rng_randint(&c, p->H), col = rng_randint(&c, p->W), tries = 0;
     while (!can_agent_occupy(&c, r, col, i)) {
       r = rng_randint(&c, p->H);

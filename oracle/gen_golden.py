@@ -165,6 +165,14 @@ GTB = [
 ]
 
 CASES = {
+    # BASELINE configs[0] (C1): uniform 15x15, 4 agents, Build+Gather (mirrors the reference's
+    # tests/test_env.py minus the auction); 2 short episodes => 2 random layouts
+    "c1_uniform15_4ag": dict(
+        cfg=dict(scenario_name="uniform/simple_wood_and_stone", n_agents=4, world_size=[15, 15],
+                 episode_length=90, components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10,
+                 starting_stone_coverage=0.10, starting_wood_coverage=0.10),
+        seed=17, t_steps=180, obs_steps=[0, 1, 45, 90, 91, 180],
+        action_kw=dict(p_move=0.6, p_build=0.3, p_trade=0.0)),
     # BASELINE configs[4] (C5) at 1 replica: one-step-economy, 100 agents, 2-step episodes
     "c5_one_step_economy_100ag": dict(
         cfg=dict(scenario_name="one-step-economy", n_agents=100, world_size=[1, 1], episode_length=2,

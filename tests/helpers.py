@@ -79,3 +79,23 @@ def compare_state(got, want, where="", f64_tol=1e-9):
         if k in want and k in got:
             np.testing.assert_allclose(np.asarray(got[k]), np.asarray(want[k]), rtol=f64_tol,
                                        atol=f64_tol, err_msg="%s: f64 field %s" % (where, k))
+
+
+def oracle_host_pre_reset(env, oracle, which=None):
+    """What BaseEnvironment.host_pre_reset does on the device, on an OracleEnv: scenarios
+    with a host-side reset part (uniform/...: a fresh layout from the replica's own MT19937
+    stream) run it here before oracle.reset()."""
+    if not hasattr(env, "generate_layout"):
+        return
+    which = range(oracle.E) if which is None else which
+    rs = np.random.RandomState()
+    for e in which:
+        rs.set_state(("MT19937", oracle.t["mt"][e].copy(), int(oracle.t["mt_pos"][e]),
+                      int(oracle.t["mt_has_gauss"][e]), float(oracle.t["mt_gauss"][e])))
+        stone, wood = env.generate_layout(rs)
+        oracle.t["cell_flags"][e] = 2 * stone + 4 * wood
+        st = rs.get_state()
+        oracle.t["mt"][e] = st[1]
+        oracle.t["mt_pos"][e] = st[2]
+        oracle.t["mt_has_gauss"][e] = st[3]
+        oracle.t["mt_gauss"][e] = st[4]

@@ -1,0 +1,65 @@
+"""The reference's own unit test (tests/test_env.py:16-107: uniform 15x15, 4 agents,
+Build + ContinuousDoubleAuction{max_num_orders: 5} + Gather, starting coin 10, 10 %
+coverage) replayed against the batched backend: same construction call, same structural
+assertions, on the batched (obs, rew, done, info) and on the per-replica reference view."""
+import pytest
+
+ENV_CONFIG = {
+    "n_agents": 4,
+    "world_size": [15, 15],
+    "episode_length": 1000,
+    "multi_action_mode_agents": False,
+    "multi_action_mode_planner": True,
+    # the batched backend always flattens observations (flatten_observations=False is the
+    # one setting of the reference's config that it does not offer)
+    "flatten_observations": True,
+    "flatten_masks": True,
+    "components": [
+        {"Build": {}},
+        {"ContinuousDoubleAuction": {"max_num_orders": 5}},
+        {"Gather": {}},
+    ],
+    "scenario_name": "uniform/simple_wood_and_stone",
+    "starting_agent_coin": 10,
+    "starting_stone_coverage": 0.10,
+    "starting_wood_coverage": 0.10,
+}
+
+
+def test_construction_matches_reference_contract():
+    from ai_economist_amd import foundation
+
+    env = foundation.make_env_instance(**ENV_CONFIG)
+    assert env.n_agents == ENV_CONFIG["n_agents"]
+    assert env.num_agents == ENV_CONFIG["n_agents"] + 1  # + the planner
+    assert [c.name for c in env.components] == ["Build", "ContinuousDoubleAuction", "Gather"]
+    assert env.resources == ["Coin", "Stone", "Wood"] and env.landmarks == ["House"]
+    with pytest.raises(NotImplementedError):
+        foundation.make_env_instance(**dict(ENV_CONFIG, flatten_observations=False))
+
+
+@pytest.mark.gpu
+def test_env_reset_and_step():
+    from ai_economist_amd import foundation
+
+    n = ENV_CONFIG["n_agents"]
+    env = foundation.make_env_instance(n_envs=8, device="cuda:0", **ENV_CONFIG)
+    env.seed(3)
+    obs = env.reset()
+    assert sorted(obs.keys()) == ["a", "p"]
+    assert tuple(obs["a"]["world-map"].shape) == (8, n, 6, 11, 11)  # no Water channel
+    assert tuple(obs["a"]["action_mask"].shape) == (8, n, 50)
+    # the per-replica view has exactly the reference's keys
+    ref_view = env.as_reference_dicts(0)
+    assert sorted(ref_view.keys()) == [str(i) for i in range(n)] + ["p"]
+    assert {"world-map", "world-idx_map", "time", "flat", "action_mask"} <= set(ref_view["0"].keys())
+    assert {"p0", "p1", "p2", "p3"} <= set(ref_view["p"].keys())
+
+    obs, reward, done, info = env.step({})  # no actions == all NO-OP (base_env.py:964-966)
+    assert obs.keys() == reward.keys()
+    assert obs.keys() == info.keys()
+    assert "__all__" in done
+    assert int(env.tensor("timestep").min()) == 1
+    # every replica got its own random layout and placement
+    flags = env.tensor("cell_flags").reshape(8, -1)
+    assert len({bytes(f.cpu().numpy().tobytes()) for f in flags}) > 1

@@ -5,7 +5,8 @@ import zlib
 import numpy as np
 import pytest
 
-from helpers import compare_state, golden_names, load_golden, make_env, state_from_golden
+from helpers import (compare_state, golden_names, load_golden, make_env, oracle_host_pre_reset,
+                     state_from_golden)
 from oracle_lib import OracleEnv
 
 OBS_TOL = 2e-6  # f32 observations: values are f64 in the reference, rounded once to f32
@@ -44,6 +45,7 @@ def test_oracle_step_matches_reference_golden(name):
         if (t + 1) in obs_steps:
             _obs_check(o, g, obs_steps.index(t + 1), "%s step %d" % (name, t + 1))
         if (t + 1) in resets:
+            oracle_host_pre_reset(env, o)
             o.reset()
             compare_state({k: v[0] for k, v in o.t.items()},
                           state_from_golden(g, "rs_", resets[t + 1]),
@@ -60,6 +62,7 @@ def test_oracle_reset_matches_reference_golden(name):
     o = OracleEnv(env.build_config(), env.layout_planes())
     o.t["mt"][0] = g["pre_reset_mt"]
     o.t["mt_pos"][0] = g["pre_reset_pos"]
+    oracle_host_pre_reset(env, o)
     o.reset()
     got = {k: v[0] for k, v in o.t.items()}
     want = state_from_golden(g, "s0_")
