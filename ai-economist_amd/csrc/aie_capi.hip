@@ -299,6 +299,20 @@ int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_of
   return AIE_OK;
 }
 
+int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_offset, int32_t* d_actions_a,
+                              int32_t* d_actions_p, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  const aie_params& P = env->P;
+  const int64_t tot = (int64_t)P.E * (P.n * P.act_a_width + P.act_p_width);
+  hipLaunchKernelGGL(aie_sample_masked_actions_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), P, env->arena, seed, global_env_offset, env->sample_t,
+                     d_actions_a, d_actions_p);
+  env->sample_t += 1;
+  AIE_HIP_CHECK(env, hipGetLastError());
+  return AIE_OK;
+}
+
 // Development aid (not part of include/aie.h): phases of the step kernel to skip.
 int aie_dev_set_skip_mask(aie_env* env, int mask) {
   if (!env) return AIE_E_INVALID;

@@ -1641,3 +1641,58 @@ extern "C" __global__ void aie_sample_actions_kernel(const aie_params P, uint64_
     act_p[(int64_t)e * P.act_p_width + (j - P.n * P.act_a_width)] = (int32_t)(((uint64_t)u * (uint64_t)range) >> 32);
   }
 }
+
+// Masked uniform random policy (see include/aie.h: aie_sample_masked_actions).  One thread
+// per (replica, agent) and one per (replica, planner subspace): count the allowed entries
+// of the relevant slice of the flattened mask, pick the floor(u * count)-th one.
+extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, const uint8_t* __restrict__ arena,
+                                                            uint64_t seed, int64_t env_offset, int64_t t,
+                                                            int32_t* __restrict__ act_a, int32_t* __restrict__ act_p) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_env = P.n * P.act_a_width + P.act_p_width;
+  if (q >= (int64_t)P.E * per_env) return;
+  const int e = (int)(q / per_env);
+  const int j = (int)(q - (int64_t)e * per_env);
+  const uint32_t u = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)j);
+  const float* mask;
+  int lo, len;
+  int32_t* dst;
+  if (j < P.n * P.act_a_width) {
+    if (!act_a) return;
+    const int i = j / P.act_a_width, s = j - i * P.act_a_width;
+    mask = reinterpret_cast<const float*>(arena + P.a_obs_a_mask) + ((int64_t)e * P.n + i) * P.MA;
+    if (P.c.multi_action_mode_agents) {
+      lo = 0;
+      for (int k = 0; k < s; ++k) lo += 1 + P.sub_a_dim[k];
+      len = P.n_sub_a ? 1 + P.sub_a_dim[s] : 1;
+    } else {
+      lo = 0;
+      len = P.MA;
+    }
+    dst = act_a + (int64_t)e * P.n * P.act_a_width + j;
+  } else {
+    if (!act_p) return;
+    const int s = j - P.n * P.act_a_width;
+    mask = reinterpret_cast<const float*>(arena + P.a_obs_p_mask) + (int64_t)e * P.MP;
+    if (P.c.multi_action_mode_planner) {
+      lo = s * (1 + P.sub_p_dim);
+      len = P.n_sub_p ? 1 + P.sub_p_dim : 1;
+    } else {
+      lo = 0;
+      len = P.MP;
+    }
+    dst = act_p + (int64_t)e * P.act_p_width + s;
+  }
+  int count = 0;
+  for (int k = 0; k < len; ++k) count += mask[lo + k] > 0.5f ? 1 : 0;
+  if (count == 0) { *dst = 0; return; }
+  int pick = (int)(((uint64_t)u * (uint64_t)count) >> 32);
+  int chosen = 0;
+  for (int k = 0; k < len; ++k) {
+    if (mask[lo + k] > 0.5f) {
+      if (pick == 0) { chosen = k; break; }
+      --pick;
+    }
+  }
+  *dst = chosen;
+}

@@ -127,17 +127,30 @@ class DeviceBackend:
         p = self._ptr(actions_p, torch.int32, "actions_p")
         self._check(self.lib.aie_step(self.handle, a, p, self._stream()))
 
-    def sample_random_actions(self, seed, env_offset=0, slot=0):
-        """Fills (and returns) caller-owned action buffers with the benchmark's uniform random
-        policy.  `slot` selects one of two buffer pairs so that the actions of step t+1 can be
-        sampled (on another stream) while step t still reads its own."""
+    def sample_masked_actions(self, seed, env_offset=0, slot=0):
+        """Like sample_random_actions, but every sub-action is drawn uniformly among the
+        entries the current `action_mask` observations allow."""
+        self.sample_random_actions  # noqa: B018  (buffers are shared)
+        a, p = self._action_buffers(slot)
+        self._check(self.lib.aie_sample_masked_actions(
+            self.handle, C.c_uint64(seed), C.c_int64(env_offset),
+            C.c_void_p(a.data_ptr()), C.c_void_p(p.data_ptr()), self._stream()))
+        return a, p
+
+    def _action_buffers(self, slot):
         torch = _torch()
         if self._rand_a is None:
             wa = 1 if not self.cfg.multi_action_mode_agents else max(1, self._n_sub_a())
             wp = self._act_p_width()
             self._rand_a = [torch.zeros((self.E, self.n, wa), dtype=torch.int32, device=self.device) for _ in range(2)]
             self._rand_p = [torch.zeros((self.E, wp), dtype=torch.int32, device=self.device) for _ in range(2)]
-        a, p = self._rand_a[slot], self._rand_p[slot]
+        return self._rand_a[slot], self._rand_p[slot]
+
+    def sample_random_actions(self, seed, env_offset=0, slot=0):
+        """Fills (and returns) caller-owned action buffers with the benchmark's uniform random
+        policy.  `slot` selects one of two buffer pairs so that the actions of step t+1 can be
+        sampled (on another stream) while step t still reads its own."""
+        a, p = self._action_buffers(slot)
         self._check(self.lib.aie_sample_random_actions(
             self.handle, C.c_uint64(seed), C.c_int64(env_offset),
             C.c_void_p(a.data_ptr()), C.c_void_p(p.data_ptr()), self._stream()))

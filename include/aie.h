@@ -228,6 +228,14 @@ int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_
 int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_offset,
                               int32_t* d_actions_a, int32_t* d_actions_p, void* stream);
 
+/* Same counter RNG, but each sub-action is drawn uniformly among the entries that the
+ * CURRENT action masks allow (obs_a_action_mask / obs_p_action_mask; NO-OP is always
+ * allowed).  This is the random policy a trainer starts from when it applies the
+ * `action_mask` observation to its logits (F/base/base_env.py:141-145,
+ * tutorials/rllib/env_wrapper.py:50-211 hand the mask to the policy network). */
+int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_offset, int32_t* d_actions_a,
+                              int32_t* d_actions_p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -323,3 +323,49 @@ def test_hip_matches_oracle_one_step_economy(variant):
             env.reset(be.tensors["done"])
             oracle.reset(oracle.t["done"].copy())
             _compare_all(be, oracle, "%s reset after step %d" % (variant, t + 1))
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_masked_action_sampler_respects_masks(multi):
+    """aie_sample_masked_actions: every sampled sub-action is allowed by the current mask,
+    all allowed entries get sampled, and a masked rollout still matches the oracle."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    cfg = dict(C2, episode_length=120, resource_regen_prob=0.05, multi_action_mode_agents=multi,
+               env_layout_file="uniform_25x25_25each_65clump.txt")
+    E = 256
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(2)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(2)
+    oracle.reset()
+    seen_move = np.zeros(5, bool)
+    for t in range(60):
+        a, p = be.sample_masked_actions(seed=5)
+        torch.cuda.synchronize()
+        ma = be.tensors["obs_a_action_mask"].cpu().numpy()
+        mp = be.tensors["obs_p_action_mask"].cpu().numpy()
+        an, pn = a.cpu().numpy(), p.cpu().numpy()
+        if multi:
+            off = 0
+            dims = [1, 11, 11, 11, 11, 4]
+            for s, d in enumerate(dims):
+                sel = np.take_along_axis(ma[:, :, off:off + d + 1], an[:, :, s:s + 1], axis=2)
+                assert np.all(sel == 1.0), "masked sub-action sampled (subspace %d)" % s
+                off += d + 1
+            seen_move[np.unique(an[:, :, 5])] = True
+        else:
+            sel = np.take_along_axis(ma, an[:, :, :1], axis=2)
+            assert np.all(sel == 1.0), "masked action sampled"
+        for b in range(7):
+            sel = np.take_along_axis(mp[:, b * 22:(b + 1) * 22], pn[:, b:b + 1], axis=1)
+            assert np.all(sel == 1.0), "masked planner action sampled"
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(an, pn, nthreads=4)
+    _compare_all(be, oracle, "masked rollout")
+    if multi:
+        assert seen_move.all()
