@@ -5,7 +5,7 @@ by env.py purely as the owner of device memory / streams.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_AGENTS = 64
 MAX_AGENTS_WIDE = 128
 MAX_COMPONENTS = 8
@@ -15,7 +15,10 @@ N_RES = 2
 MT_N = 624
 
 COMP_BUILD, COMP_CDA, COMP_GATHER, COMP_TAX, COMP_SIMPLE_LABOR = 1, 2, 3, 4, 5
-SCN_GTB, SCN_ONE_STEP_ECONOMY = 0, 1
+COMP_COVID_CONTROL, COMP_COVID_SUBSIDY, COMP_COVID_VACCINE = 6, 7, 8
+SCN_GTB, SCN_ONE_STEP_ECONOMY, SCN_COVID = 0, 1, 2
+COVID_MAX_FILTERS = 8
+MAX_TENSORS = 128  # AIE_MAX_TENSORS (csrc/aie_layout.h)
 AGENT_REWARD = {"coin_minus_labor_cost": 0, "isoelastic_coin_minus_labor": 1}
 SKILL = {"none": 0, "pareto": 1, "lognormal": 2}
 TAX_MODEL = {
@@ -33,6 +36,20 @@ PLANNER_REWARD = {
 E_INVALID, E_NOTFOUND, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5
 
 DTYPES = ["uint8", "int8", "int16", "int32", "uint32", "float32", "float64"]
+
+
+class AieCovidConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "num_stringency_levels", "beta_delay", "filter_len", "num_filters", "action_cooldown_period",
+        "subsidy_interval", "num_subsidy_levels", "delivery_interval", "time_when_vaccine_delivery_begins",
+        "reserved_")] + [(k, C.c_double) for k in (
+            "death_rate", "gamma", "value_of_life", "daily_production_per_worker",
+            "infection_too_sick_to_work_rate", "population_between_age_18_65", "risk_free_interest_rate",
+            "economic_reward_crra_eta", "planner_health_norm", "planner_economic_norm",
+            "min_marginal_planner_health_index", "max_marginal_planner_health_index",
+            "min_marginal_planner_economic_index", "max_marginal_planner_economic_index",
+            "weightage_on_marginal_planner_health_index", "weightage_on_marginal_planner_economic_index",
+            "reward_normalization_factor")]
 
 
 class AieConfig(C.Structure):
@@ -94,6 +111,7 @@ class AieConfig(C.Structure):
         ("labor_num_hours", C.c_int32),
         ("labor_pmsm", C.c_double),
         ("labor_skills", C.c_double * MAX_AGENTS_WIDE),
+        ("covid", AieCovidConfig),
     ]
 
 

@@ -9,6 +9,7 @@
 
 #include "aie_kernels.hip"
 #include "aie_kernels_ose.hip"
+#include "aie_kernels_covid.hip"  // last: switches FP contraction off for the rest of the TU
 
 struct aie_env {
   aie_params P;
@@ -71,8 +72,9 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
   int rc = aie_build_params(cfg, &env->P, &env->tt, g_create_err, sizeof(g_create_err));
   if (rc != AIE_OK) { delete env; return rc; }
   env->device = device;
-  const bool ose = cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY;
-  env->lds = ose ? aie::ose_lds_bytes(env->P) : aie::lds_bytes(env->P);
+  const bool covid = cfg->scenario == AIE_SCN_COVID;
+  const bool ose = cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY || covid;  // map-less: no cell words to initialise
+  env->lds = covid ? 0 : cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY ? aie::ose_lds_bytes(env->P) : aie::lds_bytes(env->P);
   if (env->lds > 64 * 1024) {
     snprintf(g_create_err, sizeof(g_create_err),
              "per-replica working set (%zu B of LDS) exceeds 64 KiB: reduce max_num_orders / world size", env->lds);
@@ -238,6 +240,7 @@ int aie_set_layout(aie_env* env, const uint8_t* stone_src, const uint8_t* wood_s
 
 int aie_seed(aie_env* env, uint32_t base_seed, void* stream) {
   if (!env) return AIE_E_INVALID;
+  if (env->P.c.scenario == AIE_SCN_COVID) return AIE_OK;  // the COVID simulation draws no random numbers
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   hipLaunchKernelGGL(aie_seed_kernel, dim3((unsigned)((env->P.E + 63) / 64)), dim3(64), 0,
                      static_cast<hipStream_t>(stream), env->P, env->arena, base_seed);
@@ -247,6 +250,10 @@ int aie_seed(aie_env* env, uint32_t base_seed, void* stream) {
 
 int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos) {
   if (!env || !key || !pos) return AIE_E_INVALID;
+  if (env->P.c.scenario == AIE_SCN_COVID) {
+    snprintf(env->err, sizeof(env->err), "the COVID scenario has no random stream");
+    return AIE_E_UNSUPPORTED;
+  }
   const int64_t E = env->P.E;
   int rc = aie_upload(env, "mt", key, E * AIE_MT_N * 4);
   if (rc != AIE_OK) return rc;
@@ -262,7 +269,10 @@ int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos) {
 int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
   if (!env) return AIE_E_INVALID;
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
-  if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
+  if (env->P.c.scenario == AIE_SCN_COVID)
+    hipLaunchKernelGGL(aie_covid_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0,
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
+  else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
   else
@@ -275,7 +285,18 @@ int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
 int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream) {
   if (!env) return AIE_E_INVALID;
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
-  if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
+  if (env->P.c.scenario == AIE_SCN_COVID) {
+    const dim3 g((unsigned)env->P.E), b(AIE_NT);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define AIE_CV_LAUNCH(FN) \
+  case FN: hipLaunchKernelGGL(aie_covid_step_kernel<FN>, g, b, 0, st, env->d_params, env->arena, d_actions_a, d_actions_p); break
+    switch (env->P.cv_F) {
+      AIE_CV_LAUNCH(1); AIE_CV_LAUNCH(2); AIE_CV_LAUNCH(3); AIE_CV_LAUNCH(4);
+      AIE_CV_LAUNCH(5); AIE_CV_LAUNCH(6); AIE_CV_LAUNCH(7); AIE_CV_LAUNCH(8);
+      default: return AIE_E_UNSUPPORTED;
+    }
+#undef AIE_CV_LAUNCH
+  } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
   else
@@ -302,6 +323,10 @@ int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_of
 int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_offset, int32_t* d_actions_a,
                               int32_t* d_actions_p, void* stream) {
   if (!env) return AIE_E_INVALID;
+  if (env->P.c.scenario == AIE_SCN_COVID) {
+    snprintf(env->err, sizeof(env->err), "masked sampling is not implemented for the COVID scenario");
+    return AIE_E_UNSUPPORTED;
+  }
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   const aie_params& P = env->P;
   const int64_t tot = (int64_t)P.E * (P.n * P.act_a_width + P.act_p_width);

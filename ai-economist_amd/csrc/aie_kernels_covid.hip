@@ -1,0 +1,389 @@
+// aie_kernels_covid.hip -- the COVID-19 scenario + its three components as ONE fused gfx950
+// kernel per env.step() (the reference launches five CUDA kernels through WarpDrive:
+// F/components/covid19_components_step.cu:10-262, F/scenarios/covid19/covid19_env_step.cu:274-619).
+//
+// Parity target is the reference's CPU path (`use_cuda=False`):
+//   ControlUSStateOpenCloseStatus.component_step   F/components/covid19_components.py:180-221
+//   FederalGovernmentSubsidy.component_step        :393-443
+//   VaccinationCampaign.component_step             :615-627
+//   CovidAndEconomyEnvironment.scenario_step       F/scenarios/covid19/covid19_env.py:744-792
+//     sir_step :1477-1515, unemployment_step :1374-1441, economy_step :1444-1475
+//   generate_observations :919-993, generate_masks (components), compute_reward :995-1173
+//
+// Mapping: one wavefront per replica, lane s = US state s.  Nothing is shared between lanes
+// except the three 51-term planner sums, which go through LDS in NumPy's pairwise order.
+// Every float32 / float64 conversion below sits where NumPy's promotion rules put it in the
+// reference (float32 arrays; float32 x int32 -> float64; NumPy scalars are strongly typed),
+// and the file is compiled with FP contraction off so that a*b+c stays two roundings.
+// The only deliberate reassociation is the unemployment filter bank: the reference
+// materialises delta[l]*w[s,f]*filt[f,l] and np.sum()s 3000 terms; here each lane streams its
+// own 600-day window of stringency levels once and keeps F float64 accumulators (FMA),
+// weighting them by w[s,f] at the end -- a float64 reordering, ~1e-16 relative.
+#pragma clang fp contract(off)
+
+namespace aie {
+
+__device__ __forceinline__ float np_sum_f32_lds(const float* a, int n) {
+  // NumPy pairwise_sum for n <= 128 (numpy/core/src/umath/loops_utils.h.src): 8 strided
+  // partial sums over the first n - n%8 elements, a fixed combination tree, then the tail.
+  if (n < 8) {
+    float r = 0.f;  // np.add.reduce starts from the first element; 0 + a0 is exact
+    for (int i = 0; i < n; ++i) r = r + a[i];
+    return r;
+  }
+  float r[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = a[k];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = r[k] + a[i + k];
+  }
+  float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res = res + a[i];
+  return res;
+}
+
+struct CvLane {
+  float S, I, R, D, V, U, prod, subsidy;
+  int level;     // stringency level in force at the current timestep
+  int cooldown;  // ControlUSStateOpenCloseStatus.action_in_cooldown_until
+};
+
+__device__ __forceinline__ uint8_t* cv_hist_base(const aie_params& P, uint8_t* arena, int e) {
+  return arena + P.a_cv_hist + (int64_t)e * P.cv_nch * P.cv_row;
+}
+__device__ __forceinline__ uint8_t* cv_hist_at(const aie_params& P, uint8_t* hist, int s, int tau) {
+  return hist + (int64_t)(tau >> 4) * P.cv_row + s * 16 + (tau & 15);
+}
+
+// crra_nonlinearity (covid19_env.py:1056-1078), float32 like the reference's arrays
+__device__ __forceinline__ float cv_crra(float x, float eta) {
+  float ax = 365.0f * x;
+  ax = fminf(fmaxf(ax, 0.1f), 3.0f);
+  const float ome = 1.0f - eta;
+  const float num = powf(ax, ome) - 1.0f;
+  return (1.0f + num / ome) / 365.0f;
+}
+__device__ __forceinline__ float cv_minmax(float x, float lo, float hi) { return (x - lo) / (hi - lo + 1e-10f); }
+
+// generate_observations + the three components' obs and masks, for timestep t.
+__device__ __forceinline__ void cv_write_observations(const aie_params& P, uint8_t* __restrict__ arena, int e, int s,
+                                                      int t, const CvLane& a, int subsidy_level,
+                                                      const uint8_t* hist) {
+  const aie_covid_config& V = P.c.covid;
+  const int n = P.n, NL = P.cv_NL, NS = P.cv_NS, T = P.c.episode_length;
+  const bool on = s < n;
+  const double* K = reinterpret_cast<const double*>(arena + P.a_cv_consts);
+  float* oa = reinterpret_cast<float*>(arena + P.a_cv_obs_a + (int64_t)e * P.cv_nrow_obs * n * 4);
+  float* op = reinterpret_cast<float*>(arena + P.a_cv_obs_p + (int64_t)e * (4 + P.MP) * 4);
+  const int sl = on ? s : n - 1;
+  const double pop = K[AIE_CV_K_POP * 64 + sl];
+  // float32 state / int32 population -> float64, stored as float32 (:930-947)
+  const float f6[6] = {a.S, a.I, a.R, a.D, a.V, a.U};
+  const float time_f = (float)((double)t / (double)T);
+  const int until = V.subsidy_interval - t % V.subsidy_interval;
+  const float t_sub = (float)((double)until / (double)V.subsidy_interval);
+  const float sub_lvl = (float)((double)subsidy_level / (double)NS);
+  // VaccinationCampaign.generate_observations :629-653
+  const int nt = t + 1, tf = P.cv_t_first_delivery, di = V.delivery_interval;
+  double tv;
+  if (nt <= tf) {
+    tv = (double)(tf - nt) / (double)di;
+    tv = tv < 1.0 ? tv : 1.0;
+  } else {
+    tv = (double)(di - nt % di);
+  }
+  const float t_vac = (float)(tv / (double)di);
+  // lagged stringency level (:957-970)
+  const int tb = t - V.beta_delay + 1;
+  float lag;
+  if (tb < 0) {
+    const uint8_t* tab = arena + P.a_cv_lag_obs;
+    lag = (float)((double)tab[(tb + V.beta_delay) * n + sl] / (double)NL);
+  } else {
+    lag = (float)*(hist + (int64_t)((P.cv_L + tb) >> 4) * P.cv_row + sl * 16 + ((P.cv_L + tb) & 15)) / (float)NL;
+  }
+  if (on) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) oa[(AIE_CV_OB_STATE + k) * n + s] = (float)((double)f6[k] / pop);
+    oa[AIE_CV_OB_PROD * n + s] = a.prod / (float)K[AIE_CV_K_MAX_PROD * 64 + s];
+    oa[AIE_CV_OB_LAG * n + s] = lag;
+    oa[AIE_CV_OB_TIME * n + s] = time_f;
+    oa[AIE_CV_OB_POLICY * n + s] = (float)a.level / (float)NL;
+    oa[AIE_CV_OB_T_SUBSIDY * n + s] = t_sub;
+    oa[AIE_CV_OB_SUBSIDY_LEVEL * n + s] = sub_lvl;
+    oa[AIE_CV_OB_T_VACCINE * n + s] = t_vac;
+    // generate_masks: NO-OP always allowed; levels only outside the cooldown (:97-108,223-241)
+    const float open = t >= a.cooldown ? 1.0f : 0.0f;
+    oa[AIE_CV_OB_MASK * n + s] = 1.0f;
+    for (int k = 1; k <= NL; ++k) oa[(AIE_CV_OB_MASK + k) * n + s] = open;
+  }
+  if (s == 0) {
+    op[0] = time_f;
+    op[1] = t_sub;
+    op[2] = sub_lvl;
+    op[3] = t_vac;
+  }
+  // planner mask: subsidy levels selectable only on the first day of an interval (:445-469)
+  const float pm = (t % V.subsidy_interval == 0) ? 1.0f : 0.0f;
+  for (int k = s; k < P.MP; k += AIE_NT) op[4 + k] = k == 0 ? 1.0f : pm;
+}
+
+}  // namespace aie
+
+// ---- reset: CovidAndEconomyEnvironment.reset_starting_layout / reset_agent_states /
+// additional_reset_steps (covid19_env.py:1175-1293) + the components' additional_reset_steps.
+extern "C" __global__ void __launch_bounds__(AIE_NT)
+    aie_covid_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                           const uint8_t* __restrict__ env_mask) {
+  using namespace aie;
+  const aie_params& P = *params;
+  const int e = replica_of_block((int)blockIdx.x, P.E);
+  if (env_mask && !env_mask[e]) return;
+  const int s = (int)threadIdx.x, n = P.n, L = P.cv_L;
+  const bool on = s < n;
+  uint8_t* rec = arena + P.a_records + (int64_t)e * P.rec_bytes;
+  float* st = reinterpret_cast<float*>(rec + P.o_cv_state);
+  const double* K = reinterpret_cast<const double*>(arena + P.a_cv_consts);
+  uint8_t* hist = cv_hist_base(P, arena, e);
+  // history: days -L..0 from the shared table, the episode's own days zeroed
+  const uint8_t* h0 = arena + P.a_cv_hist0;
+  for (int c = 0; c < P.cv_nch; ++c) {
+    if (s * 16 < P.cv_row) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (on) {
+        for (int j = 0; j < 16; ++j) {
+          const int tau = 16 * c + j;
+          if (tau <= L) w[j >> 2] |= (uint32_t)h0[tau * n + s] << (8 * (j & 3));
+        }
+      }
+      *reinterpret_cast<uint4*>(hist + (int64_t)c * P.cv_row + s * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  CvLane a;
+  const int sl = on ? s : n - 1;
+  a.S = (float)K[AIE_CV_K_S0 * 64 + sl];
+  a.I = (float)K[AIE_CV_K_I0 * 64 + sl];
+  a.R = (float)K[AIE_CV_K_R0 * 64 + sl];
+  a.D = (float)K[AIE_CV_K_D0 * 64 + sl];
+  a.V = (float)K[AIE_CV_K_V0 * 64 + sl];
+  a.U = (float)K[AIE_CV_K_U0 * 64 + sl];
+  a.prod = 0.f;
+  a.subsidy = 0.f;
+  a.level = h0[L * n + sl];
+  a.cooldown = 0;
+  st[AIE_CV_ST_S * 64 + s] = on ? a.S : 0.f;
+  st[AIE_CV_ST_I * 64 + s] = on ? a.I : 0.f;
+  st[AIE_CV_ST_R * 64 + s] = on ? a.R : 0.f;
+  st[AIE_CV_ST_D * 64 + s] = on ? a.D : 0.f;
+  st[AIE_CV_ST_V * 64 + s] = on ? a.V : 0.f;
+  st[AIE_CV_ST_U * 64 + s] = on ? a.U : 0.f;
+  st[AIE_CV_ST_PROD * 64 + s] = 0.f;
+  st[AIE_CV_ST_SUBSIDY * 64 + s] = 0.f;
+  reinterpret_cast<int32_t*>(rec + P.o_cv_cooldown)[s] = 0;
+  if (s == 0) {
+    *reinterpret_cast<int32_t*>(rec + P.o_cv_subsidy_level) = 0;
+    *reinterpret_cast<int32_t*>(rec + P.o_timestep) = 0;
+    arena[P.a_done + e] = 0;
+    reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.f;
+  }
+  if (on) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + s] = 0.f;
+  __syncthreads();  // the history bytes written above are read back for the lagged observation
+  cv_write_observations(P, arena, e, s, 0, a, 0, hist);
+}
+
+// ---- one env.step() (base_env.py:929-1032) ----
+template <int F>
+__global__ void __launch_bounds__(AIE_NT)
+    aie_covid_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                          const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
+  using namespace aie;
+  __shared__ float red[3][64];
+  const aie_params& P = *params;
+  const aie_covid_config& V = P.c.covid;
+  const int e = replica_of_block((int)blockIdx.x, P.E);
+  const int s = (int)threadIdx.x, n = P.n, L = P.cv_L, NL = P.cv_NL, NS = P.cv_NS;
+  const bool on = s < n;
+  const int sl = on ? s : n - 1;  // idle lanes shadow the last state (loads stay in bounds)
+  uint8_t* rec = arena + P.a_records + (int64_t)e * P.rec_bytes;
+  float* st = reinterpret_cast<float*>(rec + P.o_cv_state);
+  int32_t* cool = reinterpret_cast<int32_t*>(rec + P.o_cv_cooldown);
+  const double* K = reinterpret_cast<const double*>(arena + P.a_cv_consts);
+  uint8_t* hist = cv_hist_base(P, arena, e);
+  const int T = P.c.episode_length;
+  const int t = uni(*reinterpret_cast<const int32_t*>(rec + P.o_timestep)) + 1;
+  if (t > T) return;  // episode over: the caller has to reset (the reference would index past its arrays)
+
+  // ---- ControlUSStateOpenCloseStatus.component_step :180-221 ----
+  int act = act_a ? act_a[(int64_t)e * n + sl] : 0;
+  if (act < 0 || act > NL) act = 0;
+  const int prev_level = *cv_hist_at(P, hist, sl, L + t - 1);
+  CvLane a;
+  a.level = act == 0 ? prev_level : act;
+  a.cooldown = cool[sl];
+  if (t == a.cooldown + 1) a.cooldown += act == 0 ? 1 : V.action_cooldown_period;
+
+  // ---- FederalGovernmentSubsidy.component_step :393-443 ----
+  int sub_level = uni(*reinterpret_cast<const int32_t*>(rec + P.o_cv_subsidy_level));
+  if ((t - 1) % V.subsidy_interval == 0) {
+    int ap = act_p ? uni(act_p[e]) : 0;
+    if (ap < 0 || ap > NS) ap = 0;
+    sub_level = ap;
+  }
+  a.subsidy = (float)(((double)sub_level / (double)NS) * K[AIE_CV_K_MAX_DAILY_SUBSIDY * 64 + sl]);
+
+  // ---- VaccinationCampaign.component_step :615-627 (consumed by the scenario step below) ----
+  const int vac = (t >= V.time_when_vaccine_delivery_begins && t % V.delivery_interval == 0)
+                      ? (int)K[AIE_CV_K_VACCINES_PER_DELIVERY * 64 + sl]
+                      : 0;
+
+  // ---- sir_step :1477-1515 ----
+  const float S1 = st[AIE_CV_ST_S * 64 + sl], I1 = st[AIE_CV_ST_I * 64 + sl], R1 = st[AIE_CV_ST_R * 64 + sl];
+  const float V1 = st[AIE_CV_ST_V * 64 + sl], D1 = st[AIE_CV_ST_D * 64 + sl];
+  const double pop = K[AIE_CV_K_POP * 64 + sl];
+  {
+    const int beta_level = *cv_hist_at(P, hist, sl, L + t - V.beta_delay);  // days before the data: level 1
+    const float beta = (float)(K[AIE_CV_K_BETA_INTERCEPT * 64 + sl] + K[AIE_CV_K_BETA_SLOPE * 64 + sl] * (double)beta_level);
+    const float s_eps = S1 + 1e-10f;
+    const double q = (double)vac / (double)s_eps;
+    const float frac_vaccinated = (float)(q < 1.0 ? q : 1.0);
+    const double vaccinated_t = (double)vac < (double)S1 ? (double)vac : (double)S1;
+    const double si_over_n = ((double)S1 / pop) * (double)I1;
+    const float one_minus = 1.0f - frac_vaccinated;
+    const float dS = (float)(((double)(-beta) * si_over_n) * (double)one_minus - vaccinated_t);
+    const float gI = (float)V.gamma * I1;
+    const float dR = (float)((double)gI + vaccinated_t);
+    const float dI = -dS - dR;
+    const float dV = (float)vaccinated_t;
+    a.S = fmaxf(S1 + dS, 0.f);
+    a.I = fmaxf(I1 + dI, 0.f);
+    a.R = fmaxf(R1 + dR, 0.f);
+    a.V = fmaxf(V1 + dV, 0.f);
+    a.D = (float)V.death_rate * (a.R - a.V);
+  }
+
+  // ---- unemployment_step :1374-1441 ----
+  // deltas of the 601 most recent daily levels (history index tau in [t, t+L]), filter tap
+  // l = tau' - t - 1 for the delta between days tau'-1 and tau'.
+  double unemployed;
+  {
+    const double* G = reinterpret_cast<const double*>(arena + P.a_cv_filters);
+    double acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.0;
+    const int tau_lo = t, tau_hi = t + L - 1;  // levels that come from memory
+    const uint8_t* row = hist + sl * 16;
+    int carry = 0;
+    const int c0 = tau_lo >> 4, c1 = tau_hi >> 4;
+    uint4 w = *reinterpret_cast<const uint4*>(row + (int64_t)c0 * P.cv_row);
+    for (int c = c0; c <= c1; ++c) {
+      const uint4 wn = c < c1 ? *reinterpret_cast<const uint4*>(row + (int64_t)(c + 1) * P.cv_row) : w;
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+      const int base = 16 * c;
+      if (base > tau_lo && base + 15 <= tau_hi) {
+        const int l0 = base - t - 1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int lev = (int)((ww[j >> 2] >> (8 * (j & 3))) & 0xffu);
+          const double d = (double)(lev - carry);
+          carry = lev;
+#pragma unroll
+          for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, G[f * L + l0 + j], acc[f]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int tau = base + j;
+          const int lev = (int)((ww[j >> 2] >> (8 * (j & 3))) & 0xffu);
+          if (tau > tau_lo && tau <= tau_hi) {
+            const double d = (double)(lev - carry);
+            const int l = tau - t - 1;
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, G[f * L + l], acc[f]);
+          }
+          carry = lev;
+        }
+      }
+      w = wn;
+    }
+    // the newest delta: today's level against yesterday's
+    const double d_last = (double)(a.level - (L >= 1 ? prev_level : a.level));
+    double x = 0.0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      acc[f] = __builtin_fma(d_last, G[f * L + L - 1], acc[f]);
+      x = x + K[(AIE_CV_K_CONV_W0 + f) * 64 + sl] * acc[f];
+    }
+    const double excess = x <= 20.0 ? log(1.0 + exp(x)) : x;  // softplus :1358-1372
+    unemployed = ((excess + K[AIE_CV_K_UNEMP_BIAS * 64 + sl]) * pop) / 100.0;
+    a.U = (float)unemployed;
+  }
+
+  // ---- economy_step :1444-1475 ----
+  {
+    const float incapacitated = (float)V.infection_too_sick_to_work_rate * a.I + a.D;
+    const float p1865 = (float)V.population_between_age_18_65;
+    const double cant_work = (double)(incapacitated * p1865) + unemployed;
+    const double workers = pop * (double)p1865;
+    const double diff = workers - cant_work;
+    a.prod = (float)((diff > 0.0 ? diff : 0.0) * (double)(float)V.daily_production_per_worker) + a.subsidy;
+  }
+
+  // ---- state write-back ----
+  if (on) {
+    *cv_hist_at(P, hist, s, L + t) = (uint8_t)a.level;
+    cool[s] = a.cooldown;
+    st[AIE_CV_ST_S * 64 + s] = a.S;
+    st[AIE_CV_ST_I * 64 + s] = a.I;
+    st[AIE_CV_ST_R * 64 + s] = a.R;
+    st[AIE_CV_ST_D * 64 + s] = a.D;
+    st[AIE_CV_ST_V * 64 + s] = a.V;
+    st[AIE_CV_ST_U * 64 + s] = a.U;
+    st[AIE_CV_ST_PROD * 64 + s] = a.prod;
+    st[AIE_CV_ST_SUBSIDY * 64 + s] = a.subsidy;
+  }
+  if (s == 0) {
+    *reinterpret_cast<int32_t*>(rec + P.o_timestep) = t;
+    *reinterpret_cast<int32_t*>(rec + P.o_cv_subsidy_level) = sub_level;
+  }
+
+  // ---- compute_reward :995-1173 ----
+  const float marginal_deaths = a.D - D1;
+  red[0][s] = on ? marginal_deaths : 0.f;
+  red[1][s] = on ? a.subsidy : 0.f;
+  red[2][s] = on ? a.prod : 0.f;
+  __syncthreads();
+  const float eta = (float)V.economic_reward_crra_eta;
+  const float rnf = (float)V.reward_normalization_factor;
+  if (on) {
+    const float hn = (float)K[AIE_CV_K_HEALTH_NORM * 64 + s];
+    float h = (float)(((double)(-marginal_deaths) * V.value_of_life) / (double)hn);
+    float ec = cv_crra(a.prod / (float)K[AIE_CV_K_ECON_NORM * 64 + s], eta);
+    h = cv_minmax(h, (float)K[AIE_CV_K_MIN_HEALTH * 64 + s], (float)K[AIE_CV_K_MAX_HEALTH * 64 + s]);
+    ec = cv_minmax(ec, (float)K[AIE_CV_K_MIN_ECON * 64 + s], (float)K[AIE_CV_K_MAX_ECON * 64 + s]);
+    const float wh = (float)K[AIE_CV_K_W_HEALTH * 64 + s], we = (float)K[AIE_CV_K_W_ECON * 64 + s];
+    reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + s] = ((wh * h + we * ec) / (wh + we)) / rnf;
+  }
+  if (s == 0) {
+    const float sum_md = np_sum_f32_lds(red[0], n);
+    const float sum_sub = np_sum_f32_lds(red[1], n);
+    const float sum_pp = np_sum_f32_lds(red[2], n);
+    double ph = ((double)(-sum_md) * V.value_of_life) / (double)(float)V.planner_health_norm;
+    const float cost = (1.0f + (float)V.risk_free_interest_rate) * sum_sub;
+    float pe = cv_crra((sum_pp - cost) / (float)V.planner_economic_norm, eta);
+    const float lo_h = (float)V.min_marginal_planner_health_index, hi_h = (float)V.max_marginal_planner_health_index;
+    ph = (ph - (double)lo_h) / (double)(hi_h - lo_h + 1e-10f);
+    pe = cv_minmax(pe, (float)V.min_marginal_planner_economic_index, (float)V.max_marginal_planner_economic_index);
+    const float wph = (float)V.weightage_on_marginal_planner_health_index;
+    const float wpe = (float)V.weightage_on_marginal_planner_economic_index;
+    const double rp = (((double)wph * ph + (double)(wpe * pe)) / (double)(wph + wpe)) / (double)rnf;
+    reinterpret_cast<float*>(arena + P.a_rew_p)[e] = (float)rp;
+    arena[P.a_done + e] = t >= T ? 1 : 0;
+    if (t >= T) *reinterpret_cast<int32_t*>(rec + P.o_completions) += 1;
+  }
+
+  // ---- observations + masks for the new timestep ----
+  __syncthreads();  // today's level byte (written above) may be the lagged observation when beta_delay == 1
+  cv_write_observations(P, arena, e, s, t, a, sub_level, hist);
+}

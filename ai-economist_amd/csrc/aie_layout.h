@@ -28,7 +28,7 @@
 
 #include "aie.h"
 
-#define AIE_MAX_TENSORS 64
+#define AIE_MAX_TENSORS 128
 
 /* internal action-subspace slots of a mobile agent */
 enum {
@@ -104,6 +104,26 @@ typedef struct aie_params {
   /* development only: phases of the step kernel to skip when profiling
    * (tools/phase_profile.py); always 0 in normal operation */
   int32_t dev_skip_mask;
+
+  /* ---- COVID-19 scenario (aie__build_covid) ---- */
+  int32_t cv_L;          /* filter_len                                                     */
+  int32_t cv_F;          /* num_filters                                                    */
+  int32_t cv_NL;         /* num_stringency_levels                                          */
+  int32_t cv_NS;         /* num_subsidy_levels                                             */
+  int32_t cv_nch;        /* 16-day chunks in the per-replica stringency history           */
+  int32_t cv_row;        /* bytes per history chunk = 16 * n rounded up to 64              */
+  int32_t cv_nrow_obs;   /* rows of the per-replica agent observation block               */
+  int32_t cv_t_first_delivery;
+  int32_t o_cv_state;    /* record: AIE_CV_ST_* float32 rows of 64 lanes                  */
+  int32_t o_cv_cooldown; /* record: int32 row                                              */
+  int32_t o_cv_subsidy_level;
+  int64_t a_cv_consts;   /* AIE_CV_K_* float64 rows of 64 (shared by all replicas)         */
+  int64_t a_cv_filters;  /* float64 [F][L]                                                 */
+  int64_t a_cv_hist0;    /* uint8 [L+1][n]   stringency levels of the L days before t=0 + t=0 */
+  int64_t a_cv_lag_obs;  /* uint8 [beta_delay][n]                                          */
+  int64_t a_cv_hist;     /* uint8 [E][nch][cv_row]                                         */
+  int64_t a_cv_obs_a;    /* float32 [E][cv_nrow_obs][n]                                    */
+  int64_t a_cv_obs_p;    /* float32 [E][4 + 1 + NS]                                        */
   int32_t dev_pad;
 } aie_params;
 
@@ -166,6 +186,164 @@ static inline void aie__add(aie_tensor_table* tt, const char* name, int dtype, i
   }
   d->arena_offset = off;
   d->data = NULL;
+}
+
+/* ---- COVID-19 (F/scenarios/covid19/covid19_env.py + F/components/covid19_components.py) ----
+ * One wavefront per replica, one lane per US state.  Per-state model constants are float64
+ * rows of 64 lanes (values the reference holds as float32 / int32 are exactly representable);
+ * the stringency history is kept per replica as [16-day chunk][state][16 bytes] so that a
+ * lane streams its own 601-day window with 16-byte loads that are contiguous across lanes. */
+enum {
+  AIE_CV_K_POP = 0, AIE_CV_K_BETA_SLOPE, AIE_CV_K_BETA_INTERCEPT, AIE_CV_K_UNEMP_BIAS,
+  AIE_CV_K_MAX_PROD, AIE_CV_K_HEALTH_NORM, AIE_CV_K_ECON_NORM,
+  AIE_CV_K_MIN_HEALTH, AIE_CV_K_MAX_HEALTH, AIE_CV_K_MIN_ECON, AIE_CV_K_MAX_ECON,
+  AIE_CV_K_W_HEALTH, AIE_CV_K_W_ECON, AIE_CV_K_MAX_DAILY_SUBSIDY, AIE_CV_K_VACCINES_PER_DELIVERY,
+  AIE_CV_K_S0, AIE_CV_K_I0, AIE_CV_K_R0, AIE_CV_K_D0, AIE_CV_K_U0, AIE_CV_K_V0,
+  AIE_CV_K_CONV_W0,                                       /* + f, f < AIE_COVID_MAX_FILTERS */
+  AIE_CV_K_COUNT = AIE_CV_K_CONV_W0 + AIE_COVID_MAX_FILTERS
+};
+enum { AIE_CV_ST_S = 0, AIE_CV_ST_I, AIE_CV_ST_R, AIE_CV_ST_D, AIE_CV_ST_V, AIE_CV_ST_U,
+       AIE_CV_ST_PROD, AIE_CV_ST_SUBSIDY, AIE_CV_ST_COUNT };
+/* rows of the agent observation block */
+enum { AIE_CV_OB_STATE = 0, AIE_CV_OB_PROD = 6, AIE_CV_OB_LAG = 7, AIE_CV_OB_TIME = 8, AIE_CV_OB_POLICY = 9,
+       AIE_CV_OB_T_SUBSIDY = 10, AIE_CV_OB_SUBSIDY_LEVEL = 11, AIE_CV_OB_T_VACCINE = 12, AIE_CV_OB_MASK = 13 };
+
+static inline void aie__add_shared(aie_tensor_table* tt, const char* name, int dtype, int64_t off,
+                                   int nd, int64_t d0, int64_t d1) {
+  aie__add(tt, name, dtype, off, 0, nd, d0, d1, 0, 0, 1);
+}
+
+static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tensor_table* tt,
+                                   char* err, size_t errlen) {
+  const aie_covid_config* v = &c->covid;
+  if (c->n_agents > AIE_MAX_AGENTS) AIE__FAIL("n_agents > %d unsupported for the COVID scenario", AIE_MAX_AGENTS);
+  if (c->multi_action_mode_agents || c->multi_action_mode_planner)
+    AIE__FAIL("the COVID scenario uses single-action mode for agents and planner");
+  static const int want[3] = {AIE_COMP_COVID_CONTROL, AIE_COMP_COVID_SUBSIDY, AIE_COMP_COVID_VACCINE};
+  if (c->n_components != 3) AIE__FAIL("the COVID scenario needs exactly its three components");
+  for (int i = 0; i < 3; ++i)
+    if (c->components[i] != want[i])
+      AIE__FAIL("COVID components must be ControlUSStateOpenCloseStatus, FederalGovernmentSubsidy, VaccinationCampaign (in this order)");
+  if (v->num_stringency_levels < 1 || v->num_stringency_levels > 100) AIE__FAIL("num_stringency_levels out of range");
+  if (v->beta_delay < 1 || v->beta_delay > 4096) AIE__FAIL("beta_delay out of range");
+  if (v->filter_len < 1 || v->filter_len > 65536) AIE__FAIL("filter_len out of range");
+  if (v->num_filters < 1 || v->num_filters > AIE_COVID_MAX_FILTERS) AIE__FAIL("num_filters out of range");
+  if (v->filter_len < v->beta_delay) AIE__FAIL("filter_len < beta_delay is not supported");
+  if (v->action_cooldown_period < 1) AIE__FAIL("action_cooldown_period must be >= 1 (covid19_components.py:57)");
+  if (v->subsidy_interval < 1) AIE__FAIL("subsidy_interval must be >= 1 (covid19_components.py:278)");
+  if (v->num_subsidy_levels < 1 || v->num_subsidy_levels > 255) AIE__FAIL("num_subsidy_levels out of range");
+  if (v->delivery_interval < 1) AIE__FAIL("delivery_interval must be >= 1 (covid19_components.py:505)");
+  if (v->time_when_vaccine_delivery_begins < 0) AIE__FAIL("vaccine delivery must not begin before the start date");
+  if (!(v->economic_reward_crra_eta >= 0.0)) AIE__FAIL("economic_reward_crra_eta must be >= 0");
+  if (v->economic_reward_crra_eta == 1.0) AIE__FAIL("economic_reward_crra_eta == 1 divides by zero (covid19_env.py:1074)");
+  if (!(v->reward_normalization_factor != 0.0)) AIE__FAIL("reward_normalization_factor must be non-zero");
+
+  p->c = *c;
+  p->E = c->n_envs;
+  p->n = c->n_agents;
+  p->H = c->world_h; p->W = c->world_w; p->HW = p->H * p->W;
+  const int n = p->n;
+  p->cv_L = v->filter_len;
+  p->cv_F = v->num_filters;
+  p->cv_NL = v->num_stringency_levels;
+  p->cv_NS = v->num_subsidy_levels;
+  p->cv_nch = (v->filter_len + 1 + c->episode_length + 15) / 16;
+  p->cv_row = (int32_t)aie__align(16 * n, 64);
+  p->cv_nrow_obs = AIE_CV_OB_MASK + 1 + p->cv_NL;
+  {
+    int t = v->time_when_vaccine_delivery_begins;        /* covid19_components.py:640-646 */
+    while (t % v->delivery_interval != 0) t++;
+    p->cv_t_first_delivery = t;
+  }
+  p->A = 1 + p->cv_NL;  p->MA = p->A;  p->act_a_width = 1;  p->n_sub_a = 1;
+  p->sub_a_dim[0] = p->cv_NL; p->sub_a_base[0] = 1;
+  p->n_sub_p = 1; p->sub_p_dim = p->cv_NS; p->MP = 1 + p->cv_NS; p->act_p_width = 1;
+  p->planner_acts = 1;
+
+  int32_t cur = 0;
+  p->o_cv_state = aie__rec(&cur, 4 * 64 * AIE_CV_ST_COUNT, 256);
+  p->o_cv_cooldown = aie__rec(&cur, 4 * 64, 256);
+  p->o_cv_subsidy_level = aie__rec(&cur, 4, 4);
+  p->o_timestep = aie__rec(&cur, 4, 4);
+  p->o_completions = aie__rec(&cur, 4, 4);
+  p->rec_bytes = (int32_t)aie__align(cur, 256);
+
+  const int64_t E = p->E;
+  const int64_t no = (int64_t)p->cv_nrow_obs * n * 4, po = (int64_t)(4 + p->MP) * 4;
+  int64_t a = 0;
+  p->a_records = a;    a = aie__align(a + E * (int64_t)p->rec_bytes, 256);
+  p->a_cv_consts = a;  a = aie__align(a + (int64_t)AIE_CV_K_COUNT * 64 * 8, 256);
+  p->a_cv_filters = a; a = aie__align(a + (int64_t)p->cv_F * p->cv_L * 8, 256);
+  p->a_cv_hist0 = a;   a = aie__align(a + (int64_t)(p->cv_L + 1) * n, 256);
+  p->a_cv_lag_obs = a; a = aie__align(a + (int64_t)v->beta_delay * n, 256);
+  p->a_cv_hist = a;    a = aie__align(a + E * (int64_t)p->cv_nch * p->cv_row, 256);
+  p->a_cv_obs_a = a;   a = aie__align(a + E * no, 256);
+  p->a_cv_obs_p = a;   a = aie__align(a + E * po, 256);
+  p->a_rew_a = a; a = aie__align(a + E * n * 4, 256);
+  p->a_rew_p = a; a = aie__align(a + E * 4, 256);
+  p->a_done = a;  a = aie__align(a + E, 256);
+  p->arena_bytes = a;
+
+  if (tt) {
+    const int64_t rs = p->rec_bytes, r0 = p->a_records;
+    static const char* st_name[AIE_CV_ST_COUNT] = {"susceptible", "infected", "recovered", "deaths", "vaccinated",
+                                                   "unemployed", "postsubsidy_productivity", "subsidy"};
+    for (int k = 0; k < AIE_CV_ST_COUNT; ++k)
+      aie__add(tt, st_name[k], AIE_F32, r0 + p->o_cv_state + 256 * k, rs, 1, n, 0, 0, 0, E);
+    aie__add(tt, "cooldown_until", AIE_I32, r0 + p->o_cv_cooldown, rs, 1, n, 0, 0, 0, E);
+    aie__add(tt, "subsidy_level", AIE_I32, r0 + p->o_cv_subsidy_level, rs, 0, 0, 0, 0, 0, E);
+    aie__add(tt, "timestep", AIE_I32, r0 + p->o_timestep, rs, 0, 0, 0, 0, 0, E);
+    aie__add(tt, "completions", AIE_I32, r0 + p->o_completions, rs, 0, 0, 0, 0, 0, E);
+    /* stringency level on day (16*chunk + j - filter_len) of the episode, per state */
+    aie__add(tt, "stringency_history_chunks", AIE_U8, p->a_cv_hist, (int64_t)p->cv_nch * p->cv_row, 3,
+             p->cv_nch, n, 16, 0, E);
+    tt->t[tt->n - 1].stride[1] = p->cv_row;
+
+    static const char* k_name[AIE_CV_K_CONV_W0] = {
+        "model_us_state_population", "model_beta_slopes", "model_beta_intercepts", "model_unemployment_bias",
+        "model_maximum_productivity", "model_agents_health_norm", "model_agents_economic_norm",
+        "model_min_marginal_agent_health_index", "model_max_marginal_agent_health_index",
+        "model_min_marginal_agent_economic_index", "model_max_marginal_agent_economic_index",
+        "model_weightage_on_marginal_agent_health_index", "model_weightage_on_marginal_agent_economic_index",
+        "model_max_daily_subsidy_per_state", "model_num_vaccines_per_delivery",
+        "model_susceptible_0", "model_infected_0", "model_recovered_0", "model_deaths_0", "model_unemployed_0",
+        "model_vaccinated_0"};
+    for (int k = 0; k < AIE_CV_K_CONV_W0; ++k)
+      aie__add_shared(tt, k_name[k], AIE_F64, p->a_cv_consts + (int64_t)k * 512, 1, n, 0);
+    aie__add_shared(tt, "model_conv_weights", AIE_F64, p->a_cv_consts + (int64_t)AIE_CV_K_CONV_W0 * 512, 2, p->cv_F, n);
+    tt->t[tt->n - 1].stride[1] = 512;
+    aie__add_shared(tt, "model_unemp_conv_filters", AIE_F64, p->a_cv_filters, 2, p->cv_F, p->cv_L);
+    aie__add_shared(tt, "model_stringency_level_history_0", AIE_U8, p->a_cv_hist0, 2, p->cv_L + 1, n);
+    aie__add_shared(tt, "model_policy_before_start_obs", AIE_U8, p->a_cv_lag_obs, 2, v->beta_delay, n);
+
+#define OBA(name, row, nd, d0) aie__add(tt, name, AIE_F32, p->a_cv_obs_a + (int64_t)(row) * n * 4, no, nd, d0, (nd) == 2 ? n : 0, 0, 0, E)
+    OBA("obs_a_world-agent_state", AIE_CV_OB_STATE, 2, 6);
+    OBA("obs_a_world-agent_postsubsidy_productivity", AIE_CV_OB_PROD, 1, n);
+    OBA("obs_a_world-lagged_stringency_level", AIE_CV_OB_LAG, 1, n);
+    OBA("obs_a_time", AIE_CV_OB_TIME, 1, n);
+    OBA("obs_a_ControlUSStateOpenCloseStatus-agent_policy_indicators", AIE_CV_OB_POLICY, 1, n);
+    OBA("obs_a_FederalGovernmentSubsidy-t_until_next_subsidy", AIE_CV_OB_T_SUBSIDY, 1, n);
+    OBA("obs_a_FederalGovernmentSubsidy-current_subsidy_level", AIE_CV_OB_SUBSIDY_LEVEL, 1, n);
+    OBA("obs_a_VaccinationCampaign-t_until_next_vaccines", AIE_CV_OB_T_VACCINE, 1, n);
+    OBA("obs_a_action_mask", AIE_CV_OB_MASK, 2, 1 + p->cv_NL);
+    /* the planner sees the same per-state arrays (covid19_env.py:986-992, covid19_components.py:167-168) */
+    OBA("obs_p_world-agent_state", AIE_CV_OB_STATE, 2, 6);
+    OBA("obs_p_world-agent_postsubsidy_productivity", AIE_CV_OB_PROD, 1, n);
+    OBA("obs_p_world-lagged_stringency_level", AIE_CV_OB_LAG, 1, n);
+    OBA("obs_p_ControlUSStateOpenCloseStatus-agent_policy_indicators", AIE_CV_OB_POLICY, 1, n);
+#undef OBA
+#define OBP(name, idx, nd, d0) aie__add(tt, name, AIE_F32, p->a_cv_obs_p + 4 * (idx), po, nd, d0, 0, 0, 0, E)
+    OBP("obs_p_time", 0, 1, 1);
+    OBP("obs_p_FederalGovernmentSubsidy-t_until_next_subsidy", 1, 0, 0);
+    OBP("obs_p_FederalGovernmentSubsidy-current_subsidy_level", 2, 0, 0);
+    OBP("obs_p_VaccinationCampaign-t_until_next_vaccines", 3, 0, 0);
+    OBP("obs_p_action_mask", 4, 1, p->MP);
+#undef OBP
+    aie__add(tt, "rewards_a", AIE_F32, p->a_rew_a, (int64_t)n * 4, 1, n, 0, 0, 0, E);
+    aie__add(tt, "rewards_p", AIE_F32, p->a_rew_p, 4, 0, 0, 0, 0, 0, E);
+    aie__add(tt, "done", AIE_U8, p->a_done, 1, 0, 0, 0, 0, 0, E);
+  }
+  return AIE_OK;
 }
 
 /* one-step-economy (F/scenarios/one_step_economy/one_step_economy.py): no map, agents
@@ -291,7 +469,12 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   if (c->abi_version != AIE_ABI_VERSION) AIE__FAIL("abi_version %d != %d", c->abi_version, AIE_ABI_VERSION);
   if (c->n_envs < 1) AIE__FAIL("n_envs must be >= 1");
   if (c->n_agents < 2) AIE__FAIL("n_agents must be >= 2 (base_env.py:223)");
-  if (c->scenario != AIE_SCN_GTB && c->scenario != AIE_SCN_ONE_STEP_ECONOMY) AIE__FAIL("unknown scenario %d", c->scenario);
+  if (c->scenario != AIE_SCN_GTB && c->scenario != AIE_SCN_ONE_STEP_ECONOMY && c->scenario != AIE_SCN_COVID)
+    AIE__FAIL("unknown scenario %d", c->scenario);
+  if (c->scenario == AIE_SCN_COVID) {
+    if (c->episode_length < 1) AIE__FAIL("episode_length must be >= 1 (base_env.py:254)");
+    return aie__build_covid(c, p, tt, err, errlen);
+  }
   if (c->scenario == AIE_SCN_GTB && c->n_agents > AIE_MAX_AGENTS - 2)
     AIE__FAIL("n_agents > %d unsupported for spatial scenarios", AIE_MAX_AGENTS - 2);
   if (c->scenario == AIE_SCN_ONE_STEP_ECONOMY && c->n_agents > AIE_MAX_AGENTS_WIDE)

@@ -27,6 +27,9 @@ class BaseEnvironment:
     name = ""
     agent_subclasses = []
     required_entities = None
+    # scenarios whose observations are already per-key arrays (COVID) accept
+    # flatten_observations=False, which is how the reference's run config sets it
+    supports_unflattened_observations = False
 
     def __init__(self, components=None, n_agents=None, world_size=None, episode_length=1000,
                  multi_action_mode_agents=False, multi_action_mode_planner=True,
@@ -58,7 +61,7 @@ class BaseEnvironment:
         self.multi_action_mode_agents = bool(multi_action_mode_agents)
         self.multi_action_mode_planner = bool(multi_action_mode_planner)
         self._allow_observation_scaling = bool(allow_observation_scaling)
-        if not flatten_observations or not flatten_masks:
+        if (not flatten_observations and not self.supports_unflattened_observations) or not flatten_masks:
             raise NotImplementedError(
                 "the batched backend always produces flattened observations and masks")
         if dense_log_frequency is not None:
@@ -151,6 +154,11 @@ class BaseEnvironment:
         """Returns (stone_src, wood_src, water) uint8 [H, W] (or [E, H, W]) planes."""
         raise NotImplementedError
 
+    def upload_model_constants(self, backend):
+        """Hook: named constant tensors a scenario pushes once after the device env exists
+        (the counterpart of the reference's get_data_dictionary()).  Default: none."""
+        return None
+
     def build_config(self):
         cfg = _cabi.AieConfig()
         ctypes.memset(ctypes.byref(cfg), 0, ctypes.sizeof(cfg))
@@ -179,6 +187,7 @@ class BaseEnvironment:
 
             self._backend = DeviceBackend(self.build_config(), self.layout_planes(),
                                           device=self._device)
+            self.upload_model_constants(self._backend)
             if self._pending_seed is not None:
                 self._backend.seed(self._pending_seed + self.env_offset)
         return self._backend

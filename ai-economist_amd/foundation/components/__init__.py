@@ -6,4 +6,4 @@ constructor validation, and knows how to write itself into the C-ABI config
 (ai-economist_amd/csrc/aie_kernels.hip), not here.
 """
 from .base import BaseComponent, component_registry  # noqa: F401
-from . import build, continuous_double_auction, move, redistribution, simple_labor  # noqa: F401
+from . import build, continuous_double_auction, covid19_components, move, redistribution, simple_labor  # noqa: F401

@@ -1,0 +1,128 @@
+"""`CovidAndEconomySimulation` (reference: F/scenarios/covid19/covid19_env.py:33-1687):
+51 US-state agents + the federal government; SIR with vaccinations, an unemployment filter
+bank driven by the stringency history, productivity, subsidies, health/economy rewards.
+
+This class keeps the reference's registry name, kwargs, defaults and constructor checks,
+derives the model constants on the host once (covid19_model.py) and pushes them to the
+device as named tensors; reset / step / observations / rewards run in
+csrc/aie_kernels_covid.hip."""
+import numpy as np
+
+from ... import _cabi
+from ..base_env import BaseEnvironment, scenario_registry
+from . import covid19_model
+
+
+@scenario_registry.add
+class CovidAndEconomyEnvironment(BaseEnvironment):
+    name = "CovidAndEconomySimulation"
+    agent_subclasses = ["BasicMobileAgent", "BasicPlanner"]
+    required_entities = []
+    supports_unflattened_observations = True
+
+    def __init__(self, *base_env_args, use_real_world_data=False, use_real_world_policies=False,
+                 path_to_data_and_fitted_params="", start_date="2020-03-22", pop_between_age_18_65=0.6,
+                 infection_too_sick_to_work_rate=0.1, risk_free_interest_rate=0.03,
+                 economic_reward_crra_eta=2, health_priority_scaling_agents=1,
+                 health_priority_scaling_planner=1, reward_normalization_factor=1, **base_env_kwargs):
+        if use_real_world_data or use_real_world_policies:
+            # covid19_env.py:126-135, 735-757: replays the recorded data / policies instead of
+            # simulating -- a data-loader mode, not part of the accelerated path.
+            raise NotImplementedError("use_real_world_data / use_real_world_policies are not supported")
+        self.use_real_world_data = False
+        self.use_real_world_policies = False
+        self.model = covid19_model.build_model(
+            start_date=start_date, pop_between_age_18_65=pop_between_age_18_65,
+            infection_too_sick_to_work_rate=infection_too_sick_to_work_rate,
+            risk_free_interest_rate=risk_free_interest_rate,
+            economic_reward_crra_eta=economic_reward_crra_eta,
+            health_priority_scaling_agents=health_priority_scaling_agents,
+            health_priority_scaling_planner=health_priority_scaling_planner,
+            reward_normalization_factor=reward_normalization_factor,
+            episode_length=base_env_kwargs.get("episode_length", 1000),
+            path_to_data_and_fitted_params=path_to_data_and_fitted_params)
+        m = self.model
+        self.num_us_states = len(m["us_state_population"])
+        assert base_env_kwargs["n_agents"] == self.num_us_states, \
+            "n_agents should be set to the number of US states, i.e., {}.".format(self.num_us_states)
+        assert base_env_kwargs.get("collate_agent_step_and_reset_data", False), \
+            "The env. config 'collate_agent_step_and_reset_data' should be set to True."
+        # single-action mode for both agent classes, as in the reference run config
+        base_env_kwargs.setdefault("multi_action_mode_planner", False)
+        super().__init__(*base_env_args, **base_env_kwargs)
+        assert 0 <= m["infection_too_sick_to_work_rate"] <= 1
+        assert 0 <= m["population_between_age_18_65"] <= 1
+        assert 0.0 <= m["economic_reward_crra_eta"] < 20.0
+        assert ((m["weightage_on_marginal_agent_health_index"] >= 0)
+                & (m["weightage_on_marginal_agent_health_index"] <= 1)).all()
+        assert 0 <= m["weightage_on_marginal_planner_health_index"] <= 1
+        names = [c.name for c in self.components]
+        if names != ["ControlUSStateOpenCloseStatus", "FederalGovernmentSubsidy", "VaccinationCampaign"]:
+            raise NotImplementedError(
+                "CovidAndEconomySimulation runs with ControlUSStateOpenCloseStatus, "
+                "FederalGovernmentSubsidy and VaccinationCampaign, in this order")
+        ctrl, sub, vac = self.components
+        if ctrl.n_stringency_levels != m["num_stringency_levels"]:
+            # covid19_components.py:169-178
+            raise ValueError("The environment was not configured correctly. For the given model fit, you need "
+                             "to set the number of stringency levels to be {}".format(m["num_stringency_levels"]))
+        self.component_constants = covid19_model.component_constants(
+            m, {"max_annual_subsidy_per_person": sub.max_annual_subsidy_per_person},
+            {"daily_vaccines_per_million_people": vac.daily_vaccines_per_million_people,
+             "delivery_interval": vac.delivery_interval,
+             "vaccine_delivery_start_date": vac.vaccine_delivery_start_date.strftime("%Y-%m-%d")})
+        if self.component_constants["time_when_vaccine_delivery_begins"] < 0:
+            raise NotImplementedError("vaccine_delivery_start_date before start_date is not supported")
+
+    def layout_planes(self):
+        z = np.zeros(self.world_size, np.uint8)
+        return (z, z, z)
+
+    def fill_scenario_config(self, cfg):
+        m, v = self.model, cfg.covid
+        cfg.scenario = _cabi.SCN_COVID
+        cfg.shared_layout = 1
+        v.beta_delay = int(m["beta_delay"])
+        v.filter_len = int(m["filter_len"])
+        v.num_filters = int(m["num_filters"])
+        v.time_when_vaccine_delivery_begins = int(self.component_constants["time_when_vaccine_delivery_begins"])
+        for k in ("death_rate", "gamma", "value_of_life", "daily_production_per_worker",
+                  "infection_too_sick_to_work_rate", "population_between_age_18_65", "risk_free_interest_rate",
+                  "economic_reward_crra_eta", "planner_health_norm", "planner_economic_norm",
+                  "min_marginal_planner_health_index", "max_marginal_planner_health_index",
+                  "min_marginal_planner_economic_index", "max_marginal_planner_economic_index",
+                  "weightage_on_marginal_planner_health_index", "weightage_on_marginal_planner_economic_index",
+                  "reward_normalization_factor"):
+            setattr(v, k, float(m[k]))
+
+    def upload_model_constants(self, backend):
+        m, c = self.model, self.component_constants
+        rows = {
+            "model_us_state_population": m["us_state_population"],
+            "model_beta_slopes": m["beta_slopes"],
+            "model_beta_intercepts": m["beta_intercepts"],
+            "model_unemployment_bias": m["unemployment_bias"],
+            "model_maximum_productivity": m["maximum_productivity"],
+            "model_agents_health_norm": m["agents_health_norm"],
+            "model_agents_economic_norm": m["agents_economic_norm"],
+            "model_min_marginal_agent_health_index": m["min_marginal_agent_health_index"],
+            "model_max_marginal_agent_health_index": m["max_marginal_agent_health_index"],
+            "model_min_marginal_agent_economic_index": m["min_marginal_agent_economic_index"],
+            "model_max_marginal_agent_economic_index": m["max_marginal_agent_economic_index"],
+            "model_weightage_on_marginal_agent_health_index": m["weightage_on_marginal_agent_health_index"],
+            "model_weightage_on_marginal_agent_economic_index": m["weightage_on_marginal_agent_economic_index"],
+            "model_max_daily_subsidy_per_state": c["max_daily_subsidy_per_state"],
+            "model_num_vaccines_per_delivery": c["num_vaccines_per_delivery"],
+            "model_susceptible_0": m["susceptible_0"],
+            "model_infected_0": m["infected_0"],
+            "model_recovered_0": m["recovered_0"],
+            "model_deaths_0": m["deaths_0"],
+            "model_unemployed_0": m["unemployed_0"],
+            "model_vaccinated_0": m["vaccinated_0"],
+            "model_conv_weights": np.asarray(m["conv_weights"]).T,           # [F, n]
+            "model_unemp_conv_filters": m["unemp_conv_filters"],            # [F, L]
+            "model_stringency_level_history_0": m["stringency_level_history_0"],
+            "model_policy_before_start_obs": m["policy_before_start_obs"],
+        }
+        for name, arr in rows.items():
+            backend.upload(name, np.asarray(arr)[None])

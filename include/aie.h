@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AIE_ABI_VERSION 2
+#define AIE_ABI_VERSION 3
 
 #define AIE_MAX_AGENTS 64      /* mobile agents per replica, spatial scenarios (one lane each) */
 #define AIE_MAX_AGENTS_WIDE 128 /* mobile agents per replica, map-less one-step-economy        */
@@ -50,6 +50,7 @@ extern "C" {
 #define AIE_MAX_SUBSPACES 16   /* action subspaces per agent class                      */
 #define AIE_N_RES 2            /* collectible resources, sorted: 0 = Stone, 1 = Wood    */
 #define AIE_MT_N 624
+#define AIE_COVID_MAX_FILTERS 8 /* unemployment filter bank size (covid19_env.py:242)    */
 
 /* ---- error codes ---------------------------------------------------------------- */
 #define AIE_OK 0
@@ -65,13 +66,17 @@ enum {
   AIE_COMP_CDA = 2,            /* "ContinuousDoubleAuction"   F/components/continuous_double_auction.py:16 */
   AIE_COMP_GATHER = 3,         /* "Gather"                    F/components/move.py:16         */
   AIE_COMP_TAX = 4,            /* "PeriodicBracketTax"        F/components/redistribution.py:78 */
-  AIE_COMP_SIMPLE_LABOR = 5    /* "SimpleLabor"               F/components/simple_labor.py:15  */
+  AIE_COMP_SIMPLE_LABOR = 5,   /* "SimpleLabor"               F/components/simple_labor.py:15  */
+  AIE_COMP_COVID_CONTROL = 6,  /* "ControlUSStateOpenCloseStatus" F/components/covid19_components.py:32  */
+  AIE_COMP_COVID_SUBSIDY = 7,  /* "FederalGovernmentSubsidy"      F/components/covid19_components.py:244 */
+  AIE_COMP_COVID_VACCINE = 8   /* "VaccinationCampaign"           F/components/covid19_components.py:472 */
 };
 
 /* ---- scenario families (registry names in the reference, F/scenarios) ----------- */
 enum {
   AIE_SCN_GTB = 0,             /* "layout_from_file/simple_wood_and_stone" (+ uniform: next)   */
-  AIE_SCN_ONE_STEP_ECONOMY = 1 /* "one-step-economy"  F/scenarios/one_step_economy/one_step_economy.py:15 */
+  AIE_SCN_ONE_STEP_ECONOMY = 1,/* "one-step-economy"  F/scenarios/one_step_economy/one_step_economy.py:15 */
+  AIE_SCN_COVID = 2            /* "CovidAndEconomySimulation"  F/scenarios/covid19/covid19_env.py:33 */
 };
 enum { AIE_AGENT_REW_COIN_MINUS_LABOR_COST = 0, AIE_AGENT_REW_ISOELASTIC = 1 };
 
@@ -91,6 +96,37 @@ enum {
 enum {
   AIE_U8 = 0, AIE_I8 = 1, AIE_I16 = 2, AIE_I32 = 3, AIE_U32 = 4, AIE_F32 = 5, AIE_F64 = 6
 };
+
+/* ---- COVID-19 scenario: the scalar constants CovidAndEconomyEnvironment.__init__ derives
+ * (covid19_env.py:68-330) + the kwargs of its three components.  Per-state constants and
+ * tables are named tensors ("model_*", leading dim 1) filled with aie_upload after
+ * aie_create -- the counterpart of the reference's get_data_dictionary() push
+ * (covid19_env.py:436-560, covid19_components.py:110-143,330-359,560-591).  Floating-point
+ * constants the reference holds as float32 are passed as doubles holding the float32 value. */
+typedef struct aie_covid_config {
+  int32_t num_stringency_levels;          /* model_constants NUM_STRINGENCY_LEVELS (10)        */
+  int32_t beta_delay;                     /* fitted BETA_DELAY (days)                          */
+  int32_t filter_len;                     /* fitted FILTER_LEN (600)                           */
+  int32_t num_filters;                    /* len(CONV_LAMBDAS) <= AIE_COVID_MAX_FILTERS        */
+  int32_t action_cooldown_period;         /* ControlUSStateOpenCloseStatus kwarg               */
+  int32_t subsidy_interval;               /* FederalGovernmentSubsidy kwargs                   */
+  int32_t num_subsidy_levels;
+  int32_t delivery_interval;              /* VaccinationCampaign kwarg                         */
+  int32_t time_when_vaccine_delivery_begins; /* days from start_date to vaccine_delivery_start_date */
+  int32_t reserved_;
+  double death_rate, gamma;               /* SIR_MORTALITY, SIR_GAMMA                          */
+  double value_of_life;
+  double daily_production_per_worker;
+  double infection_too_sick_to_work_rate;
+  double population_between_age_18_65;
+  double risk_free_interest_rate;
+  double economic_reward_crra_eta;
+  double planner_health_norm, planner_economic_norm;
+  double min_marginal_planner_health_index, max_marginal_planner_health_index;
+  double min_marginal_planner_economic_index, max_marginal_planner_economic_index;
+  double weightage_on_marginal_planner_health_index, weightage_on_marginal_planner_economic_index;
+  double reward_normalization_factor;
+} aie_covid_config;
 
 /* ---- configuration: the kwargs of make_env_instance + component kwargs ---------- */
 typedef struct aie_config {
@@ -165,6 +201,8 @@ typedef struct aie_config {
   int32_t labor_num_hours;           /* 100                                             */
   double labor_pmsm;                 /* payment_max_skill_multiplier                    */
   double labor_skills[AIE_MAX_AGENTS_WIDE]; /* per-agent skill (sorted Pareto means, :66-74) */
+
+  aie_covid_config covid;            /* scenario == AIE_SCN_COVID only                  */
 } aie_config;
 
 /* ---- tensor descriptor ---------------------------------------------------------- */

@@ -53,7 +53,7 @@ def lib():
 
 
 class TensorTable(C.Structure):
-    _fields_ = [("n", C.c_int32), ("_pad", C.c_int32), ("t", _cabi.AieTensorDesc * 64)]
+    _fields_ = [("n", C.c_int32), ("_pad", C.c_int32), ("t", _cabi.AieTensorDesc * _cabi.MAX_TENSORS)]
 
 
 class OracleEnv:

@@ -19,7 +19,21 @@ F64_FIELDS = ["inv_coin", "esc_coin", "labor", "build_payment", "build_skill",
 
 
 def golden_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    """Gather-trade-build / one-step-economy fixtures (the COVID ones have their own format)."""
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    return [n for n in names if not n.startswith("c4_covid")]
+
+
+def covid_golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "c4_covid*.npz")))
+
+
+def load_covid_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        g = {k: z[k] for k in z.files}
+    g["cfg"] = json.loads(str(g["config_json"]))
+    g["cfg"]["components"] = [tuple(c) for c in g["cfg"]["components"]]
+    return g
 
 
 def load_golden(name):

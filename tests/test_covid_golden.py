@@ -1,0 +1,215 @@
+"""COVID-19 scenario (BASELINE configs[3]): the NumPy oracle and the HIP path against the
+fixtures the live reference produced (oracle/gen_golden_covid.py), and against each other on
+batched random rollouts.
+
+Tolerances (the reference's own CPU<->CUDA tolerance lives in un-vendored WarpDrive, so these
+are ours): the SIR state is float32 arithmetic with IEEE basic operations only and is compared
+at rtol 1e-6 (HIP vs oracle: a few float32 ulps would show a misplaced cast); unemployment /
+productivity go through exp/log and a reordered float64 filter sum: rtol 1e-5; rewards are
+min-max normalised differences of nearly equal float32 numbers: atol 2e-5."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, covid_golden_names, load_covid_golden
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+STATE_TOL = dict(susceptible=1e-6, infected=1e-6, recovered=1e-6, deaths=1e-6, vaccinated=1e-6,
+                 unemployed=1e-5, postsubsidy_productivity=1e-5, subsidy=1e-6)
+
+
+def model_for(cfg):
+    """Constants from the product's host-side builder (itself pinned against the live
+    reference's attributes in tests/test_covid_reference.py)."""
+    import ai_economist_amd  # noqa: F401
+    from ai_economist_amd.foundation.scenarios.covid19_model import build_model, component_constants
+
+    kw = {k: cfg[k] for k in ("start_date", "pop_between_age_18_65", "infection_too_sick_to_work_rate",
+                              "risk_free_interest_rate", "economic_reward_crra_eta",
+                              "health_priority_scaling_agents", "health_priority_scaling_planner",
+                              "episode_length")}
+    kw["reward_normalization_factor"] = cfg.get("reward_normalization_factor", 1)
+    m = build_model(**kw)
+    comps = dict(cfg["components"])
+    c = component_constants(m, comps["FederalGovernmentSubsidy"], comps["VaccinationCampaign"])
+    return m, c
+
+
+def make_oracle(cfg, n_envs):
+    from covid_oracle import CovidOracle
+
+    m, c = model_for(cfg)
+    comps = dict(cfg["components"])
+    return CovidOracle(m, c, n_envs=n_envs,
+                       action_cooldown_period=comps["ControlUSStateOpenCloseStatus"]["action_cooldown_period"],
+                       subsidy_interval=comps["FederalGovernmentSubsidy"]["subsidy_interval"],
+                       num_subsidy_levels=comps["FederalGovernmentSubsidy"]["num_subsidy_levels"],
+                       delivery_interval=comps["VaccinationCampaign"]["delivery_interval"],
+                       episode_length=cfg["episode_length"])
+
+
+def check_against_golden(g, t, state, obs, rew_a, rew_p, done, where):
+    """state/obs: dicts of arrays for ONE replica at timestep t."""
+    for k, tol in STATE_TOL.items():
+        np.testing.assert_allclose(np.asarray(state[k], np.float64), g["state_" + k][t], rtol=tol, atol=1e-3,
+                                   err_msg="%s t=%d state %s" % (where, t, k))
+    assert np.array_equal(np.asarray(state["stringency_level"]).astype(np.int64),
+                          g["state_stringency_level"][t].astype(np.int64)), "%s t=%d stringency" % (where, t)
+    assert np.array_equal(np.asarray(obs["obs_a_action_mask"]).astype(np.uint8), g["masks_a"][t]), \
+        "%s t=%d agent masks" % (where, t)
+    assert np.array_equal(np.asarray(obs["obs_p_action_mask"]).astype(np.uint8), g["masks_p"][t]), \
+        "%s t=%d planner mask" % (where, t)
+    if t in g["snap_at"]:
+        for k in g:
+            pre = "snap%d_" % t
+            if k.startswith(pre):
+                np.testing.assert_allclose(np.asarray(obs[k[len(pre):]], np.float64).reshape(g[k].shape), g[k],
+                                           rtol=1e-5, atol=1e-6, err_msg="%s t=%d %s" % (where, t, k))
+    if t > 0:
+        want = g["rewards"][t - 1]
+        np.testing.assert_allclose(np.asarray(rew_a, np.float64), want[:-1], rtol=0, atol=2e-5,
+                                   err_msg="%s t=%d agent rewards" % (where, t))
+        np.testing.assert_allclose(float(rew_p), want[-1], rtol=0, atol=2e-5, err_msg="%s t=%d planner reward" % (where, t))
+        assert int(done) == int(g["done"][t - 1]), "%s t=%d done" % (where, t)
+
+
+@pytest.mark.parametrize("name", covid_golden_names())
+def test_covid_oracle_matches_reference_golden(name):
+    g = load_covid_golden(name)
+    o = make_oracle(g["cfg"], n_envs=1)
+    obs = o.reset()
+    steps = len(g["actions_p"])
+    pick = lambda d: {k: v[0] for k, v in d.items()}  # noqa: E731
+    st = pick(o.state())
+    st["stringency_level"] = o.stringency[0, 0]
+    check_against_golden(g, 0, st, pick(obs), None, None, 0, name + "/oracle")
+    for t in range(1, steps + 1):
+        obs = o.step(g["actions_a"][t - 1][None], g["actions_p"][t - 1][None])
+        st = pick(o.state())
+        check_against_golden(g, t, st, pick(obs), o.rew_a[0], o.rew_p[0], o.done[0], name + "/oracle")
+
+
+# ------------------------------------------------------------------------------------------
+# GPU: the HIP path through the C ABI
+# ------------------------------------------------------------------------------------------
+def hip_env(cfg, n_envs):
+    from ai_economist_amd import foundation
+
+    return foundation.make_env_instance("CovidAndEconomySimulation", n_envs=n_envs, **cfg)
+
+
+def hip_state(env, e):
+    t = env.tensors
+    ts = int(t["timestep"][e].item())
+    L = env.model["filter_len"]
+    tau = L + ts
+    st = {k: t[k][e].cpu().numpy() for k in STATE_TOL}
+    st["stringency_level"] = t["stringency_history_chunks"][e, tau // 16, :, tau % 16].cpu().numpy()
+    return st
+
+
+def hip_obs(env, e):
+    return {k: v[e].cpu().numpy() for k, v in env.tensors.items() if k.startswith("obs_")}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", covid_golden_names())
+def test_covid_hip_matches_reference_golden(name):
+    import torch
+
+    g = load_covid_golden(name)
+    env = hip_env(g["cfg"], n_envs=3)
+    env.reset()
+    t = env.tensors
+    steps = len(g["actions_p"])
+    check_against_golden(g, 0, hip_state(env, 1), hip_obs(env, 1), None, None, 0, name + "/hip")
+    for k in range(1, steps + 1):
+        a = torch.as_tensor(np.repeat(g["actions_a"][k - 1][None], 3, axis=0), dtype=torch.int32, device="cuda")
+        p = torch.as_tensor(np.repeat(g["actions_p"][k - 1][None, None], 3, axis=0), dtype=torch.int32, device="cuda")
+        env.step({"a": a, "p": p})
+        if k % 7 == 0 or k < 35 or k in g["snap_at"] or k > steps - 3:
+            check_against_golden(g, k, hip_state(env, 1), hip_obs(env, 1), t["rewards_a"][1].cpu().numpy(),
+                                 t["rewards_p"][1].item(), t["done"][1].item(), name + "/hip")
+    # replicas fed identical actions stay identical
+    for key in ("susceptible", "unemployed", "rewards_a", "obs_a_world-agent_state"):
+        assert torch.equal(t[key][0], t[key][2]), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,E,T", [("c4_covid_51ag", 64, 130), ("c4_covid_variant", 33, 100)])
+def test_covid_hip_matches_oracle_on_batched_rollouts(name, E, T):
+    """Every replica gets its own action stream; masked resets mid-run; HIP vs oracle."""
+    import torch
+
+    g = load_covid_golden(name)
+    cfg = g["cfg"]
+    env = hip_env(cfg, n_envs=E)
+    o = make_oracle(cfg, n_envs=E)
+    env.reset()
+    o.reset()
+    t = env.tensors
+    rng = np.random.RandomState(5)
+    ns = dict(cfg["components"])["FederalGovernmentSubsidy"]["num_subsidy_levels"]
+
+    def compare(where):
+        st = o.state()
+        for k, tol in STATE_TOL.items():
+            np.testing.assert_allclose(t[k].cpu().numpy().astype(np.float64), st[k], rtol=tol, atol=1e-3,
+                                       err_msg="%s %s" % (where, k))
+        assert np.array_equal(t["cooldown_until"].cpu().numpy(), st["cooldown_until"]), where
+        assert np.array_equal(t["subsidy_level"].cpu().numpy(), st["subsidy_level"]), where
+        oo = o.observe()
+        for k, v in oo.items():
+            np.testing.assert_allclose(t[k].cpu().numpy().reshape(v.shape), v, rtol=1e-5, atol=1e-6,
+                                       err_msg="%s %s" % (where, k))
+
+    compare("reset")
+    for k in range(1, T + 1):
+        a = rng.randint(0, 11, size=(E, 51)).astype(np.int32)
+        a[rng.rand(E, 51) < 0.5] = 0
+        p = rng.randint(0, ns + 1, size=(E,)).astype(np.int32)
+        env.step({"a": torch.as_tensor(a, device="cuda"), "p": torch.as_tensor(p[:, None], device="cuda")})
+        o.step(a, p)
+        np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), o.rew_a, rtol=0, atol=2e-5, err_msg="step %d" % k)
+        np.testing.assert_allclose(t["rewards_p"].cpu().numpy(), o.rew_p, rtol=0, atol=2e-5, err_msg="step %d" % k)
+        assert np.array_equal(t["done"].cpu().numpy(), o.done), "done at step %d" % k
+        if k % 10 == 0 or k == T:
+            compare("step %d" % k)
+
+
+@pytest.mark.gpu
+def test_covid_masked_reset_and_config_errors():
+    import torch
+
+    g = load_covid_golden("c4_covid_variant")
+    cfg = g["cfg"]
+    env = hip_env(cfg, n_envs=4)
+    env.reset()
+    t = env.tensors
+    s0 = t["susceptible"].clone()
+    for k in range(12):
+        a = torch.full((4, 51), (k % 10) + 1, dtype=torch.int32, device="cuda")
+        env.step({"a": a, "p": torch.full((4, 1), 3, dtype=torch.int32, device="cuda")})
+    assert not torch.equal(t["susceptible"], s0)
+    mask = torch.tensor([0, 1, 0, 1], dtype=torch.uint8, device="cuda")
+    before = t["susceptible"].clone()
+    env.reset(mask)
+    assert torch.equal(t["susceptible"][1], s0[1]) and torch.equal(t["susceptible"][3], s0[3])
+    assert torch.equal(t["susceptible"][0], before[0]) and torch.equal(t["susceptible"][2], before[2])
+    assert t["timestep"].cpu().tolist() == [12, 0, 12, 0]
+    # constructor checks mirror the reference's
+    bad = dict(cfg)
+    bad["n_agents"] = 50
+    with pytest.raises(AssertionError):
+        hip_env(bad, 1)
+    bad = dict(cfg)
+    bad["components"] = [("ControlUSStateOpenCloseStatus", {"n_stringency_levels": 5})] + list(cfg["components"][1:])
+    with pytest.raises(ValueError):
+        hip_env(bad, 1)
+    bad = dict(cfg)
+    bad["use_real_world_policies"] = True
+    with pytest.raises(NotImplementedError):
+        hip_env(bad, 1)

@@ -99,6 +99,8 @@ def test_host_model_builder_matches_reference_constants():
             continue
         g, w = np.asarray(got[k]), np.asarray(v)
         assert g.shape == w.shape, k
+        if g.dtype.kind == "f" or w.dtype.kind == "f":  # dtype drives NumPy promotion in the oracle
+            assert g.dtype == w.dtype, (k, g.dtype, w.dtype)
         assert np.array_equal(g.astype(np.float64), w.astype(np.float64)), k
     cw = comp_from_reference(env)
     cg = component_constants(got, YAML_ENV["components"][1][1], YAML_ENV["components"][2][1])
