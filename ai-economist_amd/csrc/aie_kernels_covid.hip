@@ -44,6 +44,8 @@ __device__ __forceinline__ float np_sum_f32_lds(const float* a, int n) {
   return res;
 }
 
+typedef const double __attribute__((address_space(4))) * cv_tap_ptr;
+
 struct CvLane {
   float S, I, R, D, V, U, prod, subsidy;
   int level;     // stringency level in force at the current timestep
@@ -195,7 +197,7 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
 
 // ---- one env.step() (base_env.py:929-1032) ----
 template <int F>
-__global__ void __launch_bounds__(AIE_NT)
+__global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     aie_covid_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                           const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
   using namespace aie;
@@ -264,55 +266,64 @@ __global__ void __launch_bounds__(AIE_NT)
   }
 
   // ---- unemployment_step :1374-1441 ----
-  // deltas of the 601 most recent daily levels (history index tau in [t, t+L]), filter tap
-  // l = tau' - t - 1 for the delta between days tau'-1 and tau'.
+  // deltas of the 601 most recent daily levels (history index tau in [t, t+L]); the delta
+  // between days tau'-1 and tau' meets filter tap l = tau' - t - 1.  The tap table is
+  // zero-padded (AIE_CV_TAP_PAD_FRONT rows before tap 0, zeros after tap L-1), so whole
+  // 16-day chunks are processed without any window test: days outside the window meet a zero
+  // tap.  Chunks are fetched in groups of AIE_CV_GROUP, one group ahead, to keep ~128 B per
+  // lane in flight (HBM latency >> the ~300 cycles of FMA work in one chunk).
   double unemployed;
   {
-    const double* G = reinterpret_cast<const double*>(arena + P.a_cv_filters);
+    const double* __restrict__ G = reinterpret_cast<const double*>(arena + P.a_cv_filters);  // [row][F]
     double acc[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = 0.0;
-    const int tau_lo = t, tau_hi = t + L - 1;  // levels that come from memory
-    const uint8_t* row = hist + sl * 16;
+    const int c0 = t >> 4;
+    const int c_today = (t + L) >> 4, sh_today = 8 * ((t + L) & 3), q_today = ((t + L) & 15) >> 2;
+    const int ngroups = (P.dev_skip_mask & 1) ? 0 : ((L >> 4) + 2 + AIE_CV_GROUP - 1) / AIE_CV_GROUP;
+    const uint8_t* row = hist + sl * 16 + (int64_t)c0 * P.cv_row;
     int carry = 0;
-    const int c0 = tau_lo >> 4, c1 = tau_hi >> 4;
-    uint4 w = *reinterpret_cast<const uint4*>(row + (int64_t)c0 * P.cv_row);
-    for (int c = c0; c <= c1; ++c) {
-      const uint4 wn = c < c1 ? *reinterpret_cast<const uint4*>(row + (int64_t)(c + 1) * P.cv_row) : w;
-      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-      const int base = 16 * c;
-      if (base > tau_lo && base + 15 <= tau_hi) {
-        const int l0 = base - t - 1;
+    uint4 cur[AIE_CV_GROUP], nxt[AIE_CV_GROUP];
+#pragma unroll
+    for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = *reinterpret_cast<const uint4*>(row + (int64_t)k * P.cv_row);
+    for (int g = 0; g < ngroups; ++g) {
+      if (g + 1 < ngroups) {
+#pragma unroll
+        for (int k = 0; k < AIE_CV_GROUP; ++k)
+          nxt[k] = *reinterpret_cast<const uint4*>(row + (int64_t)((g + 1) * AIE_CV_GROUP + k) * P.cv_row);
+      }
+#pragma unroll
+      for (int k = 0; k < AIE_CV_GROUP; ++k) {
+        const int c = c0 + g * AIE_CV_GROUP + k;
+        uint32_t ww[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+        if (c == c_today) {  // today's level is still in registers: patch it into the stream
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q == q_today) ww[q] = (ww[q] & ~(0xffu << sh_today)) | ((uint32_t)a.level << sh_today);
+        }
+        // wave-uniform pointer into the read-only tap table -> s_load through the scalar cache
+        cv_tap_ptr g0 = (cv_tap_ptr)(uintptr_t)(G + (int64_t)(16 * c - t - 1 + AIE_CV_TAP_PAD_FRONT) * F);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int lev = (int)((ww[j >> 2] >> (8 * (j & 3))) & 0xffu);
           const double d = (double)(lev - carry);
           carry = lev;
 #pragma unroll
-          for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, G[f * L + l0 + j], acc[f]);
-        }
-      } else {
+          for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, g0[j * F + f], acc[f]);
+          // 16*F doubles of taps per chunk do not fit the SGPR file: tie the pointer to the
+          // accumulator every 4 days so that only 4*F taps are fetched ahead of their use
+          if ((j & 3) == 3) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int tau = base + j;
-          const int lev = (int)((ww[j >> 2] >> (8 * (j & 3))) & 0xffu);
-          if (tau > tau_lo && tau <= tau_hi) {
-            const double d = (double)(lev - carry);
-            const int l = tau - t - 1;
-#pragma unroll
-            for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, G[f * L + l], acc[f]);
+            for (int f = 0; f < F; ++f) asm volatile("" : "+s"(g0), "+v"(acc[f]));
           }
-          carry = lev;
         }
       }
-      w = wn;
+#pragma unroll
+      for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = nxt[k];
     }
-    // the newest delta: today's level against yesterday's
-    const double d_last = (double)(a.level - (L >= 1 ? prev_level : a.level));
     double x = 0.0;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-      acc[f] = __builtin_fma(d_last, G[f * L + L - 1], acc[f]);
       x = x + K[(AIE_CV_K_CONV_W0 + f) * 64 + sl] * acc[f];
     }
     const double excess = x <= 20.0 ? log(1.0 + exp(x)) : x;  // softplus :1358-1372

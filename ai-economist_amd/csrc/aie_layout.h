@@ -118,7 +118,7 @@ typedef struct aie_params {
   int32_t o_cv_cooldown; /* record: int32 row                                              */
   int32_t o_cv_subsidy_level;
   int64_t a_cv_consts;   /* AIE_CV_K_* float64 rows of 64 (shared by all replicas)         */
-  int64_t a_cv_filters;  /* float64 [F][L]                                                 */
+  int64_t a_cv_filters;  /* float64 [pad+L+pad][F]                                              */
   int64_t a_cv_hist0;    /* uint8 [L+1][n]   stringency levels of the L days before t=0 + t=0 */
   int64_t a_cv_lag_obs;  /* uint8 [beta_delay][n]                                          */
   int64_t a_cv_hist;     /* uint8 [E][nch][cv_row]                                         */
@@ -208,6 +208,10 @@ enum { AIE_CV_ST_S = 0, AIE_CV_ST_I, AIE_CV_ST_R, AIE_CV_ST_D, AIE_CV_ST_V, AIE_
 enum { AIE_CV_OB_STATE = 0, AIE_CV_OB_PROD = 6, AIE_CV_OB_LAG = 7, AIE_CV_OB_TIME = 8, AIE_CV_OB_POLICY = 9,
        AIE_CV_OB_T_SUBSIDY = 10, AIE_CV_OB_SUBSIDY_LEVEL = 11, AIE_CV_OB_T_VACCINE = 12, AIE_CV_OB_MASK = 13 };
 
+#define AIE_CV_GROUP 2            /* history chunks fetched per prefetch group                 */
+#define AIE_CV_TAP_PAD_FRONT 16   /* zero rows before tap 0 in the filter-tap table            */
+#define AIE_CV_TAP_PAD_BACK (16 * (AIE_CV_GROUP + 3))
+
 static inline void aie__add_shared(aie_tensor_table* tt, const char* name, int dtype, int64_t off,
                                    int nd, int64_t d0, int64_t d1) {
   aie__add(tt, name, dtype, off, 0, nd, d0, d1, 0, 0, 1);
@@ -247,7 +251,8 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   p->cv_F = v->num_filters;
   p->cv_NL = v->num_stringency_levels;
   p->cv_NS = v->num_subsidy_levels;
-  p->cv_nch = (v->filter_len + 1 + c->episode_length + 15) / 16;
+  /* + slack: the last prefetch group of the last step reads (zero-tap) chunks past day T */
+  p->cv_nch = (v->filter_len + 1 + c->episode_length + 15) / 16 + AIE_CV_GROUP + 3;
   p->cv_row = (int32_t)aie__align(16 * n, 64);
   p->cv_nrow_obs = AIE_CV_OB_MASK + 1 + p->cv_NL;
   {
@@ -273,7 +278,8 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   int64_t a = 0;
   p->a_records = a;    a = aie__align(a + E * (int64_t)p->rec_bytes, 256);
   p->a_cv_consts = a;  a = aie__align(a + (int64_t)AIE_CV_K_COUNT * 64 * 8, 256);
-  p->a_cv_filters = a; a = aie__align(a + (int64_t)p->cv_F * p->cv_L * 8, 256);
+  p->a_cv_filters = a;
+  a = aie__align(a + (int64_t)(AIE_CV_TAP_PAD_FRONT + p->cv_L + AIE_CV_TAP_PAD_BACK) * p->cv_F * 8, 256);
   p->a_cv_hist0 = a;   a = aie__align(a + (int64_t)(p->cv_L + 1) * n, 256);
   p->a_cv_lag_obs = a; a = aie__align(a + (int64_t)v->beta_delay * n, 256);
   p->a_cv_hist = a;    a = aie__align(a + E * (int64_t)p->cv_nch * p->cv_row, 256);
@@ -312,7 +318,12 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
       aie__add_shared(tt, k_name[k], AIE_F64, p->a_cv_consts + (int64_t)k * 512, 1, n, 0);
     aie__add_shared(tt, "model_conv_weights", AIE_F64, p->a_cv_consts + (int64_t)AIE_CV_K_CONV_W0 * 512, 2, p->cv_F, n);
     tt->t[tt->n - 1].stride[1] = 512;
-    aie__add_shared(tt, "model_unemp_conv_filters", AIE_F64, p->a_cv_filters, 2, p->cv_F, p->cv_L);
+    /* stored tap-major ([L][F]) so that the F taps of one day, and 16 days, are contiguous;
+     * zero rows before and after (the arena is zero-initialised) */
+    aie__add_shared(tt, "model_unemp_conv_filters", AIE_F64,
+                    p->a_cv_filters + (int64_t)AIE_CV_TAP_PAD_FRONT * p->cv_F * 8, 2, p->cv_F, p->cv_L);
+    tt->t[tt->n - 1].stride[1] = 8;
+    tt->t[tt->n - 1].stride[2] = 8 * (int64_t)p->cv_F;
     aie__add_shared(tt, "model_stringency_level_history_0", AIE_U8, p->a_cv_hist0, 2, p->cv_L + 1, n);
     aie__add_shared(tt, "model_policy_before_start_obs", AIE_U8, p->a_cv_lag_obs, 2, v->beta_delay, n);
 
