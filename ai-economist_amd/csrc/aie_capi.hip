@@ -19,6 +19,7 @@ struct aie_env {
   bool owns_arena;
   int device;
   size_t lds;
+  int step_waves;  // wavefronts per replica in aie_step_kernel (2; 1 = original schedule)
   int64_t sample_t;
   char err[512];
 };
@@ -72,6 +73,7 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
   int rc = aie_build_params(cfg, &env->P, &env->tt, g_create_err, sizeof(g_create_err));
   if (rc != AIE_OK) { delete env; return rc; }
   env->device = device;
+  env->step_waves = 2;
   const bool covid = cfg->scenario == AIE_SCN_COVID;
   const bool ose = cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY || covid;  // map-less: no cell words to initialise
   env->lds = covid ? 0 : cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY ? aie::ose_lds_bytes(env->P) : aie::lds_bytes(env->P);
@@ -299,8 +301,11 @@ int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
+  else if (env->step_waves == 2)
+    hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
   else
-    hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+    hipLaunchKernelGGL(aie_step_kernel_w1, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
@@ -335,6 +340,20 @@ int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_of
                      d_actions_a, d_actions_p);
   env->sample_t += 1;
   AIE_HIP_CHECK(env, hipGetLastError());
+  return AIE_OK;
+}
+
+// Development aid (not part of include/aie.h): wavefronts per replica of the step kernel.
+int aie_dev_set_step_waves(aie_env* env, int waves) {
+  if (!env || (waves != 1 && waves != 2)) return AIE_E_INVALID;
+  env->step_waves = waves;
+  return AIE_OK;
+}
+
+// Development aid (not part of include/aie.h): extra dynamic LDS per workgroup (lowers residency).
+int aie_dev_set_lds_pad(aie_env* env, int bytes) {
+  if (!env || bytes < 0) return AIE_E_INVALID;
+  env->lds += (size_t)bytes;
   return AIE_OK;
 }
 

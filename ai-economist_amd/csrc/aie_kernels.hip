@@ -59,7 +59,10 @@ __device__ __forceinline__ double* scr_sorted_inc(const Ctx& c) { return c.fscr 
 __device__ __forceinline__ double* scr_cmr(const Ctx& c) { return c.fscr + 2 * c.P.P + c.P.n; }
 __device__ __forceinline__ double* scr_coin(const Ctx& c) { return c.fscr + 2 * c.P.P + 2 * c.P.n; }
 __device__ __forceinline__ double* scr_part(const Ctx& c) { return c.fscr + 2 * c.P.P + 3 * c.P.n; }  // [n+1]
-__host__ __device__ inline int fscr_doubles(const aie_params& P) { return 2 * P.P + 4 * P.n + 2; }
+// sort buffer of the planner's gini (n >= 30): its own slot, because the rewards run on the
+// second wave of a replica while the first one uses scr_sorted_inc for the tax observations
+__device__ __forceinline__ double* scr_gini_sort(const Ctx& c) { return c.fscr + 2 * c.P.P + 4 * c.P.n + 2; }
+__host__ __device__ inline int fscr_doubles(const aie_params& P) { return 2 * P.P + 5 * P.n + 2; }
 
 // The LDS image of the record stops where the MT19937 key starts (it lives in VGPRs).
 __host__ __device__ inline int rec_lds_bytes(const aie_params& P) { return P.o_mt; }
@@ -105,6 +108,13 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e
 // ------------------------------------------------------------------------------------
 // wave helpers
 // ------------------------------------------------------------------------------------
+// Ordering point inside a section that ONE wavefront executes (every __device__ function
+// below is such a section: lane loops stride by AIE_NT = 64).  LDS instructions of a wave are
+// issued and executed in order, so a later ds_read of any lane sees an earlier ds_write of any
+// other lane of the same wave; what is needed is that the compiler keeps that order.  Block-
+// level barriers (__syncthreads) only appear in the kernels, between sections that different
+// waves of a replica's workgroup execute.
+#define AIE_WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) {
@@ -156,13 +166,15 @@ struct MT {
 // the step's 2*H*W np.random.rand values targets Wood cell d (d < HW) or Stone cell d-HW,
 // and only source-block cells can respawn (layout_from_file.py:394-403).
 // *c.srcn must have been zeroed (and a barrier passed) before the call.
-__device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {
+// `wave` of `nwaves` copies every nwaves-th 16-byte unit; wave 0 also takes the MT19937 key.
+__device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m, int wave = 0,
+                                            int nwaves = 1) {
   const uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
   const uint4* src = reinterpret_cast<const uint4*>(g);
   uint4* dst = reinterpret_cast<uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
   const int HW = c.P.HW;
-  for (int q = c.tid; q < nq; q += AIE_NT) {
+  for (int q = wave * AIE_NT + c.tid; q < nq; q += nwaves * AIE_NT) {
     const uint4 v = src[q];
     dst[q] = v;
     const int cell0 = 4 * q - (c.P.o_cells >> 2);
@@ -184,17 +196,20 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
       }
     }
   }
+  if (wave != 0) return;
   const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
 #pragma unroll
   for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
   m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
 }
-__device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m) {
+__device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m, int wave = 0,
+                                             int nwaves = 1) {
   uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
   uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
-  for (int q = c.tid; q < nq; q += AIE_NT) dst[q] = src[q];
+  for (int q = wave * AIE_NT + c.tid; q < nq; q += nwaves * AIE_NT) dst[q] = src[q];
+  if (wave != 0) return;
   uint32_t* key = reinterpret_cast<uint32_t*>(g + c.P.o_mt);
 #pragma unroll
   for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
@@ -847,7 +862,7 @@ __device__ __forceinline__ void tax_component_step(const Ctx& c, Agents& A) {
       const int a = c.act_p[c.tid];
       if (a > 0 && a <= c.P.c.tax_n_disc_rates) R_I32(c, o_tax_rate_idx)[c.tid] = a - 1;
     }
-    __syncthreads();
+    AIE_WSYNC();
   }
   if (pos >= c.P.c.tax_period) {
     tax_enact(c, A);
@@ -953,11 +968,11 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k)
       need |= (off_a[k] + 1 >= lo) && (off_a[k] < lo + AIE_MT_N);
     if (__ballot(need) == 0) continue;
-    __syncthreads();
+    AIE_WSYNC();
 #pragma unroll
     for (int j = 0; j < 9; ++j) buf[64 * j + lane] = m.r[j];
     if (lane < 48) buf[576 + lane] = m.r[9];
-    __syncthreads();
+    AIE_WSYNC();
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
       const int ia = off_a[k] - lo, ib = ia + 1;
@@ -969,7 +984,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
 #pragma unroll
   for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k)
     if (off_a[k] >= 0) regen_cell(c, mt_temper(wa[k]), mt_temper(wb[k]), (off_a[k] - pos0) >> 1);
-  __syncthreads();  // the dump area is the observation staging area
+  AIE_WSYNC();  // the dump area is the observation staging area
 }
 
 // ------------------------------------------------------------------------------------
@@ -986,7 +1001,7 @@ __device__ __forceinline__ double energy_weight(const Ctx& c) {  // layout_from_
 // coin_eq_times_productivity (:84-101), inv_income_weighted_* (:104-133),
 // social_metrics.get_gini (social_metrics.py:10-46).
 // Lane i < n computes agent i's utility; lane 0 finishes the planner's.
-// Results are left in scr_part()[0..n]; must be followed by __syncthreads().
+// Results are left in scr_part()[0..n]; must be followed by AIE_WSYNC().
 __device__ __forceinline__ void current_metrics(const Ctx& c) {
   const int n = c.P.n, i = c.tid;
   double* coin = scr_coin(c);
@@ -1002,7 +1017,7 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
     else util_c = (pow(ci, 1 - eta) - 1) / (1 - eta);
     out[i] = util_c - R_F64(c, o_labor)[i] * lcf;
   }
-  __syncthreads();
+  AIE_WSYNC();
   const int prt = c.P.c.planner_reward_type;
   if (prt == AIE_PLANNER_REW_COIN_EQ_TIMES_PROD) {
     if (n < 30) {
@@ -1012,7 +1027,7 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
         tmp[i] = s;
       }
     }
-    __syncthreads();
+    AIE_WSYNC();
     if (i == 0) {
       const double tot = np_sum_small(coin, n);
       double gini;
@@ -1023,7 +1038,7 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
         gini = unscaled / ((double)(n - 1) / (double)n);
       } else {
         // sorted-cumsum branch (social_metrics.py:43-46)
-        double* s = scr_sorted_inc(c);  // free here
+        double* s = scr_gini_sort(c);
         for (int j = 0; j < n; ++j) s[j] = coin[j];
         for (int a = 1; a < n; ++a) {
           double x = s[a]; int b = a - 1;
@@ -1056,7 +1071,7 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
 __device__ __forceinline__ void compute_rewards(const Ctx& c, uint8_t* __restrict__ arena) {
   const int n = c.P.n, i = c.tid;
   current_metrics(c);
-  __syncthreads();
+  AIE_WSYNC();
   double* cur = scr_part(c);
   double* util = R_F64(c, o_util);
   double* rew = scr_coin(c);  // reuse
@@ -1067,7 +1082,7 @@ __device__ __forceinline__ void compute_rewards(const Ctx& c, uint8_t* __restric
     if (i < n) reinterpret_cast<float*>(arena + c.P.a_rew_a)[(int64_t)c.e * n + i] = (float)r;
     else reinterpret_cast<float*>(arena + c.P.a_rew_p)[c.e] = (float)r;
   }
-  __syncthreads();
+  AIE_WSYNC();
   if (i == 0) {
     if (np_sum_small(rew, n) / n > 0) *R_I32(c, o_auto_warmup) += 1;
   }
@@ -1274,7 +1289,7 @@ __device__ __forceinline__ void write_flat_observations_and_masks(const Ctx& c, 
     s_pflat[P.fp_world + 2] = 0.0f;
     reinterpret_cast<float*>(arena + P.a_obs_p_time)[c.e] = tval;
   }
-  __syncthreads();
+  AIE_WSYNC();
 
   // ================= stage B: fill the vectors, one lane per element =====================
   if (P.has_cda && !(skip & 128)) {
@@ -1376,7 +1391,7 @@ __device__ __forceinline__ void write_flat_observations_and_masks(const Ctx& c, 
       s_pmask[q] = v;
     }
   }
-  __syncthreads();
+  AIE_WSYNC();
 
   // ---- stream the staged vectors out: 16-byte LDS reads, dword-aligned 16-byte stores ----
   if (!(skip & 1024)) {
@@ -1393,12 +1408,12 @@ __device__ __forceinline__ void rebuild_locmap(const Ctx& c) {
   uint32_t* lm = reinterpret_cast<uint32_t*>(c.locmap);
   const int nw = (c.P.HW + 3) >> 2;
   for (int q = c.tid; q < nw; q += AIE_NT) lm[q] = 0;
-  __syncthreads();
+  AIE_WSYNC();
   if (c.tid < c.P.n) {
     const int r = R_I32(c, o_loc_r)[c.tid], col = R_I32(c, o_loc_c)[c.tid];
     if (r >= 0 && col >= 0) c.locmap[r * c.P.W + col] = (uint8_t)(c.tid + 1);
   }
-  __syncthreads();
+  AIE_WSYNC();
 }
 
 }  // namespace aie
@@ -1409,56 +1424,86 @@ __device__ __forceinline__ void rebuild_locmap(const Ctx& c) {
 
 // BaseEnvironment.step, F/base/base_env.py:929-1032: parse actions, timestep += 1,
 // components in list order, scenario_step, observations, masks, rewards, done.
-extern "C" __global__ void __launch_bounds__(AIE_NT)
-aie_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+//
+// NW = 2 (default): a replica is a workgroup of TWO wavefronts sharing the LDS record.
+//   both   record HBM -> LDS (alternate 16-byte units)
+//   wave 0 action decode, components, regeneration           (wave 1 waits at the barrier)
+//   wave 0 flat observation vectors + masks  ||  wave 1 egocentric crops + planner map,
+//                                                 utilities / rewards / done
+//   both   record LDS -> HBM
+// The two post-dynamics halves only read the record (wave 1 alone updates util / warm-up
+// counters), so they need no synchronisation until the final store.  With <= 64 VGPRs all
+// 2 x 4096 waves of the C2 batch are resident at once (8 per SIMD) instead of 4 per SIMD.
+// NW = 1 is the original one-wave-per-replica schedule (kept for A/B measurements).
+template <int NW>
+__device__ __forceinline__ void step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                                          const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
+                                          uint8_t* lds) {
   using namespace aie;
   // The parameter block lives in device memory (uniform scalar loads).  Passing the 2.7 KB
   // struct by value made the compiler copy it to scratch on every launch (5x slower).
   const aie_params& P = *params;
-  const Ctx c = make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)threadIdx.x);
+  const int wid = NW == 1 ? 0 : uni((int)(threadIdx.x >> 6));
+  const Ctx c = make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)(threadIdx.x & (AIE_NT - 1)));
   MT m;
   Agents A;
-  if (c.tid == 0) *c.srcn = 0;
-  __syncthreads();
-  load_record(c, arena, m);
-  decode_actions(c, A, act_a, act_p);
-  __syncthreads();
-  m.pos = uni(*R_I32(c, o_mt_pos));
-  agents_load(c, A);
-  rebuild_locmap(c);
   const int skip = P.dev_skip_mask;
-  if (P.has_cda && !(skip & 1)) cda_decay_price_history(c);
+  if (threadIdx.x == 0) *c.srcn = 0;
   __syncthreads();
-  if (c.tid == 0) *R_I32(c, o_timestep) += 1;
-  if (!(skip & 1)) {
-    for (int k = 0; k < P.c.n_components; ++k) {
-      switch (P.c.components[k]) {
-        case AIE_COMP_BUILD: if (!(skip & 2048)) build_component_step(c, m, A); break;
-        case AIE_COMP_CDA: if (!(skip & 4096)) cda_component_step(c, A); break;
-        case AIE_COMP_GATHER: if (!(skip & 8192)) gather_component_step(c, m, A); break;
-        case AIE_COMP_TAX: if (!(skip & 16384)) tax_component_step(c, A); break;
-        default: break;
+  load_record(c, arena, m, wid, NW);
+  if (wid == 0) decode_actions(c, A, act_a, act_p);
+  __syncthreads();
+  if (wid == 0) {
+    m.pos = uni(*R_I32(c, o_mt_pos));
+    agents_load(c, A);
+    rebuild_locmap(c);
+    if (P.has_cda && !(skip & 1)) cda_decay_price_history(c);
+    AIE_WSYNC();
+    if (c.tid == 0) *R_I32(c, o_timestep) += 1;
+    if (!(skip & 1)) {
+      for (int k = 0; k < P.c.n_components; ++k) {
+        switch (P.c.components[k]) {
+          case AIE_COMP_BUILD: if (!(skip & 2048)) build_component_step(c, m, A); break;
+          case AIE_COMP_CDA: if (!(skip & 4096)) cda_component_step(c, A); break;
+          case AIE_COMP_GATHER: if (!(skip & 8192)) gather_component_step(c, m, A); break;
+          case AIE_COMP_TAX: if (!(skip & 16384)) tax_component_step(c, A); break;
+          default: break;
+        }
       }
     }
-  }
-  agents_store(c, A);
-  if (!(skip & 2)) scenario_step_regen(c, m);
-  if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
-  __syncthreads();
-  if (!(skip & 4)) write_spatial_observations(c, arena);
-  if (!(skip & 8)) write_flat_observations_and_masks(c, arena);
-  __syncthreads();
-  if (!(skip & 16)) compute_rewards(c, arena);
-  __syncthreads();
-  if (c.tid == 0) {
-    const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
-    (arena + P.a_done)[c.e] = (uint8_t)done;
-    if (done) *R_I32(c, o_completions) += 1;
+    agents_store(c, A);
+    if (!(skip & 2)) scenario_step_regen(c, m);
+    if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
   }
   __syncthreads();
-  if (!(skip & 32)) store_record(c, arena, m);
+  if (wid == 0) {
+    if (!(skip & 8)) write_flat_observations_and_masks(c, arena);
+  }
+  if (NW == 1 || wid == 1) {
+    if (!(skip & 4)) write_spatial_observations(c, arena);
+    if (!(skip & 16)) compute_rewards(c, arena);
+    AIE_WSYNC();
+    if (c.tid == 0) {
+      const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
+      (arena + P.a_done)[c.e] = (uint8_t)done;
+      if (done) *R_I32(c, o_completions) += 1;
+    }
+  }
+  __syncthreads();
+  if (!(skip & 32)) store_record(c, arena, m, wid, NW);
+}
+
+extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+aie_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  step_body<2>(params, arena, act_a, act_p, lds);
+}
+extern "C" __global__ void __launch_bounds__(AIE_NT)
+aie_step_kernel_w1(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                   const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  step_body<1>(params, arena, act_a, act_p, lds);
 }
 
 // BaseEnvironment.reset, F/base/base_env.py:852-927, with LayoutFromFile

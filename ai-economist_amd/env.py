@@ -59,6 +59,14 @@ class DeviceBackend:
         stone_src, wood_src, water = [np.ascontiguousarray(p, np.uint8) for p in layout_planes]
         self._check(self.lib.aie_set_layout(self.handle, stone_src.ctypes.data,
                                             wood_src.ctypes.data, water.ctypes.data))
+        import os
+
+        if os.environ.get("AIE_DEV_STEP_WAVES"):  # development A/B switch (see csrc/aie_capi.hip)
+            self.lib.aie_dev_set_step_waves.argtypes = [C.c_void_p, C.c_int]
+            self._check(self.lib.aie_dev_set_step_waves(self.handle, int(os.environ["AIE_DEV_STEP_WAVES"])))
+        if os.environ.get("AIE_DEV_LDS_PAD"):
+            self.lib.aie_dev_set_lds_pad.argtypes = [C.c_void_p, C.c_int]
+            self._check(self.lib.aie_dev_set_lds_pad(self.handle, int(os.environ["AIE_DEV_LDS_PAD"])))
         self.act_a_shape = (self.E, self.n) if not cfg.multi_action_mode_agents else None
         self._rand_a = None
         self._rand_p = None
