@@ -350,6 +350,16 @@ int aie_dev_set_step_waves(aie_env* env, int waves) {
   return AIE_OK;
 }
 
+// Development aid (not part of include/aie.h): device buffer of 8*E uint64 clock stamps per launch.
+int aie_dev_set_trace(aie_env* env, void* d_buf) {
+  if (!env) return AIE_E_INVALID;
+  env->P.dev_trace = static_cast<uint64_t*>(d_buf);
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  AIE_HIP_CHECK(env, hipDeviceSynchronize());
+  AIE_HIP_CHECK(env, hipMemcpy(env->d_params, &env->P, sizeof(aie_params), hipMemcpyHostToDevice));
+  return AIE_OK;
+}
+
 // Development aid (not part of include/aie.h): extra dynamic LDS per workgroup (lowers residency).
 int aie_dev_set_lds_pad(aie_env* env, int bytes) {
   if (!env || bytes < 0) return AIE_E_INVALID;

@@ -82,7 +82,7 @@ __host__ __device__ inline size_t lds_bytes(const aie_params& P) {
   b += ((size_t)P.HW + 15) / 16 * 16;
   b += (size_t)fscr_doubles(P) * 8;
   b += stage_bytes(P);
-  b += AIE_SRC_CAP * 2 + 16 + (size_t)P.n * 4;
+  b += AIE_SRC_CAP * 2 + 16 + (size_t)pad4(P.n) * 4;
   return (b + 15) / 16 * 16;
 }
 
@@ -124,6 +124,28 @@ __device__ __forceinline__ double bcast(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
+}
+// Buffer-descriptor stores: base + num_records in 4 SGPRs, a 32-bit VGPR byte offset and a
+// scalar byte offset per instruction (gfx9 raw buffer, DATA_FORMAT = 32 in word 3).
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ BufRsrc make_rsrc(void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_store_f32(BufRsrc r, float v, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store_i16(BufRsrc r, int v, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store_u32x2(BufRsrc r, uint32_t a, uint32_t b, int voff, int soff) {
+  const u32x2 v = {a, b};
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store_f32x4(BufRsrc r, float a, float b, float c, float d, int voff, int soff) {
+  const u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
 }
 // 16 bytes with dword alignment: global dwordx4 accesses need no more on gfx950
 struct __attribute__((packed, aligned(4))) f32x4_a4 { float x, y, z, w; };
@@ -961,7 +983,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
   }
   const int last_win = (pos0 + total - 1) / AIE_MT_N;
   for (int w = 0; w <= last_win; ++w) {
-    if (w > 0) mt_twist(m, lane);
+    if (w > 0 && !(c.P.dev_skip_mask & 65536)) mt_twist(m, lane);
     const int lo = w * AIE_MT_N;
     bool need = false;
 #pragma unroll
@@ -1111,75 +1133,125 @@ __device__ __forceinline__ void cell_channels(uint32_t w, float* ch) {
 //            stores and 2 i16 stores (the out-of-world ring: all 0, in-bounds channel 0);
 //   planner: one lane per 4 consecutive cells: one 16-byte LDS read feeds CM 16-byte
 //            stores and two 8-byte stores.
+// All stores go through buffer descriptors of this replica's observation blocks: one
+// 32-bit lane offset per item + a scalar offset per (agent, channel) plane, instead of a
+// 64-bit VGPR pointer per plane.
+struct SpatialOut {
+  BufRsrc amap, aidx, pmap, pidx;
+};
+template <bool WATER>
+__device__ __forceinline__ SpatialOut spatial_out(const Ctx& c, uint8_t* __restrict__ arena) {
+  constexpr int CM = WATER ? 6 : 5;
+  const int n = c.P.n, HW = c.P.HW, WV2 = c.P.WV * c.P.WV;
+  const uint32_t amap_bytes = (uint32_t)(n * (CM + 1) * WV2 * 4), aidx_bytes = (uint32_t)(n * 2 * WV2 * 2);
+  SpatialOut o;
+  o.amap = make_rsrc(arena + c.P.a_obs_a_map + (int64_t)c.e * amap_bytes, amap_bytes);
+  o.aidx = make_rsrc(arena + c.P.a_obs_a_idx + (int64_t)c.e * aidx_bytes, aidx_bytes);
+  const bool pl = c.P.c.planner_gets_spatial_info != 0;
+  o.pmap = make_rsrc(arena + c.P.a_obs_p_map + (int64_t)c.e * CM * HW * 4, pl ? (uint32_t)(CM * HW * 4) : 0u);
+  o.pidx = make_rsrc(arena + c.P.a_obs_p_idx + (int64_t)c.e * 2 * HW * 2, pl ? (uint32_t)(2 * HW * 2) : 0u);
+  return o;
+}
+
+// one (agent i, window cell d) item of the egocentric crop, layout_from_file.py:470-505
+template <bool WATER>
+__device__ __forceinline__ void crop_item(const Ctx& c, const SpatialOut& o, int i, int d, int r, int col) {
+  constexpr int CM = WATER ? 6 : 5;
+  const int H = c.P.H, W = c.P.W, WV2 = c.P.WV * c.P.WV;
+  const int so = i * (CM + 1) * WV2 * 4, si = i * 2 * WV2 * 2;
+  const bool in = (r >= 0) & (r < H) & (col >= 0) & (col < W);
+  const int cell = in ? r * W + col : 0;
+  const uint32_t cw = in ? R_CELLS(c)[cell] : 0x00ff0000u;  // :480-485
+  float ch[6];
+  cell_channels<WATER>(cw, ch);
+#pragma unroll
+  for (int k = 0; k < CM; ++k) buf_store_f32(o.amap, ch[k], 4 * d, so + k * WV2 * 4);
+  buf_store_f32(o.amap, in ? 1.0f : 0.0f, 4 * d, so + CM * WV2 * 4);
+  const int own = AIE_CELL_OWNER(cw);
+  int v0 = own >= 0 ? own + 2 : 0;
+  int v1 = in ? (int)c.locmap[cell] : 0;
+  v1 = v1 ? v1 + 1 : 0;     // agent k -> k + 2
+  if (v0 == i + 2) v0 = 1;  // :503
+  if (v1 == i + 2) v1 = 1;
+  buf_store_i16(o.aidx, v0, 2 * d, si);
+  buf_store_i16(o.aidx, v1, 2 * d, si + WV2 * 2);
+}
+// the whole crop of agent i (wave-uniform i; lanes over the window cells)
+template <bool WATER>
+__device__ __forceinline__ void crop_agent(const Ctx& c, const SpatialOut& o, int i) {
+  const int WV = c.P.WV, WV2 = WV * WV, w = c.P.c.obs_range;
+  const int r0 = R_I32(c, o_loc_r)[i] - w, c0 = R_I32(c, o_loc_c)[i] - w;  // LDS broadcast reads
+  for (int d = c.tid; d < WV2; d += AIE_NT) {
+    const int dr = udiv(d, WV, c.P.mg_WV), dc = d - dr * WV;
+    crop_item<WATER>(c, o, i, d, r0 + dr, c0 + dc);
+  }
+}
+// one cell of the planner's full map (:507-517)
+template <bool WATER>
+__device__ __forceinline__ void planner_cell(const Ctx& c, const SpatialOut& o, int cell) {
+  constexpr int CM = WATER ? 6 : 5;
+  const int HW = c.P.HW;
+  float ch[6];
+  const uint32_t cw = R_CELLS(c)[cell];
+  cell_channels<WATER>(cw, ch);
+#pragma unroll
+  for (int k = 0; k < CM; ++k) buf_store_f32(o.pmap, ch[k], 4 * cell, k * HW * 4);
+  const int own = AIE_CELL_OWNER(cw);
+  const int occ = c.locmap[cell];
+  buf_store_i16(o.pidx, own >= 0 ? own + 2 : 0, 2 * cell, 0);
+  buf_store_i16(o.pidx, occ ? occ + 1 : 0, 2 * cell, HW * 2);
+}
+
+// LayoutFromFile.generate_observations layout_from_file.py:412-517: the egocentric
+// (2w+1)^2 crop for every agent and the full map for the planner.
+//   crop:    one lane per window cell of a (wave-uniform) agent: one LDS word read feeds
+//            CM+1 coalesced f32 stores and 2 i16 stores (the out-of-world ring: all 0);
+//   planner: one lane per 4 consecutive cells: one 16-byte LDS read feeds CM 16-byte
+//            stores and two 8-byte stores.
 template <bool WATER>
 __device__ __forceinline__ void write_spatial_observations_t(const Ctx& c, uint8_t* __restrict__ arena) {
   constexpr int CM = WATER ? 6 : 5;
-  const int n = c.P.n, H = c.P.H, W = c.P.W, HW = c.P.HW, WV = c.P.WV;
-  const int w = c.P.c.obs_range;
-  const int WV2 = WV * WV;
+  const int n = c.P.n, HW = c.P.HW;
   const uint32_t* cells = R_CELLS(c);
-  const int32_t *lr = R_I32(c, o_loc_r), *lc = R_I32(c, o_loc_c);
-  float* amap = reinterpret_cast<float*>(arena + c.P.a_obs_a_map) + (int64_t)c.e * n * (CM + 1) * WV2;
-  int16_t* aidx = reinterpret_cast<int16_t*>(arena + c.P.a_obs_a_idx) + (int64_t)c.e * n * 2 * WV2;
-  const int tot = n * WV2;
-  for (int q = c.tid; q < tot; q += AIE_NT) {
-    const int i = udiv(q, WV2, c.P.mg_WV2);
-    const int d = q - i * WV2;
-    const int dr = udiv(d, WV, c.P.mg_WV), dc = d - dr * WV;
-    const int r = lr[i] - w + dr, col = lc[i] - w + dc;
-    const bool in = (r >= 0) & (r < H) & (col >= 0) & (col < W);
-    const int cell = in ? r * W + col : 0;
-    const uint32_t cw = in ? cells[cell] : 0x00ff0000u;  // :480-485
-    float ch[6];
-    cell_channels<WATER>(cw, ch);
-    float* o = amap + (int64_t)i * (CM + 1) * WV2 + d;
-#pragma unroll
-    for (int k = 0; k < CM; ++k) o[k * WV2] = ch[k];
-    o[CM * WV2] = in ? 1.0f : 0.0f;
-    const int own = AIE_CELL_OWNER(cw);
-    int v0 = own >= 0 ? own + 2 : 0;
-    int v1 = in ? (int)c.locmap[cell] : 0;
-    v1 = v1 ? v1 + 1 : 0;     // agent k -> k + 2
-    if (v0 == i + 2) v0 = 1;  // :503
-    if (v1 == i + 2) v1 = 1;
-    int16_t* oi = aidx + (int64_t)i * 2 * WV2 + d;
-    oi[0] = (int16_t)v0;
-    oi[WV2] = (int16_t)v1;
-  }
+  const SpatialOut o = spatial_out<WATER>(c, arena);
+  for (int i = 0; i < n; ++i) crop_agent<WATER>(c, o, i);
   if (c.P.c.planner_gets_spatial_info) {
-    float* pmap = reinterpret_cast<float*>(arena + c.P.a_obs_p_map) + (int64_t)c.e * CM * HW;
-    int16_t* pidx = reinterpret_cast<int16_t*>(arena + c.P.a_obs_p_idx) + (int64_t)c.e * 2 * HW;
     // f32 channel planes: 4 consecutive cells per lane -> CM 16-byte stores.  The planes
-    // are only dword-aligned (H*W need not be a multiple of 4): global dwordx4 stores need
-    // no more than that on gfx950.
+    // are only dword-aligned (H*W need not be a multiple of 4): dwordx4 stores need no more
+    // than that on gfx950.  The i16 owner / location planes of the same 4 cells: 8-byte stores.
     const int nq4 = HW >> 2;
+    const uint32_t* lm4 = reinterpret_cast<const uint32_t*>(c.locmap);
     for (int q = c.tid; q < nq4; q += AIE_NT) {
       const uint4 cw = reinterpret_cast<const uint4*>(cells)[q];
+      const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
       float ch[4][6];
-      cell_channels<WATER>(cw.x, ch[0]);
-      cell_channels<WATER>(cw.y, ch[1]);
-      cell_channels<WATER>(cw.z, ch[2]);
-      cell_channels<WATER>(cw.w, ch[3]);
 #pragma unroll
-      for (int k = 0; k < CM; ++k) {
-        f32x4_a4 v = {ch[0][k], ch[1][k], ch[2][k], ch[3][k]};
-        *reinterpret_cast<f32x4_a4*>(pmap + k * HW + 4 * q) = v;
+      for (int u = 0; u < 4; ++u) cell_channels<WATER>(cws[u], ch[u]);
+#pragma unroll
+      for (int k = 0; k < CM; ++k) buf_store_f32x4(o.pmap, ch[0][k], ch[1][k], ch[2][k], ch[3][k], 16 * q, k * HW * 4);
+      const uint32_t occ4 = lm4[q];
+      uint32_t ow[2], oc[2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int own = AIE_CELL_OWNER(cws[u]);
+        const uint32_t vo = (uint32_t)(own >= 0 ? own + 2 : 0);
+        const uint32_t occ = (occ4 >> (8 * u)) & 0xffu;
+        const uint32_t vc = occ ? occ + 1 : 0;
+        if (u & 1) { ow[u >> 1] |= vo << 16; oc[u >> 1] |= vc << 16; }
+        else { ow[u >> 1] = vo; oc[u >> 1] = vc; }
+      }
+      buf_store_u32x2(o.pidx, ow[0], ow[1], 8 * q, 0);
+      if ((HW & 1) == 0) {  // second plane starts 4-byte aligned too
+        buf_store_u32x2(o.pidx, oc[0], oc[1], 8 * q, HW * 2);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) buf_store_i16(o.pidx, (int)((oc[u >> 1] >> (16 * (u & 1))) & 0xffffu), 8 * q + 2 * u, HW * 2);
       }
     }
-    for (int cell = 4 * nq4 + c.tid; cell < HW; cell += AIE_NT) {  // tail cells
-      float ch[6];
-      cell_channels<WATER>(cells[cell], ch);
-#pragma unroll
-      for (int k = 0; k < CM; ++k) pmap[k * HW + cell] = ch[k];
-    }
-    for (int cell = c.tid; cell < HW; cell += AIE_NT) {  // i16 owner / location planes
-      const int own = AIE_CELL_OWNER(cells[cell]);
-      const int occ = c.locmap[cell];
-      pidx[cell] = (int16_t)(own >= 0 ? own + 2 : 0);
-      pidx[HW + cell] = (int16_t)(occ ? occ + 1 : 0);
-    }
+    for (int cell = 4 * nq4 + c.tid; cell < HW; cell += AIE_NT) planner_cell<WATER>(c, o, cell);  // tail cells
   }
 }
+
 __device__ __forceinline__ void write_spatial_observations(const Ctx& c, uint8_t* __restrict__ arena) {
   if (c.P.c.has_water) write_spatial_observations_t<true>(c, arena);
   else write_spatial_observations_t<false>(c, arena);
@@ -1189,7 +1261,7 @@ __device__ __forceinline__ void write_spatial_observations(const Ctx& c, uint8_t
 // Build (build.py:163-178), CDA (continuous_double_auction.py:491-542), Gather
 // (move.py:155-165), PeriodicBracketTax (redistribution.py:974-1023), time, world-*.
 // Built in LDS (c.stage) then streamed out.
-__device__ __forceinline__ void write_flat_observations_and_masks(const Ctx& c, uint8_t* __restrict__ arena) {
+__device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* __restrict__ arena) {
   const aie_params& P = c.P;
   const int n = P.n, tid = c.tid, Pp = P.P, NB = P.NB;
   const double isc = P.c.allow_observation_scaling ? 0.01 : 1.0;
@@ -1262,25 +1334,6 @@ __device__ __forceinline__ void write_flat_observations_and_masks(const Ctx& c, 
       q[P.fpa_tax + 1] = (float)x;
       q[P.fpa_tax + 2] = (float)R_F64(c, o_tax_last_marginal_rate)[i];
     }
-    // mask bits: Build build.py:180-193, Gather move.py:167-188, CDA :544-580
-    uint32_t mf = 0;
-    if (P.has_build) mf |= agent_can_build(c, i) ? 1u : 0u;
-    if (P.has_gather) {
-      mf |= can_agent_occupy(c, lr, lc - 1, i) ? 2u : 0u;
-      mf |= can_agent_occupy(c, lr, lc + 1, i) ? 4u : 0u;
-      mf |= can_agent_occupy(c, lr - 1, lc, i) ? 8u : 0u;
-      mf |= can_agent_occupy(c, lr + 1, lc, i) ? 16u : 0u;
-    }
-    if (P.has_cda) {
-      int kmax = coin >= (double)(Pp - 1) ? Pp - 1 : (int)coin;  // price k is affordable iff k <= coin
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const bool quota = R_I32(c, o_cda_n_orders)[r * n + i] < P.c.cda_max_num_orders;
-        if (quota && (r ? inv1 : inv0) > 0) mf |= 32u << r;
-        if (quota) mf |= (uint32_t)(kmax + 1) << (8 + 8 * r);
-      }
-    }
-    c.mflags[i] = (int32_t)mf;
   }
   if (tid == 0) {
     s_pflat[P.fp_time] = tval;
@@ -1346,6 +1399,52 @@ __device__ __forceinline__ void write_flat_observations_and_masks(const Ctx& c, 
     }
   }
 
+  AIE_WSYNC();
+
+  // ---- stream the staged vectors out: 16-byte LDS reads, dword-aligned 16-byte stores ----
+  if (!(skip & 1024)) {
+    stream_out(s_aflat, reinterpret_cast<float*>(arena + P.a_obs_a_flat) + (int64_t)c.e * n * P.FA, n * P.FA, tid);
+    stream_out(s_pag, reinterpret_cast<float*>(arena + P.a_obs_p_agents) + (int64_t)c.e * n * P.FPA, n * P.FPA, tid);
+    stream_out(s_pflat, reinterpret_cast<float*>(arena + P.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
+  }
+}
+
+
+// Action masks (own staging slots, own per-agent mask bits): independent of the flat vectors
+// above, so the second wave of a replica builds them while the first one does those.
+__device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __restrict__ arena) {
+  const aie_params& P = c.P;
+  const int n = P.n, tid = c.tid, Pp = P.P;
+  float* s_amask = c.stage + pad4(n * P.FA);
+  float* s_pmask = s_amask + pad4(n * P.MA) + pad4(n * P.FPA) + pad4(P.FP);
+  const int skip = P.dev_skip_mask;
+  if (skip & 512) return;
+  if (tid < n) {
+    const int i = tid;
+    const double coin = R_F64(c, o_inv_coin)[i];
+    const int inv0 = R_I32(c, o_inv_res)[i], inv1 = R_I32(c, o_inv_res)[n + i];
+    const int lr = R_I32(c, o_loc_r)[i], lc = R_I32(c, o_loc_c)[i];
+    // mask bits: Build build.py:180-193, Gather move.py:167-188, CDA :544-580
+    uint32_t mf = 0;
+    if (P.has_build) mf |= agent_can_build(c, i) ? 1u : 0u;
+    if (P.has_gather) {
+      mf |= can_agent_occupy(c, lr, lc - 1, i) ? 2u : 0u;
+      mf |= can_agent_occupy(c, lr, lc + 1, i) ? 4u : 0u;
+      mf |= can_agent_occupy(c, lr - 1, lc, i) ? 8u : 0u;
+      mf |= can_agent_occupy(c, lr + 1, lc, i) ? 16u : 0u;
+    }
+    if (P.has_cda) {
+      int kmax = coin >= (double)(Pp - 1) ? Pp - 1 : (int)coin;  // price k is affordable iff k <= coin
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bool quota = R_I32(c, o_cda_n_orders)[r * n + i] < P.c.cda_max_num_orders;
+        if (quota && (r ? inv1 : inv0) > 0) mf |= 32u << r;
+        if (quota) mf |= (uint32_t)(kmax + 1) << (8 + 8 * r);
+      }
+    }
+    c.mflags[i] = (int32_t)mf;
+  }
+  AIE_WSYNC();
   // ---- masks: _generate_masks base_env.py:706-756 + flatten_masks base_agent.py:440-460,
   // planner PeriodicBracketTax.generate_masks redistribution.py:1025-1104 ----
   if (!(skip & 512)) {
@@ -1392,17 +1491,11 @@ __device__ __forceinline__ void write_flat_observations_and_masks(const Ctx& c, 
     }
   }
   AIE_WSYNC();
-
-  // ---- stream the staged vectors out: 16-byte LDS reads, dword-aligned 16-byte stores ----
   if (!(skip & 1024)) {
-    stream_out(s_aflat, reinterpret_cast<float*>(arena + P.a_obs_a_flat) + (int64_t)c.e * n * P.FA, n * P.FA, tid);
     stream_out(s_amask, reinterpret_cast<float*>(arena + P.a_obs_a_mask) + (int64_t)c.e * n * P.MA, n * P.MA, tid);
-    stream_out(s_pag, reinterpret_cast<float*>(arena + P.a_obs_p_agents) + (int64_t)c.e * n * P.FPA, n * P.FPA, tid);
-    stream_out(s_pflat, reinterpret_cast<float*>(arena + P.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
     stream_out(s_pmask, reinterpret_cast<float*>(arena + P.a_obs_p_mask) + (int64_t)c.e * P.MP, P.MP, tid);
   }
 }
-
 
 __device__ __forceinline__ void rebuild_locmap(const Ctx& c) {
   uint32_t* lm = reinterpret_cast<uint32_t*>(c.locmap);
@@ -1427,13 +1520,17 @@ __device__ __forceinline__ void rebuild_locmap(const Ctx& c) {
 //
 // NW = 2 (default): a replica is a workgroup of TWO wavefronts sharing the LDS record.
 //   both   record HBM -> LDS (alternate 16-byte units)
-//   wave 0 action decode, components, regeneration           (wave 1 waits at the barrier)
-//   wave 0 flat observation vectors + masks  ||  wave 1 egocentric crops + planner map,
-//                                                 utilities / rewards / done
+//   wave 0 action decode, price-history decay          ||  wave 1 occupancy map
+//   wave 0 components, regeneration                        (wave 1 waits at the barrier)
+//   wave 0 flat observation vectors, rewards, done     ||  wave 1 egocentric crops + planner map,
+//                                                      ||         action masks
 //   both   record LDS -> HBM
-// The two post-dynamics halves only read the record (wave 1 alone updates util / warm-up
+// The two post-dynamics halves only read the record (wave 0 alone updates util / warm-up
 // counters), so they need no synchronisation until the final store.  With <= 64 VGPRs all
 // 2 x 4096 waves of the C2 batch are resident at once (8 per SIMD) instead of 4 per SIMD.
+// (Tried and dropped: writing the map observations speculatively during the dynamics and
+// repairing the changed cells afterwards -- parity-clean, but the extra store traffic slows
+// the serial dynamics of the first wave by as much as it saves.)
 // NW = 1 is the original one-wave-per-replica schedule (kept for A/B measurements).
 template <int NW>
 __device__ __forceinline__ void step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
@@ -1448,18 +1545,22 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   MT m;
   Agents A;
   const int skip = P.dev_skip_mask;
+  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[8 * blockIdx.x] = wall_clock64();
   if (threadIdx.x == 0) *c.srcn = 0;
   __syncthreads();
   load_record(c, arena, m, wid, NW);
   if (wid == 0) decode_actions(c, A, act_a, act_p);
-  __syncthreads();
+  __syncthreads();  // the record is in LDS
+  if (NW == 1 || wid == 1) rebuild_locmap(c);
   if (wid == 0) {
     m.pos = uni(*R_I32(c, o_mt_pos));
     agents_load(c, A);
-    rebuild_locmap(c);
     if (P.has_cda && !(skip & 1)) cda_decay_price_history(c);
-    AIE_WSYNC();
+  }
+  __syncthreads();  // occupancy map rebuilt
+  if (wid == 0) {
     if (c.tid == 0) *R_I32(c, o_timestep) += 1;
+    if (P.dev_trace && c.tid == 0) P.dev_trace[8 * blockIdx.x + 1] = wall_clock64();
     if (!(skip & 1)) {
       for (int k = 0; k < P.c.n_components; ++k) {
         switch (P.c.components[k]) {
@@ -1469,18 +1570,17 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
           case AIE_COMP_TAX: if (!(skip & 16384)) tax_component_step(c, A); break;
           default: break;
         }
+        if (P.dev_trace && c.tid == 0 && k < 4) P.dev_trace[8 * blockIdx.x + 2 + k] = wall_clock64();
       }
     }
     agents_store(c, A);
     if (!(skip & 2)) scenario_step_regen(c, m);
     if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
+    if (P.dev_trace && c.tid == 0) P.dev_trace[8 * blockIdx.x + 6] = wall_clock64();
   }
   __syncthreads();
   if (wid == 0) {
-    if (!(skip & 8)) write_flat_observations_and_masks(c, arena);
-  }
-  if (NW == 1 || wid == 1) {
-    if (!(skip & 4)) write_spatial_observations(c, arena);
+    if (!(skip & 8)) write_flat_observations(c, arena);
     if (!(skip & 16)) compute_rewards(c, arena);
     AIE_WSYNC();
     if (c.tid == 0) {
@@ -1489,8 +1589,13 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       if (done) *R_I32(c, o_completions) += 1;
     }
   }
+  if (NW == 1 || wid == 1) {
+    if (!(skip & 4)) write_spatial_observations(c, arena);
+    if (!(skip & 8)) write_action_masks(c, arena);
+  }
   __syncthreads();
   if (!(skip & 32)) store_record(c, arena, m, wid, NW);
+  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[8 * blockIdx.x + 7] = wall_clock64();
 }
 
 extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -1636,7 +1741,8 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   if (tid <= n) R_F64(c, o_util)[tid] = scr_part(c)[tid];
   __syncthreads();
   write_spatial_observations(c, arena);
-  write_flat_observations_and_masks(c, arena);
+  write_flat_observations(c, arena);
+  write_action_masks(c, arena);
   if (tid < n) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + tid] = 0.0f;
   if (tid == 0) {
     reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.0f;

@@ -104,6 +104,7 @@ typedef struct aie_params {
   /* development only: phases of the step kernel to skip when profiling
    * (tools/phase_profile.py); always 0 in normal operation */
   int32_t dev_skip_mask;
+  uint64_t* dev_trace;   /* development: 8 clock stamps per workgroup (start, components.., regen, end), or NULL */
 
   /* ---- COVID-19 scenario (aie__build_covid) ---- */
   int32_t cv_L;          /* filter_len                                                     */

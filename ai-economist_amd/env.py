@@ -64,6 +64,9 @@ class DeviceBackend:
         if os.environ.get("AIE_DEV_STEP_WAVES"):  # development A/B switch (see csrc/aie_capi.hip)
             self.lib.aie_dev_set_step_waves.argtypes = [C.c_void_p, C.c_int]
             self._check(self.lib.aie_dev_set_step_waves(self.handle, int(os.environ["AIE_DEV_STEP_WAVES"])))
+        if os.environ.get("AIE_DEV_SKIP_MASK"):
+            self.lib.aie_dev_set_skip_mask.argtypes = [C.c_void_p, C.c_int]
+            self._check(self.lib.aie_dev_set_skip_mask(self.handle, int(os.environ["AIE_DEV_SKIP_MASK"])))
         if os.environ.get("AIE_DEV_LDS_PAD"):
             self.lib.aie_dev_set_lds_pad.argtypes = [C.c_void_p, C.c_int]
             self._check(self.lib.aie_dev_set_lds_pad(self.handle, int(os.environ["AIE_DEV_LDS_PAD"])))
