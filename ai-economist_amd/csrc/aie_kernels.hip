@@ -44,6 +44,7 @@ struct Ctx {
   uint16_t* srcl;    // LDS [AIE_SRC_CAP] regen doubles that target a source block
   int32_t* srcn;     // LDS [1] number of source doubles found (may exceed AIE_SRC_CAP)
   int32_t* mflags;   // LDS [n] per-agent mask bits
+  uint8_t* met;      // GLOBAL: this replica's episode accumulators (aie_layout.h: a_metrics), or nullptr
   int tid;
   int e;
 };
@@ -86,7 +87,7 @@ __host__ __device__ inline size_t lds_bytes(const aie_params& P) {
   return (b + 15) / 16 * 16;
 }
 
-__device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e, int tid) {
+__device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e, int tid, uint8_t* arena = nullptr) {
   uint8_t* q = lds + rec_lds_bytes(P);
   int32_t* act_p = reinterpret_cast<int32_t*>(q);
   q += AIE_MAX_BRACKETS * 4;
@@ -102,7 +103,8 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e
   int32_t* srcn = reinterpret_cast<int32_t*>(q);
   q += 16;
   int32_t* mflags = reinterpret_cast<int32_t*>(q);
-  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, tid, e};
+  uint8_t* met = arena ? arena + P.a_metrics + (int64_t)e * P.met_bytes : nullptr;
+  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, met, tid, e};
 }
 
 // ------------------------------------------------------------------------------------
@@ -746,6 +748,13 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
       bid_hist[(r * n + buyer) * P + bprice] -= 1;
       ask_hist[(r * n + seller) * P + aprice] -= 1;
       R_F64(c, o_cda_price_history)[(r * n + seller) * P + price] += 1.0;
+      if (lane == 0 && c.met) {  // get_metrics :585-641: fire-and-forget integer atomics
+        int32_t* tm = reinterpret_cast<int32_t*>(c.met + c.P.mo_cda);
+        int32_t* sell = tm + ((0 * AIE_N_RES + r) * n + seller) * 2;
+        int32_t* buy = tm + ((1 * AIE_N_RES + r) * n + buyer) * 2;
+        atomicAdd(sell, 1); atomicAdd(sell + 1, price);
+        atomicAdd(buy, 1); atomicAdd(buy + 1, price);
+      }
       if (lane == seller) {
         if (r) { A.no1 -= 1; A.esc1 -= 1; } else { A.no0 -= 1; A.esc0 -= 1; }
         A.coin += (double)price;
@@ -858,7 +867,7 @@ __device__ __forceinline__ double tax_due(const Ctx& c, double income) {  // tax
 // in agent order (the reference's running `net_tax_revenue +=`).
 __device__ __forceinline__ void tax_enact(const Ctx& c, Agents& A) {
   const int n = c.P.n, i = c.tid;
-  double eff = 0;
+  double eff = 0, eff_rate = 0;
   if (i < n) {
     const double income = (A.coin + A.esc_coin) - R_F64(c, o_tax_last_coin)[i];
     const double due = tax_due(c, income);
@@ -866,6 +875,25 @@ __device__ __forceinline__ void tax_enact(const Ctx& c, Agents& A) {
     R_F64(c, o_tax_last_marginal_rate)[i] = tax_marginal_rate(c, income);
     R_F64(c, o_tax_last_income)[i] = income;
     A.coin -= eff;
+    eff_rate = eff / (income > 0.000001 ? income : 0.000001);  // :880
+    if (c.met) {  // episode accumulators for get_metrics :1141-1186 (no-return atomics)
+      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_income) + i, income > 0 ? income : 0.0);
+      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_paid) + i, eff);
+      int bin = 0;  // income_bin :828-835
+      if (income >= 0)
+        for (int b = 0; b < c.P.NB; ++b)
+          if (income >= c.P.c.tax_bracket_cutoffs[b] && (b + 1 == c.P.NB || income < c.P.c.tax_bracket_cutoffs[b + 1])) { bin = b; break; }
+      atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_occ) + bin, 1);
+    }
+  }
+  if (c.met) {
+    if (i < c.P.NB) unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_sched) + i, tax_rate(c, i));
+    double day = 0;
+    for (int j = 0; j < n; ++j) day += bcast(eff_rate, j);
+    if (i == 0) {
+      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_eff), day);
+      atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_days), 1);
+    }
   }
   double net = 0;
   for (int j = 0; j < n; ++j) net += bcast(eff, j);
@@ -1448,36 +1476,14 @@ __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __rest
   // ---- masks: _generate_masks base_env.py:706-756 + flatten_masks base_agent.py:440-460,
   // planner PeriodicBracketTax.generate_masks redistribution.py:1025-1104 ----
   if (!(skip & 512)) {
-    const bool multi = P.c.multi_action_mode_agents != 0;
-    // Element m of the flattened mask means the same thing for every agent: classify it
-    // once per lane (wave-uniform walk over the registered subspaces), then evaluate it
-    // against each agent's mask bits.
-    for (int m0 = 0; m0 < P.MA; m0 += AIE_NT) {
-      const int m = m0 + tid;
-      const int mm = m - (multi ? 0 : 1);  // skip the leading NO-OP entry
-      int kind = -1, loc = 0;              // -1: constant 1 (a NO-OP entry)
-      int base = 0;
-      for (int sub = 0; sub < P.n_sub_a; ++sub) {
-        const int len = P.sub_a_dim[sub] + (multi ? 1 : 0);
-        const int l = mm - base - (multi ? 1 : 0);
-        if (mm >= base && mm < base + len && l >= 0) {
-          kind = P.sub_a_slot[sub];
-          loc = l;
-        }
-        base += len;
-      }
-      if (m < P.MA) {
-        for (int i = 0; i < n; ++i) {
-          const uint32_t mf = (uint32_t)c.mflags[i];
-          bool ok = true;
-          if (kind == AIE_SUB_BUILD) ok = mf & 1u;
-          else if (kind == AIE_SUB_GATHER) ok = (mf >> (1 + loc)) & 1u;
-          else if (kind == AIE_SUB_SELL0) ok = (mf >> 5) & 1u;
-          else if (kind == AIE_SUB_SELL1) ok = (mf >> 6) & 1u;
-          else if (kind == AIE_SUB_BUY0) ok = (uint32_t)loc < ((mf >> 8) & 0xffu);
-          else if (kind == AIE_SUB_BUY1) ok = (uint32_t)loc < ((mf >> 16) & 0xffu);
-          s_amask[i * P.MA + m] = ok ? 1.0f : 0.0f;
-        }
+    // Element m of the flattened mask means the same thing for every agent: one host-built
+    // (shift, mask, threshold) test against each agent's mask bits.
+    for (int m = tid; m < P.MA; m += AIE_NT) {
+      const uint32_t t = P.mask_test[m];  // host-built test for element m (aie_layout.h)
+      const uint32_t sh = t & 31u, msk = (t >> 8) & 0xffu, thr = t >> 16;
+      for (int i = 0; i < n; ++i) {
+        const uint32_t mf = (uint32_t)c.mflags[i];
+        s_amask[i * P.MA + m] = ((mf >> sh) & msk) >= thr ? 1.0f : 0.0f;
       }
     }
     const bool pmulti = P.c.multi_action_mode_planner != 0;
@@ -1541,7 +1547,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   // struct by value made the compiler copy it to scratch on every launch (5x slower).
   const aie_params& P = *params;
   const int wid = NW == 1 ? 0 : uni((int)(threadIdx.x >> 6));
-  const Ctx c = make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)(threadIdx.x & (AIE_NT - 1)));
+  const Ctx c = make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)(threadIdx.x & (AIE_NT - 1)), arena);
   MT m;
   Agents A;
   const int skip = P.dev_skip_mask;
@@ -1624,8 +1630,9 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   const aie_params& P = *params;
   const int e = replica_of_block((int)blockIdx.x, P.E);
   if (mask && !mask[e]) return;
-  const Ctx c = make_ctx(P, lds, e, (int)threadIdx.x);
+  const Ctx c = make_ctx(P, lds, e, (int)threadIdx.x, arena);
   const int n = P.n, HW = P.HW, tid = c.tid;
+  for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
   MT m;
   if (tid == 0) *c.srcn = 0;
   __syncthreads();

@@ -45,7 +45,7 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, i
   q += (4 * P.n + 2) * 8;
   s.tmpl_a = reinterpret_cast<float*>(q);
   s.tmpl_p = s.tmpl_a + pad4(P.FA);
-  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tid, e};
+  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tid, e};
 }
 
 __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {

@@ -29,6 +29,7 @@
 #include "aie.h"
 
 #define AIE_MAX_TENSORS 128
+#define AIE_MAX_MASK 544   /* entries of one agent's flattened action mask (4 x 127 prices + ...) */
 
 /* internal action-subspace slots of a mobile agent */
 enum {
@@ -103,6 +104,20 @@ typedef struct aie_params {
 
   /* development only: phases of the step kernel to skip when profiling
    * (tools/phase_profile.py); always 0 in normal operation */
+  /* per-replica episode accumulators behind env.metrics (component get_metrics): touched only
+   * when a trade executes / on tax days, so they live outside the streamed record */
+  int64_t a_metrics;
+  int32_t met_bytes;
+  int32_t mo_cda;        /* int32 [2: sell, buy][AIE_N_RES][n][2: n_sales, sum of prices]         */
+  int32_t mo_tax_sched;  /* f64 [NB] sum over tax days of the bracket rates                       */
+  int32_t mo_tax_income; /* f64 [n]  sum over tax days of max(0, income)                          */
+  int32_t mo_tax_paid;   /* f64 [n]  sum over tax days of the tax paid                            */
+  int32_t mo_tax_eff;    /* f64      sum of all effective tax rates (n per tax day)               */
+  int32_t mo_tax_occ;    /* int32 [NB] incomes observed per bracket                               */
+  int32_t mo_tax_days;   /* int32    tax days so far                                              */
+  /* flattened agent action mask, element m: allowed iff ((mask_bits >> sh) & msk) >= thr with
+   * sh = test & 31, msk = (test >> 8) & 0xff, thr = test >> 16 (mask_bits: write_action_masks) */
+  uint32_t mask_test[AIE_MAX_MASK];
   int32_t dev_skip_mask;
   uint64_t* dev_trace;   /* development: 8 clock stamps per workgroup (start, components.., regen, end), or NULL */
 
@@ -630,6 +645,31 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   }
   if (c->multi_action_mode_planner) p->MP = p->n_sub_p ? p->n_sub_p * (1 + p->sub_p_dim) : 1;
   else p->MP = 1 + p->n_sub_p * p->sub_p_dim;
+  if (p->MA > AIE_MAX_MASK) AIE__FAIL("flattened action mask too long (%d > %d)", p->MA, AIE_MAX_MASK);
+  {
+    /* mask bits (kernel): 0 build | 1..4 move L,R,U,D | 5,6 sell Stone,Wood | 8..15, 16..23:
+     * number of affordable bid prices for Stone, Wood */
+    const int multi = c->multi_action_mode_agents ? 1 : 0;
+    int m = 0;
+    if (!multi) p->mask_test[m++] = 0;                                 /* leading NO-OP: always 1 */
+    for (int sub = 0; sub < ns; ++sub) {
+      if (multi) p->mask_test[m++] = 0;                                /* the subspace's NO-OP   */
+      for (int l = 0; l < p->sub_a_dim[sub]; ++l) {
+        uint32_t sh = 0, msk = 1, thr = 1;
+        switch (p->sub_a_slot[sub]) {
+          case AIE_SUB_BUILD: sh = 0; break;
+          case AIE_SUB_GATHER: sh = 1 + (uint32_t)l; break;
+          case AIE_SUB_SELL0: sh = 5; break;
+          case AIE_SUB_SELL1: sh = 6; break;
+          case AIE_SUB_BUY0: sh = 8; msk = 0xff; thr = (uint32_t)l + 1; break;
+          case AIE_SUB_BUY1: sh = 16; msk = 0xff; thr = (uint32_t)l + 1; break;
+          default: msk = 0; thr = 0; break;                            /* unmasked subspace      */
+        }
+        p->mask_test[m++] = sh | (msk << 8) | (thr << 16);
+      }
+    }
+    if (ns == 0 && multi) p->mask_test[m++] = 0;
+  }
 
   /* ---- flat observations: sorted keys ----------------------------------------- */
   {
@@ -729,6 +769,18 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->a_rew_a = a; a = aie__align(a + E * n * 4, 256);
   p->a_rew_p = a; a = aie__align(a + E * 4, 256);
   p->a_done = a;  a = aie__align(a + E, 256);
+  {
+    int32_t m = 0;
+    p->mo_tax_sched = m;  m += 8 * (p->has_tax ? p->NB : 0);
+    p->mo_tax_income = m; m += 8 * (p->has_tax ? n : 0);
+    p->mo_tax_paid = m;   m += 8 * (p->has_tax ? n : 0);
+    p->mo_tax_eff = m;    m += 8;
+    p->mo_cda = m;        m += 4 * (p->has_cda ? 2 * AIE_N_RES * n * 2 : 0);
+    p->mo_tax_occ = m;    m += 4 * (p->has_tax ? p->NB : 0);
+    p->mo_tax_days = m;   m += 4;
+    p->met_bytes = (int32_t)aie__align(m, 16);
+  }
+  p->a_metrics = a; a = aie__align(a + E * (int64_t)p->met_bytes, 256);
   p->arena_bytes = a;
 
   /* ---- tensor table ------------------------------------------------------------ */
@@ -806,6 +858,18 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     DENSE("rewards_a", AIE_F32, p->a_rew_a, 1, n, 0, 0, 0);
     DENSE("rewards_p", AIE_F32, p->a_rew_p, 0, 0, 0, 0, 0);
     DENSE("done", AIE_U8, p->a_done, 0, 0, 0, 0, 0);
+    {
+      const int64_t ms = p->met_bytes, m0 = p->a_metrics;
+      if (p->has_cda) aie__add(tt, "metrics_cda_trades", AIE_I32, m0 + p->mo_cda, ms, 4, 2, AIE_N_RES, n, 2, E);
+      if (p->has_tax) {
+        aie__add(tt, "metrics_tax_schedule_sum", AIE_F64, m0 + p->mo_tax_sched, ms, 1, p->NB, 0, 0, 0, E);
+        aie__add(tt, "metrics_tax_income_sum", AIE_F64, m0 + p->mo_tax_income, ms, 1, n, 0, 0, 0, E);
+        aie__add(tt, "metrics_tax_paid_sum", AIE_F64, m0 + p->mo_tax_paid, ms, 1, n, 0, 0, 0, E);
+        aie__add(tt, "metrics_tax_effective_rate_sum", AIE_F64, m0 + p->mo_tax_eff, ms, 0, 0, 0, 0, 0, E);
+        aie__add(tt, "metrics_tax_bracket_occupancy", AIE_I32, m0 + p->mo_tax_occ, ms, 1, p->NB, 0, 0, 0, E);
+        aie__add(tt, "metrics_tax_days", AIE_I32, m0 + p->mo_tax_days, ms, 0, 0, 0, 0, 0, E);
+      }
+    }
 #undef DENSE
   }
   return AIE_OK;

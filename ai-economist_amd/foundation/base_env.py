@@ -255,6 +255,26 @@ class BaseEnvironment:
         info = {"a": {}, "p": {}}
         return self._obs(), rew, done, info
 
+    # ---- metrics (base_env.py:420-432) ----
+    def scenario_metrics(self, tensors):
+        """{metric key: ndarray [E]} from host copies of the state tensors; None if the
+        scenario reports nothing (reference: BaseEnvironment.scenario_metrics)."""
+        return None
+
+    @property
+    def metrics(self):
+        """The combined scenario + component metrics, every value an array over the E replicas
+        (the reference returns one scalar per key for its single env)."""
+        from . import metrics as _metrics
+
+        t = {k: v.cpu().numpy() for k, v in self.backend.tensors.items()
+             if not k.startswith("obs_") and not k.startswith("model_") and k not in ("mt", "cells")}
+        return _metrics.env_metrics(self, t)
+
+    def metrics_of(self, e):
+        """The reference-shaped metrics dict (scalars) of replica e."""
+        return {k: v[e].item() for k, v in self.metrics.items()}
+
     def as_reference_dicts(self, e):
         """Rebuilds the reference's per-replica observation dict
         ({"0": {...}, ..., "p": {..., "p0": ...}}) for replica e as NumPy arrays."""

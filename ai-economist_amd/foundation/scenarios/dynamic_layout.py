@@ -139,6 +139,11 @@ class Uniform(LayoutFromFile):
         z = np.zeros([self.n_envs] + list(self.world_size), np.uint8)
         return (z, z, z)
 
+    def scenario_metrics(self, tensors):
+        from .. import metrics
+
+        return metrics.gtb_scenario_metrics(self, tensors)
+
     def fill_scenario_config(self, cfg):
         super().fill_scenario_config(cfg)
         cfg.has_water = 0

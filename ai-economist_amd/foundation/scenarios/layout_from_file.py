@@ -128,6 +128,11 @@ class LayoutFromFile(BaseEnvironment):
     def layout_planes(self):
         return (self._source_maps["Stone"], self._source_maps["Wood"], self._source_maps["Water"])
 
+    def scenario_metrics(self, tensors):
+        from .. import metrics
+
+        return metrics.gtb_scenario_metrics(self, tensors)
+
     def fill_scenario_config(self, cfg):
         cfg.has_water = 1
         cfg.shared_layout = 1

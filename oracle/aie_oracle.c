@@ -34,6 +34,7 @@ typedef struct {
   int act_wide[AIE_MAX_AGENTS_WIDE]; /* one-step-economy: SimpleLabor action per agent */
 } ctx_t;
 
+#define MET(c) ((c)->arena + (c)->p->a_metrics + (int64_t)(c)->e * (c)->p->met_bytes)
 #define F64(c, off) ((double*)((c)->rec + (c)->p->off))
 #define I32(c, off) ((int32_t*)((c)->rec + (c)->p->off))
 #define U8(c, off) ((uint8_t*)((c)->rec + (c)->p->off))
@@ -360,6 +361,13 @@ static void cda_match(ctx_t* c) {
           I32(c, o_cda_n_orders)[r * p->n + seller] -= 1;
           I32(c, o_cda_n_orders)[r * p->n + buyer] -= 1;
           F64(c, o_cda_price_history)[(r * p->n + seller) * p->P + price] += 1.0;
+          { /* executed_trades -> get_metrics :585-641: per (side, commodity, agent): n_sales, sum of prices */
+            int32_t* tm = (int32_t*)(MET(c) + p->mo_cda);
+            int32_t* sell = tm + ((0 * AIE_N_RES + r) * p->n + seller) * 2;
+            int32_t* buy = tm + ((1 * AIE_N_RES + r) * p->n + buyer) * 2;
+            sell[0] += 1; sell[1] += price;
+            buy[0] += 1; buy[1] += price;
+          }
           I32(c, o_esc_res)[r * p->n + seller] -= 1;
           I32(c, o_inv_res)[r * p->n + buyer] += 1;
           F64(c, o_esc_coin)[buyer] -= (double)bprice;
@@ -466,7 +474,7 @@ static double tax_due(ctx_t* c, double income) {
 /* enact_taxes :853-915 */
 static void tax_enact(ctx_t* c) {
   const aie_params* p = c->p;
-  double net = 0;
+  double net = 0, day_eff = 0;
   for (int i = 0; i < p->n; ++i) {
     double income = (F64(c, o_inv_coin)[i] + F64(c, o_esc_coin)[i]) - F64(c, o_tax_last_coin)[i];
     double due = tax_due(c, income);
@@ -477,6 +485,21 @@ static void tax_enact(ctx_t* c) {
     net += eff;
     F64(c, o_tax_last_income)[i] = income;
     F64(c, o_tax_last_marginal_rate)[i] = mr;
+    if (!p->met_bytes) continue; /* (one-step-economy: no accumulators yet) */
+    /* bookkeeping for get_metrics :1141-1186 (redistribution.py:878-895) */
+    day_eff += eff / (income > 0.000001 ? income : 0.000001);
+    ((double*)(MET(c) + p->mo_tax_income))[i] += income > 0 ? income : 0.0;
+    ((double*)(MET(c) + p->mo_tax_paid))[i] += eff;
+    int bin = 0; /* income_bin :828-835 */
+    if (income >= 0)
+      for (int b = 0; b < p->NB; ++b)
+        if (income >= p->c.tax_bracket_cutoffs[b] && (b + 1 == p->NB || income < p->c.tax_bracket_cutoffs[b + 1])) { bin = b; break; }
+    ((int32_t*)(MET(c) + p->mo_tax_occ))[bin] += 1;
+  }
+  if (p->met_bytes) {
+    for (int b = 0; b < p->NB; ++b) ((double*)(MET(c) + p->mo_tax_sched))[b] += tax_rate(c, b);
+    *(double*)(MET(c) + p->mo_tax_eff) += day_eff;
+    *(int32_t*)(MET(c) + p->mo_tax_days) += 1;
   }
   *F64(c, o_tax_total_collected) += net;
   double lump = net / p->n;
@@ -927,6 +950,7 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
   make_ctx(&c, p, arena, e);
   const int n = p->n, HW = p->HW;
   *I32(&c, o_timestep) = 0;
+  memset(MET(&c), 0, (size_t)p->met_bytes); /* component resets clear their episode logs */
   for (int cell = 0; cell < HW; ++cell) { /* layout_from_file.py:323-334 */
     unsigned fl = C_FLAGS(&c, cell);
     CELLS(&c)[cell] = AIE_CELL_PACK((fl & AIE_CELL_STONE_SRC) ? 1 : 0, (fl & AIE_CELL_WOOD_SRC) ? 1 : 0, -1, fl);
@@ -1255,6 +1279,7 @@ int aie_oracle_params(const aie_config* cfg, aie_params* out, aie_tensor_table* 
   return aie_build_params(cfg, out, tt, err, (size_t)errlen);
 }
 int aie_oracle_sizeof_params(void) { return (int)sizeof(aie_params); }
+int64_t aie_oracle_arena_bytes(const aie_params* p) { return p->arena_bytes; }
 int aie_oracle_sizeof_table(void) { return (int)sizeof(aie_tensor_table); }
 
 void aie_oracle_step(const aie_params* p, uint8_t* arena, const int32_t* aa, const int32_t* ap, int e0, int e1) {

@@ -78,9 +78,8 @@ class OracleEnv:
         for i in range(self._table.n):
             d = self._table.t[i]
             self.descs[d.name.decode()] = d
-        # arena size = end of the last dense tensor, rounded up like the library does
-        d = self.descs["done"]
-        arena_bytes = (d.arena_offset + self.E + 255) // 256 * 256
+        L.aie_oracle_arena_bytes.restype = C.c_int64
+        arena_bytes = int(L.aie_oracle_arena_bytes(self._params))
         self.arena = np.zeros(arena_bytes, np.uint8)
         self.t = {name: self._view(d) for name, d in self.descs.items()}
         if "house_owner" in self.t:

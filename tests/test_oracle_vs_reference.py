@@ -86,6 +86,26 @@ def _random_actions(env, rng, multi_a, multi_p):
     return acts, arr, pa
 
 
+def check_metrics(ref, host, o, where):
+    """env.metrics: the host-side formulas (ai_economist_amd.foundation.metrics) on the oracle's
+    state + episode accumulators against the reference's scenario + component metrics."""
+    import warnings
+
+    from ai_economist_amd.foundation.metrics import env_metrics
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # np.mean of the reference's still-empty lists
+        want = ref.metrics
+    got = env_metrics(host, dict(o.t))
+    assert sorted(got) == sorted(want), (where, sorted(set(got) ^ set(want)))
+    for k, v in want.items():
+        g = float(got[k][0])
+        if v is None or (isinstance(v, float) and np.isnan(v)) or np.isnan(float(v)):
+            assert np.isnan(g), "%s: metric %s = %r, reference NaN" % (where, k, g)
+        else:
+            np.testing.assert_allclose(g, float(v), rtol=1e-9, atol=1e-12, err_msg="%s: metric %s" % (where, k))
+
+
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
 def test_oracle_tracks_live_reference(variant):
     from oracle_lib import OracleEnv
@@ -118,6 +138,7 @@ def test_oracle_tracks_live_reference(variant):
         if rew is not None:
             got = np.concatenate([o.t["rewards_a"][0], o.t["rewards_p"][[0]]])
             np.testing.assert_allclose(got, rewards_array(ref, rew), rtol=0, atol=1e-5, err_msg=where)
+        check_metrics(ref, host, o, where)
 
     check(variant + " reset", obs)
     for t in range(170):
