@@ -31,7 +31,8 @@ __host__ __device__ inline size_t ose_lds_bytes(const aie_params& P) {
   return (b + 15) / 16 * 16;
 }
 
-__device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, int e, int tid, OseScratch& s) {
+__device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, int e, int tid, OseScratch& s,
+                                             uint8_t* arena) {
   uint8_t* q = lds + rec_lds_bytes(P);
   int32_t* act_p = reinterpret_cast<int32_t*>(q);
   q += AIE_MAX_BRACKETS * 4;
@@ -45,7 +46,8 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, i
   q += (4 * P.n + 2) * 8;
   s.tmpl_a = reinterpret_cast<float*>(q);
   s.tmpl_p = s.tmpl_a + pad4(P.FA);
-  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tid, e};
+  uint8_t* met = arena + P.a_metrics + (int64_t)e * P.met_bytes;
+  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, tid, e};
 }
 
 __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {
@@ -99,10 +101,27 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
       R_F64(c, o_tax_last_income)[i] = income;
       R_F64(c, o_inv_coin)[i] = coin - eff;
       s.tmp[i] = eff;
+      // episode accumulators for get_metrics :1141-1186 (no-return atomics)
+      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_income) + i, income > 0 ? income : 0.0);
+      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_paid) + i, eff);
+      int bin = 0;  // income_bin :828-835
+      if (income >= 0)
+        for (int b = 0; b < c.P.NB; ++b)
+          if (income >= c.P.c.tax_bracket_cutoffs[b] && (b + 1 == c.P.NB || income < c.P.c.tax_bracket_cutoffs[b + 1])) { bin = b; break; }
+      atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_occ) + bin, 1);
     }
+    if (c.tid < c.P.NB) unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_sched) + c.tid, tax_rate(c, c.tid));
     __syncthreads();
-    double net = 0;  // running sum in agent order, as the reference accumulates it
-    for (int j = 0; j < n; ++j) net += s.tmp[j];
+    double net = 0, day = 0;  // running sums in agent order, as the reference accumulates them
+    for (int j = 0; j < n; ++j) {
+      net += s.tmp[j];
+      const double inc = R_F64(c, o_tax_last_income)[j];
+      day += s.tmp[j] / (inc > 0.000001 ? inc : 0.000001);
+    }
+    if (c.tid == 0) {
+      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_eff), day);
+      atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_days), 1);
+    }
     const double lump = net / (double)n;
     for (int i = c.tid; i < n; i += AIE_NT) {
       const double v = R_F64(c, o_inv_coin)[i] + lump;
@@ -317,7 +336,7 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   using namespace aie;
   const aie_params& P = *params;
   OseScratch s;
-  const Ctx c = ose_make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)threadIdx.x, s);
+  const Ctx c = ose_make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)threadIdx.x, s, arena);
   const int n = P.n, tid = c.tid;
   MT m;
   ose_load_record(c, arena, m);
@@ -386,8 +405,9 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   const int e = replica_of_block((int)blockIdx.x, P.E);
   if (mask && !mask[e]) return;
   OseScratch s;
-  const Ctx c = ose_make_ctx(P, lds, e, (int)threadIdx.x, s);
+  const Ctx c = ose_make_ctx(P, lds, e, (int)threadIdx.x, s, arena);
   const int n = P.n, tid = c.tid;
+  for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
   MT m;
   ose_load_record(c, arena, m);
   __syncthreads();

@@ -373,6 +373,35 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   return AIE_OK;
 }
 
+/* per-replica episode accumulators (see aie_params.a_metrics): allocation + tensor views */
+static inline void aie__alloc_metrics(aie_params* p, int64_t* a) {
+  const int n = p->n;
+  int32_t m = 0;
+  p->mo_tax_sched = m;  m += 8 * (p->has_tax ? p->NB : 0);
+  p->mo_tax_income = m; m += 8 * (p->has_tax ? n : 0);
+  p->mo_tax_paid = m;   m += 8 * (p->has_tax ? n : 0);
+  p->mo_tax_eff = m;    m += 8;
+  p->mo_cda = m;        m += 4 * (p->has_cda ? 2 * AIE_N_RES * n * 2 : 0);
+  p->mo_tax_occ = m;    m += 4 * (p->has_tax ? p->NB : 0);
+  p->mo_tax_days = m;   m += 4;
+  p->met_bytes = (int32_t)aie__align(m, 16);
+  p->a_metrics = *a;
+  *a = aie__align(*a + (int64_t)p->E * p->met_bytes, 256);
+}
+static inline void aie__add_metrics_tensors(const aie_params* p, aie_tensor_table* tt) {
+  const int64_t ms = p->met_bytes, m0 = p->a_metrics, E = p->E;
+  const int n = p->n;
+  if (p->has_cda) aie__add(tt, "metrics_cda_trades", AIE_I32, m0 + p->mo_cda, ms, 4, 2, AIE_N_RES, n, 2, E);
+  if (p->has_tax) {
+    aie__add(tt, "metrics_tax_schedule_sum", AIE_F64, m0 + p->mo_tax_sched, ms, 1, p->NB, 0, 0, 0, E);
+    aie__add(tt, "metrics_tax_income_sum", AIE_F64, m0 + p->mo_tax_income, ms, 1, n, 0, 0, 0, E);
+    aie__add(tt, "metrics_tax_paid_sum", AIE_F64, m0 + p->mo_tax_paid, ms, 1, n, 0, 0, 0, E);
+    aie__add(tt, "metrics_tax_effective_rate_sum", AIE_F64, m0 + p->mo_tax_eff, ms, 0, 0, 0, 0, 0, E);
+    aie__add(tt, "metrics_tax_bracket_occupancy", AIE_I32, m0 + p->mo_tax_occ, ms, 1, p->NB, 0, 0, 0, E);
+    aie__add(tt, "metrics_tax_days", AIE_I32, m0 + p->mo_tax_days, ms, 0, 0, 0, 0, 0, E);
+  }
+}
+
 /* one-step-economy (F/scenarios/one_step_economy/one_step_economy.py): no map, agents
  * hold coin / labor / skill / production; flat observations in sorted-key order:
  *   agent   PeriodicBracketTax-{curr_rates,is_first_day,is_tax_day,last_incomes,
@@ -437,10 +466,12 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
   p->a_rew_a = a; a = aie__align(a + E * n * 4, 256);
   p->a_rew_p = a; a = aie__align(a + E * 4, 256);
   p->a_done = a;  a = aie__align(a + E, 256);
+  aie__alloc_metrics(p, &a);
   p->arena_bytes = a;
 
   if (tt) {
     const int64_t rs = p->rec_bytes, r0 = p->a_records;
+    aie__add_metrics_tensors(p, tt);
 #define REC(name, dt, off, nd, d0) aie__add(tt, name, dt, r0 + (off), rs, nd, d0, 0, 0, 0, E)
     REC("inv_coin", AIE_F64, p->o_inv_coin, 1, n);
     REC("esc_coin", AIE_F64, p->o_esc_coin, 1, n);
@@ -769,18 +800,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->a_rew_a = a; a = aie__align(a + E * n * 4, 256);
   p->a_rew_p = a; a = aie__align(a + E * 4, 256);
   p->a_done = a;  a = aie__align(a + E, 256);
-  {
-    int32_t m = 0;
-    p->mo_tax_sched = m;  m += 8 * (p->has_tax ? p->NB : 0);
-    p->mo_tax_income = m; m += 8 * (p->has_tax ? n : 0);
-    p->mo_tax_paid = m;   m += 8 * (p->has_tax ? n : 0);
-    p->mo_tax_eff = m;    m += 8;
-    p->mo_cda = m;        m += 4 * (p->has_cda ? 2 * AIE_N_RES * n * 2 : 0);
-    p->mo_tax_occ = m;    m += 4 * (p->has_tax ? p->NB : 0);
-    p->mo_tax_days = m;   m += 4;
-    p->met_bytes = (int32_t)aie__align(m, 16);
-  }
-  p->a_metrics = a; a = aie__align(a + E * (int64_t)p->met_bytes, 256);
+  aie__alloc_metrics(p, &a);
   p->arena_bytes = a;
 
   /* ---- tensor table ------------------------------------------------------------ */
@@ -858,18 +878,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     DENSE("rewards_a", AIE_F32, p->a_rew_a, 1, n, 0, 0, 0);
     DENSE("rewards_p", AIE_F32, p->a_rew_p, 0, 0, 0, 0, 0);
     DENSE("done", AIE_U8, p->a_done, 0, 0, 0, 0, 0);
-    {
-      const int64_t ms = p->met_bytes, m0 = p->a_metrics;
-      if (p->has_cda) aie__add(tt, "metrics_cda_trades", AIE_I32, m0 + p->mo_cda, ms, 4, 2, AIE_N_RES, n, 2, E);
-      if (p->has_tax) {
-        aie__add(tt, "metrics_tax_schedule_sum", AIE_F64, m0 + p->mo_tax_sched, ms, 1, p->NB, 0, 0, 0, E);
-        aie__add(tt, "metrics_tax_income_sum", AIE_F64, m0 + p->mo_tax_income, ms, 1, n, 0, 0, 0, E);
-        aie__add(tt, "metrics_tax_paid_sum", AIE_F64, m0 + p->mo_tax_paid, ms, 1, n, 0, 0, 0, E);
-        aie__add(tt, "metrics_tax_effective_rate_sum", AIE_F64, m0 + p->mo_tax_eff, ms, 0, 0, 0, 0, 0, E);
-        aie__add(tt, "metrics_tax_bracket_occupancy", AIE_I32, m0 + p->mo_tax_occ, ms, 1, p->NB, 0, 0, 0, E);
-        aie__add(tt, "metrics_tax_days", AIE_I32, m0 + p->mo_tax_days, ms, 0, 0, 0, 0, 0, E);
-      }
-    }
+    aie__add_metrics_tensors(p, tt);
 #undef DENSE
   }
   return AIE_OK;

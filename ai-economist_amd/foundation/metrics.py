@@ -82,6 +82,25 @@ def gtb_scenario_metrics(env, t):
     return m
 
 
+# ---- one-step-economy scenario_metrics: one_step_economy.py:207-277 ----
+def ose_scenario_metrics(env, t):
+    n = env.n_agents
+    coin = t["inv_coin"] + t["esc_coin"]
+    util = t["util"]
+    m = {}
+    m["social/productivity"] = get_productivity(coin)
+    m["social/equality"] = get_equality(coin)
+    m["social_welfare/coin_eq_times_productivity"] = coin_eq_times_productivity(coin, 1.0)
+    # (the reference weights by pre-tax income here, :239-243)
+    m["social_welfare/inv_income_weighted_utility"] = inv_income_weighted_utility(t["production"], util[:, :n])
+    m["endow/avg_agent/Coin"] = np.mean(coin, axis=1)
+    m["endogenous/avg_agent/Labor"] = np.mean(t["labor"], axis=1)
+    m["util/avg_agent"] = np.mean(util[:, :n], axis=1)
+    m["endow/p/Coin"] = np.zeros(coin.shape[0])
+    m["util/p"] = util[:, n]
+    return m
+
+
 # ---- component get_metrics ----
 def build_metrics(comp, env, t):  # build.py:198-222
     owner = t["house_owner"].reshape(t["house_owner"].shape[0], -1)

@@ -38,6 +38,11 @@ class OneStepEconomy(BaseEnvironment):
         z = np.zeros(self.world_size, np.uint8)
         return (z, z, z)
 
+    def scenario_metrics(self, tensors):
+        from .. import metrics
+
+        return metrics.ose_scenario_metrics(self, tensors)
+
     def fill_scenario_config(self, cfg):
         cfg.scenario = _cabi.SCN_ONE_STEP_ECONOMY
         cfg.shared_layout = 1

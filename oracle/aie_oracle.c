@@ -485,7 +485,6 @@ static void tax_enact(ctx_t* c) {
     net += eff;
     F64(c, o_tax_last_income)[i] = income;
     F64(c, o_tax_last_marginal_rate)[i] = mr;
-    if (!p->met_bytes) continue; /* (one-step-economy: no accumulators yet) */
     /* bookkeeping for get_metrics :1141-1186 (redistribution.py:878-895) */
     day_eff += eff / (income > 0.000001 ? income : 0.000001);
     ((double*)(MET(c) + p->mo_tax_income))[i] += income > 0 ? income : 0.0;
@@ -496,11 +495,9 @@ static void tax_enact(ctx_t* c) {
         if (income >= p->c.tax_bracket_cutoffs[b] && (b + 1 == p->NB || income < p->c.tax_bracket_cutoffs[b + 1])) { bin = b; break; }
     ((int32_t*)(MET(c) + p->mo_tax_occ))[bin] += 1;
   }
-  if (p->met_bytes) {
-    for (int b = 0; b < p->NB; ++b) ((double*)(MET(c) + p->mo_tax_sched))[b] += tax_rate(c, b);
-    *(double*)(MET(c) + p->mo_tax_eff) += day_eff;
-    *(int32_t*)(MET(c) + p->mo_tax_days) += 1;
-  }
+  for (int b = 0; b < p->NB; ++b) ((double*)(MET(c) + p->mo_tax_sched))[b] += tax_rate(c, b);
+  *(double*)(MET(c) + p->mo_tax_eff) += day_eff;
+  *(int32_t*)(MET(c) + p->mo_tax_days) += 1;
   *F64(c, o_tax_total_collected) += net;
   double lump = net / p->n;
   for (int i = 0; i < p->n; ++i) {
@@ -1252,6 +1249,7 @@ static void ose_reset_one(const aie_params* p, uint8_t* arena, int e) {
   make_ctx(&c, p, arena, e);
   const int n = p->n;
   *I32(&c, o_timestep) = 0;
+  memset(MET(&c), 0, (size_t)p->met_bytes);
   for (int i = 0; i < n; ++i) {
     F64(&c, o_inv_coin)[i] = 0; F64(&c, o_esc_coin)[i] = 0; F64(&c, o_labor)[i] = 0;
     F64(&c, o_skill)[i] = p->has_labor ? p->c.labor_skills[i] : 0;

@@ -197,6 +197,7 @@ def test_oracle_tracks_live_reference_one_step_economy(variant):
         if rew is not None:
             got = np.concatenate([o.t["rewards_a"][0], o.t["rewards_p"][[0]]])
             np.testing.assert_allclose(got, rewards_array(ref, rew), rtol=2e-7, atol=1e-5, err_msg=where)
+        check_metrics(ref, host, o, where)
 
     check(variant + " reset", obs)
     for t in range(9):
