@@ -112,6 +112,9 @@ class AieConfig(C.Structure):
         ("labor_pmsm", C.c_double),
         ("labor_skills", C.c_double * MAX_AGENTS_WIDE),
         ("covid", AieCovidConfig),
+        ("split_water_line", C.c_int32),
+        ("split_top_ranks", C.c_uint32 * 2),
+        ("reserved2_", C.c_int32),
     ]
 
 

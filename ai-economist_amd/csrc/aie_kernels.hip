@@ -1741,6 +1741,31 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
       R_F64(c, o_build_payment)[i] = P.c.avg_ranked_skill[k];
     }
   }
+  if (P.c.split_water_line > 0) {  // SplitLayout.additional_reset_steps layout_from_file.py:759-793
+    for (int i = 0; i < n; ++i) {
+      c.locmap[R_I32(c, o_loc_r)[i] * P.W + R_I32(c, o_loc_c)[i]] = 0;
+      R_I32(c, o_loc_r)[i] = -1;
+      R_I32(c, o_loc_c)[i] = -1;
+    }
+    const int perm = rng_permutation(m, tid, n);
+    const int wl = P.c.split_water_line;
+    for (int k = 0; k < n; ++k) {
+      const int i = bcast(perm, k);
+      R_F64(c, o_build_payment)[i] = P.c.avg_ranked_skill[k];
+      const bool top = (P.c.split_top_ranks[k >> 5] >> (k & 31)) & 1u;
+      const int r_min = top ? 0 : wl + 1, r_max = top ? wl : P.H;
+      int r = r_min + (int)rng_interval(m, tid, (uint32_t)(r_max - r_min - 1));
+      int col = (int)rng_interval(m, tid, (uint32_t)(P.W - 1)), tries = 0;
+      while (!can_agent_occupy(c, r, col, i)) {
+        r = r_min + (int)rng_interval(m, tid, (uint32_t)(r_max - r_min - 1));
+        col = (int)rng_interval(m, tid, (uint32_t)(P.W - 1));
+        if (++tries > 200) break;  // the reference raises TimeoutError
+      }
+      R_I32(c, o_loc_r)[i] = r;
+      R_I32(c, o_loc_c)[i] = col;
+      c.locmap[r * P.W + col] = (uint8_t)(i + 1);
+    }
+  }
   *R_I32(c, o_mt_pos) = m.pos;
   __syncthreads();
   current_metrics(c);

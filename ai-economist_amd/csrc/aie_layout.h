@@ -606,6 +606,13 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     if (!(c->move_labor >= 0.0) || !(c->collect_labor >= 0.0)) AIE__FAIL("Gather labor must be >= 0");
     if (c->gather_skill_dist < 0 || c->gather_skill_dist > 2) AIE__FAIL("Gather.skill_dist invalid");
   }
+  if (c->split_water_line) {
+    if (c->scenario != AIE_SCN_GTB) AIE__FAIL("split_water_line only applies to the gather-trade-build scenarios");
+    if (c->split_water_line <= 0 || c->split_water_line >= c->world_h - 1) AIE__FAIL("water_row out of range (layout_from_file.py:722)");
+    if (c->fixed_four_skill_and_loc) AIE__FAIL("The split layout scenario does not support fixed_four_skill_and_loc (layout_from_file.py:712-716)");
+    if (!(p->has_build && c->build_skill_dist == AIE_SKILL_PARETO)) AIE__FAIL("split layout requires Build with skill_dist='pareto' (layout_from_file.py:748)");
+    if (!c->has_water) AIE__FAIL("split layout needs the Water landmark");
+  }
   if (c->fixed_four_skill_and_loc && !(p->has_build && c->build_skill_dist == AIE_SKILL_PARETO))
     AIE__FAIL("fixed_four_skill_and_loc requires Build with skill_dist='pareto' (layout_from_file.py:177-178)");
   if (p->has_cda) {

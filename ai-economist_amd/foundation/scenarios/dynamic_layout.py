@@ -135,6 +135,12 @@ class Uniform(LayoutFromFile):
         return ((np.asarray(source_maps["Stone"]) > 0).astype(np.uint8),
                 (np.asarray(source_maps["Wood"]) > 0).astype(np.uint8))
 
+    def generate_layout_flags(self, rs):
+        """The packed static cell flags (1 water | 2 stone source | 4 wood source) of one
+        freshly generated layout; subclasses add water / re-draw their probability maps."""
+        stone, wood = self.generate_layout(rs)
+        return (2 * stone + 4 * wood).astype(np.uint8)
+
     def layout_planes(self):
         z = np.zeros([self.n_envs] + list(self.world_size), np.uint8)
         return (z, z, z)
@@ -176,8 +182,7 @@ class Uniform(LayoutFromFile):
         rs = np.random.RandomState()
         for k in range(len(which)):
             rs.set_state(("MT19937", keys[k], int(pos[k]), int(hasg[k]), float(gauss[k])))
-            stone, wood = self.generate_layout(rs)
-            flags[k] = 2 * stone + 4 * wood
+            flags[k] = self.generate_layout_flags(rs)
             st = rs.get_state()
             keys[k], pos[k], hasg[k], gauss[k] = st[1], st[2], st[3], st[4]
         t["cell_flags"][idx] = torch.as_tensor(flags, device=be.device)
@@ -185,3 +190,101 @@ class Uniform(LayoutFromFile):
         t["mt_pos"][idx] = torch.as_tensor(pos, device=be.device)
         t["mt_has_gauss"][idx] = torch.as_tensor(hasg, device=be.device)
         t["mt_gauss"][idx] = torch.as_tensor(gauss, device=be.device)
+
+
+@scenario_registry.add
+class MultiZone(Uniform):
+    """`multi_zone/simple_wood_and_stone` (dynamic_layout.py:705-873): the world is cut into
+    num_partitions_row x num_partitions_col regions; a random subset of them are wood, stone
+    or mixed zones, re-drawn (np.random.shuffle) at every reset."""
+    name = "multi_zone/simple_wood_and_stone"
+
+    def __init__(self, *args, num_partitions_row=8, num_partitions_col=8, num_wood_zones=6,
+                 num_stone_zones=6, num_wood_and_stone_zones=4, **kwargs):
+        self.num_partitions_row = num_partitions_row
+        self.num_partitions_col = num_partitions_col
+        self.zone_specs = {"Wood": (0, num_wood_zones), "Stone": (1, num_stone_zones),
+                           "WoodStone": (2, num_wood_and_stone_zones)}
+        super().__init__(*args, **kwargs)
+
+    def make_source_prob_maps(self, rs=None):
+        """dynamic_layout.py:778-864.  `rs`: the replica's stream at reset time; at construction
+        the reference shuffles with the global NumPy stream, and so does this."""
+        shuffle = np.random.shuffle if rs is None else rs.shuffle
+        zone_names = list(self.zone_specs.keys())
+        zone_indices = [v[0] for _, v in self.zone_specs.items()]
+        num_zones_per_type = [self.zone_specs[k][1] for k in zone_names]
+        num_zones = sum(num_zones_per_type)
+        npr, npc = self.num_partitions_row, self.num_partitions_col
+        num_regions = npr * npc
+        assert num_regions >= num_zones
+        size_r = int(np.ceil(self.world_size[0] / npr))
+        size_c = int(np.ceil(self.world_size[1] / npc))
+        grid = np.concatenate([np.repeat(zone_indices, num_zones_per_type),
+                               np.array([-1] * (num_regions - num_zones))])
+        shuffle(grid)
+        grid = grid.reshape((npr, npc))
+        out = {}
+        for res in ("Wood", "Stone"):
+            prob = np.where(np.logical_or(np.equal(grid, self.zone_specs[res][0]),
+                                          np.equal(grid, self.zone_specs["WoodStone"][0])),
+                            np.ones_like(grid), np.zeros_like(grid))
+            prob = np.kron(prob, np.ones((size_r, size_c)))
+            prob = prob[: self.world_size[0], : self.world_size[1]]
+            prob = prob / np.mean(prob)
+            assert prob.shape[0] == self.world_size[0] and prob.shape[1] == self.world_size[1]
+            # (the reference scales both maps by WOOD's coverage, :860-863)
+            out[res] = prob * self.layout_specs["Wood"]["starting_coverage"]
+        return out
+
+    def generate_layout_flags(self, rs):
+        self.source_prob_maps = self.make_source_prob_maps(rs)  # reset_starting_layout :866-872
+        return super().generate_layout_flags(rs)
+
+
+@scenario_registry.add
+class Quadrant(Uniform):
+    """`quadrant/simple_wood_and_stone` (dynamic_layout.py:875-1024): a cross of water with
+    openings splits the map into four quadrants; wood is likelier towards one corner, stone
+    towards another."""
+    name = "quadrant/simple_wood_and_stone"
+    required_entities = Uniform.required_entities + ["Water"]
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        height, width = self.world_size
+        o0, o1 = 0.2, 0.35
+        rN = (0.5 + np.arange(height)) / height
+        cN = (0.5 + np.arange(width)) / width
+        rSeg = ((rN < o0) + (rN > o1)) * ((rN < 1 - o1) + (rN > 1 - o0))
+        cSeg = ((cN < o0) + (cN > o1)) * ((cN < 1 - o1) + (cN > 1 - o0))
+        water = np.zeros((height, width))
+        water[:, height // 2] = rSeg  # (the reference swaps height/width here; square maps only)
+        water[width // 2, :] = cSeg
+        self._water = water
+        for k, v in self.source_prob_maps.items():
+            v = v * (1 - self._water)
+            self.source_prob_maps[k] = v / np.sum(v)
+
+    def make_source_prob_maps(self):  # :960-990
+        height, width = self.world_size
+        g = np.arange(height)[:, None].repeat(width, axis=1) ** (self.gradient_steepness / 2)
+        w_grad = g[::-1]
+        g = np.arange(width)[None].repeat(height, axis=0) ** (self.gradient_steepness / 2)
+        s_grad = g[:, ::-1]
+        prob_sum = s_grad + w_grad
+        s_grad = prob_sum * s_grad
+        w_grad = prob_sum * w_grad
+        return {"Stone": s_grad / np.sum(s_grad), "Wood": w_grad / np.sum(w_grad)}
+
+    def generate_layout_flags(self, rs):  # reset_starting_layout :992-1024
+        stone, wood = self.generate_layout(rs)
+        height, width = self.world_size
+        for plane in (stone, wood):  # nothing on the water lines, openings included
+            plane[:, height // 2] = 0
+            plane[width // 2, :] = 0
+        return ((self._water > 0) * 1 + 2 * stone + 4 * wood).astype(np.uint8)
+
+    def fill_scenario_config(self, cfg):
+        super().fill_scenario_config(cfg)
+        cfg.has_water = 1

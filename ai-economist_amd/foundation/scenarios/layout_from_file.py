@@ -156,3 +156,52 @@ class LayoutFromFile(BaseEnvironment):
                 cfg.ranked_locs[i][0] = r
                 cfg.ranked_locs[i][1] = c
                 cfg.avg_ranked_skill[i] = float(self._avg_ranked_skill[i])
+
+
+@scenario_registry.add
+class SplitLayout(LayoutFromFile):
+    """`split_layout/simple_wood_and_stone` (layout_from_file.py:653-800): the file layout plus
+    a row of water midway; ranked pareto build skills handed out in a random order at reset;
+    the listed skill ranks start above the water, everybody else below."""
+    name = "split_layout/simple_wood_and_stone"
+
+    def __init__(self, *args, water_row=None, skill_rank_of_top_agents=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.fixed_four_skill_and_loc:
+            raise ValueError("The split layout scenario does not support fixed_four_skill_and_loc. "
+                             "Set this to False.")
+        if water_row is None:
+            self._water_line = self.world_size[0] // 2
+        else:
+            self._water_line = int(water_row)
+            assert 0 < self._water_line < self.world_size[0] - 1
+        for landmark, landmark_map in self._source_maps.items():
+            landmark_map[self._water_line, :] = 1 if landmark == "Water" else 0
+        if skill_rank_of_top_agents is None:
+            skill_rank_of_top_agents = [0]
+        if isinstance(skill_rank_of_top_agents, (int, float)):
+            self.skill_rank_of_top_agents = [int(skill_rank_of_top_agents)]
+        elif isinstance(skill_rank_of_top_agents, (tuple, list)):
+            self.skill_rank_of_top_agents = list(set(skill_rank_of_top_agents))
+        else:
+            raise TypeError("skill_rank_of_top_agents must be a scalar index, or a list of scalar indices.")
+        for rank in self.skill_rank_of_top_agents:
+            assert 0 <= rank < self.n_agents
+        assert 0 < len(self.skill_rank_of_top_agents) < self.n_agents
+        bm = self.get_component("Build")
+        assert bm.skill_dist == "pareto"
+        pmsm = bm.payment_max_skill_multiplier
+        # Like the reference (:750-757) the ranked skills are a Monte-Carlo estimate drawn from
+        # the GLOBAL NumPy stream at construction time (no fixed seed here, unlike
+        # fixed_four_skill_and_loc).  Index 0 = highest skill.
+        pareto_samples = np.random.pareto(4, size=(100000, self.n_agents))
+        clipped = np.minimum(pmsm, (pmsm - 1) * pareto_samples + 1)
+        self._avg_ranked_skill = (np.sort(clipped, axis=1).mean(axis=0) * bm.payment)[::-1]
+
+    def fill_scenario_config(self, cfg):
+        super().fill_scenario_config(cfg)
+        cfg.split_water_line = self._water_line
+        for rank in self.skill_rank_of_top_agents:
+            cfg.split_top_ranks[rank >> 5] |= 1 << (rank & 31)
+        for i in range(self.n_agents):
+            cfg.avg_ranked_skill[i] = float(self._avg_ranked_skill[i])

@@ -203,6 +203,13 @@ typedef struct aie_config {
   double labor_skills[AIE_MAX_AGENTS_WIDE]; /* per-agent skill (sorted Pareto means, :66-74) */
 
   aie_covid_config covid;            /* scenario == AIE_SCN_COVID only                  */
+
+  /* "split_layout/simple_wood_and_stone" (layout_from_file.py:653-800): a water row; at reset the
+   * agents get the ranked build skills (avg_ranked_skill[], highest first) in a random order and
+   * are placed above the water row if their skill rank is listed, else below it. */
+  int32_t split_water_line;          /* 0: not a split layout; else 0 < row < world_h - 1 */
+  uint32_t split_top_ranks[2];       /* bit k: skill rank k starts in the top part        */
+  int32_t reserved2_;
 } aie_config;
 
 /* ---- tensor descriptor ---------------------------------------------------------- */

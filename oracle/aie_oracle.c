@@ -1034,6 +1034,26 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
       F64(&c, o_build_payment)[i] = p->c.avg_ranked_skill[k];
     }
   }
+  if (p->c.split_water_line > 0) { /* SplitLayout.additional_reset_steps layout_from_file.py:759-793 */
+    int order[AIE_MAX_AGENTS];
+    const int wl = p->c.split_water_line;
+    for (int i = 0; i < n; ++i) { I32(&c, o_loc_r)[i] = -1; I32(&c, o_loc_c)[i] = -1; }
+    rng_permutation(&c, n, order);
+    for (int k = 0; k < n; ++k) {
+      int i = order[k];
+      F64(&c, o_build_payment)[i] = p->c.avg_ranked_skill[k];
+      int top = (p->c.split_top_ranks[k >> 5] >> (k & 31)) & 1u;
+      int r_min = top ? 0 : wl + 1, r_max = top ? wl : p->H;
+      int r = r_min + rng_randint(&c, r_max - r_min), col = rng_randint(&c, p->W), tries = 0;
+      while (!can_agent_occupy(&c, r, col, i)) {
+        r = r_min + rng_randint(&c, r_max - r_min);
+        col = rng_randint(&c, p->W);
+        if (++tries > 200) break; /* the reference raises TimeoutError */
+      }
+      I32(&c, o_loc_r)[i] = r;
+      I32(&c, o_loc_c)[i] = col;
+    }
+  }
   current_metrics(&c, F64(&c, o_util));
   write_obs(&c);
   write_masks(&c);

@@ -77,11 +77,13 @@ def run_case(name, cfg, seed, t_steps, obs_steps, action_seed=123, action_kw=Non
     kwargs = dict(cfg)
     scenario = kwargs.pop("scenario_name")
     kwargs["components"] = [tuple(c) for c in kwargs["components"]]
-    np.random.seed(seed + 1000)  # SimpleLabor draws its skills from the global stream at construction
+    out_seed = seed + 1000
+    np.random.seed(out_seed)  # SimpleLabor / SplitLayout draw skills from the global stream at construction
     env = foundation.make_env_instance(scenario, **kwargs)
     np.random.seed(seed)
     st = np.random.get_state()
     out = {"cfg_json": np.array(json.dumps(cfg))}
+    out["construction_seed"] = np.array(out_seed, np.int64)
     out["pre_reset_mt"] = np.array(st[1], np.uint32)
     out["pre_reset_pos"] = np.array(st[2], np.int32)
     obs = env.reset()
@@ -240,6 +242,29 @@ CASES = {
                  energy_warmup_method="auto",
                  env_layout_file="quadrant_25x25_20each_30clump.txt"),
         seed=5, t_steps=150, obs_steps=[0, 1, 100, 101, 150]),
+    # dynamic-layout variants: a water cross with openings / randomly drawn resource zones,
+    # 2 short episodes each => 2 generated layouts (np.random.shuffle / rand / randn draws)
+    "quadrant_dyn15_4ag": dict(
+        cfg=dict(scenario_name="quadrant/simple_wood_and_stone", n_agents=4, world_size=[15, 15],
+                 episode_length=70, components=GTB, starting_agent_coin=10,
+                 starting_stone_coverage=0.10, starting_wood_coverage=0.10),
+        seed=23, t_steps=140, obs_steps=[0, 1, 35, 70, 71, 140]),
+    "split_layout25_5ag": dict(
+        cfg=dict(scenario_name="split_layout/simple_wood_and_stone", n_agents=5, world_size=[25, 25],
+                 episode_length=50,
+                 components=[["Build", {"skill_dist": "pareto", "payment_max_skill_multiplier": 3}],
+                             ["ContinuousDoubleAuction", {"max_num_orders": 5}], ["Gather", {}],
+                             ["PeriodicBracketTax", {"period": 20}]],
+                 starting_agent_coin=10, water_row=11, skill_rank_of_top_agents=[0, 3],
+                 env_layout_file="uniform_25x25_25each_65clump.txt"),
+        seed=31, t_steps=100, obs_steps=[0, 1, 50, 51, 100]),
+    "multizone16_4ag": dict(
+        cfg=dict(scenario_name="multi_zone/simple_wood_and_stone", n_agents=4, world_size=[16, 16],
+                 episode_length=60, components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10,
+                 num_partitions_row=4, num_partitions_col=4, num_wood_zones=3, num_stone_zones=3,
+                 num_wood_and_stone_zones=2, starting_stone_coverage=0.08, starting_wood_coverage=0.08),
+        seed=29, t_steps=120, obs_steps=[0, 1, 60, 61, 120],
+        action_kw=dict(p_move=0.6, p_build=0.3, p_trade=0.0)),
 }
 
 

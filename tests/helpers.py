@@ -40,6 +40,10 @@ def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
         g = {k: z[k] for k in z.files}
     g["cfg"] = json.loads(str(g["cfg_json"]))
+    if "construction_seed" in g:
+        # scenarios that draw from the GLOBAL NumPy stream in their constructor (SplitLayout's
+        # ranked skills): make_env re-seeds the global stream the way the generator did
+        g["cfg"]["_construction_seed"] = int(g["construction_seed"])
     if "s0_skill" in g:
         # SimpleLabor estimates its skills from the GLOBAL NumPy stream at construction
         # (simple_labor.py:66-74); the fixture carries the values the reference drew.
@@ -54,6 +58,9 @@ def make_env(cfg, n_envs=1, **extra):
     from ai_economist_amd import foundation
 
     kw = dict(cfg)
+    cseed = kw.pop("_construction_seed", None)
+    if cseed is not None:
+        np.random.seed(cseed)
     scenario = kw.pop("scenario_name")
     kw["components"] = [tuple(c) for c in kw["components"]]
     kw.update(extra)
@@ -106,8 +113,7 @@ def oracle_host_pre_reset(env, oracle, which=None):
     for e in which:
         rs.set_state(("MT19937", oracle.t["mt"][e].copy(), int(oracle.t["mt_pos"][e]),
                       int(oracle.t["mt_has_gauss"][e]), float(oracle.t["mt_gauss"][e])))
-        stone, wood = env.generate_layout(rs)
-        oracle.t["cell_flags"][e] = 2 * stone + 4 * wood
+        oracle.t["cell_flags"][e] = env.generate_layout_flags(rs)
         st = rs.get_state()
         oracle.t["mt"][e] = st[1]
         oracle.t["mt_pos"][e] = st[2]

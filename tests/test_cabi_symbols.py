@@ -58,7 +58,9 @@ def test_host_registry_and_kwargs_validation():
                                              "FederalGovernmentSubsidy", "Gather", "PeriodicBracketTax",
                                              "SimpleLabor", "VaccinationCampaign"]
     assert foundation.scenarios.entries == ["CovidAndEconomySimulation", "layout_from_file/simple_wood_and_stone",
-                                            "one-step-economy", "uniform/simple_wood_and_stone"]
+                                            "multi_zone/simple_wood_and_stone", "one-step-economy",
+                                            "quadrant/simple_wood_and_stone", "split_layout/simple_wood_and_stone",
+                                            "uniform/simple_wood_and_stone"]
     with pytest.raises(KeyError):
         foundation.make_env_instance("no/such_scenario")
     base = dict(n_agents=4, world_size=[25, 25], components=[("Build", {}), ("Gather", {})])
