@@ -115,6 +115,11 @@ class AieConfig(C.Structure):
         ("split_water_line", C.c_int32),
         ("split_top_ranks", C.c_uint32 * 2),
         ("reserved2_", C.c_int32),
+        ("tax_annealing", C.c_int32),
+        ("reserved3_", C.c_int32),
+        ("tax_annealing_warmup", C.c_double),
+        ("tax_annealing_slope", C.c_double),
+        ("tax_rate_max", C.c_double),
     ]
 
 

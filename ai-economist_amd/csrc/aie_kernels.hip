@@ -819,9 +819,28 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
 // ------------------------------------------------------------------------------------
 // PeriodicBracketTax, F/components/redistribution.py
 // ------------------------------------------------------------------------------------
+// curr_rate_max :390-394: the annealed limit follows _last_completions, which generate_masks
+// refreshes AFTER the observations of a reset are built (:1036-1046) -- kept as a state field.
+__device__ __forceinline__ double tax_curr_rate_max(const Ctx& c) {
+  return aie_annealed_tax_limit(*R_I32(c, o_tax_last_completions), c.P.c.tax_annealing_warmup,
+                                c.P.c.tax_annealing_slope, c.P.c.tax_rate_max);
+}
 __device__ __forceinline__ double tax_rate(const Ctx& c, int b) {  // curr_marginal_rates :396-417
   if (c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER) return c.P.c.tax_disc_rates[R_I32(c, o_tax_rate_idx)[b]];
-  return c.P.c.tax_fixed_rates[b];
+  const double r = c.P.c.tax_fixed_rates[b];
+  if (!c.P.c.tax_annealing) return r;
+  const double cap = tax_curr_rate_max(c);
+  return r < cap ? r : cap;
+}
+// planner tax-rate action j of a bracket: allowed by the annealing schedule? (annealed_tax_mask,
+// utils.py:59-118, evaluated with the completions count of the episode's reset)
+__device__ __forceinline__ bool tax_rate_action_visible(const Ctx& c, int j) {
+  if (!c.P.c.tax_annealing) return true;
+  double full = 0;
+  for (int k = 0; k < c.P.c.tax_n_disc_rates; ++k) full = fmax(full, fabs(c.P.c.tax_disc_rates[k]));
+  const double vis = aie_annealed_tax_limit(*R_I32(c, o_tax_last_completions), c.P.c.tax_annealing_warmup,
+                                            c.P.c.tax_annealing_slope, full);
+  return fabs(c.P.c.tax_disc_rates[j]) <= vis;
 }
 __device__ __forceinline__ double tax_marginal_rate(const Ctx& c, double income) {  // marginal_rate :837-844
   if (income < 0) return 0.0;
@@ -1490,9 +1509,12 @@ __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __rest
     const float open = (P.n_sub_p && *R_I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
     for (int q = tid; q < P.MP; q += AIE_NT) {
       float v;
-      if (P.n_sub_p == 0) v = 1.0f;
-      else if (pmulti) v = (q - udiv(q, 1 + P.sub_p_dim, P.mg_sub_p) * (1 + P.sub_p_dim) == 0) ? 1.0f : open;
-      else v = (q == 0) ? 1.0f : open;
+      int j = -1;  // index of the discretised rate this entry stands for (-1: a NO-OP entry)
+      if (P.n_sub_p == 0) j = -1;
+      else if (pmulti) j = q - udiv(q, 1 + P.sub_p_dim, P.mg_sub_p) * (1 + P.sub_p_dim) - 1;
+      else if (q > 0) j = (q - 1) - udiv(q - 1, P.sub_p_dim, P.mg_sub_p_dim) * P.sub_p_dim;
+      if (j < 0) v = 1.0f;
+      else v = (open != 0.0f && tax_rate_action_visible(c, j)) ? 1.0f : 0.0f;
       s_pmask[q] = v;
     }
   }
@@ -1774,6 +1796,9 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   __syncthreads();
   write_spatial_observations(c, arena);
   write_flat_observations(c, arena);
+  AIE_WSYNC();
+  if (P.has_tax && P.c.tax_annealing && tid == 0) *R_I32(c, o_tax_last_completions) = *R_I32(c, o_completions);  // generate_masks :1036-1046
+  AIE_WSYNC();
   write_action_masks(c, arena);
   if (tid < n) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + tid] = 0.0f;
   if (tid == 0) {

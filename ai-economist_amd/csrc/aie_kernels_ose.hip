@@ -213,7 +213,8 @@ __device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s) {
 
 // Observations + masks (one_step_economy.py:120-176, simple_labor.py:97-103,128-134,
 // redistribution.py:974-1104), flat vectors in sorted-key order (base_env.py:561-612).
-__device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseScratch& s, uint8_t* __restrict__ arena) {
+__device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseScratch& s, uint8_t* __restrict__ arena,
+                                                       bool at_reset = false) {
   const aie_params& P = c.P;
   const int n = P.n, NB = P.NB, tid = c.tid;
   const int t = *R_I32(c, o_timestep);
@@ -299,15 +300,20 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
       g[q] = (mm == 0 || P.n_sub_a == 0) ? 1.0f : on;
       (void)multi;
     }
+    if (at_reset && P.has_tax && P.c.tax_annealing) {  // generate_masks refreshes _last_completions after the reset's observations
+      __syncthreads();
+      if (tid == 0) *R_I32(c, o_tax_last_completions) = *R_I32(c, o_completions);
+      __syncthreads();
+    }
     const bool pmulti = P.c.multi_action_mode_planner != 0;
     const float open = (P.n_sub_p && *R_I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
     float* gp = reinterpret_cast<float*>(arena + P.a_obs_p_mask) + (int64_t)c.e * P.MP;
     for (int q = tid; q < P.MP; q += AIE_NT) {
-      float v;
-      if (P.n_sub_p == 0) v = 1.0f;
-      else if (pmulti) v = (q - udiv(q, 1 + P.sub_p_dim, P.mg_sub_p) * (1 + P.sub_p_dim) == 0) ? 1.0f : open;
-      else v = (q == 0) ? 1.0f : open;
-      gp[q] = v;
+      int j = -1;  // index of the discretised rate this entry stands for (-1: a NO-OP entry)
+      if (P.n_sub_p == 0) j = -1;
+      else if (pmulti) j = q - udiv(q, 1 + P.sub_p_dim, P.mg_sub_p) * (1 + P.sub_p_dim) - 1;
+      else if (q > 0) j = (q - 1) - udiv(q - 1, P.sub_p_dim, P.mg_sub_p_dim) * P.sub_p_dim;
+      gp[q] = (j < 0 || (open != 0.0f && tax_rate_action_visible(c, j))) ? 1.0f : 0.0f;
     }
   }
   __syncthreads();
@@ -432,7 +438,7 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   ose_metrics(c, s);
   for (int i = tid; i <= n; i += AIE_NT) R_F64(c, o_util)[i] = s.part[i];
   __syncthreads();
-  ose_write_observations(c, s, arena);
+  ose_write_observations(c, s, arena, true);
   for (int i = tid; i < n; i += AIE_NT) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + i] = 0.0f;
   if (tid == 0) {
     reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.0f;

@@ -90,6 +90,7 @@ typedef struct aie_params {
   int32_t o_timestep, o_completions, o_auto_warmup;
   int32_t o_skill, o_production, o_first_step; /* one-step-economy / SimpleLabor           */
   int32_t o_mt, o_mt_pos, o_mt_has_gauss, o_mt_gauss;
+  int32_t o_tax_last_completions; /* PeriodicBracketTax._last_completions (tax annealing)     */
 
   /* arena: byte offsets of the dense regions */
   int64_t a_records;
@@ -100,7 +101,7 @@ typedef struct aie_params {
 
   /* exact unsigned division by run-time constants: q / d == __umulhi(q, mg_d) for
    * q < 2^32 / d (d >= 2); see aie__magic() */
-  uint32_t mg_WV2, mg_WV, mg_MA, mg_FA, mg_P, mg_2P, mg_taxA, mg_HW, mg_W, mg_sub_p;
+  uint32_t mg_WV2, mg_WV, mg_MA, mg_FA, mg_P, mg_2P, mg_taxA, mg_HW, mg_W, mg_sub_p, mg_sub_p_dim;
 
   /* development only: phases of the step kernel to skip when profiling
    * (tools/phase_profile.py); always 0 in normal operation */
@@ -441,6 +442,7 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
     p->o_tax_last_marginal_rate = aie__rec(&cur, 8 * n, 8);
     p->o_tax_total_collected = aie__rec(&cur, 8, 8);
     p->o_tax_cycle_pos = aie__rec(&cur, 4, 4);
+    p->o_tax_last_completions = aie__rec(&cur, 4, 4);
     p->o_tax_rate_idx = aie__rec(&cur, 4 * p->NB, 4);
   }
   p->o_timestep = aie__rec(&cur, 4, 4);
@@ -481,6 +483,7 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
     REC("util", AIE_F64, p->o_util, 1, n + 1);
     if (p->has_tax) {
       REC("tax_cycle_pos", AIE_I32, p->o_tax_cycle_pos, 0, 0);
+      REC("tax_last_completions", AIE_I32, p->o_tax_last_completions, 0, 0);
       REC("tax_rate_idx", AIE_I32, p->o_tax_rate_idx, 1, p->NB);
       REC("tax_last_coin", AIE_F64, p->o_tax_last_coin, 1, n);
       REC("tax_last_income", AIE_F64, p->o_tax_last_income, 1, n);
@@ -741,6 +744,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->mg_HW = aie__magic(p->HW);
   p->mg_W = aie__magic(p->W);
   p->mg_sub_p = aie__magic(1 + p->sub_p_dim);
+  p->mg_sub_p_dim = aie__magic(p->sub_p_dim > 0 ? p->sub_p_dim : 1);
 
   if (!gtb) return aie__build_one_step_economy(c, p, tt);
 
@@ -775,6 +779,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     p->o_tax_last_marginal_rate = aie__rec(&cur, 8 * n, 8);
     p->o_tax_total_collected = aie__rec(&cur, 8, 8);
     p->o_tax_cycle_pos = aie__rec(&cur, 4, 4);
+    p->o_tax_last_completions = aie__rec(&cur, 4, 4);
     p->o_tax_rate_idx = aie__rec(&cur, 4 * p->NB, 4);
   }
   p->o_timestep = aie__rec(&cur, 4, 4);
@@ -848,6 +853,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     }
     if (p->has_tax) {
       REC("tax_cycle_pos", AIE_I32, p->o_tax_cycle_pos, 0, 0, 0, 0);
+    REC("tax_last_completions", AIE_I32, p->o_tax_last_completions, 0, 0, 0, 0);
       REC("tax_rate_idx", AIE_I32, p->o_tax_rate_idx, 1, p->NB, 0, 0);
       REC("tax_last_coin", AIE_F64, p->o_tax_last_coin, 1, n, 0, 0);
       REC("tax_last_income", AIE_F64, p->o_tax_last_income, 1, n, 0, 0);
@@ -898,6 +904,14 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
 #else
 #define AIE_HD
 #endif
+/* annealed_tax_limit, F/components/utils.py:10-56 */
+AIE_HD static inline double aie_annealed_tax_limit(int completions, double warmup, double slope, double final_max) {
+  double pv = slope * ((double)completions - warmup);
+  pv = pv < 1.0 ? pv : 1.0;
+  pv = pv > 0.0 ? pv : 0.0;
+  return pv * final_max;
+}
+
 AIE_HD static inline uint32_t aie_counter_rng(uint64_t seed, uint64_t env, uint64_t t, uint64_t slot) {
   uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env + 1ull);
   z ^= (t + 1ull) * 0xBF58476D1CE4E5B9ull;

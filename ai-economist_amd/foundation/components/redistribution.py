@@ -35,8 +35,11 @@ class PeriodicBracketTax(BaseComponent):
         if self.tax_model == "saez":
             raise NotImplementedError(
                 "tax_model='saez' is not implemented by the MI355X backend yet")
-        if tax_annealing_schedule is not None:
-            raise NotImplementedError("tax_annealing_schedule is not implemented yet")
+        self.tax_annealing_schedule = tax_annealing_schedule
+        if tax_annealing_schedule is not None:  # redistribution.py:317-325
+            assert isinstance(self.tax_annealing_schedule, (tuple, list))
+            self._annealing_warmup = self.tax_annealing_schedule[0]
+            self._annealing_slope = self.tax_annealing_schedule[1]
         self.period = int(period)
         assert self.period > 0
         self.rate_min = 0.0 if self.disable_taxes else float(rate_min)
@@ -98,6 +101,11 @@ class PeriodicBracketTax(BaseComponent):
         if self.n_brackets > _cabi.MAX_BRACKETS:
             raise ValueError("n_brackets > {}".format(_cabi.MAX_BRACKETS))
         cfg.tax_disable = int(self.disable_taxes)
+        cfg.tax_rate_max = float(self.rate_max)
+        if self.tax_annealing_schedule is not None:
+            cfg.tax_annealing = 1
+            cfg.tax_annealing_warmup = float(self._annealing_warmup)
+            cfg.tax_annealing_slope = float(self._annealing_slope)
         cfg.tax_model = _cabi.TAX_MODEL[self.tax_model]
         cfg.tax_period = self.period
         cfg.tax_n_brackets = self.n_brackets

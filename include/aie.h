@@ -210,6 +210,13 @@ typedef struct aie_config {
   int32_t split_water_line;          /* 0: not a split layout; else 0 < row < world_h - 1 */
   uint32_t split_top_ranks[2];       /* bit k: skill rank k starts in the top part        */
   int32_t reserved2_;
+
+  /* PeriodicBracketTax tax_annealing_schedule=[warmup, slope] (redistribution.py:311-330,
+   * utils.py:10-118): the highest allowed rate grows with the number of completed episodes */
+  int32_t tax_annealing;             /* 1: schedule given                                 */
+  int32_t reserved3_;
+  double tax_annealing_warmup, tax_annealing_slope;
+  double tax_rate_max;               /* rate_max kwarg (0 when taxes are disabled)        */
 } aie_config;
 
 /* ---- tensor descriptor ---------------------------------------------------------- */

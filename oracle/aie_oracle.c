@@ -440,11 +440,28 @@ static void cda_step(ctx_t* c) {
 /* ------------------------------------------------------------------------------- */
 /* PeriodicBracketTax: F/components/redistribution.py                               */
 /* ------------------------------------------------------------------------------- */
-/* curr_marginal_rates :396-417 */
+/* curr_marginal_rates :396-417 with curr_rate_max :390-394 (tax annealing: the limit follows
+ * _last_completions, refreshed by generate_masks :1036-1046) */
 static double tax_rate(ctx_t* c, int b) {
   const aie_params* p = c->p;
   if (p->c.tax_model == AIE_TAX_MODEL_WRAPPER) return p->c.tax_disc_rates[I32(c, o_tax_rate_idx)[b]];
-  return p->c.tax_fixed_rates[b];
+  double r = p->c.tax_fixed_rates[b];
+  if (p->c.tax_annealing) {
+    double cap = aie_annealed_tax_limit(*I32(c, o_tax_last_completions), p->c.tax_annealing_warmup,
+                                        p->c.tax_annealing_slope, p->c.tax_rate_max);
+    if (cap < r) r = cap;
+  }
+  return r;
+}
+/* annealed_tax_mask utils.py:59-118 for discretised rate k */
+static float tax_rate_action_mask(ctx_t* c, int k) {
+  const aie_params* p = c->p;
+  if (!p->c.tax_annealing) return 1.0f;
+  double full = 0;
+  for (int q = 0; q < p->c.tax_n_disc_rates; ++q) if (fabs(p->c.tax_disc_rates[q]) > full) full = fabs(p->c.tax_disc_rates[q]);
+  double vis = aie_annealed_tax_limit(*I32(c, o_tax_last_completions), p->c.tax_annealing_warmup,
+                                      p->c.tax_annealing_slope, full);
+  return fabs(p->c.tax_disc_rates[k]) <= vis ? 1.0f : 0.0f;
 }
 /* marginal_rate :837-844 */
 static double tax_marginal_rate(ctx_t* c, double income) {
@@ -845,7 +862,7 @@ static void write_masks(ctx_t* c) {
       }
     }
   }
-  /* planner: redistribution.py:1025-1104 (no annealing) */
+  /* planner: redistribution.py:1025-1104 */
   float* pm = (float*)(c->arena + p->a_obs_p_mask) + (int64_t)e * p->MP;
   int o = 0;
   const int pmulti = p->c.multi_action_mode_planner;
@@ -854,7 +871,7 @@ static void write_masks(ctx_t* c) {
     float v = (*I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
     for (int b = 0; b < p->n_sub_p; ++b) {
       if (pmulti) pm[o++] = 1.0f;
-      for (int k = 0; k < p->sub_p_dim; ++k) pm[o++] = v;
+      for (int k = 0; k < p->sub_p_dim; ++k) pm[o++] = v * tax_rate_action_mask(c, k);
     }
   }
 }
@@ -1056,6 +1073,7 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
   }
   current_metrics(&c, F64(&c, o_util));
   write_obs(&c);
+  if (p->has_tax && p->c.tax_annealing) *I32(&c, o_tax_last_completions) = *I32(&c, o_completions); /* generate_masks :1036-1046 */
   write_masks(&c);
   float* ra = (float*)(arena + p->a_rew_a) + (int64_t)e * n;
   for (int i = 0; i < n; ++i) ra[i] = 0;
@@ -1127,7 +1145,7 @@ static void ose_metrics(ctx_t* c, double* out) {
   }
 }
 
-static void ose_write_obs(ctx_t* c) {
+static void ose_write_obs(ctx_t* c, int at_reset) {
   const aie_params* p = c->p;
   const int n = p->n, e = c->e, NB = p->NB;
   const int t = *I32(c, o_timestep);
@@ -1204,6 +1222,7 @@ static void ose_write_obs(ctx_t* c) {
       for (int k = 0; k < p->sub_a_dim[s]; ++k) m[o++] = on;
     }
   }
+  if (at_reset && p->has_tax && p->c.tax_annealing) *I32(c, o_tax_last_completions) = *I32(c, o_completions); /* generate_masks :1036-1046 */
   float* pm = (float*)(c->arena + p->a_obs_p_mask) + (int64_t)e * p->MP;
   int o = 0;
   const int pmulti = p->c.multi_action_mode_planner;
@@ -1212,7 +1231,7 @@ static void ose_write_obs(ctx_t* c) {
     float v = (*I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
     for (int b = 0; b < p->n_sub_p; ++b) {
       if (pmulti) pm[o++] = 1.0f;
-      for (int k = 0; k < p->sub_p_dim; ++k) pm[o++] = v;
+      for (int k = 0; k < p->sub_p_dim; ++k) pm[o++] = v * tax_rate_action_mask(c, k);
     }
   }
 }
@@ -1247,7 +1266,7 @@ static void ose_step_one(const aie_params* p, uint8_t* arena, int e, const int32
     if (p->c.components[k] == AIE_COMP_SIMPLE_LABOR) labor_step(&c);
     else if (p->c.components[k] == AIE_COMP_TAX) tax_step(&c);
   }
-  ose_write_obs(&c);
+  ose_write_obs(&c, 0);
   /* compute_reward one_step_economy.py:195-222 */
   const int n = p->n;
   double cur[AIE_MAX_AGENTS_WIDE + 1];
@@ -1285,7 +1304,7 @@ static void ose_reset_one(const aie_params* p, uint8_t* arena, int e) {
     *F64(&c, o_tax_total_collected) = 0;
   }
   ose_metrics(&c, F64(&c, o_util));
-  ose_write_obs(&c);
+  ose_write_obs(&c, 1);
   float* ra = (float*)(arena + p->a_rew_a) + (int64_t)e * n;
   for (int i = 0; i < n; ++i) ra[i] = 0;
   ((float*)(arena + p->a_rew_p))[e] = 0;

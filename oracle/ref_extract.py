@@ -32,6 +32,7 @@ def extract_state_one_step_economy(env):
     if "PeriodicBracketTax" in comps:
         c = comps["PeriodicBracketTax"]
         s["tax_cycle_pos"] = np.array(c.tax_cycle_pos, np.int32)
+        s["tax_last_completions"] = np.array(c._last_completions, np.int32)
         s["tax_rate_idx"] = np.array(c.curr_rate_indices, np.int32)
         s["tax_last_coin"] = np.array(c.last_coin, np.float64)
         s["tax_last_income"] = np.array(c.last_income, np.float64)
@@ -123,6 +124,7 @@ def extract_state(env):
     if "PeriodicBracketTax" in comps:
         c = comps["PeriodicBracketTax"]
         s["tax_cycle_pos"] = np.array(c.tax_cycle_pos, np.int32)
+        s["tax_last_completions"] = np.array(c._last_completions, np.int32)
         s["tax_rate_idx"] = np.array(c.curr_rate_indices, np.int32)
         s["tax_last_coin"] = np.array(c.last_coin, np.float64)
         s["tax_last_income"] = np.array(c.last_income, np.float64)

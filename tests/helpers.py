@@ -10,7 +10,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 INT_FIELDS = ["stone", "wood", "house_owner", "loc_r", "loc_c", "inv_res", "esc_res",
               "cda_n_bids", "cda_n_asks", "cda_n_orders", "cda_bid_hist", "cda_ask_hist",
-              "tax_cycle_pos", "tax_rate_idx", "timestep", "completions", "auto_warmup", "mt_pos",
+              "tax_cycle_pos", "tax_last_completions", "tax_rate_idx", "timestep", "completions", "auto_warmup", "mt_pos",
               "labor_first_step"]
 F64_FIELDS = ["inv_coin", "esc_coin", "labor", "build_payment", "build_skill",
               "bonus_gather_prob", "util", "cda_price_history", "tax_last_coin",

@@ -29,6 +29,14 @@ VARIANTS = {
     "fixed_bracket_linear": dict(components=GTB[:3] + [["PeriodicBracketTax", {
         "period": 10, "tax_model": "fixed-bracket-rates", "bracket_spacing": "linear", "n_brackets": 4,
         "top_bracket_cutoff": 30, "fixed_bracket_rates": [0.0, 0.1, 0.3, 0.6]}]]),
+    # tax annealing (the paper's phase-2 setting): planner rate actions unmasked as episodes
+    # complete; 80-step episodes => the limit moves twice within the test
+    "annealed_wrapper": dict(components=GTB[:3] + [["PeriodicBracketTax", {
+        "period": 10, "rate_disc": 0.1, "tax_annealing_schedule": [-1, 0.35]}]]),
+    "annealed_wrapper_single_planner": dict(multi_action_mode_planner=False, components=GTB[:3] + [[
+        "PeriodicBracketTax", {"period": 10, "n_brackets": 3, "tax_annealing_schedule": [0, 0.4]}]]),
+    "annealed_us_federal": dict(components=GTB[:3] + [["PeriodicBracketTax", {
+        "period": 10, "tax_model": "us-federal-single-filer-2018-scaled", "tax_annealing_schedule": [-1, 0.3]}]]),
     "taxes_disabled": dict(components=GTB[:3] + [["PeriodicBracketTax", {"period": 10, "disable_taxes": True}]]),
     "log_brackets_wrapper": dict(components=GTB[:3] + [["PeriodicBracketTax", {
         "period": 10, "bracket_spacing": "log", "n_brackets": 5, "top_bracket_cutoff": 40, "rate_disc": 0.1}]]),
