@@ -183,10 +183,15 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
   st[AIE_CV_ST_U * 64 + s] = on ? a.U : 0.f;
   st[AIE_CV_ST_PROD * 64 + s] = 0.f;
   st[AIE_CV_ST_SUBSIDY * 64 + s] = 0.f;
+  st[AIE_CV_ST_HEALTH_INDEX * 64 + s] = 0.f;
+  st[AIE_CV_ST_ECONOMIC_INDEX * 64 + s] = 0.f;
+  for (int k = 0; k < AIE_CV_SUM_COUNT; ++k) reinterpret_cast<double*>(rec + P.o_cv_sums)[k * 64 + s] = 0.0;
   reinterpret_cast<int32_t*>(rec + P.o_cv_cooldown)[s] = 0;
   if (s == 0) {
     *reinterpret_cast<int32_t*>(rec + P.o_cv_subsidy_level) = 0;
     *reinterpret_cast<int32_t*>(rec + P.o_timestep) = 0;
+    reinterpret_cast<float*>(rec + P.o_cv_p_index)[0] = 0.f;
+    reinterpret_cast<float*>(rec + P.o_cv_p_index)[1] = 0.f;
     arena[P.a_done + e] = 0;
     reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.f;
   }
@@ -353,6 +358,12 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     st[AIE_CV_ST_U * 64 + s] = a.U;
     st[AIE_CV_ST_PROD * 64 + s] = a.prod;
     st[AIE_CV_ST_SUBSIDY * 64 + s] = a.subsidy;
+    // per-state sums over the days of the episode, for scenario_metrics :1613-1687
+    double* sums = reinterpret_cast<double*>(rec + P.o_cv_sums);
+    sums[AIE_CV_SUM_UNEMPLOYED * 64 + s] += (double)a.U;
+    sums[AIE_CV_SUM_STRINGENCY * 64 + s] += (double)a.level;
+    sums[AIE_CV_SUM_PRODUCTIVITY * 64 + s] += (double)a.prod;
+    sums[AIE_CV_SUM_SUBSIDY * 64 + s] += (double)a.subsidy;
   }
   if (s == 0) {
     *reinterpret_cast<int32_t*>(rec + P.o_timestep) = t;
@@ -375,6 +386,8 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     ec = cv_minmax(ec, (float)K[AIE_CV_K_MIN_ECON * 64 + s], (float)K[AIE_CV_K_MAX_ECON * 64 + s]);
     const float wh = (float)K[AIE_CV_K_W_HEALTH * 64 + s], we = (float)K[AIE_CV_K_W_ECON * 64 + s];
     reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + s] = ((wh * h + we * ec) / (wh + we)) / rnf;
+    st[AIE_CV_ST_HEALTH_INDEX * 64 + s] += h;  // agent.state["Health Index"] += ... :1123-1125 (float32)
+    st[AIE_CV_ST_ECONOMIC_INDEX * 64 + s] += ec;
   }
   if (s == 0) {
     const float sum_md = np_sum_f32_lds(red[0], n);
@@ -390,6 +403,9 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     const float wpe = (float)V.weightage_on_marginal_planner_economic_index;
     const double rp = (((double)wph * ph + (double)(wpe * pe)) / (double)(wph + wpe)) / (double)rnf;
     reinterpret_cast<float*>(arena + P.a_rew_p)[e] = (float)rp;
+    float* pidx = reinterpret_cast<float*>(rec + P.o_cv_p_index);  // planner.state[...] += ... :1160-1161
+    pidx[0] = (float)((double)pidx[0] + ph);
+    pidx[1] = pidx[1] + pe;
     arena[P.a_done + e] = t >= T ? 1 : 0;
     if (t >= T) *reinterpret_cast<int32_t*>(rec + P.o_completions) += 1;
   }

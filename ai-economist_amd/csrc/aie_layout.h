@@ -134,6 +134,8 @@ typedef struct aie_params {
   int32_t o_cv_state;    /* record: AIE_CV_ST_* float32 rows of 64 lanes                  */
   int32_t o_cv_cooldown; /* record: int32 row                                              */
   int32_t o_cv_subsidy_level;
+  int32_t o_cv_sums;     /* record: AIE_CV_SUM_* float64 rows of 64 lanes                 */
+  int32_t o_cv_p_index;  /* record: planner Health Index, Economic Index (float32 x 2)    */
   int64_t a_cv_consts;   /* AIE_CV_K_* float64 rows of 64 (shared by all replicas)         */
   int64_t a_cv_filters;  /* float64 [pad+L+pad][F]                                              */
   int64_t a_cv_hist0;    /* uint8 [L+1][n]   stringency levels of the L days before t=0 + t=0 */
@@ -220,7 +222,11 @@ enum {
   AIE_CV_K_COUNT = AIE_CV_K_CONV_W0 + AIE_COVID_MAX_FILTERS
 };
 enum { AIE_CV_ST_S = 0, AIE_CV_ST_I, AIE_CV_ST_R, AIE_CV_ST_D, AIE_CV_ST_V, AIE_CV_ST_U,
-       AIE_CV_ST_PROD, AIE_CV_ST_SUBSIDY, AIE_CV_ST_COUNT };
+       AIE_CV_ST_PROD, AIE_CV_ST_SUBSIDY,
+       AIE_CV_ST_HEALTH_INDEX, AIE_CV_ST_ECONOMIC_INDEX, /* agent.state["Health/Economic Index"], float32 running sums */
+       AIE_CV_ST_COUNT };
+/* float64 per-state sums over the episode's days (scenario_metrics, covid19_env.py:1613-1687) */
+enum { AIE_CV_SUM_UNEMPLOYED = 0, AIE_CV_SUM_STRINGENCY, AIE_CV_SUM_PRODUCTIVITY, AIE_CV_SUM_SUBSIDY, AIE_CV_SUM_COUNT };
 /* rows of the agent observation block */
 enum { AIE_CV_OB_STATE = 0, AIE_CV_OB_PROD = 6, AIE_CV_OB_LAG = 7, AIE_CV_OB_TIME = 8, AIE_CV_OB_POLICY = 9,
        AIE_CV_OB_T_SUBSIDY = 10, AIE_CV_OB_SUBSIDY_LEVEL = 11, AIE_CV_OB_T_VACCINE = 12, AIE_CV_OB_MASK = 13 };
@@ -285,7 +291,9 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   int32_t cur = 0;
   p->o_cv_state = aie__rec(&cur, 4 * 64 * AIE_CV_ST_COUNT, 256);
   p->o_cv_cooldown = aie__rec(&cur, 4 * 64, 256);
+  p->o_cv_sums = aie__rec(&cur, 8 * 64 * AIE_CV_SUM_COUNT, 256);
   p->o_cv_subsidy_level = aie__rec(&cur, 4, 4);
+  p->o_cv_p_index = aie__rec(&cur, 8, 4);
   p->o_timestep = aie__rec(&cur, 4, 4);
   p->o_completions = aie__rec(&cur, 4, 4);
   p->rec_bytes = (int32_t)aie__align(cur, 256);
@@ -310,7 +318,13 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   if (tt) {
     const int64_t rs = p->rec_bytes, r0 = p->a_records;
     static const char* st_name[AIE_CV_ST_COUNT] = {"susceptible", "infected", "recovered", "deaths", "vaccinated",
-                                                   "unemployed", "postsubsidy_productivity", "subsidy"};
+                                                   "unemployed", "postsubsidy_productivity", "subsidy",
+                                                   "health_index", "economic_index"};
+    static const char* sum_name[AIE_CV_SUM_COUNT] = {"sum_unemployed", "sum_stringency_level",
+                                                     "sum_postsubsidy_productivity", "sum_subsidy"};
+    for (int k = 0; k < AIE_CV_SUM_COUNT; ++k)
+      aie__add(tt, sum_name[k], AIE_F64, r0 + p->o_cv_sums + 512 * k, rs, 1, n, 0, 0, 0, E);
+    aie__add(tt, "planner_health_economic_index", AIE_F32, r0 + p->o_cv_p_index, rs, 1, 2, 0, 0, 0, E);
     for (int k = 0; k < AIE_CV_ST_COUNT; ++k)
       aie__add(tt, st_name[k], AIE_F32, r0 + p->o_cv_state + 256 * k, rs, 1, n, 0, 0, 0, E);
     aie__add(tt, "cooldown_until", AIE_I32, r0 + p->o_cv_cooldown, rs, 1, n, 0, 0, 0, E);

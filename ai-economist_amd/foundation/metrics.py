@@ -101,6 +101,36 @@ def ose_scenario_metrics(env, t):
     return m
 
 
+# ---- COVID-19 scenario_metrics: covid19_env.py:1613-1687 ----
+def covid_scenario_metrics(env, t):
+    """From the current state + the per-state day sums the kernel keeps.  Note that the
+    reference averages over ALL episode_length days (days not simulated yet count as zeros)."""
+    m = env.model
+    names = m["us_state_names"]
+    pop = np.asarray(m["us_state_population"], np.float64)
+    us_pop = float(m["us_population"])
+    T = float(env.episode_length)
+    out = {}
+    as_int = lambda x: np.trunc(np.asarray(x, np.float64))  # noqa: E731  (.astype(np.int32) of a float)
+    for i, nm in enumerate(names):
+        out["%s/infected (millions)" % nm] = as_int(t["infected"][:, i]) / 1e6
+        out["%s/recovered (millions)" % nm] = as_int(t["recovered"][:, i]) / 1e6
+        out["%s/deaths (millions)" % nm] = as_int(t["deaths"][:, i]) / 1e6
+        out["%s/mean_unemployment_rate (%%)" % nm] = t["sum_unemployed"][:, i] / T / pop[i] * 100
+        out["%s/mean_open_close_stringency_level" % nm] = t["sum_stringency_level"][:, i] / T
+        out["%s/total_productivity (billion $)" % nm] = t["sum_postsubsidy_productivity"][:, i] / 1e9
+        out["%s/health_index_at_end_of_episode" % nm] = t["health_index"][:, i].astype(np.float64)
+        out["%s/economic_index_at_end_of_episode" % nm] = t["economic_index"][:, i].astype(np.float64)
+    out["usa/vaccinated (% of population)"] = t["vaccinated"].astype(np.float64).sum(axis=1) / us_pop * 100
+    out["usa/deaths (thousands)"] = t["deaths"].astype(np.float64).sum(axis=1) / 1e3
+    out["usa/mean_unemployment_rate (%)"] = t["sum_unemployed"].sum(axis=1) / us_pop / T * 100
+    out["usa/total_amount_subsidized (trillion $)"] = t["sum_subsidy"].sum(axis=1) / 1e12
+    out["usa/total_productivity (trillion $)"] = t["sum_postsubsidy_productivity"].sum(axis=1) / 1e12
+    out["usa/health_index_at_end_of_episode"] = t["planner_health_economic_index"][:, 0].astype(np.float64)
+    out["usa/economic_index_at_end_of_episode"] = t["planner_health_economic_index"][:, 1].astype(np.float64)
+    return out
+
+
 # ---- component get_metrics ----
 def build_metrics(comp, env, t):  # build.py:198-222
     owner = t["house_owner"].reshape(t["house_owner"].shape[0], -1)

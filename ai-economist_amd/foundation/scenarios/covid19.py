@@ -78,6 +78,11 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
         z = np.zeros(self.world_size, np.uint8)
         return (z, z, z)
 
+    def scenario_metrics(self, tensors):
+        from .. import metrics
+
+        return metrics.covid_scenario_metrics(self, tensors)
+
     def fill_scenario_config(self, cfg):
         m, v = self.model, cfg.covid
         cfg.scenario = _cabi.SCN_COVID

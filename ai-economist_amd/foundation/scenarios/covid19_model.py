@@ -54,6 +54,8 @@ def build_model(start_date="2020-03-22", pop_between_age_18_65=0.6, infection_to
     n = len(pop)
     us_pop = I32(d["mc_US_POPULATION"])
     m["us_state_population"] = pop
+    m["us_state_names"] = [str(x) for x in np.asarray(d["mc_US_STATE_IDX_TO_STATE_NAME"]).reshape(-1)] \
+        if np.asarray(d["mc_US_STATE_IDX_TO_STATE_NAME"]).ndim else None
     m["us_population"] = us_pop
     m["num_stringency_levels"] = int(d["mc_NUM_STRINGENCY_LEVELS"])
     m["death_rate"] = F32(d["mc_SIR_MORTALITY"])

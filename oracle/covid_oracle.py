@@ -66,6 +66,10 @@ class CovidOracle:
         self.rew_a = np.zeros((E, n))
         self.rew_p = np.zeros(E)
         self.done = np.zeros(E, np.uint8)
+        # agent.state / planner.state["Health Index"], ["Economic Index"] (:1255-1290): float32 running sums
+        self.health_index = np.zeros((E, n), F32)
+        self.economic_index = np.zeros((E, n), F32)
+        self.planner_index = np.zeros((E, 2), F32)
         return self.observe()
 
     # ---- one env.step(): base_env.py:929-1032 ----
@@ -158,6 +162,8 @@ class CovidOracle:
         wh = m["weightage_on_marginal_agent_health_index"][None]
         we = m["weightage_on_marginal_agent_economic_index"][None]
         self.rew_a = (wh * h + we * e) / (wh + we) / m["reward_normalization_factor"]
+        self.health_index += h   # :1123-1125
+        self.economic_index += e
         ph = -np.sum(md, axis=1).astype(F32) * m["value_of_life"] / m["planner_health_norm"]
         cost = (1 + m["risk_free_interest_rate"]) * np.sum(sub, axis=1)
         pe = crra((np.sum(pp, axis=1) - cost) / m["planner_economic_norm"])
@@ -166,6 +172,8 @@ class CovidOracle:
         wph = m["weightage_on_marginal_planner_health_index"]
         wpe = m["weightage_on_marginal_planner_economic_index"]
         self.rew_p = (wph * ph + wpe * pe) / (wph + wpe) / m["reward_normalization_factor"]
+        self.planner_index[:, 0] += ph   # :1160-1161 (in-place add on a float32 array)
+        self.planner_index[:, 1] += pe
 
     # ---- observations + masks, in the batched tensor naming ----
     def observe(self):
@@ -216,4 +224,11 @@ class CovidOracle:
                 "deaths": self.D[:, t], "vaccinated": self.V[:, t], "unemployed": self.U[:, t],
                 "stringency_level": self.stringency[:, t], "subsidy": self.subsidy[:, t],
                 "postsubsidy_productivity": self.postprod[:, t], "subsidy_level": self.subsidy_level.astype(np.int32),
-                "cooldown_until": self.cooldown_until.astype(np.int32), "timestep": np.full(self.E, t, np.int32)}
+                "cooldown_until": self.cooldown_until.astype(np.int32), "timestep": np.full(self.E, t, np.int32),
+                "health_index": self.health_index, "economic_index": self.economic_index,
+                "planner_health_economic_index": self.planner_index,
+                # what scenario_metrics (:1613-1687) reduces over the day axis of global_state
+                "sum_unemployed": self.U[:, 1:].astype(np.float64).sum(axis=1),
+                "sum_stringency_level": self.stringency[:, 1:].astype(np.float64).sum(axis=1),
+                "sum_postsubsidy_productivity": self.postprod[:, 1:].astype(np.float64).sum(axis=1),
+                "sum_subsidy": self.subsidy[:, 1:].astype(np.float64).sum(axis=1)}

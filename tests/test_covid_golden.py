@@ -161,6 +161,17 @@ def test_covid_hip_matches_oracle_on_batched_rollouts(name, E, T):
                                        err_msg="%s %s" % (where, k))
         assert np.array_equal(t["cooldown_until"].cpu().numpy(), st["cooldown_until"]), where
         assert np.array_equal(t["subsidy_level"].cpu().numpy(), st["subsidy_level"]), where
+        for k in ("health_index", "economic_index", "planner_health_economic_index", "sum_unemployed",
+                  "sum_stringency_level", "sum_postsubsidy_productivity", "sum_subsidy"):
+            np.testing.assert_allclose(t[k].cpu().numpy().astype(np.float64), st[k], rtol=2e-5, atol=2e-4,
+                                       err_msg="%s %s" % (where, k))
+        # env.metrics from the device state vs the same formulas on the oracle's state
+        from ai_economist_amd.foundation.metrics import covid_scenario_metrics
+
+        got, want = env.metrics, covid_scenario_metrics(env, st)
+        assert sorted(got) == sorted(want) and len(got) == 51 * 8 + 7
+        for k, v in want.items():
+            np.testing.assert_allclose(got[k], v, rtol=2e-5, atol=2e-4, err_msg="%s metric %s" % (where, k))
         oo = o.observe()
         for k, v in oo.items():
             np.testing.assert_allclose(t[k].cpu().numpy().reshape(v.shape), v, rtol=1e-5, atol=1e-6,

@@ -137,7 +137,30 @@ def test_oracle_tracks_live_reference_covid(start_date, steps):
             np.testing.assert_allclose(st[name][1], gs[key][env.world.timestep], rtol=2e-6, atol=1e-3,
                                        err_msg="%s state %s" % (where, name))
 
+    class _Host:  # what covid_scenario_metrics needs from the host env
+        model = dict(model_from_reference(env), us_state_names=[env.us_state_idx_to_state_name[str(i)] for i in range(51)],
+                     us_population=env.us_population)
+        episode_length = 340
+
+    def check_metrics(where):
+        import warnings
+
+        if not np.isfinite(o.state()["susceptible"]).all():
+            return  # start dates before the real-world tables are complete: NaN state, int casts of NaN
+
+        from ai_economist_amd.foundation.metrics import covid_scenario_metrics
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = env.metrics
+        got = covid_scenario_metrics(_Host, o.state())
+        assert sorted(got) == sorted(want), sorted(set(got) ^ set(want))[:6]
+        for k, v in want.items():
+            np.testing.assert_allclose(float(got[k][1]), float(np.asarray(v).reshape(-1)[0]), rtol=2e-5, atol=1e-7,
+                                       err_msg="%s metric %s" % (where, k))
+
     check("reset", obs, oo)
+    check_metrics("reset")
     for t in range(steps):
         a = rng.randint(0, 11, size=51)
         a[rng.rand(51) < 0.6] = 0
@@ -147,3 +170,5 @@ def test_oracle_tracks_live_reference_covid(start_date, steps):
         obs, rew, done, _ = env.step(acts)
         oo = o.step(np.stack([a * 0, a]), np.array([0, p]))
         check("step %d" % (t + 1), obs, oo, rew)
+        if (t + 1) % 50 == 0 or t + 1 == steps:
+            check_metrics("step %d" % (t + 1))
