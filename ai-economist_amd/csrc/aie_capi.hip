@@ -350,7 +350,7 @@ int aie_dev_set_step_waves(aie_env* env, int waves) {
   return AIE_OK;
 }
 
-// Development aid (not part of include/aie.h): device buffer of 8*E uint64 clock stamps per launch.
+// Development aid (not part of include/aie.h): device buffer of 12*E uint64 clock stamps per launch.
 int aie_dev_set_trace(aie_env* env, void* d_buf) {
   if (!env) return AIE_E_INVALID;
   env->P.dev_trace = static_cast<uint64_t*>(d_buf);

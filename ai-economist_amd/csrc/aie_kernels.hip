@@ -1573,12 +1573,14 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   MT m;
   Agents A;
   const int skip = P.dev_skip_mask;
-  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[8 * blockIdx.x] = wall_clock64();
+  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x] = wall_clock64();
   if (threadIdx.x == 0) *c.srcn = 0;
   __syncthreads();
+  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
   load_record(c, arena, m, wid, NW);
   if (wid == 0) decode_actions(c, A, act_a, act_p);
   __syncthreads();  // the record is in LDS
+  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
   if (NW == 1 || wid == 1) rebuild_locmap(c);
   if (wid == 0) {
     m.pos = uni(*R_I32(c, o_mt_pos));
@@ -1588,7 +1590,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   __syncthreads();  // occupancy map rebuilt
   if (wid == 0) {
     if (c.tid == 0) *R_I32(c, o_timestep) += 1;
-    if (P.dev_trace && c.tid == 0) P.dev_trace[8 * blockIdx.x + 1] = wall_clock64();
+    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 1] = wall_clock64();
     if (!(skip & 1)) {
       for (int k = 0; k < P.c.n_components; ++k) {
         switch (P.c.components[k]) {
@@ -1598,17 +1600,18 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
           case AIE_COMP_TAX: if (!(skip & 16384)) tax_component_step(c, A); break;
           default: break;
         }
-        if (P.dev_trace && c.tid == 0 && k < 4) P.dev_trace[8 * blockIdx.x + 2 + k] = wall_clock64();
+        if (P.dev_trace && c.tid == 0 && k < 4) P.dev_trace[12 * blockIdx.x + 2 + k] = wall_clock64();
       }
     }
     agents_store(c, A);
     if (!(skip & 2)) scenario_step_regen(c, m);
     if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
-    if (P.dev_trace && c.tid == 0) P.dev_trace[8 * blockIdx.x + 6] = wall_clock64();
+    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
   }
   __syncthreads();
   if (wid == 0) {
     if (!(skip & 8)) write_flat_observations(c, arena);
+    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
     if (!(skip & 16)) compute_rewards(c, arena);
     AIE_WSYNC();
     if (c.tid == 0) {
@@ -1620,10 +1623,11 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (NW == 1 || wid == 1) {
     if (!(skip & 4)) write_spatial_observations(c, arena);
     if (!(skip & 8)) write_action_masks(c, arena);
+    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
   }
   __syncthreads();
   if (!(skip & 32)) store_record(c, arena, m, wid, NW);
-  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[8 * blockIdx.x + 7] = wall_clock64();
+  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 7] = wall_clock64();
 }
 
 extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))

@@ -15,6 +15,7 @@ import bench  # noqa: E402
 from helpers import make_env  # noqa: E402
 
 E = 4096
+SKIP = int(os.environ.get("AIE_DEV_SKIP_MASK", "0"))
 env = make_env(dict(bench.WORKLOAD), n_envs=E, device="cuda:0")
 env.seed(1)
 env.reset()
@@ -22,21 +23,25 @@ be = env.backend
 for _ in range(300):
     a, p = be.sample_random_actions(1234)
     be.step(a, p)
-buf = torch.zeros(8 * E, dtype=torch.int64, device="cuda")
+buf = torch.zeros(12 * E, dtype=torch.int64, device="cuda")
 be.lib.aie_dev_set_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 be.lib.aie_dev_set_trace(be.handle, ctypes.c_void_p(buf.data_ptr()))
-names = ["start", "loaded", "build", "cda", "gather", "tax", "regen", "end"]
+names = ["start", "loaded", "build", "cda", "gather", "tax", "regen", "end", "rec_in_lds", "srcn_zeroed", "flat_done(w0)", "spatial+masks(w1)"]
 for rep in range(2):
     a, p = be.sample_random_actions(1234)
     torch.cuda.synchronize()
     be.step(a, p)
     torch.cuda.synchronize()
-    t = buf.cpu().numpy().reshape(E, 8).astype(np.float64)
+    t = buf.cpu().numpy().reshape(E, 12).astype(np.float64)
     t = (t - t[:, 0].min()) / 100.0  # wall_clock64 ticks at 100 MHz -> us
     q = lambda x: " ".join("%6.1f" % v for v in np.percentile(x, [0, 10, 50, 90, 99, 100]))  # noqa: E731
     print("absolute (us)             p0    p10    p50    p90    p99   p100")
     for k, nm in enumerate(names):
         print("  %-10s            %s" % (nm, q(t[:, k])))
+    print("  pre-dynamics: srcn zero+barrier %.2f | record load+decode+barrier %.2f | locmap/agents_load/decay+barrier %.2f (medians)" % (
+        np.median(t[:, 9] - t[:, 0]), np.median(t[:, 8] - t[:, 9]), np.median(t[:, 1] - t[:, 8])))
+    print("  post-dynamics: flat %.2f | rewards+done+wait %.2f | wave1 spatial+masks %.2f (medians, from regen end)" % (
+        np.median(t[:, 10] - t[:, 6]), np.median(t[:, 7] - t[:, 10]), np.median(t[:, 11] - t[:, 6])))
     print("phase durations")
     for k in range(1, 8):
         print("  %-10s            %s" % (names[k], q(t[:, k] - t[:, k - 1])))
