@@ -192,7 +192,7 @@ struct MT {
 // *c.srcn must have been zeroed (and a barrier passed) before the call.
 // `wave` of `nwaves` copies every nwaves-th 16-byte unit; wave 0 also takes the MT19937 key.
 __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m, int wave = 0,
-                                            int nwaves = 1) {
+                                            int nwaves = 1, bool key_to_lds = false) {
   const uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
   const uint4* src = reinterpret_cast<const uint4*>(g);
   uint4* dst = reinterpret_cast<uint4*>(c.rec);
@@ -219,6 +219,12 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
         }
       }
     }
+  }
+  if (key_to_lds) {  // step kernel: the key goes to the LDS window (see MTL), 16 bytes per lane
+    const uint4* ksrc = reinterpret_cast<const uint4*>(g + c.P.o_mt);
+    uint4* kdst = reinterpret_cast<uint4*>(c.stage);
+    for (int q = wave * AIE_NT + c.tid; q < AIE_MT_N / 4; q += nwaves * AIE_NT) kdst[q] = ksrc[q];
+    return;
   }
   if (wave != 0) return;
   const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
@@ -378,6 +384,57 @@ __device__ __forceinline__ int rng_permutation(MT& m, int lane, int n) {
   }
   return p;
 }
+// ---- the same draws for the step kernel's components, with the CURRENT 624-word window of
+// the generator living in LDS (the observation staging area, free until the observations are
+// built) instead of 10 VGPRs: the serial component code is register-starved under the
+// 64-VGPR budget, and a draw becomes one LDS broadcast read.  The regeneration afterwards
+// takes the rows back into registers (mtl_to_regs) to twist them.
+struct MTL {
+  uint32_t* w;  // LDS [624] raw (untempered) words of the current window
+  int pos;      // wave-uniform index of the next unused word (624 = twist first)
+};
+__device__ __forceinline__ void mtl_to_regs(const MTL& l, MT& m, int lane) {
+#pragma unroll
+  for (int j = 0; j < 9; ++j) m.r[j] = l.w[64 * j + lane];
+  m.r[9] = lane < 48 ? l.w[576 + lane] : 0u;
+  m.pos = l.pos;
+}
+__device__ __forceinline__ uint32_t rng_u32(MTL& l, int lane) {
+  if (l.pos >= AIE_MT_N) {  // rare inside the components: ~10 of a step's ~2510 words are drawn here
+    MT m;
+    mtl_to_regs(l, m, lane);
+    mt_twist(m, lane);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) l.w[64 * j + lane] = m.r[j];
+    if (lane < 48) l.w[576 + lane] = m.r[9];
+    AIE_WSYNC();
+    l.pos = 0;
+  }
+  const uint32_t w = l.w[l.pos];  // same address in every lane: LDS broadcast
+  l.pos += 1;
+  return mt_temper(w);
+}
+__device__ __forceinline__ double rng_double(MTL& l, int lane) {
+  const uint32_t a = rng_u32(l, lane);
+  const uint32_t b = rng_u32(l, lane);
+  return u53(a, b);
+}
+__device__ __forceinline__ uint32_t rng_interval(MTL& l, int lane, uint32_t max) {
+  if (max == 0) return 0;
+  uint32_t mask = max, v;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  while ((v = (rng_u32(l, lane) & mask)) > max) {}
+  return v;
+}
+__device__ __forceinline__ int rng_permutation(MTL& l, int lane, int n) {
+  int p = lane;
+  for (int i = n - 1; i >= 1; --i) {
+    const int j = (int)rng_interval(l, lane, (uint32_t)i);
+    const int vi = bcast(p, i), vj = bcast(p, j);
+    p = (lane == i) ? vj : ((lane == j) ? vi : p);
+  }
+  return p;
+}
 __device__ __forceinline__ double rng_gauss(const Ctx& c, MT& m) {  // legacy_gauss (polar Box-Muller, cached)
   int32_t* has = R_I32(c, o_mt_has_gauss);
   double* g = R_F64(c, o_mt_gauss);
@@ -518,7 +575,7 @@ __device__ __forceinline__ void decode_actions(const Ctx& c, Agents& A, const in
 // builders are found with one ballot, so the common "nobody builds" step costs only the
 // permutation draw (which the reference consumes regardless, build.py:121).
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void build_component_step(const Ctx& c, MT& m, Agents& A) {
+__device__ __forceinline__ void build_component_step(const Ctx& c, MTL& m, Agents& A) {
   const int n = c.P.n, lane = c.tid;
   const int perm = rng_permutation(m, lane, n);
   const uint64_t builders = __ballot(lane < n && AIE_ACT_BUILD(A.act));
@@ -546,7 +603,7 @@ __device__ __forceinline__ void build_component_step(const Ctx& c, MT& m, Agents
 // ------------------------------------------------------------------------------------
 // Gather.component_step, F/components/move.py:93-153 (wave-uniform control flow)
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void gather_component_step(const Ctx& c, MT& m, Agents& A) {
+__device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agents& A) {
   const int n = c.P.n, W = c.P.W, H = c.P.H, lane = c.tid;
   const int perm = rng_permutation(m, lane, n);
   uint32_t* cells = R_CELLS(c);
@@ -1009,7 +1066,9 @@ __device__ __forceinline__ void scenario_step_regen_rows(const Ctx& c, MT& m) {
 // d_j and needs stream words pos+2*d_j, +1.  The state is advanced window by window (one
 // twist each); in every window the 624 raw words are dumped to LDS and each lane picks the
 // word(s) that fall into it.  ~800 instructions per step instead of ~2200.
-__device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
+// win0_in_lds: the caller kept the current window's raw words in c.stage (MTL), so the first
+// window needs no dump.
+__device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool win0_in_lds = false) {
   const int S = uni(*c.srcn);
   if (S > AIE_SRC_CAP) {
     scenario_step_regen_rows(c, m);
@@ -1037,11 +1096,13 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k)
       need |= (off_a[k] + 1 >= lo) && (off_a[k] < lo + AIE_MT_N);
     if (__ballot(need) == 0) continue;
-    AIE_WSYNC();
+    if (!(w == 0 && win0_in_lds)) {
+      AIE_WSYNC();
 #pragma unroll
-    for (int j = 0; j < 9; ++j) buf[64 * j + lane] = m.r[j];
-    if (lane < 48) buf[576 + lane] = m.r[9];
-    AIE_WSYNC();
+      for (int j = 0; j < 9; ++j) buf[64 * j + lane] = m.r[j];
+      if (lane < 48) buf[576 + lane] = m.r[9];
+      AIE_WSYNC();
+    }
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
       const int ia = off_a[k] - lo, ib = ia + 1;
@@ -1577,13 +1638,14 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (threadIdx.x == 0) *c.srcn = 0;
   __syncthreads();
   if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
-  load_record(c, arena, m, wid, NW);
+  load_record(c, arena, m, wid, NW, /*key_to_lds=*/true);
   if (wid == 0) decode_actions(c, A, act_a, act_p);
   __syncthreads();  // the record is in LDS
   if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
   if (NW == 1 || wid == 1) rebuild_locmap(c);
+  MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0};
   if (wid == 0) {
-    m.pos = uni(*R_I32(c, o_mt_pos));
+    ml.pos = uni(*R_I32(c, o_mt_pos));
     agents_load(c, A);
     if (P.has_cda && !(skip & 1)) cda_decay_price_history(c);
   }
@@ -1594,9 +1656,9 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     if (!(skip & 1)) {
       for (int k = 0; k < P.c.n_components; ++k) {
         switch (P.c.components[k]) {
-          case AIE_COMP_BUILD: if (!(skip & 2048)) build_component_step(c, m, A); break;
+          case AIE_COMP_BUILD: if (!(skip & 2048)) build_component_step(c, ml, A); break;
           case AIE_COMP_CDA: if (!(skip & 4096)) cda_component_step(c, A); break;
-          case AIE_COMP_GATHER: if (!(skip & 8192)) gather_component_step(c, m, A); break;
+          case AIE_COMP_GATHER: if (!(skip & 8192)) gather_component_step(c, ml, A); break;
           case AIE_COMP_TAX: if (!(skip & 16384)) tax_component_step(c, A); break;
           default: break;
         }
@@ -1604,7 +1666,9 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       }
     }
     agents_store(c, A);
-    if (!(skip & 2)) scenario_step_regen(c, m);
+    AIE_WSYNC();
+    mtl_to_regs(ml, m, c.tid);  // the generator's rows come back into registers for the twists
+    if (!(skip & 2)) scenario_step_regen(c, m, /*win0_in_lds=*/true);
     if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
     if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
   }
