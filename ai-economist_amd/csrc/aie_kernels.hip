@@ -1089,7 +1089,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool wi
   }
   const int last_win = (pos0 + total - 1) / AIE_MT_N;
   for (int w = 0; w <= last_win; ++w) {
-    if (w > 0 && !(c.P.dev_skip_mask & 65536)) mt_twist(m, lane);
+    if (w > 0 && !(c.P.dev_skip_mask & 65536)) mt_twist_body(m, lane);  // the hot site: inlined (4 twists per step)
     const int lo = w * AIE_MT_N;
     bool need = false;
 #pragma unroll
