@@ -284,7 +284,32 @@ int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
   return AIE_OK;
 }
 
+static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream,
+                         const NextActions& next);
+
 int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream) {
+  return aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{nullptr, nullptr, 0, 0, 0});
+}
+
+int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, uint64_t seed,
+                         int64_t global_env_offset, int32_t* d_next_a, int32_t* d_next_p, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  if ((d_next_a && d_next_a == d_actions_a) || (d_next_p && d_next_p == d_actions_p)) {
+    snprintf(env->err, sizeof(env->err), "aie_step_sample_next: the next-action buffers must differ from the current ones");
+    return AIE_E_INVALID;
+  }
+  if (env->P.c.scenario != AIE_SCN_GTB || env->step_waves != 2) {  // no fused kernel: two launches
+    int rc = aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{nullptr, nullptr, 0, 0, 0});
+    if (rc != AIE_OK) return rc;
+    return aie_sample_random_actions(env, seed, global_env_offset, d_next_a, d_next_p, stream);
+  }
+  const NextActions next{d_next_a, d_next_p, seed, global_env_offset, env->sample_t};
+  env->sample_t += 1;
+  return aie_step_impl(env, d_actions_a, d_actions_p, stream, next);
+}
+
+static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream,
+                         const NextActions& next) {
   if (!env) return AIE_E_INVALID;
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   if (env->P.c.scenario == AIE_SCN_COVID) {
@@ -303,7 +328,7 @@ int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
   else if (env->step_waves == 2)
     hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
-                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
   else
     hipLaunchKernelGGL(aie_step_kernel_w1, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);

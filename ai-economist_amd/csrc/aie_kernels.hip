@@ -178,6 +178,25 @@ __device__ __forceinline__ int replica_of_block(int b, int E) {
 }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
+// One action slot j of replica e under the benchmark's uniform random policy (slots: the
+// agents' sub-actions in order, then the planner's).
+__device__ __forceinline__ void sample_action_slot(const aie_params& P, uint64_t seed, int64_t env_offset, int64_t t,
+                                                   int e, int j, int32_t* __restrict__ act_a,
+                                                   int32_t* __restrict__ act_p) {
+  const uint32_t u = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)j);
+  if (j < P.n * P.act_a_width) {
+    if (!act_a) return;
+    int range;
+    if (P.c.multi_action_mode_agents) range = P.n_sub_a ? P.sub_a_dim[j % P.act_a_width] + 1 : 1;
+    else range = P.A;
+    act_a[(int64_t)e * P.n * P.act_a_width + j] = (int32_t)(((uint64_t)u * (uint64_t)range) >> 32);
+  } else {
+    if (!act_p) return;
+    const int range = P.c.multi_action_mode_planner ? P.sub_p_dim + 1 : 1 + P.n_sub_p * P.sub_p_dim;
+    act_p[(int64_t)e * P.act_p_width + (j - P.n * P.act_a_width)] = (int32_t)(((uint64_t)u * (uint64_t)range) >> 32);
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // record streaming HBM <-> LDS (16 B per lane, fully coalesced); MT key HBM <-> VGPRs
 // ------------------------------------------------------------------------------------
@@ -1621,10 +1640,16 @@ __device__ __forceinline__ void rebuild_locmap(const Ctx& c) {
 // repairing the changed cells afterwards -- parity-clean, but the extra store traffic slows
 // the serial dynamics of the first wave by as much as it saves.)
 // NW = 1 is the original one-wave-per-replica schedule (kept for A/B measurements).
+struct NextActions {  // aie_step_sample_next: where and how to sample the next step's random actions
+  int32_t* a;
+  int32_t* p;
+  uint64_t seed;
+  int64_t env_offset, t;
+};
 template <int NW>
 __device__ __forceinline__ void step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                                           const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
-                                          uint8_t* lds) {
+                                          uint8_t* lds, const NextActions& next) {
   using namespace aie;
   // The parameter block lives in device memory (uniform scalar loads).  Passing the 2.7 KB
   // struct by value made the compiler copy it to scratch on every launch (5x slower).
@@ -1671,6 +1696,10 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     if (!(skip & 2)) scenario_step_regen(c, m, /*win0_in_lds=*/true);
     if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
     if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
+  } else if (next.a || next.p) {
+    // the second wave has nothing to do until the dynamics are done: next step's random actions
+    const int per_env = P.n * P.act_a_width + P.act_p_width;
+    for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, c.e, j, next.a, next.p);
   }
   __syncthreads();
   if (wid == 0) {
@@ -1696,15 +1725,15 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
 
 extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 aie_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
+                const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  step_body<2>(params, arena, act_a, act_p, lds);
+  step_body<2>(params, arena, act_a, act_p, lds, next);
 }
 extern "C" __global__ void __launch_bounds__(AIE_NT)
 aie_step_kernel_w1(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  step_body<1>(params, arena, act_a, act_p, lds);
+  step_body<1>(params, arena, act_a, act_p, lds, NextActions{nullptr, nullptr, 0, 0, 0});
 }
 
 // BaseEnvironment.reset, F/base/base_env.py:852-927, with LayoutFromFile
@@ -1903,19 +1932,7 @@ extern "C" __global__ void aie_sample_actions_kernel(const aie_params P, uint64_
   const int per_env = P.n * P.act_a_width + P.act_p_width;
   if (q >= (int64_t)P.E * per_env) return;
   const int e = (int)(q / per_env);
-  const int j = (int)(q - (int64_t)e * per_env);
-  const uint32_t u = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)j);
-  if (j < P.n * P.act_a_width) {
-    if (!act_a) return;
-    int range;
-    if (P.c.multi_action_mode_agents) range = P.n_sub_a ? P.sub_a_dim[j % P.act_a_width] + 1 : 1;
-    else range = P.A;
-    act_a[(int64_t)e * P.n * P.act_a_width + j] = (int32_t)(((uint64_t)u * (uint64_t)range) >> 32);
-  } else {
-    if (!act_p) return;
-    const int range = P.c.multi_action_mode_planner ? P.sub_p_dim + 1 : 1 + P.n_sub_p * P.sub_p_dim;
-    act_p[(int64_t)e * P.act_p_width + (j - P.n * P.act_a_width)] = (int32_t)(((uint64_t)u * (uint64_t)range) >> 32);
-  }
+  aie::sample_action_slot(P, seed, env_offset, t, e, (int)(q - (int64_t)e * per_env), act_a, act_p);
 }
 
 // Masked uniform random policy (see include/aie.h: aie_sample_masked_actions).  One thread

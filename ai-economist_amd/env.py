@@ -138,6 +138,18 @@ class DeviceBackend:
         p = self._ptr(actions_p, torch.int32, "actions_p")
         self._check(self.lib.aie_step(self.handle, a, p, self._stream()))
 
+    def step_sample_next(self, actions_a, actions_p, seed, env_offset=0, next_slot=1):
+        """One launch: step with (actions_a, actions_p) and fill the action buffers of `next_slot`
+        with the uniform random policy's next draw (same values as sample_random_actions)."""
+        torch = _torch()
+        a = self._ptr(actions_a, torch.int32, "actions_a")
+        p = self._ptr(actions_p, torch.int32, "actions_p")
+        na, np_ = self._action_buffers(next_slot)
+        self._check(self.lib.aie_step_sample_next(
+            self.handle, a, p, C.c_uint64(seed), C.c_int64(env_offset),
+            C.c_void_p(na.data_ptr()), C.c_void_p(np_.data_ptr()), self._stream()))
+        return na, np_
+
     def sample_masked_actions(self, seed, env_offset=0, slot=0):
         """Like sample_random_actions, but every sub-action is drawn uniformly among the
         entries the current `action_mask` observations allow."""

@@ -167,11 +167,16 @@ def main():
     T_ep = env.episode_length
     gather = RewardDoneGather(E, n, device) if world > 1 else None
     t_in_ep = 0
+    # uniform random policy: the actions of step t+1 are drawn inside the launch of step t
+    # (aie_step_sample_next: the replica's second wavefront is idle during the serial dynamics),
+    # so a rollout step is ONE launch; the first draw is a launch of its own.
+    cur = be.sample_random_actions(ACTION_SEED, env_offset, slot=0)
+    slot = 0
 
     def one_step():
-        nonlocal t_in_ep
-        a, p = be.sample_random_actions(ACTION_SEED, env_offset)
-        be.step(a, p)
+        nonlocal t_in_ep, cur, slot
+        cur = be.step_sample_next(cur[0], cur[1], ACTION_SEED, env_offset, next_slot=slot ^ 1)
+        slot ^= 1
         t_in_ep += 1
         if gather is not None:
             gather(be.tensors["rewards_a"], be.tensors["rewards_p"], be.tensors["done"])
@@ -237,6 +242,8 @@ def main():
                             "episode_length 1000, uniform random policy, mobile agents counted (planner excluded)",
                 "envs_per_gpu": E, "global_envs": world * E, "n_agents": n,
                 "rng": "per-replica NumPy-legacy MT19937 (parity mode)",
+                "policy": "uniform random (counter RNG); the draw for step t+1 happens inside the launch of step t "
+                          "(aie_step_sample_next), one launch per step",
                 "parallelism": "replica sharding, %d rank(s); per-step RCCL gather of (reward, done)" % world
                 if world > 1 else "single GPU",
             },

@@ -280,6 +280,14 @@ int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_
 int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_offset,
                               int32_t* d_actions_a, int32_t* d_actions_p, void* stream);
 
+/* aie_step + aie_sample_random_actions for the NEXT step in one launch: steps with
+ * d_actions_a/p and, while the replica's first wavefront runs the serial dynamics, lets the
+ * otherwise idle second wavefront fill d_next_a/p (caller-owned, must differ from the current
+ * action buffers) with exactly what aie_sample_random_actions would write next.  A rollout loop
+ * of the uniform random policy then needs one launch per step instead of two. */
+int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, uint64_t seed,
+                         int64_t global_env_offset, int32_t* d_next_a, int32_t* d_next_p, void* stream);
+
 /* Same counter RNG, but each sub-action is drawn uniformly among the entries that the
  * CURRENT action masks allow (obs_a_action_mask / obs_p_action_mask; NO-OP is always
  * allowed).  This is the random policy a trainer starts from when it applies the

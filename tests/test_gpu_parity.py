@@ -204,6 +204,36 @@ def test_hip_matches_oracle_on_random_rollouts(n_agents, E, T):
             _compare_all(be, oracle, "after episode reset")
 
 
+def test_step_sample_next_equals_two_launches():
+    """aie_step_sample_next == aie_step followed by aie_sample_random_actions: same actions, same
+    trajectory, bit for bit."""
+    import torch
+
+    cfg = dict(C2, episode_length=50)
+    envs = [make_env(cfg, n_envs=96, device="cuda:0", env_offset=640) for _ in range(2)]
+    for env in envs:
+        env.seed(9)
+        env.reset()
+    b0, b1 = envs[0].backend, envs[1].backend
+    cur = b1.sample_random_actions(seed=4242, env_offset=640, slot=0)
+    slot = 0
+    for t in range(60):
+        a, p = b0.sample_random_actions(seed=4242, env_offset=640)
+        assert torch.equal(a, cur[0]) and torch.equal(p, cur[1]), "actions differ at step %d" % t
+        b0.step(a, p)
+        cur = b1.step_sample_next(cur[0], cur[1], seed=4242, env_offset=640, next_slot=slot ^ 1)
+        slot ^= 1
+        if t == 49:
+            b0.reset(b0.tensors["done"])
+            b1.reset(b1.tensors["done"])
+    torch.cuda.synchronize()
+    assert torch.equal(b0.arena, b1.arena)
+    with pytest.raises(ValueError):
+        b1.lib.aie_step_sample_next  # noqa: B018
+        b1._check(b1.lib.aie_step_sample_next(b1.handle, cur[0].data_ptr(), cur[1].data_ptr(), 1, 0,
+                                              cur[0].data_ptr(), cur[1].data_ptr(), None))
+
+
 def test_full_batch_properties_c2_4096():
     """BASELINE configs[1] at full size (4096 replicas): determinism, shard invariance
     (a replica's trajectory depends only on its global id), coin conservation."""
