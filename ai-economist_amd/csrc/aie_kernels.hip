@@ -1270,7 +1270,9 @@ template <bool WATER>
 __device__ __forceinline__ SpatialOut spatial_out(const Ctx& c, uint8_t* __restrict__ arena) {
   constexpr int CM = WATER ? 6 : 5;
   const int n = c.P.n, HW = c.P.HW, WV2 = c.P.WV * c.P.WV;
-  const uint32_t amap_bytes = (uint32_t)(n * (CM + 1) * WV2 * 4), aidx_bytes = (uint32_t)(n * 2 * WV2 * 2);
+  (void)WV2;
+  const int plane = c.P.am_h * c.P.am_w;
+  const uint32_t amap_bytes = (uint32_t)(n * c.P.am_ch * plane * 4), aidx_bytes = (uint32_t)(n * 2 * plane * 2);
   SpatialOut o;
   o.amap = make_rsrc(arena + c.P.a_obs_a_map + (int64_t)c.e * amap_bytes, amap_bytes);
   o.aidx = make_rsrc(arena + c.P.a_obs_a_idx + (int64_t)c.e * aidx_bytes, aidx_bytes);
@@ -1341,7 +1343,52 @@ __device__ __forceinline__ void write_spatial_observations_t(const Ctx& c, uint8
   const int n = c.P.n, HW = c.P.HW;
   const uint32_t* cells = R_CELLS(c);
   const SpatialOut o = spatial_out<WATER>(c, arena);
-  for (int i = 0; i < n; ++i) crop_agent<WATER>(c, o, i);
+  if (c.P.c.full_observability) {
+    // layout_from_file.py:466-472: every agent gets the whole map (CM channels, no in-bounds
+    // channel) and the owner / occupant planes with its own id replaced by 1
+    const uint32_t* lm4f = reinterpret_cast<const uint32_t*>(c.locmap);
+    for (int i = 0; i < n; ++i) {
+      const int so = i * CM * HW * 4, si = i * 2 * HW * 2;
+      for (int q = c.tid; q < (HW >> 2); q += AIE_NT) {
+        const uint4 cw = reinterpret_cast<const uint4*>(cells)[q];
+        const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+        float ch[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cell_channels<WATER>(cws[u], ch[u]);
+#pragma unroll
+        for (int k = 0; k < CM; ++k) buf_store_f32x4(o.amap, ch[0][k], ch[1][k], ch[2][k], ch[3][k], 16 * q, so + k * HW * 4);
+        const uint32_t occ4 = lm4f[q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int own = AIE_CELL_OWNER(cws[u]);
+          int v0 = own >= 0 ? own + 2 : 0;
+          const int occ = (int)((occ4 >> (8 * u)) & 0xffu);
+          int v1 = occ ? occ + 1 : 0;
+          if (v0 == i + 2) v0 = 1;
+          if (v1 == i + 2) v1 = 1;
+          buf_store_i16(o.aidx, v0, 8 * q + 2 * u, si);
+          buf_store_i16(o.aidx, v1, 8 * q + 2 * u, si + HW * 2);
+        }
+      }
+      for (int cell = 4 * (HW >> 2) + c.tid; cell < HW; cell += AIE_NT) {  // tail cells
+        float ch[6];
+        const uint32_t cw = cells[cell];
+        cell_channels<WATER>(cw, ch);
+#pragma unroll
+        for (int k = 0; k < CM; ++k) buf_store_f32(o.amap, ch[k], 4 * cell, so + k * HW * 4);
+        const int own = AIE_CELL_OWNER(cw);
+        int v0 = own >= 0 ? own + 2 : 0;
+        const int occ = c.locmap[cell];
+        int v1 = occ ? occ + 1 : 0;
+        if (v0 == i + 2) v0 = 1;
+        if (v1 == i + 2) v1 = 1;
+        buf_store_i16(o.aidx, v0, 2 * cell, si);
+        buf_store_i16(o.aidx, v1, 2 * cell, si + HW * 2);
+      }
+    }
+  } else {
+    for (int i = 0; i < n; ++i) crop_agent<WATER>(c, o, i);
+  }
   if (c.P.c.planner_gets_spatial_info) {
     // f32 channel planes: 4 consecutive cells per lane -> CM 16-byte stores.  The planes
     // are only dword-aligned (H*W need not be a multiple of 4): dwordx4 stores need no more
@@ -1440,10 +1487,12 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
     const float w3 = (float)((double)lc / (double)P.W);
     const float w4 = (float)((double)lr / (double)P.H);
     f[P.fa_world + 0] = w0; f[P.fa_world + 1] = w1; f[P.fa_world + 2] = w2;
-    f[P.fa_world + 3] = w3; f[P.fa_world + 4] = w4;
     float* q = s_pag + i * P.FPA;
-    q[P.fpa_world + 0] = w0; q[P.fpa_world + 1] = w1; q[P.fpa_world + 2] = w2;
-    if (P.c.planner_gets_spatial_info) { q[P.fpa_world + 3] = w3; q[P.fpa_world + 4] = w4; }
+    if (!P.c.full_observability) {  // locations and the planner's per-agent fragments: egocentric mode only
+      f[P.fa_world + 3] = w3; f[P.fa_world + 4] = w4;
+      q[P.fpa_world + 0] = w0; q[P.fpa_world + 1] = w1; q[P.fpa_world + 2] = w2;
+      if (P.c.planner_gets_spatial_info) { q[P.fpa_world + 3] = w3; q[P.fpa_world + 4] = w4; }
+    }
     reinterpret_cast<float*>(arena + P.a_obs_a_time)[(int64_t)c.e * n + i] = tval;
     if (P.has_tax) {
       // last_incomes sorted ascending (redistribution.py:908-911): rank by counting

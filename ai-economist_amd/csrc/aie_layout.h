@@ -54,6 +54,8 @@ typedef struct aie_params {
   int32_t M;        /* order-book capacity per commodity side = n * max_num_orders     */
   int32_t CM;       /* map channels in Maps.state: 5 (no water) or 6                   */
   int32_t WV;       /* egocentric window edge = 2*obs_range + 1                        */
+  int32_t am_ch, am_h, am_w; /* agents' "world-map": CM+1 x WV x WV (egocentric, last channel =
+                              * in-bounds) or, with full_observability, CM x H x W          */
   int32_t has_build, has_cda, has_gather, has_tax, has_labor;
   int32_t planner_acts; /* 1 if the planner has tax action subspaces                   */
 
@@ -569,10 +571,6 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
       if (c->components[j] == k) AIE__FAIL("component %d listed twice", k);
   }
   const int gtb = c->scenario == AIE_SCN_GTB;
-  if (gtb && c->full_observability) {
-    if (err) snprintf(err, errlen, "full_observability=True is not supported yet");
-    return AIE_E_UNSUPPORTED;
-  }
   if (gtb && (c->obs_range < 0 || c->obs_range > 15)) AIE__FAIL("mobile_agent_observation_range out of range");
   for (int r = 0; gtb && r < AIE_N_RES; ++r) {
     if (c->regen_halfwidth[r] != 0) {
@@ -734,7 +732,9 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     p->fa_gather = f; if (p->has_gather) f += 1;
     p->fa_tax = f;    if (p->has_tax) f += p->NB + p->n + 4;
     p->fa_time = f;   f += 1;
-    p->fa_world = f;  f += 5; /* inventory-Coin,-Stone,-Wood, loc-col, loc-row */
+    /* inventory-Coin,-Stone,-Wood, loc-col, loc-row; with full_observability the location is
+     * only conveyed through the maps (layout_from_file.py:466-472) */
+    p->fa_world = f;  f += c->full_observability ? 3 : 5;
     p->FA = f;
     f = 0;
     p->fp_cda = f;    if (p->has_cda) f += 6 * p->P + 2;
@@ -744,7 +744,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     p->FP = f;
     f = 0;
     p->fpa_tax = f;   if (p->has_tax) f += 3;
-    p->fpa_world = f; f += 3 + (c->planner_gets_spatial_info ? 2 : 0);
+    /* the scenario's per-agent planner fragments only exist with egocentric observations (:508-515) */
+    p->fpa_world = f; if (!c->full_observability) f += 3 + (c->planner_gets_spatial_info ? 2 : 0);
     p->FPA = f;
   }
 
@@ -809,8 +810,11 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   const int64_t E = p->E;
   int64_t a = 0;
   p->a_records = a; a = aie__align(a + E * (int64_t)p->rec_bytes, 256);
-  const int64_t wv2 = (int64_t)p->WV * p->WV;
-  p->a_obs_a_map = a;  a = aie__align(a + E * n * (p->CM + 1) * wv2 * 4, 256);
+  p->am_ch = c->full_observability ? p->CM : p->CM + 1;
+  p->am_h = c->full_observability ? p->H : p->WV;
+  p->am_w = c->full_observability ? p->W : p->WV;
+  const int64_t wv2 = (int64_t)p->am_h * p->am_w;
+  p->a_obs_a_map = a;  a = aie__align(a + E * n * p->am_ch * wv2 * 4, 256);
   p->a_obs_a_idx = a;  a = aie__align(a + E * n * 2 * wv2 * 2, 256);
   p->a_obs_a_flat = a; a = aie__align(a + E * n * p->FA * 4, 256);
   p->a_obs_a_mask = a; a = aie__align(a + E * n * p->MA * 4, 256);
@@ -822,7 +826,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->a_obs_p_flat = a;   a = aie__align(a + E * p->FP * 4, 256);
   p->a_obs_p_mask = a;   a = aie__align(a + E * p->MP * 4, 256);
   p->a_obs_p_time = a;   a = aie__align(a + E * 4, 256);
-  p->a_obs_p_agents = a; a = aie__align(a + E * n * p->FPA * 4, 256);
+  p->a_obs_p_agents = a; a = aie__align(a + E * n * (p->FPA ? p->FPA : 1) * 4, 256);
   p->a_rew_a = a; a = aie__align(a + E * n * 4, 256);
   p->a_rew_p = a; a = aie__align(a + E * 4, 256);
   p->a_done = a;  a = aie__align(a + E, 256);
@@ -889,8 +893,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     for (int q = 0; q < nd; ++q) es *= dd[q];                                               \
     aie__add(tt, name, dt, off, es, nd, d0, d1, d2, d3, E);                                 \
   } while (0)
-    DENSE("obs_a_world-map", AIE_F32, p->a_obs_a_map, 4, n, p->CM + 1, p->WV, p->WV);
-    DENSE("obs_a_world-idx_map", AIE_I16, p->a_obs_a_idx, 4, n, 2, p->WV, p->WV);
+    DENSE("obs_a_world-map", AIE_F32, p->a_obs_a_map, 4, n, p->am_ch, p->am_h, p->am_w);
+    DENSE("obs_a_world-idx_map", AIE_I16, p->a_obs_a_idx, 4, n, 2, p->am_h, p->am_w);
     DENSE("obs_a_flat", AIE_F32, p->a_obs_a_flat, 2, n, p->FA, 0, 0);
     DENSE("obs_a_action_mask", AIE_F32, p->a_obs_a_mask, 2, n, p->MA, 0, 0);
     DENSE("obs_a_time", AIE_F32, p->a_obs_a_time, 2, n, 1, 0, 0);
@@ -901,7 +905,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     DENSE("obs_p_flat", AIE_F32, p->a_obs_p_flat, 1, p->FP, 0, 0, 0);
     DENSE("obs_p_action_mask", AIE_F32, p->a_obs_p_mask, 1, p->MP, 0, 0, 0);
     DENSE("obs_p_time", AIE_F32, p->a_obs_p_time, 1, 1, 0, 0, 0);
-    DENSE("obs_p_agents", AIE_F32, p->a_obs_p_agents, 2, n, p->FPA, 0, 0);
+    if (p->FPA) DENSE("obs_p_agents", AIE_F32, p->a_obs_p_agents, 2, n, p->FPA, 0, 0);
     DENSE("rewards_a", AIE_F32, p->a_rew_a, 1, n, 0, 0, 0);
     DENSE("rewards_p", AIE_F32, p->a_rew_p, 0, 0, 0, 0, 0);
     DENSE("done", AIE_U8, p->a_done, 0, 0, 0, 0, 0);

@@ -665,9 +665,22 @@ static void write_obs(ctx_t* c) {
                       : ((k) == 3 ? FL(cell, AIE_CELL_STONE_SRC) : FL(cell, AIE_CELL_WOOD_SRC))))
   #define OWN(cell) AIE_CELL_OWNER(cells[cell])
 
-  float* amap = (float*)(c->arena + p->a_obs_a_map) + (int64_t)e * n * (CM + 1) * WV * WV;
-  int16_t* aidx = (int16_t*)(c->arena + p->a_obs_a_idx) + (int64_t)e * n * 2 * WV * WV;
-  for (int i = 0; i < n; ++i) {
+  float* amap = (float*)(c->arena + p->a_obs_a_map) + (int64_t)e * n * p->am_ch * p->am_h * p->am_w;
+  int16_t* aidx = (int16_t*)(c->arena + p->a_obs_a_idx) + (int64_t)e * n * 2 * p->am_h * p->am_w;
+  if (p->c.full_observability) { /* :466-472: the whole map + idx maps with the own id -> 1 */
+    for (int i = 0; i < n; ++i) {
+      for (int k = 0; k < CM; ++k)
+        for (int cell = 0; cell < HW; ++cell) amap[(i * CM + k) * HW + cell] = (float)CHAN(k, cell);
+      for (int cell = 0; cell < HW; ++cell) {
+        int16_t v0 = (int16_t)(OWN(cell) >= 0 ? OWN(cell) + 2 : 0), v1 = locmap[cell];
+        if (v0 == i + 2) v0 = 1;
+        if (v1 == i + 2) v1 = 1;
+        aidx[(i * 2 + 0) * HW + cell] = v0;
+        aidx[(i * 2 + 1) * HW + cell] = v1;
+      }
+    }
+  }
+  for (int i = 0; i < n && !p->c.full_observability; ++i) {
     for (int dr = 0; dr < WV; ++dr)
       for (int dc = 0; dc < WV; ++dc) {
         int r = lr[i] - w + dr, col = lc[i] - w + dc;
@@ -781,8 +794,10 @@ static void write_obs(ctx_t* c) {
     f[p->fa_world + 0] = (float)(F64(c, o_inv_coin)[i] * isc);
     f[p->fa_world + 1] = (float)((double)I32(c, o_inv_res)[0 * n + i] * isc);
     f[p->fa_world + 2] = (float)((double)I32(c, o_inv_res)[1 * n + i] * isc);
-    f[p->fa_world + 3] = (float)((double)lc[i] / (double)W);
-    f[p->fa_world + 4] = (float)((double)lr[i] / (double)H);
+    if (!p->c.full_observability) {
+      f[p->fa_world + 3] = (float)((double)lc[i] / (double)W);
+      f[p->fa_world + 4] = (float)((double)lr[i] / (double)H);
+    }
     atime[i] = (float)tval;
     /* planner's per-agent view p{i} */
     float* q = pag + i * p->FPA;
@@ -791,12 +806,14 @@ static void write_obs(ctx_t* c) {
       q[p->fpa_tax + 1] = (float)(F64(c, o_tax_last_income)[i] / (double)p->c.tax_period);
       q[p->fpa_tax + 2] = (float)F64(c, o_tax_last_marginal_rate)[i];
     }
-    q[p->fpa_world + 0] = f[p->fa_world + 0];
-    q[p->fpa_world + 1] = f[p->fa_world + 1];
-    q[p->fpa_world + 2] = f[p->fa_world + 2];
-    if (p->c.planner_gets_spatial_info) {
-      q[p->fpa_world + 3] = f[p->fa_world + 3];
-      q[p->fpa_world + 4] = f[p->fa_world + 4];
+    if (!p->c.full_observability) { /* :508-515: only the egocentric branch builds "p<idx>" */
+      q[p->fpa_world + 0] = f[p->fa_world + 0];
+      q[p->fpa_world + 1] = f[p->fa_world + 1];
+      q[p->fpa_world + 2] = f[p->fa_world + 2];
+      if (p->c.planner_gets_spatial_info) {
+        q[p->fpa_world + 3] = f[p->fa_world + 3];
+        q[p->fpa_world + 4] = f[p->fa_world + 4];
+      }
     }
   }
   /* planner flat */

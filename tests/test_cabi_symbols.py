@@ -46,8 +46,11 @@ def test_arena_bytes_and_validation_without_gpu():
     assert lib.aie_arena_bytes(ctypes.byref(c)) == _cabi.E_INVALID
     assert b"n_agents" in lib.aie_last_error(None)
     c = env.build_config()
-    c.full_observability = 1
+    c.regen_halfwidth[0] = 1
     assert lib.aie_arena_bytes(ctypes.byref(c)) == _cabi.E_UNSUPPORTED
+    c = env.build_config()
+    c.full_observability = 1  # every agent sees the whole map: n x 6 x 25 x 25 floats instead of n x 7 x 11 x 11
+    assert lib.aie_arena_bytes(ctypes.byref(c)) > nbytes
 
 
 def test_host_registry_and_kwargs_validation():

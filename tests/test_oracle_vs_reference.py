@@ -37,6 +37,9 @@ VARIANTS = {
         "PeriodicBracketTax", {"period": 10, "n_brackets": 3, "tax_annealing_schedule": [0, 0.4]}]]),
     "annealed_us_federal": dict(components=GTB[:3] + [["PeriodicBracketTax", {
         "period": 10, "tax_model": "us-federal-single-filer-2018-scaled", "tax_annealing_schedule": [-1, 0.3]}]]),
+    "full_observability": dict(components=GTB, full_observability=True, world_size=[25, 25]),
+    "full_observability_no_tax_planner_blind": dict(components=GTB[:3], full_observability=True,
+                                                    planner_gets_spatial_info=False),
     "taxes_disabled": dict(components=GTB[:3] + [["PeriodicBracketTax", {"period": 10, "disable_taxes": True}]]),
     "log_brackets_wrapper": dict(components=GTB[:3] + [["PeriodicBracketTax", {
         "period": 10, "bracket_spacing": "log", "n_brackets": 5, "top_bracket_cutoff": 40, "rate_disc": 0.1}]]),
