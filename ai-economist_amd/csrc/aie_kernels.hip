@@ -1163,6 +1163,8 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
     coin[i] = ci;
     double util_c;
     if (eta == 1.0) util_c = log(ci > 1 ? ci : 1);
+    else if (eta == 0.0) util_c = ci - 1;  // x ** 1.0 is exact in NumPy; the device pow() is not (1-2 ulp), and with a
+                                           // linear utility zero-sum transfers must cancel exactly (auto warm-up sign test)
     else util_c = (pow(ci, 1 - eta) - 1) / (1 - eta);
     out[i] = util_c - R_F64(c, o_labor)[i] * lcf;
   }

@@ -111,7 +111,7 @@ def _compare_all(be, oracle, where, fields=None):
             # moves by one ulp and the sign of the resulting ~1e-16 reward depends on the
             # last bit of pow() (glibc vs the device libm).  Float-derived => tolerance.
             d = np.abs(be.tensors[k].cpu().numpy() - oracle.t[k])
-            assert d.max() <= 3 and (d > 0).mean() < 0.1, "%s: auto_warmup drifted" % where
+            assert d.max() <= 3 and (d > 0).mean() < 0.25, "%s: auto_warmup drifted" % where
             continue
         if k == "auto_warmup":
             continue
@@ -153,7 +153,7 @@ def _compare_all(be, oracle, where, fields=None):
                 np.testing.assert_allclose(got, want, rtol=OBS_TOL, atol=OBS_TOL, err_msg="%s: %s" % (where, k))
 
 
-def _compare_metrics(env, oracle, where):
+def _compare_metrics(env, oracle, where, require_trade_tax=True):
     """env.metrics (scenario + component metrics, one array over replicas per key) from the
     device state against the same formulas on the oracle's state."""
     from ai_economist_amd.foundation.metrics import env_metrics
@@ -161,7 +161,8 @@ def _compare_metrics(env, oracle, where):
     got = env.metrics
     want = env_metrics(env, dict(oracle.t))
     assert sorted(got) == sorted(want)
-    assert any(k.startswith("Trade/") for k in got) and "PeriodicTax/avg_effective_tax_rate" in got
+    if require_trade_tax:
+        assert any(k.startswith("Trade/") for k in got) and "PeriodicTax/avg_effective_tax_rate" in got
     for k, v in want.items():
         if k == "labor/warmup_integrator":
             continue  # float-derived counter, see _compare_all
@@ -347,6 +348,44 @@ OSE_VARIANTS = {
                                      planner_reward_type="coin_eq_times_productivity", isoelastic_eta=0.4),
     "no_first_step_mask_128ag": dict(n_agents=128, labor_kw=dict(mask_first_step=False)),
 }
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_hip_matches_oracle_on_random_configs(seed):
+    """helpers.random_gtb_config: the same randomly drawn configurations the reference-marked
+    CPU test pins against the live reference (seeds 0..23 there), HIP vs oracle, two episodes."""
+    import torch
+    from helpers import oracle_host_pre_reset, random_gtb_config
+    from oracle_lib import OracleEnv
+
+    cfg = random_gtb_config(seed)
+    np.random.seed(500 + seed)
+    E = 24
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(3)
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(3)
+    env.reset()
+    oracle_host_pre_reset(env, oracle)
+    oracle.reset()
+    where0 = "random config %d" % seed
+    _compare_all(be, oracle, where0 + " reset")
+    T = cfg["episode_length"]
+    for t in range(2 * T + 5):
+        a, p = be.sample_random_actions(seed=17)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+        if (t + 1) % 9 == 0 or (t + 1) % T == 0:
+            _compare_all(be, oracle, "%s step %d" % (where0, t + 1))
+        if (t + 1) % T == 0:
+            assert bool(be.tensors["done"].all())
+            _compare_metrics(env, oracle, "%s step %d" % (where0, t + 1), require_trade_tax=False)
+            env.reset(be.tensors["done"])
+            oracle_host_pre_reset(env, oracle)
+            oracle.reset(oracle.t["done"].copy())
+            _compare_all(be, oracle, "%s reset after step %d" % (where0, t + 1))
 
 
 @pytest.mark.parametrize("variant", sorted(OSE_VARIANTS))

@@ -164,6 +164,57 @@ def test_oracle_tracks_live_reference(variant):
             check("%s reset after step %d" % (variant, t + 1), obs)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_oracle_tracks_live_reference_random_configs(seed):
+    """Randomly drawn valid configurations (helpers.random_gtb_config): same side-by-side check."""
+    from helpers import oracle_host_pre_reset, random_gtb_config
+    from oracle_lib import OracleEnv
+    from ref_extract import extract_obs, extract_state, rewards_array
+
+    cfg = random_gtb_config(seed)
+    np.random.seed(500 + seed)  # pareto/lognormal skill draws etc. come from the global stream
+    ref = _ref_env(cfg)
+    host = make_env(cfg)
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    np.random.seed(31 + seed)
+    st = np.random.get_state()
+    o.t["mt"][0] = st[1]
+    o.t["mt_pos"][0] = st[2]
+    obs = ref.reset()
+    oracle_host_pre_reset(host, o)
+    o.reset()
+    rng = np.random.RandomState(5)
+    multi_a, multi_p = cfg["multi_action_mode_agents"], cfg["multi_action_mode_planner"]
+
+    def check(where, obs, rew=None):
+        compare_state({k: v[0] for k, v in o.t.items()}, extract_state(ref), where=where, f64_tol=1e-9)
+        assert np.array_equal(o.t["mt"][0], np.random.get_state()[1]), where + ": MT19937 state"
+        for k, want in extract_obs(ref, obs).items():
+            got = o.t[k][0]
+            if want.dtype.kind in "iu":
+                assert np.array_equal(got, want), "%s: obs %s" % (where, k)
+            else:
+                np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6, err_msg="%s: obs %s" % (where, k))
+        if rew is not None:
+            got = np.concatenate([o.t["rewards_a"][0], o.t["rewards_p"][[0]]])
+            np.testing.assert_allclose(got, rewards_array(ref, rew), rtol=0, atol=1e-5, err_msg=where)
+        check_metrics(ref, host, o, where)
+
+    where0 = "random config %d %r" % (seed, cfg)
+    check(where0 + " reset", obs)
+    for t in range(2 * cfg["episode_length"] + 7):
+        acts, aa, pa = _random_actions(ref, rng, multi_a, multi_p)
+        obs, rew, done, _ = ref.step(acts)
+        o.step(aa[None], pa[None])
+        check("%s step %d" % (where0, t + 1), obs, rew)
+        assert bool(o.t["done"][0]) == bool(done["__all__"])
+        if done["__all__"]:
+            obs = ref.reset()
+            oracle_host_pre_reset(host, o)
+            o.reset()
+            check("%s reset after step %d" % (where0, t + 1), obs)
+
+
 OSE_VARIANTS = {
     "c5_default": dict(n_agents=100),
     "coin_eq_40": dict(n_agents=40, planner_reward_type="coin_eq_times_productivity", mixing_weight_gini_vs_coin=0.25),
