@@ -78,6 +78,13 @@ class PeriodicBracketTax(BaseComponent):
             self.n_brackets = len(self.bracket_cutoffs)
             self.top_bracket_cutoff = float(self.bracket_cutoffs[-1])
         assert self.bracket_cutoffs[0] == 0
+        if self.tax_model == "model_wrapper" and not self.disable_taxes and \
+                len({int(c) for c in self.bracket_cutoffs}) < len(self.bracket_cutoffs):
+            # The reference names the planner's action subspaces "TaxIndexBracket_%03d" % int(cutoff)
+            # (redistribution.py:331-337): brackets whose cutoffs share an integer part would silently
+            # share one action there.  Refuse instead of reproducing that.
+            raise ValueError("bracket cutoffs {} collide after int(): choose a smaller usd_scaling / other "
+                             "spacing".format([float(c) for c in self.bracket_cutoffs]))
 
         if self.tax_model == "us-federal-single-filer-2018-scaled":
             assert self.bracket_spacing == "us-federal"

@@ -190,3 +190,65 @@ def random_gtb_config(seed):
     rng.shuffle(comps)
     cfg["components"] = comps
     return cfg
+
+
+def random_ose_config(seed):
+    """A random valid one-step-economy configuration (deterministic in `seed`)."""
+    rng = np.random.RandomState(2000 + seed)
+    pick = lambda xs: xs[rng.randint(len(xs))]  # noqa: E731
+    n = int(pick([2, 5, 17, 33, 64, 100, 128]))
+    tax = dict(period=int(pick([1, 1, 2])), disable_taxes=bool(rng.rand() < 0.1))
+    model = pick(["model_wrapper", "model_wrapper", "us-federal-single-filer-2018-scaled", "fixed-bracket-rates"])
+    tax["tax_model"] = model
+    tax["bracket_spacing"] = "us-federal" if model != "fixed-bracket-rates" or rng.rand() < 0.5 else pick(["linear", "log"])
+    if tax["bracket_spacing"] != "us-federal":
+        tax.update(n_brackets=int(pick([3, 6])), top_bracket_cutoff=float(pick([50, 200])))
+    if model == "model_wrapper":
+        tax["rate_disc"] = float(pick([0.05, 0.1]))
+        tax["usd_scaling"] = float(pick([1000.0, 500.0]))
+    if model == "fixed-bracket-rates":
+        nb = 7 if tax["bracket_spacing"] == "us-federal" else tax["n_brackets"]
+        tax["fixed_bracket_rates"] = [round(float(x), 3) for x in np.sort(rng.rand(nb))]
+    if rng.rand() < 0.25:
+        tax["tax_annealing_schedule"] = [int(pick([-1, 0])), float(pick([0.2, 0.5]))]
+    labor = dict(mask_first_step=bool(rng.rand() < 0.7), payment_max_skill_multiplier=int(pick([2, 3])),
+                 pareto_param=float(pick([3.0, 4.0])))
+    comps = [["SimpleLabor", labor], ["PeriodicBracketTax", tax]]
+    if rng.rand() < 0.3:
+        comps = comps[::-1]
+    cfg = dict(scenario_name="one-step-economy", world_size=[1, 1], n_agents=n, episode_length=int(pick([1, 2, 5])),
+               components=comps, multi_action_mode_planner=bool(rng.rand() < 0.7),
+               allow_observation_scaling=bool(rng.rand() < 0.8),
+               agent_reward_type=pick(["coin_minus_labor_cost", "isoelastic_coin_minus_labor"]),
+               isoelastic_eta=float(pick([0.0, 0.23, 0.6])), labor_exponent=float(pick([1.5, 2.0, 3.5])),
+               labor_cost=float(pick([0.5, 1.0])),
+               planner_reward_type=pick(["coin_eq_times_productivity", "inv_income_weighted_utility"]),
+               mixing_weight_gini_vs_coin=float(pick([0.0, 0.4])))
+    return cfg
+
+
+def random_covid_config(seed):
+    """A random valid CovidAndEconomySimulation configuration (dates within the complete part
+    of the real-world tables)."""
+    rng = np.random.RandomState(3000 + seed)
+    pick = lambda xs: xs[rng.randint(len(xs))]  # noqa: E731
+    start = pick(["2020-02-25", "2020-03-22", "2020-05-01", "2020-08-15", "2020-11-01"])
+    vac = {"2020-02-25": "2020-03-20", "2020-03-22": "2020-05-01", "2020-05-01": "2020-05-11",
+           "2020-08-15": "2021-01-12", "2020-11-01": "2020-11-20"}[start]
+    return dict(
+        collate_agent_step_and_reset_data=True,
+        components=[("ControlUSStateOpenCloseStatus", {"action_cooldown_period": int(pick([1, 7, 28]))}),
+                    ("FederalGovernmentSubsidy", {"num_subsidy_levels": int(pick([5, 20])),
+                                                  "subsidy_interval": int(pick([7, 30, 90])),
+                                                  "max_annual_subsidy_per_person": float(pick([5000, 20000]))}),
+                    ("VaccinationCampaign", {"daily_vaccines_per_million_people": int(pick([1000, 4500])),
+                                             "delivery_interval": int(pick([1, 3, 7])),
+                                             "vaccine_delivery_start_date": vac})],
+        economic_reward_crra_eta=float(pick([0.5, 2, 3.5])), episode_length=int(pick([40, 75])),
+        flatten_masks=True, flatten_observations=False,
+        health_priority_scaling_agents=float(pick([0.3, 1, 2.5])), health_priority_scaling_planner=float(pick([0.45, 1])),
+        infection_too_sick_to_work_rate=float(pick([0.05, 0.1, 0.3])), multi_action_mode_agents=False,
+        multi_action_mode_planner=False, n_agents=51, path_to_data_and_fitted_params="",
+        pop_between_age_18_65=float(pick([0.5, 0.6])), risk_free_interest_rate=float(pick([0.0, 0.03, 0.1])),
+        reward_normalization_factor=float(pick([1, 4])), world_size=[1, 1], start_date=start,
+        use_real_world_data=False, use_real_world_policies=False)

@@ -192,6 +192,53 @@ def test_covid_hip_matches_oracle_on_batched_rollouts(name, E, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_covid_hip_matches_oracle_on_random_configs(seed):
+    """helpers.random_covid_config (seeds 0..7 are pinned against the live reference on CPU):
+    HIP vs oracle over a whole episode, then a masked reset and a few more days."""
+    import torch
+    from helpers import random_covid_config
+
+    cfg = random_covid_config(seed)
+    E = 12
+    env = hip_env(cfg, n_envs=E)
+    o = make_oracle(cfg, n_envs=E)
+    env.reset()
+    o.reset()
+    t = env.tensors
+    rng = np.random.RandomState(seed)
+    ns = dict(cfg["components"])["FederalGovernmentSubsidy"]["num_subsidy_levels"]
+
+    def compare(where):
+        st = o.state()
+        for k, tol in STATE_TOL.items():
+            np.testing.assert_allclose(t[k].cpu().numpy().astype(np.float64), st[k], rtol=tol, atol=1e-3,
+                                       err_msg="%s %s %r" % (where, k, cfg))
+        assert np.array_equal(t["cooldown_until"].cpu().numpy(), st["cooldown_until"]), where
+        for k, v in o.observe().items():
+            np.testing.assert_allclose(t[k].cpu().numpy().reshape(v.shape), v, rtol=1e-5, atol=1e-6,
+                                       err_msg="%s %s" % (where, k))
+
+    compare("reset")
+    T = cfg["episode_length"]
+    for k in range(1, T + 1):
+        a = rng.randint(0, 11, size=(E, 51)).astype(np.int32)
+        a[rng.rand(E, 51) < 0.5] = 0
+        p = rng.randint(0, ns + 1, size=(E,)).astype(np.int32)
+        env.step({"a": torch.as_tensor(a, device="cuda"), "p": torch.as_tensor(p[:, None], device="cuda")})
+        o.step(a, p)
+        np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), o.rew_a, rtol=0, atol=2e-5, err_msg="step %d" % k)
+        np.testing.assert_allclose(t["rewards_p"].cpu().numpy(), o.rew_p, rtol=0, atol=2e-5, err_msg="step %d" % k)
+        assert np.array_equal(t["done"].cpu().numpy(), o.done), "done at step %d" % k
+        if k % 15 == 0 or k == T:
+            compare("step %d" % k)
+    assert bool(t["done"].all())
+    env.reset(t["done"])
+    o.reset()
+    compare("second reset")
+
+
+@pytest.mark.gpu
 def test_covid_masked_reset_and_config_errors():
     import torch
 

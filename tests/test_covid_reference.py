@@ -172,3 +172,44 @@ def test_oracle_tracks_live_reference_covid(start_date, steps):
         check("step %d" % (t + 1), obs, oo, rew)
         if (t + 1) % 50 == 0 or t + 1 == steps:
             check_metrics("step %d" % (t + 1))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_oracle_and_host_model_track_live_reference_random_covid_configs(seed):
+    """Random scenario / component kwargs (helpers.random_covid_config): the NumPy oracle, driven by
+    the PRODUCT's host-side model builder, against the live reference for a whole episode + reset."""
+    from helpers import random_covid_config
+    from test_covid_golden import make_oracle
+
+    cfg = random_covid_config(seed)
+    env = ref_env(**cfg)
+    obs = env.reset()
+    o = make_oracle(cfg, n_envs=1)
+    oo = o.reset()
+    rng = np.random.RandomState(seed)
+    ns = dict(cfg["components"])["FederalGovernmentSubsidy"]["num_subsidy_levels"]
+
+    def check(where, obs, oo, rew=None):
+        for grp in ("a", "p"):
+            for k, v in obs[grp].items():
+                if k == "world-agent_index":
+                    continue
+                np.testing.assert_allclose(oo["obs_%s_%s" % (grp, k)][0], np.asarray(v, np.float64), rtol=2e-6, atol=1e-7,
+                                           err_msg="%s obs %s/%s %r" % (where, grp, k, cfg))
+        if rew is not None:
+            np.testing.assert_allclose(o.rew_a[0], np.asarray(rew["a"], np.float64), rtol=1e-6, atol=1e-7, err_msg=where)
+            np.testing.assert_allclose(o.rew_p[0], float(rew["p"]), rtol=1e-6, atol=1e-7, err_msg=where)
+
+    check("reset", obs, oo)
+    T = cfg["episode_length"]
+    for t in range(T):
+        a = rng.randint(0, 11, size=51)
+        a[rng.rand(51) < 0.5] = 0
+        p = int(rng.randint(0, ns + 1))
+        acts = {str(i): int(a[i]) for i in range(51)}
+        acts["p"] = p
+        obs, rew, done, _ = env.step(acts)
+        oo = o.step(a[None], np.array([p]))
+        check("step %d" % (t + 1), obs, oo, rew)
+        assert bool(done["__all__"]) == bool(o.done[0]) == (t + 1 == T)
+    check("second reset", env.reset(), o.reset())

@@ -278,3 +278,60 @@ def test_oracle_tracks_live_reference_one_step_economy(variant):
             obs = ref.reset()
             o.reset()
             check("%s reset after step %d" % (variant, t + 1), obs)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_oracle_tracks_live_reference_random_one_step_economy(seed):
+    from helpers import random_ose_config
+    from oracle_lib import OracleEnv
+    from ref_extract import extract_obs, extract_state, rewards_array
+
+    cfg = random_ose_config(seed)
+    np.random.seed(77 + seed)
+    ref = _ref_env(cfg)
+    for comp in cfg["components"]:  # SimpleLabor's skills come from the global stream at construction
+        if comp[0] == "SimpleLabor":
+            comp[1]["skills"] = [float(x) for x in ref.get_component("SimpleLabor").skills]
+    host = make_env(cfg)
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    np.random.seed(5)
+    st = np.random.get_state()
+    o.t["mt"][0] = st[1]
+    o.t["mt_pos"][0] = st[2]
+    obs = ref.reset()
+    o.reset()
+    rng = np.random.RandomState(8)
+    n = cfg["n_agents"]
+    pl = ref.world.planner
+    names = [nm for nm in pl._action_names if nm != "PassiveAgentPlaceholder"]
+
+    def check(where, obs, rew=None):
+        compare_state({k: v[0] for k, v in o.t.items()}, extract_state(ref), where=where, f64_tol=1e-9)
+        assert np.array_equal(o.t["mt"][0], np.random.get_state()[1]), where + ": MT19937 state"
+        for k, want in extract_obs(ref, obs).items():
+            np.testing.assert_allclose(o.t[k][0], want, rtol=2e-6, atol=2e-6, err_msg="%s: obs %s" % (where, k))
+        if rew is not None:
+            got = np.concatenate([o.t["rewards_a"][0], o.t["rewards_p"][[0]]])
+            np.testing.assert_allclose(got, rewards_array(ref, rew), rtol=2e-7, atol=1e-5, err_msg=where)
+        check_metrics(ref, host, o, where)
+
+    where0 = "random one-step-economy %d %r" % (seed, cfg)
+    check(where0 + " reset", obs)
+    for t in range(3 * cfg["episode_length"] + 1):
+        aa = rng.randint(0, 101, size=(n, 1)).astype(np.int32)
+        acts = {str(i): int(aa[i, 0]) for i in range(n)}
+        if not names:
+            pa = np.zeros(1, np.int32)
+        elif cfg["multi_action_mode_planner"]:
+            pa = rng.randint(0, pl.action_dim[names[0]], size=len(names)).astype(np.int32)
+            acts["p"] = [int(x) for x in pa]
+        else:
+            pa = np.array([rng.randint(0, pl.action_spaces)], np.int32)
+            acts["p"] = int(pa[0])
+        obs, rew, done, _ = ref.step(acts)
+        o.step(aa[None], pa[None])
+        check("%s step %d" % (where0, t + 1), obs, rew)
+        if done["__all__"]:
+            obs = ref.reset()
+            o.reset()
+            check("%s reset after step %d" % (where0, t + 1), obs)
