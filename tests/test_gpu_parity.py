@@ -430,6 +430,43 @@ def test_hip_matches_oracle_one_step_economy(variant):
             _compare_all(be, oracle, "%s reset after step %d" % (variant, t + 1))
 
 
+@pytest.mark.parametrize("seed", [1, 3, 4, 9])
+def test_partial_resets_mid_episode(seed):
+    """reset(env_mask) of an arbitrary subset of replicas in the middle of an episode (what a
+    vectorised trainer does with `done`, F/env_wrapper.py:341-353), incl. scenarios whose reset has
+    a host-side part: the untouched replicas must not notice, the reset ones restart exactly."""
+    import torch
+    from helpers import oracle_host_pre_reset, random_gtb_config
+    from oracle_lib import OracleEnv
+
+    cfg = random_gtb_config(seed)
+    np.random.seed(500 + seed)
+    E = 20
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(11)
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(11)
+    env.reset()
+    oracle_host_pre_reset(env, oracle)
+    oracle.reset()
+    rng = np.random.RandomState(seed)
+    for t in range(36):
+        a, p = be.sample_random_actions(seed=5)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+        if t in (7, 19, 20):
+            mask = (rng.rand(E) < 0.4).astype(np.uint8)
+            env.reset(torch.as_tensor(mask, device="cuda"))
+            oracle_host_pre_reset(env, oracle, which=np.nonzero(mask)[0])
+            oracle.reset(mask)
+            _compare_all(be, oracle, "partial reset after step %d" % (t + 1))
+    _compare_all(be, oracle, "end")
+    ts = be.tensors["timestep"].cpu().numpy()
+    assert len(set(ts.tolist())) > 1  # replicas really are at different points of their episodes
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_hip_matches_oracle_on_random_one_step_economy_configs(seed):
     """helpers.random_ose_config (seeds 0..11 are pinned against the live reference on CPU)."""
