@@ -26,6 +26,7 @@
 #include "aie_layout.h"
 
 #define AIE_NT 64  // threads per replica (one wavefront)
+#define AIE_DIRTY_CAP 64  // map cells one step may change before the incremental map observations give up (= one lane each)
 #define AIE_SRC_CAP 256  // source-block doubles handled by the gather regen (else row regen)
 
 namespace aie {
@@ -44,6 +45,7 @@ struct Ctx {
   uint16_t* srcl;    // LDS [AIE_SRC_CAP] regen doubles that target a source block
   int32_t* srcn;     // LDS [1] number of source doubles found (may exceed AIE_SRC_CAP)
   int32_t* mflags;   // LDS [n] per-agent mask bits
+  int32_t* dirty;    // LDS [4 + AIE_DIRTY_CAP/2]: count, moved-agent mask (2 words), pad, uint16 cell list
   uint8_t* met;      // GLOBAL: this replica's episode accumulators (aie_layout.h: a_metrics), or nullptr
   int tid;
   int e;
@@ -84,6 +86,7 @@ __host__ __device__ inline size_t lds_bytes(const aie_params& P) {
   b += (size_t)fscr_doubles(P) * 8;
   b += stage_bytes(P);
   b += AIE_SRC_CAP * 2 + 16 + (size_t)pad4(P.n) * 4;
+  b += 16 + AIE_DIRTY_CAP * 2;
   return (b + 15) / 16 * 16;
 }
 
@@ -103,8 +106,10 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e
   int32_t* srcn = reinterpret_cast<int32_t*>(q);
   q += 16;
   int32_t* mflags = reinterpret_cast<int32_t*>(q);
+  q += pad4(P.n) * 4;
+  int32_t* dirty = reinterpret_cast<int32_t*>(q);
   uint8_t* met = arena ? arena + P.a_metrics + (int64_t)e * P.met_bytes : nullptr;
-  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, met, tid, e};
+  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, met, tid, e};
 }
 
 // ------------------------------------------------------------------------------------
@@ -590,6 +595,32 @@ __device__ __forceinline__ void decode_actions(const Ctx& c, Agents& A, const in
 }
 
 // ------------------------------------------------------------------------------------
+// Change log of one step.  The map observations (egocentric crops, planner map: 85 % of a
+// step's output bytes) live in the arena from one step to the next, and a step changes only a
+// handful of map cells, so the step kernel rewrites just those (update_spatial_observations)
+// instead of all of them.  Every map cell whose packed word or occupant changes is appended
+// to a short LDS list, every agent that moves gets a bit in the moved mask; a list overflow
+// makes the step fall back to the full rewrite.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t* dirty_list(const Ctx& c) { return reinterpret_cast<uint16_t*>(c.dirty + 4); }
+// wave-uniform call site (all lanes pass the same cell): lane 0 appends
+__device__ __forceinline__ void dirty_add_uniform(const Ctx& c, int cell) {
+  if (c.tid == 0) {
+    const int s = c.dirty[0];
+    if (s < AIE_DIRTY_CAP) dirty_list(c)[s] = (uint16_t)cell;
+    c.dirty[0] = s + 1;
+  }
+}
+// divergent call site (each active lane its own cell)
+__device__ __forceinline__ void dirty_add_lane(const Ctx& c, int cell) {
+  const int s = atomicAdd(&c.dirty[0], 1);
+  if (s < AIE_DIRTY_CAP) dirty_list(c)[s] = (uint16_t)cell;
+}
+__device__ __forceinline__ void dirty_agent_moved(const Ctx& c, int i) {
+  if (c.tid == 0) c.dirty[1 + (i >> 5)] |= 1 << (i & 31);
+}
+
+// ------------------------------------------------------------------------------------
 // Build.component_step, F/components/build.py:112-161.  Wave-uniform control flow; the
 // builders are found with one ballot, so the common "nobody builds" step costs only the
 // permutation draw (which the reference consumes regardless, build.py:121).
@@ -616,6 +647,7 @@ __device__ __forceinline__ void build_component_step(const Ctx& c, MTL& m, Agent
       A.labor += c.P.c.build_labor;
     }
     cells[cell] = (w & 0xff00ffffu) | ((uint32_t)i << 16);  // world.py:474-479 (every lane, same value)
+    dirty_add_uniform(c, cell);
   }
 }
 
@@ -644,6 +676,9 @@ __device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agen
         if (!(AIE_CELL_FLAGS(tw) & AIE_CELL_WATER) && (own < 0 || own == i) && occ == 0) {
           c.locmap[land] = 0;
           c.locmap[tcell] = (uint8_t)(i + 1);
+          dirty_add_uniform(c, land);
+          dirty_add_uniform(c, tcell);
+          dirty_agent_moved(c, i);
           if (lane == i) {
             A.lr = nr;
             A.lc = nc;
@@ -671,6 +706,7 @@ __device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agen
         }
       }
       cells[land] = w;
+      dirty_add_uniform(c, land);
     }
   }
 }
@@ -1033,7 +1069,10 @@ __device__ __forceinline__ void regen_cell(const Ctx& c, uint32_t ta, uint32_t t
     const uint32_t mval = cb[rs];
     const uint32_t health = mval > 1u ? mval : 1u;  // max(map, source block = 1)
     const double u = u53(ta, tb);
-    if (u < c.P.c.regen_weight[rs] * (double)health && mval < (uint32_t)c.P.c.max_health[rs]) cb[rs] = (uint8_t)(mval + 1);
+    if (u < c.P.c.regen_weight[rs] * (double)health && mval < (uint32_t)c.P.c.max_health[rs]) {
+      cb[rs] = (uint8_t)(mval + 1);
+      dirty_add_lane(c, cell);
+    }
   }
 }
 __device__ __forceinline__ void scenario_step_regen_rows(const Ctx& c, MT& m) {
@@ -1428,9 +1467,65 @@ __device__ __forceinline__ void write_spatial_observations_t(const Ctx& c, uint8
   }
 }
 
+// one cell of agent i's whole-map observation (full_observability, layout_from_file.py:466-472)
+template <bool WATER>
+__device__ __forceinline__ void agent_full_cell(const Ctx& c, const SpatialOut& o, int i, int cell) {
+  constexpr int CM = WATER ? 6 : 5;
+  const int HW = c.P.HW;
+  const int so = i * CM * HW * 4, si = i * 2 * HW * 2;
+  float ch[6];
+  const uint32_t cw = R_CELLS(c)[cell];
+  cell_channels<WATER>(cw, ch);
+#pragma unroll
+  for (int k = 0; k < CM; ++k) buf_store_f32(o.amap, ch[k], 4 * cell, so + k * HW * 4);
+  const int own = AIE_CELL_OWNER(cw);
+  int v0 = own >= 0 ? own + 2 : 0;
+  const int occ = c.locmap[cell];
+  int v1 = occ ? occ + 1 : 0;
+  if (v0 == i + 2) v0 = 1;
+  if (v1 == i + 2) v1 = 1;
+  buf_store_i16(o.aidx, v0, 2 * cell, si);
+  buf_store_i16(o.aidx, v1, 2 * cell, si + HW * 2);
+}
+
+// Incremental form of write_spatial_observations: the tensors still hold the previous step's
+// values; rewrite the crops of the agents that moved and every item that shows one of the
+// cells the dynamics logged (dirty_*).  One lane per logged cell.
+template <bool WATER>
+__device__ __forceinline__ void update_spatial_observations_t(const Ctx& c, uint8_t* __restrict__ arena) {
+  const int n = c.P.n, W = c.P.W, WV = c.P.WV, w = c.P.c.obs_range;
+  const int cnt = uni(c.dirty[0]);
+  if (cnt > AIE_DIRTY_CAP) {  // log overflow: start over
+    write_spatial_observations_t<WATER>(c, arena);
+    return;
+  }
+  const SpatialOut o = spatial_out<WATER>(c, arena);
+  const uint32_t mv0 = (uint32_t)uni(c.dirty[1]), mv1 = (uint32_t)uni(c.dirty[2]);
+  const uint16_t* dl = dirty_list(c);
+  const int cell = c.tid < cnt ? (int)dl[c.tid] : -1;  // AIE_DIRTY_CAP == wave size
+  const int r = cell >= 0 ? udiv(cell, W, c.P.mg_W) : 0, col = cell - r * W;
+  for (int i = 0; i < n; ++i) {
+    if (c.P.c.full_observability) {
+      if (cell >= 0) agent_full_cell<WATER>(c, o, i, cell);
+      continue;
+    }
+    const bool moved = ((i < 32 ? mv0 >> i : mv1 >> (i - 32)) & 1u) != 0;
+    if (moved) {
+      crop_agent<WATER>(c, o, i);
+    } else if (cell >= 0) {
+      const int dr = r - (R_I32(c, o_loc_r)[i] - w), dc = col - (R_I32(c, o_loc_c)[i] - w);
+      if (dr >= 0 && dr < WV && dc >= 0 && dc < WV) crop_item<WATER>(c, o, i, dr * WV + dc, r, col);
+    }
+  }
+  if (c.P.c.planner_gets_spatial_info && cell >= 0) planner_cell<WATER>(c, o, cell);
+}
 __device__ __forceinline__ void write_spatial_observations(const Ctx& c, uint8_t* __restrict__ arena) {
   if (c.P.c.has_water) write_spatial_observations_t<true>(c, arena);
   else write_spatial_observations_t<false>(c, arena);
+}
+__device__ __forceinline__ void update_spatial_observations(const Ctx& c, uint8_t* __restrict__ arena) {
+  if (c.P.c.has_water) update_spatial_observations_t<true>(c, arena);
+  else update_spatial_observations_t<false>(c, arena);
 }
 
 // Component + scalar observations, packed in SORTED key order (base_env.py:561-612):
@@ -1711,7 +1806,12 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   Agents A;
   const int skip = P.dev_skip_mask;
   if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x] = wall_clock64();
-  if (threadIdx.x == 0) *c.srcn = 0;
+  if (threadIdx.x == 0) {
+    *c.srcn = 0;
+    c.dirty[0] = 0;
+    c.dirty[1] = 0;
+    c.dirty[2] = 0;
+  }
   __syncthreads();
   if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
   load_record(c, arena, m, wid, NW, /*key_to_lds=*/true);
@@ -1765,7 +1865,13 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     }
   }
   if (NW == 1 || wid == 1) {
-    if (!(skip & 4)) write_spatial_observations(c, arena);
+    if (!(skip & 4)) {
+      // the map observations of the previous step are still in the arena: update them in place,
+      // unless something outside the kernels touched the state (obs_valid == 0)
+      if (uni(*R_I32(c, o_obs_valid)) && !(skip & 32768)) update_spatial_observations(c, arena);
+      else write_spatial_observations(c, arena);
+      if (c.tid == 0) *R_I32(c, o_obs_valid) = 1;
+    }
     if (!(skip & 8)) write_action_masks(c, arena);
     if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
   }
@@ -1943,6 +2049,7 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   if (tid <= n) R_F64(c, o_util)[tid] = scr_part(c)[tid];
   __syncthreads();
   write_spatial_observations(c, arena);
+  if (tid == 0) *R_I32(c, o_obs_valid) = 1;
   write_flat_observations(c, arena);
   AIE_WSYNC();
   if (P.has_tax && P.c.tax_annealing && tid == 0) *R_I32(c, o_tax_last_completions) = *R_I32(c, o_completions);  // generate_masks :1036-1046

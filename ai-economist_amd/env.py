@@ -203,9 +203,19 @@ class DeviceBackend:
         self._check(self.lib.aie_download(self.handle, name.encode(), arr.ctypes.data, arr.nbytes))
         return arr
 
+    def invalidate_observations(self, e=None):
+        """Call after editing state tensors from outside the kernels: the next step rewrites the
+        map observations in full instead of updating them in place (`obs_valid`)."""
+        if "obs_valid" in self.tensors:
+            if e is None:
+                self.tensors["obs_valid"].zero_()
+            else:
+                self.tensors["obs_valid"][e] = 0
+
     def load_state(self, state, e=None):
         """Injects a host state ({field: array without env dim}) into replica e (or all)."""
         torch = _torch()
+        self.invalidate_observations(e)
         for k, v in state.items():
             if k in ("stone_src", "wood_src", "water"):
                 continue

@@ -964,6 +964,7 @@ static void step_one(const aie_params* p, uint8_t* arena, int e, const int32_t* 
   }
   scenario_step(&c);
   write_obs(&c);
+  *I32(&c, o_obs_valid) = 1; /* device bookkeeping (incremental map observations); always full here */
   write_masks(&c);
   write_rewards(&c);
   int done = *I32(&c, o_timestep) >= p->c.episode_length;
@@ -1090,6 +1091,7 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
   }
   current_metrics(&c, F64(&c, o_util));
   write_obs(&c);
+  *I32(&c, o_obs_valid) = 1;
   if (p->has_tax && p->c.tax_annealing) *I32(&c, o_tax_last_completions) = *I32(&c, o_completions); /* generate_masks :1036-1046 */
   write_masks(&c);
   float* ra = (float*)(arena + p->a_rew_a) + (int64_t)e * n;
