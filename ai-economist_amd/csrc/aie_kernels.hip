@@ -1856,13 +1856,6 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (wid == 0) {
     if (!(skip & 8)) write_flat_observations(c, arena);
     if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
-    if (!(skip & 16)) compute_rewards(c, arena);
-    AIE_WSYNC();
-    if (c.tid == 0) {
-      const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
-      (arena + P.a_done)[c.e] = (uint8_t)done;
-      if (done) *R_I32(c, o_completions) += 1;
-    }
   }
   if (NW == 1 || wid == 1) {
     if (!(skip & 4)) {
@@ -1873,6 +1866,13 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       if (c.tid == 0) *R_I32(c, o_obs_valid) = 1;
     }
     if (!(skip & 8)) write_action_masks(c, arena);
+    if (!(skip & 16)) compute_rewards(c, arena);
+    AIE_WSYNC();
+    if (c.tid == 0) {
+      const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
+      (arena + P.a_done)[c.e] = (uint8_t)done;
+      if (done) *R_I32(c, o_completions) += 1;
+    }
     if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
   }
   __syncthreads();
