@@ -192,9 +192,15 @@ def main():
         one_step()
     torch.cuda.synchronize()
     barrier()
+    # one pair of HIP events on the launch stream around the whole timed region: K back-to-back
+    # aie_step_kernel launches (one per step, see aie_step_sample_next) -> average launch period.
+    # (Bracketing every single launch with its own event pair adds ~4 us of queue packets per step.)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         one_step()
+    ev1.record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -203,20 +209,10 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- roofline of the dominant kernel: per-launch HIP-event timing, same stream ----
+    # ---- roofline of the dominant kernel ----
     roof = None
     if rank == 0:
-        nk = 300
-        a, p = be.sample_random_actions(ACTION_SEED, env_offset)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nk)]
-        torch.cuda.synchronize()
-        for s, e in ev:
-            s.record()
-            be.step(a, p)
-            e.record()
-        torch.cuda.synchronize()
-        durs = sorted(s.elapsed_time(e) for s, e in ev)  # ms
-        avg_ms = sum(durs) / len(durs)
+        avg_ms = ev0.elapsed_time(ev1) / args.steps
         b = algorithmic_bytes_per_env_step(be)
         bytes_per_launch = b["total"] * E
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
@@ -225,7 +221,10 @@ def main():
                     frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=bytes_per_launch,
                     algorithmic_bytes_per_agent_step=b["total"] / n, bytes_breakdown_per_env_step=b,
-                    avg_launch_ms=avg_ms, median_launch_ms=durs[len(durs) // 2], launches_timed=nk)
+                    avg_launch_ms=avg_ms, launches_timed=args.steps,
+                    note="achieved = bytes of the reference-format observations + state a step produces / consumes "
+                         "(algorithmic) per launch time; the kernel keeps the map observations in place and rewrites "
+                         "only what a step changes, so the measured HBM traffic is lower than the algorithmic bytes")
 
     if rank == 0:
         agent_steps = world * E * n * args.steps
