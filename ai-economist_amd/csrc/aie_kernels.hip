@@ -72,9 +72,14 @@ __host__ __device__ inline int rec_lds_bytes(const aie_params& P) { return P.o_m
 
 // staging area: small observation vectors; reused as the 624-word MT19937 dump of regen
 __host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline int stage_window_words(const aie_params& P) {
+  const int m = pad4(P.n * P.MA) + pad4(P.MP);
+  return m < AIE_MT_N ? AIE_MT_N : m;
+}
 __host__ __device__ inline size_t stage_bytes(const aie_params& P) {
-  size_t b = (size_t)(pad4(P.n * P.FA) + pad4(P.n * P.MA) + pad4(P.n * P.FPA) + pad4(P.FP) + pad4(P.MP)) * 4;
-  if (b < AIE_MT_N * 4) b = AIE_MT_N * 4;
+  // [0, 624 words): MT19937 window / regeneration dump, later the mask staging;
+  // behind it: the planner's flat vector + per-agent fragments (write_flat_observations)
+  const size_t b = (size_t)(stage_window_words(P) + pad4(P.n * P.FPA) + pad4(P.FP)) * 4;
   return (b + 15) / 16 * 16;
 }
 
@@ -1536,11 +1541,14 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
   const aie_params& P = c.P;
   const int n = P.n, tid = c.tid, Pp = P.P, NB = P.NB;
   const double isc = P.c.allow_observation_scaling ? 0.01 : 1.0;
-  float* s_aflat = c.stage;
-  float* s_amask = s_aflat + pad4(n * P.FA);
-  float* s_pag = s_amask + pad4(n * P.MA);
+  // The agents' vectors (n x FA floats) go straight to HBM through a buffer descriptor; only the
+  // planner's vector (read back by the agents' CDA fragment) and its per-agent fragments are
+  // staged in LDS -- behind the 624-word MT19937 window, which the regeneration may still be
+  // using on the other wave (see step_body).
+  float* s_pag = c.stage + stage_window_words(P);
   float* s_pflat = s_pag + pad4(n * P.FPA);
-  float* s_pmask = s_pflat + pad4(P.FP);
+  const BufRsrc aflat = make_rsrc(arena + P.a_obs_a_flat + (int64_t)c.e * n * P.FA * 4, (uint32_t)(n * P.FA * 4));
+  auto AF = [&](int idx, float v) { buf_store_f32(aflat, v, 4 * idx, 0); };
   const int t = *R_I32(c, o_timestep);
   const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)P.c.episode_length : 1.0));
 
@@ -1568,25 +1576,25 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
   }
   if (tid < n && !(skip & 64)) {
     const int i = tid;
-    float* f = s_aflat + i * P.FA;
+    const int f0 = i * P.FA;
     const double coin = R_F64(c, o_inv_coin)[i];
     const int inv0 = R_I32(c, o_inv_res)[i], inv1 = R_I32(c, o_inv_res)[n + i];
     const int lr = R_I32(c, o_loc_r)[i], lc = R_I32(c, o_loc_c)[i];
     if (P.has_build) {  // build.py:163-178
-      f[P.fa_build + 0] = (float)(R_F64(c, o_build_payment)[i] / (double)P.c.build_payment);
-      f[P.fa_build + 1] = (float)R_F64(c, o_build_skill)[i];
+      AF(f0 + P.fa_build + 0, (float)(R_F64(c, o_build_payment)[i] / (double)P.c.build_payment));
+      AF(f0 + P.fa_build + 1, (float)R_F64(c, o_build_skill)[i]);
     }
-    if (P.has_gather) f[P.fa_gather] = (float)R_F64(c, o_bonus_gather_prob)[i];  // move.py:155-165
-    f[P.fa_time] = tval;
+    if (P.has_gather) AF(f0 + P.fa_gather, (float)R_F64(c, o_bonus_gather_prob)[i]);  // move.py:155-165
+    AF(f0 + P.fa_time, tval);
     const float w0 = (float)(coin * isc);
     const float w1 = (float)((double)inv0 * isc);
     const float w2 = (float)((double)inv1 * isc);
     const float w3 = (float)((double)lc / (double)P.W);
     const float w4 = (float)((double)lr / (double)P.H);
-    f[P.fa_world + 0] = w0; f[P.fa_world + 1] = w1; f[P.fa_world + 2] = w2;
+    AF(f0 + P.fa_world + 0, w0); AF(f0 + P.fa_world + 1, w1); AF(f0 + P.fa_world + 2, w2);
     float* q = s_pag + i * P.FPA;
     if (!P.c.full_observability) {  // locations and the planner's per-agent fragments: egocentric mode only
-      f[P.fa_world + 3] = w3; f[P.fa_world + 4] = w4;
+      AF(f0 + P.fa_world + 3, w3); AF(f0 + P.fa_world + 4, w4);
       q[P.fpa_world + 0] = w0; q[P.fpa_world + 1] = w1; q[P.fpa_world + 2] = w2;
       if (P.c.planner_gets_spatial_info) { q[P.fpa_world + 3] = w3; q[P.fpa_world + 4] = w4; }
     }
@@ -1602,7 +1610,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
       }
       scr_sorted_inc(c)[rank] = x;
       const double cmr = tax_marginal_rate(c, (coin + R_F64(c, o_esc_coin)[i]) - R_F64(c, o_tax_last_coin)[i]);
-      f[P.fa_tax + NB + 2 + n] = (float)cmr;
+      AF(f0 + P.fa_tax + NB + 2 + n, (float)cmr);
       q[P.fpa_tax + 0] = (float)cmr;
       q[P.fpa_tax + 1] = (float)x;
       q[P.fpa_tax + 2] = (float)R_F64(c, o_tax_last_marginal_rate)[i];
@@ -1628,7 +1636,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
       const double tot = np_sum_small(a, Pp);
       const float mr = (float)(dot / (tot > 0.001 ? tot : 0.001));
       s_pflat[P.fp_cda + 4 * Pp + r] = mr;
-      for (int i = 0; i < n; ++i) s_aflat[i * P.FA + P.fa_cda + 4 * Pp + r] = mr;
+      for (int i = 0; i < n; ++i) AF(i * P.FA + P.fa_cda + 4 * Pp + r, mr);
     }
     const float* g = s_pflat + P.fp_cda;
     for (int it = tid; it < n * 2 * Pp; it += AIE_NT) {
@@ -1637,12 +1645,12 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
       const int r = q >= Pp ? 1 : 0, k = q - r * Pp;
       const float mya = (float)R_U8(c, o_cda_ask_hist)[(r * n + i) * Pp + k];
       const float myb = (float)R_U8(c, o_cda_bid_hist)[(r * n + i) * Pp + k];
-      float* f = s_aflat + i * P.FA + P.fa_cda;
-      f[0 * Pp + q] = g[0 * Pp + q] - mya;  // available_asks
-      f[2 * Pp + q] = g[2 * Pp + q] - myb;  // available_bids
-      f[4 * Pp + 2 + q] = mya;              // my_asks
-      f[6 * Pp + 2 + q] = myb;              // my_bids
-      f[8 * Pp + 2 + q] = g[4 * Pp + 2 + q];  // price_history
+      const int fc = i * P.FA + P.fa_cda;
+      AF(fc + 0 * Pp + q, g[0 * Pp + q] - mya);    // available_asks
+      AF(fc + 2 * Pp + q, g[2 * Pp + q] - myb);    // available_bids
+      AF(fc + 4 * Pp + 2 + q, mya);                // my_asks
+      AF(fc + 6 * Pp + 2 + q, myb);                // my_bids
+      AF(fc + 8 * Pp + 2 + q, g[4 * Pp + 2 + q]);  // price_history
     }
   }
   if (P.has_tax && !(skip & 256)) {
@@ -1668,7 +1676,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
       else if (j < NB + 2 + n) v = (float)scr_sorted_inc(c)[j - NB - 2];
       else v = tax_phase;
       if (planner) s_pflat[P.fp_tax + j] = v;
-      else s_aflat[i * P.FA + P.fa_tax + j] = v;
+      else AF(i * P.FA + P.fa_tax + j, v);
     }
   }
 
@@ -1676,7 +1684,6 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
 
   // ---- stream the staged vectors out: 16-byte LDS reads, dword-aligned 16-byte stores ----
   if (!(skip & 1024)) {
-    stream_out(s_aflat, reinterpret_cast<float*>(arena + P.a_obs_a_flat) + (int64_t)c.e * n * P.FA, n * P.FA, tid);
     stream_out(s_pag, reinterpret_cast<float*>(arena + P.a_obs_p_agents) + (int64_t)c.e * n * P.FPA, n * P.FPA, tid);
     stream_out(s_pflat, reinterpret_cast<float*>(arena + P.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
   }
@@ -1688,8 +1695,10 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
 __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __restrict__ arena) {
   const aie_params& P = c.P;
   const int n = P.n, tid = c.tid, Pp = P.P;
-  float* s_amask = c.stage + pad4(n * P.FA);
-  float* s_pmask = s_amask + pad4(n * P.MA) + pad4(n * P.FPA) + pad4(P.FP);
+  // staged in the MT19937 window area of the staging buffer: free once this wave's regeneration
+  // is done (step kernel) / unused (reset kernel)
+  float* s_amask = c.stage;
+  float* s_pmask = s_amask + pad4(n * P.MA);
   const int skip = P.dev_skip_mask;
   if (skip & 512) return;
   if (tid < n) {
