@@ -262,13 +262,13 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
   m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
 }
 __device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m, int wave = 0,
-                                             int nwaves = 1) {
+                                             int nwaves = 1, int key_wave = 0) {
   uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
   uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
   for (int q = wave * AIE_NT + c.tid; q < nq; q += nwaves * AIE_NT) dst[q] = src[q];
-  if (wave != 0) return;
+  if (wave != key_wave) return;  // the generator's rows are in that wave's registers
   uint32_t* key = reinterpret_cast<uint32_t*>(g + c.P.o_mt);
 #pragma unroll
   for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
@@ -1782,18 +1782,20 @@ __device__ __forceinline__ void rebuild_locmap(const Ctx& c) {
 // components in list order, scenario_step, observations, masks, rewards, done.
 //
 // NW = 2 (default): a replica is a workgroup of TWO wavefronts sharing the LDS record.
-//   both   record HBM -> LDS (alternate 16-byte units)
+//   both   record HBM -> LDS (alternate 16-byte units; the MT19937 key goes to the LDS window)
 //   wave 0 action decode, price-history decay          ||  wave 1 occupancy map
-//   wave 0 components, regeneration                        (wave 1 waits at the barrier)
-//   wave 0 flat observation vectors, rewards, done     ||  wave 1 egocentric crops + planner map,
-//                                                      ||         action masks
-//   both   record LDS -> HBM
-// The two post-dynamics halves only read the record (wave 0 alone updates util / warm-up
-// counters), so they need no synchronisation until the final store.  With <= 64 VGPRs all
-// 2 x 4096 waves of the C2 batch are resident at once (8 per SIMD) instead of 4 per SIMD.
+//   wave 0 components (draws read the LDS window)      ||  wave 1 next step's random actions (opt.)
+//   wave 0 flat observation vectors, rewards, done     ||  wave 1 regeneration (rows in registers,
+//          (none of them looks at the map)             ||         4 twists), incremental map
+//                                                      ||         observations, action masks
+//   both   record LDS -> HBM (wave 1 also the generator's rows)
+// After the components the two halves touch disjoint state: wave 0 reads agents / auction / tax
+// fields and writes util + warm-up counters, wave 1 reads and writes the map cells and the
+// generator.  With <= 64 VGPRs all 2 x 4096 waves of the C2 batch are resident at once (8 per
+// SIMD) instead of 4 per SIMD.
 // (Tried and dropped: writing the map observations speculatively during the dynamics and
-// repairing the changed cells afterwards -- parity-clean, but the extra store traffic slows
-// the serial dynamics of the first wave by as much as it saves.)
+// repairing the changed cells afterwards -- parity-clean, but the co-resident second waves'
+// instruction stream slows the serial dynamics of the first waves by as much as it saves.)
 // NW = 1 is the original one-wave-per-replica schedule (kept for A/B measurements).
 struct NextActions {  // aie_step_sample_next: where and how to sample the next step's random actions
   int32_t* a;
@@ -1851,22 +1853,35 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       }
     }
     agents_store(c, A);
-    AIE_WSYNC();
-    mtl_to_regs(ml, m, c.tid);  // the generator's rows come back into registers for the twists
-    if (!(skip & 2)) scenario_step_regen(c, m, /*win0_in_lds=*/true);
-    if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
-    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
+    if (c.tid == 0) *R_I32(c, o_mt_pos) = ml.pos;
+    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 5] = wall_clock64();
   } else if (next.a || next.p) {
-    // the second wave has nothing to do until the dynamics are done: next step's random actions
+    // the second wave has nothing to do until the components are done: next step's random actions
     const int per_env = P.n * P.act_a_width + P.act_p_width;
     for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, c.e, j, next.a, next.p);
   }
-  __syncthreads();
+  __syncthreads();  // components done; the generator's window (LDS) and position are final
   if (wid == 0) {
+    // first wave: flat observation vectors (they do not look at the map)
     if (!(skip & 8)) write_flat_observations(c, arena);
     if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
+    if (!(skip & 16)) compute_rewards(c, arena);  // utilities do not look at the map either
+    AIE_WSYNC();
+    if (c.tid == 0) {
+      const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
+      (arena + P.a_done)[c.e] = (uint8_t)done;
+      if (done) *R_I32(c, o_completions) += 1;
+    }
   }
   if (NW == 1 || wid == 1) {
+    // second wave: resource regeneration (rows back into registers for the twists), then what
+    // depends on the map: incremental map observations, action masks
+    MTL mw{reinterpret_cast<uint32_t*>(c.stage), uni(*R_I32(c, o_mt_pos))};
+    mtl_to_regs(mw, m, c.tid);
+    if (!(skip & 2)) scenario_step_regen(c, m, /*win0_in_lds=*/true);
+    if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
+    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
+    AIE_WSYNC();
     if (!(skip & 4)) {
       // the map observations of the previous step are still in the arena: update them in place,
       // unless something outside the kernels touched the state (obs_valid == 0)
@@ -1875,17 +1890,10 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       if (c.tid == 0) *R_I32(c, o_obs_valid) = 1;
     }
     if (!(skip & 8)) write_action_masks(c, arena);
-    if (!(skip & 16)) compute_rewards(c, arena);
-    AIE_WSYNC();
-    if (c.tid == 0) {
-      const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
-      (arena + P.a_done)[c.e] = (uint8_t)done;
-      if (done) *R_I32(c, o_completions) += 1;
-    }
     if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
   }
   __syncthreads();
-  if (!(skip & 32)) store_record(c, arena, m, wid, NW);
+  if (!(skip & 32)) store_record(c, arena, m, wid, NW, /*key_wave=*/NW - 1);
   if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 7] = wall_clock64();
 }
 
