@@ -263,16 +263,28 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
   __syncthreads();
   // ---- agent flat vectors: the shared template with two per-agent entries ----
   {
-    float* g = reinterpret_cast<float*>(arena + P.a_obs_a_flat) + (int64_t)c.e * n * P.FA;
+    // n x FA floats, four consecutive elements (possibly straddling two agents) per lane and store
+    const BufRsrc g = make_rsrc(arena + P.a_obs_a_flat + (int64_t)c.e * n * P.FA * 4, (uint32_t)(n * P.FA * 4));
     const int i_mr = P.has_tax ? P.fa_tax + NB + 2 + n : -1;
     const int i_sk = P.has_labor ? P.fa_labor : -1;
-    for (int q = tid; q < n * P.FA; q += AIE_NT) {
-      const int i = udiv(q, P.FA, P.mg_FA);
-      const int j = q - i * P.FA;
+    auto val = [&](int i, int j) {
       float v = s.tmpl_a[j];
       if (j == i_mr) v = (float)s.tmp[i];
       if (j == i_sk) v = (float)(R_F64(c, o_skill)[i] / P.c.labor_pmsm);
-      g[q] = v;
+      return v;
+    };
+    const int tot = n * P.FA;
+    for (int q = 4 * tid; q < tot; q += 4 * AIE_NT) {
+      int i = udiv(q, P.FA, P.mg_FA), j = q - i * P.FA;
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = (q + u < tot) ? val(i, j) : 0.0f;
+        if (++j == P.FA) { j = 0; ++i; }
+      }
+      if (q + 3 < tot) buf_store_f32x4(g, v[0], v[1], v[2], v[3], 4 * q, 0);
+      else
+        for (int u = 0; u < 4 && q + u < tot; ++u) buf_store_f32(g, v[u], 4 * (q + u), 0);
     }
     float* gt = reinterpret_cast<float*>(arena + P.a_obs_a_time) + (int64_t)c.e * n;
     for (int i = tid; i < n; i += AIE_NT) gt[i] = tval;
@@ -294,13 +306,21 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
       if (first && P.c.labor_mask_first_step) on = 0.0f;
     }
     const bool multi = P.c.multi_action_mode_agents != 0;
-    float* g = reinterpret_cast<float*>(arena + P.a_obs_a_mask) + (int64_t)c.e * n * P.MA;
-    for (int q = tid; q < n * P.MA; q += AIE_NT) {
-      const int i = udiv(q, P.MA, P.mg_MA);
-      const int mm = q - i * P.MA;
-      // single-action: [NO-OP, hours...]; multi-action: [NO-OP, hours...] of the only subspace
-      g[q] = (mm == 0 || P.n_sub_a == 0) ? 1.0f : on;
-      (void)multi;
+    // single-action: [NO-OP, hours...]; multi-action: [NO-OP, hours...] of the only subspace
+    const BufRsrc g = make_rsrc(arena + P.a_obs_a_mask + (int64_t)c.e * n * P.MA * 4, (uint32_t)(n * P.MA * 4));
+    const int tot = n * P.MA;
+    (void)multi;
+    for (int q = 4 * tid; q < tot; q += 4 * AIE_NT) {
+      int mm = q - udiv(q, P.MA, P.mg_MA) * P.MA;
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = (mm == 0 || P.n_sub_a == 0) ? 1.0f : on;
+        if (++mm == P.MA) mm = 0;
+      }
+      if (q + 3 < tot) buf_store_f32x4(g, v[0], v[1], v[2], v[3], 4 * q, 0);
+      else
+        for (int u = 0; u < 4 && q + u < tot; ++u) buf_store_f32(g, v[u], 4 * (q + u), 0);
     }
     if (at_reset && P.has_tax && P.c.tax_annealing) {  // generate_masks refreshes _last_completions after the reset's observations
       __syncthreads();
