@@ -5,7 +5,7 @@ by env.py purely as the owner of device memory / streams.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_AGENTS = 64
 MAX_AGENTS_WIDE = 128
 MAX_COMPONENTS = 8
@@ -16,6 +16,9 @@ MT_N = 624
 
 COMP_BUILD, COMP_CDA, COMP_GATHER, COMP_TAX, COMP_SIMPLE_LABOR = 1, 2, 3, 4, 5
 COMP_COVID_CONTROL, COMP_COVID_SUBSIDY, COMP_COVID_VACCINE = 6, 7, 8
+COMP_WEALTH_REDISTRIBUTION = 9
+# flag byte of the packed map cell ("cell_flags" tensor; csrc/aie_layout.h: AIE_CELL_*)
+CELL_WATER, CELL_STONE_SRC, CELL_WOOD_SRC = 1, 2, 4
 SCN_GTB, SCN_ONE_STEP_ECONOMY, SCN_COVID = 0, 1, 2
 COVID_MAX_FILTERS = 8
 MAX_TENSORS = 128  # AIE_MAX_TENSORS (csrc/aie_layout.h)
@@ -116,7 +119,7 @@ class AieConfig(C.Structure):
         ("split_top_ranks", C.c_uint32 * 2),
         ("reserved2_", C.c_int32),
         ("tax_annealing", C.c_int32),
-        ("reserved3_", C.c_int32),
+        ("dense_log_replicas", C.c_int32),
         ("tax_annealing_warmup", C.c_double),
         ("tax_annealing_slope", C.c_double),
         ("tax_rate_max", C.c_double),

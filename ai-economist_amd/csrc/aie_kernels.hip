@@ -47,6 +47,7 @@ struct Ctx {
   int32_t* mflags;   // LDS [n] per-agent mask bits
   int32_t* dirty;    // LDS [4 + AIE_DIRTY_CAP/2]: count, moved-agent mask (2 words), pad, uint16 cell list
   uint8_t* met;      // GLOBAL: this replica's episode accumulators (aie_layout.h: a_metrics), or nullptr
+  int32_t* ev;       // GLOBAL: this replica's dense-log event rows (a_events), or nullptr (not logged)
   int tid;
   int e;
 };
@@ -95,7 +96,8 @@ __host__ __device__ inline size_t lds_bytes(const aie_params& P) {
   return (b + 15) / 16 * 16;
 }
 
-__device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e, int tid, uint8_t* arena = nullptr) {
+__device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e, int tid, uint8_t* arena = nullptr,
+                                        bool with_events = true) {
   uint8_t* q = lds + rec_lds_bytes(P);
   int32_t* act_p = reinterpret_cast<int32_t*>(q);
   q += AIE_MAX_BRACKETS * 4;
@@ -114,7 +116,10 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e
   q += pad4(P.n) * 4;
   int32_t* dirty = reinterpret_cast<int32_t*>(q);
   uint8_t* met = arena ? arena + P.a_metrics + (int64_t)e * P.met_bytes : nullptr;
-  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, met, tid, e};
+  // with_events == false is a compile-time constant in the common step kernel: every `if (c.ev)` folds away
+  int32_t* ev = (with_events && arena && e < P.ev_replicas)
+                    ? reinterpret_cast<int32_t*>(arena + P.a_events + (int64_t)e * P.ev_stride) : nullptr;
+  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, met, ev, tid, e};
 }
 
 // ------------------------------------------------------------------------------------
@@ -503,6 +508,20 @@ __device__ __forceinline__ bool can_agent_occupy(const Ctx& c, int r, int col, i
   return occ == 0 || occ == agent + 1;
 }
 
+// Dense-log event of a logged replica (include/aie.h: AIE_EV_*): wave-uniform arguments, lane 0
+// writes the row; the per-step row count lives in LDS (c.srcn[2]) until the components are done.
+__device__ __forceinline__ void log_event(const Ctx& c, int type, int a1, int a2, int a3, int a4, int a5,
+                                          int a6, int a7, int a8, double f) {
+  if (c.tid != 0) return;
+  const int k = c.srcn[2];
+  if (k >= c.P.ev_cap) return;
+  int32_t* row = c.ev + 4 + k * AIE_EV_WORDS;
+  row[0] = type; row[1] = a1; row[2] = a2; row[3] = a3; row[4] = a4;
+  row[5] = a5; row[6] = a6; row[7] = a7; row[8] = a8; row[9] = 0;
+  *reinterpret_cast<double*>(row + 10) = f;
+  c.srcn[2] = k + 1;
+}
+
 // Build.agent_can_build, F/components/build.py:70-83 (+ world.py:284-293)
 __device__ __forceinline__ bool agent_can_build(const Ctx& c, int i) {
   const int n = c.P.n;
@@ -653,6 +672,7 @@ __device__ __forceinline__ void build_component_step(const Ctx& c, MTL& m, Agent
     }
     cells[cell] = (w & 0xff00ffffu) | ((uint32_t)i << 16);  // world.py:474-479 (every lane, same value)
     dirty_add_uniform(c, cell);
+    if (c.ev) log_event(c, AIE_EV_BUILD, i, cell / c.P.W, cell % c.P.W, 0, 0, 0, 0, 0, R_F64(c, o_build_payment)[i]);
   }
 }
 
@@ -708,6 +728,7 @@ __device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agen
             A.labor += c.P.c.collect_labor;
           }
           w -= (1u << (8 * rs));  // consume_resource, world.py:481-483
+          if (c.ev) log_event(c, AIE_EV_GATHER, i, rs, got, land / W, land % W, 0, 0, 0, 0.0);
         }
       }
       cells[land] = w;
@@ -872,6 +893,7 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
         atomicAdd(sell, 1); atomicAdd(sell + 1, price);
         atomicAdd(buy, 1); atomicAdd(buy + 1, price);
       }
+      if (c.ev) log_event(c, AIE_EV_TRADE, r, seller, buyer, aprice, bprice, price, AIE_ORD_LIFE(ask), AIE_ORD_LIFE(bid), 0.0);
       if (lane == seller) {
         if (r) { A.no1 -= 1; A.esc1 -= 1; } else { A.no0 -= 1; A.esc0 -= 1; }
         A.coin += (double)price;
@@ -1031,6 +1053,10 @@ __device__ __forceinline__ void tax_enact(const Ctx& c, Agents& A) {
       atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_days), 1);
     }
   }
+  if (c.ev) {
+    for (int b = 0; b < c.P.NB; ++b) log_event(c, AIE_EV_TAX_BRACKET, b, 0, 0, 0, 0, 0, 0, 0, tax_rate(c, b));
+    for (int j = 0; j < n; ++j) log_event(c, AIE_EV_TAX, j, 0, 0, 0, 0, 0, 0, 0, bcast(eff, j));
+  }
   double net = 0;
   for (int j = 0; j < n; ++j) net += bcast(eff, j);
   *R_F64(c, o_tax_total_collected) += net;
@@ -1055,6 +1081,28 @@ __device__ __forceinline__ void tax_component_step(const Ctx& c, Agents& A) {
     pos = 0;
   }
   *R_I32(c, o_tax_cycle_pos) = pos + 1;
+}
+
+// WealthRedistribution.component_step, F/components/redistribution.py:46-65: inventory coin
+// := np.sum(inventory + escrow) / n - escrow.  The sum follows NumPy's pairwise order
+// (np_sum_small) with the lanes' values read through wave broadcasts.
+__device__ __forceinline__ void wealth_component_step(const Ctx& c, Agents& A) {
+  const int n = c.P.n;
+  const double v = A.coin + A.esc_coin;
+  double tot;
+  if (n < 8) {
+    tot = -0.0;
+    for (int j = 0; j < n; ++j) tot += bcast(v, j);
+  } else {
+    double r[8];
+    for (int q = 0; q < 8; ++q) r[q] = bcast(v, q);
+    int j = 8;
+    for (; j < n - (n % 8); j += 8)
+      for (int q = 0; q < 8; ++q) r[q] += bcast(v, j + q);
+    tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; j < n; ++j) tot += bcast(v, j);
+  }
+  if (c.tid < n) A.coin = tot / (double)n - A.esc_coin;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1803,7 +1851,7 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
   uint64_t seed;
   int64_t env_offset, t;
 };
-template <int NW>
+template <int NW, bool LOG>
 __device__ __forceinline__ void step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                                           const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
                                           uint8_t* lds, const NextActions& next) {
@@ -1812,7 +1860,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   // struct by value made the compiler copy it to scratch on every launch (5x slower).
   const aie_params& P = *params;
   const int wid = NW == 1 ? 0 : uni((int)(threadIdx.x >> 6));
-  const Ctx c = make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)(threadIdx.x & (AIE_NT - 1)), arena);
+  const Ctx c = make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG);
   MT m;
   Agents A;
   const int skip = P.dev_skip_mask;
@@ -1839,6 +1887,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   __syncthreads();  // occupancy map rebuilt
   if (wid == 0) {
     if (c.tid == 0) *R_I32(c, o_timestep) += 1;
+    if (c.ev && c.tid == 0) c.srcn[2] = 0;
     if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 1] = wall_clock64();
     if (!(skip & 1)) {
       for (int k = 0; k < P.c.n_components; ++k) {
@@ -1847,12 +1896,14 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
           case AIE_COMP_CDA: if (!(skip & 4096)) cda_component_step(c, A); break;
           case AIE_COMP_GATHER: if (!(skip & 8192)) gather_component_step(c, ml, A); break;
           case AIE_COMP_TAX: if (!(skip & 16384)) tax_component_step(c, A); break;
+          case AIE_COMP_WEALTH_REDISTRIBUTION: wealth_component_step(c, A); break;
           default: break;
         }
         if (P.dev_trace && c.tid == 0 && k < 4) P.dev_trace[12 * blockIdx.x + 2 + k] = wall_clock64();
       }
     }
     agents_store(c, A);
+    if (c.ev && c.tid == 0) c.ev[0] = c.srcn[2];
     if (c.tid == 0) *R_I32(c, o_mt_pos) = ml.pos;
     if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 5] = wall_clock64();
   } else if (next.a || next.p) {
@@ -1901,13 +1952,20 @@ extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_w
 aie_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                 const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  step_body<2>(params, arena, act_a, act_p, lds, next);
+  step_body<2, false>(params, arena, act_a, act_p, lds, next);
+}
+// the same step for environments with dense-log replicas (aie_config.dense_log_replicas > 0): records AIE_EV_* rows
+extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+aie_step_kernel_log(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  step_body<2, true>(params, arena, act_a, act_p, lds, next);
 }
 extern "C" __global__ void __launch_bounds__(AIE_NT)
 aie_step_kernel_w1(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  step_body<1>(params, arena, act_a, act_p, lds, NextActions{nullptr, nullptr, 0, 0, 0});
+  step_body<1, true>(params, arena, act_a, act_p, lds, NextActions{nullptr, nullptr, 0, 0, 0});
 }
 
 // BaseEnvironment.reset, F/base/base_env.py:852-927, with LayoutFromFile
@@ -1926,6 +1984,7 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   const Ctx c = make_ctx(P, lds, e, (int)threadIdx.x, arena);
   const int n = P.n, HW = P.HW, tid = c.tid;
   for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
+  if (c.ev && tid == 0) c.ev[0] = 0;
   MT m;
   if (tid == 0) *c.srcn = 0;
   __syncthreads();

@@ -47,7 +47,8 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, i
   s.tmpl_a = reinterpret_cast<float*>(q);
   s.tmpl_p = s.tmpl_a + pad4(P.FA);
   uint8_t* met = arena + P.a_metrics + (int64_t)e * P.met_bytes;
-  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, tid, e};
+  int32_t* ev = e < P.ev_replicas ? reinterpret_cast<int32_t*>(arena + P.a_events + (int64_t)e * P.ev_stride) : nullptr;
+  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, tid, e};
 }
 
 __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {
@@ -80,6 +81,17 @@ __device__ __forceinline__ void labor_component_step(const Ctx& c, const OseScra
   __syncthreads();
 }
 
+// WealthRedistribution.component_step, F/components/redistribution.py:46-65
+__device__ __forceinline__ void ose_wealth_component_step(const Ctx& c, const OseScratch& s) {
+  const int n = c.P.n;
+  __syncthreads();
+  for (int i = c.tid; i < n; i += AIE_NT) s.tmp[i] = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
+  __syncthreads();
+  const double share = np_sum_small(s.tmp, n) / (double)n;  // every lane, same value
+  for (int i = c.tid; i < n; i += AIE_NT) R_F64(c, o_inv_coin)[i] = share - R_F64(c, o_esc_coin)[i];
+  __syncthreads();
+}
+
 // PeriodicBracketTax.component_step :945-972 with enact_taxes :853-915
 __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseScratch& s) {
   const int n = c.P.n;
@@ -101,6 +113,13 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
       R_F64(c, o_tax_last_income)[i] = income;
       R_F64(c, o_inv_coin)[i] = coin - eff;
       s.tmp[i] = eff;
+      if (c.ev) {  // dense log: one AIE_EV_TAX row per agent, in agent order
+        int32_t* row = c.ev + 4 + (c.P.NB + i) * AIE_EV_WORDS;
+        row[0] = AIE_EV_TAX; row[1] = i;
+        for (int q = 2; q < 10; ++q) row[q] = 0;
+        *reinterpret_cast<double*>(row + 10) = eff;
+        if (i == 0) c.ev[0] = c.P.NB + n;
+      }
       // episode accumulators for get_metrics :1141-1186 (no-return atomics)
       unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_income) + i, income > 0 ? income : 0.0);
       unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_paid) + i, eff);
@@ -111,6 +130,12 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
       atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_occ) + bin, 1);
     }
     if (c.tid < c.P.NB) unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_sched) + c.tid, tax_rate(c, c.tid));
+    if (c.ev && c.tid < c.P.NB) {  // the day's schedule: AIE_EV_TAX_BRACKET rows first
+      int32_t* row = c.ev + 4 + c.tid * AIE_EV_WORDS;
+      row[0] = AIE_EV_TAX_BRACKET; row[1] = c.tid;
+      for (int q = 2; q < 10; ++q) row[q] = 0;
+      *reinterpret_cast<double*>(row + 10) = tax_rate(c, c.tid);
+    }
     __syncthreads();
     double net = 0, day = 0;  // running sums in agent order, as the reference accumulates them
     for (int j = 0; j < n; ++j) {
@@ -393,9 +418,11 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   __syncthreads();
   m.pos = uni(*R_I32(c, o_mt_pos));
   if (tid == 0) *R_I32(c, o_timestep) += 1;
+  if (c.ev && tid == 0) c.ev[0] = 0;
   for (int k = 0; k < P.c.n_components; ++k) {
     if (P.c.components[k] == AIE_COMP_SIMPLE_LABOR) labor_component_step(c, s, m);
     else if (P.c.components[k] == AIE_COMP_TAX) ose_tax_component_step(c, s);
+    else if (P.c.components[k] == AIE_COMP_WEALTH_REDISTRIBUTION) ose_wealth_component_step(c, s);
   }
   if (tid == 0) *R_I32(c, o_mt_pos) = m.pos;
   __syncthreads();
@@ -436,6 +463,7 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   const Ctx c = ose_make_ctx(P, lds, e, (int)threadIdx.x, s, arena);
   const int n = P.n, tid = c.tid;
   for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
+  if (c.ev && tid == 0) c.ev[0] = 0;
   MT m;
   ose_load_record(c, arena, m);
   __syncthreads();

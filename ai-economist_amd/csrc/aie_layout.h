@@ -112,6 +112,8 @@ typedef struct aie_params {
    * (tools/phase_profile.py); always 0 in normal operation */
   /* per-replica episode accumulators behind env.metrics (component get_metrics): touched only
    * when a trade executes / on tax days, so they live outside the streamed record */
+  int64_t a_events;      /* dense-log events of replicas [0, ev_replicas): int32 count (16 B), then rows */
+  int32_t ev_replicas, ev_cap, ev_stride, ev_pad_;
   int64_t a_metrics;
   int32_t met_bytes;
   int32_t mo_cda;        /* int32 [2: sell, buy][AIE_N_RES][n][2: n_sales, sum of prices]         */
@@ -253,6 +255,7 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
     AIE__FAIL("the COVID scenario uses single-action mode for agents and planner");
   static const int want[3] = {AIE_COMP_COVID_CONTROL, AIE_COMP_COVID_SUBSIDY, AIE_COMP_COVID_VACCINE};
   if (c->n_components != 3) AIE__FAIL("the COVID scenario needs exactly its three components");
+  if (c->dense_log_replicas != 0) AIE__FAIL("dense logs are not available for the COVID scenario");
   for (int i = 0; i < 3; ++i)
     if (c->components[i] != want[i])
       AIE__FAIL("COVID components must be ControlUSStateOpenCloseStatus, FederalGovernmentSubsidy, VaccinationCampaign (in this order)");
@@ -408,6 +411,25 @@ static inline void aie__alloc_metrics(aie_params* p, int64_t* a) {
   p->a_metrics = *a;
   *a = aie__align(*a + (int64_t)p->E * p->met_bytes, 256);
 }
+/* dense-log event rows (include/aie.h: AIE_EV_*): at most n builds, 2n gathers, NB + n tax rows
+ * and one trade per resting order of a commodity in a step */
+static inline void aie__alloc_events(const aie_config* c, aie_params* p, int64_t* a) {
+  const int n = p->n;
+  p->ev_replicas = c->dense_log_replicas;
+  p->ev_cap = p->ev_stride = 0;
+  p->a_events = 0;
+  if (p->ev_replicas <= 0) return;
+  p->ev_cap = 4 * n + (p->has_tax ? p->NB : 0) + (p->has_cda ? AIE_N_RES * n * c->cda_max_num_orders : 0);
+  p->ev_stride = (int32_t)aie__align(16 + (int64_t)p->ev_cap * AIE_EV_WORDS * 4, 64);
+  p->a_events = *a;
+  *a = aie__align(*a + (int64_t)p->ev_replicas * p->ev_stride, 256);
+}
+static inline void aie__add_event_tensors(const aie_params* p, aie_tensor_table* tt) {
+  if (p->ev_replicas <= 0) return;
+  aie__add(tt, "log_event_count", AIE_I32, p->a_events, p->ev_stride, 0, 0, 0, 0, 0, p->ev_replicas);
+  aie__add(tt, "log_events", AIE_I32, p->a_events + 16, p->ev_stride, 2, p->ev_cap, AIE_EV_WORDS, 0, 0,
+           p->ev_replicas);
+}
 static inline void aie__add_metrics_tensors(const aie_params* p, aie_tensor_table* tt) {
   const int64_t ms = p->met_bytes, m0 = p->a_metrics, E = p->E;
   const int n = p->n;
@@ -488,11 +510,13 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
   p->a_rew_p = a; a = aie__align(a + E * 4, 256);
   p->a_done = a;  a = aie__align(a + E, 256);
   aie__alloc_metrics(p, &a);
+  aie__alloc_events(c, p, &a);
   p->arena_bytes = a;
 
   if (tt) {
     const int64_t rs = p->rec_bytes, r0 = p->a_records;
     aie__add_metrics_tensors(p, tt);
+    aie__add_event_tensors(p, tt);
 #define REC(name, dt, off, nd, d0) aie__add(tt, name, dt, r0 + (off), rs, nd, d0, 0, 0, 0, E)
     REC("inv_coin", AIE_F64, p->o_inv_coin, 1, n);
     REC("esc_coin", AIE_F64, p->o_esc_coin, 1, n);
@@ -562,14 +586,18 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   if (c->world_h < 1 || c->world_w < 1 || c->world_h > 255 || c->world_w > 255)
     AIE__FAIL("world_size out of range");
   if (c->episode_length < 1) AIE__FAIL("episode_length must be >= 1 (base_env.py:254)");
+  if (c->dense_log_replicas < 0 || c->dense_log_replicas > c->n_envs)
+    AIE__FAIL("dense_log_replicas must be in [0, n_envs]");
   if (c->n_components < 0 || c->n_components > AIE_MAX_COMPONENTS) AIE__FAIL("bad n_components");
   for (int i = 0; i < c->n_components; ++i) {
     int k = c->components[i];
-    if (k < AIE_COMP_BUILD || k > AIE_COMP_SIMPLE_LABOR) AIE__FAIL("unknown component id %d", k);
+    if (k < AIE_COMP_BUILD || (k > AIE_COMP_SIMPLE_LABOR && k != AIE_COMP_WEALTH_REDISTRIBUTION))
+      AIE__FAIL("unknown component id %d", k);
     if (c->scenario == AIE_SCN_GTB && k == AIE_COMP_SIMPLE_LABOR)
       AIE__FAIL("SimpleLabor is only supported with the one-step-economy scenario");
-    if (c->scenario == AIE_SCN_ONE_STEP_ECONOMY && k != AIE_COMP_SIMPLE_LABOR && k != AIE_COMP_TAX)
-      AIE__FAIL("one-step-economy supports SimpleLabor and PeriodicBracketTax only");
+    if (c->scenario == AIE_SCN_ONE_STEP_ECONOMY && k != AIE_COMP_SIMPLE_LABOR && k != AIE_COMP_TAX &&
+        k != AIE_COMP_WEALTH_REDISTRIBUTION)
+      AIE__FAIL("one-step-economy supports SimpleLabor, PeriodicBracketTax and WealthRedistribution only");
     for (int j = 0; j < i; ++j)
       if (c->components[j] == k) AIE__FAIL("component %d listed twice", k);
   }
@@ -835,6 +863,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->a_rew_p = a; a = aie__align(a + E * 4, 256);
   p->a_done = a;  a = aie__align(a + E, 256);
   aie__alloc_metrics(p, &a);
+  aie__alloc_events(c, p, &a);
   p->arena_bytes = a;
 
   /* ---- tensor table ------------------------------------------------------------ */
@@ -915,6 +944,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     DENSE("rewards_p", AIE_F32, p->a_rew_p, 0, 0, 0, 0, 0);
     DENSE("done", AIE_U8, p->a_done, 0, 0, 0, 0, 0);
     aie__add_metrics_tensors(p, tt);
+    aie__add_event_tensors(p, tt);
 #undef DENSE
   }
   return AIE_OK;

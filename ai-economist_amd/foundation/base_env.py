@@ -64,8 +64,18 @@ class BaseEnvironment:
         if (not flatten_observations and not self.supports_unflattened_observations) or not flatten_masks:
             raise NotImplementedError(
                 "the batched backend always produces flattened observations and masks")
+        # dense logs (base_env.py:148-163, 273-283): replica `dense_log_replica` of the batch is
+        # the one whose episodes are logged; the device records its component events
+        self._create_dense_log_every = None
         if dense_log_frequency is not None:
-            raise NotImplementedError("dense logs are not produced by the batched backend yet")
+            self._create_dense_log_every = int(dense_log_frequency)
+            assert self._create_dense_log_every >= 1
+        self.world_dense_log_frequency = int(world_dense_log_frequency)
+        assert self.world_dense_log_frequency >= 1
+        self._dense_log_this_episode = False
+        self._dense_logger = None
+        self._dense_log = {"world": [], "states": [], "actions": [], "rewards": []}
+        self._last_ep_dense_log = dict(self._dense_log)
         self.collate_agent_step_and_reset_data = True
         self.n_envs = int(n_envs)
         assert self.n_envs >= 1
@@ -170,6 +180,7 @@ class BaseEnvironment:
         cfg.multi_action_mode_agents = int(self.multi_action_mode_agents)
         cfg.multi_action_mode_planner = int(self.multi_action_mode_planner)
         cfg.allow_observation_scaling = int(self._allow_observation_scaling)
+        cfg.dense_log_replicas = 1 if self._create_dense_log_every is not None else 0
         if len(self._components) > _cabi.MAX_COMPONENTS:
             raise ValueError("too many components")
         cfg.n_components = len(self._components)
@@ -223,16 +234,65 @@ class BaseEnvironment:
                 obs["p"][k[6:]] = v
         return obs
 
-    def reset(self, env_mask=None):
+    def reset(self, env_mask=None, force_dense_logging=False):
         """Resets all replicas (or those selected by the uint8/bool device tensor
-        `env_mask`, e.g. the `done` tensor) and returns batched observations."""
+        `env_mask`, e.g. the `done` tensor) and returns batched observations.
+        force_dense_logging: log the coming episode of replica 0 even if it is not one of the
+        every-`dense_log_frequency`-th episodes (base_env.py:883-891); needs an environment
+        built with dense_log_frequency set (the device event buffer exists only then)."""
         if self._backend is None and self._pending_seed is None:
             # the reference falls back on whatever the global NumPy stream holds;
             # here an unseeded env is seeded from the OS once.
             self._pending_seed = int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31 - 1)) + 1
+        if force_dense_logging and self._create_dense_log_every is None:
+            raise ValueError("force_dense_logging needs an environment created with dense_log_frequency")
+        log_replica_resets = self._create_dense_log_every is not None and (
+            env_mask is None or bool(env_mask[0].item()))
+        if log_replica_resets:
+            # completed episodes of the logged replica, before this reset (base_env.py:885-891)
+            done_eps = int(self.backend.tensors["completions"][0].item()) if self._backend is not None else 0
+            self._dense_log_this_episode = bool(force_dense_logging) or done_eps % self._create_dense_log_every == 0
         self.host_pre_reset(env_mask)
         self.backend.reset(env_mask)
+        if log_replica_resets:
+            self._dense_log = {"world": [], "states": [], "actions": [], "rewards": []}
+            if self._dense_log_this_episode:
+                from .dense_log import DenseLogger
+
+                if self._dense_logger is None:
+                    self._dense_logger = DenseLogger(self, 0)
+                self._dense_logger.begin_episode()
+                self._dense_log = self._dense_logger.log
         return self._obs()
+
+    @property
+    def dense_log(self):
+        """The (possibly still growing) dense log of the logged replica's current episode."""
+        return self._dense_log
+
+    @property
+    def previous_episode_dense_log(self):
+        """Dense log of the logged replica's most recent completed, logged episode."""
+        return self._last_ep_dense_log
+
+    def action_subspace_names(self):
+        """([(name, n_actions)] of the mobile agents, [...] of the planner), in action-index
+        order (base_agent.py:116-171: "<Component>" or "<Component>.<sub-action>")."""
+        out = []
+        for cls in ("BasicMobileAgent", "BasicPlanner"):
+            names = []
+            for comp in self._components:
+                if cls not in comp.agent_subclasses:
+                    continue
+                n = comp.get_n_actions(cls)
+                if n is None or n == 0:
+                    continue
+                if isinstance(n, int):
+                    names.append((comp.name, n))
+                else:
+                    names.extend(("%s.%s" % (comp.name, sub), int(k)) for sub, k in n)
+            out.append(names)
+        return out[0], out[1]
 
     def host_pre_reset(self, env_mask):
         """Hook for scenarios whose reset has a host-side part (e.g. uniform/...: a fresh
@@ -248,8 +308,16 @@ class BaseEnvironment:
             assert isinstance(actions, dict)
             a = actions.get("a")
             p = actions.get("p")
+        logging = self._dense_log_this_episode and self._dense_logger is not None
+        if logging:
+            self._dense_logger.before_step(a, p)
         self.backend.step(a, p)
         t = self.backend.tensors
+        if logging:
+            self._dense_logger.after_step()
+            if bool(t["done"][0].item()):  # _finalize_logs, base_env.py:763-814
+                self._last_ep_dense_log = self._dense_logger.finalize()
+                self._dense_log_this_episode = False
         rew = {"a": t["rewards_a"], "p": t["rewards_p"]}
         done = {"__all__": t["done"]}
         info = {"a": {}, "p": {}}

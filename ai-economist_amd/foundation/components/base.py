@@ -33,6 +33,11 @@ class BaseComponent:
     def get_n_actions(self, agent_cls_name):
         raise NotImplementedError
 
+    def agent_state_fields(self):
+        """{agent.state field the component adds (get_additional_state_fields): state tensor};
+        used when the reference-shaped per-agent state is rebuilt (dense logs)."""
+        return {}
+
     def fill_config(self, cfg):
         """Writes this component's kwargs into an AieConfig (ctypes)."""
         raise NotImplementedError

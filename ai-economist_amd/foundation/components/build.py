@@ -28,6 +28,9 @@ class Build(BaseComponent):
     def get_n_actions(self, agent_cls_name):
         return 1 if agent_cls_name == "BasicMobileAgent" else None
 
+    def agent_state_fields(self):
+        return {"build_payment": "build_payment", "build_skill": "build_skill"}
+
     def fill_config(self, cfg):
         cfg.build_payment = self.payment
         cfg.build_payment_max_skill_multiplier = self.payment_max_skill_multiplier

@@ -23,6 +23,9 @@ class Gather(BaseComponent):
     def get_n_actions(self, agent_cls_name):
         return 4 if agent_cls_name == "BasicMobileAgent" else None
 
+    def agent_state_fields(self):
+        return {"bonus_gather_prob": "bonus_gather_prob"}
+
     def fill_config(self, cfg):
         cfg.move_labor = self.move_labor
         cfg.collect_labor = self.collect_labor

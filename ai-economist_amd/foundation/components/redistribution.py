@@ -1,4 +1,6 @@
-"""`PeriodicBracketTax` (reference: F/components/redistribution.py:78-346, 920-939;
+"""`WealthRedistribution` (reference: F/components/redistribution.py:21-75; dynamics ->
+wealth_component_step in csrc/aie_kernels.hip / aie_kernels_ose.hip) and
+`PeriodicBracketTax` (reference: F/components/redistribution.py:78-346, 920-939;
 dynamics -> tax_component_step / tax_enact in csrc/aie_kernels.hip).
 
 Supported tax models: "model_wrapper" (planner picks discretised rates),
@@ -10,6 +12,22 @@ import numpy as np
 
 from ... import _cabi
 from .base import BaseComponent, component_registry
+
+
+@component_registry.add
+class WealthRedistribution(BaseComponent):
+    """Passive: every step the mobile agents' total coin (inventory + escrow) is split evenly;
+    no actions, state fields, observations, masks or metrics."""
+    name = "WealthRedistribution"
+    required_entities = ["Coin"]
+    agent_subclasses = ["BasicMobileAgent"]
+    comp_id = _cabi.COMP_WEALTH_REDISTRIBUTION
+
+    def get_n_actions(self, agent_cls_name):
+        return None
+
+    def fill_config(self, cfg):
+        pass
 
 
 @component_registry.add

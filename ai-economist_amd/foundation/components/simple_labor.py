@@ -37,6 +37,9 @@ class SimpleLabor(BaseComponent):
     def get_n_actions(self, agent_cls_name):
         return self.num_labor_hours if agent_cls_name == "BasicMobileAgent" else None
 
+    def agent_state_fields(self):
+        return {"skill": "skill", "production": "production"}
+
     def fill_config(self, cfg):
         if self.n_agents > _cabi.MAX_AGENTS_WIDE:
             raise ValueError("SimpleLabor supports at most {} agents".format(_cabi.MAX_AGENTS_WIDE))

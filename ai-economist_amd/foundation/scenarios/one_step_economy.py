@@ -30,9 +30,9 @@ class OneStepEconomy(BaseEnvironment):
         self.mixing_weight_gini_vs_coin = mixing_weight_gini_vs_coin
         self.planner_starting_coin = 0
         for c in self.components:
-            if c.name not in ("SimpleLabor", "PeriodicBracketTax"):
+            if c.name not in ("SimpleLabor", "PeriodicBracketTax", "WealthRedistribution"):
                 raise NotImplementedError(
-                    "one-step-economy is implemented for SimpleLabor + PeriodicBracketTax")
+                    "one-step-economy is implemented for SimpleLabor, PeriodicBracketTax, WealthRedistribution")
 
     def layout_planes(self):
         z = np.zeros(self.world_size, np.uint8)

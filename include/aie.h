@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AIE_ABI_VERSION 3
+#define AIE_ABI_VERSION 4
 
 #define AIE_MAX_AGENTS 64      /* mobile agents per replica, spatial scenarios (one lane each) */
 #define AIE_MAX_AGENTS_WIDE 128 /* mobile agents per replica, map-less one-step-economy        */
@@ -69,7 +69,8 @@ enum {
   AIE_COMP_SIMPLE_LABOR = 5,   /* "SimpleLabor"               F/components/simple_labor.py:15  */
   AIE_COMP_COVID_CONTROL = 6,  /* "ControlUSStateOpenCloseStatus" F/components/covid19_components.py:32  */
   AIE_COMP_COVID_SUBSIDY = 7,  /* "FederalGovernmentSubsidy"      F/components/covid19_components.py:244 */
-  AIE_COMP_COVID_VACCINE = 8   /* "VaccinationCampaign"           F/components/covid19_components.py:472 */
+  AIE_COMP_COVID_VACCINE = 8,  /* "VaccinationCampaign"           F/components/covid19_components.py:472 */
+  AIE_COMP_WEALTH_REDISTRIBUTION = 9 /* "WealthRedistribution"     F/components/redistribution.py:21-75 */
 };
 
 /* ---- scenario families (registry names in the reference, F/scenarios) ----------- */
@@ -214,10 +215,26 @@ typedef struct aie_config {
   /* PeriodicBracketTax tax_annealing_schedule=[warmup, slope] (redistribution.py:311-330,
    * utils.py:10-118): the highest allowed rate grows with the number of completed episodes */
   int32_t tax_annealing;             /* 1: schedule given                                 */
-  int32_t reserved3_;
+  /* dense logs (base_env.py:984-1016, component get_dense_log): replicas [0, dense_log_replicas)
+   * record the component events of the current step (AIE_EV_*) in the tensors
+   * "log_event_count" / "log_events"; 0 = off. */
+  int32_t dense_log_replicas;
   double tax_annealing_warmup, tax_annealing_slope;
   double tax_rate_max;               /* rate_max kwarg (0 when taxes are disabled)        */
 } aie_config;
+
+/* ---- dense-log events: one row of "log_events" int32 [L, cap, AIE_EV_WORDS] ------- */
+#define AIE_EV_WORDS 12 /* [0] type, [1..8] integers, [10..11] one float64 (bit pattern)          */
+enum aie_event {
+  AIE_EV_BUILD = 1,  /* builder, row, col; f64 income              build.py:149-155                */
+  AIE_EV_TRADE = 2,  /* commodity (0 Stone, 1 Wood), seller, buyer, ask, bid, price, ask_lifetime,
+                        bid_lifetime                               continuous_double_auction.py:289-305 */
+  AIE_EV_GATHER = 3, /* agent, resource (0 Stone, 1 Wood), n, row, col   move.py:141-149          */
+  AIE_EV_TAX = 4,    /* agent; f64 tax_paid (income, marginal rate: tensors "tax_last_*")
+                                                                  redistribution.py:878-883        */
+  AIE_EV_TAX_BRACKET = 5 /* bracket; f64 marginal rate in force (the tax day's "schedule"; precedes
+                        that day's AIE_EV_TAX rows)              redistribution.py:856-859        */
+};
 
 /* ---- tensor descriptor ---------------------------------------------------------- */
 typedef struct aie_tensor_desc {

@@ -34,6 +34,8 @@ typedef struct {
   int act_wide[AIE_MAX_AGENTS_WIDE]; /* one-step-economy: SimpleLabor action per agent */
 } ctx_t;
 
+/* dense-log event rows of replicas [0, ev_replicas) (include/aie.h: AIE_EV_*) */
+#define EV(c) ((c)->e < (c)->p->ev_replicas ? (int32_t*)((c)->arena + (c)->p->a_events + (int64_t)(c)->e * (c)->p->ev_stride) : (int32_t*)0)
 #define MET(c) ((c)->arena + (c)->p->a_metrics + (int64_t)(c)->e * (c)->p->met_bytes)
 #define F64(c, off) ((double*)((c)->rec + (c)->p->off))
 #define I32(c, off) ((int32_t*)((c)->rec + (c)->p->off))
@@ -207,6 +209,16 @@ static int agent_can_build(ctx_t* c, int i) {
   return 1;
 }
 
+static void log_event(ctx_t* c, int type, int a1, int a2, int a3, int a4, int a5, int a6, int a7, int a8, double f) {
+  int32_t* ev = EV(c);
+  if (!ev || ev[0] >= c->p->ev_cap) return;
+  int32_t* row = ev + 4 + ev[0] * AIE_EV_WORDS;
+  row[0] = type; row[1] = a1; row[2] = a2; row[3] = a3; row[4] = a4;
+  row[5] = a5; row[6] = a6; row[7] = a7; row[8] = a8; row[9] = 0;
+  memcpy(row + 10, &f, 8);
+  ev[0] += 1;
+}
+
 /* Build.component_step, build.py:112-161 */
 static void build_step(ctx_t* c) {
   const aie_params* p = c->p;
@@ -222,6 +234,7 @@ static void build_step(ctx_t* c) {
     C_OWNER(c, cell) = (int8_t)i; /* world.py:474-479, 240-259 */
     F64(c, o_inv_coin)[i] += F64(c, o_build_payment)[i];
     F64(c, o_labor)[i] += p->c.build_labor;
+    log_event(c, AIE_EV_BUILD, i, I32(c, o_loc_r)[i], I32(c, o_loc_c)[i], 0, 0, 0, 0, 0, F64(c, o_build_payment)[i]);
   }
 }
 
@@ -261,6 +274,7 @@ static void gather_step(ctx_t* c) {
         I32(c, o_inv_res)[rsrc * p->n + i] += n_gathered;
         CB(c, cell, rsrc) -= 1; /* consume_resource, world.py:481-483 */
         F64(c, o_labor)[i] += p->c.collect_labor;
+        log_event(c, AIE_EV_GATHER, i, rsrc, n_gathered, nr, nc, 0, 0, 0, 0.0);
       }
     }
   }
@@ -368,6 +382,7 @@ static void cda_match(ctx_t* c) {
             sell[0] += 1; sell[1] += price;
             buy[0] += 1; buy[1] += price;
           }
+          log_event(c, AIE_EV_TRADE, r, seller, buyer, aprice, bprice, price, AIE_ORD_LIFE(ask), AIE_ORD_LIFE(bid), 0.0);
           I32(c, o_esc_res)[r * p->n + seller] -= 1;
           I32(c, o_inv_res)[r * p->n + buyer] += 1;
           F64(c, o_esc_coin)[buyer] -= (double)bprice;
@@ -492,6 +507,7 @@ static double tax_due(ctx_t* c, double income) {
 static void tax_enact(ctx_t* c) {
   const aie_params* p = c->p;
   double net = 0, day_eff = 0;
+  for (int b = 0; b < p->NB; ++b) log_event(c, AIE_EV_TAX_BRACKET, b, 0, 0, 0, 0, 0, 0, 0, tax_rate(c, b));
   for (int i = 0; i < p->n; ++i) {
     double income = (F64(c, o_inv_coin)[i] + F64(c, o_esc_coin)[i]) - F64(c, o_tax_last_coin)[i];
     double due = tax_due(c, income);
@@ -500,6 +516,7 @@ static void tax_enact(ctx_t* c) {
     double mr = tax_marginal_rate(c, income);
     F64(c, o_inv_coin)[i] -= eff;
     net += eff;
+    log_event(c, AIE_EV_TAX, i, 0, 0, 0, 0, 0, 0, 0, eff);
     F64(c, o_tax_last_income)[i] = income;
     F64(c, o_tax_last_marginal_rate)[i] = mr;
     /* bookkeeping for get_metrics :1141-1186 (redistribution.py:878-895) */
@@ -537,6 +554,17 @@ static void tax_step(ctx_t* c) {
     *pos = 0;
   }
   *pos += 1;
+}
+
+/* WealthRedistribution.component_step, F/components/redistribution.py:46-65: every agent's
+ * inventory coin becomes (np.sum(inventory + escrow) / n) - its escrow. */
+static void wealth_step(ctx_t* c) {
+  const int n = c->p->n;
+  double tot[AIE_MAX_AGENTS_WIDE];
+  double *ic = F64(c, o_inv_coin), *ec = F64(c, o_esc_coin);
+  for (int i = 0; i < n; ++i) tot[i] = ic[i] + ec[i];
+  const double share = np_sum(tot, n) / n;
+  for (int i = 0; i < n; ++i) ic[i] = share - ec[i];
 }
 
 /* ------------------------------------------------------------------------------- */
@@ -954,12 +982,14 @@ static void step_one(const aie_params* p, uint8_t* arena, int e, const int32_t* 
   make_ctx(&c, p, arena, e);
   decode_actions(&c, aa, ap);
   *I32(&c, o_timestep) += 1;
+  if (EV(&c)) EV(&c)[0] = 0;
   for (int k = 0; k < p->c.n_components; ++k) {
     switch (p->c.components[k]) {
       case AIE_COMP_BUILD: build_step(&c); break;
       case AIE_COMP_CDA: cda_step(&c); break;
       case AIE_COMP_GATHER: gather_step(&c); break;
       case AIE_COMP_TAX: tax_step(&c); break;
+      case AIE_COMP_WEALTH_REDISTRIBUTION: wealth_step(&c); break;
     }
   }
   scenario_step(&c);
@@ -983,6 +1013,7 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
   const int n = p->n, HW = p->HW;
   *I32(&c, o_timestep) = 0;
   memset(MET(&c), 0, (size_t)p->met_bytes); /* component resets clear their episode logs */
+  if (EV(&c)) EV(&c)[0] = 0;
   for (int cell = 0; cell < HW; ++cell) { /* layout_from_file.py:323-334 */
     unsigned fl = C_FLAGS(&c, cell);
     CELLS(&c)[cell] = AIE_CELL_PACK((fl & AIE_CELL_STONE_SRC) ? 1 : 0, (fl & AIE_CELL_WOOD_SRC) ? 1 : 0, -1, fl);
@@ -1281,9 +1312,11 @@ static void ose_step_one(const aie_params* p, uint8_t* arena, int e, const int32
   make_ctx(&c, p, arena, e);
   ose_decode_actions(&c, aa, ap);
   *I32(&c, o_timestep) += 1;
+  if (EV(&c)) EV(&c)[0] = 0;
   for (int k = 0; k < p->c.n_components; ++k) {
     if (p->c.components[k] == AIE_COMP_SIMPLE_LABOR) labor_step(&c);
     else if (p->c.components[k] == AIE_COMP_TAX) tax_step(&c);
+    else if (p->c.components[k] == AIE_COMP_WEALTH_REDISTRIBUTION) wealth_step(&c);
   }
   ose_write_obs(&c, 0);
   /* compute_reward one_step_economy.py:195-222 */
@@ -1308,6 +1341,7 @@ static void ose_reset_one(const aie_params* p, uint8_t* arena, int e) {
   const int n = p->n;
   *I32(&c, o_timestep) = 0;
   memset(MET(&c), 0, (size_t)p->met_bytes);
+  if (EV(&c)) EV(&c)[0] = 0;
   for (int i = 0; i < n; ++i) {
     F64(&c, o_inv_coin)[i] = 0; F64(&c, o_esc_coin)[i] = 0; F64(&c, o_labor)[i] = 0;
     F64(&c, o_skill)[i] = p->has_labor ? p->c.labor_skills[i] : 0;

@@ -188,6 +188,10 @@ def random_gtb_config(seed):
             tax["tax_annealing_schedule"] = [int(pick([-1, 0, 1])), float(pick([0.3, 0.6]))]
         comps.append(["PeriodicBracketTax", tax])
     rng.shuffle(comps)
+    # passive equal-split component at a random position (own stream: keeps the draws above stable)
+    rng2 = np.random.RandomState(7000 + seed)
+    if rng2.rand() < 0.2:
+        comps.insert(int(rng2.randint(len(comps) + 1)), ["WealthRedistribution", {}])
     cfg["components"] = comps
     return cfg
 

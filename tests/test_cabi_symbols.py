@@ -59,7 +59,7 @@ def test_host_registry_and_kwargs_validation():
     assert foundation.scenarios.has("LAYOUT_FROM_FILE/simple_wood_and_stone")  # case-insensitive
     assert foundation.components.entries == ["Build", "ContinuousDoubleAuction", "ControlUSStateOpenCloseStatus",
                                              "FederalGovernmentSubsidy", "Gather", "PeriodicBracketTax",
-                                             "SimpleLabor", "VaccinationCampaign"]
+                                             "SimpleLabor", "VaccinationCampaign", "WealthRedistribution"]
     assert foundation.scenarios.entries == ["CovidAndEconomySimulation", "layout_from_file/simple_wood_and_stone",
                                             "multi_zone/simple_wood_and_stone", "one-step-economy",
                                             "quadrant/simple_wood_and_stone", "split_layout/simple_wood_and_stone",

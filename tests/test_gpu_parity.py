@@ -353,6 +353,7 @@ OSE_VARIANTS = {
     "isoelastic_12ag_coin_eq": dict(n_agents=12, agent_reward_type="isoelastic_coin_minus_labor",
                                      planner_reward_type="coin_eq_times_productivity", isoelastic_eta=0.4),
     "no_first_step_mask_128ag": dict(n_agents=128, labor_kw=dict(mask_first_step=False)),
+    "wealth_redistribution_77ag": dict(n_agents=77, extra_components=[["WealthRedistribution", {}]]),
 }
 
 
@@ -402,12 +403,13 @@ def test_hip_matches_oracle_one_step_economy(variant):
 
     kw = dict(OSE_VARIANTS[variant])
     labor_kw = kw.pop("labor_kw", {})
+    extra = kw.pop("extra_components", [])
     rs = np.random.RandomState(4)
     n = kw["n_agents"]
     labor_kw["skills"] = [float(x) for x in np.sort(1 + rs.rand(n) * 2)]
     cfg = dict(scenario_name="one-step-economy", world_size=[1, 1], episode_length=2,
-               components=[["SimpleLabor", labor_kw],
-                           ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+               components=[["SimpleLabor", labor_kw]] + extra +
+                          [["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
                                                    "tax_model": "model_wrapper"}]], **kw)
     E, T = 96, 12
     env = make_env(cfg, n_envs=E, device="cuda:0")

@@ -46,6 +46,9 @@ VARIANTS = {
     "no_cda_obs_range3": dict(components=[GTB[0], GTB[2], GTB[3]], mobile_agent_observation_range=3),
     "energy_decay_warmup": dict(components=GTB, energy_warmup_constant=3, energy_warmup_method="decay",
                                  isoelastic_eta=0.5),
+    "wealth_redistribution": dict(components=GTB[:3] + [["WealthRedistribution", {}]]),
+    "wealth_redistribution_then_tax": dict(components=GTB[:3] + [["WealthRedistribution", {}], GTB[3]],
+                                           n_agents=9),
     "six_agents_40x40": dict(components=GTB, n_agents=6, world_size=[40, 40],
                              env_layout_file="quadrant_40x40_50each.txt"),
 }
@@ -221,6 +224,7 @@ OSE_VARIANTS = {
     "isoelastic_12_coin_eq": dict(n_agents=12, agent_reward_type="isoelastic_coin_minus_labor",
                                   planner_reward_type="coin_eq_times_productivity", isoelastic_eta=0.4),
     "single_action_planner_25": dict(n_agents=25, multi_action_mode_planner=False, labor_cost=0.5, labor_exponent=1.5),
+    "wealth_redistribution_20": dict(n_agents=20, extra_components=[["WealthRedistribution", {}]]),
     "no_first_step_mask": dict(n_agents=30, labor_kw=dict(mask_first_step=False), episode_length=3),
 }
 
@@ -232,9 +236,10 @@ def test_oracle_tracks_live_reference_one_step_economy(variant):
 
     kw = dict(OSE_VARIANTS[variant])
     labor_kw = kw.pop("labor_kw", {})
+    extra = kw.pop("extra_components", [])
     cfg = dict(scenario_name="one-step-economy", world_size=[1, 1], episode_length=kw.pop("episode_length", 2),
-               components=[["SimpleLabor", dict(labor_kw)],
-                           ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+               components=[["SimpleLabor", dict(labor_kw)]] + extra +
+                          [["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
                                                    "tax_model": "model_wrapper"}]], **kw)
     np.random.seed(77)
     ref = _ref_env(cfg)
