@@ -1108,6 +1108,7 @@ __device__ __forceinline__ void wealth_component_step(const Ctx& c, Agents& A) {
 // ------------------------------------------------------------------------------------
 // LayoutFromFile.scenario_step, layout_from_file.py:372-410.
 // regen_halfwidth == 0: p = regen_weight * max(map, src); only source blocks spawn.
+// regen_halfwidth > 0 (dynamic_layout.py:446-463): p from the per-episode window counts.
 // np.random.rand(H, W) is consumed for Wood, then for Stone: 4*H*W MT19937 words per
 // step, read row by row straight from the state registers (pairs of adjacent lanes
 // form one 53-bit double); a double that straddles a twist is carried over.
@@ -1122,7 +1123,11 @@ __device__ __forceinline__ void regen_cell(const Ctx& c, uint32_t ta, uint32_t t
     const uint32_t mval = cb[rs];
     const uint32_t health = mval > 1u ? mval : 1u;  // max(map, source block = 1)
     const double u = u53(ta, tb);
-    if (u < c.P.c.regen_weight[rs] * (double)health && mval < (uint32_t)c.P.c.max_health[rs]) {
+    // halfwidth 0: p = regen_weight * health; else regen_p[source blocks in the window] (aie_layout.h: regen_conv)
+    const double p = (c.P.regen_conv && c.P.c.regen_halfwidth[rs] > 0)
+                         ? c.P.regen_p[rs][R_U8(c, o_regen_count)[rs * HW + cell]]
+                         : c.P.c.regen_weight[rs] * (double)health;
+    if (u < p && mval < (uint32_t)c.P.c.max_health[rs]) {
       cb[rs] = (uint8_t)(mval + 1);
       dirty_add_lane(c, cell);
     }
@@ -2019,6 +2024,19 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
     }
   }
   __syncthreads();
+  if (P.regen_conv) {  // source blocks per d x d window, zero-padded ("same"), once per episode
+    const uint8_t* cb = reinterpret_cast<const uint8_t*>(R_CELLS(c));
+    for (int q = tid; q < AIE_N_RES * HW; q += AIE_NT) {
+      const int rs = q >= HW ? 1 : 0, cell = q - rs * HW, r0 = cell / P.W, c0 = cell - r0 * P.W;
+      const int hw = P.c.regen_halfwidth[rs];
+      const uint32_t bit = rs ? AIE_CELL_WOOD_SRC : AIE_CELL_STONE_SRC;
+      int cnt = 0;
+      for (int r = max(r0 - hw, 0); r <= min(r0 + hw, P.H - 1); ++r)
+        for (int cc = max(c0 - hw, 0); cc <= min(c0 + hw, P.W - 1); ++cc)
+          cnt += (cb[4 * (r * P.W + cc) + 3] & bit) ? 1 : 0;
+      R_U8(c, o_regen_count)[q] = (uint8_t)cnt;
+    }
+  }
   rebuild_locmap(c);  // all agents off the board
   // ---- wave-uniform sequential part (every lane performs the same LDS updates) ----
   *R_I32(c, o_timestep) = 0;

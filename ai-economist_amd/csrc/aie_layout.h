@@ -112,6 +112,14 @@ typedef struct aie_params {
    * (tools/phase_profile.py); always 0 in normal operation */
   /* per-replica episode accumulators behind env.metrics (component get_metrics): touched only
    * when a trade executes / on tax days, so they live outside the streamed record */
+  /* regen_halfwidth > 0 (dynamic_layout.py:446-463): the regeneration probability of a source block
+   * is signal.convolve2d(max(map, source blocks), regen_weight / d^2 * ones(d, d), "same"), d = 1 + 2 *
+   * halfwidth.  With max_health == 1 the convolved plane IS the source-block plane, so the
+   * probability is regen_p[resource][number of source blocks in the d x d window]; the reset kernel
+   * counts the window once per episode into the record plane o_regen_count. */
+  int32_t regen_conv;    /* 1: some regen_halfwidth > 0 */
+  int32_t o_regen_count; /* u8 [AIE_N_RES][H*W] */
+  double regen_p[AIE_N_RES][50];
   int64_t a_events;      /* dense-log events of replicas [0, ev_replicas): int32 count (16 B), then rows */
   int32_t ev_replicas, ev_cap, ev_stride, ev_pad_;
   int64_t a_metrics;
@@ -604,8 +612,10 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   const int gtb = c->scenario == AIE_SCN_GTB;
   if (gtb && (c->obs_range < 0 || c->obs_range > 15)) AIE__FAIL("mobile_agent_observation_range out of range");
   for (int r = 0; gtb && r < AIE_N_RES; ++r) {
-    if (c->regen_halfwidth[r] != 0) {
-      if (err) snprintf(err, errlen, "regen_halfwidth > 0 is not supported (bit-exact guarantee is for 0)");
+    if (c->regen_halfwidth[r] < 0 || c->regen_halfwidth[r] > 3)
+      AIE__FAIL("regen_halfwidth must be in [0, 3] (dynamic_layout.py:152-153)");
+    if (c->regen_halfwidth[r] > 0 && c->max_health[r] != 1) {
+      if (err) snprintf(err, errlen, "regen_halfwidth > 0 is supported with max_health == 1 (what the reference's scenarios use)");
       return AIE_E_UNSUPPORTED;
     }
     if (!(c->regen_weight[r] >= 0.0 && c->regen_weight[r] <= 1.0)) AIE__FAIL("regen_weight not in [0,1]");
@@ -798,6 +808,15 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   const int n = p->n, HW = p->HW, R = AIE_N_RES;
   int32_t cur = 0;
   p->o_cells = aie__rec(&cur, 4 * HW, 16);
+  p->regen_conv = c->regen_halfwidth[0] > 0 || c->regen_halfwidth[1] > 0;
+  if (p->regen_conv) p->o_regen_count = aie__rec(&cur, AIE_N_RES * HW, 16);
+  for (int r = 0; r < AIE_N_RES; ++r) {
+    /* convolve2d accumulates sum += health * kernel over the window: m equal terms k, in sequence */
+    const int d = 1 + 2 * c->regen_halfwidth[r];
+    const double k = c->regen_weight[r] / (double)(d * d);
+    p->regen_p[r][0] = 0.0;
+    for (int m = 1; m < 50; ++m) p->regen_p[r][m] = p->regen_p[r][m - 1] + k;
+  }
   p->o_inv_coin = aie__rec(&cur, 8 * n, 8);
   p->o_esc_coin = aie__rec(&cur, 8 * n, 8);
   p->o_labor = aie__rec(&cur, 8 * n, 8);
@@ -881,6 +900,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
         d->stride[1] = 4 * (int64_t)p->W;
       }
     }
+    if (p->regen_conv) REC("regen_source_count", AIE_U8, p->o_regen_count, 3, R, p->H, p->W);
     REC("loc_r", AIE_I32, p->o_loc_r, 1, n, 0, 0);
     REC("loc_c", AIE_I32, p->o_loc_c, 1, n, 0, 0);
     REC("inv_res", AIE_I32, p->o_inv_res, 2, R, n, 0);

@@ -579,11 +579,27 @@ static void scenario_step(ctx_t* c) {
     unsigned srcbit = rsrc ? AIE_CELL_WOOD_SRC : AIE_CELL_STONE_SRC;
     double w = p->c.regen_weight[rsrc];
     int mh = p->c.max_health[rsrc];
+    const int hw = p->c.regen_halfwidth[rsrc], d = 1 + 2 * hw;
+    const double kern = w / (double)(d * d); /* regen_weight * ones((d, d)) / d**2, dynamic_layout.py:446-449 */
     for (int cell = 0; cell < p->HW; ++cell) {
       double u = rng_double(c);
       int m = CB(c, cell, rsrc), src = (C_FLAGS(c, cell) & srcbit) ? 1 : 0;
       int health = m > src ? m : src;
-      int respawn = (u < w * (double)health) && src > 0;
+      double prob = w * (double)health;
+      if (hw > 0) {
+        /* signal.convolve2d(health, kernel, "same"): zero-padded window sum, one multiply-add per
+         * kernel element (scipy/signal/_firfilter.c pylab_convolve_2d) */
+        const int r0 = cell / p->W, c0 = cell % p->W;
+        prob = 0.0;
+        for (int r = r0 - hw; r <= r0 + hw; ++r)
+          for (int cc = c0 - hw; cc <= c0 + hw; ++cc) {
+            if (r < 0 || r >= p->H || cc < 0 || cc >= p->W) continue;
+            int q2 = r * p->W + cc;
+            int m2 = CB(c, q2, rsrc), s2 = (C_FLAGS(c, q2) & srcbit) ? 1 : 0;
+            prob += (double)(m2 > s2 ? m2 : s2) * kern;
+          }
+      }
+      int respawn = (u < prob) && src > 0;
       int v = m + respawn;
       CB(c, cell, rsrc) = (uint8_t)(v < mh ? v : mh);
     }
@@ -1018,6 +1034,18 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
     unsigned fl = C_FLAGS(&c, cell);
     CELLS(&c)[cell] = AIE_CELL_PACK((fl & AIE_CELL_STONE_SRC) ? 1 : 0, (fl & AIE_CELL_WOOD_SRC) ? 1 : 0, -1, fl);
   }
+  if (p->regen_conv) /* device bookkeeping: source blocks per regen window (aie_layout.h: regen_conv) */
+    for (int rs = 0; rs < AIE_N_RES; ++rs)
+      for (int cell = 0; cell < HW; ++cell) {
+        const int hw = p->c.regen_halfwidth[rs], r0 = cell / p->W, c0 = cell % p->W;
+        int cnt = 0;
+        for (int r = r0 - hw; r <= r0 + hw; ++r)
+          for (int cc = c0 - hw; cc <= c0 + hw; ++cc)
+            if (r >= 0 && r < p->H && cc >= 0 && cc < p->W &&
+                (C_FLAGS(&c, r * p->W + cc) & (rs ? AIE_CELL_WOOD_SRC : AIE_CELL_STONE_SRC)))
+              cnt++;
+        U8(&c, o_regen_count)[rs * HW + cell] = (uint8_t)cnt;
+      }
   for (int i = 0; i < n; ++i) {
     I32(&c, o_inv_res)[i] = I32(&c, o_inv_res)[n + i] = 0;
     I32(&c, o_esc_res)[i] = I32(&c, o_esc_res)[n + i] = 0;

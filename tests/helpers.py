@@ -155,6 +155,14 @@ def random_gtb_config(seed):
                    starting_wood_coverage=float(pick([0.05, 0.1])), starting_stone_coverage=float(pick([0.05, 0.1])),
                    wood_regen_weight=float(pick([0.01, 0.2])), stone_regen_weight=float(pick([0.01, 0.2])),
                    wood_max_health=int(pick([1, 2])), stone_max_health=int(pick([1, 3])))
+        rng3 = np.random.RandomState(8000 + seed)  # own stream: keeps the draws of older seeds stable
+        if rng3.rand() < 0.6:  # regeneration probability from the d x d neighbourhood of source blocks
+            cfg.update(wood_regen_halfwidth=int(rng3.randint(0, 4)), stone_regen_halfwidth=int(rng3.randint(0, 4)))
+            if cfg["wood_regen_halfwidth"]:
+                cfg["wood_max_health"] = 1
+            if cfg["stone_regen_halfwidth"]:
+                cfg["stone_max_health"] = 1
+            cfg.update(wood_regen_weight=float(rng3.choice([0.2, 0.9])), stone_regen_weight=float(rng3.choice([0.3, 1.0])))
         if kind == "multi_zone":
             cfg.update(num_partitions_row=4, num_partitions_col=4, num_wood_zones=3, num_stone_zones=3,
                        num_wood_and_stone_zones=2)

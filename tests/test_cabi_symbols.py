@@ -46,8 +46,12 @@ def test_arena_bytes_and_validation_without_gpu():
     assert lib.aie_arena_bytes(ctypes.byref(c)) == _cabi.E_INVALID
     assert b"n_agents" in lib.aie_last_error(None)
     c = env.build_config()
-    c.regen_halfwidth[0] = 1
+    c.regen_halfwidth[0] = 1  # one more byte plane pair per record (source blocks per regen window)
+    assert lib.aie_arena_bytes(ctypes.byref(c)) > nbytes
+    c.max_health[0] = 2  # neighbourhood regeneration is implemented for max_health == 1
     assert lib.aie_arena_bytes(ctypes.byref(c)) == _cabi.E_UNSUPPORTED
+    c.regen_halfwidth[0] = 4
+    assert lib.aie_arena_bytes(ctypes.byref(c)) == _cabi.E_INVALID
     c = env.build_config()
     c.full_observability = 1  # every agent sees the whole map: n x 6 x 25 x 25 floats instead of n x 7 x 11 x 11
     assert lib.aie_arena_bytes(ctypes.byref(c)) > nbytes
