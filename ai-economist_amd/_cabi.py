@@ -5,7 +5,7 @@ by env.py purely as the owner of device memory / streams.
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_AGENTS = 64
 MAX_AGENTS_WIDE = 128
 MAX_COMPONENTS = 8
@@ -28,6 +28,7 @@ TAX_MODEL = {
     "model_wrapper": 0,
     "us-federal-single-filer-2018-scaled": 1,
     "fixed-bracket-rates": 2,
+    "saez": 3,
 }
 WARMUP = {"decay": 0, "auto": 1}
 PLANNER_REWARD = {
@@ -123,6 +124,12 @@ class AieConfig(C.Structure):
         ("tax_annealing_warmup", C.c_double),
         ("tax_annealing_slope", C.c_double),
         ("tax_rate_max", C.c_double),
+        ("tax_rate_min", C.c_double),
+        ("saez_buffer_size", C.c_int32),
+        ("saez_pareto_weight_uniform", C.c_int32),
+        ("saez_fixed_elas_given", C.c_int32),
+        ("reserved4_", C.c_int32),
+        ("saez_fixed_elas", C.c_double),
     ]
 
 

@@ -9,6 +9,7 @@
 
 #include "aie_kernels.hip"
 #include "aie_kernels_ose.hip"
+#include "aie_kernels_saez.hip"
 #include "aie_kernels_covid.hip"  // last: switches FP contraction off for the rest of the TU
 
 struct aie_env {
@@ -113,6 +114,11 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
     const int64_t tot = (int64_t)env->P.E * env->P.HW;
     hipLaunchKernelGGL(aie_init_cells_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, env->P, env->arena);
     he = hipDeviceSynchronize();
+  }
+  if (he == hipSuccess && env->P.saez_stride) {  // elas_t = elas_tm1 = 0.5 at construction (redistribution.py:263-266)
+    std::vector<double> rows((size_t)env->P.E * 2, 0.5);
+    he = hipMemcpy2D(env->arena + env->P.a_saez + AIE_SAEZ_OFF_ELAS, (size_t)env->P.saez_stride, rows.data(), 16, 16,
+                     (size_t)env->P.E, hipMemcpyHostToDevice);
   }
   if (he != hipSuccess) {
     snprintf(g_create_err, sizeof(g_create_err), "arena init: %s", hipGetErrorString(he));
@@ -312,6 +318,9 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
                          const NextActions& next) {
   if (!env) return AIE_E_INVALID;
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  if (env->P.saez_stride)  // tax_model "saez": the period-start formula runs ahead of the step (aie_kernels_saez.hip)
+    hipLaunchKernelGGL(aie_saez_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0, static_cast<hipStream_t>(stream),
+                       env->d_params, env->arena);
   if (env->P.c.scenario == AIE_SCN_COVID) {
     const dim3 g((unsigned)env->P.E), b(AIE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -326,7 +335,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
-  else if (env->step_waves == 2 && env->P.ev_replicas > 0)
+  else if (env->step_waves == 2 && (env->P.ev_replicas > 0 || env->P.saez_stride))
     hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
   else if (env->step_waves == 2)

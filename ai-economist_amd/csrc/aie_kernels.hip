@@ -48,6 +48,7 @@ struct Ctx {
   int32_t* dirty;    // LDS [4 + AIE_DIRTY_CAP/2]: count, moved-agent mask (2 words), pad, uint16 cell list
   uint8_t* met;      // GLOBAL: this replica's episode accumulators (aie_layout.h: a_metrics), or nullptr
   int32_t* ev;       // GLOBAL: this replica's dense-log event rows (a_events), or nullptr (not logged)
+  bool saez;         // tax_model == "saez" (compile-time false in the common step kernel, like ev == nullptr)
   int tid;
   int e;
 };
@@ -116,10 +117,12 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e
   q += pad4(P.n) * 4;
   int32_t* dirty = reinterpret_cast<int32_t*>(q);
   uint8_t* met = arena ? arena + P.a_metrics + (int64_t)e * P.met_bytes : nullptr;
-  // with_events == false is a compile-time constant in the common step kernel: every `if (c.ev)` folds away
+  // with_events == false is a compile-time constant in the common step kernel: every `if (c.ev)` / `if (c.saez)`
+  // folds away (environments with dense-log replicas or tax_model "saez" run aie_step_kernel_log)
   int32_t* ev = (with_events && arena && e < P.ev_replicas)
                     ? reinterpret_cast<int32_t*>(arena + P.a_events + (int64_t)e * P.ev_stride) : nullptr;
-  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, met, ev, tid, e};
+  const bool saez = with_events && P.c.tax_model == AIE_TAX_SAEZ;
+  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, met, ev, saez, tid, e};
 }
 
 // ------------------------------------------------------------------------------------
@@ -958,18 +961,37 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
 // ------------------------------------------------------------------------------------
 // PeriodicBracketTax, F/components/redistribution.py
 // ------------------------------------------------------------------------------------
+// Coin arithmetic of the tax / redistribution components without multiply-add contraction: the
+// reference (and the restatement, built with -ffp-contract=off) round every product, and a one-ulp
+// difference in an agent's coin flips discrete decisions later on (income residues of +-1e-15 decide
+// `income < 0` in marginal_rate and `z_t > 0` in the Saez sample filter).
+#pragma clang fp contract(off)
 // curr_rate_max :390-394: the annealed limit follows _last_completions, which generate_masks
 // refreshes AFTER the observations of a reset are built (:1036-1046) -- kept as a state field.
 __device__ __forceinline__ double tax_curr_rate_max(const Ctx& c) {
   return aie_annealed_tax_limit(*R_I32(c, o_tax_last_completions), c.P.c.tax_annealing_warmup,
                                 c.P.c.tax_annealing_slope, c.P.c.tax_rate_max);
 }
+// this replica's Saez block (tax_model "saez", aie_layout.h: a_saez); step / reset kernels only (c.met set)
+__device__ __forceinline__ uint8_t* saez_block(const Ctx& c) {
+  return c.met - c.P.a_metrics - (int64_t)c.e * c.P.met_bytes + c.P.a_saez + (int64_t)c.e * c.P.saez_stride;
+}
 __device__ __forceinline__ double tax_rate(const Ctx& c, int b) {  // curr_marginal_rates :396-417
   if (c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER) return c.P.c.tax_disc_rates[R_I32(c, o_tax_rate_idx)[b]];
+  if (c.saez) {  // np.minimum(curr_bracket_tax_rates, curr_rate_max) :406-409
+    const double r = R_F64(c, o_tax_saez_rates)[b];
+    const double cap = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.P.c.tax_rate_max;
+    return r < cap ? r : cap;
+  }
   const double r = c.P.c.tax_fixed_rates[b];
   if (!c.P.c.tax_annealing) return r;
   const double cap = tax_curr_rate_max(c);
   return r < cap ? r : cap;
+}
+// _curr_rates_obs: the rates the "curr_rates" observation shows (cached at period starts and resets)
+__device__ __forceinline__ double tax_rate_obs(const Ctx& c, int b) {
+  if (c.saez) return R_F64(c, o_tax_saez_obs_rates)[b];
+  return tax_rate(c, b);
 }
 // planner tax-rate action j of a bracket: allowed by the annealing schedule? (annealed_tax_mask,
 // utils.py:59-118, evaluated with the completions count of the episode's reset)
@@ -1065,10 +1087,51 @@ __device__ __forceinline__ void tax_enact(const Ctx& c, Agents& A) {
     A.coin += lump;
     R_F64(c, o_tax_last_coin)[i] = A.coin + A.esc_coin;
   }
+  if (c.saez) {  // _update_saez_buffer :533-541 (global memory, tax days only)
+    uint8_t* blk = saez_block(c);
+    int32_t* hdr = reinterpret_cast<int32_t*>(blk);
+    double* buf = reinterpret_cast<double*>(blk + AIE_SAEZ_OFF_BUF);
+    int len = uni(hdr[0]);
+    if (i < n) {
+      buf[2 * (len + i)] = R_F64(c, o_tax_last_income)[i];
+      buf[2 * (len + i) + 1] = R_F64(c, o_tax_last_marginal_rate)[i];
+    }
+    len += n;
+    const int size = c.P.c.saez_buffer_size;
+    if (len > size) {  // drop the oldest: move down chunk by chunk (a chunk's loads precede its stores;
+      const int shift = 2 * (len - size);  // later chunks only read above what earlier ones wrote)
+      __builtin_amdgcn_s_waitcnt(0);
+      for (int base = 0; base < 2 * size; base += AIE_NT) {
+        const int q = base + i;
+        double v = 0;
+        if (q < 2 * size) v = buf[q + shift];
+        __builtin_amdgcn_s_waitcnt(0);
+        if (q < 2 * size) buf[q] = v;
+      }
+      len = size;
+    }
+    if (i == 0) hdr[0] = len;
+  }
 }
 // component_step :945-972 + set_new_period_rates_model :419-434
-__device__ __forceinline__ void tax_component_step(const Ctx& c, Agents& A) {
+__device__ __forceinline__ void tax_component_step(const Ctx& c, MTL& ml, Agents& A) {
   int pos = uni(*R_I32(c, o_tax_cycle_pos));
+  if (pos == 1 && c.saez) {  // compute_and_set_new_period_rates_from_saez_formula
+    uint8_t* blk = saez_block(c);
+    if (uni(reinterpret_cast<const int32_t*>(blk)[1])) {  // the formula ran in aie_saez_kernel just before this launch
+      if (c.tid < c.P.NB) R_F64(c, o_tax_saez_rates)[c.tid] = reinterpret_cast<const double*>(blk + AIE_SAEZ_OFF_NEXT)[c.tid];
+    } else {  // np.random.uniform(low=rate_min, high=curr_rate_max, size=n_brackets) :451-457
+      const double lo = c.P.c.tax_rate_min;
+      const double hi = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.P.c.tax_rate_max;
+      for (int b = 0; b < c.P.NB; ++b) {
+        const double r = lo + (hi - lo) * rng_double(ml, c.tid);
+        if (c.tid == b) R_F64(c, o_tax_saez_rates)[b] = r;
+      }
+    }
+    AIE_WSYNC();
+    if (c.tid < c.P.NB) R_F64(c, o_tax_saez_obs_rates)[c.tid] = tax_rate(c, c.tid);  // _curr_rates_obs :959
+    AIE_WSYNC();
+  }
   if (pos == 1 && c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER && !c.P.c.tax_disable) {
     if (c.tid < c.P.NB) {
       const int a = c.act_p[c.tid];
@@ -1104,6 +1167,8 @@ __device__ __forceinline__ void wealth_component_step(const Ctx& c, Agents& A) {
   }
   if (c.tid < n) A.coin = tot / (double)n - A.esc_coin;
 }
+
+#pragma clang fp contract(fast)
 
 // ------------------------------------------------------------------------------------
 // LayoutFromFile.scenario_step, layout_from_file.py:372-410.
@@ -1723,7 +1788,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
       }
       if (planner && j == NB + 3 + n) continue;
       float v;
-      if (j < NB) v = (float)tax_rate(c, j);
+      if (j < NB) v = (float)tax_rate_obs(c, j);
       else if (j == NB) v = is_first_day;
       else if (j == NB + 1) v = is_tax_day;
       else if (j < NB + 2 + n) v = (float)scr_sorted_inc(c)[j - NB - 2];
@@ -1900,7 +1965,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
           case AIE_COMP_BUILD: if (!(skip & 2048)) build_component_step(c, ml, A); break;
           case AIE_COMP_CDA: if (!(skip & 4096)) cda_component_step(c, A); break;
           case AIE_COMP_GATHER: if (!(skip & 8192)) gather_component_step(c, ml, A); break;
-          case AIE_COMP_TAX: if (!(skip & 16384)) tax_component_step(c, A); break;
+          case AIE_COMP_TAX: if (!(skip & 16384)) tax_component_step(c, ml, A); break;
           case AIE_COMP_WEALTH_REDISTRIBUTION: wealth_component_step(c, A); break;
           default: break;
         }
@@ -2089,6 +2154,14 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
           R_F64(c, o_tax_last_marginal_rate)[i] = 0;
         }
         *R_F64(c, o_tax_total_collected) = 0;
+        if (P.c.tax_model == AIE_TAX_SAEZ) {
+          // _curr_rates_obs first (:1123, still the previous episode's rates), then
+          // curr_bracket_tax_rates = running_avg_tax_rates (:1136-1137)
+          for (int b = 0; b < P.NB; ++b) R_F64(c, o_tax_saez_obs_rates)[b] = tax_rate(c, b);
+          AIE_WSYNC();
+          for (int b = 0; b < P.NB; ++b)
+            R_F64(c, o_tax_saez_rates)[b] = reinterpret_cast<const double*>(saez_block(c) + AIE_SAEZ_OFF_AVG)[b];
+        }
         break;
       default: break;
     }

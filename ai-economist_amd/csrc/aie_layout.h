@@ -120,6 +120,18 @@ typedef struct aie_params {
   int32_t regen_conv;    /* 1: some regen_halfwidth > 0 */
   int32_t o_regen_count; /* u8 [AIE_N_RES][H*W] */
   double regen_p[AIE_N_RES][50];
+  /* tax_model "saez" (redistribution.py:436-823): per-replica block outside the streamed record,
+   * touched on tax days and period starts only.  Layout (bytes): int32 len, int32 reached_min_samples,
+   * pad to 16; f64 elas[4] = {elas_t, elas_tm1, log_z0_t, log_z0_tm1}; f64 running_avg[AIE_MAX_BRACKETS];
+   * f64 next_rates[AIE_MAX_BRACKETS] (formula output for the coming period start, written by
+   * aie_saez_kernel); f64 buffer[saez_cap][2] = (income, marginal rate), oldest first. */
+  int64_t a_saez;
+  int32_t saez_stride, saez_cap;
+  int32_t o_tax_saez_rates; /* record: f64 [NB] curr_bracket_tax_rates */
+  int32_t o_tax_saez_obs_rates; /* record: f64 [NB] _curr_rates_obs: the rates the "curr_rates" observation shows,
+                                   refreshed at period starts and -- BEFORE the running average replaces the
+                                   bracket rates -- at reset (redistribution.py:1123, 1136-1137) */
+  double saez_edges[AIE_SAEZ_BINS + 1]; /* np.linspace(0, top cutoff, 101), :286-288 */
   int64_t a_events;      /* dense-log events of replicas [0, ev_replicas): int32 count (16 B), then rows */
   int32_t ev_replicas, ev_cap, ev_stride, ev_pad_;
   int64_t a_metrics;
@@ -419,6 +431,32 @@ static inline void aie__alloc_metrics(aie_params* p, int64_t* a) {
   p->a_metrics = *a;
   *a = aie__align(*a + (int64_t)p->E * p->met_bytes, 256);
 }
+#define AIE_SAEZ_OFF_ELAS 16
+#define AIE_SAEZ_OFF_AVG (AIE_SAEZ_OFF_ELAS + 32)
+#define AIE_SAEZ_OFF_NEXT (AIE_SAEZ_OFF_AVG + 8 * AIE_MAX_BRACKETS)
+#define AIE_SAEZ_OFF_BUF (AIE_SAEZ_OFF_NEXT + 8 * AIE_MAX_BRACKETS)
+static inline void aie__alloc_saez(const aie_config* c, aie_params* p, int64_t* a) {
+  p->a_saez = 0; p->saez_stride = 0; p->saez_cap = 0;
+  if (!p->has_tax || c->tax_model != AIE_TAX_SAEZ) return;
+  p->saez_cap = c->saez_buffer_size + p->n; /* a tax day appends n pairs before the oldest are dropped */
+  p->saez_stride = (int32_t)aie__align(AIE_SAEZ_OFF_BUF + (int64_t)p->saez_cap * 16, 64);
+  p->a_saez = *a;
+  *a = aie__align(*a + (int64_t)p->E * p->saez_stride, 256);
+  const double top = c->tax_bracket_cutoffs[p->NB - 1], step = top / (double)AIE_SAEZ_BINS;
+  for (int i = 0; i <= AIE_SAEZ_BINS; ++i) p->saez_edges[i] = (double)i * step + 0.0; /* np.linspace */
+  p->saez_edges[AIE_SAEZ_BINS] = top;
+}
+static inline void aie__add_saez_tensors(const aie_params* p, aie_tensor_table* tt) {
+  if (!p->saez_stride) return;
+  const int64_t s0 = p->a_saez, ss = p->saez_stride, E = p->E;
+  aie__add(tt, "saez_buffer_len", AIE_I32, s0, ss, 0, 0, 0, 0, 0, E);
+  aie__add(tt, "saez_reached_min_samples", AIE_I32, s0 + 4, ss, 0, 0, 0, 0, 0, E);
+  aie__add(tt, "saez_elas", AIE_F64, s0 + AIE_SAEZ_OFF_ELAS, ss, 1, 4, 0, 0, 0, E);
+  aie__add(tt, "saez_running_avg_tax_rates", AIE_F64, s0 + AIE_SAEZ_OFF_AVG, ss, 1, p->NB, 0, 0, 0, E);
+  aie__add(tt, "saez_next_rates", AIE_F64, s0 + AIE_SAEZ_OFF_NEXT, ss, 1, p->NB, 0, 0, 0, E);
+  aie__add(tt, "saez_buffer", AIE_F64, s0 + AIE_SAEZ_OFF_BUF, ss, 2, p->saez_cap, 2, 0, 0, E);
+}
+
 /* dense-log event rows (include/aie.h: AIE_EV_*): at most n builds, 2n gathers, NB + n tax rows
  * and one trade per resting order of a commodity in a step */
 static inline void aie__alloc_events(const aie_config* c, aie_params* p, int64_t* a) {
@@ -682,9 +720,15 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   if (p->has_tax) {
     if (c->tax_period < 1) AIE__FAIL("Tax.period must be > 0");
     if (c->tax_n_brackets < 2 || c->tax_n_brackets > AIE_MAX_BRACKETS) AIE__FAIL("Tax.n_brackets out of range");
-    if (c->tax_model < AIE_TAX_MODEL_WRAPPER || c->tax_model > AIE_TAX_FIXED) {
-      if (err) snprintf(err, errlen, "tax_model not supported (saez is host-side episodic numerics)");
-      return AIE_E_UNSUPPORTED;
+    if (c->tax_model < AIE_TAX_MODEL_WRAPPER || c->tax_model > AIE_TAX_SAEZ) AIE__FAIL("unknown tax_model");
+    if (c->tax_model == AIE_TAX_SAEZ) {
+      if (c->scenario != AIE_SCN_GTB) {
+        if (err) snprintf(err, errlen, "tax_model saez is implemented for the gather-trade-build scenarios");
+        return AIE_E_UNSUPPORTED;
+      }
+      if (c->saez_buffer_size < 1 || c->saez_buffer_size > 4096) AIE__FAIL("saez_buffer_size out of range");
+      if (!(c->tax_rate_min >= 0.0 && c->tax_rate_min <= c->tax_rate_max)) AIE__FAIL("rate_min / rate_max");
+      if (c->saez_fixed_elas_given && !(c->saez_fixed_elas >= 0.0)) AIE__FAIL("saez_fixed_elas must be >= 0");
     }
     if (c->tax_bracket_cutoffs[0] != 0.0) AIE__FAIL("bracket_cutoffs[0] must be 0 (redistribution.py:243)");
     if (c->tax_model == AIE_TAX_MODEL_WRAPPER && !c->tax_disable) {
@@ -846,6 +890,10 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     p->o_tax_cycle_pos = aie__rec(&cur, 4, 4);
     p->o_tax_last_completions = aie__rec(&cur, 4, 4);
     p->o_tax_rate_idx = aie__rec(&cur, 4 * p->NB, 4);
+    if (c->tax_model == AIE_TAX_SAEZ) {
+      p->o_tax_saez_rates = aie__rec(&cur, 8 * p->NB, 8);
+      p->o_tax_saez_obs_rates = aie__rec(&cur, 8 * p->NB, 8);
+    }
   }
   p->o_timestep = aie__rec(&cur, 4, 4);
   p->o_completions = aie__rec(&cur, 4, 4);
@@ -883,6 +931,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->a_done = a;  a = aie__align(a + E, 256);
   aie__alloc_metrics(p, &a);
   aie__alloc_events(c, p, &a);
+  aie__alloc_saez(c, p, &a);
   p->arena_bytes = a;
 
   /* ---- tensor table ------------------------------------------------------------ */
@@ -926,6 +975,10 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
       REC("tax_cycle_pos", AIE_I32, p->o_tax_cycle_pos, 0, 0, 0, 0);
     REC("tax_last_completions", AIE_I32, p->o_tax_last_completions, 0, 0, 0, 0);
       REC("tax_rate_idx", AIE_I32, p->o_tax_rate_idx, 1, p->NB, 0, 0);
+      if (c->tax_model == AIE_TAX_SAEZ) {
+        REC("tax_saez_bracket_rates", AIE_F64, p->o_tax_saez_rates, 1, p->NB, 0, 0);
+        REC("tax_saez_observed_rates", AIE_F64, p->o_tax_saez_obs_rates, 1, p->NB, 0, 0);
+      }
       REC("tax_last_coin", AIE_F64, p->o_tax_last_coin, 1, n, 0, 0);
       REC("tax_last_income", AIE_F64, p->o_tax_last_income, 1, n, 0, 0);
       REC("tax_last_marginal_rate", AIE_F64, p->o_tax_last_marginal_rate, 1, n, 0, 0);
@@ -965,6 +1018,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     DENSE("done", AIE_U8, p->a_done, 0, 0, 0, 0, 0);
     aie__add_metrics_tensors(p, tt);
     aie__add_event_tensors(p, tt);
+    aie__add_saez_tensors(p, tt);
 #undef DENSE
   }
   return AIE_OK;

@@ -3,10 +3,11 @@ wealth_component_step in csrc/aie_kernels.hip / aie_kernels_ose.hip) and
 `PeriodicBracketTax` (reference: F/components/redistribution.py:78-346, 920-939;
 dynamics -> tax_component_step / tax_enact in csrc/aie_kernels.hip).
 
-Supported tax models: "model_wrapper" (planner picks discretised rates),
-"us-federal-single-filer-2018-scaled", "fixed-bracket-rates".  The Saez model
-(redistribution.py:436-823) is episodic host-side numerics and is listed under
-"next" in DESIGN.md.
+Tax models: "model_wrapper" (planner picks discretised rates),
+"us-federal-single-filer-2018-scaled", "fixed-bracket-rates" and "saez"
+(redistribution.py:436-823: rates from the Saez formula over a per-replica buffer of
+observed (income, marginal rate) pairs -> csrc/aie_kernels_saez.hip; the cross-replica
+"global" buffer of the RLlib trainer, remote.py:56-73, is not part of the environment step).
 """
 import numpy as np
 
@@ -50,9 +51,14 @@ class PeriodicBracketTax(BaseComponent):
         self.tax_model = tax_model
         assert self.tax_model in ["model_wrapper", "us-federal-single-filer-2018-scaled",
                                   "saez", "fixed-bracket-rates"]
-        if self.tax_model == "saez":
-            raise NotImplementedError(
-                "tax_model='saez' is not implemented by the MI355X backend yet")
+        self.pareto_weight_type = pareto_weight_type
+        assert self.pareto_weight_type in ("inverse_income", "uniform")  # redistribution.py:636-643
+        self._saez_fixed_elas = saez_fixed_elas
+        if self._saez_fixed_elas is not None:
+            self._saez_fixed_elas = float(self._saez_fixed_elas)
+            assert self._saez_fixed_elas >= 0
+        # samples a replica collects before the formula replaces random rates (redistribution.py:276)
+        self._buffer_size = 500
         self.tax_annealing_schedule = tax_annealing_schedule
         if tax_annealing_schedule is not None:  # redistribution.py:317-325
             assert isinstance(self.tax_annealing_schedule, (tuple, list))
@@ -115,6 +121,23 @@ class PeriodicBracketTax(BaseComponent):
         else:
             self._fixed_bracket_rates = None
 
+    # ---- Saez sample buffers (redistribution.py:515-546); `env` = the owning environment ----
+    def reset_saez_buffers(self, env):
+        """Empties every replica's sample buffer: random rates again until it refills."""
+        t = env.backend.tensors
+        t["saez_buffer_len"].zero_()
+        t["saez_reached_min_samples"].zero_()
+
+    def get_local_saez_buffer(self, env):
+        """(buffer [E, capacity, 2] of (income, marginal rate) pairs, oldest first; filled lengths [E])."""
+        t = env.backend.tensors
+        return t["saez_buffer"], t["saez_buffer_len"]
+
+    def set_global_saez_buffer(self, global_saez_buffer):
+        raise NotImplementedError(
+            "the cross-replica buffer union belongs to the RLlib trainer (tutorials/rllib/utils/remote.py:56-73), "
+            "not to the environment step; every replica of the batch uses its own buffer")
+
     def get_n_actions(self, agent_cls_name):
         if agent_cls_name == "BasicPlanner":
             if self.tax_model == "model_wrapper" and not self.disable_taxes:
@@ -127,6 +150,11 @@ class PeriodicBracketTax(BaseComponent):
             raise ValueError("n_brackets > {}".format(_cabi.MAX_BRACKETS))
         cfg.tax_disable = int(self.disable_taxes)
         cfg.tax_rate_max = float(self.rate_max)
+        cfg.tax_rate_min = float(self.rate_min)
+        cfg.saez_buffer_size = int(self._buffer_size)
+        cfg.saez_pareto_weight_uniform = int(self.pareto_weight_type == "uniform")
+        cfg.saez_fixed_elas_given = int(self._saez_fixed_elas is not None)
+        cfg.saez_fixed_elas = float(self._saez_fixed_elas or 0.0)
         if self.tax_annealing_schedule is not None:
             cfg.tax_annealing = 1
             cfg.tax_annealing_warmup = float(self._annealing_warmup)
@@ -146,6 +174,7 @@ class PeriodicBracketTax(BaseComponent):
             cfg.tax_n_disc_rates = 0
             base = (self.US_FEDERAL_2018
                     if self.tax_model == "us-federal-single-filer-2018-scaled"
+                    else np.zeros(self.n_brackets) if self.tax_model == "saez"
                     else self._fixed_bracket_rates)
             for i, v in enumerate(np.minimum(np.array(base, dtype=np.float64), self.rate_max)):
                 cfg.tax_fixed_rates[i] = float(v)

@@ -177,6 +177,8 @@ def tax_metrics(comp, env, t):  # redistribution.py:1141-1186
                 inc = t["metrics_tax_income_sum"][rows, idx]
                 paid = t["metrics_tax_paid_sum"][rows, idx]
                 out["avg_tax_rate/%s" % tag] = paid / np.maximum(0.001, inc)
+            if comp.tax_model == "saez":  # running elasticity estimate, :1183-1185
+                out["saez/estimated_elasticity"] = t["saez_elas"][:, 1].astype(np.float64)
     return out
 
 

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AIE_ABI_VERSION 4
+#define AIE_ABI_VERSION 5
 
 #define AIE_MAX_AGENTS 64      /* mobile agents per replica, spatial scenarios (one lane each) */
 #define AIE_MAX_AGENTS_WIDE 128 /* mobile agents per replica, map-less one-step-economy        */
@@ -85,8 +85,11 @@ enum { AIE_SKILL_NONE = 0, AIE_SKILL_PARETO = 1, AIE_SKILL_LOGNORMAL = 2 };
 enum {
   AIE_TAX_MODEL_WRAPPER = 0,   /* "model_wrapper": planner actions pick the rates       */
   AIE_TAX_US_FEDERAL = 1,      /* "us-federal-single-filer-2018-scaled"                 */
-  AIE_TAX_FIXED = 2            /* "fixed-bracket-rates"                                 */
+  AIE_TAX_FIXED = 2,           /* "fixed-bracket-rates"                                 */
+  AIE_TAX_SAEZ = 3             /* "saez": rates from the Saez formula on a buffer of observed
+                                  (income, marginal rate) pairs, redistribution.py:436-823 */
 };
+#define AIE_SAEZ_BINS 100      /* _saez_n_estimation_bins, redistribution.py:284         */
 enum { AIE_WARMUP_DECAY = 0, AIE_WARMUP_AUTO = 1 };
 enum {
   AIE_PLANNER_REW_COIN_EQ_TIMES_PROD = 0,
@@ -221,6 +224,14 @@ typedef struct aie_config {
   int32_t dense_log_replicas;
   double tax_annealing_warmup, tax_annealing_slope;
   double tax_rate_max;               /* rate_max kwarg (0 when taxes are disabled)        */
+
+  /* tax_model="saez" (redistribution.py:262-296) */
+  double tax_rate_min;               /* rate_min kwarg (0 when taxes are disabled)        */
+  int32_t saez_buffer_size;          /* _buffer_size: samples before the formula is used (500) */
+  int32_t saez_pareto_weight_uniform;/* pareto_weight_type: 0 "inverse_income", 1 "uniform" */
+  int32_t saez_fixed_elas_given;     /* saez_fixed_elas is not None                        */
+  int32_t reserved4_;
+  double saez_fixed_elas;
 } aie_config;
 
 /* ---- dense-log events: one row of "log_events" int32 [L, cap, AIE_EV_WORDS] ------- */

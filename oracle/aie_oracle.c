@@ -461,12 +461,21 @@ static double tax_rate(ctx_t* c, int b) {
   const aie_params* p = c->p;
   if (p->c.tax_model == AIE_TAX_MODEL_WRAPPER) return p->c.tax_disc_rates[I32(c, o_tax_rate_idx)[b]];
   double r = p->c.tax_fixed_rates[b];
+  if (p->c.tax_model == AIE_TAX_SAEZ) { /* np.minimum(curr_bracket_tax_rates, curr_rate_max) :406-409 */
+    r = F64(c, o_tax_saez_rates)[b];
+    if (!p->c.tax_annealing && p->c.tax_rate_max < r) r = p->c.tax_rate_max;
+  }
   if (p->c.tax_annealing) {
     double cap = aie_annealed_tax_limit(*I32(c, o_tax_last_completions), p->c.tax_annealing_warmup,
                                         p->c.tax_annealing_slope, p->c.tax_rate_max);
     if (cap < r) r = cap;
   }
   return r;
+}
+/* _curr_rates_obs: what the "curr_rates" observation shows (cached at period starts and resets) */
+static double tax_rate_obs(ctx_t* c, int b) {
+  if (c->p->c.tax_model == AIE_TAX_SAEZ) return F64(c, o_tax_saez_obs_rates)[b];
+  return tax_rate(c, b);
 }
 /* annealed_tax_mask utils.py:59-118 for discretised rate k */
 static float tax_rate_action_mask(ctx_t* c, int k) {
@@ -539,6 +548,201 @@ static void tax_enact(ctx_t* c) {
     F64(c, o_tax_last_coin)[i] = F64(c, o_inv_coin)[i] + F64(c, o_esc_coin)[i];
   }
 }
+/* ------------------------------------------------------------------------------- */
+/* tax_model == "saez", redistribution.py:436-823.  State: aie_layout.h a_saez.     */
+/* ------------------------------------------------------------------------------- */
+#define SAEZ(c) ((c)->arena + (c)->p->a_saez + (int64_t)(c)->e * (c)->p->saez_stride)
+static double saez_curr_rate_max(ctx_t* c) { /* curr_rate_max :390-394 */
+  const aie_params* p = c->p;
+  if (!p->c.tax_annealing) return p->c.tax_rate_max;
+  return aie_annealed_tax_limit(*I32(c, o_tax_last_completions), p->c.tax_annealing_warmup,
+                                p->c.tax_annealing_slope, p->c.tax_rate_max);
+}
+static double saez_pareto(const aie_params* p, double z) { /* :636-643 */
+  if (p->c.saez_pareto_weight_uniform) return 1.0;
+  return 1.0 / (z > 1.0 ? z : 1.0);
+}
+static double clip01(double x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
+
+/* estimate_uniform_income_elasticity :548-596 */
+static void saez_estimate_elasticity(const double* buf, int len, double elas_tm1, double log_z0_tm1,
+                                     double* elas_out, double* log_z0_out) {
+  double* zs = (double*)malloc(sizeof(double) * (size_t)(2 * len + 2));
+  double* taus = zs + len + 1;
+  int m = 0;
+  for (int k = 0; k < len; ++k)
+    if (buf[2 * k] > 0 && buf[2 * k + 1] < 1) { zs[m] = buf[2 * k]; taus[m] = buf[2 * k + 1]; m++; }
+  *elas_out = elas_tm1; *log_z0_out = log_z0_tm1;
+  if (m >= 10) {
+    double mean = np_sum(taus, m) / m; /* np.std: sqrt(mean(abs(x - mean)**2)) */
+    double* d = (double*)malloc(sizeof(double) * (size_t)m);
+    for (int k = 0; k < m; ++k) d[k] = (taus[k] - mean) * (taus[k] - mean);
+    double sd = sqrt(np_sum(d, m) / m);
+    free(d);
+    if (!(sd < 1e-6)) {
+      /* OLS of log income on [log(1 - marginal rate), 1]; the 2x2 normal equations in closed form
+       * (the reference goes through np.linalg.inv: agreement to ~1e-12 relative, not bitwise) */
+      double sxx = 0, sx = 0, sxy = 0, sy = 0;
+      for (int k = 0; k < m; ++k) {
+        double t1 = 1 - taus[k]; if (t1 < 1e-9) t1 = 1e-9;
+        double zz = zs[k]; if (zz < 1e-9) zz = 1e-9;
+        double x = log(t1), y = log(zz);
+        sxx += x * x; sx += x; sxy += x * y; sy += y;
+      }
+      double det = sxx * (double)m - sx * sx;
+      double i00 = (double)m / det, i01 = -sx / det, i11 = sxx / det;
+      double elas = i00 * sxy + i01 * sy, log_z0 = i01 * sxy + i11 * sy;
+      double inst = elas > 0.0 ? elas : 0.0;
+      *elas_out = ((1 - 0.98) * inst) + (0.98 * elas_tm1);
+      *log_z0_out = log_z0;
+    }
+  }
+  free(zs);
+}
+
+/* compute_and_set_new_period_rates_from_saez_formula :437-513 (buffer already has >= min samples) */
+static void saez_formula(ctx_t* c, double* rates) {
+  const aie_params* p = c->p;
+  uint8_t* blk = SAEZ(c);
+  const int len = *(int32_t*)blk, NB = p->NB, T = AIE_SAEZ_BINS;
+  double* el = (double*)(blk + AIE_SAEZ_OFF_ELAS); /* elas_t, elas_tm1, log_z0_t, log_z0_tm1 */
+  double* avg = (double*)(blk + AIE_SAEZ_OFF_AVG);
+  const double* buf = (const double*)(blk + AIE_SAEZ_OFF_BUF);
+  const double* edges = p->saez_edges;
+  el[1] = el[0]; el[3] = el[2];
+  double elas_t, log_z0_t;
+  saez_estimate_elasticity(buf, len, el[1], el[3], &elas_t, &log_z0_t);
+  el[0] = elas_t; el[2] = log_z0_t;
+  if (p->c.saez_fixed_elas_given) elas_t = p->c.saez_fixed_elas;
+
+  /* get_binned_saez_welfare_weight_and_pareto_params :598-752; np.histogram: [e_i, e_i+1), last bin closed */
+  double counts[AIE_SAEZ_BINS];
+  for (int i = 0; i < T; ++i) counts[i] = 0;
+  int n_below = 0, n_above = 0;
+  double* above = (double*)malloc(sizeof(double) * (size_t)(2 * len + 2));
+  double* above_w = above + len + 1;
+  for (int k = 0; k < len; ++k) {
+    double z = buf[2 * k];
+    if (z < edges[0]) n_below++;
+    else if (z > edges[T]) { above[n_above] = z; above_w[n_above] = saez_pareto(p, z); n_above++; }
+    else {
+      int lo = 0, hi = T; /* largest i with edges[i] <= z */
+      while (hi - lo > 1) { int mid = (lo + hi) / 2; if (edges[mid] <= z) lo = mid; else hi = mid; }
+      counts[lo] += 1;
+    }
+  }
+  double w_below = (double)n_below; /* pareto(max(z, 0)) == 1 for z < 0, either weight type */
+  double w_above = n_above > 0 ? np_sum(above_w, n_above) : 0.0;
+  double per_bin[AIE_SAEZ_BINS + 1], dens[AIE_SAEZ_BINS + 1], pz[AIE_SAEZ_BINS + 1];
+  for (int i = 0; i < T; ++i) per_bin[i] = counts[i] * saez_pareto(p, 0.5 * (edges[i] + edges[i + 1]));
+  double cum = np_sum(per_bin, T);
+  cum += w_below; cum += w_above;
+  const double norm = cum + 1e-9;
+  for (int i = 0; i < T; ++i) dens[i] = per_bin[i] / norm;
+  dens[T] = w_above / norm;
+  const double n_total = np_sum(counts, T) + n_below + n_above;
+  for (int i = 0; i < T; ++i) pz[i] = counts[i] / n_total;
+  pz[T] = n_above / n_total;
+  const double p_below = n_below / n_total;
+  double g[AIE_SAEZ_BINS + 1], gz[AIE_SAEZ_BINS + 1], az[AIE_SAEZ_BINS + 1], taus[AIE_SAEZ_BINS + 1];
+  { /* reversed cumulative sums: weight / probability of incomes >= z */
+    double cd = 0, cp = 0;
+    for (int i = T; i >= 0; --i) {
+      cd = (i == T) ? dens[i] : cd + dens[i];
+      cp = (i == T) ? pz[i] : cp + pz[i];
+      g[i] = cd / (cp + 1e-9);
+    }
+  }
+  for (int i = 0; i < T; ++i) gz[i] = 0.5 * (g[i] + g[i + 1]);
+  gz[T] = g[T];
+  { /* compute_binned_a_distribution :700-744 */
+    double cum_pz = pz[0] + p_below;
+    for (int i = 0; i < T; ++i) {
+      if (i > 0) cum_pz = clip01(cum_pz + pz[i]);
+      double p_geq = 1 - cum_pz + (0.5 * pz[i]);
+      if (pz[i] == 0) az[i] = NAN;
+      else {
+        double z = 0.5 * (edges[i] + edges[i + 1]);
+        double paz = z * pz[i] / (clip01(p_geq) + 1e-9);
+        az[i] = paz / (edges[i + 1] - edges[i]);
+      }
+    }
+    if (n_above > 0) {
+      double mean_above = np_sum(above, n_above) / n_above;
+      az[T] = mean_above / (mean_above - edges[T] + 1e-9);
+    } else az[T] = 0.0;
+  }
+  free(above);
+  /* get_saez_marginal_rates :754-790 */
+  for (int i = 0; i <= T; ++i) taus[i] = (1.0 - gz[i]) / (1.0 - gz[i] + az[i] * elas_t + 1e-9);
+  {
+    double last_rate = 0.0; int last_idx = -1;
+    for (int i = 0; i <= T; ++i) {
+      if (isnan(taus[i])) continue;
+      if (i - last_idx > 1) { /* np.linspace(last, tau, gap + 2)[1:-1] */
+        int gap = i - last_idx - 1;
+        double step = (taus[i] - last_rate) / (double)(gap + 1);
+        for (int j = 1; j <= gap; ++j) taus[last_idx + j] = (double)j * step + last_rate;
+      }
+      last_rate = taus[i]; last_idx = i;
+    }
+  }
+  /* bracketize_schedule :792-823 */
+  double last_total = 0;
+  for (int b = 0; b + 1 < NB; ++b) {
+    const double income = p->c.tax_bracket_cutoffs[b + 1];
+    double bin_taxes[AIE_SAEZ_BINS + 1];
+    for (int i = 0; i <= T; ++i) {
+      double past = income - edges[i]; if (past < 0) past = 0;
+      double size = i < T ? edges[i + 1] - edges[i] : INFINITY;
+      bin_taxes[i] = taus[i] * (size < past ? size : past);
+    }
+    double due = np_sum(bin_taxes, T + 1); if (due < 0) due = 0;
+    rates[b] = (due - last_total) / (p->c.tax_bracket_cutoffs[b + 1] - p->c.tax_bracket_cutoffs[b]);
+    last_total = due;
+  }
+  rates[NB - 1] = taus[T];
+  const double lo = p->c.tax_rate_min, hi = saez_curr_rate_max(c); /* np.clip :497-506 */
+  for (int b = 0; b < NB; ++b) {
+    if (rates[b] < lo) rates[b] = lo;
+    if (rates[b] > hi) rates[b] = hi;
+    avg[b] = (avg[b] * 0.99) + (rates[b] * 0.01);
+  }
+}
+
+/* period start: random rates until the buffer holds _buffer_size samples :444-458 */
+static void saez_set_new_period_rates(ctx_t* c) {
+  const aie_params* p = c->p;
+  int32_t* hdr = (int32_t*)SAEZ(c);
+  double* rates = F64(c, o_tax_saez_rates);
+  if (!hdr[1] && hdr[0] >= p->c.saez_buffer_size) hdr[1] = 1;
+  if (!hdr[1]) { /* np.random.uniform(low=rate_min, high=curr_rate_max, size=n_brackets): low + (high - low) * u */
+    const double lo = p->c.tax_rate_min, hi = saez_curr_rate_max(c);
+    for (int b = 0; b < p->NB; ++b) rates[b] = lo + (hi - lo) * rng_double(c);
+    return;
+  }
+  double next[AIE_MAX_BRACKETS];
+  saez_formula(c, next);
+  for (int b = 0; b < p->NB; ++b) rates[b] = next[b];
+  memcpy(SAEZ(c) + AIE_SAEZ_OFF_NEXT, next, sizeof(double) * (size_t)p->NB);
+}
+/* _update_saez_buffer :533-541 */
+static void saez_update_buffer(ctx_t* c) {
+  const aie_params* p = c->p;
+  int32_t* hdr = (int32_t*)SAEZ(c);
+  double* buf = (double*)(SAEZ(c) + AIE_SAEZ_OFF_BUF);
+  for (int i = 0; i < p->n; ++i) {
+    buf[2 * (hdr[0] + i)] = F64(c, o_tax_last_income)[i];
+    buf[2 * (hdr[0] + i) + 1] = F64(c, o_tax_last_marginal_rate)[i];
+  }
+  hdr[0] += p->n;
+  if (hdr[0] > p->c.saez_buffer_size) {
+    int drop = hdr[0] - p->c.saez_buffer_size;
+    memmove(buf, buf + 2 * drop, sizeof(double) * 2 * (size_t)p->c.saez_buffer_size);
+    hdr[0] = p->c.saez_buffer_size;
+  }
+}
+
 /* component_step :945-972 (+ set_new_period_rates_model :419-434) */
 static void tax_step(ctx_t* c) {
   const aie_params* p = c->p;
@@ -549,8 +753,13 @@ static void tax_step(ctx_t* c) {
       if (a > 0 && a <= p->c.tax_n_disc_rates) I32(c, o_tax_rate_idx)[b] = a - 1;
     }
   }
+  if (*pos == 1 && p->c.tax_model == AIE_TAX_SAEZ) {
+    saez_set_new_period_rates(c);
+    for (int b = 0; b < p->NB; ++b) F64(c, o_tax_saez_obs_rates)[b] = tax_rate(c, b); /* _curr_rates_obs :959 */
+  }
   if (*pos >= p->c.tax_period) {
     tax_enact(c);
+    if (p->c.tax_model == AIE_TAX_SAEZ) saez_update_buffer(c);
     *pos = 0;
   }
   *pos += 1;
@@ -826,7 +1035,7 @@ static void write_obs(ctx_t* c) {
     double cmr = 0;
     if (p->has_tax) {
       float* g = f + p->fa_tax;
-      for (int b = 0; b < p->NB; ++b) g[b] = (float)tax_rate(c, b);
+      for (int b = 0; b < p->NB; ++b) g[b] = (float)tax_rate_obs(c, b);
       g[p->NB + 0] = (float)is_first_day;
       g[p->NB + 1] = (float)is_tax_day;
       for (int k = 0; k < n; ++k) g[p->NB + 2 + k] = (float)sorted_inc[k];
@@ -876,7 +1085,7 @@ static void write_obs(ctx_t* c) {
   }
   if (p->has_tax) {
     float* g = pf + p->fp_tax;
-    for (int b = 0; b < p->NB; ++b) g[b] = (float)tax_rate(c, b);
+    for (int b = 0; b < p->NB; ++b) g[b] = (float)tax_rate_obs(c, b);
     g[p->NB + 0] = (float)is_first_day;
     g[p->NB + 1] = (float)is_tax_day;
     for (int k = 0; k < n; ++k) g[p->NB + 2 + k] = (float)sorted_inc[k];
@@ -1112,6 +1321,11 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
           F64(&c, o_tax_last_marginal_rate)[i] = 0;
         }
         *F64(&c, o_tax_total_collected) = 0;
+        if (p->c.tax_model == AIE_TAX_SAEZ) { /* _curr_rates_obs first (:1123), with the previous episode's rates */
+          for (int b = 0; b < p->NB; ++b) F64(&c, o_tax_saez_obs_rates)[b] = tax_rate(&c, b);
+        }
+        if (p->c.tax_model == AIE_TAX_SAEZ) /* curr_bracket_tax_rates = running_avg_tax_rates :1136-1137 */
+          memcpy(F64(&c, o_tax_saez_rates), SAEZ(&c) + AIE_SAEZ_OFF_AVG, sizeof(double) * (size_t)p->NB);
         break;
     }
   }
@@ -1404,6 +1618,16 @@ void aie_oracle_step(const aie_params* p, uint8_t* arena, const int32_t* aa, con
   for (int e = e0; e < e1; ++e) {
     if (p->c.scenario == AIE_SCN_ONE_STEP_ECONOMY) ose_step_one(p, arena, e, aa, ap);
     else step_one(p, arena, e, aa, ap);
+  }
+}
+/* tax_model "saez": what a period start does to the rates (random draw or formula) for every replica,
+ * on whatever buffer / estimates the arena holds -- lets tests check the formula in isolation */
+void aie_oracle_saez_period_start(const aie_params* p, uint8_t* arena) {
+  for (int e = 0; e < p->E; ++e) {
+    ctx_t c;
+    make_ctx(&c, p, arena, e);
+    saez_set_new_period_rates(&c);
+    for (int b = 0; b < p->NB; ++b) F64(&c, o_tax_saez_obs_rates)[b] = tax_rate(&c, b);
   }
 }
 void aie_oracle_reset(const aie_params* p, uint8_t* arena, const uint8_t* mask, int e0, int e1) {

@@ -44,6 +44,8 @@ def lib():
         L.aie_oracle_step.restype = None
         L.aie_oracle_step_mt.argtypes = [vp, vp, vp, vp, C.c_int]
         L.aie_oracle_step_mt.restype = None
+        L.aie_oracle_saez_period_start.argtypes = [vp, vp]
+        L.aie_oracle_saez_period_start.restype = None
         L.aie_oracle_reset.argtypes = [vp, vp, vp, C.c_int, C.c_int]
         L.aie_oracle_reset.restype = None
         L.aie_oracle_seed.argtypes = [vp, vp, C.c_uint32]
@@ -84,8 +86,14 @@ class OracleEnv:
         self.t = {name: self._view(d) for name, d in self.descs.items()}
         if "house_owner" in self.t:
             self.t["house_owner"][...] = -1
+        if "saez_elas" in self.t:  # elas_t = elas_tm1 = 0.5 at construction (redistribution.py:263-266)
+            self.t["saez_elas"][:, 0:2] = 0.5
         if layout_planes is not None and "cell_flags" in self.t:
             self.set_layout(*layout_planes)
+
+    def saez_period_start(self):
+        """Runs PeriodicBracketTax's period-start rate update (tax_model "saez") on every replica."""
+        lib().aie_oracle_saez_period_start(self._params, self.arena.ctypes.data_as(C.c_void_p))
 
     def _view(self, d):
         dt = np.dtype(NP_DTYPES[d.dtype])

@@ -38,6 +38,14 @@ def extract_state_one_step_economy(env):
         s["tax_last_income"] = np.array(c.last_income, np.float64)
         s["tax_last_marginal_rate"] = np.array(c.last_marginal_rate, np.float64)
         s["tax_total_collected"] = np.array(c.total_collected_taxes, np.float64)
+        if c.tax_model == "saez":
+            buf = np.array(c._local_saez_buffer, np.float64).reshape(-1, 2)
+            s["saez_buffer_len"] = np.array(len(buf), np.int32)
+            s["saez_reached_min_samples"] = np.array(int(c._reached_min_samples), np.int32)
+            s["saez_buffer_filled"] = buf
+            s["saez_elas"] = np.array([c.elas_t, c.elas_tm1, c.log_z0_t, c.log_z0_tm1], np.float64)
+            s["saez_running_avg_tax_rates"] = np.array(c.running_avg_tax_rates, np.float64)
+            s["tax_saez_bracket_rates"] = np.array(c.curr_bracket_tax_rates, np.float64)
     if "SimpleLabor" in comps:
         s["labor_first_step"] = np.array(int(comps["SimpleLabor"].is_first_step), np.int32)
     s["timestep"] = np.array(w.timestep, np.int32)

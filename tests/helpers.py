@@ -11,11 +11,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 INT_FIELDS = ["stone", "wood", "house_owner", "loc_r", "loc_c", "inv_res", "esc_res",
               "cda_n_bids", "cda_n_asks", "cda_n_orders", "cda_bid_hist", "cda_ask_hist",
               "tax_cycle_pos", "tax_last_completions", "tax_rate_idx", "timestep", "completions", "auto_warmup", "mt_pos",
-              "labor_first_step"]
+              "labor_first_step", "saez_buffer_len", "saez_reached_min_samples"]
 F64_FIELDS = ["inv_coin", "esc_coin", "labor", "build_payment", "build_skill",
               "bonus_gather_prob", "util", "cda_price_history", "tax_last_coin",
               "tax_last_income", "tax_last_marginal_rate", "tax_total_collected", "skill",
-              "production"]
+              "production", "saez_elas", "saez_running_avg_tax_rates", "tax_saez_bracket_rates"]
 
 
 def golden_names():
@@ -96,6 +96,10 @@ def compare_state(got, want, where="", f64_tol=1e-9):
             "%s: bid book differs" % where)
         assert book_equal(got["cda_n_asks"], got["cda_asks"], want["cda_n_asks"], want["cda_asks"]), (
             "%s: ask book differs" % where)
+    if "saez_buffer_filled" in want and "saez_buffer" in got:  # the filled prefix of the sample buffer
+        m = len(want["saez_buffer_filled"])
+        np.testing.assert_allclose(np.asarray(got["saez_buffer"])[:m], want["saez_buffer_filled"], rtol=f64_tol,
+                                   atol=f64_tol, err_msg="%s: saez buffer" % where)
     for k in F64_FIELDS:
         if k in want and k in got:
             np.testing.assert_allclose(np.asarray(got[k]), np.asarray(want[k]), rtol=f64_tol,

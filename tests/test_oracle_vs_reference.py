@@ -340,3 +340,197 @@ def test_oracle_tracks_live_reference_random_one_step_economy(seed):
             obs = ref.reset()
             o.reset()
             check("%s reset after step %d" % (where0, t + 1), obs)
+
+
+SAEZ_CASES = {
+    "inverse_income": dict(tax={"period": 5}, n_agents=5),
+    "uniform_weights_fixed_elas": dict(tax={"period": 4, "pareto_weight_type": "uniform", "saez_fixed_elas": 0.4,
+                                            "rate_max": 0.8, "rate_min": 0.05}, n_agents=4),
+    "annealed_linear_brackets": dict(tax={"period": 6, "bracket_spacing": "linear", "n_brackets": 5,
+                                          "top_bracket_cutoff": 60, "tax_annealing_schedule": [-1, 0.25]}, n_agents=6),
+    "log_brackets_few_samples": dict(tax={"period": 3, "bracket_spacing": "log", "n_brackets": 4,
+                                          "top_bracket_cutoff": 25}, n_agents=4, buffer=24),
+}
+
+
+def _saez_cfg(case):
+    kw = dict(SAEZ_CASES[case])
+    size = kw.pop("buffer", 60)
+    tax = dict(kw.pop("tax"), tax_model="saez")
+    cfg = dict(BASE, episode_length=60, starting_agent_coin=20, **kw)
+    cfg["components"] = [["Build", {"skill_dist": "pareto", "payment_max_skill_multiplier": 3}],
+                         ["ContinuousDoubleAuction", {"max_num_orders": 4, "order_duration": 15}],
+                         ["Gather", {"skill_dist": "pareto"}], ["PeriodicBracketTax", tax]]
+    return cfg, size
+
+
+@pytest.mark.parametrize("case", sorted(SAEZ_CASES))
+def test_oracle_tracks_live_reference_saez_random_rate_phase(case):
+    """tax_model="saez" before the sample buffer is full (redistribution.py:444-458): every period starts
+    with np.random.uniform rates drawn from the replica's stream, in the middle of the step's other
+    draws; tax days append (income, marginal rate) pairs.  Side by side with the live reference over three
+    episodes with the reference's own buffer size (500): state, MT19937 stream, observations, rewards,
+    metrics."""
+    from oracle_lib import OracleEnv
+    from ref_extract import extract_obs, extract_state, rewards_array
+
+    cfg, _ = _saez_cfg(case)
+    np.random.seed(9)
+    ref = _ref_env(cfg)
+    host = make_env(cfg)
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    np.random.seed(31)
+    st = np.random.get_state()
+    o.t["mt"][0] = st[1]
+    o.t["mt_pos"][0] = st[2]
+    rng = np.random.RandomState(5)
+
+    def check(where, obs, rew=None):
+        compare_state({k: v[0] for k, v in o.t.items()}, extract_state(ref), where=where, f64_tol=1e-9)
+        assert np.array_equal(o.t["mt"][0], np.random.get_state()[1]), where + ": MT19937 state"
+        for k, want in extract_obs(ref, obs).items():
+            got = o.t[k][0]
+            if want.dtype.kind in "iu":
+                assert np.array_equal(got, want), "%s: obs %s" % (where, k)
+            else:
+                np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6, err_msg="%s: obs %s" % (where, k))
+        if rew is not None:
+            got = np.concatenate([o.t["rewards_a"][0], o.t["rewards_p"][[0]]])
+            np.testing.assert_allclose(got, rewards_array(ref, rew), rtol=0, atol=1e-5, err_msg=where)
+
+    for ep in range(3):
+        obs = ref.reset()
+        o.reset()
+        check("%s reset %d" % (case, ep), obs)
+        for t in range(cfg["episode_length"]):
+            acts, aa, pa = _random_actions(ref, rng, False, True)
+            obs, rew, done, _ = ref.step(acts)
+            o.step(aa[None], pa[None])
+            check("%s episode %d step %d" % (case, ep, t + 1), obs, rew)
+        check_metrics(ref, host, o, "%s episode %d" % (case, ep))
+    assert not ref.get_component("PeriodicBracketTax")._reached_min_samples
+    assert o.t["saez_buffer_len"][0] > 100
+
+
+@pytest.mark.parametrize("case", sorted(SAEZ_CASES))
+def test_oracle_saez_formula_matches_live_reference(case):
+    """The Saez formula itself (elasticity OLS, binned welfare weights / Pareto parameters, marginal
+    rates, gap interpolation, bracket averaging, clipping, running average; redistribution.py:459-823).
+
+    Checked as a FUNCTION of the reference's state at every period start of a live reference run: the
+    sample buffer, elasticity estimates and running average are copied into the restatement, its period
+    start runs, and the new bracket rates / estimates are compared with what the reference computed from
+    the same state (1e-9).  A side-by-side trajectory is not meaningful past the first formula period:
+    `z_t > 0` filters incomes that are rounding residue (~1e-15, from coin moving into escrow and back), so
+    the reference's own trajectory changes with the last bit of BLAS / LAPACK results."""
+    from oracle_lib import OracleEnv
+
+    cfg, size = _saez_cfg(case)
+    np.random.seed(9)
+    ref = _ref_env(cfg)
+    tc = ref.get_component("PeriodicBracketTax")
+    tc._buffer_size = size
+    host = make_env(cfg)
+    host.get_component("PeriodicBracketTax")._buffer_size = size
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    o.seed(1)
+    o.reset()
+    rng = np.random.RandomState(5)
+    checked = early_exit = 0
+    for ep in range(6):
+        ref.reset()
+        for t in range(cfg["episode_length"]):
+            at_start = tc.tax_cycle_pos == 1 and (tc._reached_min_samples or len(tc._local_saez_buffer) >= size)
+            if at_start:  # copy the state the coming period start will see
+                buf = np.array(tc._local_saez_buffer, np.float64)
+                o.t["saez_buffer"][0][: len(buf)] = buf
+                o.t["saez_buffer_len"][0] = len(buf)
+                o.t["saez_reached_min_samples"][0] = int(tc._reached_min_samples)
+                o.t["saez_elas"][0] = [tc.elas_t, tc.elas_tm1, tc.log_z0_t, tc.log_z0_tm1]
+                o.t["saez_running_avg_tax_rates"][0] = tc.running_avg_tax_rates
+                o.t["tax_last_completions"][0] = tc._last_completions
+                before = tc.elas_t
+            acts, _, _ = _random_actions(ref, rng, False, True)
+            ref.step(acts)
+            if at_start:
+                o.saez_period_start()
+                where = "%s episode %d step %d" % (case, ep, t + 1)
+                np.testing.assert_allclose(o.t["tax_saez_bracket_rates"][0], tc.curr_bracket_tax_rates,
+                                           rtol=1e-9, atol=1e-9, err_msg=where)
+                np.testing.assert_allclose(o.t["saez_elas"][0], [tc.elas_t, tc.elas_tm1, tc.log_z0_t, tc.log_z0_tm1],
+                                           rtol=1e-9, atol=1e-9, err_msg=where)
+                np.testing.assert_allclose(o.t["saez_running_avg_tax_rates"][0], tc.running_avg_tax_rates,
+                                           rtol=1e-9, atol=1e-12, err_msg=where)
+                np.testing.assert_allclose(o.t["tax_saez_observed_rates"][0], tc._curr_rates_obs, rtol=1e-9, atol=1e-9)
+                assert o.t["saez_reached_min_samples"][0] == 1
+                checked += 1
+                early_exit += int(tc.elas_t == before)
+    assert checked >= 30, checked
+    if "few_samples" not in case:  # the OLS path (>= 10 usable samples, spread-out rates) was exercised
+        assert early_exit < checked, (checked, early_exit)
+
+
+def synthetic_saez_buffer(rs, m, top, e):
+    """(income, marginal rate) samples covering the formula's branches: negative, zero, rounding-residue,
+    in-range and above-top incomes; spread, clustered and constant rates."""
+    kind = rs.randint(0, 5, size=m)
+    z = np.where(kind == 0, -rs.rand(m) * 3, np.where(kind == 1, 0.0, np.where(
+        kind == 2, rs.rand(m) * 1e-14, np.where(kind == 3, rs.rand(m) * top, top * (1 + rs.rand(m))))))
+    if e % 7 == 0:
+        z = np.abs(z) * 0.3  # nobody above the top cutoff
+    tau = rs.choice([0.0, 0.1, 0.25, 1.0], size=m) if e % 3 == 0 else rs.rand(m)
+    if e % 11 == 0:
+        tau[:] = 0.35  # no spread: the elasticity estimate keeps its value
+    return np.stack([z, tau], 1)
+
+
+@pytest.mark.parametrize("case", sorted(SAEZ_CASES))
+def test_oracle_saez_formula_matches_reference_on_synthetic_buffers(case):
+    """The reference component's own compute_and_set_new_period_rates_from_saez_formula() on 60 synthetic
+    buffers per configuration (most of them take the OLS path) against the restatement's period start."""
+    from oracle_lib import OracleEnv
+
+    cfg, size = _saez_cfg(case)
+    np.random.seed(9)
+    ref = _ref_env(cfg)
+    ref.reset()
+    tc = ref.get_component("PeriodicBracketTax")
+    host = make_env(cfg)
+    host.get_component("PeriodicBracketTax")._buffer_size = size
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    o.seed(1)
+    o.reset()
+    rs = np.random.RandomState(123)
+    top = float(tc.bracket_cutoffs[-1])
+    ols = 0
+    for e in range(60):
+        buf = synthetic_saez_buffer(rs, size, top, e)
+        elas = [rs.rand() * 2, rs.rand(), rs.randn(), rs.randn()]
+        avg = rs.rand(tc.n_brackets) * 0.5
+        completions = int(rs.randint(0, 6))
+        tc._local_saez_buffer = buf.tolist()
+        tc._reached_min_samples = True
+        tc.elas_t, tc.elas_tm1, tc.log_z0_t, tc.log_z0_tm1 = elas
+        tc.running_avg_tax_rates = avg.copy()
+        if tc.tax_annealing_schedule is not None:  # what generate_masks does at a reset, :1036-1046
+            from ai_economist.foundation.components.utils import annealed_tax_limit
+
+            tc._last_completions = completions
+            tc._annealed_rate_max = annealed_tax_limit(completions, tc._annealing_warmup, tc._annealing_slope, tc.rate_max)
+        o.t["saez_buffer"][0][:size] = buf
+        o.t["saez_buffer_len"][0] = size
+        o.t["saez_reached_min_samples"][0] = 1
+        o.t["saez_elas"][0] = elas
+        o.t["saez_running_avg_tax_rates"][0] = avg
+        o.t["tax_last_completions"][0] = completions
+        tc.compute_and_set_new_period_rates_from_saez_formula()
+        o.saez_period_start()
+        where = "%s buffer %d" % (case, e)
+        np.testing.assert_allclose(o.t["tax_saez_bracket_rates"][0], tc.curr_bracket_tax_rates, rtol=1e-9, atol=1e-9,
+                                   err_msg=where)
+        np.testing.assert_allclose(o.t["saez_elas"][0], [tc.elas_t, tc.elas_tm1, tc.log_z0_t, tc.log_z0_tm1],
+                                   rtol=1e-9, atol=1e-9, err_msg=where)
+        np.testing.assert_allclose(o.t["saez_running_avg_tax_rates"][0], tc.running_avg_tax_rates, rtol=1e-9, atol=1e-12,
+                                   err_msg=where)
+        ols += int(tc.elas_t != elas[0])
+    assert ols >= 30, ols
