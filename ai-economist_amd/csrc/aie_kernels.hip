@@ -305,14 +305,20 @@ __device__ __forceinline__ uint32_t lane_get(uint32_t v, int src_lane) { return 
 // k+1 and k+397 (mod 624, with the sequential in-place semantics: indices that wrap
 // refer to ALREADY UPDATED words).  k+397 = 64*(J+6) + l+13 and k-227 = 64*(J-4) + l+29,
 // so every row is two lane rotations (by 13 or by 29) of two other rows.
+// The two source rows of a row feed DISJOINT source lanes (l < SPLIT reads lanes [ROT, 64) of ROW_LO, the rest
+// lanes [0, ROT) of ROW_HI), so they are merged per source lane first and fetched with one permute; the
+// neighbour word k+1 is a one-lane wave rotation (DPP), with the last lane patched from the next row.
+__device__ __forceinline__ uint32_t lane_rol1(uint32_t v) {  // lane l <- lane (l + 1) & 63
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+}
 #define AIE_MT_ROW(J, ROT, SPLIT, ROW_LO, ROW_HI, NEXT0)                                      \
   {                                                                                          \
     const uint32_t a = m.r[J];                                                               \
-    uint32_t b = lane_get(a, (lane + 1) & 63);                                               \
+    uint32_t b = lane_rol1(a);                                                               \
     b = (lane == ((J) == 9 ? 47 : 63)) ? (NEXT0) : b;                                        \
-    const uint32_t x_lo = lane_get(ROW_LO, (lane + (ROT)) & 63);                             \
-    const uint32_t x_hi = lane_get(ROW_HI, (lane + (ROT)) & 63);                             \
-    m.r[J] = mt_mix(a, b, lane < (SPLIT) ? x_lo : x_hi);                                     \
+    const uint32_t src = lane >= (ROT) ? (ROW_LO) : (ROW_HI);                                \
+    const uint32_t x = lane_get(src, (lane + (ROT)) & 63);                                   \
+    m.r[J] = mt_mix(a, b, x);                                                                \
   }
 __device__ __forceinline__ void mt_twist_body(MT& m, int lane) {
   // rows 0..2: old[k+397] from rows J+6 (l < 51) / J+7 (l >= 51), rotation 13
@@ -321,7 +327,7 @@ __device__ __forceinline__ void mt_twist_body(MT& m, int lane) {
   AIE_MT_ROW(2, 13, 51, m.r[8], m.r[9], bcast(m.r[3], 0))
   {  // row 3: l < 35 old row 9 (rotation 13), l >= 35 NEW row 0 (rotation 29)
     const uint32_t a = m.r[3];
-    uint32_t b = lane_get(a, (lane + 1) & 63);
+    uint32_t b = lane_rol1(a);
     b = (lane == 63) ? bcast(m.r[4], 0) : b;
     const uint32_t x_lo = lane_get(m.r[9], (lane + 13) & 63);
     const uint32_t x_hi = lane_get(m.r[0], (lane + 29) & 63);
@@ -866,6 +872,81 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
     for (int q = na0[r]; q < na[r]; ++q) book_insert<false>(asks, q, lane);
     if (nb[r] == 0 || na[r] == 0) continue;
     uint64_t possible = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    if (M <= AIE_NT) {
+      // Both books fit one wavefront: lane q keeps order q in a register and the loop works on "alive" lane
+      // masks -- finding the best eligible bid / ask is a ballot + find-first-set, a trade clears two bits;
+      // nothing in the loop's control flow waits on LDS.  The survivors are compacted once, afterwards.
+      const int32_t bv = lane < nb[r] ? bids[lane] : 0;
+      const int32_t av = lane < na[r] ? asks[lane] : 0;
+      uint64_t alive_b = nb[r] >= 64 ? ~0ull : ((1ull << nb[r]) - 1ull);
+      uint64_t alive_a = na[r] >= 64 ? ~0ull : ((1ull << na[r]) - 1ull);
+      const int my_buyer = AIE_ORD_AGENT(bv), my_seller = AIE_ORD_AGENT(av);
+      int ntrades = 0, trade = 0;
+      while (possible) {
+        const uint64_t bh = __ballot((possible >> my_buyer) & 1ull) & alive_b;
+        if (!bh) break;  // out of bids to check (:262-264)
+        const int ib = __ffsll((unsigned long long)bh) - 1;
+        const int32_t bid = bcast(bv, ib);
+        const int buyer = AIE_ORD_AGENT(bid), bprice = AIE_ORD_PRICE(bid);
+        const uint64_t ah = __ballot(my_seller != buyer) & alive_a;
+        int ia = -1;
+        int32_t ask = 0;
+        if (ah) { ia = __ffsll((unsigned long long)ah) - 1; ask = bcast(av, ia); }
+        if (ia < 0 || bprice < AIE_ORD_PRICE(ask)) {  // :273-286
+          possible &= ~(1ull << buyer);
+          continue;
+        }
+        // TRADE :289-346.  Only the agents' registers change inside the loop; the book-keeping in LDS
+        // (order histograms, price history) and the episode accumulators are applied after it, one lane
+        // per trade, through atomics (equal addends / no byte borrow: the order of arrival is immaterial).
+        alive_b &= ~(1ull << ib);
+        alive_a &= ~(1ull << ia);
+        const int seller = AIE_ORD_AGENT(ask), aprice = AIE_ORD_PRICE(ask);
+        const bool at_ask = AIE_ORD_LIFE(bid) <= AIE_ORD_LIFE(ask);  // :297-304
+        const int price = at_ask ? aprice : bprice;
+        if (lane == ntrades) trade = buyer | (seller << 6) | (bprice << 12) | (aprice << 20) | ((int)at_ask << 28);
+        ntrades += 1;
+        if (c.ev) log_event(c, AIE_EV_TRADE, r, seller, buyer, aprice, bprice, price, AIE_ORD_LIFE(ask), AIE_ORD_LIFE(bid), 0.0);
+        if (lane == seller) {
+          if (r) { A.no1 -= 1; A.esc1 -= 1; } else { A.no0 -= 1; A.esc0 -= 1; }
+          A.coin += (double)price;
+        }
+        if (lane == buyer) {
+          if (r) { A.no1 -= 1; A.inv1 += 1; } else { A.no0 -= 1; A.inv0 += 1; }
+          A.esc_coin -= (double)bprice;
+          A.coin += (double)(bprice - price);
+        }
+      }
+      if (lane < ntrades) {
+        const int buyer = trade & 63, seller = (trade >> 6) & 63, bprice = (trade >> 12) & 255, aprice = (trade >> 20) & 255;
+        const int price = ((trade >> 28) & 1) ? aprice : bprice;
+        const int bi = (r * n + buyer) * P + bprice, ai = (r * n + seller) * P + aprice;
+        atomicSub(reinterpret_cast<uint32_t*>(bid_hist + (bi & ~3)), 1u << (8 * (bi & 3)));
+        atomicSub(reinterpret_cast<uint32_t*>(ask_hist + (ai & ~3)), 1u << (8 * (ai & 3)));
+        unsafeAtomicAdd(R_F64(c, o_cda_price_history) + (r * n + seller) * P + price, 1.0);
+        if (c.met) {  // get_metrics :585-641: fire-and-forget integer atomics
+          int32_t* tm = reinterpret_cast<int32_t*>(c.met + c.P.mo_cda);
+          int32_t* sell = tm + ((0 * AIE_N_RES + r) * n + seller) * 2;
+          int32_t* buy = tm + ((1 * AIE_N_RES + r) * n + buyer) * 2;
+          atomicAdd(sell, 1); atomicAdd(sell + 1, price);
+          atomicAdd(buy, 1); atomicAdd(buy + 1, price);
+        }
+      }
+      // leftover orders keep their (sorted) order: slot = number of survivors in front
+      const int nbr = __popcll(alive_b), nar = __popcll(alive_a);
+      if (nbr != nb[r]) {
+        AIE_WSYNC();
+        if ((alive_b >> lane) & 1ull) bids[__popcll(alive_b & ((1ull << lane) - 1ull))] = bv;
+        nb[r] = nbr;
+      }
+      if (nar != na[r]) {
+        AIE_WSYNC();
+        if ((alive_a >> lane) & 1ull) asks[__popcll(alive_a & ((1ull << lane) - 1ull))] = av;
+        na[r] = nar;
+      }
+      AIE_WSYNC();
+      continue;
+    }
     while (possible) {
       const uint64_t poss = possible;
       const int ib = book_find_first(bids, nb[r], lane, [poss](int32_t o) { return ((poss >> AIE_ORD_AGENT(o)) & 1ull) != 0; });
