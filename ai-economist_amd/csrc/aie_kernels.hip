@@ -435,6 +435,13 @@ __device__ __forceinline__ int rng_permutation(MT& m, int lane, int n) {
 struct MTL {
   uint32_t* w;  // LDS [624] raw (untempered) words of the current window
   int pos;      // wave-uniform index of the next unused word (624 = twist first)
+  // 64 tempered words in a register (lane j: word cbase + j): a draw is a v_readlane, the LDS read and the
+  // tempering happen once per 64 draws (a step's components draw ~10-30 words)
+  uint32_t cache;
+  int cbase;
+  // this step's changes to the maps, kept in registers until the components are done (-> c.dirty):
+  int dn;             // cells appended to the change list
+  uint32_t mv0, mv1;  // agents that moved
 };
 __device__ __forceinline__ void mtl_to_regs(const MTL& l, MT& m, int lane) {
 #pragma unroll
@@ -452,10 +459,17 @@ __device__ __forceinline__ uint32_t rng_u32(MTL& l, int lane) {
     if (lane < 48) l.w[576 + lane] = m.r[9];
     AIE_WSYNC();
     l.pos = 0;
+    l.cbase = -AIE_MT_N;
   }
-  const uint32_t w = l.w[l.pos];  // same address in every lane: LDS broadcast
+  int k = l.pos - l.cbase;
+  if ((unsigned)k >= (unsigned)AIE_NT) {  // refill: words [pos, pos + 64) of the window
+    const int idx = l.pos + lane;
+    l.cache = mt_temper(l.w[idx < AIE_MT_N ? idx : AIE_MT_N - 1]);
+    l.cbase = l.pos;
+    k = 0;
+  }
   l.pos += 1;
-  return mt_temper(w);
+  return bcast(l.cache, k);
 }
 __device__ __forceinline__ double rng_double(MTL& l, int lane) {
   const uint32_t a = rng_u32(l, lane);
@@ -637,20 +651,17 @@ __device__ __forceinline__ void decode_actions(const Ctx& c, Agents& A, const in
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ uint16_t* dirty_list(const Ctx& c) { return reinterpret_cast<uint16_t*>(c.dirty + 4); }
 // wave-uniform call site (all lanes pass the same cell): lane 0 appends
-__device__ __forceinline__ void dirty_add_uniform(const Ctx& c, int cell) {
-  if (c.tid == 0) {
-    const int s = c.dirty[0];
-    if (s < AIE_DIRTY_CAP) dirty_list(c)[s] = (uint16_t)cell;
-    c.dirty[0] = s + 1;
-  }
+__device__ __forceinline__ void dirty_add_uniform(const Ctx& c, MTL& m, int cell) {
+  if (c.tid == 0 && m.dn < AIE_DIRTY_CAP) dirty_list(c)[m.dn] = (uint16_t)cell;
+  m.dn += 1;
 }
 // divergent call site (each active lane its own cell)
 __device__ __forceinline__ void dirty_add_lane(const Ctx& c, int cell) {
   const int s = atomicAdd(&c.dirty[0], 1);
   if (s < AIE_DIRTY_CAP) dirty_list(c)[s] = (uint16_t)cell;
 }
-__device__ __forceinline__ void dirty_agent_moved(const Ctx& c, int i) {
-  if (c.tid == 0) c.dirty[1 + (i >> 5)] |= 1 << (i & 31);
+__device__ __forceinline__ void dirty_agent_moved(MTL& m, int i) {
+  if (i < 32) m.mv0 |= 1u << i; else m.mv1 |= 1u << (i - 32);
 }
 
 // ------------------------------------------------------------------------------------
@@ -680,7 +691,7 @@ __device__ __forceinline__ void build_component_step(const Ctx& c, MTL& m, Agent
       A.labor += c.P.c.build_labor;
     }
     cells[cell] = (w & 0xff00ffffu) | ((uint32_t)i << 16);  // world.py:474-479 (every lane, same value)
-    dirty_add_uniform(c, cell);
+    dirty_add_uniform(c, m, cell);
     if (c.ev) log_event(c, AIE_EV_BUILD, i, cell / c.P.W, cell % c.P.W, 0, 0, 0, 0, 0, R_F64(c, o_build_payment)[i]);
   }
 }
@@ -692,6 +703,7 @@ __device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agen
   const int n = c.P.n, W = c.P.W, H = c.P.H, lane = c.tid;
   const int perm = rng_permutation(m, lane, n);
   uint32_t* cells = R_CELLS(c);
+  const double my_bonus = R_F64(c, o_bonus_gather_prob)[lane < n ? lane : 0];
   for (int k = 0; k < n; ++k) {
     const int i = bcast(perm, k);
     const int a = (int)AIE_ACT_GATHER(bcast(A.act, i));
@@ -710,9 +722,9 @@ __device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agen
         if (!(AIE_CELL_FLAGS(tw) & AIE_CELL_WATER) && (own < 0 || own == i) && occ == 0) {
           c.locmap[land] = 0;
           c.locmap[tcell] = (uint8_t)(i + 1);
-          dirty_add_uniform(c, land);
-          dirty_add_uniform(c, tcell);
-          dirty_agent_moved(c, i);
+          dirty_add_uniform(c, m, land);
+          dirty_add_uniform(c, m, tcell);
+          dirty_agent_moved(m, i);
           if (lane == i) {
             A.lr = nr;
             A.lc = nc;
@@ -726,7 +738,7 @@ __device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agen
     uint32_t w = cells[land];
     if ((w & 0xffffu) != 0) {
       const int health[2] = {(int)AIE_CELL_STONE(w), (int)AIE_CELL_WOOD(w)};
-      const double bonus = R_F64(c, o_bonus_gather_prob)[i];
+      const double bonus = bcast(my_bonus, i);
 #pragma unroll
       for (int rs = 0; rs < 2; ++rs) {
         if (health[rs] >= 1) {
@@ -741,7 +753,7 @@ __device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agen
         }
       }
       cells[land] = w;
-      dirty_add_uniform(c, land);
+      dirty_add_uniform(c, m, land);
     }
   }
 }
@@ -2029,7 +2041,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   __syncthreads();  // the record is in LDS
   if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
   if (NW == 1 || wid == 1) rebuild_locmap(c);
-  MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0};
+  MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0, 0u, -AIE_MT_N, 0, 0u, 0u};
   if (wid == 0) {
     ml.pos = uni(*R_I32(c, o_mt_pos));
     agents_load(c, A);
@@ -2055,7 +2067,12 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     }
     agents_store(c, A);
     if (c.ev && c.tid == 0) c.ev[0] = c.srcn[2];
-    if (c.tid == 0) *R_I32(c, o_mt_pos) = ml.pos;
+    if (c.tid == 0) {
+      *R_I32(c, o_mt_pos) = ml.pos;
+      c.dirty[0] = ml.dn;
+      c.dirty[1] = (int32_t)ml.mv0;
+      c.dirty[2] = (int32_t)ml.mv1;
+    }
     if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 5] = wall_clock64();
   } else if (next.a || next.p) {
     // the second wave has nothing to do until the components are done: next step's random actions
