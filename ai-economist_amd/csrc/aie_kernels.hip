@@ -49,6 +49,10 @@ struct Ctx {
   uint8_t* met;      // GLOBAL: this replica's episode accumulators (aie_layout.h: a_metrics), or nullptr
   int32_t* ev;       // GLOBAL: this replica's dense-log event rows (a_events), or nullptr (not logged)
   bool saez;         // tax_model == "saez" (compile-time false in the common step kernel, like ev == nullptr)
+  bool full;         // compile-time: false in the common step kernel (aie_step_kernel), which leaves out what
+                     // only some environments need -- dense-log rows, Saez hooks, order books larger than a
+                     // wavefront, development hooks -- to keep its code small (the kernel does not fit the
+                     // instruction cache, and rarely taken paths pay for every line they add)
   int tid;
   int e;
 };
@@ -122,7 +126,7 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e
   int32_t* ev = (with_events && arena && e < P.ev_replicas)
                     ? reinterpret_cast<int32_t*>(arena + P.a_events + (int64_t)e * P.ev_stride) : nullptr;
   const bool saez = with_events && P.c.tax_model == AIE_TAX_SAEZ;
-  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, met, ev, saez, tid, e};
+  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, met, ev, saez, with_events, tid, e};
 }
 
 // ------------------------------------------------------------------------------------
@@ -817,6 +821,16 @@ __device__ __forceinline__ int book_find_first(const int32_t* v, int len, int la
   return -1;
 }
 
+// Order-count histograms are bytes; they are updated through 32-bit LDS atomics on the containing word
+// (no carry / borrow between bytes: counts stay within [0, max_num_orders]), which, unlike a byte
+// read-modify-write, does not make the wave wait for LDS.
+__device__ __forceinline__ void hist_add(uint8_t* hist, int idx, int lane) {  // wave-uniform idx
+  if (lane == 0) atomicAdd(reinterpret_cast<uint32_t*>(hist + (idx & ~3)), 1u << (8 * (idx & 3)));
+}
+__device__ __forceinline__ void hist_sub_lane(uint8_t* hist, int idx) {  // one decrement per calling lane
+  atomicSub(reinterpret_cast<uint32_t*>(hist + (idx & ~3)), 1u << (8 * (idx & 3)));
+}
+
 // ContinuousDoubleAuction.component_step :440-489 (decay of :451 already applied)
 __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
   const int n = c.P.n, M = c.P.M, P = c.P.P, lane = c.tid;
@@ -844,7 +858,7 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
         if (no < maxo && !(bcast(A.coin, i) < (double)price)) {
           bids[nb[r]] = AIE_ORD_PACK(i, price, 0);
           nb[r] += 1;
-          bid_hist[(r * n + i) * P + price] += 1;
+          hist_add(bid_hist, (r * n + i) * P + price, lane);
           if (lane == i) {
             if (r) A.no1 += 1; else A.no0 += 1;
             const double tr = A.coin < (double)price ? A.coin : (double)price;  // base_agent.py:279-299
@@ -860,7 +874,7 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
         if (no2 < maxo && bcast(r ? A.inv1 : A.inv0, i) > 0) {
           asks[na[r]] = AIE_ORD_PACK(i, price, 0);
           na[r] += 1;
-          ask_hist[(r * n + i) * P + price] += 1;
+          hist_add(ask_hist, (r * n + i) * P + price, lane);
           if (lane == i) {
             if (r) { A.no1 += 1; A.inv1 -= 1; A.esc1 += 1; }
             else { A.no0 += 1; A.inv0 -= 1; A.esc0 += 1; }
@@ -880,18 +894,32 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
     // Without a new order nothing can match: last step's loop ended with every buyer's
     // best bid below the cheapest ask of another agent, and expiry only removes orders.
     if (nb[r] == nb0[r] && na[r] == na0[r]) continue;
-    for (int q = nb0[r]; q < nb[r]; ++q) book_insert<true>(bids, q, lane);
-    for (int q = na0[r]; q < na[r]; ++q) book_insert<false>(asks, q, lane);
-    if (nb[r] == 0 || na[r] == 0) continue;
     uint64_t possible = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    if (M <= AIE_NT) {
-      // Both books fit one wavefront: lane q keeps order q in a register and the loop works on "alive" lane
-      // masks -- finding the best eligible bid / ask is a ballot + find-first-set, a trade clears two bits;
-      // nothing in the loop's control flow waits on LDS.  The survivors are compacted once, afterwards.
-      const int32_t bv = lane < nb[r] ? bids[lane] : 0;
-      const int32_t av = lane < na[r] ? asks[lane] : 0;
+    if (!c.full || M <= AIE_NT) {
+      // Both books fit one wavefront: lane q keeps order q in a register.  This step's new orders
+      // (appended behind the sorted part) are inserted with a ballot (position) and a one-lane shift; the
+      // matching loop works on "alive" lane masks -- the best eligible bid / ask is a ballot +
+      // find-first-set, a trade clears two bits; nothing in the loop's control flow waits on LDS.  The
+      // survivors go back to LDS once, in order.
+      int32_t bv = lane < nb[r] ? bids[lane] : 0;
+      int32_t av = lane < na[r] ? asks[lane] : 0;
+      for (int q = nb0[r]; q < nb[r]; ++q) {
+        const int32_t x = bcast(bv, q);
+        const int pb = __popcll(__ballot(lane < q && !order_before<true>(x, bv)));
+        const int32_t up = (int32_t)__builtin_amdgcn_update_dpp(0, bv, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        bv = (lane > pb && lane <= q) ? up : bv;
+        bv = (lane == pb) ? x : bv;
+      }
+      for (int q = na0[r]; q < na[r]; ++q) {
+        const int32_t x = bcast(av, q);
+        const int pa = __popcll(__ballot(lane < q && !order_before<false>(x, av)));
+        const int32_t up = (int32_t)__builtin_amdgcn_update_dpp(0, av, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        av = (lane > pa && lane <= q) ? up : av;
+        av = (lane == pa) ? x : av;
+      }
       uint64_t alive_b = nb[r] >= 64 ? ~0ull : ((1ull << nb[r]) - 1ull);
       uint64_t alive_a = na[r] >= 64 ? ~0ull : ((1ull << na[r]) - 1ull);
+      if (nb[r] == 0 || na[r] == 0) possible = 0;
       const int my_buyer = AIE_ORD_AGENT(bv), my_seller = AIE_ORD_AGENT(av);
       int ntrades = 0, trade = 0;
       while (possible) {
@@ -945,20 +973,17 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
         }
       }
       // leftover orders keep their (sorted) order: slot = number of survivors in front
-      const int nbr = __popcll(alive_b), nar = __popcll(alive_a);
-      if (nbr != nb[r]) {
-        AIE_WSYNC();
-        if ((alive_b >> lane) & 1ull) bids[__popcll(alive_b & ((1ull << lane) - 1ull))] = bv;
-        nb[r] = nbr;
-      }
-      if (nar != na[r]) {
-        AIE_WSYNC();
-        if ((alive_a >> lane) & 1ull) asks[__popcll(alive_a & ((1ull << lane) - 1ull))] = av;
-        na[r] = nar;
-      }
+      AIE_WSYNC();
+      if ((alive_b >> lane) & 1ull) bids[__popcll(alive_b & ((1ull << lane) - 1ull))] = bv;
+      if ((alive_a >> lane) & 1ull) asks[__popcll(alive_a & ((1ull << lane) - 1ull))] = av;
+      nb[r] = __popcll(alive_b);
+      na[r] = __popcll(alive_a);
       AIE_WSYNC();
       continue;
     }
+    for (int q = nb0[r]; q < nb[r]; ++q) book_insert<true>(bids, q, lane);
+    for (int q = na0[r]; q < na[r]; ++q) book_insert<false>(asks, q, lane);
+    if (nb[r] == 0 || na[r] == 0) continue;
     while (possible) {
       const uint64_t poss = possible;
       const int ib = book_find_first(bids, nb[r], lane, [poss](int32_t o) { return ((poss >> AIE_ORD_AGENT(o)) & 1ull) != 0; });
@@ -1003,6 +1028,52 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
   }
 
   // ---- remove_expired_orders :352-406: lifetime += 1 everywhere, compaction by ballot
+  if (!c.full || M <= AIE_NT) {
+    // one lane per resting order: the four books are read back to back, survivors are scattered to their new
+    // slots, expired orders decrement their histogram byte themselves (LDS atomics); only the owners'
+    // registers are updated one expiry after the other, in book order (coin additions do not commute)
+    int32_t ob[2][2];
+#pragma unroll
+    for (int r = 0; r < AIE_N_RES; ++r) {
+      ob[r][0] = lane < nb[r] ? (R_I32(c, o_cda_bids) + r * M)[lane] : 0;
+      ob[r][1] = lane < na[r] ? (R_I32(c, o_cda_asks) + r * M)[lane] : 0;
+    }
+    AIE_WSYNC();
+#pragma unroll
+    for (int r = 0; r < AIE_N_RES; ++r) {
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        int32_t* v = (side == 0 ? R_I32(c, o_cda_bids) : R_I32(c, o_cda_asks)) + r * M;
+        const int len = side == 0 ? nb[r] : na[r];
+        const int32_t o = ob[r][side];
+        const bool valid = lane < len;
+        const int life = AIE_ORD_LIFE(o) + 1;
+        const bool keep = valid && life <= dur;
+        const uint64_t km = __ballot(keep);
+        uint64_t em = __ballot(valid && !keep);
+        if (keep) v[__popcll(km & lanemask_lt(lane))] = AIE_ORD_PACK(AIE_ORD_AGENT(o), AIE_ORD_PRICE(o), life);
+        if (valid && !keep) hist_sub_lane(side == 0 ? bid_hist : ask_hist, (r * n + AIE_ORD_AGENT(o)) * P + AIE_ORD_PRICE(o));
+        while (em) {
+          const int q = __ffsll((unsigned long long)em) - 1;
+          em &= em - 1;
+          const int32_t eo = bcast(o, q);
+          const int ag = AIE_ORD_AGENT(eo), pr = AIE_ORD_PRICE(eo);
+          if (lane == ag) {
+            if (side == 0) {
+              const double tr = A.esc_coin < (double)pr ? A.esc_coin : (double)pr;  // escrow_to_inventory
+              A.esc_coin -= tr;
+              A.coin += tr;
+              if (r) A.no1 -= 1; else A.no0 -= 1;
+            } else {
+              if (r) { A.esc1 -= 1; A.inv1 += 1; A.no1 -= 1; }
+              else { A.esc0 -= 1; A.inv0 += 1; A.no0 -= 1; }
+            }
+          }
+        }
+        if (side == 0) nb[r] = __popcll(km); else na[r] = __popcll(km);
+      }
+    }
+  } else {
 #pragma unroll
   for (int r = 0; r < AIE_N_RES; ++r) {
 #pragma unroll
@@ -1044,6 +1115,7 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
       }
       if (side == 0) nb[r] = kept; else na[r] = kept;
     }
+  }
   }
   R_I32(c, o_cda_n_bids)[0] = nb[0];
   R_I32(c, o_cda_n_bids)[1] = nb[1];
@@ -1363,7 +1435,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool wi
   }
   const int last_win = (pos0 + total - 1) / AIE_MT_N;
   for (int w = 0; w <= last_win; ++w) {
-    if (w > 0 && !(c.P.dev_skip_mask & 65536)) mt_twist_body(m, lane);  // the hot site: inlined (4 twists per step)
+    if (w > 0 && !(c.full && (c.P.dev_skip_mask & 65536))) mt_twist_body(m, lane);  // the hot site: inlined (4 twists per step)
     const int lo = w * AIE_MT_N;
     bool need = false;
 #pragma unroll
@@ -1763,7 +1835,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
   const int t = *R_I32(c, o_timestep);
   const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)P.c.episode_length : 1.0));
 
-  const int skip = P.dev_skip_mask;
+  const int skip = c.full ? P.dev_skip_mask : 0;
   // ================= stage A: per-(commodity, price) sums, per-agent scalars ===========
   if (P.has_cda && !(skip & 64)) {
     // lanes over (commodity r, price k): net price history and full bid / ask histograms
@@ -1910,7 +1982,7 @@ __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __rest
   // is done (step kernel) / unused (reset kernel)
   float* s_amask = c.stage;
   float* s_pmask = s_amask + pad4(n * P.MA);
-  const int skip = P.dev_skip_mask;
+  const int skip = c.full ? P.dev_skip_mask : 0;
   if (skip & 512) return;
   if (tid < n) {
     const int i = tid;
@@ -2026,8 +2098,8 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   const Ctx c = make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG);
   MT m;
   Agents A;
-  const int skip = P.dev_skip_mask;
-  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x] = wall_clock64();
+  const int skip = c.full ? P.dev_skip_mask : 0;
+  if (LOG && P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x] = wall_clock64();
   if (threadIdx.x == 0) {
     *c.srcn = 0;
     c.dirty[0] = 0;
@@ -2035,11 +2107,11 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     c.dirty[2] = 0;
   }
   __syncthreads();
-  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
+  if (LOG && P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
   load_record(c, arena, m, wid, NW, /*key_to_lds=*/true);
   if (wid == 0) decode_actions(c, A, act_a, act_p);
   __syncthreads();  // the record is in LDS
-  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
+  if (LOG && P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
   if (NW == 1 || wid == 1) rebuild_locmap(c);
   MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0, 0u, -AIE_MT_N, 0, 0u, 0u};
   if (wid == 0) {
@@ -2051,7 +2123,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (wid == 0) {
     if (c.tid == 0) *R_I32(c, o_timestep) += 1;
     if (c.ev && c.tid == 0) c.srcn[2] = 0;
-    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 1] = wall_clock64();
+    if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 1] = wall_clock64();
     if (!(skip & 1)) {
       for (int k = 0; k < P.c.n_components; ++k) {
         switch (P.c.components[k]) {
@@ -2062,7 +2134,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
           case AIE_COMP_WEALTH_REDISTRIBUTION: wealth_component_step(c, A); break;
           default: break;
         }
-        if (P.dev_trace && c.tid == 0 && k < 4) P.dev_trace[12 * blockIdx.x + 2 + k] = wall_clock64();
+        if (LOG && P.dev_trace && c.tid == 0 && k < 4) P.dev_trace[12 * blockIdx.x + 2 + k] = wall_clock64();
       }
     }
     agents_store(c, A);
@@ -2073,7 +2145,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       c.dirty[1] = (int32_t)ml.mv0;
       c.dirty[2] = (int32_t)ml.mv1;
     }
-    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 5] = wall_clock64();
+    if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 5] = wall_clock64();
   } else if (next.a || next.p) {
     // the second wave has nothing to do until the components are done: next step's random actions
     const int per_env = P.n * P.act_a_width + P.act_p_width;
@@ -2083,7 +2155,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (wid == 0) {
     // first wave: flat observation vectors (they do not look at the map)
     if (!(skip & 8)) write_flat_observations(c, arena);
-    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
+    if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
     if (!(skip & 16)) compute_rewards(c, arena);  // utilities do not look at the map either
     AIE_WSYNC();
     if (c.tid == 0) {
@@ -2099,7 +2171,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     mtl_to_regs(mw, m, c.tid);
     if (!(skip & 2)) scenario_step_regen(c, m, /*win0_in_lds=*/true);
     if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
-    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
+    if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
     AIE_WSYNC();
     if (!(skip & 4)) {
       // the map observations of the previous step are still in the arena: update them in place,
@@ -2109,11 +2181,11 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       if (c.tid == 0) *R_I32(c, o_obs_valid) = 1;
     }
     if (!(skip & 8)) write_action_masks(c, arena);
-    if (P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
+    if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
   }
   __syncthreads();
   if (!(skip & 32)) store_record(c, arena, m, wid, NW, /*key_wave=*/NW - 1);
-  if (P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 7] = wall_clock64();
+  if (LOG && P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 7] = wall_clock64();
 }
 
 extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))

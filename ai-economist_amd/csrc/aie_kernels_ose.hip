@@ -48,7 +48,7 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, i
   s.tmpl_p = s.tmpl_a + pad4(P.FA);
   uint8_t* met = arena + P.a_metrics + (int64_t)e * P.met_bytes;
   int32_t* ev = e < P.ev_replicas ? reinterpret_cast<int32_t*>(arena + P.a_events + (int64_t)e * P.ev_stride) : nullptr;
-  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, false, tid, e};
+  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, false, true, tid, e};
 }
 
 __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {

@@ -30,8 +30,14 @@ names = ["start", "loaded", "build", "cda", "gather", "tax", "regen", "end", "re
 for rep in range(2):
     a, p = be.sample_random_actions(1234)
     torch.cuda.synchronize()
+    tr0 = be.tensors["metrics_cda_trades"].cpu().numpy()[:, 0, :, :, 0].sum(axis=(1, 2))
+    no0 = be.tensors["cda_n_orders"].cpu().numpy().sum(axis=(1, 2))
     be.step(a, p)
     torch.cuda.synchronize()
+    tr1 = be.tensors["metrics_cda_trades"].cpu().numpy()[:, 0, :, :, 0].sum(axis=(1, 2))
+    no1 = be.tensors["cda_n_orders"].cpu().numpy().sum(axis=(1, 2))
+    acts = a.cpu().numpy().reshape(E, -1)
+    n_order_acts = ((acts >= 2) & (acts <= 45)).sum(axis=1)
     t = buf.cpu().numpy().reshape(E, 12).astype(np.float64)
     t = (t - t[:, 0].min()) / 100.0  # wall_clock64 ticks at 100 MHz -> us
     q = lambda x: " ".join("%6.1f" % v for v in np.percentile(x, [0, 10, 50, 90, 99, 100]))  # noqa: E731
@@ -52,3 +58,9 @@ for rep in range(2):
     e_of_block = np.arange(E)
     e_of_block = (e_of_block & 7) * (E >> 3) + (e_of_block >> 3)
     print("orders in book: all %.1f, slowest blocks %.1f" % (nb.mean(), nb[e_of_block[slow]].mean()))
+    cda_t = t[:, 3] - t[:, 2]
+    trades = (tr1 - tr0)[e_of_block]
+    removed = (no0 + n_order_acts - no1)[e_of_block] - 2 * trades  # expiries (upper bound: refused orders count too)
+    for nm, x in (("trades", trades), ("order actions", n_order_acts[e_of_block]), ("expired/refused", removed)):
+        print("  cda time by %-16s" % nm, " ".join("%d:%.1f(%d)" % (k, cda_t[x == k].mean(), (x == k).sum()) for k in sorted(set(x.tolist()))[:9]))
+    print("  corr(cda time, start time) = %.2f" % np.corrcoef(cda_t, t[:, 0])[0, 1])
