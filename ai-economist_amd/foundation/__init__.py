@@ -16,6 +16,7 @@ from .entities import agent_registry as agents
 from .entities import endogenous_registry as endogenous
 from .entities import landmark_registry as landmarks
 from .entities import resource_registry as resources
+from . import utils  # save_episode_log / load_episode_log (F/utils.py)
 from .scenarios import scenario_registry as scenarios
 
 

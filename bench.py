@@ -39,6 +39,7 @@ WORKLOAD = dict(
     components=[["Build", {}], ["ContinuousDoubleAuction", {"max_num_orders": 5}],
                 ["Gather", {}], ["PeriodicBracketTax", {}]],
     starting_agent_coin=10, env_layout_file="quadrant_25x25_20each_30clump.txt")
+WORKLOAD_NAME = "C2"  # BASELINE.json configs[1]; tools/bench_c3.py reuses this file for configs[2]
 ENVS_PER_GPU = 4096
 ACTION_SEED = 1234
 ENV_SEED = 1
@@ -67,8 +68,13 @@ def measured_traffic(envs_per_gpu):
     passes of this same command).  Only valid for the default batch size."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files or envs_per_gpu != ENVS_PER_GPU:
+    import re
+
+    def version(path):  # r01_v10_pmc.json after r01_v9_pmc.json
+        return [int(x) for x in re.findall(r"\d+", os.path.basename(path))]
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=version)
+    if not files or envs_per_gpu != ENVS_PER_GPU or WORKLOAD_NAME != "C2":
         return None, None
     d = json.load(open(files[-1]))
     return d["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
@@ -230,13 +236,13 @@ def main():
         agent_steps = world * E * n * args.steps
         value = agent_steps / elapsed
         out = {
-            "metric": "agent-steps/sec, gather-trade-build 25x25 4-agent batched envs",
+            "metric": "agent-steps/sec, gather-trade-build 25x25 %d-agent batched envs" % n,
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i32 state + f64 coin/utility (f32 observations)", "data": "synthetic",
             "config": {
-                "workload": "C2: layout_from_file/simple_wood_and_stone 25x25 quadrant layout, 4 agents + planner, "
+                "workload": WORKLOAD_NAME + ": layout_from_file/simple_wood_and_stone 25x25 quadrant layout, %d agents + planner, " % n +
                             "Build+ContinuousDoubleAuction(max_num_orders=5)+Gather+PeriodicBracketTax, "
                             "episode_length 1000, uniform random policy, mobile agents counted (planner excluded)",
                 "envs_per_gpu": E, "global_envs": world * E, "n_agents": n,
