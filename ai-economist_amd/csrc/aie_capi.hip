@@ -22,6 +22,8 @@ struct aie_env {
   size_t lds;
   int step_waves;  // wavefronts per replica in aie_step_kernel (2; 1 = original schedule)
   int64_t sample_t;
+  float* rew_log;        // aie_set_reward_log: caller's ring of n_slots step slots, or nullptr
+  int32_t rew_log_slots, rew_log_next;
   char err[512];
 };
 
@@ -293,8 +295,20 @@ int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
 static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream,
                          const NextActions& next);
 
+int aie_set_reward_log(aie_env* env, float* d_log, int32_t n_slots) {
+  if (!env) return AIE_E_INVALID;
+  if (d_log && (n_slots < 1 || env->P.c.scenario != AIE_SCN_GTB || env->step_waves != 2)) {
+    snprintf(env->err, sizeof(env->err), "aie_set_reward_log: needs n_slots >= 1 and a gather-trade-build environment");
+    return d_log && n_slots < 1 ? AIE_E_INVALID : AIE_E_UNSUPPORTED;
+  }
+  env->rew_log = d_log;
+  env->rew_log_slots = d_log ? n_slots : 0;
+  env->rew_log_next = 0;
+  return AIE_OK;
+}
+
 int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream) {
-  return aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{nullptr, nullptr, 0, 0, 0});
+  return aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{nullptr, nullptr, 0, 0, 0, nullptr});
 }
 
 int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, uint64_t seed,
@@ -305,18 +319,23 @@ int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t
     return AIE_E_INVALID;
   }
   if (env->P.c.scenario != AIE_SCN_GTB || env->step_waves != 2) {  // no fused kernel: two launches
-    int rc = aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{nullptr, nullptr, 0, 0, 0});
+    int rc = aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{nullptr, nullptr, 0, 0, 0, nullptr});
     if (rc != AIE_OK) return rc;
     return aie_sample_random_actions(env, seed, global_env_offset, d_next_a, d_next_p, stream);
   }
-  const NextActions next{d_next_a, d_next_p, seed, global_env_offset, env->sample_t};
+  const NextActions next{d_next_a, d_next_p, seed, global_env_offset, env->sample_t, nullptr};
   env->sample_t += 1;
   return aie_step_impl(env, d_actions_a, d_actions_p, stream, next);
 }
 
 static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream,
-                         const NextActions& next) {
+                         const NextActions& next_in) {
   if (!env) return AIE_E_INVALID;
+  NextActions next = next_in;
+  if (env->rew_log) {  // this step's slot of the reward log (aie_set_reward_log)
+    next.rew_log = env->rew_log + (int64_t)env->rew_log_next * env->P.E * (env->P.n + 2);
+    env->rew_log_next = (env->rew_log_next + 1) % env->rew_log_slots;
+  }
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   if (env->P.saez_stride)  // tax_model "saez": the period-start formula runs ahead of the step (aie_kernels_saez.hip)
     hipLaunchKernelGGL(aie_saez_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0, static_cast<hipStream_t>(stream),

@@ -1546,7 +1546,7 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
 }
 
 // compute_reward layout_from_file.py:519-559
-__device__ __forceinline__ void compute_rewards(const Ctx& c, uint8_t* __restrict__ arena) {
+__device__ __forceinline__ void compute_rewards(const Ctx& c, uint8_t* __restrict__ arena, float* rew_log = nullptr) {
   const int n = c.P.n, i = c.tid;
   current_metrics(c);
   AIE_WSYNC();
@@ -1559,6 +1559,7 @@ __device__ __forceinline__ void compute_rewards(const Ctx& c, uint8_t* __restric
     rew[i] = r;
     if (i < n) reinterpret_cast<float*>(arena + c.P.a_rew_a)[(int64_t)c.e * n + i] = (float)r;
     else reinterpret_cast<float*>(arena + c.P.a_rew_p)[c.e] = (float)r;
+    if (rew_log) rew_log[(int64_t)c.e * (n + 2) + i] = (float)r;
   }
   AIE_WSYNC();
   if (i == 0) {
@@ -2085,6 +2086,9 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
   int32_t* p;
   uint64_t seed;
   int64_t env_offset, t;
+  // aie_set_reward_log: this step's slot of the caller's reward log, f32 [E][n + 2] = agents' rewards, the
+  // planner's reward, done -- or nullptr
+  float* rew_log;
 };
 template <int NW, bool LOG>
 __device__ __forceinline__ void step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
@@ -2156,11 +2160,12 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     // first wave: flat observation vectors (they do not look at the map)
     if (!(skip & 8)) write_flat_observations(c, arena);
     if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
-    if (!(skip & 16)) compute_rewards(c, arena);  // utilities do not look at the map either
+    if (!(skip & 16)) compute_rewards(c, arena, next.rew_log);  // utilities do not look at the map either
     AIE_WSYNC();
     if (c.tid == 0) {
       const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
       (arena + P.a_done)[c.e] = (uint8_t)done;
+      if (next.rew_log) next.rew_log[(int64_t)c.e * (P.n + 2) + P.n + 1] = done ? 1.0f : 0.0f;
       if (done) *R_I32(c, o_completions) += 1;
     }
   }
@@ -2205,7 +2210,7 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
 aie_step_kernel_w1(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  step_body<1, true>(params, arena, act_a, act_p, lds, NextActions{nullptr, nullptr, 0, 0, 0});
+  step_body<1, true>(params, arena, act_a, act_p, lds, NextActions{nullptr, nullptr, 0, 0, 0, nullptr});
 }
 
 // BaseEnvironment.reset, F/base/base_env.py:852-927, with LayoutFromFile

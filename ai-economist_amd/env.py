@@ -138,6 +138,19 @@ class DeviceBackend:
         p = self._ptr(actions_p, torch.int32, "actions_p")
         self._check(self.lib.aie_step(self.handle, a, p, self._stream()))
 
+    def set_reward_log(self, n_slots):
+        """Allocates a reward log of `n_slots` step slots, f32 [n_slots, E, n_agents + 2] = (agent rewards,
+        planner reward, done), and makes every following step fill the next slot (slot 0 first, wrapping).
+        n_slots = 0 switches it off.  Returns the log tensor (or None)."""
+        torch = _torch()
+        if not n_slots:
+            self._check(self.lib.aie_set_reward_log(self.handle, None, 0))
+            self.reward_log = None
+            return None
+        self.reward_log = torch.zeros((int(n_slots), self.E, self.n + 2), dtype=torch.float32, device=self.device)
+        self._check(self.lib.aie_set_reward_log(self.handle, C.c_void_p(self.reward_log.data_ptr()), int(n_slots)))
+        return self.reward_log
+
     def step_sample_next(self, actions_a, actions_p, seed, env_offset=0, next_slot=1):
         """One launch: step with (actions_a, actions_p) and fill the action buffers of `next_slot`
         with the uniform random policy's next draw (same values as sample_random_actions)."""

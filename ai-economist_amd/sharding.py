@@ -54,3 +54,72 @@ class RewardDoneGather:
         else:
             full = self.send
         return full[:, : self.n], full[:, self.n], full[:, self.n + 1] > 0.5
+
+
+class RewardLogGather:
+    """The same exchange, sized for xGMI: instead of one small collective per 40-microsecond step, the step
+    kernel itself appends (rewards, done) of every step to a device-side log (aie_set_reward_log: slots of
+    f32 [E, n + 2]) and ONE gather per `steps_per_gather` steps ships that many slots to the learner rank.
+    The log holds two such blocks, so the (asynchronous) collective of one block overlaps the steps that fill
+    the other.
+
+        g = RewardLogGather(backend, steps_per_gather=64)   # after env.reset()
+        for t in range(T):
+            backend.step(...)            # or step_sample_next
+            block = g.after_step()       # every 64th step: launches the gather of the block just completed
+        g.finish()                       # waits for the outstanding collective
+
+    On the destination rank `g.received` is the list of gathered blocks, each f32
+    [W, steps_per_gather, E, n + 2] (rank-major => global replica id = rank * E + e), if `keep` is set.
+    """
+
+    def __init__(self, backend, steps_per_gather=64, dst=0, keep=False, force_collective=False):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.dst, self.K, self.keep = dst, int(steps_per_gather), keep
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.log = backend.set_reward_log(2 * self.K)  # [2K, E, n + 2]
+        self.filled = 0   # steps written into the current block
+        self.block = 0    # block being written (0 / 1)
+        self.pending = [None, None]  # outstanding collective per block
+        # force_collective: issue the gather even in a 1-rank group (exercises the RCCL path on one GPU)
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
+        self.recv = None
+        if self.rank == dst and self.collective:
+            self.recv = [[torch.empty_like(self.log[: self.K]) for _ in range(self.world)] for _ in range(2)]
+        self.received = []
+
+    def after_step(self):
+        """Call once after every step; returns True when a block was handed to the collective."""
+        self.filled += 1
+        if self.filled < self.K:
+            return False
+        b = self.block
+        view = self.log[b * self.K: (b + 1) * self.K]
+        if self.collective:
+            # async_op: the backend orders the collective behind the steps already enqueued (RCCL runs it on its
+            # own stream), and wait() below orders later steps behind it -- the steps in between overlap it
+            self.pending[b] = self.dist.gather(view, self.recv[b] if self.rank == self.dst else None,
+                                               dst=self.dst, async_op=True)
+        elif self.keep:
+            self.received.append(view.clone()[None])
+        self.filled = 0
+        self.block ^= 1
+        self._wait(self.block)  # the block about to be overwritten must have left
+        return True
+
+    def _wait(self, b):
+        w = self.pending[b]
+        if w is None:
+            return
+        w.wait()
+        self.pending[b] = None
+        if self.keep and self.rank == self.dst:
+            self.received.append(self.torch.stack(self.recv[b]).clone())
+
+    def finish(self):
+        self._wait(self.block ^ 1)
+        self._wait(self.block)

@@ -145,15 +145,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="development: run the N > 1 reward-log gather in a 1-rank group (under torch.distributed.run)")
     args = ap.parse_args()
 
     import torch
 
-    from ai_economist_amd.sharding import RewardDoneGather, dist_info
+    from ai_economist_amd.sharding import RewardLogGather, dist_info
     from helpers import make_env
 
     rank, local_rank, world = dist_info()
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_gather:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -171,7 +173,10 @@ def main():
     be = env.backend
     n = env.n_agents
     T_ep = env.episode_length
-    gather = RewardDoneGather(E, n, device) if world > 1 else None
+    # N > 1: (reward, done) of every step travel to the learner rank, 64 steps per collective, straight from the
+    # log the step kernel fills (aie_set_reward_log) -- no per-step launches or collectives beside the step
+    gather = (RewardLogGather(be, steps_per_gather=64, force_collective=args.force_gather)
+              if world > 1 or args.force_gather else None)
     t_in_ep = 0
     # uniform random policy: the actions of step t+1 are drawn inside the launch of step t
     # (aie_step_sample_next: the replica's second wavefront is idle during the serial dynamics),
@@ -185,7 +190,7 @@ def main():
         slot ^= 1
         t_in_ep += 1
         if gather is not None:
-            gather(be.tensors["rewards_a"], be.tensors["rewards_p"], be.tensors["done"])
+            gather.after_step()
         if t_in_ep == T_ep:  # all replicas are in lock-step: every one is done now
             be.reset(be.tensors["done"])
             t_in_ep = 0
@@ -207,6 +212,8 @@ def main():
     for _ in range(args.steps):
         one_step()
     ev1.record()
+    if gather is not None:
+        gather.finish()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -249,7 +256,8 @@ def main():
                 "rng": "per-replica NumPy-legacy MT19937 (parity mode)",
                 "policy": "uniform random (counter RNG); the draw for step t+1 happens inside the launch of step t "
                           "(aie_step_sample_next), one launch per step",
-                "parallelism": "replica sharding, %d rank(s); per-step RCCL gather of (reward, done)" % world
+                "parallelism": "replica sharding, %d rank(s); (reward, done) of every step gathered to rank 0 over RCCL, "
+                               "64 steps per collective, overlapped with the steps" % world
                 if world > 1 else "single GPU",
             },
             "roofline": roof,
@@ -257,7 +265,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

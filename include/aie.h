@@ -316,6 +316,15 @@ int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_of
 int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, uint64_t seed,
                          int64_t global_env_offset, int32_t* d_next_a, int32_t* d_next_p, void* stream);
 
+/* Reward log for learners on another device: every following aie_step / aie_step_sample_next ALSO
+ * writes replica e's (agent rewards [n_agents], planner reward, done as 0/1) as n_agents + 2 floats to
+ * d_log[((slot * n_envs) + e) * (n_agents + 2) + ...], slot = 0, 1, ... n_slots - 1, 0, ... advancing by one per
+ * step (this call resets it to 0).  The caller owns d_log (n_slots * n_envs * (n_agents + 2) floats) and ships
+ * whole ranges of slots to the learner rank with one collective per many steps instead of one per step
+ * (ai_economist_amd/sharding.py).  d_log == NULL switches the log off.  Gather-trade-build
+ * scenarios; AIE_E_UNSUPPORTED otherwise. */
+int aie_set_reward_log(aie_env* env, float* d_log, int32_t n_slots);
+
 /* Same counter RNG, but each sub-action is drawn uniformly among the entries that the
  * CURRENT action masks allow (obs_a_action_mask / obs_p_action_mask; NO-OP is always
  * allowed).  This is the random policy a trainer starts from when it applies the

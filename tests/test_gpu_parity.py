@@ -544,3 +544,39 @@ def test_masked_action_sampler_respects_masks(multi):
     _compare_all(be, oracle, "masked rollout")
     if multi:
         assert seen_move.all()
+
+
+@pytest.mark.gpu
+def test_reward_log_slots_follow_the_steps():
+    """aie_set_reward_log: every step also writes (rewards, done) into the next slot of the caller's log."""
+    import torch
+    from test_oracle_vs_reference import BASE, GTB
+
+    cfg = dict(BASE, components=GTB, episode_length=5)
+    E = 40
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(4)
+    env.reset()
+    be = env.backend
+    log = be.set_reward_log(3)
+    assert tuple(log.shape) == (3, E, cfg["n_agents"] + 2)
+    cur = be.sample_random_actions(7, 0, slot=0)
+    slot = 0
+    for t in range(8):
+        if t % 2:  # both step entry points fill the log
+            env.step({"a": cur[0], "p": cur[1]})
+            cur = be.sample_random_actions(7, 0, slot=slot)
+        else:
+            cur = be.step_sample_next(cur[0], cur[1], 7, 0, next_slot=slot ^ 1)
+            slot ^= 1
+        row = log[t % 3].cpu().numpy()
+        n = cfg["n_agents"]
+        assert np.array_equal(row[:, :n], be.tensors["rewards_a"].cpu().numpy()), t
+        assert np.array_equal(row[:, n], be.tensors["rewards_p"].cpu().numpy()), t
+        assert np.array_equal(row[:, n + 1] > 0.5, be.tensors["done"].cpu().numpy().astype(bool)), t
+        if bool(be.tensors["done"][0]):
+            env.reset(be.tensors["done"])
+    before = log.clone()
+    be.set_reward_log(0)
+    env.step({"a": cur[0], "p": cur[1]})
+    assert torch.equal(log, before)

@@ -66,3 +66,65 @@ def test_shard_ranges_cover_all_replicas():
         lo, hi = shard_range(32768, r, 8)
         got += list(range(lo, hi))
     assert got == list(range(32768))
+
+
+class _FakeBackend:
+    """What RewardLogGather needs from a DeviceBackend: set_reward_log + something that fills the slots."""
+
+    def __init__(self, E, n):
+        self.E, self.n, self.t, self.log = E, n, 0, None
+
+    def set_reward_log(self, n_slots):
+        self.log = torch.zeros((n_slots, self.E, self.n + 2))
+        return self.log
+
+    def step(self, lo):
+        slot = self.t % self.log.shape[0]
+        gid = torch.arange(lo, lo + self.E, dtype=torch.float32)
+        self.log[slot, :, : self.n] = gid[:, None] * 10 + torch.arange(self.n)[None, :] + 1000 * self.t
+        self.log[slot, :, self.n] = -gid - self.t
+        self.log[slot, :, self.n + 1] = ((torch.arange(lo, lo + self.E) + self.t) % 3 == 0).float()
+        self.t += 1
+
+
+def _log_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ai_economist_amd.sharding import RewardLogGather, shard_range
+
+    E_total, n, K, T = 12, 3, 4, 20
+    lo, hi = shard_range(E_total, rank, world)
+    be = _FakeBackend(hi - lo, n)
+    g = RewardLogGather(be, steps_per_gather=K, dst=0, keep=True)
+    launched = 0
+    for t in range(T):
+        be.step(lo)
+        launched += int(g.after_step())
+    g.finish()
+    ok = launched == T // K
+    if rank == 0:
+        ok &= len(g.received) == T // K
+        gid = torch.arange(E_total, dtype=torch.float32)
+        for blk, got in enumerate(g.received):  # [W, K, E, n + 2]
+            full = got.permute(1, 0, 2, 3).reshape(K, E_total, n + 2)  # rank-major replica order
+            for k in range(K):
+                t = blk * K + k
+                ok &= torch.equal(full[k, :, :n], gid[:, None] * 10 + torch.arange(n)[None, :] + 1000 * t)
+                ok &= torch.equal(full[k, :, n], -gid - t)
+                ok &= torch.equal(full[k, :, n + 1], ((torch.arange(E_total) + t) % 3 == 0).float())
+    else:
+        ok &= g.received == []
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reward_log_gather_world2_gloo():
+    """The batched exchange bench.py uses for N > 1: one gather per K steps, two alternating blocks."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_log_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
