@@ -283,7 +283,7 @@ int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
     hipLaunchKernelGGL(aie_covid_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
   else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
-    hipLaunchKernelGGL(aie_ose_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+    hipLaunchKernelGGL(aie_ose_reset_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
   else
     hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
@@ -352,7 +352,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
     }
 #undef AIE_CV_LAUNCH
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
-    hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+    hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
   else if (env->step_waves == 2 && (env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT ||
                                     env->P.dev_skip_mask != 0 || env->P.dev_trace != nullptr))

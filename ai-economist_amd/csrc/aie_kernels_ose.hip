@@ -10,6 +10,12 @@
 // F/components/simple_labor.py, F/components/redistribution.py.
 #include "aie_kernels.hip"
 
+// Threads per replica (a multiple of the wavefront size; every wave keeps its own copy of the generator rows
+// and performs the same draws, the first wave writes them back).  Two waves per replica were measured at
+// BASELINE configs[4] (100 agents, 65 536 replicas): 1.49 G agent-steps/s vs 1.54 G with one -- the kernel is not
+// limited by one wave's store issue rate, so one wave (and 13 replicas per CU) it stays.
+#define OSE_NT 64
+
 namespace aie {
 
 struct OseScratch {
@@ -56,11 +62,12 @@ __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __r
   const uint4* src = reinterpret_cast<const uint4*>(g);
   uint4* dst = reinterpret_cast<uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
-  for (int q = c.tid; q < nq; q += AIE_NT) dst[q] = src[q];
+  for (int q = c.tid; q < nq; q += OSE_NT) dst[q] = src[q];
   const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
+  const int lane = c.tid & 63;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
-  m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
+  for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + lane];
+  m.r[9] = lane < 48 ? key[576 + lane] : 0u;
 }
 
 // SimpleLabor.component_step simple_labor.py:105-126.  The random agent order
@@ -68,8 +75,8 @@ __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __r
 // on it, so the update itself runs one lane per agent.
 __device__ __forceinline__ void labor_component_step(const Ctx& c, const OseScratch& s, MT& m) {
   const int n = c.P.n;
-  for (int i = n - 1; i >= 1; --i) (void)rng_interval(m, c.tid, (uint32_t)i);
-  for (int i = c.tid; i < n; i += AIE_NT) {
+  for (int i = n - 1; i >= 1; --i) (void)rng_interval(m, c.tid & 63, (uint32_t)i);
+  for (int i = c.tid; i < n; i += OSE_NT) {
     const int a = s.act[i];
     if (a != 0) {
       R_F64(c, o_labor)[i] = (double)a;  // hours worked this step (set, not accumulated)
@@ -85,10 +92,10 @@ __device__ __forceinline__ void labor_component_step(const Ctx& c, const OseScra
 __device__ __forceinline__ void ose_wealth_component_step(const Ctx& c, const OseScratch& s) {
   const int n = c.P.n;
   __syncthreads();
-  for (int i = c.tid; i < n; i += AIE_NT) s.tmp[i] = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
+  for (int i = c.tid; i < n; i += OSE_NT) s.tmp[i] = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
   __syncthreads();
   const double share = np_sum_small(s.tmp, n) / (double)n;  // every lane, same value
-  for (int i = c.tid; i < n; i += AIE_NT) R_F64(c, o_inv_coin)[i] = share - R_F64(c, o_esc_coin)[i];
+  for (int i = c.tid; i < n; i += OSE_NT) R_F64(c, o_inv_coin)[i] = share - R_F64(c, o_esc_coin)[i];
   __syncthreads();
 }
 
@@ -104,7 +111,7 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
     __syncthreads();
   }
   if (pos >= c.P.c.tax_period) {
-    for (int i = c.tid; i < n; i += AIE_NT) {
+    for (int i = c.tid; i < n; i += OSE_NT) {
       const double coin = R_F64(c, o_inv_coin)[i];
       const double income = (coin + R_F64(c, o_esc_coin)[i]) - R_F64(c, o_tax_last_coin)[i];
       const double due = tax_due(c, income);
@@ -148,7 +155,7 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
       atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_days), 1);
     }
     const double lump = net / (double)n;
-    for (int i = c.tid; i < n; i += AIE_NT) {
+    for (int i = c.tid; i < n; i += OSE_NT) {
       const double v = R_F64(c, o_inv_coin)[i] + lump;
       R_F64(c, o_inv_coin)[i] = v;
       R_F64(c, o_tax_last_coin)[i] = v + R_F64(c, o_esc_coin)[i];
@@ -163,7 +170,7 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
 
 // ascending sort of src[0..n) into dst by counting ranks (one lane per element)
 __device__ __forceinline__ void rank_sort(const double* src, double* dst, int n, int tid) {
-  for (int i = tid; i < n; i += AIE_NT) {
+  for (int i = tid; i < n; i += OSE_NT) {
     const double x = src[i];
     int rank = 0;
     for (int j = 0; j < n; ++j) {
@@ -197,7 +204,7 @@ __device__ __forceinline__ double ose_gini(const OseScratch& s, double* cs, int 
 __device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s) {
   const aie_params& P = c.P;
   const int n = P.n;
-  for (int i = c.tid; i < n; i += AIE_NT) {
+  for (int i = c.tid; i < n; i += OSE_NT) {
     const double coin = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
     const double labor = R_F64(c, o_labor)[i];
     s.coin[i] = coin;
@@ -225,13 +232,13 @@ __device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s) {
     }
   } else {
     const bool use_util = prt == AIE_PLANNER_REW_INV_INCOME_UTIL;
-    for (int i = c.tid; i < n; i += AIE_NT) {
+    for (int i = c.tid; i < n; i += OSE_NT) {
       const double base = use_util ? R_F64(c, o_production)[i] : s.coin[i];
       s.tmp[i] = 1 / (base > 1 ? base : 1);
     }
     __syncthreads();
     const double sw = np_sum_small(s.tmp, n);  // every lane, same value
-    for (int i = c.tid; i < n; i += AIE_NT) s.sorted[i] = (use_util ? s.part[i] : s.coin[i]) * (s.tmp[i] / sw);
+    for (int i = c.tid; i < n; i += OSE_NT) s.sorted[i] = (use_util ? s.part[i] : s.coin[i]) * (s.tmp[i] / sw);
     __syncthreads();
     if (c.tid == 0) s.part[n] = np_sum_small(s.sorted, n);
   }
@@ -249,12 +256,12 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
   // ---- shared quantities ----
   if (P.has_tax) {
     const double per = (double)P.c.tax_period;
-    for (int i = tid; i < n; i += AIE_NT) s.tmp[i] = R_F64(c, o_tax_last_income)[i] / per;
+    for (int i = tid; i < n; i += OSE_NT) s.tmp[i] = R_F64(c, o_tax_last_income)[i] / per;
     __syncthreads();
     rank_sort(s.tmp, s.sorted, n, tid);
     __syncthreads();
     const int pos = *R_I32(c, o_tax_cycle_pos);
-    for (int j = tid; j < NB + n + 4; j += AIE_NT) {
+    for (int j = tid; j < NB + n + 4; j += OSE_NT) {
       float v;
       if (j < NB) v = (float)tax_rate(c, j);
       else if (j == NB) v = pos == 1 ? 1.0f : 0.0f;               // is_first_day
@@ -266,7 +273,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
       else if (j == NB + 3 + n) s.tmpl_p[P.fp_tax + NB + 2 + n] = v;
     }
   }
-  for (int i = tid; i < n; i += AIE_NT) {
+  for (int i = tid; i < n; i += OSE_NT) {
     const double coin = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
     s.coin[i] = coin;
     if (P.has_tax) s.tmp[i] = tax_marginal_rate(c, coin - R_F64(c, o_tax_last_coin)[i]);
@@ -299,7 +306,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
       return v;
     };
     const int tot = n * P.FA;
-    for (int q = 4 * tid; q < tot; q += 4 * AIE_NT) {
+    for (int q = 4 * tid; q < tot; q += 4 * OSE_NT) {
       int i = udiv(q, P.FA, P.mg_FA), j = q - i * P.FA;
       float v[4];
 #pragma unroll
@@ -312,10 +319,10 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
         for (int u = 0; u < 4 && q + u < tot; ++u) buf_store_f32(g, v[u], 4 * (q + u), 0);
     }
     float* gt = reinterpret_cast<float*>(arena + P.a_obs_a_time) + (int64_t)c.e * n;
-    for (int i = tid; i < n; i += AIE_NT) gt[i] = tval;
+    for (int i = tid; i < n; i += OSE_NT) gt[i] = tval;
     if (P.FPA) {
       float* gp = reinterpret_cast<float*>(arena + P.a_obs_p_agents) + (int64_t)c.e * n * P.FPA;
-      for (int i = tid; i < n; i += AIE_NT) {
+      for (int i = tid; i < n; i += OSE_NT) {
         gp[i * 3 + 0] = (float)s.tmp[i];
         gp[i * 3 + 1] = (float)(R_F64(c, o_tax_last_income)[i] / (double)P.c.tax_period);
         gp[i * 3 + 2] = (float)R_F64(c, o_tax_last_marginal_rate)[i];
@@ -335,7 +342,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
     const BufRsrc g = make_rsrc(arena + P.a_obs_a_mask + (int64_t)c.e * n * P.MA * 4, (uint32_t)(n * P.MA * 4));
     const int tot = n * P.MA;
     (void)multi;
-    for (int q = 4 * tid; q < tot; q += 4 * AIE_NT) {
+    for (int q = 4 * tid; q < tot; q += 4 * OSE_NT) {
       int mm = q - udiv(q, P.MA, P.mg_MA) * P.MA;
       float v[4];
 #pragma unroll
@@ -355,7 +362,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
     const bool pmulti = P.c.multi_action_mode_planner != 0;
     const float open = (P.n_sub_p && *R_I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
     float* gp = reinterpret_cast<float*>(arena + P.a_obs_p_mask) + (int64_t)c.e * P.MP;
-    for (int q = tid; q < P.MP; q += AIE_NT) {
+    for (int q = tid; q < P.MP; q += OSE_NT) {
       int j = -1;  // index of the discretised rate this entry stands for (-1: a NO-OP entry)
       if (P.n_sub_p == 0) j = -1;
       else if (pmulti) j = q - udiv(q, 1 + P.sub_p_dim, P.mg_sub_p) * (1 + P.sub_p_dim) - 1;
@@ -372,8 +379,9 @@ __device__ __forceinline__ void ose_store_record(const Ctx& c, uint8_t* __restri
   uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
-  for (int q = c.tid; q < nq; q += AIE_NT) dst[q] = src[q];
+  for (int q = c.tid; q < nq; q += OSE_NT) dst[q] = src[q];
   uint32_t* key = reinterpret_cast<uint32_t*>(g + c.P.o_mt);
+  if (c.tid >= 64) return;  // every wave holds the same rows
 #pragma unroll
   for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
   if (c.tid < 48) key[576 + c.tid] = m.r[9];
@@ -382,7 +390,7 @@ __device__ __forceinline__ void ose_store_record(const Ctx& c, uint8_t* __restri
 }  // namespace aie
 
 // BaseEnvironment.step (base_env.py:929-1032) for the one-step-economy scenario
-extern "C" __global__ void __launch_bounds__(AIE_NT)
+extern "C" __global__ void __launch_bounds__(OSE_NT)
 aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                     const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -394,7 +402,7 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   MT m;
   ose_load_record(c, arena, m);
   // parse_actions (base_agent.py:407-438)
-  for (int i = tid; i < n; i += AIE_NT) {
+  for (int i = tid; i < n; i += OSE_NT) {
     int a = 0;
     if (act_a && P.n_sub_a) {
       const int v = act_a[((int64_t)c.e * n + i) * P.act_a_width];
@@ -432,7 +440,7 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   ose_metrics(c, s);
   {
     double* util = R_F64(c, o_util);
-    for (int i = tid; i <= n; i += AIE_NT) {
+    for (int i = tid; i <= n; i += OSE_NT) {
       const double r = s.part[i] - util[i];
       util[i] = s.part[i];
       if (i < n) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)c.e * n + i] = (float)r;
@@ -451,7 +459,7 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
 
 // reset: one_step_economy.py:99-118 + simple_labor.py:76-95 + redistribution.py:1109-1139
 // + additional_reset_steps :224-241.  No random draws.
-extern "C" __global__ void __launch_bounds__(AIE_NT)
+extern "C" __global__ void __launch_bounds__(OSE_NT)
 aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                      const uint8_t* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -462,12 +470,12 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   OseScratch s;
   const Ctx c = ose_make_ctx(P, lds, e, (int)threadIdx.x, s, arena);
   const int n = P.n, tid = c.tid;
-  for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
+  for (int q = tid; q < (P.met_bytes >> 2); q += OSE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
   if (c.ev && tid == 0) c.ev[0] = 0;
   MT m;
   ose_load_record(c, arena, m);
   __syncthreads();
-  for (int i = tid; i < n; i += AIE_NT) {
+  for (int i = tid; i < n; i += OSE_NT) {
     R_F64(c, o_inv_coin)[i] = 0; R_F64(c, o_esc_coin)[i] = 0; R_F64(c, o_labor)[i] = 0;
     R_F64(c, o_skill)[i] = P.has_labor ? P.c.labor_skills[i] : 0;
     R_F64(c, o_production)[i] = 0;
@@ -486,10 +494,10 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   if (P.has_tax && tid < P.NB) R_I32(c, o_tax_rate_idx)[tid] = 0;
   __syncthreads();
   ose_metrics(c, s);
-  for (int i = tid; i <= n; i += AIE_NT) R_F64(c, o_util)[i] = s.part[i];
+  for (int i = tid; i <= n; i += OSE_NT) R_F64(c, o_util)[i] = s.part[i];
   __syncthreads();
   ose_write_observations(c, s, arena, true);
-  for (int i = tid; i < n; i += AIE_NT) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + i] = 0.0f;
+  for (int i = tid; i < n; i += OSE_NT) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + i] = 0.0f;
   if (tid == 0) {
     reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.0f;
     (arena + P.a_done)[e] = 0;
