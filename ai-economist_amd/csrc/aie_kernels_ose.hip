@@ -173,6 +173,7 @@ __device__ __forceinline__ void rank_sort(const double* src, double* dst, int n,
   for (int i = tid; i < n; i += OSE_NT) {
     const double x = src[i];
     int rank = 0;
+#pragma unroll 10
     for (int j = 0; j < n; ++j) {
       const double y = src[j];
       rank += (y < x || (y == x && j < i)) ? 1 : 0;
@@ -181,23 +182,34 @@ __device__ __forceinline__ void rank_sort(const double* src, double* dst, int n,
   }
 }
 
-// social_metrics.get_gini (social_metrics.py:10-46) of s.coin; lane 0 only, sorted copy
-// must be in s.sorted for n >= 30.
-__device__ __forceinline__ double ose_gini(const OseScratch& s, double* cs, int n) {
+// social_metrics.get_gini (social_metrics.py:10-46) of s.coin; called by every thread, the result is valid on
+// thread 0; the sorted copy must be in s.sorted for n >= 30.  The running sums of the sorted-cumsum branch are
+// sequential (one thread), the 100 divisions by the total and nothing else are spread over the lanes.
+__device__ __forceinline__ double ose_gini(const OseScratch& s, double* cs, int n, int tid) {
+  __shared__ double s_tot;
   if (n < 30) {
+    if (tid != 0) return 0.0;
     double diff = 0;
     for (int i = 0; i < n; ++i)
       for (int j = 0; j < n; ++j) diff += fabs(s.coin[i] - s.coin[j]);
     const double unscaled = diff / (2 * n * np_sum_small(s.coin, n) + 1e-10);
     return unscaled / ((double)(n - 1) / (double)n);
   }
-  const double tot = np_sum_small(s.sorted, n) + 1e-10;
-  double run = 0;
-  for (int i = 0; i < n; ++i) {
-    run += s.sorted[i];
-    cs[i] = run / tot;
+  __syncthreads();
+  if (tid == 0) {
+    s_tot = np_sum_small(s.sorted, n) + 1e-10;
+    double run = 0;
+#pragma unroll 10
+    for (int i = 0; i < n; ++i) {
+      run += s.sorted[i];
+      cs[i] = run;
+    }
   }
-  return 1 - (2.0 / (n + 1)) * np_sum_small(cs, n);
+  __syncthreads();
+  const double tot = s_tot;
+  for (int i = tid; i < n; i += OSE_NT) cs[i] = cs[i] / tot;
+  __syncthreads();
+  return tid == 0 ? 1 - (2.0 / (n + 1)) * np_sum_small(cs, n) : 0.0;
 }
 
 // get_current_optimization_metrics one_step_economy.py:280-336 -> s.part[0..n]
@@ -225,10 +237,11 @@ __device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s) {
   if (prt == AIE_PLANNER_REW_COIN_EQ_TIMES_PROD) {
     if (n >= 30) rank_sort(s.coin, s.sorted, n, c.tid);
     __syncthreads();
+    const double gini = ose_gini(s, s.tmp, n, c.tid);
     if (c.tid == 0) {
       const double ew = 1 - P.c.mixing_weight_gini_vs_coin;
       const double prod = np_sum_small(s.coin, n) / n;
-      s.part[n] = (ew * (1 - ose_gini(s, s.tmp, n)) + (1 - ew)) * prod;
+      s.part[n] = (ew * (1 - gini) + (1 - ew)) * prod;
     }
   } else {
     const bool use_util = prt == AIE_PLANNER_REW_INV_INCOME_UTIL;
@@ -287,9 +300,9 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
   // planner world-equality / world-normalized_per_capita_productivity (:161-172)
   if (n >= 30) rank_sort(s.coin, s.sorted, n, tid);
   __syncthreads();
+  const double gini = ose_gini(s, s.part, n, tid);  // s.part is free here (rewards are computed afterwards)
   if (tid == 0) {
-    // s.part is free here (rewards are computed afterwards)
-    s.tmpl_p[P.fp_world + 0] = (float)(1 - ose_gini(s, s.part, n));
+    s.tmpl_p[P.fp_world + 0] = (float)(1 - gini);
     s.tmpl_p[P.fp_world + 1] = (float)(np_sum_small(s.coin, n) / n / 1000);
   }
   __syncthreads();
