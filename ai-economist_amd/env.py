@@ -251,6 +251,27 @@ class DeviceBackend:
                 self.tensors["cell_flags"][...] = src
             else:
                 self.tensors["cell_flags"][e] = src
+            if "regen_source_count" in self.tensors:
+                # bookkeeping the reset kernel derives from the layout (source blocks per regeneration window,
+                # csrc/aie_layout.h: regen_conv): a layout injected here needs the same counts
+                cnt = self._source_window_counts(np.asarray(state["stone_src"]), np.asarray(state["wood_src"]))
+                src = torch.as_tensor(cnt, device=self.device)
+                if e is None:
+                    self.tensors["regen_source_count"][...] = src
+                else:
+                    self.tensors["regen_source_count"][e] = src
+
+    def _source_window_counts(self, stone_src, wood_src):
+        out = []
+        for plane, hw in ((stone_src, int(self.cfg.regen_halfwidth[0])), (wood_src, int(self.cfg.regen_halfwidth[1]))):
+            p = np.pad((np.asarray(plane) > 0).astype(np.int32), hw)
+            H, W = np.asarray(plane).shape
+            acc = np.zeros((H, W), np.int32)
+            for dr in range(2 * hw + 1):
+                for dc in range(2 * hw + 1):
+                    acc += p[dr: dr + H, dc: dc + W]
+            out.append(acc)
+        return np.stack(out).astype(np.uint8)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -258,6 +258,24 @@ CASES = {
                  starting_agent_coin=10, water_row=11, skill_rank_of_top_agents=[0, 3],
                  env_layout_file="uniform_25x25_25each_65clump.txt"),
         seed=31, t_steps=100, obs_steps=[0, 1, 50, 51, 100]),
+    # neighbourhood regeneration (regen_halfwidth 2 / 1: scipy convolve2d over the source blocks) and the
+    # WealthRedistribution component in front of the tax component
+    "quadrant_halfwidth_wealth_4ag": dict(
+        cfg=dict(scenario_name="quadrant/simple_wood_and_stone", n_agents=4, world_size=[16, 16],
+                 episode_length=60,
+                 components=GTB[:3] + [["WealthRedistribution", {}], ["PeriodicBracketTax", {"period": 20}]],
+                 starting_agent_coin=10, starting_stone_coverage=0.10, starting_wood_coverage=0.10,
+                 wood_regen_halfwidth=2, wood_regen_weight=0.6, stone_regen_halfwidth=1, stone_regen_weight=0.4),
+        seed=37, t_steps=120, obs_steps=[0, 1, 20, 60, 61, 120]),
+    # tax_model "saez" while the sample buffer is short of its 500 samples: np.random.uniform bracket rates at
+    # every period start (drawn between the step's other draws), (income, marginal rate) pairs collected
+    "saez_random_rate_phase_5ag": dict(
+        cfg=dict(scenario_name="layout_from_file/simple_wood_and_stone", n_agents=5, world_size=[25, 25],
+                 episode_length=50,
+                 components=GTB[:3] + [["PeriodicBracketTax", {"period": 5, "tax_model": "saez", "rate_max": 0.9}]],
+                 starting_agent_coin=15, resource_regen_prob=0.08,
+                 env_layout_file="uniform_25x25_25each_65clump.txt"),
+        seed=41, t_steps=100, obs_steps=[0, 1, 5, 6, 50, 51, 100]),
     "multizone16_4ag": dict(
         cfg=dict(scenario_name="multi_zone/simple_wood_and_stone", n_agents=4, world_size=[16, 16],
                  episode_length=60, components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10,

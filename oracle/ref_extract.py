@@ -16,6 +16,21 @@ def pack_order(agent, price, lifetime):
     return np.int32(int(agent) | (int(price) << 8) | (int(lifetime) << 16))
 
 
+def _saez_state(c, s, n_agents):
+    """tax_model "saez": sample buffer (zero-padded to the device capacity), estimates, rates."""
+    if c.tax_model != "saez":
+        return
+    buf = np.array(c._local_saez_buffer, np.float64).reshape(-1, 2)
+    pad = np.zeros((c._buffer_size + n_agents, 2))
+    pad[: len(buf)] = buf
+    s["saez_buffer_len"] = np.array(len(buf), np.int32)
+    s["saez_reached_min_samples"] = np.array(int(c._reached_min_samples), np.int32)
+    s["saez_buffer_filled"] = pad
+    s["saez_elas"] = np.array([c.elas_t, c.elas_tm1, c.log_z0_t, c.log_z0_tm1], np.float64)
+    s["saez_running_avg_tax_rates"] = np.array(c.running_avg_tax_rates, np.float64)
+    s["tax_saez_bracket_rates"] = np.array(c.curr_bracket_tax_rates, np.float64)
+
+
 def extract_state_one_step_economy(env):
     w = env.world
     ag = w.agents
@@ -38,14 +53,7 @@ def extract_state_one_step_economy(env):
         s["tax_last_income"] = np.array(c.last_income, np.float64)
         s["tax_last_marginal_rate"] = np.array(c.last_marginal_rate, np.float64)
         s["tax_total_collected"] = np.array(c.total_collected_taxes, np.float64)
-        if c.tax_model == "saez":
-            buf = np.array(c._local_saez_buffer, np.float64).reshape(-1, 2)
-            s["saez_buffer_len"] = np.array(len(buf), np.int32)
-            s["saez_reached_min_samples"] = np.array(int(c._reached_min_samples), np.int32)
-            s["saez_buffer_filled"] = buf
-            s["saez_elas"] = np.array([c.elas_t, c.elas_tm1, c.log_z0_t, c.log_z0_tm1], np.float64)
-            s["saez_running_avg_tax_rates"] = np.array(c.running_avg_tax_rates, np.float64)
-            s["tax_saez_bracket_rates"] = np.array(c.curr_bracket_tax_rates, np.float64)
+        _saez_state(c, s, len(ag))
     if "SimpleLabor" in comps:
         s["labor_first_step"] = np.array(int(comps["SimpleLabor"].is_first_step), np.int32)
     s["timestep"] = np.array(w.timestep, np.int32)
@@ -138,6 +146,7 @@ def extract_state(env):
         s["tax_last_income"] = np.array(c.last_income, np.float64)
         s["tax_last_marginal_rate"] = np.array(c.last_marginal_rate, np.float64)
         s["tax_total_collected"] = np.array(c.total_collected_taxes, np.float64)
+        _saez_state(c, s, len(ag))
     s["timestep"] = np.array(w.timestep, np.int32)
     s["completions"] = np.array(env._completions, np.int32)
     s["auto_warmup"] = np.array(env._auto_warmup_integrator, np.int32)

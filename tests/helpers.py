@@ -97,8 +97,8 @@ def compare_state(got, want, where="", f64_tol=1e-9):
         assert book_equal(got["cda_n_asks"], got["cda_asks"], want["cda_n_asks"], want["cda_asks"]), (
             "%s: ask book differs" % where)
     if "saez_buffer_filled" in want and "saez_buffer" in got:  # the filled prefix of the sample buffer
-        m = len(want["saez_buffer_filled"])
-        np.testing.assert_allclose(np.asarray(got["saez_buffer"])[:m], want["saez_buffer_filled"], rtol=f64_tol,
+        m = int(want["saez_buffer_len"])
+        np.testing.assert_allclose(np.asarray(got["saez_buffer"])[:m], np.asarray(want["saez_buffer_filled"])[:m], rtol=f64_tol,
                                    atol=f64_tol, err_msg="%s: saez buffer" % where)
     for k in F64_FIELDS:
         if k in want and k in got:
