@@ -54,7 +54,7 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, i
   s.tmpl_p = s.tmpl_a + pad4(P.FA);
   uint8_t* met = arena + P.a_metrics + (int64_t)e * P.met_bytes;
   int32_t* ev = e < P.ev_replicas ? reinterpret_cast<int32_t*>(arena + P.a_events + (int64_t)e * P.ev_stride) : nullptr;
-  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, false, true, tid, e};
+  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e};
 }
 
 __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {
@@ -100,9 +100,25 @@ __device__ __forceinline__ void ose_wealth_component_step(const Ctx& c, const Os
 }
 
 // PeriodicBracketTax.component_step :945-972 with enact_taxes :853-915
-__device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseScratch& s) {
+__device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseScratch& s, MT& m) {
   const int n = c.P.n;
   int pos = uni(*R_I32(c, o_tax_cycle_pos));
+  if (pos == 1 && c.saez) {  // compute_and_set_new_period_rates_from_saez_formula (see tax_component_step)
+    uint8_t* blk = saez_block(c);
+    if (uni(reinterpret_cast<const int32_t*>(blk)[1])) {
+      if (c.tid < c.P.NB) R_F64(c, o_tax_saez_rates)[c.tid] = reinterpret_cast<const double*>(blk + AIE_SAEZ_OFF_NEXT)[c.tid];
+    } else {
+      const double lo = c.P.c.tax_rate_min;
+      const double hi = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.P.c.tax_rate_max;
+      for (int b = 0; b < c.P.NB; ++b) {
+        const double r = lo + (hi - lo) * rng_double(m, c.tid & 63);
+        if (c.tid == b) R_F64(c, o_tax_saez_rates)[b] = r;
+      }
+    }
+    __syncthreads();
+    if (c.tid < c.P.NB) R_F64(c, o_tax_saez_obs_rates)[c.tid] = tax_rate(c, c.tid);
+    __syncthreads();
+  }
   if (pos == 1 && c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER && !c.P.c.tax_disable) {
     if (c.tid < c.P.NB) {
       const int a = c.act_p[c.tid];
@@ -161,6 +177,32 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
       R_F64(c, o_tax_last_coin)[i] = v + R_F64(c, o_esc_coin)[i];
     }
     if (c.tid == 0) *R_F64(c, o_tax_total_collected) += net;
+    if (c.saez) {  // _update_saez_buffer :533-541 (one wavefront per replica: OSE_NT == 64)
+      static_assert(OSE_NT == AIE_NT, "the in-place move below relies on one wavefront per replica");
+      uint8_t* blk = saez_block(c);
+      int32_t* hdr = reinterpret_cast<int32_t*>(blk);
+      double* buf = reinterpret_cast<double*>(blk + AIE_SAEZ_OFF_BUF);
+      int len = uni(hdr[0]);
+      for (int i = c.tid; i < n; i += OSE_NT) {
+        buf[2 * (len + i)] = R_F64(c, o_tax_last_income)[i];
+        buf[2 * (len + i) + 1] = R_F64(c, o_tax_last_marginal_rate)[i];
+      }
+      len += n;
+      const int size = c.P.c.saez_buffer_size;
+      if (len > size) {  // drop the oldest: chunk by chunk, a chunk's loads precede its stores
+        const int shift = 2 * (len - size);
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int base = 0; base < 2 * size; base += OSE_NT) {
+          const int q = base + c.tid;
+          double v = 0;
+          if (q < 2 * size) v = buf[q + shift];
+          __builtin_amdgcn_s_waitcnt(0);
+          if (q < 2 * size) buf[q] = v;
+        }
+        len = size;
+      }
+      if (c.tid == 0) hdr[0] = len;
+    }
     pos = 0;
     __syncthreads();
   }
@@ -276,7 +318,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
     const int pos = *R_I32(c, o_tax_cycle_pos);
     for (int j = tid; j < NB + n + 4; j += OSE_NT) {
       float v;
-      if (j < NB) v = (float)tax_rate(c, j);
+      if (j < NB) v = (float)tax_rate_obs(c, j);
       else if (j == NB) v = pos == 1 ? 1.0f : 0.0f;               // is_first_day
       else if (j == NB + 1) v = pos >= P.c.tax_period ? 1.0f : 0.0f;  // is_tax_day
       else if (j < NB + 2 + n) v = (float)s.sorted[j - NB - 2];   // last_incomes (sorted)
@@ -442,7 +484,7 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   if (c.ev && tid == 0) c.ev[0] = 0;
   for (int k = 0; k < P.c.n_components; ++k) {
     if (P.c.components[k] == AIE_COMP_SIMPLE_LABOR) labor_component_step(c, s, m);
-    else if (P.c.components[k] == AIE_COMP_TAX) ose_tax_component_step(c, s);
+    else if (P.c.components[k] == AIE_COMP_TAX) ose_tax_component_step(c, s, m);
     else if (P.c.components[k] == AIE_COMP_WEALTH_REDISTRIBUTION) ose_wealth_component_step(c, s);
   }
   if (tid == 0) *R_I32(c, o_mt_pos) = m.pos;
@@ -506,6 +548,12 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   }
   if (P.has_tax && tid < P.NB) R_I32(c, o_tax_rate_idx)[tid] = 0;
   __syncthreads();
+  if (c.saez) {  // _curr_rates_obs first (:1123, the previous episode's rates), then the running average (:1136-1137)
+    if (tid < P.NB) R_F64(c, o_tax_saez_obs_rates)[tid] = tax_rate(c, tid);
+    __syncthreads();
+    if (tid < P.NB) R_F64(c, o_tax_saez_rates)[tid] = reinterpret_cast<const double*>(saez_block(c) + AIE_SAEZ_OFF_AVG)[tid];
+    __syncthreads();
+  }
   ose_metrics(c, s);
   for (int i = tid; i <= n; i += OSE_NT) R_F64(c, o_util)[i] = s.part[i];
   __syncthreads();

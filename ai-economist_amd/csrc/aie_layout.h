@@ -531,6 +531,10 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
     p->o_tax_cycle_pos = aie__rec(&cur, 4, 4);
     p->o_tax_last_completions = aie__rec(&cur, 4, 4);
     p->o_tax_rate_idx = aie__rec(&cur, 4 * p->NB, 4);
+    if (c->tax_model == AIE_TAX_SAEZ) {
+      p->o_tax_saez_rates = aie__rec(&cur, 8 * p->NB, 8);
+      p->o_tax_saez_obs_rates = aie__rec(&cur, 8 * p->NB, 8);
+    }
   }
   p->o_timestep = aie__rec(&cur, 4, 4);
   p->o_completions = aie__rec(&cur, 4, 4);
@@ -557,12 +561,14 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
   p->a_done = a;  a = aie__align(a + E, 256);
   aie__alloc_metrics(p, &a);
   aie__alloc_events(c, p, &a);
+  aie__alloc_saez(c, p, &a);
   p->arena_bytes = a;
 
   if (tt) {
     const int64_t rs = p->rec_bytes, r0 = p->a_records;
     aie__add_metrics_tensors(p, tt);
     aie__add_event_tensors(p, tt);
+    aie__add_saez_tensors(p, tt);
 #define REC(name, dt, off, nd, d0) aie__add(tt, name, dt, r0 + (off), rs, nd, d0, 0, 0, 0, E)
     REC("inv_coin", AIE_F64, p->o_inv_coin, 1, n);
     REC("esc_coin", AIE_F64, p->o_esc_coin, 1, n);
@@ -574,6 +580,10 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
       REC("tax_cycle_pos", AIE_I32, p->o_tax_cycle_pos, 0, 0);
       REC("tax_last_completions", AIE_I32, p->o_tax_last_completions, 0, 0);
       REC("tax_rate_idx", AIE_I32, p->o_tax_rate_idx, 1, p->NB);
+      if (c->tax_model == AIE_TAX_SAEZ) {
+        REC("tax_saez_bracket_rates", AIE_F64, p->o_tax_saez_rates, 1, p->NB);
+        REC("tax_saez_observed_rates", AIE_F64, p->o_tax_saez_obs_rates, 1, p->NB);
+      }
       REC("tax_last_coin", AIE_F64, p->o_tax_last_coin, 1, n);
       REC("tax_last_income", AIE_F64, p->o_tax_last_income, 1, n);
       REC("tax_last_marginal_rate", AIE_F64, p->o_tax_last_marginal_rate, 1, n);
@@ -722,10 +732,6 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     if (c->tax_n_brackets < 2 || c->tax_n_brackets > AIE_MAX_BRACKETS) AIE__FAIL("Tax.n_brackets out of range");
     if (c->tax_model < AIE_TAX_MODEL_WRAPPER || c->tax_model > AIE_TAX_SAEZ) AIE__FAIL("unknown tax_model");
     if (c->tax_model == AIE_TAX_SAEZ) {
-      if (c->scenario != AIE_SCN_GTB) {
-        if (err) snprintf(err, errlen, "tax_model saez is implemented for the gather-trade-build scenarios");
-        return AIE_E_UNSUPPORTED;
-      }
       if (c->saez_buffer_size < 1 || c->saez_buffer_size > 4096) AIE__FAIL("saez_buffer_size out of range");
       if (!(c->tax_rate_min >= 0.0 && c->tax_rate_min <= c->tax_rate_max)) AIE__FAIL("rate_min / rate_max");
       if (c->saez_fixed_elas_given && !(c->saez_fixed_elas >= 0.0)) AIE__FAIL("saez_fixed_elas must be >= 0");

@@ -1465,7 +1465,7 @@ static void ose_write_obs(ctx_t* c, int at_reset) {
     coin[i] = F64(c, o_inv_coin)[i] + F64(c, o_esc_coin)[i];
     if (p->has_tax) {
       float* g = f + p->fa_tax;
-      for (int b = 0; b < NB; ++b) g[b] = (float)tax_rate(c, b);
+      for (int b = 0; b < NB; ++b) g[b] = (float)tax_rate_obs(c, b);
       g[NB + 0] = (float)is_first_day;
       g[NB + 1] = (float)is_tax_day;
       for (int k = 0; k < n; ++k) g[NB + 2 + k] = (float)sorted_inc[k];
@@ -1484,7 +1484,7 @@ static void ose_write_obs(ctx_t* c, int at_reset) {
   float* pf = (float*)(c->arena + p->a_obs_p_flat) + (int64_t)e * p->FP;
   if (p->has_tax) {
     float* g = pf + p->fp_tax;
-    for (int b = 0; b < NB; ++b) g[b] = (float)tax_rate(c, b);
+    for (int b = 0; b < NB; ++b) g[b] = (float)tax_rate_obs(c, b);
     g[NB + 0] = (float)is_first_day;
     g[NB + 1] = (float)is_tax_day;
     for (int k = 0; k < n; ++k) g[NB + 2 + k] = (float)sorted_inc[k];
@@ -1597,6 +1597,10 @@ static void ose_reset_one(const aie_params* p, uint8_t* arena, int e) {
       F64(&c, o_tax_last_coin)[i] = 0; F64(&c, o_tax_last_income)[i] = 0; F64(&c, o_tax_last_marginal_rate)[i] = 0;
     }
     *F64(&c, o_tax_total_collected) = 0;
+    if (p->c.tax_model == AIE_TAX_SAEZ) { /* _curr_rates_obs (:1123), then the running average (:1136-1137) */
+      for (int b = 0; b < p->NB; ++b) F64(&c, o_tax_saez_obs_rates)[b] = tax_rate(&c, b);
+      memcpy(F64(&c, o_tax_saez_rates), SAEZ(&c) + AIE_SAEZ_OFF_AVG, sizeof(double) * (size_t)p->NB);
+    }
   }
   ose_metrics(&c, F64(&c, o_util));
   ose_write_obs(&c, 1);

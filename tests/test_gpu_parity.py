@@ -354,6 +354,9 @@ OSE_VARIANTS = {
                                      planner_reward_type="coin_eq_times_productivity", isoelastic_eta=0.4),
     "no_first_step_mask_128ag": dict(n_agents=128, labor_kw=dict(mask_first_step=False)),
     "wealth_redistribution_77ag": dict(n_agents=77, extra_components=[["WealthRedistribution", {}]]),
+    # tax_model "saez": 45 samples per step => the 500-sample buffer fills during the test (random rates, then the
+    # formula kernel's first periods; compared with the restatement every step)
+    "saez_45ag": dict(n_agents=45, steps=16, tax_kw={"tax_model": "saez", "rate_max": 0.8}),
 }
 
 
@@ -404,14 +407,14 @@ def test_hip_matches_oracle_one_step_economy(variant):
     kw = dict(OSE_VARIANTS[variant])
     labor_kw = kw.pop("labor_kw", {})
     extra = kw.pop("extra_components", [])
+    tax_kw = dict({"bracket_spacing": "us-federal", "period": 1, "tax_model": "model_wrapper"}, **kw.pop("tax_kw", {}))
     rs = np.random.RandomState(4)
     n = kw["n_agents"]
     labor_kw["skills"] = [float(x) for x in np.sort(1 + rs.rand(n) * 2)]
     cfg = dict(scenario_name="one-step-economy", world_size=[1, 1], episode_length=2,
-               components=[["SimpleLabor", labor_kw]] + extra +
-                          [["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
-                                                   "tax_model": "model_wrapper"}]], **kw)
-    E, T = 96, 12
+               components=[["SimpleLabor", labor_kw]] + extra + [["PeriodicBracketTax", tax_kw]], **kw)
+    E, T = 96, kw.pop("steps", 12)
+    cfg.pop("steps", None)
     env = make_env(cfg, n_envs=E, device="cuda:0")
     env.seed(9)
     env.reset()

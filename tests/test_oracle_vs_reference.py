@@ -225,6 +225,8 @@ OSE_VARIANTS = {
                                   planner_reward_type="coin_eq_times_productivity", isoelastic_eta=0.4),
     "single_action_planner_25": dict(n_agents=25, multi_action_mode_planner=False, labor_cost=0.5, labor_exponent=1.5),
     "wealth_redistribution_20": dict(n_agents=20, extra_components=[["WealthRedistribution", {}]]),
+    # tax_model "saez" on the map-less scenario: 12 samples per step, the buffer (500) stays short => random rates
+    "saez_random_rates_12": dict(n_agents=12, tax_kw={"tax_model": "saez", "rate_max": 0.7}),
     "no_first_step_mask": dict(n_agents=30, labor_kw=dict(mask_first_step=False), episode_length=3),
 }
 
@@ -237,10 +239,9 @@ def test_oracle_tracks_live_reference_one_step_economy(variant):
     kw = dict(OSE_VARIANTS[variant])
     labor_kw = kw.pop("labor_kw", {})
     extra = kw.pop("extra_components", [])
+    tax_kw = dict({"bracket_spacing": "us-federal", "period": 1, "tax_model": "model_wrapper"}, **kw.pop("tax_kw", {}))
     cfg = dict(scenario_name="one-step-economy", world_size=[1, 1], episode_length=kw.pop("episode_length", 2),
-               components=[["SimpleLabor", dict(labor_kw)]] + extra +
-                          [["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
-                                                   "tax_model": "model_wrapper"}]], **kw)
+               components=[["SimpleLabor", dict(labor_kw)]] + extra + [["PeriodicBracketTax", tax_kw]], **kw)
     np.random.seed(77)
     ref = _ref_env(cfg)
     cfg["components"][0][1]["skills"] = [float(x) for x in ref.get_component("SimpleLabor").skills]
@@ -270,7 +271,9 @@ def test_oracle_tracks_live_reference_one_step_economy(variant):
     for t in range(9):
         aa = rng.randint(0, 101, size=(n, 1)).astype(np.int32)
         acts = {str(i): int(aa[i, 0]) for i in range(n)}
-        if multi_p:
+        if tax_kw["tax_model"] != "model_wrapper":  # the planner has no actions
+            pa = np.zeros(1, np.int32)
+        elif multi_p:
             pa = rng.randint(0, 22, size=7).astype(np.int32)
             acts["p"] = [int(x) for x in pa]
         else:
