@@ -2127,6 +2127,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (wid == 0) {
     if (c.tid == 0) *R_I32(c, o_timestep) += 1;
     if (c.ev && c.tid == 0) c.srcn[2] = 0;
+    __builtin_amdgcn_s_setprio(3);  // the serial dynamics are the replica's critical path
     if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 1] = wall_clock64();
     if (!(skip & 1)) {
       for (int k = 0; k < P.c.n_components; ++k) {
@@ -2141,6 +2142,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
         if (LOG && P.dev_trace && c.tid == 0 && k < 4) P.dev_trace[12 * blockIdx.x + 2 + k] = wall_clock64();
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     agents_store(c, A);
     if (c.ev && c.tid == 0) c.ev[0] = c.srcn[2];
     if (c.tid == 0) {
@@ -2172,6 +2174,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (NW == 1 || wid == 1) {
     // second wave: resource regeneration (rows back into registers for the twists), then what
     // depends on the map: incremental map observations, action masks
+    if (NW == 2) __builtin_amdgcn_s_setprio(3);  // from here on this wave is the critical one (the first has slack)
     MTL mw{reinterpret_cast<uint32_t*>(c.stage), uni(*R_I32(c, o_mt_pos))};
     mtl_to_regs(mw, m, c.tid);
     if (!(skip & 2)) scenario_step_regen(c, m, /*win0_in_lds=*/true);
@@ -2187,6 +2190,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     }
     if (!(skip & 8)) write_action_masks(c, arena);
     if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
+    if (NW == 2) __builtin_amdgcn_s_setprio(0);
   }
   __syncthreads();
   if (!(skip & 32)) store_record(c, arena, m, wid, NW, /*key_wave=*/NW - 1);
