@@ -2174,7 +2174,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (NW == 1 || wid == 1) {
     // second wave: resource regeneration (rows back into registers for the twists), then what
     // depends on the map: incremental map observations, action masks
-    if (NW == 2) __builtin_amdgcn_s_setprio(3);  // from here on this wave is the critical one (the first has slack)
+    if (NW == 2) __builtin_amdgcn_s_setprio(2);  // from here on this wave is the critical one (the first has slack)
     MTL mw{reinterpret_cast<uint32_t*>(c.stage), uni(*R_I32(c, o_mt_pos))};
     mtl_to_regs(mw, m, c.tid);
     if (!(skip & 2)) scenario_step_regen(c, m, /*win0_in_lds=*/true);
