@@ -14,21 +14,25 @@ import bench  # noqa: E402
 from helpers import make_env  # noqa: E402
 
 E = 4096
-for S in (1, 2, 4):
+for S in (1, 2, 3, 4):
     envs, streams = [], []
     for s in range(S):
-        env = make_env(bench.WORKLOAD, n_envs=E // S, device="cuda:0", env_offset=s * (E // S))
+        env = make_env(bench.WORKLOAD, n_envs=(E // S if S != 3 else [1366, 1365, 1365][s]), device="cuda:0", env_offset=s * 1366)
         env.seed(1)
         env.reset()
         envs.append(env)
         streams.append(torch.cuda.Stream())
     torch.cuda.synchronize()
+    cur = []
+    for env, st in zip(envs, streams):
+        with torch.cuda.stream(st):
+            cur.append([env.backend.sample_random_actions(1234, env.env_offset, slot=0), 0])
 
-    def step_all():
-        for env, st in zip(envs, streams):
+    def step_all():  # one launch per shard and step (aie_step_sample_next), as in bench.py
+        for k, (env, st) in enumerate(zip(envs, streams)):
             with torch.cuda.stream(st):
-                a, p = env.backend.sample_random_actions(1234, env.env_offset)
-                env.backend.step(a, p)
+                (a, p), slot = cur[k]
+                cur[k] = [env.backend.step_sample_next(a, p, 1234, env.env_offset, next_slot=slot ^ 1), slot ^ 1]
 
     for _ in range(200):
         step_all()
