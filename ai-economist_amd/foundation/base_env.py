@@ -97,6 +97,7 @@ class BaseEnvironment:
             obj = ccls(self.n_agents, self._episode_length, inventory_scale=self.inv_scale, **ckw)
             if obj.name in self._components_dict:
                 raise ValueError("component {} listed twice".format(obj.name))
+            obj._env = self  # components whose state lives on the device reach it through their environment
             self._components.append(obj)
             self._components_dict[obj.name] = obj
             self._shorthand_lookup[obj.shorthand] = obj

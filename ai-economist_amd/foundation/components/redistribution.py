@@ -121,16 +121,16 @@ class PeriodicBracketTax(BaseComponent):
         else:
             self._fixed_bracket_rates = None
 
-    # ---- Saez sample buffers (redistribution.py:515-546); `env` = the owning environment ----
-    def reset_saez_buffers(self, env):
+    # ---- Saez sample buffers (redistribution.py:515-546); they live on the device of the owning environment ----
+    def reset_saez_buffers(self, env=None):
         """Empties every replica's sample buffer: random rates again until it refills."""
-        t = env.backend.tensors
+        t = (env or self._env).backend.tensors
         t["saez_buffer_len"].zero_()
         t["saez_reached_min_samples"].zero_()
 
-    def get_local_saez_buffer(self, env):
+    def get_local_saez_buffer(self, env=None):
         """(buffer [E, capacity, 2] of (income, marginal rate) pairs, oldest first; filled lengths [E])."""
-        t = env.backend.tensors
+        t = (env or self._env).backend.tensors
         return t["saez_buffer"], t["saez_buffer_len"]
 
     def set_global_saez_buffer(self, global_saez_buffer):
