@@ -271,7 +271,21 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
 int aie_destroy(aie_env* env);
 const char* aie_last_error(const aie_env* env /* NULL: last create error */);
 
-/* Number of exported tensors and their descriptors (index or name lookup). */
+/* Number of exported tensors and their descriptors (index or name lookup).  Names (aie_num_tensors /
+ * aie_tensor_at enumerate what a configuration has; csrc/aie_layout.h is where they are defined):
+ *   observations  obs_a_world-map, obs_a_world-idx_map, obs_a_flat, obs_a_action_mask, obs_a_time, obs_p_* (flat,
+ *                 action_mask, time, world-map, world-idx_map, agents = the planner's per-agent p{i} fragments)
+ *   outputs       rewards_a [E, n], rewards_p [E], done [E]
+ *   state         cells (+ byte-plane views stone / wood / house_owner / cell_flags), loc_r/c, inv_res, esc_res,
+ *                 inv_coin, esc_coin, labor, build_payment, build_skill, bonus_gather_prob, util, cda_* (books,
+ *                 histograms, price history), tax_* (cycle position, rate indices, last coin / income / marginal
+ *                 rate, total collected; tax_saez_bracket_rates / tax_saez_observed_rates), timestep, completions,
+ *                 mt / mt_pos / mt_has_gauss / mt_gauss (the replica's NumPy-legacy generator), regen_source_count
+ *   episode       metrics_cda_trades, metrics_tax_* (accumulators behind env.metrics)
+ *   Saez          saez_buffer, saez_buffer_len, saez_reached_min_samples, saez_elas, saez_running_avg_tax_rates,
+ *                 saez_next_rates
+ *   dense log     log_event_count [L], log_events [L, cap, AIE_EV_WORDS]
+ *   COVID         susceptible ... economic_index state rows, stringency_history_chunks, model_* constants */
 int aie_num_tensors(const aie_env* env);
 int aie_tensor_at(const aie_env* env, int index, aie_tensor_desc* out);
 int aie_get_tensor(const aie_env* env, const char* name, aie_tensor_desc* out);
