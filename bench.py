@@ -175,8 +175,12 @@ def main():
     T_ep = env.episode_length
     # N > 1: (reward, done) of every step travel to the learner rank, 64 steps per collective, straight from the
     # log the step kernel fills (aie_set_reward_log) -- no per-step launches or collectives beside the step
-    gather = (RewardLogGather(be, steps_per_gather=64, force_collective=args.force_gather)
-              if world > 1 or args.force_gather else None)
+    gather, gather_note = None, None
+    if world > 1 or args.force_gather:
+        try:
+            gather = RewardLogGather(be, steps_per_gather=64, force_collective=args.force_gather)
+        except Exception as exc:  # keep the scaling run alive; the JSON line says what happened
+            gather_note = "reward gather disabled: %r" % (exc,)
     t_in_ep = 0
     # uniform random policy: the actions of step t+1 are drawn inside the launch of step t
     # (aie_step_sample_next: the replica's second wavefront is idle during the serial dynamics),
@@ -185,12 +189,16 @@ def main():
     slot = 0
 
     def one_step():
-        nonlocal t_in_ep, cur, slot
+        nonlocal t_in_ep, cur, slot, gather, gather_note
         cur = be.step_sample_next(cur[0], cur[1], ACTION_SEED, env_offset, next_slot=slot ^ 1)
         slot ^= 1
         t_in_ep += 1
         if gather is not None:
-            gather.after_step()
+            try:
+                gather.after_step()
+            except Exception as exc:
+                gather_note = "reward gather disabled after an error: %r" % (exc,)
+                gather = None
         if t_in_ep == T_ep:  # all replicas are in lock-step: every one is done now
             be.reset(be.tensors["done"])
             t_in_ep = 0
@@ -262,6 +270,8 @@ def main():
             },
             "roofline": roof,
         }
+        if gather_note:
+            out["config"]["exchange_note"] = gather_note
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
