@@ -103,6 +103,7 @@ class BaseEnvironment:
             self._shorthand_lookup[obj.shorthand] = obj
 
         self._completions = 0
+        self._last_ep_metrics = None
         self._backend = None
         self._pending_seed = None if seed is None else int(seed)
         if seed is not None:
@@ -247,6 +248,13 @@ class BaseEnvironment:
             self._pending_seed = int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31 - 1)) + 1
         if force_dense_logging and self._create_dense_log_every is None:
             raise ValueError("force_dense_logging needs an environment created with dense_log_frequency")
+        if self._backend is not None and env_mask is None and bool(self._backend.tensors["done"].all().item()):
+            # the episode that just ended, before its state is replaced (the reference stores the metrics when the
+            # last step of an episode finishes, base_env.py:763-765; a full reset is the batch's episode boundary)
+            try:
+                self._last_ep_metrics = {k: np.array(v, copy=True) for k, v in self.metrics.items()}
+            except Exception:  # metrics are a convenience: never let them stand in the way of a reset
+                self._last_ep_metrics = None
         log_replica_resets = self._create_dense_log_every is not None and (
             env_mask is None or bool(env_mask[0].item()))
         if log_replica_resets:
@@ -339,6 +347,12 @@ class BaseEnvironment:
         t = {k: v.cpu().numpy() for k, v in self.backend.tensors.items()
              if not k.startswith("obs_") and not k.startswith("model_") and k not in ("mt", "cells")}
         return _metrics.env_metrics(self, t)
+
+    @property
+    def previous_episode_metrics(self):
+        """env.metrics as they stood at the end of the last completed episode (captured by the full reset that
+        follows it; None before that and for environments that are only ever reset through a mask)."""
+        return self._last_ep_metrics
 
     def metrics_of(self, e):
         """The reference-shaped metrics dict (scalars) of replica e."""

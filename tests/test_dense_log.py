@@ -138,6 +138,9 @@ def test_dense_log_matches_live_reference(case):
             _, _, done, _ = ref.step(_as_ref_actions(host, a, p))
             host.step({"a": torch.from_numpy(a[None]), "p": torch.from_numpy(p[None])})
         assert done["__all__"] and bool(o.t["done"][0])
+        if ep > 0:  # the full reset at the start of this episode captured the previous episode's metrics
+            assert host.previous_episode_metrics is not None
+        want_metrics = ref.previous_episode_metrics
         if ep % every == 0:
             n_logged += 1
             want = ref.previous_episode_dense_log
@@ -145,6 +148,15 @@ def test_dense_log_matches_live_reference(case):
             assert len(want["states"]) == cfg["episode_length"] + 1
             assert_logs_equal(got, want)
     assert n_logged >= 2
+    host.reset()  # episode boundary: previous_episode_metrics == the reference's, key by key
+    got_metrics = host.previous_episode_metrics
+    assert sorted(got_metrics) == sorted(want_metrics)
+    for k, v in want_metrics.items():
+        g = float(got_metrics[k][0])
+        if v is None or np.isnan(float(v)):
+            assert np.isnan(g), k
+        else:
+            np.testing.assert_allclose(g, float(v), rtol=1e-9, atol=1e-12, err_msg=k)
 
 
 @pytest.mark.gpu
