@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libaie_hip.so")
 SOURCES = ["aie_capi.hip", "aie_kernels.hip", "aie_kernels_ose.hip", "aie_kernels_saez.hip", "aie_kernels_covid.hip",
-           "aie_layout.h"]
+           "aie_layout.h", "aie_glibc_math.h", "aie_glibc_tables.h"]
 
 
 def hipcc_path():

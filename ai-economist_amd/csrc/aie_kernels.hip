@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "aie_layout.h"
+#include "aie_glibc_math.h"
 
 #define AIE_NT 64  // threads per replica (one wavefront)
 #define AIE_DIRTY_CAP 64  // map cells one step may change before the incremental map observations give up (= one lane each)
@@ -1469,7 +1470,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool wi
 __device__ __forceinline__ double energy_weight(const Ctx& c) {  // layout_from_file.py:249-267
   if (c.P.c.energy_warmup_constant <= 0.0) return 1.0;
   const int v = c.P.c.energy_warmup_method == AIE_WARMUP_DECAY ? *R_I32(c, o_completions) : *R_I32(c, o_auto_warmup);
-  return 1.0 - exp(-(double)v / c.P.c.energy_warmup_constant);
+  return 1.0 - aie_exp_glibc(-(double)v / c.P.c.energy_warmup_constant);  // libm's exp, bit for bit (aie_glibc_math.h)
 }
 
 // get_current_optimization_metrics layout_from_file.py:269-318 with
@@ -1490,9 +1491,8 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
     coin[i] = ci;
     double util_c;
     if (eta == 1.0) util_c = log(ci > 1 ? ci : 1);
-    else if (eta == 0.0) util_c = ci - 1;  // x ** 1.0 is exact in NumPy; the device pow() is not (1-2 ulp), and with a
-                                           // linear utility zero-sum transfers must cancel exactly (auto warm-up sign test)
-    else util_c = (pow(ci, 1 - eta) - 1) / (1 - eta);
+    else util_c = (aie_pow_glibc(ci, 1 - eta) - 1) / (1 - eta);  // libm's pow bit for bit: the sign of a ~1e-16 mean reward
+                                                                  // feeds the integer auto_warmup counter (aie_glibc_math.h)
     out[i] = util_c - R_F64(c, o_labor)[i] * lcf;
   }
   AIE_WSYNC();

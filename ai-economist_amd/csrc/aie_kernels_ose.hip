@@ -265,12 +265,10 @@ __device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s) {
     double u;
     if (P.c.ose_agent_reward_type == AIE_AGENT_REW_ISOELASTIC) {
       const double eta = P.c.isoelastic_eta;
-      const double uc = (eta == 1.0) ? log(coin > 1 ? coin : 1)
-                        : (eta == 0.0) ? coin - 1  // exact, as NumPy's x ** 1.0
-                                       : (pow(coin, 1 - eta) - 1) / (1 - eta);
+      const double uc = (eta == 1.0) ? log(coin > 1 ? coin : 1) : (aie_pow_glibc(coin, 1 - eta) - 1) / (1 - eta);
       u = uc - labor * P.c.ose_labor_cost;
     } else {
-      u = coin - pow(labor, P.c.ose_labor_exponent) * P.c.ose_labor_cost;
+      u = coin - aie_pow_glibc(labor, P.c.ose_labor_exponent) * P.c.ose_labor_cost;
     }
     s.part[i] = u;
   }

@@ -241,7 +241,7 @@ CASES = {
                  energy_cost=0.21, energy_warmup_constant=10000,
                  energy_warmup_method="auto",
                  env_layout_file="quadrant_25x25_20each_30clump.txt"),
-        seed=5, t_steps=150, obs_steps=[0, 1, 100, 101, 150]),
+        seed=5, t_steps=1000, obs_steps=[0, 1, 100, 101, 150, 500, 1000]),  # a whole episode: auto_warmup over 1000 steps
     # dynamic-layout variants: a water cross with openings / randomly drawn resource zones,
     # 2 short episodes each => 2 generated layouts (np.random.shuffle / rand / randn draws)
     "quadrant_dyn15_4ag": dict(

@@ -1,0 +1,164 @@
+"""The HIP path against the oracle AT THE BASELINE SIZES (BASELINE.json configs[1..4]): every replica, every field.
+
+The smaller rollouts of test_gpu_parity.py never fill the chip; here all workgroups of a launch are resident at
+once (C2/C3: 4096 replicas = 16 workgroups per CU, the XCD-aware replica mapping in `replica_of_block`), C5 runs its
+65 536 replicas in several rounds of workgroups and C4 its 8192.  Integer state, order books and the MT19937 keys are
+compared bit for bit, floats within the tolerances of test_gpu_parity.py / test_covid_golden.py."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_env
+from test_gpu_parity import C2, _compare_all
+
+pytestmark = pytest.mark.gpu
+
+NTHREADS = max(1, min(32, len(os.sched_getaffinity(0))))
+
+
+def _chunks(E, size):
+    return [slice(lo, min(E, lo + size)) for lo in range(0, E, size)]
+
+
+@pytest.mark.parametrize("n_agents", [4, 10])
+def test_c2_c3_full_batch_matches_oracle(n_agents):
+    """BASELINE configs[1] (4 agents) and one GPU's share of configs[2] (10 agents): 4096 replicas of the
+    benchmark workload itself, 130 steps = across the first tax day (period 100), the first order expiries
+    (order_duration 50) and with books filling up; every field of every replica every 10 steps."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    E, T = 4096, 130
+    cfg = dict(C2, n_agents=n_agents)
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(1)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(1)
+    oracle.reset()
+    _compare_all(be, oracle, "C2/C3 n=%d reset" % n_agents)
+    trades = 0
+    for t in range(T):
+        a, p = be.sample_random_actions(seed=1234)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=NTHREADS)
+        if (t + 1) % 10 == 0 or t + 1 in (51, 52, 100, 101):
+            _compare_all(be, oracle, "n=%d step %d" % (n_agents, t + 1))
+    trades = int(oracle.t["metrics_cda"].sum()) if "metrics_cda" in oracle.t else 0
+    assert int(oracle.t["tax_cycle_pos"].min()) >= 1 and int(be.tensors["timestep"].min()) == T
+    assert trades > 0 or n_agents == 4  # the sparse quadrant layout trades little with 4 agents
+
+
+def test_c2_dense_full_batch_matches_oracle_with_autowarmup():
+    """4096 replicas of a busier C2 (dense layout, regeneration, energy warm-up "auto"): builds, trades, gathers in
+    every step, an episode boundary with reset, and the integer auto_warmup counter exact in all of them."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    E, T = 4096, 140
+    cfg = dict(C2, episode_length=120, starting_agent_coin=15, resource_regen_prob=0.05,
+               env_layout_file="uniform_25x25_25each_65clump.txt", energy_warmup_constant=50.0,
+               energy_warmup_method="auto", isoelastic_eta=0.23)
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(3)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(3)
+    oracle.reset()
+    for t in range(T):
+        a, p = be.sample_random_actions(seed=77)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=NTHREADS)
+        if (t + 1) % 20 == 0:
+            _compare_all(be, oracle, "dense C2 step %d" % (t + 1))
+        if t + 1 == 120:
+            assert bool(be.tensors["done"].all())
+            env.reset(be.tensors["done"])
+            oracle.reset(oracle.t["done"].copy())
+            _compare_all(be, oracle, "dense C2 episode reset")
+    aw = be.tensors["auto_warmup"].cpu().numpy()
+    assert np.array_equal(aw, oracle.t["auto_warmup"]) and aw.max() > 0
+
+
+def test_c5_full_batch_matches_oracle():
+    """BASELINE configs[4]: one-step-economy, 100 agents, 65 536 replicas, one 2-step episode + reset + one more
+    step, compared in blocks of 4096 replicas (the observation tensors alone are 5.8 GB)."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    E = 65536
+    rs = np.random.RandomState(4)
+    cfg = dict(scenario_name="one-step-economy", n_agents=100, world_size=[1, 1], episode_length=2,
+               components=[["SimpleLabor", {"skills": [float(x) for x in np.sort(1 + rs.rand(100) * 2)]}],
+                           ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+                                                   "tax_model": "model_wrapper"}]])
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(9)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(9)
+    oracle.reset()
+
+    def compare(where):
+        for sl in _chunks(E, 4096):
+            _compare_all(be, oracle, "%s replicas %d.." % (where, sl.start), sl=sl)
+
+    compare("C5 reset")
+    for t in range(3):
+        a, p = be.sample_random_actions(seed=23)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=NTHREADS)
+        compare("C5 step %d" % (t + 1))
+        if t == 1:
+            assert bool(be.tensors["done"].all())
+            env.reset(be.tensors["done"])
+            oracle.reset(oracle.t["done"].copy())
+            compare("C5 episode reset")
+
+
+def test_c4_full_batch_matches_oracle():
+    """BASELINE configs[3]: COVID, 51 states + planner, 8192 replicas, 64 days, every replica its own action
+    stream.  The NumPy oracle materialises the reference's [n, filters, 600] signal tensor per replica, so it runs
+    in cache-sized blocks of 8 replicas on worker subprocesses (tests/covid_pool.py)."""
+    import torch
+    from covid_pool import run_blocks
+    from helpers import load_covid_golden
+    from test_covid_golden import STATE_TOL, hip_env
+
+    E, T, B = 8192, 64, 8
+    cfg = load_covid_golden("c4_covid_51ag")["cfg"]
+    ns = dict(cfg["components"])["FederalGovernmentSubsidy"]["num_subsidy_levels"]
+    env = hip_env(cfg, n_envs=E)
+    env.reset()
+    t = env.tensors
+    rng = np.random.RandomState(8)
+    acts_a = rng.randint(0, 11, size=(T, E, 51)).astype(np.int32)
+    acts_a[rng.rand(T, E, 51) < 0.5] = 0
+    acts_p = rng.randint(0, ns + 1, size=(T, E)).astype(np.int32)
+    check_at = (1, 30, T)
+    want = run_blocks(cfg, acts_a, acts_p, B, check_at, workers=min(16, NTHREADS))
+    for k in range(1, T + 1):
+        env.step({"a": torch.as_tensor(acts_a[k - 1], device="cuda"),
+                  "p": torch.as_tensor(acts_p[k - 1][:, None], device="cuda")})
+        np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), want["rew_a"][k - 1], rtol=0, atol=2e-5,
+                                   err_msg="C4 day %d agent rewards" % k)
+        np.testing.assert_allclose(t["rewards_p"].cpu().numpy(), want["rew_p"][k - 1], rtol=0, atol=2e-5,
+                                   err_msg="C4 day %d planner reward" % k)
+        if k in check_at:
+            st = want["state"][k]
+            for name, tol in STATE_TOL.items():
+                np.testing.assert_allclose(t[name].cpu().numpy().astype(np.float64), st[name], rtol=tol, atol=1e-3,
+                                           err_msg="C4 day %d %s" % (k, name))
+            assert np.array_equal(t["cooldown_until"].cpu().numpy(), st["cooldown_until"]), "day %d" % k
+            assert np.array_equal(t["subsidy_level"].cpu().numpy(), st["subsidy_level"]), "day %d" % k
+            for name, v in want["obs"][k].items():
+                np.testing.assert_allclose(t[name].cpu().numpy().reshape(v.shape), v, rtol=1e-5, atol=1e-6,
+                                           err_msg="C4 day %d %s" % (k, name))
+    assert not bool(t["done"].any()) and int(t["timestep"].min()) == T
