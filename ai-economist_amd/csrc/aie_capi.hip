@@ -401,15 +401,15 @@ int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_of
 }
 
 // Test hook (not part of include/aie.h): evaluates the device build of aie_glibc_math.h on arrays, so that a GPU test
-// can compare it with the host's libm bit for bit.  fn 0: out = pow(x, y); fn 1: out = exp(x).
+// can compare it with the host's libm bit for bit.  fn 0: out = pow(x, y); fn 1: out = exp(x); fn 2: out = log(x).
 __global__ void aie_test_glibc_math_kernel(int fn, const double* __restrict__ x, const double* __restrict__ y,
                                            double* __restrict__ out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  out[i] = fn == 0 ? aie_pow_glibc(x[i], y[i]) : aie_exp_glibc(x[i]);
+  out[i] = fn == 0 ? aie_pow_glibc(x[i], y[i]) : fn == 1 ? aie_exp_glibc(x[i]) : aie_log_glibc(x[i]);
 }
 int aie_test_glibc_math(int fn, const void* d_x, const void* d_y, void* d_out, int64_t n, void* stream) {
-  if (n <= 0 || !d_x || !d_out || (fn == 0 && !d_y) || (fn != 0 && fn != 1)) return AIE_E_INVALID;
+  if (n <= 0 || !d_x || !d_out || (fn == 0 && !d_y) || fn < 0 || fn > 2) return AIE_E_INVALID;
   hipLaunchKernelGGL(aie_test_glibc_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), fn, static_cast<const double*>(d_x),
                      static_cast<const double*>(d_y), static_cast<double*>(d_out), n);

@@ -175,3 +175,76 @@ AIE_GLIBC_FN double aie_pow_glibc(double x, double y) {
   }
   return aie_gl_exp_core(ehi, elo, 1, abstop);
 }
+
+/* log(x) (e_log.c: __log; operation order read off libm-2.35.a:e_log-fma.o). Used by the legacy NumPy
+ * distributions behind the skill draws (legacy_gauss, standard_exponential -> pareto, lognormal:
+ * numpy/random/src/legacy/legacy-distributions.c), whose results become build payments, i.e. coin. */
+AIE_GLIBC_FN double aie_log_glibc(double x) {
+  AIE_GLIBC_NOCONTRACT
+  uint64_t ix = aie_gl_u64(x);
+  if (ix - 0x3fee000000000000ull <= 0x308ffffffffffull) { /* 1 - 2^-4 <= x < 1 + 0x1.09p-4 */
+    if (ix == 0x3ff0000000000000ull) return 0.0;
+    const double B0 = aie_gl_f64(aie_glibc_log_head[7]), B1 = aie_gl_f64(aie_glibc_log_head[8]);
+    const double B2 = aie_gl_f64(aie_glibc_log_head[9]), B3 = aie_gl_f64(aie_glibc_log_head[10]);
+    const double B4 = aie_gl_f64(aie_glibc_log_head[11]), B5 = aie_gl_f64(aie_glibc_log_head[12]);
+    const double B6 = aie_gl_f64(aie_glibc_log_head[13]), B7 = aie_gl_f64(aie_glibc_log_head[14]);
+    const double B8 = aie_gl_f64(aie_glibc_log_head[15]), B9 = aie_gl_f64(aie_glibc_log_head[16]);
+    const double B10 = aie_gl_f64(aie_glibc_log_head[17]);
+    const double r = x - 1.0;
+    double p1 = __builtin_fma(r, B2, B1);
+    double p4 = __builtin_fma(r, B5, B4);
+    const double r2 = r * r;
+    double p7 = __builtin_fma(r, B8, B7);
+    p1 = __builtin_fma(r2, B3, p1);
+    p4 = __builtin_fma(r2, B6, p4);
+    const double r3 = r * r2;
+    p7 = __builtin_fma(r2, B9, p7);
+    p7 = __builtin_fma(r3, B10, p7);
+    double P = __builtin_fma(p7, r3, p4);
+    P = __builtin_fma(P, r3, p1);
+    const double rw = __builtin_fma(r, 0x1p27, r);
+    const double rhi = __builtin_fma(-0x1p27, r, rw);
+    const double rhi2 = rhi * rhi;
+    const double rlo = r - rhi;
+    const double hi = __builtin_fma(rhi2, B0, r);
+    const double d = r - hi;
+    const double s = r + rhi;
+    double lo = __builtin_fma(rhi2, B0, d);
+    const double t = B0 * rlo;
+    lo = __builtin_fma(t, s, lo);
+    const double y = __builtin_fma(P, r3, lo);
+    return hi + y;
+  }
+  const uint32_t top = (uint32_t)(ix >> 48);
+  if (top - 0x0010u >= 0x7ff0u - 0x0010u) {
+    if (ix * 2 == 0) return -aie_gl_f64(0x7ff0000000000000ull);              /* log(0) = -inf */
+    if (ix == 0x7ff0000000000000ull) return x;                                 /* log(inf) */
+    if ((top & 0x8000u) || (top & 0x7ff0u) == 0x7ff0u) return aie_gl_f64(0x7ff8000000000000ull);
+    ix = aie_gl_u64(x * 0x1p52);                                               /* subnormal */
+    ix -= 52ull << 52;
+  }
+  const double Ln2hi = aie_gl_f64(aie_glibc_log_head[0]), Ln2lo = aie_gl_f64(aie_glibc_log_head[1]);
+  const double A0 = aie_gl_f64(aie_glibc_log_head[2]), A1 = aie_gl_f64(aie_glibc_log_head[3]);
+  const double A2 = aie_gl_f64(aie_glibc_log_head[4]), A3 = aie_gl_f64(aie_glibc_log_head[5]);
+  const double A4 = aie_gl_f64(aie_glibc_log_head[6]);
+  const uint64_t tmp = ix - 0x3fe6000000000000ull;
+  const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
+  const int64_t k = (int64_t)tmp >> 52;
+  const uint64_t iz = ix - (tmp & (0xfffull << 52));
+  const double invc = aie_gl_f64(aie_glibc_log_tab[2 * i]), logc = aie_gl_f64(aie_glibc_log_tab[2 * i + 1]);
+  const double z = aie_gl_f64(iz), kd = (double)k;
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double w = __builtin_fma(kd, Ln2hi, logc);
+  const double q12 = __builtin_fma(r, A2, A1);
+  const double hi = r + w;
+  const double r2 = r * r;
+  double lo = w - hi;
+  lo = lo + r;
+  lo = __builtin_fma(kd, Ln2lo, lo);
+  const double r3 = r * r2;
+  double q34 = __builtin_fma(r, A4, A3);
+  lo = __builtin_fma(r2, A0, lo);
+  q34 = __builtin_fma(q34, r2, q12);
+  const double y = __builtin_fma(r3, q34, lo);
+  return y + hi;
+}

@@ -26,6 +26,12 @@
 #include "aie_layout.h"
 #include "aie_glibc_math.h"
 
+// Floating-point contraction is OFF for every kernel of this library: NumPy (and the C oracle) round a product before
+// they add it, and state such as coin, labor and utilities has to come out bit for bit -- the sign of a ~1e-16 reward
+// decides an integer state field (layout_from_file.py:553-557).  Fused multiply-adds appear only where libm itself
+// fuses them (aie_glibc_math.h, written out with __builtin_fma).
+#pragma clang fp contract(off)
+
 #define AIE_NT 64  // threads per replica (one wavefront)
 #define AIE_DIRTY_CAP 64  // map cells one step may change before the incremental map observations give up (= one lane each)
 #define AIE_SRC_CAP 256  // source-block doubles handled by the gather regen (else row regen)
@@ -512,13 +518,13 @@ __device__ __forceinline__ double rng_gauss(const Ctx& c, MT& m) {  // legacy_ga
     x2 = 2.0 * rng_double(m, c.tid) - 1.0;
     r2 = x1 * x1 + x2 * x2;
   } while (r2 >= 1.0 || r2 == 0.0);
-  f = sqrt(-2.0 * log(r2) / r2);
+  f = sqrt(-2.0 * aie_log_glibc(r2) / r2);  // libm's log bit for bit (aie_glibc_math.h); sqrt and / are IEEE-exact
   *g = f * x1;
   *has = 1;
   return f * x2;
 }
-__device__ __forceinline__ double rng_pareto(MT& m, int lane, double a) { return exp(-log(1.0 - rng_double(m, lane)) / a) - 1.0; }
-__device__ __forceinline__ double rng_lognormal(const Ctx& c, MT& m, double mean, double sigma) { return exp(mean + sigma * rng_gauss(c, m)); }
+__device__ __forceinline__ double rng_pareto(MT& m, int lane, double a) { return aie_exp_glibc(-aie_log_glibc(1.0 - rng_double(m, lane)) / a) - 1.0; }
+__device__ __forceinline__ double rng_lognormal(const Ctx& c, MT& m, double mean, double sigma) { return aie_exp_glibc(mean + sigma * rng_gauss(c, m)); }
 
 // ------------------------------------------------------------------------------------
 // World helpers (F/base/world.py)
@@ -1334,7 +1340,7 @@ __device__ __forceinline__ void wealth_component_step(const Ctx& c, Agents& A) {
   if (c.tid < n) A.coin = tot / (double)n - A.esc_coin;
 }
 
-#pragma clang fp contract(fast)
+// (contraction stays off, see the top of the file)
 
 // ------------------------------------------------------------------------------------
 // LayoutFromFile.scenario_step, layout_from_file.py:372-410.
@@ -1490,7 +1496,7 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
     const double ci = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
     coin[i] = ci;
     double util_c;
-    if (eta == 1.0) util_c = log(ci > 1 ? ci : 1);
+    if (eta == 1.0) util_c = aie_log_glibc(ci > 1 ? ci : 1);
     else util_c = (aie_pow_glibc(ci, 1 - eta) - 1) / (1 - eta);  // libm's pow bit for bit: the sign of a ~1e-16 mean reward
                                                                   // feeds the integer auto_warmup counter (aie_glibc_math.h)
     out[i] = util_c - R_F64(c, o_labor)[i] * lcf;

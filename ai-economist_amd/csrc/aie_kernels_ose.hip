@@ -265,7 +265,7 @@ __device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s) {
     double u;
     if (P.c.ose_agent_reward_type == AIE_AGENT_REW_ISOELASTIC) {
       const double eta = P.c.isoelastic_eta;
-      const double uc = (eta == 1.0) ? log(coin > 1 ? coin : 1) : (aie_pow_glibc(coin, 1 - eta) - 1) / (1 - eta);
+      const double uc = (eta == 1.0) ? aie_log_glibc(coin > 1 ? coin : 1) : (aie_pow_glibc(coin, 1 - eta) - 1) / (1 - eta);
       u = uc - labor * P.c.ose_labor_cost;
     } else {
       u = coin - aie_pow_glibc(labor, P.c.ose_labor_exponent) * P.c.ose_labor_cost;

@@ -91,6 +91,9 @@ class RewardLogGather:
         if self.rank == dst and self.collective:
             self.recv = [[torch.empty_like(self.log[: self.K]) for _ in range(self.world)] for _ in range(2)]
         self.received = []
+        self.n_collectives = 0
+        self.bytes_per_collective = int(self.log[: self.K].numel() * self.log.element_size())
+        self.wait_seconds = 0.0  # host time spent waiting for a collective before its log block could be reused
 
     def after_step(self):
         """Call once after every step; returns True when a block was handed to the collective."""
@@ -104,6 +107,7 @@ class RewardLogGather:
             # own stream), and wait() below orders later steps behind it -- the steps in between overlap it
             self.pending[b] = self.dist.gather(view, self.recv[b] if self.rank == self.dst else None,
                                                dst=self.dst, async_op=True)
+            self.n_collectives += 1
         elif self.keep:
             self.received.append(view.clone()[None])
         self.filled = 0
@@ -115,7 +119,11 @@ class RewardLogGather:
         w = self.pending[b]
         if w is None:
             return
+        import time
+
+        t0 = time.perf_counter()
         w.wait()
+        self.wait_seconds += time.perf_counter() - t0
         self.pending[b] = None
         if self.keep and self.rank == self.dst:
             self.received.append(self.torch.stack(self.recv[b]).clone())

@@ -1,83 +1,143 @@
 #!/usr/bin/env python
 """bench.py -- random-policy rollout throughput of the batched Foundation env.step().
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload C2|C3|C4|C5]
 
-Workload (BASELINE.json configs[1], "C2"): layout_from_file/simple_wood_and_stone, 25x25
-quadrant layout, 4 mobile agents + planner, components Build + ContinuousDoubleAuction
-(max_num_orders 5) + Gather + PeriodicBracketTax (model_wrapper, us-federal, period 100),
-starting_agent_coin 10, episode_length 1000, 4096 env replicas PER GPU (weak scaling),
-uniform random actions from a counter RNG keyed (seed, global replica, t, slot).
+Workloads = BASELINE.json configs[1..4]; the default, C2, is the configuration the metric
+is quoted on: layout_from_file/simple_wood_and_stone, 25x25 quadrant layout, 4 mobile agents + planner, Build +
+ContinuousDoubleAuction(max_num_orders 5) + Gather + PeriodicBracketTax (model_wrapper, us-federal, period 100),
+starting_agent_coin 10, episode_length 1000, 4096 replicas PER GPU (weak scaling), uniform random actions from a
+counter RNG keyed (seed, global replica, t, slot).
 
-One "step" = sample actions on device + one env.step() of every replica (+ a batched
-reset whenever an episode ends; with N > 1 also the per-step (reward, done) gather to
-rank 0, the path's only exchange).  Inputs are resident in HBM before the timed region.
+One "step" = one env.step() of every replica of the rank (+ the masked reset launch of the replicas whose episode
+ended, + with N > 1 the (reward, done) gather to rank 0, the path's only exchange).  Inputs are resident in HBM
+before the timed region.  The replicas are DE-PHASED before the timed region: blocks of replicas are reset at
+staggered points of a prologue, so that any window of the rollout -- including a 20-step one -- contains tax days,
+order expiries, mid-episode order books and episode ends in their long-run proportions.
 
-Prints ONE JSON line (rank 0) with the contract fields plus:
-  roofline     dominant kernel (aie_step_kernel): algorithmic bytes per launch / average
-               launch duration measured live with HIP events on the launch stream
-  cpu_baseline the C restatement of the reference step (oracle/, kind "port") timed on
-               this host's cores on a bounded sample of the same workload
+`--gpus N` with N > 1 started as a plain process re-executes itself under torch.distributed.run (one rank per GPU).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      dominant kernel: algorithmic bytes per launch (SURVEY.md 8(d) figure, and the figure recomputed from
+                the final layouts) / average launch duration measured live with HIP events on the launch stream;
+                measured HBM traffic from the committed rocprofv3 PMC summary of the same command
+  cpu_baseline  the UNMODIFIED reference env.step (oracle/_ref, kind "reference") on this host's cores, P pinned
+                processes timed concurrently on a bounded window; `cpu_port` = the C restatement (oracle/) beside it
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
-    if _p not in sys.path:
-        sys.path.insert(0, _p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
-
-WORKLOAD = dict(
-    scenario_name="layout_from_file/simple_wood_and_stone", n_agents=4, world_size=[25, 25],
-    episode_length=1000,
-    components=[["Build", {}], ["ContinuousDoubleAuction", {"max_num_orders": 5}],
-                ["Gather", {}], ["PeriodicBracketTax", {}]],
-    starting_agent_coin=10, env_layout_file="quadrant_25x25_20each_30clump.txt")
-WORKLOAD_NAME = "C2"  # BASELINE.json configs[1]; tools/bench_c3.py reuses this file for configs[2]
-ENVS_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable copy rate
 ACTION_SEED = 1234
 ENV_SEED = 1
+STAGGER_STRIDE = 20  # steps between the prologue's block resets = steps between reset launches in the rollout
+
+GTB = [["Build", {}], ["ContinuousDoubleAuction", {"max_num_orders": 5}], ["Gather", {}], ["PeriodicBracketTax", {}]]
+C2_CFG = dict(scenario_name="layout_from_file/simple_wood_and_stone", n_agents=4, world_size=[25, 25],
+              episode_length=1000, components=GTB, starting_agent_coin=10,
+              env_layout_file="quadrant_25x25_20each_30clump.txt")
 
 
-def algorithmic_bytes_per_env_step(be):
-    """B_alg of SURVEY.md 8(d), recomputed from the final layouts: observation tensors in
-    the reference's own format + state record read+write + actions + rewards/done."""
-    import torch
+def _c5_cfg():
+    import numpy as np
 
-    obs = 0
-    for k, t in be.tensors.items():
-        if k.startswith("obs_"):
-            obs += t[0].numel() * t.element_size()
-    # per-replica record bytes = stride of any record field along the env axis
-    rec = be.descs["cells"][2][0]
+    rs = np.random.RandomState(4)  # SimpleLabor's skills are a construction-time Monte-Carlo draw in the reference
+    return dict(scenario_name="one-step-economy", n_agents=100, world_size=[1, 1], episode_length=2,
+                components=[["SimpleLabor", {"skills": [float(x) for x in np.sort(1 + rs.rand(100) * 2)]}],
+                            ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+                                                    "tax_model": "model_wrapper"}]])
+
+
+def _c4_cfg():
+    # the env block of the reference's training/run_configs/covid_and_economy_environment.yaml:10-39
+    return dict(scenario_name="CovidAndEconomySimulation", collate_agent_step_and_reset_data=True,
+                components=[["ControlUSStateOpenCloseStatus", {"action_cooldown_period": 28}],
+                            ["FederalGovernmentSubsidy", {"num_subsidy_levels": 20, "subsidy_interval": 90,
+                                                          "max_annual_subsidy_per_person": 20000}],
+                            ["VaccinationCampaign", {"daily_vaccines_per_million_people": 3000, "delivery_interval": 1,
+                                                     "vaccine_delivery_start_date": "2021-01-12"}]],
+                economic_reward_crra_eta=2, episode_length=540, flatten_masks=True, flatten_observations=False,
+                health_priority_scaling_agents=0.3, health_priority_scaling_planner=0.45,
+                infection_too_sick_to_work_rate=0.1, multi_action_mode_agents=False, multi_action_mode_planner=False,
+                n_agents=51, path_to_data_and_fitted_params="", pop_between_age_18_65=0.6,
+                risk_free_interest_rate=0.03, world_size=[1, 1], start_date="2020-03-22", use_real_world_data=False,
+                use_real_world_policies=False)
+
+
+# name -> (description, cfg builder, replicas per GPU, SURVEY 8(d) B_alg per unit, units per replica-step,
+#          kernel, counted agents)
+WORKLOADS = {
+    "C2": dict(desc="BASELINE configs[1]: gather-trade-build 25x25 quadrant layout, 4 agents + planner, Build+"
+                    "ContinuousDoubleAuction(max_num_orders=5)+Gather+PeriodicBracketTax, episode_length 1000",
+               cfg=lambda: dict(C2_CFG), envs=4096, survey_bytes=10984.0, kernel="aie_step_kernel"),
+    "C3": dict(desc="BASELINE configs[2], one GPU's share (32768 replicas over 8 GPUs = 4096 each): as C2 with 10 agents",
+               cfg=lambda: dict(C2_CFG, n_agents=10), envs=4096, survey_bytes=7666.0, kernel="aie_step_kernel"),
+    "C4": dict(desc="BASELINE configs[3]: CovidAndEconomySimulation, 51 US-state agents + planner, run config "
+                    "covid_and_economy_environment.yaml, episode_length 540",
+               cfg=_c4_cfg, envs=8192, survey_bytes=1580.0, kernel="aie_covid_step_kernel"),
+    "C5": dict(desc="BASELINE configs[4]: one-step-economy, 100 agents + SimpleLabor + PeriodicBracketTax(period 1), "
+                    "episode_length 2",
+               cfg=_c5_cfg, envs=65536, survey_bytes=987.0, kernel="aie_ose_step_kernel"),
+}
+
+
+def make_env(cfg, n_envs, **extra):
+    from ai_economist_amd import foundation
+
+    kw = dict(cfg)
+    scenario = kw.pop("scenario_name")
+    kw["components"] = [tuple(c) for c in kw["components"]]
+    kw.update(extra)
+    return foundation.make_env_instance(scenario, n_envs=n_envs, **kw)
+
+
+def layout_bytes_per_env_step(be, wl):
+    """B_alg of SURVEY.md 8(d) recomputed from the FINAL layouts: observation tensors in the reference's own
+    format + state record read+write (+ C4: the 601-day stringency window each state streams) + actions +
+    rewards/done."""
+    obs = sum(t[0].numel() * t.element_size() for k, t in be.tensors.items() if k.startswith("obs_"))
     n = be.n
-    act = n * 4 + be._act_p_width() * 4
-    rew = (n + 1) * 4 + 1
-    return dict(obs=obs, state_rw=2 * rec, act=act, rew_done=rew, total=obs + 2 * rec + act + rew)
+    if wl == "C4":
+        L = int(be.cfg.covid.filter_len)
+        state_rw = 2 * (8 + 1) * n * 4 + n
+        b = dict(history_window=(L + 1) * n, state_rw=state_rw, obs=obs, act=(n + 1) * 4, rew_done=(n + 1) * 4 + 1)
+    else:
+        key = "cells" if "cells" in be.descs else "inv_coin"
+        rec = be.descs[key][2][0]  # per-replica record bytes = stride of any record field along the replica axis
+        b = dict(obs=obs, state_rw=2 * rec, act=n * 4 + be._act_p_width() * 4, rew_done=(n + 1) * 4 + 1)
+    b["total"] = sum(b.values())
+    return b
 
 
-def measured_traffic(envs_per_gpu):
-    """HBM bytes per aie_step_kernel launch from the committed rocprofv3 PMC summary
-    (profiles/*_pmc.json, made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE
-    passes of this same command).  Only valid for the default batch size."""
+def measured_traffic(wl, envs_per_gpu):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary for this workload
+    (profiles/*<wl>*pmc.json, made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same
+    command).  Counters cannot be collected from inside the run; only valid for the default batch size."""
     import glob
-
     import re
 
-    def version(path):  # r01_v10_pmc.json after r01_v9_pmc.json
+    def version(path):
         return [int(x) for x in re.findall(r"\d+", os.path.basename(path))]
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=version)
-    if not files or envs_per_gpu != ENVS_PER_GPU or WORKLOAD_NAME != "C2":
+    tag = wl.lower()
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")) if ("_%s_" % tag) in os.path.basename(f)]
+    if wl == "C2":
+        files += [f for f in glob.glob(os.path.join(ROOT, "profiles", "r01_v*_pmc.json"))]
+    files = sorted(files, key=version)
+    if not files or envs_per_gpu != WORKLOADS[wl]["envs"]:
         return None, None
     d = json.load(open(files[-1]))
-    return d["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
 def usable_cores():
@@ -94,17 +154,64 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(seconds_target=12.0):
-    """Times the CPU restatement (oracle/aie_oracle.c, OpenMP over replicas) on a bounded
-    sample of the same workload.  The thread count that gives the best throughput among
-    {1, 8, 32, all usable cores} is reported together with its core count."""
+def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64):
+    """The reference's own env.step (oracle/_ref or the live tree, through oracle/ref_harness.py): P = usable cores
+    processes, one environment each, pinned, stepped concurrently with uniform random actions."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_harness
+
+    if not ref_harness.reference_available():
+        return None
+    cfg = json.loads(json.dumps(cfg))
+    for comp in cfg["components"]:  # `skills=` is an extension of the host mirror (the reference estimates them itself)
+        comp[1].pop("skills", None)
+    ncores = usable_cores()
+    P = max(1, min(ncores, max_procs))
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = list(range(P))
+    start = time.time() + 6.0 + 0.05 * P
+    procs = []
+    for k in range(P):
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_worker.py"), "--cfg-json", json.dumps(cfg),
+               "--core", str(cores[k % len(cores)]), "--start", repr(start), "--seconds", repr(seconds),
+               "--seed", str(1 + k)]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                      env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")))
+    rate, steps, late, n_agents, ok = 0.0, 0, 0, None, 0
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=seconds + 120)
+            d = json.loads(out.strip().splitlines()[-1])
+        except Exception:
+            pr.kill()
+            continue
+        ok += 1
+        n_agents = d["n_agents"]
+        rate += d["steps"] * d["n_agents"] / d["elapsed"]
+        steps += d["steps"]
+        late += int(d["late"])
+    if not ok:
+        return None
+    return dict(value=rate, unit="agent-steps/s", cores=ok, kind="reference", per_core=rate / ok,
+                sample="%d pinned processes x one environment each, the unmodified reference env.step "
+                       "(base_env.py:929-1032, %s) stepped concurrently for %.0f s with uniform random actions: "
+                       "%d steps in total (%d agents each); host reports %d usable cores%s"
+                       % (ok, "byte-compiled into oracle/_ref" if not ref_harness.reference_is_live_tree()
+                          else "live tree", seconds, steps, n_agents, ncores,
+                          ", %d workers started late" % late if late else ""))
+
+
+def cpu_port_baseline(cfg, seconds_target=4.0):
+    """The C restatement (oracle/aie_oracle.c, OpenMP over replicas) on a bounded sample: a second, labelled figure."""
     import numpy as np
 
-    from helpers import make_env
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle_lib import OracleEnv
 
     E = 1024
-    env = make_env(WORKLOAD, n_envs=E)
+    env = make_env(cfg, n_envs=E)
     o = OracleEnv(env.build_config(), env.layout_planes())
     o.seed(ENV_SEED)
     o.reset()
@@ -112,30 +219,100 @@ def cpu_baseline(seconds_target=12.0):
     n = env.n_agents
     acts = rng.randint(0, 50, size=(20, E, n)).astype(np.int32)
     acts_p = rng.randint(0, 22, size=(20, E, 7)).astype(np.int32)
-    ncores = usable_cores()
-    cands = sorted({c for c in (1, 8, 32, ncores) if c <= ncores})
-    best = None
-    per = seconds_target / len(cands)
-    for th in cands:
-        for t in range(2):
+    th = usable_cores()
+    for t in range(2):
+        o.step(acts[t], acts_p[t], nthreads=th)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds_target:
+        for t in range(20):
             o.step(acts[t], acts_p[t], nthreads=th)
-        steps = 0
-        t0 = time.perf_counter()
-        while True:
-            for t in range(20):
-                o.step(acts[t], acts_p[t], nthreads=th)
-            steps += 20
-            if time.perf_counter() - t0 > per:
-                break
-        dt = time.perf_counter() - t0
-        rate = E * n * steps / dt
-        if best is None or rate > best[0]:
-            best = (rate, th, steps, dt)
-    rate, th, steps, dt = best
-    return dict(value=rate, unit="agent-steps/s", cores=th, kind="port",
-                sample="%d replicas x %d steps of the same C2 workload (%.1f s), C restatement of the reference "
-                       "step, OpenMP over replicas; best of thread counts %s (host reports %d usable cores)"
-                       % (E, steps, dt, cands, ncores))
+        steps += 20
+    dt = time.perf_counter() - t0
+    return dict(value=E * n * steps / dt, unit="agent-steps/s", cores=th, kind="port",
+                sample="%d replicas x %d steps (%.1f s), C restatement of the reference step (oracle/aie_oracle.c), "
+                       "OpenMP over replicas" % (E, steps, dt))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) as a plain process: re-execute under torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class Rollout:
+    """The timed loop of one rank: one launch per step, de-phased replicas, masked resets on a host-known
+    schedule (block g of the replicas, g = e mod G, ends its episode at steps = offset_g mod episode_length)."""
+
+    def __init__(self, wl, env, rank_offset, stagger=True):
+        import torch
+
+        self.torch = torch
+        self.wl, self.env, self.be = wl, env, env.backend
+        self.off = rank_offset
+        self.T = int(env.episode_length)
+        self.E = self.be.E
+        self.t = 0  # rollout steps since the common reset
+        self.fused = hasattr(self.be, "step_sample_next") and wl in ("C2", "C3")
+        stride = STAGGER_STRIDE if (stagger and self.T > 2 * STAGGER_STRIDE) else 0
+        self.G = (self.T // stride) if stride else 1
+        self.stride = stride
+        e = torch.arange(self.E, device=self.be.device)
+        self.group_masks = [((e % self.G) == g).to(torch.uint8) for g in range(self.G)] if self.G > 1 else None
+        self.reset_events = []
+        self.cur = self.be.sample_random_actions(ACTION_SEED, self.off, slot=0)
+        self.slot = 0
+
+    def prologue(self):
+        """De-phasing (outside the timed region): one episode length of steps; block g is reset after g * stride of
+        them, so afterwards block g sits at timestep T - g * stride ... and the blocks' episodes end `stride` apart."""
+        if self.G == 1:
+            return 0
+        for s in range(self.T):
+            if s % self.stride == 0 and 0 < s // self.stride < self.G:
+                self.be.reset(self.group_masks[s // self.stride])
+            self._launch()
+        self.t = 0
+        # block 0 was never re-reset: its episode (T steps) ended exactly now
+        self.be.reset(self.group_masks[0])
+        return self.T
+
+    def _launch(self):
+        be = self.be
+        if self.fused:
+            self.cur = be.step_sample_next(self.cur[0], self.cur[1], ACTION_SEED, self.off, next_slot=self.slot ^ 1)
+            self.slot ^= 1
+        else:
+            a, p = be.sample_random_actions(ACTION_SEED, self.off)
+            be.step(a, p)
+
+    def step(self, timed=False):
+        self._launch()
+        self.t += 1
+        if self.G == 1:
+            if self.t % self.T == 0:
+                self._reset(self.be.tensors["done"], timed)
+        elif self.t % self.stride == 0:
+            # block g sits at timestep T - g * stride (mod T) at t = 0, so its episode ends at t = g * stride (mod T)
+            g = (self.t % self.T) // self.stride
+            if g < self.G:
+                self._reset(self.group_masks[g], timed)
+
+    def _reset(self, mask, timed):
+        if timed:
+            ev = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            self.be.reset(mask)
+            ev[1].record()
+            self.reset_events.append(ev)
+        else:
+            self.be.reset(mask)
 
 
 def main():
@@ -143,137 +320,168 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="C2")
+    ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stagger", action="store_true", help="keep all replicas in lock-step (round-1 behaviour)")
     ap.add_argument("--force-gather", action="store_true",
-                    help="development: run the N > 1 reward-log gather in a 1-rank group (under torch.distributed.run)")
+                    help="run the N > 1 reward-log gather in a 1-rank group (exercises the RCCL path on one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
 
     from ai_economist_amd.sharding import RewardLogGather, dist_info
-    from helpers import make_env
+
+    dev_env = sorted(k for k in os.environ if k.startswith("AIE_DEV_"))
+    if dev_env:
+        sys.exit("bench.py refuses to run with development switches set: %s" % dev_env)
 
     rank, local_rank, world = dist_info()
     if args.gpus > 1 or world > 1 or args.force_gather:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        os.environ.setdefault("MASTER_PORT", "29513")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        assert world == max(1, args.gpus), "world size %d != --gpus %d" % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    E = args.envs_per_gpu
+    wl = args.workload
+    W = WORKLOADS[wl]
+    cfg = W["cfg"]()
+    E = args.envs_per_gpu or W["envs"]
     env_offset = rank * E
-    env = make_env(WORKLOAD, n_envs=E, device=device, env_offset=env_offset)
+    env = make_env(cfg, n_envs=E, device=device, env_offset=env_offset)
     env.seed(ENV_SEED)
     env.reset()
     be = env.backend
     n = env.n_agents
-    T_ep = env.episode_length
-    # N > 1: (reward, done) of every step travel to the learner rank, 64 steps per collective, straight from the
-    # log the step kernel fills (aie_set_reward_log) -- no per-step launches or collectives beside the step
-    gather, gather_note = None, None
-    if world > 1 or args.force_gather:
-        try:
-            gather = RewardLogGather(be, steps_per_gather=64, force_collective=args.force_gather)
-        except Exception as exc:  # keep the scaling run alive; the JSON line says what happened
-            gather_note = "reward gather disabled: %r" % (exc,)
-    t_in_ep = 0
-    # uniform random policy: the actions of step t+1 are drawn inside the launch of step t
-    # (aie_step_sample_next: the replica's second wavefront is idle during the serial dynamics),
-    # so a rollout step is ONE launch; the first draw is a launch of its own.
-    cur = be.sample_random_actions(ACTION_SEED, env_offset, slot=0)
-    slot = 0
+    roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger)
+    prologue_steps = roll.prologue()
 
-    def one_step():
-        nonlocal t_in_ep, cur, slot, gather, gather_note
-        cur = be.step_sample_next(cur[0], cur[1], ACTION_SEED, env_offset, next_slot=slot ^ 1)
-        slot ^= 1
-        t_in_ep += 1
-        if gather is not None:
-            try:
-                gather.after_step()
-            except Exception as exc:
-                gather_note = "reward gather disabled after an error: %r" % (exc,)
-                gather = None
-        if t_in_ep == T_ep:  # all replicas are in lock-step: every one is done now
-            be.reset(be.tensors["done"])
-            t_in_ep = 0
+    # N > 1: (reward, done) of every step travel to the learner rank, 64 steps per collective, straight from the
+    # log the step kernel fills (aie_set_reward_log) -- no per-step launches or collectives beside the step.
+    # A failure here fails the run: the scaling line must not silently drop the exchange.
+    gather = None
+    if world > 1 or args.force_gather:
+        gather = RewardLogGather(be, steps_per_gather=64, force_collective=args.force_gather)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
-        one_step()
+        roll.step()
+        if gather is not None:
+            gather.after_step()
     torch.cuda.synchronize()
     barrier()
-    # one pair of HIP events on the launch stream around the whole timed region: K back-to-back
-    # aie_step_kernel launches (one per step, see aie_step_sample_next) -> average launch period.
-    # (Bracketing every single launch with its own event pair adds ~4 us of queue packets per step.)
+    # one pair of HIP events on the launch stream around the whole timed region (K back-to-back step launches)
+    # plus one pair around each of the (rare) reset launches inside it: average step-kernel launch period =
+    # (region - resets) / K.  Bracketing every step launch would add ~4 us of queue packets per step.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
-        one_step()
+        roll.step(timed=True)
+        if gather is not None:
+            gather.after_step()
     ev1.record()
+    t_issue = time.perf_counter() - t0
     if gather is not None:
         gather.finish()
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    per_rank = [elapsed_local]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # ---- roofline of the dominant kernel ----
-    roof = None
-    if rank == 0:
-        avg_ms = ev0.elapsed_time(ev1) / args.steps
-        b = algorithmic_bytes_per_env_step(be)
-        bytes_per_launch = b["total"] * E
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(E)
-        roof = dict(bound="hbm", kernel="aie_step_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=bytes_per_launch,
-                    algorithmic_bytes_per_agent_step=b["total"] / n, bytes_breakdown_per_env_step=b,
-                    avg_launch_ms=avg_ms, launches_timed=args.steps,
-                    note="achieved = bytes of the reference-format observations + state a step produces / consumes "
-                         "(algorithmic) per launch time; the kernel keeps the map observations in place and rewrites "
-                         "only what a step changes, so the measured HBM traffic is lower than the algorithmic bytes")
+        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        torch.distributed.all_gather(allt, tt)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = max(per_rank)
 
     if rank == 0:
+        region_ms = ev0.elapsed_time(ev1)
+        reset_ms = sum(a.elapsed_time(b) for a, b in roll.reset_events)
+        avg_ms = (region_ms - reset_ms) / args.steps
+        lay = layout_bytes_per_env_step(be, wl)
+        units = (n + 1) if wl == "C4" else n  # C4's per-unit figure counts the planner
+        survey_per_launch = W["survey_bytes"] * units * E
+        layout_per_launch = lay["total"] * E
+        achieved = survey_per_launch / (avg_ms * 1e-3) / 1e9
+        achieved_layout = layout_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(wl, E)
+        roof = dict(
+            bound="latency/issue", roof="hbm", kernel=W["kernel"], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+            frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+            hbm_traffic_frac=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            algorithmic_bytes_per_launch=survey_per_launch, algorithmic_bytes_per_unit=W["survey_bytes"],
+            unit_of_work="agent-step incl. planner" if wl == "C4" else "agent-step",
+            achieved_final_layout=achieved_layout, frac_final_layout=achieved_layout / HBM_PEAK_GBS,
+            final_layout_bytes_per_launch=layout_per_launch, final_layout_bytes_per_env_step=lay,
+            avg_launch_ms=avg_ms, launches_timed=args.steps, reset_launches_in_region=len(roll.reset_events),
+            reset_ms_in_region=reset_ms,
+            note="achieved/frac price SURVEY.md 8(d)'s algorithmic bytes per launch against the HBM peak; "
+                 "*_final_layout does the same with the bytes of the layouts actually used (u32 map cells, 2.5 KB "
+                 "MT19937 key per replica); hbm_traffic_frac = measured HBM bytes / time / peak. The kernel is NOT "
+                 "HBM-bound: it is limited by per-wave instruction issue and dependent-chain latency (DESIGN.md 4); "
+                 "the map observations stay in place and only changed cells are rewritten, hence traffic < algorithmic")
         agent_steps = world * E * n * args.steps
-        value = agent_steps / elapsed
         out = {
-            "metric": "agent-steps/sec, gather-trade-build 25x25 %d-agent batched envs" % n,
-            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
+            "metric": "agent-steps/sec, %s" % {"C2": "gather-trade-build 25x25 4-agent batched envs",
+                                                "C3": "gather-trade-build 25x25 10-agent batched envs",
+                                                "C4": "covid19_env 51 US-state agents + planner",
+                                                "C5": "one_step_economy 100 agents + SimpleLabor + planner tax"}[wl],
+            "value": agent_steps / elapsed, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/i32 state + f64 coin/utility (f32 observations)", "data": "synthetic",
+            "dtype": {"C4": "f32 state, f64 filter bank (f32 observations)"}.get(
+                wl, "u8/i32 state + f64 coin/utility (f32 observations)"),
+            "data": "synthetic",
             "config": {
-                "workload": WORKLOAD_NAME + ": layout_from_file/simple_wood_and_stone 25x25 quadrant layout, %d agents + planner, " % n +
-                            "Build+ContinuousDoubleAuction(max_num_orders=5)+Gather+PeriodicBracketTax, "
-                            "episode_length 1000, uniform random policy, mobile agents counted (planner excluded)",
+                "workload": "%s: %s; uniform random policy; mobile agents counted (planner excluded)" % (wl, W["desc"]),
                 "envs_per_gpu": E, "global_envs": world * E, "n_agents": n,
                 "rng": "per-replica NumPy-legacy MT19937 (parity mode)",
-                "policy": "uniform random (counter RNG); the draw for step t+1 happens inside the launch of step t "
-                          "(aie_step_sample_next), one launch per step",
-                "parallelism": "replica sharding, %d rank(s); (reward, done) of every step gathered to rank 0 over RCCL, "
-                               "64 steps per collective, overlapped with the steps" % world
+                "policy": "uniform random (counter RNG)" + ("; the draw for step t+1 happens inside the launch of "
+                                                             "step t (aie_step_sample_next), one launch per step"
+                                                             if roll.fused else ""),
+                "phasing": ("replicas de-phased in %d blocks, episode ends %d steps apart (prologue of %d untimed "
+                            "steps); one masked reset launch per block end inside the timed region"
+                            % (roll.G, roll.stride, prologue_steps)) if roll.G > 1 else
+                           "lock-step replicas, one reset launch per episode end",
+                "parallelism": ("replica sharding, %d ranks; (reward, done) of every step gathered to rank 0 over "
+                                "RCCL, 64 steps per collective, overlapped with the steps" % world)
                 if world > 1 else "single GPU",
+                "dev_switches": [],
             },
+            "per_rank_seconds": per_rank,
+            "host_issue_seconds": t_issue,
+            "exchange_ok": (gather is not None) if (world > 1 or args.force_gather) else None,
             "roofline": roof,
         }
-        if gather_note:
-            out["config"]["exchange_note"] = gather_note
+        if gather is not None:
+            out["gather"] = {"collectives": gather.n_collectives, "bytes_per_collective": gather.bytes_per_collective,
+                             "wait_seconds": gather.wait_seconds}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            ref = None
+            try:
+                ref = cpu_reference_baseline(cfg)
+            except Exception as exc:  # the reference leg must not take the GPU line down
+                out["cpu_baseline_error"] = repr(exc)
+            if wl in ("C2", "C3"):
+                port = cpu_port_baseline(cfg)
+                if ref is not None:
+                    out["cpu_baseline"], out["cpu_port"] = ref, port
+                else:
+                    out["cpu_baseline"] = port
+            elif ref is not None:
+                out["cpu_baseline"] = ref
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

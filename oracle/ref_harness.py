@@ -19,11 +19,20 @@ import types
 
 import numpy as np
 
-REFERENCE_ROOT = os.environ.get("AIE_REFERENCE_ROOT", "/root/reference")
+# The live tree where it exists (build container); otherwise oracle/_ref/: the same package byte-compiled from
+# /root/reference by oracle/make_ref.py (git-ignored, travels to the GPU box with the tree).
+_REF_BUILT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+REFERENCE_ROOT = os.environ.get("AIE_REFERENCE_ROOT") or (
+    "/root/reference" if os.path.isdir("/root/reference/ai_economist/foundation") else _REF_BUILT)
 
 
 def reference_available():
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "ai_economist", "foundation"))
+
+
+def reference_is_live_tree():
+    """False when only the byte-compiled copy (oracle/_ref) is available."""
+    return reference_available() and os.path.abspath(REFERENCE_ROOT) != os.path.abspath(_REF_BUILT)
 
 
 _foundation = None
