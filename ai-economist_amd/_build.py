@@ -22,12 +22,31 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build the gfx950 kernels")
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def have_hipcc():
+    try:
+        hipcc_path()
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(ROOT, "include", "aie.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    except RuntimeError:
+        return False
+
+
+def _source_hash():
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(ROOT, "include", "aie.h")]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def is_stale():
+    """True when the library is missing or was built from other sources: judged by a content hash kept beside the
+    binary (file times do not survive the copy to the GPU box)."""
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".srchash"):
+        return True
+    with open(LIB + ".srchash") as f:
+        return f.read().strip() != _source_hash()
 
 
 def build(force=False, verbose=False):
@@ -39,4 +58,6 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    with open(LIB + ".srchash", "w") as f:
+        f.write(_source_hash() + "\n")
     return LIB

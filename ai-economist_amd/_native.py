@@ -15,5 +15,9 @@ def lib():
             raise RuntimeError(
                 "HIP extension {} is not built; run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (needs hipcc). There is no CPU fallback.".format(_build.LIB))
+        if _build.is_stale() and _build.have_hipcc():
+            # sources newer than the binary: never run an old kernel silently (on a box without hipcc -- the GPU box
+            # receives the prebuilt library -- there is nothing to rebuild with, and file times there are the copy's)
+            _build.build()
         _LIB = _cabi.bind(ctypes.CDLL(_build.LIB))
     return _LIB

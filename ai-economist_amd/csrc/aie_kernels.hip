@@ -414,6 +414,45 @@ __device__ __forceinline__ double np_sum_small(const double* a, int n) {
   return res;
 }
 
+// The same reduction over sequences of up to 1024 elements that are not stored anywhere, evaluated by the whole wave:
+// element idx is a[idx] (mode 0) or |a[idx / n] - a[idx % n]| (mode 1: the flattened n x n matrix
+// np.abs(endowments[:, None] - endowments[None, :]) of social_metrics.get_gini, social_metrics.py:36-41).
+// Lanes 0..7 carry numpy's eight accumulators; blocks above 128 elements split as numpy's recursion does.
+// M = 65536 / n + 1 (exact idx / n for idx < 2259 and n <= 29).  The result is wave-uniform.
+__device__ __forceinline__ double np_seq_elem(const double* a, int n, int mode, uint32_t M, int idx) {
+  if (mode == 0) return a[idx];
+  const int r = (int)(((uint32_t)idx * M) >> 16);
+  return fabs(a[r] - a[idx - r * n]);
+}
+__device__ __attribute__((noinline)) double np_sum_leaf(const double* a, int n, int mode, uint32_t M, int o, int m,
+                                                        int lane) {
+  if (m < 8) {
+    double res = -0.0;
+    for (int i = 0; i < m; ++i) res += np_seq_elem(a, n, mode, M, o + i);
+    return res;
+  }
+  const int k = lane & 7, body = m - (m % 8);
+  double r = np_seq_elem(a, n, mode, M, o + k);
+  for (int i = 8; i < body; i += 8) r += np_seq_elem(a, n, mode, M, o + i + k);
+  const double r0 = bcast(r, 0), r1 = bcast(r, 1), r2 = bcast(r, 2), r3 = bcast(r, 3);
+  const double r4 = bcast(r, 4), r5 = bcast(r, 5), r6 = bcast(r, 6), r7 = bcast(r, 7);
+  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (int i = body; i < m; ++i) res += np_seq_elem(a, n, mode, M, o + i);
+  return res;
+}
+template <int D>
+__device__ __forceinline__ double np_sum_seq(const double* a, int n, int mode, uint32_t M, int o, int m, int lane) {
+  if constexpr (D == 0) {
+    return np_sum_leaf(a, n, mode, M, o, m, lane);
+  } else {
+    if (m <= 128) return np_sum_leaf(a, n, mode, M, o, m, lane);
+    int n2 = m / 2;
+    n2 -= n2 % 8;
+    const double lo = np_sum_seq<D - 1>(a, n, mode, M, o, n2, lane);
+    return lo + np_sum_seq<D - 1>(a, n, mode, M, o + n2, m - n2, lane);
+  }
+}
+
 __device__ __forceinline__ double rng_double(MT& m, int lane) {
   const uint32_t a = rng_u32(m, lane);
   const uint32_t b = rng_u32(m, lane);
@@ -1503,51 +1542,44 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
   }
   AIE_WSYNC();
   const int prt = c.P.c.planner_reward_type;
+  // every sum below follows NumPy's pairwise add.reduce order (np_sum_small / np_sum_seq): the planner's utility is
+  // state (`util`), compared with the reference bit for bit
   if (prt == AIE_PLANNER_REW_COIN_EQ_TIMES_PROD) {
+    double gini;
+    const double tot = np_sum_small(coin, n);
     if (n < 30) {
-      if (i < n) {
-        double s = 0, ci = coin[i];
-        for (int j = 0; j < n; ++j) s += fabs(ci - coin[j]);
-        tmp[i] = s;
-      }
-    }
-    AIE_WSYNC();
-    if (i == 0) {
-      const double tot = np_sum_small(coin, n);
-      double gini;
-      if (n < 30) {
-        double diff = 0;
-        for (int j = 0; j < n; ++j) diff += tmp[j];
-        const double unscaled = diff / (2 * n * tot + 1e-10);
-        gini = unscaled / ((double)(n - 1) / (double)n);
-      } else {
-        // sorted-cumsum branch (social_metrics.py:43-46)
-        double* s = scr_gini_sort(c);
+      const double diff = np_sum_seq<3>(coin, n, 1, 65536u / (uint32_t)n + 1u, 0, n * n, i);
+      const double unscaled = diff / (2 * n * tot + 1e-10);
+      gini = unscaled / ((double)(n - 1) / (double)n);
+    } else {
+      // sorted-cumsum branch (social_metrics.py:43-46)
+      double* s = scr_gini_sort(c);
+      if (i == 0) {
         for (int j = 0; j < n; ++j) s[j] = coin[j];
         for (int a = 1; a < n; ++a) {
           double x = s[a]; int b = a - 1;
           while (b >= 0 && s[b] > x) { s[b + 1] = s[b]; --b; }
           s[b + 1] = x;
         }
-        const double tots = np_sum_small(s, n);
-        double run = 0, acc = 0;
-        for (int j = 0; j < n; ++j) { run += s[j]; acc += run / (tots + 1e-10); }
-        gini = 1 - (2.0 / (n + 1)) * acc;
+        const double tots = np_sum_small(s, n) + 1e-10;
+        double run = 0;
+        for (int j = 0; j < n; ++j) { run += s[j]; s[j] = run / tots; }
       }
+      AIE_WSYNC();
+      gini = 1 - (2.0 / (n + 1)) * np_sum_small(s, n);
+    }
+    if (i == 0) {
       const double ew = 1 - c.P.c.mixing_weight_gini_vs_coin;
       out[n] = (ew * (1 - gini) + (1 - ew)) * (tot / n);
     }
   } else {
-    if (i == 0) {
-      double sw = 0;
-      for (int j = 0; j < n; ++j) sw += 1 / (coin[j] > 1 ? coin[j] : 1);
-      double acc = 0;
-      for (int j = 0; j < n; ++j) {
-        const double w = (1 / (coin[j] > 1 ? coin[j] : 1)) / sw;
-        acc += (prt == AIE_PLANNER_REW_INV_INCOME_COIN ? coin[j] : out[j]) * w;
-      }
-      out[n] = acc;
-    }
+    if (i < n) tmp[i] = 1 / (coin[i] > 1 ? coin[i] : 1);
+    AIE_WSYNC();
+    const double sw = np_sum_small(tmp, n);
+    AIE_WSYNC();
+    if (i < n) tmp[i] = (prt == AIE_PLANNER_REW_INV_INCOME_COIN ? coin[i] : out[i]) * (tmp[i] / sw);
+    AIE_WSYNC();
+    if (i == 0) out[n] = np_sum_small(tmp, n);
   }
 }
 

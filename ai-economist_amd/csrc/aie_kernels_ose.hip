@@ -229,11 +229,8 @@ __device__ __forceinline__ void rank_sort(const double* src, double* dst, int n,
 // sequential (one thread), the 100 divisions by the total and nothing else are spread over the lanes.
 __device__ __forceinline__ double ose_gini(const OseScratch& s, double* cs, int n, int tid) {
   __shared__ double s_tot;
-  if (n < 30) {
-    if (tid != 0) return 0.0;
-    double diff = 0;
-    for (int i = 0; i < n; ++i)
-      for (int j = 0; j < n; ++j) diff += fabs(s.coin[i] - s.coin[j]);
+  if (n < 30) {  // the flattened n x n difference matrix in NumPy's pairwise order (np_sum_seq, whole wave)
+    const double diff = np_sum_seq<3>(s.coin, n, 1, 65536u / (uint32_t)n + 1u, 0, n * n, tid);
     const double unscaled = diff / (2 * n * np_sum_small(s.coin, n) + 1e-10);
     return unscaled / ((double)(n - 1) / (double)n);
   }

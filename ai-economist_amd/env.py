@@ -35,12 +35,14 @@ class DeviceBackend:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
+        if self.device.index is None:  # "cuda": the CURRENT device, which is where torch allocates the arena
+            self.device = torch.device("cuda", torch.cuda.current_device())
         nbytes = self.lib.aie_arena_bytes(C.byref(cfg))
         if nbytes < 0:
             raise self._err(None, nbytes)
         self.arena = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
         h = C.c_void_p()
-        rc = self.lib.aie_create(C.byref(cfg), self.device.index or 0, self.arena.data_ptr(),
+        rc = self.lib.aie_create(C.byref(cfg), self.device.index, self.arena.data_ptr(),
                                  int(nbytes), C.byref(h))
         if rc != 0:
             raise self._err(None, rc)
@@ -59,20 +61,13 @@ class DeviceBackend:
         stone_src, wood_src, water = [np.ascontiguousarray(p, np.uint8) for p in layout_planes]
         self._check(self.lib.aie_set_layout(self.handle, stone_src.ctypes.data,
                                             wood_src.ctypes.data, water.ctypes.data))
-        import os
-
-        if os.environ.get("AIE_DEV_STEP_WAVES"):  # development A/B switch (see csrc/aie_capi.hip)
-            self.lib.aie_dev_set_step_waves.argtypes = [C.c_void_p, C.c_int]
-            self._check(self.lib.aie_dev_set_step_waves(self.handle, int(os.environ["AIE_DEV_STEP_WAVES"])))
-        if os.environ.get("AIE_DEV_SKIP_MASK"):
-            self.lib.aie_dev_set_skip_mask.argtypes = [C.c_void_p, C.c_int]
-            self._check(self.lib.aie_dev_set_skip_mask(self.handle, int(os.environ["AIE_DEV_SKIP_MASK"])))
-        if os.environ.get("AIE_DEV_LDS_PAD"):
-            self.lib.aie_dev_set_lds_pad.argtypes = [C.c_void_p, C.c_int]
-            self._check(self.lib.aie_dev_set_lds_pad(self.handle, int(os.environ["AIE_DEV_LDS_PAD"])))
-        self.act_a_shape = (self.E, self.n) if not cfg.multi_action_mode_agents else None
         self._rand_a = None
         self._rand_p = None
+        # element counts the kernels index (aie_kernels.hip: decode_actions reads aa[(e*n + i) * act_a_width + s] and
+        # ap[e * act_p_width + b]): checked on every call, a wrongly shaped buffer would be read out of bounds
+        wa = 1 if not cfg.multi_action_mode_agents else max(1, self._n_sub_a())
+        self.act_a_numel = self.E * self.n * wa
+        self.act_p_numel = self.E * self._act_p_width_for(cfg)
 
     # ---- plumbing ----
     def _err(self, handle, rc):
@@ -103,12 +98,16 @@ class DeviceBackend:
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
-    def _ptr(self, t, dtype, what):
+    def _ptr(self, t, dtype, what, numel=None):
         torch = _torch()
         if t is None:
             return None
         if not isinstance(t, torch.Tensor):
             t = torch.as_tensor(np.asarray(t), device=self.device)
+        if numel is not None and t.numel() != numel:
+            raise ValueError("%s has %d elements (shape %s), the environment needs %d: actions_a is int32 "
+                             "[n_envs, n_agents(, n_subspaces)], actions_p int32 [n_envs, planner subspaces], env_mask "
+                             "uint8 [n_envs]" % (what, t.numel(), tuple(t.shape), numel))
         if t.device != self.device:
             t = t.to(self.device)
         if t.dtype != dtype:
@@ -129,13 +128,13 @@ class DeviceBackend:
 
     def reset(self, env_mask=None):
         torch = _torch()
-        m = self._ptr(env_mask, torch.uint8, "env_mask")
+        m = self._ptr(env_mask, torch.uint8, "env_mask", self.E)
         self._check(self.lib.aie_reset(self.handle, m, self._stream()))
 
     def step(self, actions_a=None, actions_p=None):
         torch = _torch()
-        a = self._ptr(actions_a, torch.int32, "actions_a")
-        p = self._ptr(actions_p, torch.int32, "actions_p")
+        a = self._ptr(actions_a, torch.int32, "actions_a", self.act_a_numel)
+        p = self._ptr(actions_p, torch.int32, "actions_p", self.act_p_numel)
         self._check(self.lib.aie_step(self.handle, a, p, self._stream()))
 
     def set_reward_log(self, n_slots):
@@ -155,8 +154,8 @@ class DeviceBackend:
         """One launch: step with (actions_a, actions_p) and fill the action buffers of `next_slot`
         with the uniform random policy's next draw (same values as sample_random_actions)."""
         torch = _torch()
-        a = self._ptr(actions_a, torch.int32, "actions_a")
-        p = self._ptr(actions_p, torch.int32, "actions_p")
+        a = self._ptr(actions_a, torch.int32, "actions_a", self.act_a_numel)
+        p = self._ptr(actions_p, torch.int32, "actions_p", self.act_p_numel)
         na, np_ = self._action_buffers(next_slot)
         self._check(self.lib.aie_step_sample_next(
             self.handle, a, p, C.c_uint64(seed), C.c_int64(env_offset),
@@ -198,11 +197,15 @@ class DeviceBackend:
                     _cabi.COMP_SIMPLE_LABOR: 1}.get(c, 0) for c in comps)
 
     def _act_p_width(self):
+        return self._act_p_width_for(self.cfg)
+
+    @staticmethod
+    def _act_p_width_for(cfg):
         has_planner_actions = (
-            _cabi.COMP_TAX in list(self.cfg.components)[: self.cfg.n_components]
-            and self.cfg.tax_model == 0 and not self.cfg.tax_disable)
-        if self.cfg.multi_action_mode_planner and has_planner_actions:
-            return self.cfg.tax_n_brackets
+            _cabi.COMP_TAX in list(cfg.components)[: cfg.n_components]
+            and cfg.tax_model == 0 and not cfg.tax_disable)
+        if cfg.multi_action_mode_planner and has_planner_actions:
+            return cfg.tax_n_brackets
         return 1
 
     def upload(self, name, array):

@@ -61,9 +61,13 @@ class BaseEnvironment:
         self.multi_action_mode_agents = bool(multi_action_mode_agents)
         self.multi_action_mode_planner = bool(multi_action_mode_planner)
         self._allow_observation_scaling = bool(allow_observation_scaling)
-        if (not flatten_observations and not self.supports_unflattened_observations) or not flatten_masks:
-            raise NotImplementedError(
-                "the batched backend always produces flattened observations and masks")
+        if not flatten_masks:
+            raise NotImplementedError("the batched backend always produces flattened masks (the reference's "
+                                      "recommended setting, tests/test_env.py:41-44)")
+        # flatten_observations=False (base_env.py:591-612): the kernels still write the packed `flat` vectors; the
+        # observation dicts then hand out every key as a zero-copy slice of them (foundation/obs_keys.py)
+        self._flatten_observations = bool(flatten_observations)
+        self._flat_key_views = None
         # dense logs (base_env.py:148-163, 273-283): replica `dense_log_replica` of the batch is
         # the one whose episodes are logged; the device records its component events
         self._create_dense_log_every = None
@@ -227,14 +231,41 @@ class BaseEnvironment:
         return self.backend.tensors
 
     def _obs(self):
-        t = self.backend.tensors
-        obs = {"a": {}, "p": {}}
-        for k, v in t.items():
-            if k.startswith("obs_a_"):
-                obs["a"][k[6:]] = v
-            elif k.startswith("obs_p_"):
-                obs["p"][k[6:]] = v
+        obs = self._obs_raw()
+        if not self._flatten_observations and not self.supports_unflattened_observations:
+            obs = self._unflatten(obs)
         return obs
+
+    def _unflatten(self, obs):
+        """The reference's `flatten_observations=False` form: every scalar / vector observation under its own key
+        (views of the packed vectors, no copies); `time` stays, the 2-D+ arrays and `action_mask` are untouched.
+        The planner's per-agent fragments become obs["p"]["agents"][key] = [E, n(, size)]."""
+        if self._flat_key_views is None:
+            from .obs_keys import flat_keys
+
+            self._flat_key_views = flat_keys(self)
+            sizes = self._flat_key_views["sizes"]
+            t = self.backend.tensors
+            assert sizes["a"] == t["obs_a_flat"].shape[-1] and sizes["p"] == t["obs_p_flat"].shape[-1], \
+                "key table does not match the packed vectors"
+            if "obs_p_agents" in t:
+                assert sizes["pa"] == t["obs_p_agents"].shape[-1]
+        tab = self._flat_key_views
+        out = {"a": {}, "p": {}}
+        for who, flat_name in (("a", "flat"), ("p", "flat")):
+            for k, v in obs[who].items():
+                if k not in ("flat", "agents"):
+                    out[who][k] = v
+            flat = obs[who][flat_name]
+            for key, off, size, scalar in tab[who]:
+                if key == "time":
+                    continue
+                out[who][key] = flat[..., off] if scalar else flat[..., off:off + size]
+        if "agents" in obs["p"]:
+            pa = obs["p"]["agents"]
+            out["p"]["agents"] = {key: (pa[..., off] if scalar else pa[..., off:off + size])
+                                  for key, off, size, scalar in tab["pa"]}
+        return out
 
     def reset(self, env_mask=None, force_dense_logging=False):
         """Resets all replicas (or those selected by the uint8/bool device tensor
@@ -315,6 +346,11 @@ class BaseEnvironment:
         a = p = None
         if actions is not None:
             assert isinstance(actions, dict)
+            unknown = [k for k in actions if k not in ("a", "p")]
+            if unknown:
+                # a reference-style {"0": 3, "1": 0, ..., "p": [...]} dict would silently turn into NO-OPs
+                raise ValueError("batched actions are {'a': int32 [n_envs, n_agents(, n_subspaces)], 'p': int32 "
+                                 "[n_envs, planner subspaces]}; unexpected keys %r" % (unknown,))
             a = actions.get("a")
             p = actions.get("p")
         logging = self._dense_log_this_episode and self._dense_logger is not None
@@ -360,9 +396,25 @@ class BaseEnvironment:
 
     def as_reference_dicts(self, e):
         """Rebuilds the reference's per-replica observation dict
-        ({"0": {...}, ..., "p": {..., "p0": ...}}) for replica e as NumPy arrays."""
+        ({"0": {...}, ..., "p": {..., "p0": ...}}) for replica e as NumPy arrays -- with
+        `flatten_observations=False` in the reference's unflattened form (scalars as floats)."""
         t = self.backend.tensors
         out = {}
+        unflat = not self._flatten_observations and not self.supports_unflattened_observations
+        if unflat:
+            obs = self._unflatten(self._obs_raw())
+
+            def val(x):
+                x = x.cpu().numpy()
+                return float(x) if x.ndim == 0 else x
+
+            for i in range(self.n_agents):
+                out[str(i)] = {k: val(v[e, i]) for k, v in obs["a"].items()}
+            d = {k: val(v[e]) for k, v in obs["p"].items() if k != "agents"}
+            for i in range(self.n_agents):
+                d["p%d" % i] = {k: val(v[e, i]) for k, v in obs["p"].get("agents", {}).items()}
+            out["p"] = d
+            return out
         for i in range(self.n_agents):
             d = {}
             for k, v in t.items():
@@ -379,6 +431,16 @@ class BaseEnvironment:
                 d[k[6:]] = v[e].cpu().numpy()
         out["p"] = d
         return out
+
+    def _obs_raw(self):
+        t = self.backend.tensors
+        obs = {"a": {}, "p": {}}
+        for k, v in t.items():
+            if k.startswith("obs_a_"):
+                obs["a"][k[6:]] = v
+            elif k.startswith("obs_p_"):
+                obs["p"][k[6:]] = v
+        return obs
 
 
 scenario_registry = Registry(BaseEnvironment)

@@ -128,6 +128,14 @@ class LayoutFromFile(BaseEnvironment):
     def layout_planes(self):
         return (self._source_maps["Stone"], self._source_maps["Wood"], self._source_maps["Water"])
 
+    def world_flat_keys(self):
+        """The scenario's scalar observations (layout_from_file.py:474-517), see foundation/obs_keys.py."""
+        inv = [("world-inventory-%s" % r, 1, True) for r in ("Coin", "Stone", "Wood")]
+        loc = [("world-loc-col", 1, True), ("world-loc-row", 1, True)]
+        a = inv + ([] if self._full_observability else loc)
+        pa = [] if self._full_observability else inv + (loc if self._planner_gets_spatial_info else [])
+        return a, list(inv), pa
+
     def scenario_metrics(self, tensors):
         from .. import metrics
 

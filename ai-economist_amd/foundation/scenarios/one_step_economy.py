@@ -38,6 +38,10 @@ class OneStepEconomy(BaseEnvironment):
         z = np.zeros(self.world_size, np.uint8)
         return (z, z, z)
 
+    def world_flat_keys(self):
+        """one_step_economy.py:118-183: only the planner has scenario observations."""
+        return [], [("world-equality", 1, True), ("world-normalized_per_capita_productivity", 1, True)], []
+
     def scenario_metrics(self, tensors):
         from .. import metrics
 

@@ -10,9 +10,8 @@ ENV_CONFIG = {
     "episode_length": 1000,
     "multi_action_mode_agents": False,
     "multi_action_mode_planner": True,
-    # the batched backend always flattens observations (flatten_observations=False is the
-    # one setting of the reference's config that it does not offer)
-    "flatten_observations": True,
+    # as in the reference's test: observations with minimal processing (every key on its own)
+    "flatten_observations": False,
     "flatten_masks": True,
     "components": [
         {"Build": {}},
@@ -35,7 +34,7 @@ def test_construction_matches_reference_contract():
     assert [c.name for c in env.components] == ["Build", "ContinuousDoubleAuction", "Gather"]
     assert env.resources == ["Coin", "Stone", "Wood"] and env.landmarks == ["House"]
     with pytest.raises(NotImplementedError):
-        foundation.make_env_instance(**dict(ENV_CONFIG, flatten_observations=False))
+        foundation.make_env_instance(**dict(ENV_CONFIG, flatten_masks=False))
 
 
 @pytest.mark.gpu
@@ -52,8 +51,24 @@ def test_env_reset_and_step():
     # the per-replica view has exactly the reference's keys
     ref_view = env.as_reference_dicts(0)
     assert sorted(ref_view.keys()) == [str(i) for i in range(n)] + ["p"]
-    assert {"world-map", "world-idx_map", "time", "flat", "action_mask"} <= set(ref_view["0"].keys())
+    # flatten_observations=False: every key on its own (base_env.py:591-612), zero-copy slices of the packed vector
+    assert "flat" not in obs["a"] and "flat" not in ref_view["0"]
+    assert {"world-map", "world-idx_map", "time", "action_mask", "world-inventory-Coin", "world-loc-row",
+            "Build-build_payment", "ContinuousDoubleAuction-available_asks-Stone",
+            "Gather-bonus_gather_prob"} <= set(ref_view["0"].keys())
+    assert ref_view["0"]["world-inventory-Coin"] == pytest.approx(10 * 0.01)
+    assert ref_view["0"]["ContinuousDoubleAuction-available_asks-Stone"].shape == (11,)
     assert {"p0", "p1", "p2", "p3"} <= set(ref_view["p"].keys())
+    assert {"world-inventory-Coin", "world-loc-col"} <= set(ref_view["p"]["p2"].keys())
+    flat = env.tensor("obs_a_flat")
+    assert obs["a"]["world-inventory-Coin"].data_ptr() >= flat.data_ptr()  # a view, not a copy
+    assert tuple(obs["a"]["ContinuousDoubleAuction-my_bids-Wood"].shape) == (8, n, 11)
+    # and the flattened form of the same environment
+    env_f = foundation.make_env_instance(n_envs=8, device="cuda:0", **dict(ENV_CONFIG, flatten_observations=True))
+    env_f.seed(3)
+    obs_f = env_f.reset()
+    assert {"world-map", "world-idx_map", "time", "flat", "action_mask"} <= set(obs_f["a"].keys())
+    assert (obs_f["a"]["flat"] == flat).all()
 
     obs, reward, done, info = env.step({})  # no actions == all NO-OP (base_env.py:964-966)
     assert obs.keys() == reward.keys()

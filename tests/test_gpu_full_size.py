@@ -39,7 +39,6 @@ def test_c2_c3_full_batch_matches_oracle(n_agents):
     oracle.seed(1)
     oracle.reset()
     _compare_all(be, oracle, "C2/C3 n=%d reset" % n_agents)
-    trades = 0
     for t in range(T):
         a, p = be.sample_random_actions(seed=1234)
         env.step({"a": a, "p": p})
@@ -47,9 +46,9 @@ def test_c2_c3_full_batch_matches_oracle(n_agents):
         oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=NTHREADS)
         if (t + 1) % 10 == 0 or t + 1 in (51, 52, 100, 101):
             _compare_all(be, oracle, "n=%d step %d" % (n_agents, t + 1))
-    trades = int(oracle.t["metrics_cda"].sum()) if "metrics_cda" in oracle.t else 0
-    assert int(oracle.t["tax_cycle_pos"].min()) >= 1 and int(be.tensors["timestep"].min()) == T
-    assert trades > 0 or n_agents == 4  # the sparse quadrant layout trades little with 4 agents
+    trades = int(oracle.t["metrics_cda_trades"][..., 0].sum())
+    assert int(oracle.t["metrics_tax_days"].min()) == 1 and int(be.tensors["timestep"].min()) == T
+    assert trades > 0, "no trade in 4096 replicas x %d steps?" % T
 
 
 def test_c2_dense_full_batch_matches_oracle_with_autowarmup():

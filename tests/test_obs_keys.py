@@ -1,0 +1,66 @@
+"""foundation/obs_keys.py (which slice of the packed `flat` vector is which observation key) pinned against the live
+reference: the reference environment is built with flatten_observations=False, its per-key observations are put
+side by side with the slices the key table cuts out of the reference's own flattened vector (base_env.py:561-612),
+for agents, the planner and the planner's per-agent fragments."""
+import numpy as np
+import pytest
+
+from helpers import make_env
+from test_oracle_vs_reference import BASE, GTB, VARIANTS
+
+pytestmark = pytest.mark.reference
+
+CASES = {k: VARIANTS[k] for k in ("multi_action_agents", "full_observability", "full_observability_no_tax_planner_blind",
+                                   "no_cda_obs_range3", "log_brackets_wrapper", "six_agents_40x40",
+                                   "wealth_redistribution_then_tax")}
+CASES["c2_default"] = dict(components=GTB)
+CASES["planner_blind"] = dict(components=GTB, planner_gets_spatial_info=False)
+OSE = dict(scenario_name="one-step-economy", n_agents=7, world_size=[1, 1], episode_length=2,
+           components=[["SimpleLabor", {}], ["PeriodicBracketTax", {"period": 1, "bracket_spacing": "us-federal"}]])
+
+
+def _ref(cfg, flatten):
+    from ref_harness import load_reference_foundation
+
+    kw = dict(cfg, flatten_observations=flatten, flatten_masks=True)
+    scenario = kw.pop("scenario_name")
+    kw["components"] = [tuple(c) for c in kw["components"]]
+    np.random.seed(5)
+    env = load_reference_foundation().make_env_instance(scenario, **kw)
+    env.seed(3)
+    obs = env.reset()
+    for t in range(3):
+        obs, _, _, _ = env.step({})
+    return env, obs
+
+
+def _check(table, raw, flat, where):
+    """raw: the reference's per-key dict; flat: its packed vector; table: our [(key, offset, size, scalar)]."""
+    packable = {k: v for k, v in raw.items() if k != "action_mask" and not isinstance(v, dict) and np.ndim(v) < 2}
+    assert sorted(packable) == [k for k, _, _, _ in table], "%s: key set / order" % where
+    total = 0
+    for key, off, size, scalar in table:
+        v = np.asarray(packable[key], np.float32).reshape(-1)
+        assert v.size == size, "%s: size of %s" % (where, key)
+        assert scalar == (np.ndim(packable[key]) == 0), "%s: %s scalar?" % (where, key)
+        assert off == total
+        np.testing.assert_array_equal(flat[off:off + size], v, err_msg="%s: slice of %s" % (where, key))
+        total += size
+    assert total == flat.size, "%s: packed length" % where
+
+
+@pytest.mark.parametrize("case", sorted(CASES) + ["one_step_economy"])
+def test_key_tables_match_reference(case):
+    from ai_economist_amd.foundation.obs_keys import flat_keys
+
+    cfg = dict(OSE) if case == "one_step_economy" else dict(BASE, **CASES[case])
+    _, raw = _ref(cfg, flatten=False)
+    _, packed = _ref(cfg, flatten=True)
+    env = make_env(dict(cfg, flatten_observations=False), n_envs=1)
+    tab = flat_keys(env)
+    _check(tab["a"], raw["0"], np.asarray(packed["0"]["flat"]), case + " agent")
+    _check(tab["p"], raw["p"], np.asarray(packed["p"]["flat"]), case + " planner")
+    if tab["pa"]:
+        _check(tab["pa"], raw["p"]["p1"], np.asarray(packed["p"]["p1"]), case + " planner p1")
+    else:
+        assert "p1" not in raw["p"]
