@@ -43,7 +43,9 @@ namespace aie {
 // (2.7 KB) to scratch memory on every launch -- measured 5x slower.
 
 struct Ctx {
-  const aie_params& P;
+  const aie_params& P;  // everything a kernel needs; in the compile-time instances of the step kernel (aie_spec_generated.h)
+                        // a CONSTANT image of the block, so that dims, offsets and component lists fold into the code
+  const aie_params& R;  // the run-time block in device memory: what depends on the batch (E, arena offsets a_*)
   uint8_t* rec;      // LDS copy of the record (everything before the MT19937 key)
   int32_t* act_p;    // LDS [AIE_MAX_BRACKETS] decoded planner actions
   uint8_t* locmap;   // LDS [HW] 0 = empty, i+1 = agent i
@@ -108,8 +110,8 @@ __host__ __device__ inline size_t lds_bytes(const aie_params& P) {
   return (b + 15) / 16 * 16;
 }
 
-__device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e, int tid, uint8_t* arena = nullptr,
-                                        bool with_events = true) {
+__device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R, uint8_t* lds, int e, int tid,
+                                        uint8_t* arena = nullptr, bool with_events = true) {
   uint8_t* q = lds + rec_lds_bytes(P);
   int32_t* act_p = reinterpret_cast<int32_t*>(q);
   q += AIE_MAX_BRACKETS * 4;
@@ -127,13 +129,13 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, uint8_t* lds, int e
   int32_t* mflags = reinterpret_cast<int32_t*>(q);
   q += pad4(P.n) * 4;
   int32_t* dirty = reinterpret_cast<int32_t*>(q);
-  uint8_t* met = arena ? arena + P.a_metrics + (int64_t)e * P.met_bytes : nullptr;
+  uint8_t* met = arena ? arena + R.a_metrics + (int64_t)e * P.met_bytes : nullptr;
   // with_events == false is a compile-time constant in the common step kernel: every `if (c.ev)` / `if (c.saez)`
   // folds away (environments with dense-log replicas or tax_model "saez" run aie_step_kernel_log)
   int32_t* ev = (with_events && arena && e < P.ev_replicas)
-                    ? reinterpret_cast<int32_t*>(arena + P.a_events + (int64_t)e * P.ev_stride) : nullptr;
+                    ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * P.ev_stride) : nullptr;
   const bool saez = with_events && P.c.tax_model == AIE_TAX_SAEZ;
-  return Ctx{P, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, met, ev, saez, with_events, tid, e};
+  return Ctx{P, R, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, met, ev, saez, with_events, tid, e};
 }
 
 // ------------------------------------------------------------------------------------
@@ -241,7 +243,7 @@ struct MT {
 // `wave` of `nwaves` copies every nwaves-th 16-byte unit; wave 0 also takes the MT19937 key.
 __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m, int wave = 0,
                                             int nwaves = 1, bool key_to_lds = false) {
-  const uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
+  const uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
   const uint4* src = reinterpret_cast<const uint4*>(g);
   uint4* dst = reinterpret_cast<uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
@@ -282,7 +284,7 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
 }
 __device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m, int wave = 0,
                                              int nwaves = 1, int key_wave = 0) {
-  uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
+  uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
   uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
@@ -661,6 +663,7 @@ __device__ __forceinline__ void decode_actions(const Ctx& c, Agents& A, const in
   const aie_params& P = c.P;
   const int i = c.tid;
   uint32_t act = 0;
+  bool bad_a = false, bad_p = false;  // out-of-range indices: NO-OP here, an exception in the reference (AIE_ERR_*)
   if (i < P.n && aa) {
     const int32_t* a = aa + ((int64_t)c.e * P.n + i) * P.act_a_width;
     static const int shift[AIE_N_SUB_SLOTS] = {0, 4, 11, 18, 25, 1, 0};
@@ -668,9 +671,11 @@ __device__ __forceinline__ void decode_actions(const Ctx& c, Agents& A, const in
       for (int s = 0; s < P.n_sub_a; ++s) {
         const int v = a[s];
         if (v >= 0 && v <= P.sub_a_dim[s]) act |= (uint32_t)v << shift[P.sub_a_slot[s]];
+        else bad_a = true;
       }
     } else {
       const int v = a[0];
+      bad_a = v < 0 || v >= P.A;
       for (int s = 0; s < P.n_sub_a; ++s)
         if (v >= P.sub_a_base[s] && v < P.sub_a_base[s] + P.sub_a_dim[s])
           act |= (uint32_t)(v - P.sub_a_base[s] + 1) << shift[P.sub_a_slot[s]];
@@ -681,14 +686,20 @@ __device__ __forceinline__ void decode_actions(const Ctx& c, Agents& A, const in
     int v = 0;
     if (ap && i < P.n_sub_p) {
       const int32_t* a = ap + (int64_t)c.e * P.act_p_width;
-      if (P.c.multi_action_mode_planner) v = a[i];
-      else {
+      if (P.c.multi_action_mode_planner) {
+        v = a[i];
+        bad_p = v < 0 || v > P.sub_p_dim;  // (the tax component ignores what its mask forbids; out of range is an error)
+        if (bad_p) v = 0;
+      } else {
         const int x = a[0];
+        bad_p = x < 0 || x >= 1 + P.n_sub_p * P.sub_p_dim;
         if (x >= 1 && x < 1 + P.n_sub_p * P.sub_p_dim && (x - 1) / P.sub_p_dim == i) v = (x - 1) % P.sub_p_dim + 1;
       }
     }
     c.act_p[i] = v;
   }
+  const int err = (__ballot(bad_a) ? AIE_ERR_AGENT_ACTION : 0) | (__ballot(bad_p) ? AIE_ERR_PLANNER_ACTION : 0);
+  if (err && i == 0) *R_I32(c, o_error_flags) |= err;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1185,7 +1196,7 @@ __device__ __forceinline__ double tax_curr_rate_max(const Ctx& c) {
 }
 // this replica's Saez block (tax_model "saez", aie_layout.h: a_saez); step / reset kernels only (c.met set)
 __device__ __forceinline__ uint8_t* saez_block(const Ctx& c) {
-  return c.met - c.P.a_metrics - (int64_t)c.e * c.P.met_bytes + c.P.a_saez + (int64_t)c.e * c.P.saez_stride;
+  return c.met - c.R.a_metrics - (int64_t)c.e * c.P.met_bytes + c.R.a_saez + (int64_t)c.e * c.P.saez_stride;
 }
 __device__ __forceinline__ double tax_rate(const Ctx& c, int b) {  // curr_marginal_rates :396-417
   if (c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER) return c.P.c.tax_disc_rates[R_I32(c, o_tax_rate_idx)[b]];
@@ -1595,8 +1606,8 @@ __device__ __forceinline__ void compute_rewards(const Ctx& c, uint8_t* __restric
     const double r = cur[i] - util[i];
     util[i] = cur[i];
     rew[i] = r;
-    if (i < n) reinterpret_cast<float*>(arena + c.P.a_rew_a)[(int64_t)c.e * n + i] = (float)r;
-    else reinterpret_cast<float*>(arena + c.P.a_rew_p)[c.e] = (float)r;
+    if (i < n) reinterpret_cast<float*>(arena + c.R.a_rew_a)[(int64_t)c.e * n + i] = (float)r;
+    else reinterpret_cast<float*>(arena + c.R.a_rew_p)[c.e] = (float)r;
     if (rew_log) rew_log[(int64_t)c.e * (n + 2) + i] = (float)r;
   }
   AIE_WSYNC();
@@ -1642,11 +1653,11 @@ __device__ __forceinline__ SpatialOut spatial_out(const Ctx& c, uint8_t* __restr
   const int plane = c.P.am_h * c.P.am_w;
   const uint32_t amap_bytes = (uint32_t)(n * c.P.am_ch * plane * 4), aidx_bytes = (uint32_t)(n * 2 * plane * 2);
   SpatialOut o;
-  o.amap = make_rsrc(arena + c.P.a_obs_a_map + (int64_t)c.e * amap_bytes, amap_bytes);
-  o.aidx = make_rsrc(arena + c.P.a_obs_a_idx + (int64_t)c.e * aidx_bytes, aidx_bytes);
+  o.amap = make_rsrc(arena + c.R.a_obs_a_map + (int64_t)c.e * amap_bytes, amap_bytes);
+  o.aidx = make_rsrc(arena + c.R.a_obs_a_idx + (int64_t)c.e * aidx_bytes, aidx_bytes);
   const bool pl = c.P.c.planner_gets_spatial_info != 0;
-  o.pmap = make_rsrc(arena + c.P.a_obs_p_map + (int64_t)c.e * CM * HW * 4, pl ? (uint32_t)(CM * HW * 4) : 0u);
-  o.pidx = make_rsrc(arena + c.P.a_obs_p_idx + (int64_t)c.e * 2 * HW * 2, pl ? (uint32_t)(2 * HW * 2) : 0u);
+  o.pmap = make_rsrc(arena + c.R.a_obs_p_map + (int64_t)c.e * CM * HW * 4, pl ? (uint32_t)(CM * HW * 4) : 0u);
+  o.pidx = make_rsrc(arena + c.R.a_obs_p_idx + (int64_t)c.e * 2 * HW * 2, pl ? (uint32_t)(2 * HW * 2) : 0u);
   return o;
 }
 
@@ -2322,6 +2333,7 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   rebuild_locmap(c);  // all agents off the board
   // ---- wave-uniform sequential part (every lane performs the same LDS updates) ----
   *R_I32(c, o_timestep) = 0;
+  *R_I32(c, o_error_flags) = 0;
   // layout_from_file.py:360-370 places agents in index order, dynamic_layout.py:420-431
   // (uniform/...) in a random order
   const int place_perm = P.c.reset_random_order ? rng_permutation(m, tid, n) : tid;
@@ -2331,7 +2343,10 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
     while (!can_agent_occupy(c, r, col, i)) {
       r = (int)rng_interval(m, tid, (uint32_t)(P.H - 1));
       col = (int)rng_interval(m, tid, (uint32_t)(P.W - 1));
-      if (++tries > 200) break;  // the reference raises TimeoutError
+      if (++tries > 200) {  // the reference raises TimeoutError (layout_from_file.py:366-368): flagged, see AIE_ERR_*
+        *R_I32(c, o_error_flags) |= AIE_ERR_RESET_PLACEMENT;
+        break;
+      }
     }
     R_I32(c, o_loc_r)[i] = r;
     R_I32(c, o_loc_c)[i] = col;
@@ -2419,7 +2434,10 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
       while (!can_agent_occupy(c, r, col, i)) {
         r = r_min + (int)rng_interval(m, tid, (uint32_t)(r_max - r_min - 1));
         col = (int)rng_interval(m, tid, (uint32_t)(P.W - 1));
-        if (++tries > 200) break;  // the reference raises TimeoutError
+        if (++tries > 200) {  // the reference raises TimeoutError
+          *R_I32(c, o_error_flags) |= AIE_ERR_RESET_PLACEMENT;
+          break;
+        }
       }
       R_I32(c, o_loc_r)[i] = r;
       R_I32(c, o_loc_c)[i] = col;

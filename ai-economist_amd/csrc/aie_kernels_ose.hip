@@ -452,10 +452,12 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   MT m;
   ose_load_record(c, arena, m);
   // parse_actions (base_agent.py:407-438)
+  bool bad_a = false, bad_p = false;  // out-of-range indices: NO-OP here, an exception in the reference (AIE_ERR_*)
   for (int i = tid; i < n; i += OSE_NT) {
     int a = 0;
     if (act_a && P.n_sub_a) {
       const int v = act_a[((int64_t)c.e * n + i) * P.act_a_width];
+      bad_a |= v < 0 || v > P.sub_a_dim[0];
       if (P.c.multi_action_mode_agents) a = (v >= 0 && v <= P.sub_a_dim[0]) ? v : 0;
       else a = (v >= 1 && v < 1 + P.sub_a_dim[0]) ? v : 0;
     }
@@ -465,13 +467,21 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
     int v = 0;
     if (act_p && tid < P.n_sub_p) {
       const int32_t* a = act_p + (int64_t)c.e * P.act_p_width;
-      if (P.c.multi_action_mode_planner) v = a[tid];
-      else {
+      if (P.c.multi_action_mode_planner) {
+        v = a[tid];
+        bad_p = v < 0 || v > P.sub_p_dim;
+        if (bad_p) v = 0;
+      } else {
         const int x = a[0];
+        bad_p = x < 0 || x >= 1 + P.n_sub_p * P.sub_p_dim;
         if (x >= 1 && x < 1 + P.n_sub_p * P.sub_p_dim && (x - 1) / P.sub_p_dim == tid) v = (x - 1) % P.sub_p_dim + 1;
       }
     }
     c.act_p[tid] = v;
+  }
+  {
+    const int err = (__ballot(bad_a) ? AIE_ERR_AGENT_ACTION : 0) | (__ballot(bad_p) ? AIE_ERR_PLANNER_ACTION : 0);
+    if (err && tid == 0) atomicOr(R_I32(c, o_error_flags), err);
   }
   __syncthreads();
   m.pos = uni(*R_I32(c, o_mt_pos));
@@ -535,6 +545,7 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   }
   if (tid == 0) {
     *R_I32(c, o_timestep) = 0;
+    *R_I32(c, o_error_flags) = 0;
     *R_I32(c, o_first_step) = 1;
     if (P.has_tax) {
       *R_I32(c, o_tax_cycle_pos) = 1;

@@ -93,6 +93,7 @@ typedef struct aie_params {
   int32_t o_skill, o_production, o_first_step; /* one-step-economy / SimpleLabor           */
   int32_t o_mt, o_mt_pos, o_mt_has_gauss, o_mt_gauss;
   int32_t o_tax_last_completions; /* PeriodicBracketTax._last_completions (tax annealing)     */
+  int32_t o_error_flags; /* AIE_ERR_* bits (include/aie.h), sticky until reset */
   int32_t o_obs_valid;   /* 1: the map observation tensors hold this replica's current state (the step
                           * kernel then only rewrites what a step changes); cleared by anything that
                           * edits state from outside the kernels                                     */
@@ -540,6 +541,7 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
   p->o_completions = aie__rec(&cur, 4, 4);
   p->o_auto_warmup = aie__rec(&cur, 4, 4);
   p->o_first_step = aie__rec(&cur, 4, 4);
+  p->o_error_flags = aie__rec(&cur, 4, 4);
   p->o_mt_gauss = aie__rec(&cur, 8, 8);
   p->o_mt_pos = aie__rec(&cur, 4, 4);
   p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
@@ -592,6 +594,7 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
     REC("timestep", AIE_I32, p->o_timestep, 0, 0);
     REC("completions", AIE_I32, p->o_completions, 0, 0);
     REC("labor_first_step", AIE_I32, p->o_first_step, 0, 0);
+    REC("error_flags", AIE_I32, p->o_error_flags, 0, 0);
     REC("mt", AIE_U32, p->o_mt, 1, AIE_MT_N);
     REC("mt_pos", AIE_I32, p->o_mt_pos, 0, 0);
     REC("mt_has_gauss", AIE_I32, p->o_mt_has_gauss, 0, 0);
@@ -905,6 +908,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->o_completions = aie__rec(&cur, 4, 4);
   p->o_auto_warmup = aie__rec(&cur, 4, 4);
   p->o_obs_valid = aie__rec(&cur, 4, 4);
+  p->o_error_flags = aie__rec(&cur, 4, 4);
   p->o_mt_gauss = aie__rec(&cur, 8, 8);
   p->o_mt_pos = aie__rec(&cur, 4, 4);
   p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
@@ -994,6 +998,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     REC("completions", AIE_I32, p->o_completions, 0, 0, 0, 0);
     REC("auto_warmup", AIE_I32, p->o_auto_warmup, 0, 0, 0, 0);
     REC("obs_valid", AIE_I32, p->o_obs_valid, 0, 0, 0, 0);
+    REC("error_flags", AIE_I32, p->o_error_flags, 0, 0, 0, 0);
     REC("mt", AIE_U32, p->o_mt, 1, AIE_MT_N, 0, 0);
     REC("mt_pos", AIE_I32, p->o_mt_pos, 0, 0, 0, 0);
     REC("mt_has_gauss", AIE_I32, p->o_mt_has_gauss, 0, 0, 0, 0);

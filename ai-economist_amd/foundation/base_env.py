@@ -368,6 +368,27 @@ class BaseEnvironment:
         info = {"a": {}, "p": {}}
         return self._obs(), rew, done, info
 
+    def check_errors(self):
+        """Raises what the reference raises from inside step() / reset() for conditions a batched launch can only
+        record (tensor `error_flags`, include/aie.h AIE_ERR_*): an action index outside an action space
+        (ValueError, F/components/move.py:133-134, build.py:158-159) or a reset that found no free tile for an agent
+        (TimeoutError, layout_from_file.py:366-368).  One device->host read; call it where a check is affordable."""
+        t = self.backend.tensors
+        if "error_flags" not in t:
+            return
+        flags = t["error_flags"]
+        if not bool(flags.any().item()):
+            return
+        f = flags.cpu().numpy()
+        bad = np.nonzero(f)[0]
+        e = int(bad[0])
+        if f[e] & 4:
+            raise TimeoutError("replica %d (and %d more): reset found no free tile for an agent in 200 tries"
+                               % (e, bad.size - 1))
+        who = "agent" if f[e] & 1 else "planner"
+        raise ValueError("replica %d (and %d more): %s action index outside its action space (treated as NO-OP)"
+                         % (e, bad.size - 1, who))
+
     # ---- metrics (base_env.py:420-432) ----
     def scenario_metrics(self, tensors):
         """{metric key: ndarray [E]} from host copies of the state tensors; None if the

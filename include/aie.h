@@ -60,6 +60,16 @@ extern "C" {
 #define AIE_E_NOMEM (-4)
 #define AIE_E_UNSUPPORTED (-5)
 
+/* Per-replica `error_flags` tensor (int32 [E]): conditions on which the reference RAISES from inside step() / reset()
+ * while a batched launch cannot (it carries on as documented and leaves the evidence here; sticky until the replica is
+ * reset).  The host mirror's env.check_errors() turns them into the reference's exceptions. */
+#define AIE_ERR_AGENT_ACTION 1    /* an agent's action index outside its action space: treated as NO-OP (reference:
+                                     ValueError, F/components/move.py:133-134, build.py:158-159; TypeError from
+                                     base_agent.py:407-438 in single-action mode)                                   */
+#define AIE_ERR_PLANNER_ACTION 2  /* likewise for the planner (redistribution.py:953-960)                             */
+#define AIE_ERR_RESET_PLACEMENT 4 /* reset could not find a free tile for an agent in 200 tries (reference: TimeoutError,
+                                     layout_from_file.py:366-368); the agent was put on the last tile tried           */
+
 /* ---- component ids (registry names in the reference, F/components/*.py) -------- */
 enum {
   AIE_COMP_BUILD = 1,          /* "Build"                     F/components/build.py:15        */

@@ -16,7 +16,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.environ.get("AIE_REFERENCE_SRC", "/root/reference")
 DST = os.path.join(HERE, "_ref")
-DATA_DIRS = ["ai_economist/foundation/scenarios/simple_wood_and_stone/map_txt"]
+DATA_DIRS = ["ai_economist/foundation/scenarios/simple_wood_and_stone/map_txt",
+             "ai_economist/datasets/covid19_datasets/data_and_fitted_params"]
 
 
 def main():
