@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libaie_hip.so")
 SOURCES = ["aie_capi.hip", "aie_kernels.hip", "aie_kernels_ose.hip", "aie_kernels_saez.hip", "aie_kernels_covid.hip",
-           "aie_layout.h", "aie_glibc_math.h", "aie_glibc_tables.h"]
+           "aie_layout.h", "aie_glibc_math.h", "aie_glibc_tables.h", "aie_spec_generated.h"]
 
 
 def hipcc_path():
@@ -50,6 +50,11 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
+    # the constant parameter images of the compile-time step-kernel instances follow the layout code
+    from . import _specs
+
+    if _specs.write_header() and verbose:
+        print("regenerated", _specs.OUT)
     if not force and not is_stale():
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",

@@ -182,6 +182,8 @@ def bind(lib):
     lib.aie_set_reward_log.argtypes = [vp, vp, C.c_int32]
     lib.aie_step_sample_next.restype = C.c_int
     lib.aie_step_sample_next.argtypes = [vp, vp, vp, C.c_uint64, C.c_int64, vp, vp, vp]
+    lib.aie_step_kernel_instance.restype = C.c_int
+    lib.aie_step_kernel_instance.argtypes = [vp]
     lib.aie_sample_masked_actions.restype = C.c_int
     lib.aie_sample_masked_actions.argtypes = [vp, C.c_uint64, C.c_int64, vp, vp, vp]
     return lib

@@ -21,6 +21,7 @@ struct aie_env {
   int device;
   size_t lds;
   int step_waves;  // wavefronts per replica in aie_step_kernel (2; 1 = original schedule)
+  int spec;        // >= 0: the compile-time instance aie_step_kernel_spec<spec> runs this configuration; -1: generic
   int64_t sample_t;
   float* rew_log;        // aie_set_reward_log: caller's ring of n_slots step slots, or nullptr
   int32_t rew_log_slots, rew_log_next;
@@ -77,6 +78,14 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
   if (rc != AIE_OK) { delete env; return rc; }
   env->device = device;
   env->step_waves = 2;
+  env->spec = -1;
+  if (cfg->scenario == AIE_SCN_GTB) {  // a compile-time instance exists for exactly this parameter block?
+    static aie_params norm;
+    norm = env->P;
+    aie_spec_normalize(&norm);
+    for (int k = 0; k < AIE_N_SPECS; ++k)
+      if (memcmp(&norm, aie_spec_table[k], sizeof(aie_params)) == 0) env->spec = k;
+  }
   const bool covid = cfg->scenario == AIE_SCN_COVID;
   const bool ose = cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY || covid;  // map-less: no cell words to initialise
   env->lds = covid ? 0 : cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY ? aie::ose_lds_bytes(env->P) : aie::lds_bytes(env->P);
@@ -358,7 +367,17 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
                                     env->P.dev_skip_mask != 0 || env->P.dev_trace != nullptr))
     hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
-  else if (env->step_waves == 2)
+  else if (env->step_waves == 2 && env->spec >= 0) {
+    const dim3 g((unsigned)env->P.E), b(2 * AIE_NT);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define AIE_SPEC_LAUNCH(K) \
+  case K: hipLaunchKernelGGL(aie_step_kernel_spec<K>, g, b, env->lds, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); break;
+    switch (env->spec) {
+      AIE_SPEC_LIST(AIE_SPEC_LAUNCH)
+      default: return AIE_E_INVALID;
+    }
+#undef AIE_SPEC_LAUNCH
+  } else if (env->step_waves == 2)
     hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
   else
@@ -414,6 +433,15 @@ int aie_test_glibc_math(int fn, const void* d_x, const void* d_y, void* d_out, i
                      static_cast<hipStream_t>(stream), fn, static_cast<const double*>(d_x),
                      static_cast<const double*>(d_y), static_cast<double*>(d_out), n);
   return hipGetLastError() == hipSuccess ? AIE_OK : AIE_E_HIP;
+}
+
+// Which step kernel runs this environment: >= 0 = compile-time instance (index into aie_spec_generated.h), -1 = generic.
+int aie_step_kernel_instance(aie_env* env) { return env ? env->spec : -2; }
+// Development aid (not part of include/aie.h): force the generic step kernel (A/B runs, parity tests of both).
+int aie_dev_use_generic_kernel(aie_env* env) {
+  if (!env) return AIE_E_INVALID;
+  env->spec = -1;
+  return AIE_OK;
 }
 
 // Development aid (not part of include/aie.h): wavefronts per replica of the step kernel.

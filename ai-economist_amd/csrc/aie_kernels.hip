@@ -32,6 +32,13 @@
 // fuses them (aie_glibc_math.h, written out with __builtin_fma).
 #pragma clang fp contract(off)
 
+#include "aie_spec_generated.h"  // constant images of the parameter block for the compile-time step-kernel instances
+template <int SPEC>
+__device__ __forceinline__ const aie_params& aie_spec_params(const aie_params* run_time) {
+  if constexpr (SPEC < 0) return *run_time;
+  else return *reinterpret_cast<const aie_params*>(aie_spec_image<SPEC>::bytes);
+}
+
 #define AIE_NT 64  // threads per replica (one wavefront)
 #define AIE_DIRTY_CAP 64  // map cells one step may change before the incremental map observations give up (= one lane each)
 #define AIE_SRC_CAP 256  // source-block doubles handled by the gather regen (else row regen)
@@ -1880,7 +1887,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
   // using on the other wave (see step_body).
   float* s_pag = c.stage + stage_window_words(P);
   float* s_pflat = s_pag + pad4(n * P.FPA);
-  const BufRsrc aflat = make_rsrc(arena + P.a_obs_a_flat + (int64_t)c.e * n * P.FA * 4, (uint32_t)(n * P.FA * 4));
+  const BufRsrc aflat = make_rsrc(arena + c.R.a_obs_a_flat + (int64_t)c.e * n * P.FA * 4, (uint32_t)(n * P.FA * 4));
   auto AF = [&](int idx, float v) { buf_store_f32(aflat, v, 4 * idx, 0); };
   const int t = *R_I32(c, o_timestep);
   const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)P.c.episode_length : 1.0));
@@ -1931,7 +1938,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
       q[P.fpa_world + 0] = w0; q[P.fpa_world + 1] = w1; q[P.fpa_world + 2] = w2;
       if (P.c.planner_gets_spatial_info) { q[P.fpa_world + 3] = w3; q[P.fpa_world + 4] = w4; }
     }
-    reinterpret_cast<float*>(arena + P.a_obs_a_time)[(int64_t)c.e * n + i] = tval;
+    reinterpret_cast<float*>(arena + c.R.a_obs_a_time)[(int64_t)c.e * n + i] = tval;
     if (P.has_tax) {
       // last_incomes sorted ascending (redistribution.py:908-911): rank by counting
       const double per = (double)P.c.tax_period;
@@ -1954,7 +1961,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
     s_pflat[P.fp_world + 0] = 0.0f;  // the planner's inventory never changes
     s_pflat[P.fp_world + 1] = 0.0f;
     s_pflat[P.fp_world + 2] = 0.0f;
-    reinterpret_cast<float*>(arena + P.a_obs_p_time)[c.e] = tval;
+    reinterpret_cast<float*>(arena + c.R.a_obs_p_time)[c.e] = tval;
   }
   AIE_WSYNC();
 
@@ -2017,8 +2024,8 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
 
   // ---- stream the staged vectors out: 16-byte LDS reads, dword-aligned 16-byte stores ----
   if (!(skip & 1024)) {
-    stream_out(s_pag, reinterpret_cast<float*>(arena + P.a_obs_p_agents) + (int64_t)c.e * n * P.FPA, n * P.FPA, tid);
-    stream_out(s_pflat, reinterpret_cast<float*>(arena + P.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
+    stream_out(s_pag, reinterpret_cast<float*>(arena + c.R.a_obs_p_agents) + (int64_t)c.e * n * P.FPA, n * P.FPA, tid);
+    stream_out(s_pflat, reinterpret_cast<float*>(arena + c.R.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
   }
 }
 
@@ -2088,8 +2095,8 @@ __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __rest
   }
   AIE_WSYNC();
   if (!(skip & 1024)) {
-    stream_out(s_amask, reinterpret_cast<float*>(arena + P.a_obs_a_mask) + (int64_t)c.e * n * P.MA, n * P.MA, tid);
-    stream_out(s_pmask, reinterpret_cast<float*>(arena + P.a_obs_p_mask) + (int64_t)c.e * P.MP, P.MP, tid);
+    stream_out(s_amask, reinterpret_cast<float*>(arena + c.R.a_obs_a_mask) + (int64_t)c.e * n * P.MA, n * P.MA, tid);
+    stream_out(s_pmask, reinterpret_cast<float*>(arena + c.R.a_obs_p_mask) + (int64_t)c.e * P.MP, P.MP, tid);
   }
 }
 
@@ -2139,16 +2146,21 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
   // planner's reward, done -- or nullptr
   float* rew_log;
 };
-template <int NW, bool LOG>
+// SPEC >= 0: a compile-time instance (aie_spec_generated.h): P is a constant image of the parameter block of one
+// configuration -- every dimension, record offset, component list, mask table and magic divisor folds into the
+// instruction stream (no scalar loads of parameters, fully unrolled per-agent loops) -- and only what depends on
+// the batch (R: E, arena offsets) is read at run time.  SPEC < 0: the generic kernel, P == R == *params.
+template <int NW, bool LOG, int SPEC = -1>
 __device__ __forceinline__ void step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                                           const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
                                           uint8_t* lds, const NextActions& next) {
   using namespace aie;
   // The parameter block lives in device memory (uniform scalar loads).  Passing the 2.7 KB
   // struct by value made the compiler copy it to scratch on every launch (5x slower).
-  const aie_params& P = *params;
+  const aie_params& R = *params;
+  const aie_params& P = aie_spec_params<SPEC>(params);
   const int wid = NW == 1 ? 0 : uni((int)(threadIdx.x >> 6));
-  const Ctx c = make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG);
+  const Ctx c = make_ctx(P, R, lds, replica_of_block((int)blockIdx.x, R.E), (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG);
   MT m;
   Agents A;
   const int skip = c.full ? P.dev_skip_mask : 0;
@@ -2215,7 +2227,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     AIE_WSYNC();
     if (c.tid == 0) {
       const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
-      (arena + P.a_done)[c.e] = (uint8_t)done;
+      (arena + c.R.a_done)[c.e] = (uint8_t)done;
       if (next.rew_log) next.rew_log[(int64_t)c.e * (P.n + 2) + P.n + 1] = done ? 1.0f : 0.0f;
       if (done) *R_I32(c, o_completions) += 1;
     }
@@ -2259,6 +2271,14 @@ aie_step_kernel_log(const aie_params* __restrict__ params, uint8_t* __restrict__
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   step_body<2, true>(params, arena, act_a, act_p, lds, next);
 }
+// compile-time instances for the configurations listed in ai-economist_amd/_specs.py (BASELINE configs[1], [2], ...)
+template <int SPEC>
+__global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+aie_step_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                     const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  step_body<2, false, SPEC>(params, arena, act_a, act_p, lds, next);
+}
 extern "C" __global__ void __launch_bounds__(AIE_NT)
 aie_step_kernel_w1(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
@@ -2279,7 +2299,7 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   const aie_params& P = *params;
   const int e = replica_of_block((int)blockIdx.x, P.E);
   if (mask && !mask[e]) return;
-  const Ctx c = make_ctx(P, lds, e, (int)threadIdx.x, arena);
+  const Ctx c = make_ctx(P, P, lds, e, (int)threadIdx.x, arena);
   const int n = P.n, HW = P.HW, tid = c.tid;
   for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
   if (c.ev && tid == 0) c.ev[0] = 0;

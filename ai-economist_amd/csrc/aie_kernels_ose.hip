@@ -33,7 +33,7 @@ __host__ __device__ inline size_t ose_lds_bytes(const aie_params& P) {
   b += AIE_MAX_BRACKETS * 4 + (size_t)P.n * 4;
   b = (b + 15) / 16 * 16;
   b += (size_t)(4 * P.n + 2) * 8;
-  b += (size_t)(pad4(P.FA) + pad4(P.FP)) * 4;
+  b += (size_t)(pad4(P.FA > P.MA ? P.FA : P.MA) + pad4(P.FP)) * 4;  // agent row template (flat vector, then mask) + planner's
   return (b + 15) / 16 * 16;
 }
 
@@ -51,10 +51,10 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, i
   s.part = s.tmp + P.n;
   q += (4 * P.n + 2) * 8;
   s.tmpl_a = reinterpret_cast<float*>(q);
-  s.tmpl_p = s.tmpl_a + pad4(P.FA);
+  s.tmpl_p = s.tmpl_a + pad4(P.FA > P.MA ? P.FA : P.MA);
   uint8_t* met = arena + P.a_metrics + (int64_t)e * P.met_bytes;
   int32_t* ev = e < P.ev_replicas ? reinterpret_cast<int32_t*>(arena + P.a_events + (int64_t)e * P.ev_stride) : nullptr;
-  return Ctx{P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e};
+  return Ctx{P, P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e};
 }
 
 __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {
@@ -70,12 +70,50 @@ __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __r
   m.r[9] = lane < 48 ? key[576 + lane] : 0u;
 }
 
+// The draws of np.random.permutation(n) (World.get_random_order_agents, world.py:418-422) for a caller that never
+// looks at the order: only the position of the stream afterwards matters.  Fisher-Yates index i = n-1 .. 1 consumes
+// 32-bit words until one satisfies (word & mask(i)) <= i.  Instead of one word per loop trip on one lane, a block of
+// up to 64 consecutive words of the generator window is tempered at once (lane l: word pos + l) and every index is one
+// ballot over the not yet consumed lanes + find-first-set.
+__device__ __forceinline__ void rng_skip_permutation(MT& m, int lane, int n) {
+  int i = n - 1;
+  while (i >= 1) {
+    if (m.pos >= AIE_MT_N) {
+      mt_twist(m, lane);
+      m.pos = 0;
+    }
+    const int pos = m.pos, cnt = min(64, AIE_MT_N - pos);
+    // word pos + lane lives in row (pos + lane) >> 6, lane (pos + lane) & 63: at most two adjacent rows
+    const int row_a = pos >> 6, src = (pos + lane) & 63;
+    uint32_t ra = m.r[0], rb = m.r[1];
+#pragma unroll
+    for (int j = 1; j < 10; ++j) {
+      ra = (row_a == j) ? m.r[j] : ra;
+      rb = (row_a + 1 == j) ? m.r[j] : rb;
+    }
+    const uint32_t wa = lane_get(ra, src), wb = lane_get(rb, src);
+    const uint32_t w = mt_temper((pos & 63) + lane < 64 ? wa : wb);
+    uint64_t open = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);  // lanes whose word is still unconsumed
+    while (i >= 1) {
+      uint32_t mask = (uint32_t)i;
+      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8;
+      const uint64_t acc = __ballot((w & mask) <= (uint32_t)i) & open;
+      if (acc == 0) { open = 0; break; }     // every remaining word of the block rejected for this index
+      const int p = __ffsll((unsigned long long)acc) - 1;
+      open &= ~((2ull << p) - 1ull);         // words up to and including p are consumed
+      --i;
+      if (open == 0) break;
+    }
+    m.pos = pos + (open == 0 ? cnt : (__ffsll((unsigned long long)open) - 1));
+  }
+}
+
 // SimpleLabor.component_step simple_labor.py:105-126.  The random agent order
 // (world.py:418-422) is drawn -- it advances the stream -- but the result does not depend
 // on it, so the update itself runs one lane per agent.
 __device__ __forceinline__ void labor_component_step(const Ctx& c, const OseScratch& s, MT& m) {
   const int n = c.P.n;
-  for (int i = n - 1; i >= 1; --i) (void)rng_interval(m, c.tid & 63, (uint32_t)i);
+  rng_skip_permutation(m, c.tid & 63, n);
   for (int i = c.tid; i < n; i += OSE_NT) {
     const int a = s.act[i];
     if (a != 0) {
@@ -160,11 +198,18 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
       *reinterpret_cast<double*>(row + 10) = tax_rate(c, c.tid);
     }
     __syncthreads();
-    double net = 0, day = 0;  // running sums in agent order, as the reference accumulates them
+    // running sums in agent order, as the reference accumulates them; the n divisions of the effective rates are
+    // done one lane per agent first (s.sorted is free here), the sequential part is additions only
+    for (int i = c.tid; i < n; i += OSE_NT) {
+      const double inc = R_F64(c, o_tax_last_income)[i];
+      s.sorted[i] = s.tmp[i] / (inc > 0.000001 ? inc : 0.000001);
+    }
+    __syncthreads();
+    double net = 0, day = 0;
+#pragma unroll 10
     for (int j = 0; j < n; ++j) {
       net += s.tmp[j];
-      const double inc = R_F64(c, o_tax_last_income)[j];
-      day += s.tmp[j] / (inc > 0.000001 ? inc : 0.000001);
+      day += s.sorted[j];
     }
     if (c.tid == 0) {
       unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_eff), day);
@@ -295,6 +340,51 @@ __device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s) {
   __syncthreads();
 }
 
+// n rows of F floats at g (row i at float offset i * F: only dword-aligned), every row = the same template with up to
+// two per-row entries patched (entry ip0 <- (float)p0[i], entry ip1 <- (float)p1[i]; -1 = none).  A lane keeps ONE
+// 16-byte quad of the template in registers for the whole loop and L4 = ceil(F / 4) neighbouring lanes write one row
+// with one store instruction; 64 / L4 rows go out per instruction (global dwordx4 accesses need only dword alignment
+// on gfx950).  ~6 instructions per pass instead of ~45 per quad when every element is looked up and tested.
+__device__ __forceinline__ void ose_store_rows(BufRsrc g, int n, int F, const float* tmpl, int lane, int ip0,
+                                               const double* p0, int ip1, const double* p1) {
+  const int L4 = (F + 3) >> 2;
+  if (L4 > 64) return;  // (F <= 256 always: n <= 128)
+  const int rpp = 64 / L4;                    // rows per pass
+  const int sub = lane / L4, l = lane - sub * L4;
+  const bool active = sub < rpp;
+  const int j0 = 4 * l;
+  float t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  if (active) {
+    t0 = tmpl[j0];
+    if (j0 + 1 < F) t1 = tmpl[j0 + 1];
+    if (j0 + 2 < F) t2 = tmpl[j0 + 2];
+    if (j0 + 3 < F) t3 = tmpl[j0 + 3];
+  }
+  const int u0 = ip0 - j0, u1 = ip1 - j0;     // 0..3 on the lane that owns a patched entry
+  const bool own0 = active && ip0 >= 0 && (unsigned)u0 < 4u, own1 = active && ip1 >= 0 && (unsigned)u1 < 4u;
+  const int width = F - j0 >= 4 ? 4 : F - j0; // dwords this lane writes (the last quad of a row may be short)
+  for (int r0 = 0; r0 < n; r0 += rpp) {
+    const int i = r0 + sub;
+    if (!active || i >= n) continue;
+    float v0 = t0, v1 = t1, v2 = t2, v3 = t3;
+    if (own0) {
+      const float x = (float)p0[i];
+      v0 = u0 == 0 ? x : v0; v1 = u0 == 1 ? x : v1; v2 = u0 == 2 ? x : v2; v3 = u0 == 3 ? x : v3;
+    }
+    if (own1) {
+      const float x = (float)p1[i];
+      v0 = u1 == 0 ? x : v0; v1 = u1 == 1 ? x : v1; v2 = u1 == 2 ? x : v2; v3 = u1 == 3 ? x : v3;
+    }
+    const int off = 4 * (i * F + j0);
+    if (width == 4) buf_store_f32x4(g, v0, v1, v2, v3, off, 0);
+    else {
+      buf_store_f32(g, v0, off, 0);
+      if (width > 1) buf_store_f32(g, v1, off + 4, 0);
+      if (width > 2) buf_store_f32(g, v2, off + 8, 0);
+    }
+  }
+}
+
 // Observations + masks (one_step_economy.py:120-176, simple_labor.py:97-103,128-134,
 // redistribution.py:974-1104), flat vectors in sorted-key order (base_env.py:561-612).
 __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseScratch& s, uint8_t* __restrict__ arena,
@@ -345,29 +435,14 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
   __syncthreads();
   // ---- agent flat vectors: the shared template with two per-agent entries ----
   {
-    // n x FA floats, four consecutive elements (possibly straddling two agents) per lane and store
     const BufRsrc g = make_rsrc(arena + P.a_obs_a_flat + (int64_t)c.e * n * P.FA * 4, (uint32_t)(n * P.FA * 4));
     const int i_mr = P.has_tax ? P.fa_tax + NB + 2 + n : -1;
     const int i_sk = P.has_labor ? P.fa_labor : -1;
-    auto val = [&](int i, int j) {
-      float v = s.tmpl_a[j];
-      if (j == i_mr) v = (float)s.tmp[i];
-      if (j == i_sk) v = (float)(R_F64(c, o_skill)[i] / P.c.labor_pmsm);
-      return v;
-    };
-    const int tot = n * P.FA;
-    for (int q = 4 * tid; q < tot; q += 4 * OSE_NT) {
-      int i = udiv(q, P.FA, P.mg_FA), j = q - i * P.FA;
-      float v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v[u] = (q + u < tot) ? val(i, j) : 0.0f;
-        if (++j == P.FA) { j = 0; ++i; }
-      }
-      if (q + 3 < tot) buf_store_f32x4(g, v[0], v[1], v[2], v[3], 4 * q, 0);
-      else
-        for (int u = 0; u < 4 && q + u < tot; ++u) buf_store_f32(g, v[u], 4 * (q + u), 0);
+    if (i_sk >= 0) {  // SimpleLabor-skill = skill / pmsm: n divisions, one lane per agent (s.part is free until the rewards)
+      for (int i = tid; i < n; i += OSE_NT) s.part[i] = R_F64(c, o_skill)[i] / P.c.labor_pmsm;
+      __syncthreads();
     }
+    ose_store_rows(g, n, P.FA, s.tmpl_a, tid, i_mr, s.tmp, i_sk, s.part);
     float* gt = reinterpret_cast<float*>(arena + P.a_obs_a_time) + (int64_t)c.e * n;
     for (int i = tid; i < n; i += OSE_NT) gt[i] = tval;
     if (P.FPA) {
@@ -387,23 +462,13 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
       const int first = *R_I32(c, o_first_step);
       if (first && P.c.labor_mask_first_step) on = 0.0f;
     }
-    const bool multi = P.c.multi_action_mode_agents != 0;
-    // single-action: [NO-OP, hours...]; multi-action: [NO-OP, hours...] of the only subspace
+    // single-action: [NO-OP, hours...]; multi-action: [NO-OP, hours...] of the only subspace -- every agent's row is
+    // the same; the row template goes through the (now free) agent template area
     const BufRsrc g = make_rsrc(arena + P.a_obs_a_mask + (int64_t)c.e * n * P.MA * 4, (uint32_t)(n * P.MA * 4));
-    const int tot = n * P.MA;
-    (void)multi;
-    for (int q = 4 * tid; q < tot; q += 4 * OSE_NT) {
-      int mm = q - udiv(q, P.MA, P.mg_MA) * P.MA;
-      float v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v[u] = (mm == 0 || P.n_sub_a == 0) ? 1.0f : on;
-        if (++mm == P.MA) mm = 0;
-      }
-      if (q + 3 < tot) buf_store_f32x4(g, v[0], v[1], v[2], v[3], 4 * q, 0);
-      else
-        for (int u = 0; u < 4 && q + u < tot; ++u) buf_store_f32(g, v[u], 4 * (q + u), 0);
-    }
+    __syncthreads();
+    for (int q = tid; q < P.MA; q += OSE_NT) s.tmpl_a[q] = (q == 0 || P.n_sub_a == 0) ? 1.0f : on;
+    __syncthreads();
+    ose_store_rows(g, n, P.MA, s.tmpl_a, tid, -1, nullptr, -1, nullptr);
     if (at_reset && P.has_tax && P.c.tax_annealing) {  // generate_masks refreshes _last_completions after the reset's observations
       __syncthreads();
       if (tid == 0) *R_I32(c, o_tax_last_completions) = *R_I32(c, o_completions);
@@ -437,6 +502,56 @@ __device__ __forceinline__ void ose_store_record(const Ctx& c, uint8_t* __restri
   if (c.tid < 48) key[576 + c.tid] = m.r[9];
 }
 
+}  // namespace aie
+
+// reset: one_step_economy.py:99-118 + simple_labor.py:76-95 + redistribution.py:1109-1139
+// + additional_reset_steps :224-241.  No random draws.  The record is in LDS; `keep_rewards`: called from the step
+// kernel for a replica that just finished its episode (auto-reset): the terminal step's rewards / done stay.
+namespace aie {
+__device__ __forceinline__ void ose_reset_body(const Ctx& c, const OseScratch& s, uint8_t* __restrict__ arena,
+                                               bool keep_rewards) {
+  const aie_params& P = c.P;
+  const int n = P.n, tid = c.tid, e = c.e;
+  for (int q = tid; q < (P.met_bytes >> 2); q += OSE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
+  if (c.ev && tid == 0) c.ev[0] = 0;
+  for (int i = tid; i < n; i += OSE_NT) {
+    R_F64(c, o_inv_coin)[i] = 0; R_F64(c, o_esc_coin)[i] = 0; R_F64(c, o_labor)[i] = 0;
+    R_F64(c, o_skill)[i] = P.has_labor ? P.c.labor_skills[i] : 0;
+    R_F64(c, o_production)[i] = 0;
+    if (P.has_tax) {
+      R_F64(c, o_tax_last_coin)[i] = 0; R_F64(c, o_tax_last_income)[i] = 0; R_F64(c, o_tax_last_marginal_rate)[i] = 0;
+    }
+  }
+  if (tid == 0) {
+    *R_I32(c, o_timestep) = 0;
+    *R_I32(c, o_error_flags) = 0;
+    *R_I32(c, o_first_step) = 1;
+    if (P.has_tax) {
+      *R_I32(c, o_tax_cycle_pos) = 1;
+      *R_F64(c, o_tax_total_collected) = 0;
+    }
+  }
+  if (P.has_tax && tid < P.NB) R_I32(c, o_tax_rate_idx)[tid] = 0;
+  __syncthreads();
+  if (c.saez) {  // _curr_rates_obs first (:1123, the previous episode's rates), then the running average (:1136-1137)
+    if (tid < P.NB) R_F64(c, o_tax_saez_obs_rates)[tid] = tax_rate(c, tid);
+    __syncthreads();
+    if (tid < P.NB) R_F64(c, o_tax_saez_rates)[tid] = reinterpret_cast<const double*>(saez_block(c) + AIE_SAEZ_OFF_AVG)[tid];
+    __syncthreads();
+  }
+  ose_metrics(c, s);
+  for (int i = tid; i <= n; i += OSE_NT) R_F64(c, o_util)[i] = s.part[i];
+  __syncthreads();
+  ose_write_observations(c, s, arena, true);
+  if (!keep_rewards) {
+    for (int i = tid; i < n; i += OSE_NT) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + i] = 0.0f;
+    if (tid == 0) {
+      reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.0f;
+      (arena + P.a_done)[e] = 0;
+    }
+  }
+  __syncthreads();
+}
 }  // namespace aie
 
 // BaseEnvironment.step (base_env.py:929-1032) for the one-step-economy scenario
@@ -494,7 +609,12 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   }
   if (tid == 0) *R_I32(c, o_mt_pos) = m.pos;
   __syncthreads();
-  ose_write_observations(c, s, arena);
+  const bool done = uni(*R_I32(c, o_timestep)) >= P.c.episode_length;
+  // auto-reset (aie_set_auto_reset): a replica that finishes its episode in this step restarts inside this launch;
+  // its terminal observations would be overwritten by the reset's before anything can read them, so they are not
+  // written (rewards and `done` are the terminal step's)
+  const bool restart = done && P.auto_reset;
+  if (!restart) ose_write_observations(c, s, arena);
   __syncthreads();
   // compute_reward one_step_economy.py:195-222
   ose_metrics(c, s);
@@ -509,16 +629,14 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   }
   __syncthreads();
   if (tid == 0) {
-    const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
     (arena + P.a_done)[c.e] = (uint8_t)done;
     if (done) *R_I32(c, o_completions) += 1;
   }
   __syncthreads();
+  if (restart) ose_reset_body(c, s, arena, true);
   ose_store_record(c, arena, m);
 }
 
-// reset: one_step_economy.py:99-118 + simple_labor.py:76-95 + redistribution.py:1109-1139
-// + additional_reset_steps :224-241.  No random draws.
 extern "C" __global__ void __launch_bounds__(OSE_NT)
 aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                      const uint8_t* __restrict__ mask) {
@@ -529,46 +647,9 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   if (mask && !mask[e]) return;
   OseScratch s;
   const Ctx c = ose_make_ctx(P, lds, e, (int)threadIdx.x, s, arena);
-  const int n = P.n, tid = c.tid;
-  for (int q = tid; q < (P.met_bytes >> 2); q += OSE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
-  if (c.ev && tid == 0) c.ev[0] = 0;
   MT m;
   ose_load_record(c, arena, m);
   __syncthreads();
-  for (int i = tid; i < n; i += OSE_NT) {
-    R_F64(c, o_inv_coin)[i] = 0; R_F64(c, o_esc_coin)[i] = 0; R_F64(c, o_labor)[i] = 0;
-    R_F64(c, o_skill)[i] = P.has_labor ? P.c.labor_skills[i] : 0;
-    R_F64(c, o_production)[i] = 0;
-    if (P.has_tax) {
-      R_F64(c, o_tax_last_coin)[i] = 0; R_F64(c, o_tax_last_income)[i] = 0; R_F64(c, o_tax_last_marginal_rate)[i] = 0;
-    }
-  }
-  if (tid == 0) {
-    *R_I32(c, o_timestep) = 0;
-    *R_I32(c, o_error_flags) = 0;
-    *R_I32(c, o_first_step) = 1;
-    if (P.has_tax) {
-      *R_I32(c, o_tax_cycle_pos) = 1;
-      *R_F64(c, o_tax_total_collected) = 0;
-    }
-  }
-  if (P.has_tax && tid < P.NB) R_I32(c, o_tax_rate_idx)[tid] = 0;
-  __syncthreads();
-  if (c.saez) {  // _curr_rates_obs first (:1123, the previous episode's rates), then the running average (:1136-1137)
-    if (tid < P.NB) R_F64(c, o_tax_saez_obs_rates)[tid] = tax_rate(c, tid);
-    __syncthreads();
-    if (tid < P.NB) R_F64(c, o_tax_saez_rates)[tid] = reinterpret_cast<const double*>(saez_block(c) + AIE_SAEZ_OFF_AVG)[tid];
-    __syncthreads();
-  }
-  ose_metrics(c, s);
-  for (int i = tid; i <= n; i += OSE_NT) R_F64(c, o_util)[i] = s.part[i];
-  __syncthreads();
-  ose_write_observations(c, s, arena, true);
-  for (int i = tid; i < n; i += OSE_NT) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + i] = 0.0f;
-  if (tid == 0) {
-    reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.0f;
-    (arena + P.a_done)[e] = 0;
-  }
-  __syncthreads();
+  ose_reset_body(c, s, arena, false);
   ose_store_record(c, arena, m);
 }

@@ -171,8 +171,27 @@ typedef struct aie_params {
   int64_t a_cv_hist;     /* uint8 [E][nch][cv_row]                                         */
   int64_t a_cv_obs_a;    /* float32 [E][cv_nrow_obs][n]                                    */
   int64_t a_cv_obs_p;    /* float32 [E][4 + 1 + NS]                                        */
-  int32_t dev_pad;
+  int32_t auto_reset;    /* run-time switch (aie_set_auto_reset): replicas restart inside the launch that ends their episode */
 } aie_params;
+
+/* Compile-time instances of the step kernel (aie_spec_generated.h) bake a CONSTANT image of aie_params into the code;
+ * what depends on the batch rather than on the configuration is read from the run-time block instead and is zeroed
+ * in the image: the replica count, every arena offset, development hooks.  An environment runs on an instance iff its
+ * normalised block equals the instance's image byte for byte (aie_capi.hip: aie_create). */
+static inline void aie_spec_normalize(aie_params* p) {
+  p->E = 0;
+  p->c.n_envs = 0;
+  p->a_records = 0;
+  p->a_obs_a_map = p->a_obs_a_idx = p->a_obs_a_flat = p->a_obs_a_mask = p->a_obs_a_time = 0;
+  p->a_obs_p_map = p->a_obs_p_idx = p->a_obs_p_flat = p->a_obs_p_mask = p->a_obs_p_time = p->a_obs_p_agents = 0;
+  p->a_rew_a = p->a_rew_p = p->a_done = 0;
+  p->arena_bytes = 0;
+  p->a_saez = p->a_events = p->a_metrics = 0;
+  p->a_cv_consts = p->a_cv_filters = p->a_cv_hist0 = p->a_cv_lag_obs = p->a_cv_hist = p->a_cv_obs_a = p->a_cv_obs_p = 0;
+  p->dev_skip_mask = 0;
+  p->dev_trace = 0;
+  p->auto_reset = 0;
+}
 
 typedef struct aie_tensor_table {
   int32_t n;

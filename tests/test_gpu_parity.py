@@ -623,3 +623,49 @@ def test_error_flags_for_what_the_reference_raises():
         env.step({"a": a, "p": p[0]})
     with pytest.raises(ValueError):
         env.step({"0": 3, "1": 0, "p": [0] * 7})
+
+
+@pytest.mark.parametrize("n_agents", [4, 10])
+def test_compile_time_instance_equals_generic_kernel(n_agents):
+    """BASELINE configs[1] / [2] run on a compile-time instance of the step kernel (aie_spec_generated.h: the parameter
+    block folded into the code); the generic kernel on the same replicas must produce the same arena, bit for bit."""
+    import ctypes
+
+    import torch
+
+    cfg = dict(C2, n_agents=n_agents, episode_length=150)
+    cfg_spec = dict(C2, n_agents=n_agents)
+    env_s = make_env(cfg_spec, n_envs=8, device="cuda:0")
+    assert env_s.backend.lib.aie_step_kernel_instance(env_s.backend.handle) >= 0, "no compile-time instance selected"
+    envs = [make_env(cfg, n_envs=512, device="cuda:0") for _ in range(2)]
+    for env in envs:
+        env.seed(21)
+        env.reset()
+    b_gen, b_other = envs[0].backend, envs[1].backend
+    # episode_length 150 is not an instance's configuration: both run the generic kernel ...
+    assert b_gen.lib.aie_step_kernel_instance(b_gen.handle) == -1
+    # ... so compare instance vs generic on the instance's own configuration instead
+    pair = [make_env(cfg_spec, n_envs=512, device="cuda:0") for _ in range(2)]
+    for env in pair:
+        env.seed(21)
+        env.reset()
+    b_spec, b_ref = pair[0].backend, pair[1].backend
+    b_ref.lib.aie_dev_use_generic_kernel.argtypes = [ctypes.c_void_p]
+    assert b_ref.lib.aie_dev_use_generic_kernel(b_ref.handle) == 0
+    assert b_spec.lib.aie_step_kernel_instance(b_spec.handle) >= 0 and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == -1
+    cur_s = b_spec.sample_random_actions(seed=4, slot=0)
+    slot = 0
+    for t in range(230):
+        a, p = b_ref.sample_random_actions(seed=4)
+        b_ref.step(a, p)
+        if t % 3 == 0:  # both entry points of the instance
+            cur_s = b_spec.step_sample_next(cur_s[0], cur_s[1], seed=4, next_slot=slot ^ 1)
+            slot ^= 1
+        else:
+            b_spec.step(cur_s[0], cur_s[1])
+            cur_s = b_spec.sample_random_actions(seed=4, slot=slot)
+        if t in (0, 57, 101, 229):
+            torch.cuda.synchronize()
+            for k in b_ref.tensors:
+                assert torch.equal(b_ref.tensors[k], b_spec.tensors[k]), "step %d: %s differs" % (t + 1, k)
+    del b_gen, b_other
