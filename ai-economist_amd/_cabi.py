@@ -182,6 +182,8 @@ def bind(lib):
     lib.aie_set_reward_log.argtypes = [vp, vp, C.c_int32]
     lib.aie_step_sample_next.restype = C.c_int
     lib.aie_step_sample_next.argtypes = [vp, vp, vp, C.c_uint64, C.c_int64, vp, vp, vp]
+    lib.aie_set_auto_reset.restype = C.c_int
+    lib.aie_set_auto_reset.argtypes = [vp, C.c_int]
     lib.aie_step_kernel_instance.restype = C.c_int
     lib.aie_step_kernel_instance.argtypes = [vp]
     lib.aie_sample_masked_actions.restype = C.c_int
@@ -193,5 +195,6 @@ EXPORTED_SYMBOLS = [
     "aie_arena_bytes", "aie_create", "aie_destroy", "aie_last_error", "aie_num_tensors",
     "aie_tensor_at", "aie_get_tensor", "aie_upload", "aie_download", "aie_set_layout",
     "aie_seed", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
-    "aie_sample_masked_actions", "aie_step_sample_next", "aie_set_reward_log",
+    "aie_sample_masked_actions", "aie_step_sample_next", "aie_set_reward_log", "aie_set_auto_reset",
+    "aie_step_kernel_instance",
 ]

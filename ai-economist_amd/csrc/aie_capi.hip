@@ -290,13 +290,13 @@ int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   if (env->P.c.scenario == AIE_SCN_COVID)
     hipLaunchKernelGGL(aie_covid_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0,
-                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask, 0);
   else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_reset_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
   else
     hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
-                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask, 0);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
 }
@@ -306,7 +306,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
 
 int aie_set_reward_log(aie_env* env, float* d_log, int32_t n_slots) {
   if (!env) return AIE_E_INVALID;
-  if (d_log && (n_slots < 1 || env->P.c.scenario != AIE_SCN_GTB || env->step_waves != 2)) {
+  if (d_log && (n_slots < 1 || env->step_waves != 2)) {
     snprintf(env->err, sizeof(env->err), "aie_set_reward_log: needs n_slots >= 1 and a gather-trade-build environment");
     return d_log && n_slots < 1 ? AIE_E_INVALID : AIE_E_UNSUPPORTED;
   }
@@ -353,7 +353,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
     const dim3 g((unsigned)env->P.E), b(AIE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define AIE_CV_LAUNCH(FN) \
-  case FN: hipLaunchKernelGGL(aie_covid_step_kernel<FN>, g, b, 0, st, env->d_params, env->arena, d_actions_a, d_actions_p); break
+  case FN: hipLaunchKernelGGL(aie_covid_step_kernel<FN>, g, b, 0, st, env->d_params, env->arena, d_actions_a, d_actions_p, next.rew_log); break
     switch (env->P.cv_F) {
       AIE_CV_LAUNCH(1); AIE_CV_LAUNCH(2); AIE_CV_LAUNCH(3); AIE_CV_LAUNCH(4);
       AIE_CV_LAUNCH(5); AIE_CV_LAUNCH(6); AIE_CV_LAUNCH(7); AIE_CV_LAUNCH(8);
@@ -362,7 +362,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
 #undef AIE_CV_LAUNCH
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
-                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next.rew_log);
   else if (env->step_waves == 2 && (env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT ||
                                     env->P.dev_skip_mask != 0 || env->P.dev_trace != nullptr))
     hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
@@ -383,7 +383,33 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   else
     hipLaunchKernelGGL(aie_step_kernel_w1, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
+  if (env->P.auto_reset && env->P.c.scenario != AIE_SCN_ONE_STEP_ECONOMY) {
+    // auto-reset: the replicas this step finished restart right behind it on the same stream (mask = the `done`
+    // tensor the step just wrote; the reset keeps the terminal rewards / done).  one-step-economy does it inside the
+    // step launch itself.
+    const uint8_t* done = env->arena + env->P.a_done;
+    if (env->P.c.scenario == AIE_SCN_COVID)
+      hipLaunchKernelGGL(aie_covid_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0,
+                         static_cast<hipStream_t>(stream), env->d_params, env->arena, done, 1);
+    else
+      hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+                         static_cast<hipStream_t>(stream), env->d_params, env->arena, done, 1);
+  }
   AIE_HIP_CHECK(env, hipGetLastError());
+  return AIE_OK;
+}
+
+int aie_set_auto_reset(aie_env* env, int on) {
+  if (!env) return AIE_E_INVALID;
+  if (on && env->P.c.scenario == AIE_SCN_GTB && !env->P.c.shared_layout) {
+    // uniform/, quadrant/, multi_zone/: the layout of the next episode is generated on the host (host_pre_reset)
+    snprintf(env->err, sizeof(env->err), "auto-reset is not available for scenarios whose reset has a host-side part");
+    return AIE_E_UNSUPPORTED;
+  }
+  env->P.auto_reset = on ? 1 : 0;
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  AIE_HIP_CHECK(env, hipDeviceSynchronize());
+  AIE_HIP_CHECK(env, hipMemcpy(env->d_params, &env->P, sizeof(aie_params), hipMemcpyHostToDevice));
   return AIE_OK;
 }
 

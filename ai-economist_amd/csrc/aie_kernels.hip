@@ -2293,7 +2293,7 @@ aie_step_kernel_w1(const aie_params* __restrict__ params, uint8_t* __restrict__ 
 // Runs once per episode: the sequential part is executed wave-uniformly out of LDS.
 extern "C" __global__ void __launch_bounds__(AIE_NT)
 aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                 const uint8_t* __restrict__ mask) {
+                 const uint8_t* __restrict__ mask, int keep_rewards) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   using namespace aie;
   const aie_params& P = *params;
@@ -2477,10 +2477,12 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   if (P.has_tax && P.c.tax_annealing && tid == 0) *R_I32(c, o_tax_last_completions) = *R_I32(c, o_completions);  // generate_masks :1036-1046
   AIE_WSYNC();
   write_action_masks(c, arena);
-  if (tid < n) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + tid] = 0.0f;
-  if (tid == 0) {
-    reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.0f;
-    (arena + P.a_done)[e] = 0;
+  if (!keep_rewards) {  // (auto-reset right behind the step that ended the episode: its rewards / done stay)
+    if (tid < n) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + tid] = 0.0f;
+    if (tid == 0) {
+      reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.0f;
+      (arena + P.a_done)[e] = 0;
+    }
   }
   __syncthreads();
   store_record(c, arena, m);

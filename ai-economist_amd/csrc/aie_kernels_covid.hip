@@ -138,7 +138,7 @@ __device__ __forceinline__ void cv_write_observations(const aie_params& P, uint8
 // additional_reset_steps (covid19_env.py:1175-1293) + the components' additional_reset_steps.
 extern "C" __global__ void __launch_bounds__(AIE_NT)
     aie_covid_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                           const uint8_t* __restrict__ env_mask) {
+                           const uint8_t* __restrict__ env_mask, int keep_rewards) {
   using namespace aie;
   const aie_params& P = *params;
   const int e = replica_of_block((int)blockIdx.x, P.E);
@@ -192,10 +192,12 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
     *reinterpret_cast<int32_t*>(rec + P.o_timestep) = 0;
     reinterpret_cast<float*>(rec + P.o_cv_p_index)[0] = 0.f;
     reinterpret_cast<float*>(rec + P.o_cv_p_index)[1] = 0.f;
-    arena[P.a_done + e] = 0;
-    reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.f;
+    if (!keep_rewards) {
+      arena[P.a_done + e] = 0;
+      reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.f;
+    }
   }
-  if (on) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + s] = 0.f;
+  if (on && !keep_rewards) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + s] = 0.f;
   __syncthreads();  // the history bytes written above are read back for the lagged observation
   cv_write_observations(P, arena, e, s, 0, a, 0, hist);
 }
@@ -204,7 +206,8 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
 template <int F>
 __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     aie_covid_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                          const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
+                          const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
+                          float* __restrict__ rew_log /* this step's slot of aie_set_reward_log, or nullptr */) {
   using namespace aie;
   __shared__ float red[3][64];
   const aie_params& P = *params;
@@ -385,7 +388,9 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     h = cv_minmax(h, (float)K[AIE_CV_K_MIN_HEALTH * 64 + s], (float)K[AIE_CV_K_MAX_HEALTH * 64 + s]);
     ec = cv_minmax(ec, (float)K[AIE_CV_K_MIN_ECON * 64 + s], (float)K[AIE_CV_K_MAX_ECON * 64 + s]);
     const float wh = (float)K[AIE_CV_K_W_HEALTH * 64 + s], we = (float)K[AIE_CV_K_W_ECON * 64 + s];
-    reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + s] = ((wh * h + we * ec) / (wh + we)) / rnf;
+    const float ra = ((wh * h + we * ec) / (wh + we)) / rnf;
+    reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + s] = ra;
+    if (rew_log) rew_log[(int64_t)e * (n + 2) + s] = ra;
     st[AIE_CV_ST_HEALTH_INDEX * 64 + s] += h;  // agent.state["Health Index"] += ... :1123-1125 (float32)
     st[AIE_CV_ST_ECONOMIC_INDEX * 64 + s] += ec;
   }
@@ -403,6 +408,10 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     const float wpe = (float)V.weightage_on_marginal_planner_economic_index;
     const double rp = (((double)wph * ph + (double)(wpe * pe)) / (double)(wph + wpe)) / (double)rnf;
     reinterpret_cast<float*>(arena + P.a_rew_p)[e] = (float)rp;
+    if (rew_log) {
+      rew_log[(int64_t)e * (n + 2) + n] = (float)rp;
+      rew_log[(int64_t)e * (n + 2) + n + 1] = t >= T ? 1.0f : 0.0f;
+    }
     float* pidx = reinterpret_cast<float*>(rec + P.o_cv_p_index);  // planner.state[...] += ... :1160-1161
     pidx[0] = (float)((double)pidx[0] + ph);
     pidx[1] = pidx[1] + pe;

@@ -255,18 +255,21 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
   __syncthreads();
 }
 
-// ascending sort of src[0..n) into dst by counting ranks (one lane per element)
+// ascending (stable) sort of src[0..n) into dst by counting ranks; a lane ranks its two elements (i, i + 64) in one
+// sweep, so every src[j] is read from LDS once per lane
 __device__ __forceinline__ void rank_sort(const double* src, double* dst, int n, int tid) {
-  for (int i = tid; i < n; i += OSE_NT) {
-    const double x = src[i];
-    int rank = 0;
+  static_assert(OSE_NT == 64, "two elements per lane cover n <= 128");
+  const int i0 = tid, i1 = tid + OSE_NT;
+  const double x0 = i0 < n ? src[i0] : 0.0, x1 = i1 < n ? src[i1] : 0.0;
+  int r0 = 0, r1 = 0;
 #pragma unroll 10
-    for (int j = 0; j < n; ++j) {
-      const double y = src[j];
-      rank += (y < x || (y == x && j < i)) ? 1 : 0;
-    }
-    dst[rank] = x;
+  for (int j = 0; j < n; ++j) {
+    const double y = src[j];
+    r0 += (y < x0 || (y == x0 && j < i0)) ? 1 : 0;
+    r1 += (y < x1 || (y == x1 && j < i1)) ? 1 : 0;
   }
+  if (i0 < n) dst[r0] = x0;
+  if (i1 < n) dst[r1] = x1;
 }
 
 // social_metrics.get_gini (social_metrics.py:10-46) of s.coin; called by every thread, the result is valid on
@@ -557,7 +560,8 @@ __device__ __forceinline__ void ose_reset_body(const Ctx& c, const OseScratch& s
 // BaseEnvironment.step (base_env.py:929-1032) for the one-step-economy scenario
 extern "C" __global__ void __launch_bounds__(OSE_NT)
 aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
+                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
+                    float* __restrict__ rew_log /* this step's slot of aie_set_reward_log, or nullptr */) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   using namespace aie;
   const aie_params& P = *params;
@@ -625,11 +629,13 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
       util[i] = s.part[i];
       if (i < n) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)c.e * n + i] = (float)r;
       else reinterpret_cast<float*>(arena + P.a_rew_p)[c.e] = (float)r;
+      if (rew_log) rew_log[(int64_t)c.e * (n + 2) + i] = (float)r;
     }
   }
   __syncthreads();
   if (tid == 0) {
     (arena + P.a_done)[c.e] = (uint8_t)done;
+    if (rew_log) rew_log[(int64_t)c.e * (n + 2) + n + 1] = done ? 1.0f : 0.0f;
     if (done) *R_I32(c, o_completions) += 1;
   }
   __syncthreads();

@@ -150,6 +150,11 @@ class DeviceBackend:
         self._check(self.lib.aie_set_reward_log(self.handle, C.c_void_p(self.reward_log.data_ptr()), int(n_slots)))
         return self.reward_log
 
+    def set_auto_reset(self, on=True):
+        """Replicas restart inside / right behind the step that ends their episode (include/aie.h:
+        aie_set_auto_reset): `done` and the rewards are the terminal step's, state and observations the new episode's."""
+        self._check(self.lib.aie_set_auto_reset(self.handle, 1 if on else 0))
+
     def step_sample_next(self, actions_a, actions_p, seed, env_offset=0, next_slot=1):
         """One launch: step with (actions_a, actions_p) and fill the action buffers of `next_slot`
         with the uniform random policy's next draw (same values as sample_random_actions)."""

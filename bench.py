@@ -250,7 +250,7 @@ class Rollout:
     """The timed loop of one rank: one launch per step, de-phased replicas, masked resets on a host-known
     schedule (block g of the replicas, g = e mod G, ends its episode at steps = offset_g mod episode_length)."""
 
-    def __init__(self, wl, env, rank_offset, stagger=True):
+    def __init__(self, wl, env, rank_offset, stagger=True, auto_reset=True):
         import torch
 
         self.torch = torch
@@ -260,6 +260,11 @@ class Rollout:
         self.E = self.be.E
         self.t = 0  # rollout steps since the common reset
         self.fused = hasattr(self.be, "step_sample_next") and wl in ("C2", "C3")
+        # C5 (2-step episodes): auto-reset -- the replicas restart inside the step launch that ends their episode
+        # (aie_set_auto_reset), as a vectorised trainer runs it; no separate reset launches
+        self.auto_reset = wl == "C5" and auto_reset
+        if self.auto_reset:
+            self.be.set_auto_reset(True)
         stride = STAGGER_STRIDE if (stagger and self.T > 2 * STAGGER_STRIDE) else 0
         self.G = (self.T // stride) if stride else 1
         self.stride = stride
@@ -296,7 +301,7 @@ class Rollout:
         self._launch()
         self.t += 1
         if self.G == 1:
-            if self.t % self.T == 0:
+            if self.t % self.T == 0 and not self.auto_reset:
                 self._reset(self.be.tensors["done"], timed)
         elif self.t % self.stride == 0:
             # block g sits at timestep T - g * stride (mod T) at t = 0, so its episode ends at t = g * stride (mod T)
@@ -324,6 +329,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stagger", action="store_true", help="keep all replicas in lock-step (round-1 behaviour)")
+    ap.add_argument("--no-auto-reset", action="store_true",
+                    help="C5: separate reset launches instead of restarting replicas inside the step launch")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the N > 1 reward-log gather in a 1-rank group (exercises the RCCL path on one GPU)")
     args = ap.parse_args()
@@ -360,7 +367,7 @@ def main():
     env.reset()
     be = env.backend
     n = env.n_agents
-    roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger)
+    roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger, auto_reset=not args.no_auto_reset)
     prologue_steps = roll.prologue()
 
     # N > 1: (reward, done) of every step travel to the learner rank, 64 steps per collective, straight from the
@@ -454,7 +461,9 @@ def main():
                 "phasing": ("replicas de-phased in %d blocks, episode ends %d steps apart (prologue of %d untimed "
                             "steps); one masked reset launch per block end inside the timed region"
                             % (roll.G, roll.stride, prologue_steps)) if roll.G > 1 else
-                           "lock-step replicas, one reset launch per episode end",
+                           ("lock-step replicas; auto-reset: a replica restarts inside the step launch that ends its "
+                            "episode, the terminal observations are replaced by the next episode's first ones"
+                            if roll.auto_reset else "lock-step replicas, one reset launch per episode end"),
                 "parallelism": ("replica sharding, %d ranks; (reward, done) of every step gathered to rank 0 over "
                                 "RCCL, 64 steps per collective, overlapped with the steps" % world)
                 if world > 1 else "single GPU",

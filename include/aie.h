@@ -345,9 +345,21 @@ int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t
  * d_log[((slot * n_envs) + e) * (n_agents + 2) + ...], slot = 0, 1, ... n_slots - 1, 0, ... advancing by one per
  * step (this call resets it to 0).  The caller owns d_log (n_slots * n_envs * (n_agents + 2) floats) and ships
  * whole ranges of slots to the learner rank with one collective per many steps instead of one per step
- * (ai_economist_amd/sharding.py).  d_log == NULL switches the log off.  Gather-trade-build
- * scenarios; AIE_E_UNSUPPORTED otherwise. */
+ * (ai_economist_amd/sharding.py).  d_log == NULL switches the log off.  All scenarios. */
 int aie_set_reward_log(aie_env* env, float* d_log, int32_t n_slots);
+
+/* Auto-reset (the vectorised-trainer convention, reference analogue: F/env_wrapper.py:341-353 reset_only_done_envs):
+ * with on != 0 a replica whose episode ends in a step restarts before the step call returns control of the stream --
+ * its state and observations are those of the fresh episode, `done` and the rewards stay the terminal step's.
+ * one-step-economy does it inside the step launch (the terminal observations, which nothing could read before they
+ * are overwritten, are not written at all); the other scenarios enqueue their reset kernel, masked with `done`,
+ * right behind the step.  AIE_E_UNSUPPORTED for scenarios whose reset has a host-side part (uniform/, quadrant/,
+ * multi_zone/ layouts).  Episode metrics of a finished episode are gone once it restarts. */
+int aie_set_auto_reset(aie_env* env, int on);
+
+/* Which step kernel runs this environment: >= 0 = a compile-time instance (the configuration's parameter block folded
+ * into the code, csrc/aie_spec_generated.h), -1 = the generic kernel. */
+int aie_step_kernel_instance(aie_env* env);
 
 /* Same counter RNG, but each sub-action is drawn uniformly among the entries that the
  * CURRENT action masks allow (obs_a_action_mask / obs_p_action_mask; NO-OP is always

@@ -553,31 +553,42 @@ def test_masked_action_sampler_respects_masks(multi):
         assert seen_move.all()
 
 
-@pytest.mark.gpu
-def test_reward_log_slots_follow_the_steps():
-    """aie_set_reward_log: every step also writes (rewards, done) into the next slot of the caller's log."""
-    import torch
+def _reward_log_cases():
+    from helpers import load_covid_golden
     from test_oracle_vs_reference import BASE, GTB
 
-    cfg = dict(BASE, components=GTB, episode_length=5)
+    c = _auto_reset_cases()
+    covid = dict(load_covid_golden("c4_covid_variant")["cfg"], scenario_name="CovidAndEconomySimulation")
+    return {"gather_trade_build": dict(BASE, components=GTB, episode_length=5), "one_step_economy": c["one_step_economy"],
+            "covid": covid}
+
+
+@pytest.mark.parametrize("case", ["gather_trade_build", "one_step_economy", "covid"])
+def test_reward_log_slots_follow_the_steps(case):
+    """aie_set_reward_log: every step also writes (rewards, done) into the next slot of the caller's log -- in every
+    scenario family (the multi-GPU exchange ships whole blocks of slots, sharding.RewardLogGather)."""
+    import torch
+
+    cfg = _reward_log_cases()[case]
     E = 40
     env = make_env(cfg, n_envs=E, device="cuda:0")
-    env.seed(4)
+    if case != "covid":
+        env.seed(4)
     env.reset()
     be = env.backend
+    n = be.n
     log = be.set_reward_log(3)
-    assert tuple(log.shape) == (3, E, cfg["n_agents"] + 2)
+    assert tuple(log.shape) == (3, E, n + 2)
     cur = be.sample_random_actions(7, 0, slot=0)
     slot = 0
     for t in range(8):
-        if t % 2:  # both step entry points fill the log
+        if t % 2 or case != "gather_trade_build":  # both step entry points fill the log
             env.step({"a": cur[0], "p": cur[1]})
             cur = be.sample_random_actions(7, 0, slot=slot)
         else:
             cur = be.step_sample_next(cur[0], cur[1], 7, 0, next_slot=slot ^ 1)
             slot ^= 1
         row = log[t % 3].cpu().numpy()
-        n = cfg["n_agents"]
         assert np.array_equal(row[:, :n], be.tensors["rewards_a"].cpu().numpy()), t
         assert np.array_equal(row[:, n], be.tensors["rewards_p"].cpu().numpy()), t
         assert np.array_equal(row[:, n + 1] > 0.5, be.tensors["done"].cpu().numpy().astype(bool)), t
@@ -587,6 +598,44 @@ def test_reward_log_slots_follow_the_steps():
     be.set_reward_log(0)
     env.step({"a": cur[0], "p": cur[1]})
     assert torch.equal(log, before)
+
+
+def test_reward_log_gather_over_rccl():
+    """sharding.RewardLogGather on the real collective backend: an RCCL ("nccl") process group over whatever GPUs
+    this process sees (one rank here; the multi-rank logic is covered by the gloo tests): blocks of 4 steps travel
+    through dist.gather and arrive with exactly the rewards / done flags the steps produced."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from ai_economist_amd.sharding import RewardLogGather
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        env = make_env(dict(C2, episode_length=50), n_envs=64, device="cuda:0")
+        env.seed(2)
+        env.reset()
+        be = env.backend
+        g = RewardLogGather(be, steps_per_gather=4, keep=True, force_collective=True)
+        want = []
+        for t in range(12):
+            a, p = be.sample_random_actions(seed=9)
+            be.step(a, p)
+            want.append(torch.cat([be.tensors["rewards_a"], be.tensors["rewards_p"][:, None],
+                                   be.tensors["done"].to(torch.float32)[:, None]], dim=1).clone())
+            g.after_step()
+        g.finish()
+        assert g.n_collectives == 3 and len(g.received) == 3
+        got = torch.cat([blk[0] for blk in g.received], dim=0)  # rank 0's slots, [12, E, n + 2]
+        assert torch.equal(got, torch.stack(want))
+    finally:
+        dist.destroy_process_group()
 
 
 def test_error_flags_for_what_the_reference_raises():
@@ -669,3 +718,51 @@ def test_compile_time_instance_equals_generic_kernel(n_agents):
             for k in b_ref.tensors:
                 assert torch.equal(b_ref.tensors[k], b_spec.tensors[k]), "step %d: %s differs" % (t + 1, k)
     del b_gen, b_other
+
+
+def _auto_reset_cases():
+    rs = np.random.RandomState(4)
+    ose = dict(scenario_name="one-step-economy", n_agents=12, world_size=[1, 1], episode_length=3,
+               components=[["SimpleLabor", {"skills": [float(x) for x in np.sort(1 + rs.rand(12) * 2)]}],
+                           ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+                                                   "tax_model": "model_wrapper"}]])
+    gtb = dict(C2, episode_length=7, starting_agent_coin=15, resource_regen_prob=0.05,
+               env_layout_file="uniform_25x25_25each_65clump.txt")
+    return {"one_step_economy": ose, "gather_trade_build": gtb}
+
+
+@pytest.mark.parametrize("case", ["one_step_economy", "gather_trade_build"])
+def test_auto_reset_equals_step_then_masked_reset(case):
+    """aie_set_auto_reset: a replica that ends its episode restarts inside (one-step-economy) / right behind (others) the
+    step -- the same state as step + reset(done) from the host, with the terminal step's rewards and `done` kept."""
+    import torch
+
+    cfg = _auto_reset_cases()[case]
+    envs = [make_env(cfg, n_envs=32, device="cuda:0") for _ in range(2)]
+    for env in envs:
+        env.seed(6)
+        env.reset()
+    b_auto, b_ref = envs[0].backend, envs[1].backend
+    # de-phase: half of the replicas restart one step in
+    a, p = b_ref.sample_random_actions(seed=3)
+    for b in (b_auto, b_ref):
+        b.step(a, p)
+        b.reset(torch.as_tensor((np.arange(32) % 2).astype(np.uint8), device="cuda:0"))
+    b_auto.set_auto_reset(True)
+    T = cfg["episode_length"]
+    for t in range(3 * T + 2):
+        a, p = b_ref.sample_random_actions(seed=3)
+        b_auto.step(a, p)
+        b_ref.step(a, p)
+        done = b_ref.tensors["done"].clone()
+        rew_a, rew_p = b_ref.tensors["rewards_a"].clone(), b_ref.tensors["rewards_p"].clone()
+        if bool(done.any()):
+            b_ref.reset(done)
+        torch.cuda.synchronize()
+        assert torch.equal(b_auto.tensors["done"], done), "step %d: done" % (t + 1)
+        assert torch.equal(b_auto.tensors["rewards_a"], rew_a) and torch.equal(b_auto.tensors["rewards_p"], rew_p)
+        for k, v in b_ref.tensors.items():
+            if k in ("done", "rewards_a", "rewards_p") or k.startswith("metrics_"):
+                continue
+            assert torch.equal(v, b_auto.tensors[k]), "step %d: %s differs" % (t + 1, k)
+    assert int(b_auto.tensors["completions"].min()) >= 2

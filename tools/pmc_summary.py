@@ -13,18 +13,21 @@ import statistics as st
 import sys
 
 fetch_csv, write_csv, out = sys.argv[1:4]
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "aie_step_kernel"  # substring of the kernel name
 
 
-def col(path, name, kernel="aie_step_kernel"):
+def col(path, name, kernel=None):
+    kernel = kernel or KERNEL
     return [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-            if r["Kernel_Name"] == kernel and r["Counter_Name"] == name]
+            if kernel in r["Kernel_Name"] and "reset" not in r["Kernel_Name"] and r["Counter_Name"] == name
+            and (kernel != "aie_step_kernel" or "_log" not in r["Kernel_Name"])]
 
 
 f = col(fetch_csv, "FETCH_SIZE")
 w = col(write_csv, "WRITE_SIZE")
 fill = [float(r["Counter_Value"]) for r in csv.DictReader(open(write_csv)) if "FillFunctor<unsigned char>" in r["Kernel_Name"]]
 res = {
-    "kernel": "aie_step_kernel",
+    "kernel": KERNEL,
     "launches": len(f),
     "FETCH_SIZE_KiB_mean": st.mean(f),
     "WRITE_SIZE_KiB_mean": st.mean(w),
