@@ -5,7 +5,7 @@ by env.py purely as the owner of device memory / streams.
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_AGENTS = 64
 MAX_AGENTS_WIDE = 128
 MAX_COMPONENTS = 8
@@ -46,14 +46,14 @@ class AieCovidConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
         "num_stringency_levels", "beta_delay", "filter_len", "num_filters", "action_cooldown_period",
         "subsidy_interval", "num_subsidy_levels", "delivery_interval", "time_when_vaccine_delivery_begins",
-        "reserved_")] + [(k, C.c_double) for k in (
+        "filter_recurrence")] + [(k, C.c_double) for k in (
             "death_rate", "gamma", "value_of_life", "daily_production_per_worker",
             "infection_too_sick_to_work_rate", "population_between_age_18_65", "risk_free_interest_rate",
             "economic_reward_crra_eta", "planner_health_norm", "planner_economic_norm",
             "min_marginal_planner_health_index", "max_marginal_planner_health_index",
             "min_marginal_planner_economic_index", "max_marginal_planner_economic_index",
             "weightage_on_marginal_planner_health_index", "weightage_on_marginal_planner_economic_index",
-            "reward_normalization_factor")]
+            "reward_normalization_factor")] + [("filter_decay", C.c_double * COVID_MAX_FILTERS), ("filter_tail", C.c_double * COVID_MAX_FILTERS)]
 
 
 class AieConfig(C.Structure):

@@ -228,7 +228,14 @@ static int copy_tensor(aie_env* env, const char* name, void* host, int64_t bytes
 }
 
 int aie_upload(aie_env* env, const char* name, const void* host, int64_t bytes) {
-  return copy_tensor(env, name, const_cast<void*>(host), bytes, true);
+  const int rc = copy_tensor(env, name, const_cast<void*>(host), bytes, true);
+  if (rc == AIE_OK && env->P.c.scenario == AIE_SCN_COVID && strcmp(name, "model_stringency_level_history_0") == 0) {
+    // what every reset derives from this table is derived once, here (history-format image, filter sums at t = 0)
+    hipLaunchKernelGGL(aie_covid_prepare_kernel, dim3(1), dim3(AIE_NT), 0, 0, env->d_params, env->arena);
+    AIE_HIP_CHECK(env, hipGetLastError());
+    AIE_HIP_CHECK(env, hipDeviceSynchronize());
+  }
+  return rc;
 }
 int aie_download(aie_env* env, const char* name, void* host, int64_t bytes) {
   return copy_tensor(env, name, host, bytes, false);
@@ -327,7 +334,7 @@ int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t
     snprintf(env->err, sizeof(env->err), "aie_step_sample_next: the next-action buffers must differ from the current ones");
     return AIE_E_INVALID;
   }
-  if (env->P.c.scenario != AIE_SCN_GTB || env->step_waves != 2) {  // no fused kernel: two launches
+  if (env->step_waves != 2) {  // development schedule without the fused draw: two launches
     int rc = aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{nullptr, nullptr, 0, 0, 0, nullptr});
     if (rc != AIE_OK) return rc;
     return aie_sample_random_actions(env, seed, global_env_offset, d_next_a, d_next_p, stream);
@@ -353,7 +360,9 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
     const dim3 g((unsigned)env->P.E), b(AIE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define AIE_CV_LAUNCH(FN) \
-  case FN: hipLaunchKernelGGL(aie_covid_step_kernel<FN>, g, b, 0, st, env->d_params, env->arena, d_actions_a, d_actions_p, next.rew_log); break
+  case FN: if (env->P.c.covid.filter_recurrence) hipLaunchKernelGGL((aie_covid_step_kernel<FN, true>), g, b, 0, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); \
+           else hipLaunchKernelGGL((aie_covid_step_kernel<FN, false>), g, b, 0, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); \
+           break
     switch (env->P.cv_F) {
       AIE_CV_LAUNCH(1); AIE_CV_LAUNCH(2); AIE_CV_LAUNCH(3); AIE_CV_LAUNCH(4);
       AIE_CV_LAUNCH(5); AIE_CV_LAUNCH(6); AIE_CV_LAUNCH(7); AIE_CV_LAUNCH(8);
@@ -362,7 +371,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
 #undef AIE_CV_LAUNCH
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
-                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next.rew_log);
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
   else if (env->step_waves == 2 && (env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT ||
                                     env->P.dev_skip_mask != 0 || env->P.dev_trace != nullptr))
     hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,

@@ -134,6 +134,46 @@ __device__ __forceinline__ void cv_write_observations(const aie_params& P, uint8
 
 }  // namespace aie
 
+// One-time derivation of what every reset needs from the shared pre-episode table (run by aie_upload whenever
+// "model_stringency_level_history_0" is written): the table in the per-replica history format (reset then copies
+// 16-byte rows instead of assembling them byte by byte) and, with filter_recurrence, A_0 -- each filter's discounted
+// sum of the pre-episode level changes (Horner, oldest first).  One wavefront, lane = state.
+extern "C" __global__ void __launch_bounds__(AIE_NT)
+    aie_covid_prepare_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena) {
+  const aie_params& P = *params;
+  const int s = (int)threadIdx.x, n = P.n, L = P.cv_L;
+  const bool on = s < n;
+  const int sl = on ? s : n - 1;
+  const uint8_t* h0 = arena + P.a_cv_hist0;
+  uint8_t* img = arena + P.a_cv_hist0c;
+  for (int c = 0; c < P.cv_nch; ++c) {
+    if (s * 16 < P.cv_row) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (on) {
+        for (int j = 0; j < 16; ++j) {
+          const int tau = 16 * c + j;
+          if (tau <= L) w[j >> 2] |= (uint32_t)h0[tau * n + s] << (8 * (j & 3));
+        }
+      }
+      *reinterpret_cast<uint4*>(img + (int64_t)c * P.cv_row + s * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  if (P.c.covid.filter_recurrence) {
+    double* acc0 = reinterpret_cast<double*>(arena + P.a_cv_acc0);
+    for (int f = 0; f < P.cv_F; ++f) {
+      const double r = P.c.covid.filter_decay[f];
+      double A = 0.0;
+      int prev = h0[sl];
+      for (int tau = 1; tau <= L; ++tau) {
+        const int lev = h0[tau * n + sl];
+        A = A * r + (double)(lev - prev);
+        prev = lev;
+      }
+      acc0[f * 64 + s] = on ? A : 0.0;
+    }
+  }
+}
+
 // ---- reset: CovidAndEconomyEnvironment.reset_starting_layout / reset_agent_states /
 // additional_reset_steps (covid19_env.py:1175-1293) + the components' additional_reset_steps.
 extern "C" __global__ void __launch_bounds__(AIE_NT)
@@ -149,22 +189,21 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
   float* st = reinterpret_cast<float*>(rec + P.o_cv_state);
   const double* K = reinterpret_cast<const double*>(arena + P.a_cv_consts);
   uint8_t* hist = cv_hist_base(P, arena, e);
-  // history: days -L..0 from the shared table, the episode's own days zeroed
+  // history: days -L..0 from the shared table (already in the history format: aie_covid_prepare_kernel), the
+  // episode's own days zeroed
   const uint8_t* h0 = arena + P.a_cv_hist0;
-  for (int c = 0; c < P.cv_nch; ++c) {
-    if (s * 16 < P.cv_row) {
-      uint32_t w[4] = {0u, 0u, 0u, 0u};
-      if (on) {
-        for (int j = 0; j < 16; ++j) {
-          const int tau = 16 * c + j;
-          if (tau <= L) w[j >> 2] |= (uint32_t)h0[tau * n + s] << (8 * (j & 3));
-        }
-      }
-      *reinterpret_cast<uint4*>(hist + (int64_t)c * P.cv_row + s * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-  }
+  const uint8_t* img = arena + P.a_cv_hist0c;
+  if (s * 16 < P.cv_row)
+    for (int c = 0; c < P.cv_nch; ++c)
+      *reinterpret_cast<uint4*>(hist + (int64_t)c * P.cv_row + s * 16) =
+          *reinterpret_cast<const uint4*>(img + (int64_t)c * P.cv_row + s * 16);
   CvLane a;
   const int sl = on ? s : n - 1;
+  if (P.c.covid.filter_recurrence) {  // A_0 of every filter (aie_covid_prepare_kernel)
+    double* accs = reinterpret_cast<double*>(rec + P.o_cv_acc);
+    const double* acc0 = reinterpret_cast<const double*>(arena + P.a_cv_acc0);
+    for (int f = 0; f < P.cv_F; ++f) accs[f * 64 + s] = acc0[f * 64 + s];
+  }
   a.S = (float)K[AIE_CV_K_S0 * 64 + sl];
   a.I = (float)K[AIE_CV_K_I0 * 64 + sl];
   a.R = (float)K[AIE_CV_K_R0 * 64 + sl];
@@ -203,11 +242,11 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
 }
 
 // ---- one env.step() (base_env.py:929-1032) ----
-template <int F>
+template <int F, bool RECUR>
 __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     aie_covid_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                          const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
-                          float* __restrict__ rew_log /* this step's slot of aie_set_reward_log, or nullptr */) {
+                          const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  float* __restrict__ rew_log = next.rew_log;  // this step's slot of aie_set_reward_log, or nullptr
   using namespace aie;
   __shared__ float red[3][64];
   const aie_params& P = *params;
@@ -282,13 +321,29 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   // lane in flight (HBM latency >> the ~300 cycles of FMA work in one chunk).
   double unemployed;
   {
-    const double* __restrict__ G = reinterpret_cast<const double*>(arena + P.a_cv_filters);  // [row][F]
     double acc[F];
+    if constexpr (RECUR) {
+      // The taps are exp(-age / lambda_f): each filter's discounted delta sum over the window obeys
+      //   A_t = r_f * (A_{t-1} - r_f^(L-1) * d_old) + d_new,
+      // d_new = today's level change (tap L-1, weight 1), d_old = the change between history days t-1 and t, which
+      // had tap 0 at step t-1 and now leaves the window.  O(1) per step and state instead of L * F multiply-adds
+      // and a 601-byte history read; A_0 comes from the reset kernel (Horner over the pre-episode days).
+      double* accs = reinterpret_cast<double*>(rec + P.o_cv_acc);
+      const int lev_t = *cv_hist_at(P, hist, sl, t), lev_tm1 = *cv_hist_at(P, hist, sl, t - 1);
+      const double d_old = (double)(lev_t - lev_tm1), d_new = (double)(a.level - prev_level);
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const double r = V.filter_decay[f];
+        acc[f] = r * (accs[f * 64 + sl] - V.filter_tail[f] * d_old) + d_new;
+        if (on) accs[f * 64 + s] = acc[f];
+      }
+    } else {
+    const double* __restrict__ G = reinterpret_cast<const double*>(arena + P.a_cv_filters);  // [row][F]
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = 0.0;
     const int c0 = t >> 4;
     const int c_today = (t + L) >> 4, sh_today = 8 * ((t + L) & 3), q_today = ((t + L) & 15) >> 2;
-    const int ngroups = (P.dev_skip_mask & 1) ? 0 : ((L >> 4) + 2 + AIE_CV_GROUP - 1) / AIE_CV_GROUP;
+    const int ngroups = ((L >> 4) + 2 + AIE_CV_GROUP - 1) / AIE_CV_GROUP;
     const uint8_t* row = hist + sl * 16 + (int64_t)c0 * P.cv_row;
     int carry = 0;
     uint4 cur[AIE_CV_GROUP], nxt[AIE_CV_GROUP];
@@ -329,6 +384,7 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
 #pragma unroll
       for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = nxt[k];
     }
+    }  // direct sum over the uploaded taps
     double x = 0.0;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
@@ -422,4 +478,8 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   // ---- observations + masks for the new timestep ----
   __syncthreads();  // today's level byte (written above) may be the lagged observation when beta_delay == 1
   cv_write_observations(P, arena, e, s, t, a, sub_level, hist);
+  if (next.a || next.p) {  // aie_step_sample_next: the uniform random policy's draw for the next step, one lane per slot
+    const int per_env = P.n * P.act_a_width + P.act_p_width;
+    for (int j = s; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, e, j, next.a, next.p);
+  }
 }

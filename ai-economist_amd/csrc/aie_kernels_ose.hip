@@ -560,8 +560,8 @@ __device__ __forceinline__ void ose_reset_body(const Ctx& c, const OseScratch& s
 // BaseEnvironment.step (base_env.py:929-1032) for the one-step-economy scenario
 extern "C" __global__ void __launch_bounds__(OSE_NT)
 aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
-                    float* __restrict__ rew_log /* this step's slot of aie_set_reward_log, or nullptr */) {
+                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  float* __restrict__ rew_log = next.rew_log;  // this step's slot of aie_set_reward_log, or nullptr
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   using namespace aie;
   const aie_params& P = *params;
@@ -640,6 +640,10 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   }
   __syncthreads();
   if (restart) ose_reset_body(c, s, arena, true);
+  if (next.a || next.p) {  // aie_step_sample_next: the uniform random policy's draw for the next step
+    const int per_env = P.n * P.act_a_width + P.act_p_width;
+    for (int j = tid; j < per_env; j += OSE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, c.e, j, next.a, next.p);
+  }
   ose_store_record(c, arena, m);
 }
 

@@ -164,9 +164,14 @@ typedef struct aie_params {
   int32_t o_cv_subsidy_level;
   int32_t o_cv_sums;     /* record: AIE_CV_SUM_* float64 rows of 64 lanes                 */
   int32_t o_cv_p_index;  /* record: planner Health Index, Economic Index (float32 x 2)    */
+  int32_t o_cv_acc;      /* record: float64 [F] rows of 64 lanes: each filter's discounted sum of stringency deltas
+                          * over the current window (filter_recurrence), else unused       */
   int64_t a_cv_consts;   /* AIE_CV_K_* float64 rows of 64 (shared by all replicas)         */
   int64_t a_cv_filters;  /* float64 [pad+L+pad][F]                                              */
   int64_t a_cv_hist0;    /* uint8 [L+1][n]   stringency levels of the L days before t=0 + t=0 */
+  int64_t a_cv_hist0c;   /* uint8 [nch][cv_row]: the same days in the per-replica history format (what reset copies);
+                          * derived from a_cv_hist0 by aie_covid_prepare_kernel whenever that table is uploaded  */
+  int64_t a_cv_acc0;     /* float64 [F][64]: every filter's discounted delta sum at t = 0 (filter_recurrence), ditto */
   int64_t a_cv_lag_obs;  /* uint8 [beta_delay][n]                                          */
   int64_t a_cv_hist;     /* uint8 [E][nch][cv_row]                                         */
   int64_t a_cv_obs_a;    /* float32 [E][cv_nrow_obs][n]                                    */
@@ -188,6 +193,7 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->arena_bytes = 0;
   p->a_saez = p->a_events = p->a_metrics = 0;
   p->a_cv_consts = p->a_cv_filters = p->a_cv_hist0 = p->a_cv_lag_obs = p->a_cv_hist = p->a_cv_obs_a = p->a_cv_obs_p = 0;
+  p->a_cv_hist0c = p->a_cv_acc0 = 0;
   p->dev_skip_mask = 0;
   p->dev_trace = 0;
   p->auto_reset = 0;
@@ -312,6 +318,9 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   if (!(v->economic_reward_crra_eta >= 0.0)) AIE__FAIL("economic_reward_crra_eta must be >= 0");
   if (v->economic_reward_crra_eta == 1.0) AIE__FAIL("economic_reward_crra_eta == 1 divides by zero (covid19_env.py:1074)");
   if (!(v->reward_normalization_factor != 0.0)) AIE__FAIL("reward_normalization_factor must be non-zero");
+  if (v->filter_recurrence)
+    for (int f = 0; f < v->num_filters; ++f)
+      if (!(v->filter_decay[f] > 0.0 && v->filter_decay[f] < 1.0)) AIE__FAIL("filter_decay[%d] must be in (0, 1)", f);
 
   p->c = *c;
   p->E = c->n_envs;
@@ -340,6 +349,7 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   p->o_cv_state = aie__rec(&cur, 4 * 64 * AIE_CV_ST_COUNT, 256);
   p->o_cv_cooldown = aie__rec(&cur, 4 * 64, 256);
   p->o_cv_sums = aie__rec(&cur, 8 * 64 * AIE_CV_SUM_COUNT, 256);
+  p->o_cv_acc = aie__rec(&cur, 8 * 64 * (v->filter_recurrence ? v->num_filters : 0), 256);
   p->o_cv_subsidy_level = aie__rec(&cur, 4, 4);
   p->o_cv_p_index = aie__rec(&cur, 8, 4);
   p->o_timestep = aie__rec(&cur, 4, 4);
@@ -354,6 +364,8 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   p->a_cv_filters = a;
   a = aie__align(a + (int64_t)(AIE_CV_TAP_PAD_FRONT + p->cv_L + AIE_CV_TAP_PAD_BACK) * p->cv_F * 8, 256);
   p->a_cv_hist0 = a;   a = aie__align(a + (int64_t)(p->cv_L + 1) * n, 256);
+  p->a_cv_hist0c = a;  a = aie__align(a + (int64_t)p->cv_nch * p->cv_row, 256);
+  p->a_cv_acc0 = a;    a = aie__align(a + (int64_t)AIE_COVID_MAX_FILTERS * 64 * 8, 256);
   p->a_cv_lag_obs = a; a = aie__align(a + (int64_t)v->beta_delay * n, 256);
   p->a_cv_hist = a;    a = aie__align(a + E * (int64_t)p->cv_nch * p->cv_row, 256);
   p->a_cv_obs_a = a;   a = aie__align(a + E * no, 256);
@@ -373,6 +385,10 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
     for (int k = 0; k < AIE_CV_SUM_COUNT; ++k)
       aie__add(tt, sum_name[k], AIE_F64, r0 + p->o_cv_sums + 512 * k, rs, 1, n, 0, 0, 0, E);
     aie__add(tt, "planner_health_economic_index", AIE_F32, r0 + p->o_cv_p_index, rs, 1, 2, 0, 0, 0, E);
+    if (v->filter_recurrence) {
+      aie__add(tt, "filter_discounted_delta_sums", AIE_F64, r0 + p->o_cv_acc, rs, 2, p->cv_F, n, 0, 0, E);
+      tt->t[tt->n - 1].stride[1] = 512;
+    }
     for (int k = 0; k < AIE_CV_ST_COUNT; ++k)
       aie__add(tt, st_name[k], AIE_F32, r0 + p->o_cv_state + 256 * k, rs, 1, n, 0, 0, 0, E);
     aie__add(tt, "cooldown_until", AIE_I32, r0 + p->o_cv_cooldown, rs, 1, n, 0, 0, 0, E);

@@ -24,13 +24,19 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
                  path_to_data_and_fitted_params="", start_date="2020-03-22", pop_between_age_18_65=0.6,
                  infection_too_sick_to_work_rate=0.1, risk_free_interest_rate=0.03,
                  economic_reward_crra_eta=2, health_priority_scaling_agents=1,
-                 health_priority_scaling_planner=1, reward_normalization_factor=1, **base_env_kwargs):
+                 health_priority_scaling_planner=1, reward_normalization_factor=1, exact_filter_sums=False,
+                 **base_env_kwargs):
         if use_real_world_data or use_real_world_policies:
             # covid19_env.py:126-135, 735-757: replays the recorded data / policies instead of
             # simulating -- a data-loader mode, not part of the accelerated path.
             raise NotImplementedError("use_real_world_data / use_real_world_policies are not supported")
         self.use_real_world_data = False
         self.use_real_world_policies = False
+        # extension (not a reference kwarg): True re-sums the whole 600-day filter window every step over the
+        # reference's float32 taps, as the reference does; the default updates each filter's discounted delta sum
+        # in O(1) per step, exploiting that the taps ARE exp(-age / lambda) (covid19_env.py:242-247) -- the two agree
+        # to ~1e-7 relative (float32 rounding of the taps), two orders inside the comparison tolerance
+        self.exact_filter_sums = bool(exact_filter_sums)
         self.model = covid19_model.build_model(
             start_date=start_date, pop_between_age_18_65=pop_between_age_18_65,
             infection_too_sick_to_work_rate=infection_too_sick_to_work_rate,
@@ -91,6 +97,11 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
         v.filter_len = int(m["filter_len"])
         v.num_filters = int(m["num_filters"])
         v.time_when_vaccine_delivery_begins = int(self.component_constants["time_when_vaccine_delivery_begins"])
+        v.filter_recurrence = 0 if self.exact_filter_sums else 1
+        for f, lam in enumerate(np.asarray(m["conv_lambdas"], np.float64)):
+            r = float(np.exp(-1.0 / lam))
+            v.filter_decay[f] = r
+            v.filter_tail[f] = float(np.exp(-(int(m["filter_len"]) - 1) / lam))
         for k in ("death_rate", "gamma", "value_of_life", "daily_production_per_worker",
                   "infection_too_sick_to_work_rate", "population_between_age_18_65", "risk_free_interest_rate",
                   "economic_reward_crra_eta", "planner_health_norm", "planner_economic_norm",

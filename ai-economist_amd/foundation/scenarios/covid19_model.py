@@ -78,6 +78,7 @@ def build_model(start_date="2020-03-22", pop_between_age_18_65=0.6, infection_to
     lambdas = np.array(d["fp_CONV_LAMBDAS"], dtype=F32)
     m["filter_len"] = filter_len
     m["num_filters"] = len(lambdas)
+    m["conv_lambdas"] = lambdas
     m["unemployment_bias"] = np.array(d["fp_UNEMPLOYMENT_BIAS"], dtype=F32)
     gw = np.array(d["fp_GROUPED_CONVOLUTIONAL_FILTER_WEIGHTS"], dtype=F32)
     m["conv_weights"] = gw.reshape(n, len(lambdas))

@@ -108,9 +108,13 @@ def layout_bytes_per_env_step(be, wl):
     obs = sum(t[0].numel() * t.element_size() for k, t in be.tensors.items() if k.startswith("obs_"))
     n = be.n
     if wl == "C4":
-        L = int(be.cfg.covid.filter_len)
+        L, F = int(be.cfg.covid.filter_len), int(be.cfg.covid.num_filters)
         state_rw = 2 * (8 + 1) * n * 4 + n
-        b = dict(history_window=(L + 1) * n, state_rw=state_rw, obs=obs, act=(n + 1) * 4, rew_done=(n + 1) * 4 + 1)
+        if be.cfg.covid.filter_recurrence:  # O(1) filter update: F float64 sums per state r+w, 5 history bytes per state
+            b = dict(filter_sums_rw=2 * F * n * 8, history_bytes=6 * n, state_rw=state_rw, obs=obs, act=(n + 1) * 4,
+                     rew_done=(n + 1) * 4 + 1)
+        else:
+            b = dict(history_window=(L + 1) * n, state_rw=state_rw, obs=obs, act=(n + 1) * 4, rew_done=(n + 1) * 4 + 1)
     else:
         key = "cells" if "cells" in be.descs else "inv_coin"
         rec = be.descs[key][2][0]  # per-replica record bytes = stride of any record field along the replica axis
@@ -259,7 +263,7 @@ class Rollout:
         self.T = int(env.episode_length)
         self.E = self.be.E
         self.t = 0  # rollout steps since the common reset
-        self.fused = hasattr(self.be, "step_sample_next") and wl in ("C2", "C3")
+        self.fused = True  # every scenario draws the next step's random actions inside the step launch
         # C5 (2-step episodes): auto-reset -- the replicas restart inside the step launch that ends their episode
         # (aie_set_auto_reset), as a vectorised trainer runs it; no separate reset launches
         self.auto_reset = wl == "C5" and auto_reset

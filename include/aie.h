@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AIE_ABI_VERSION 5
+#define AIE_ABI_VERSION 6
 
 #define AIE_MAX_AGENTS 64      /* mobile agents per replica, spatial scenarios (one lane each) */
 #define AIE_MAX_AGENTS_WIDE 128 /* mobile agents per replica, map-less one-step-economy        */
@@ -127,7 +127,11 @@ typedef struct aie_covid_config {
   int32_t num_subsidy_levels;
   int32_t delivery_interval;              /* VaccinationCampaign kwarg                         */
   int32_t time_when_vaccine_delivery_begins; /* days from start_date to vaccine_delivery_start_date */
-  int32_t reserved_;
+  int32_t filter_recurrence;              /* 1: the unemployment filters are exp(-age / lambda_f) (covid19_env.py:242-247)
+                                             and filter_decay[] holds exp(-1 / lambda_f): the step updates each
+                                             filter's discounted delta sum in O(1) (A_t = r (A_{t-1} - r^{L-1} d_old)
+                                             + d_new) instead of re-summing the filter_len-day window; 0: direct sum
+                                             over the uploaded taps (any filter shape)                              */
   double death_rate, gamma;               /* SIR_MORTALITY, SIR_GAMMA                          */
   double value_of_life;
   double daily_production_per_worker;
@@ -140,6 +144,8 @@ typedef struct aie_covid_config {
   double min_marginal_planner_economic_index, max_marginal_planner_economic_index;
   double weightage_on_marginal_planner_health_index, weightage_on_marginal_planner_economic_index;
   double reward_normalization_factor;
+  double filter_decay[AIE_COVID_MAX_FILTERS]; /* r_f = exp(-1 / CONV_LAMBDAS[f]), used iff filter_recurrence      */
+  double filter_tail[AIE_COVID_MAX_FILTERS];  /* r_f^(filter_len - 1): the weight with which a delta leaves the window */
 } aie_covid_config;
 
 /* ---- configuration: the kwargs of make_env_instance + component kwargs ---------- */

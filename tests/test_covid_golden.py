@@ -271,3 +271,41 @@ def test_covid_masked_reset_and_config_errors():
     bad["use_real_world_policies"] = True
     with pytest.raises(NotImplementedError):
         hip_env(bad, 1)
+
+
+@pytest.mark.gpu
+def test_covid_filter_recurrence_vs_exact_window_sums():
+    """The default step updates each unemployment filter's discounted delta sum in O(1) (the taps are exp(-age/lambda),
+    covid19_env.py:242-247); `exact_filter_sums=True` re-sums the 600-day window over the reference's float32 taps.
+    Same actions through both: identical integer state, `unemployed` within 4e-6 relative (the reference's taps are
+    float32 exp(-float32(age) / lambda): up to ~1.3e-6 off the exponential law they sample), everything downstream
+    within the suite's tolerances."""
+    import torch
+
+    g = load_covid_golden("c4_covid_51ag")
+    cfg = g["cfg"]
+    E, T = 96, 200
+    env_r = hip_env(cfg, n_envs=E)
+    env_x = hip_env(dict(cfg, exact_filter_sums=True), n_envs=E)
+    assert "filter_discounted_delta_sums" in env_r.tensors and "filter_discounted_delta_sums" not in env_x.tensors
+    env_r.reset()
+    env_x.reset()
+    rng = np.random.RandomState(3)
+    worst = 0.0
+    for k in range(1, T + 1):
+        a = rng.randint(0, 11, size=(E, 51)).astype(np.int32)
+        a[rng.rand(E, 51) < 0.5] = 0
+        p = rng.randint(0, 21, size=(E, 1)).astype(np.int32)
+        for env in (env_r, env_x):
+            env.step({"a": torch.as_tensor(a, device="cuda"), "p": torch.as_tensor(p, device="cuda")})
+        if k % 20 == 0 or k == T:
+            tr, tx = env_r.tensors, env_x.tensors
+            for name in ("cooldown_until", "subsidy_level", "timestep", "stringency_history_chunks"):
+                assert torch.equal(tr[name], tx[name]), name
+            u_r, u_x = tr["unemployed"].double(), tx["unemployed"].double()
+            worst = max(worst, float(((u_r - u_x).abs() / u_x.abs().clamp_min(1.0)).max()))
+            for name, tol in STATE_TOL.items():
+                np.testing.assert_allclose(tr[name].cpu().numpy(), tx[name].cpu().numpy(), rtol=tol, atol=1e-3, err_msg=name)
+            np.testing.assert_allclose(tr["rewards_a"].cpu().numpy(), tx["rewards_a"].cpu().numpy(), rtol=0, atol=2e-5)
+    assert worst < 4e-6, "unemployed: recurrence vs exact window sums differ by %.3g relative" % worst
+    print("covid filter recurrence: max relative deviation of `unemployed` from the exact window sums: %.3g" % worst)

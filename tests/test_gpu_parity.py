@@ -215,32 +215,34 @@ def test_hip_matches_oracle_on_random_rollouts(n_agents, E, T):
             _compare_all(be, oracle, "after episode reset")
 
 
-def test_step_sample_next_equals_two_launches():
+@pytest.mark.parametrize("case", ["gather_trade_build", "one_step_economy", "covid"])
+def test_step_sample_next_equals_two_launches(case):
     """aie_step_sample_next == aie_step followed by aie_sample_random_actions: same actions, same
-    trajectory, bit for bit."""
+    trajectory, bit for bit -- in every scenario family."""
     import torch
 
-    cfg = dict(C2, episode_length=50)
+    cfg = dict(C2, episode_length=50) if case == "gather_trade_build" else _reward_log_cases()[case]
+    T = cfg["episode_length"]
     envs = [make_env(cfg, n_envs=96, device="cuda:0", env_offset=640) for _ in range(2)]
     for env in envs:
-        env.seed(9)
+        if case != "covid":
+            env.seed(9)
         env.reset()
     b0, b1 = envs[0].backend, envs[1].backend
     cur = b1.sample_random_actions(seed=4242, env_offset=640, slot=0)
     slot = 0
-    for t in range(60):
+    for t in range(min(60, 2 * T + 3)):
         a, p = b0.sample_random_actions(seed=4242, env_offset=640)
         assert torch.equal(a, cur[0]) and torch.equal(p, cur[1]), "actions differ at step %d" % t
         b0.step(a, p)
         cur = b1.step_sample_next(cur[0], cur[1], seed=4242, env_offset=640, next_slot=slot ^ 1)
         slot ^= 1
-        if t == 49:
+        if (t + 1) % T == 0:
             b0.reset(b0.tensors["done"])
             b1.reset(b1.tensors["done"])
     torch.cuda.synchronize()
     assert torch.equal(b0.arena, b1.arena)
     with pytest.raises(ValueError):
-        b1.lib.aie_step_sample_next  # noqa: B018
         b1._check(b1.lib.aie_step_sample_next(b1.handle, cur[0].data_ptr(), cur[1].data_ptr(), 1, 0,
                                               cur[0].data_ptr(), cur[1].data_ptr(), None))
 
