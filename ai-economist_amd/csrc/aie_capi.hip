@@ -79,7 +79,7 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
   env->device = device;
   env->step_waves = 2;
   env->spec = -1;
-  if (cfg->scenario == AIE_SCN_GTB) {  // a compile-time instance exists for exactly this parameter block?
+  if (cfg->scenario != AIE_SCN_COVID) {  // a compile-time instance exists for exactly this parameter block?
     static aie_params norm;
     norm = env->P;
     aie_spec_normalize(&norm);
@@ -369,6 +369,16 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
       default: return AIE_E_UNSUPPORTED;
     }
 #undef AIE_CV_LAUNCH
+  } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY && env->spec >= 0 && env->P.ev_replicas == 0) {
+    const dim3 g((unsigned)env->P.E), b(OSE_NT);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define AIE_SPEC_LAUNCH_OSE(K) \
+  case K: hipLaunchKernelGGL(aie_ose_step_kernel_spec<K>, g, b, env->lds, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); break;
+    switch (env->spec) {
+      AIE_SPEC_LIST_OSE(AIE_SPEC_LAUNCH_OSE)
+      default: return AIE_E_INVALID;
+    }
+#undef AIE_SPEC_LAUNCH_OSE
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
@@ -382,7 +392,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
 #define AIE_SPEC_LAUNCH(K) \
   case K: hipLaunchKernelGGL(aie_step_kernel_spec<K>, g, b, env->lds, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); break;
     switch (env->spec) {
-      AIE_SPEC_LIST(AIE_SPEC_LAUNCH)
+      AIE_SPEC_LIST_GTB(AIE_SPEC_LAUNCH)
       default: return AIE_E_INVALID;
     }
 #undef AIE_SPEC_LAUNCH

@@ -37,8 +37,8 @@ __host__ __device__ inline size_t ose_lds_bytes(const aie_params& P) {
   return (b + 15) / 16 * 16;
 }
 
-__device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, int e, int tid, OseScratch& s,
-                                             uint8_t* arena) {
+__device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, const aie_params& R, uint8_t* lds, int e, int tid,
+                                             OseScratch& s, uint8_t* arena) {
   uint8_t* q = lds + rec_lds_bytes(P);
   int32_t* act_p = reinterpret_cast<int32_t*>(q);
   q += AIE_MAX_BRACKETS * 4;
@@ -52,13 +52,13 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, uint8_t* lds, i
   q += (4 * P.n + 2) * 8;
   s.tmpl_a = reinterpret_cast<float*>(q);
   s.tmpl_p = s.tmpl_a + pad4(P.FA > P.MA ? P.FA : P.MA);
-  uint8_t* met = arena + P.a_metrics + (int64_t)e * P.met_bytes;
-  int32_t* ev = e < P.ev_replicas ? reinterpret_cast<int32_t*>(arena + P.a_events + (int64_t)e * P.ev_stride) : nullptr;
-  return Ctx{P, P, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e};
+  uint8_t* met = arena + R.a_metrics + (int64_t)e * P.met_bytes;
+  int32_t* ev = e < P.ev_replicas ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * P.ev_stride) : nullptr;
+  return Ctx{P, R, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e};
 }
 
 __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {
-  const uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
+  const uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
   const uint4* src = reinterpret_cast<const uint4*>(g);
   uint4* dst = reinterpret_cast<uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
@@ -424,7 +424,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
   if (tid == 0) {
     s.tmpl_a[P.fa_time] = tval;
     s.tmpl_p[P.fp_time] = tval;
-    reinterpret_cast<float*>(arena + P.a_obs_p_time)[c.e] = tval;
+    reinterpret_cast<float*>(arena + c.R.a_obs_p_time)[c.e] = tval;
   }
   __syncthreads();
   // planner world-equality / world-normalized_per_capita_productivity (:161-172)
@@ -438,7 +438,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
   __syncthreads();
   // ---- agent flat vectors: the shared template with two per-agent entries ----
   {
-    const BufRsrc g = make_rsrc(arena + P.a_obs_a_flat + (int64_t)c.e * n * P.FA * 4, (uint32_t)(n * P.FA * 4));
+    const BufRsrc g = make_rsrc(arena + c.R.a_obs_a_flat + (int64_t)c.e * n * P.FA * 4, (uint32_t)(n * P.FA * 4));
     const int i_mr = P.has_tax ? P.fa_tax + NB + 2 + n : -1;
     const int i_sk = P.has_labor ? P.fa_labor : -1;
     if (i_sk >= 0) {  // SimpleLabor-skill = skill / pmsm: n divisions, one lane per agent (s.part is free until the rewards)
@@ -446,17 +446,17 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
       __syncthreads();
     }
     ose_store_rows(g, n, P.FA, s.tmpl_a, tid, i_mr, s.tmp, i_sk, s.part);
-    float* gt = reinterpret_cast<float*>(arena + P.a_obs_a_time) + (int64_t)c.e * n;
+    float* gt = reinterpret_cast<float*>(arena + c.R.a_obs_a_time) + (int64_t)c.e * n;
     for (int i = tid; i < n; i += OSE_NT) gt[i] = tval;
     if (P.FPA) {
-      float* gp = reinterpret_cast<float*>(arena + P.a_obs_p_agents) + (int64_t)c.e * n * P.FPA;
+      float* gp = reinterpret_cast<float*>(arena + c.R.a_obs_p_agents) + (int64_t)c.e * n * P.FPA;
       for (int i = tid; i < n; i += OSE_NT) {
         gp[i * 3 + 0] = (float)s.tmp[i];
         gp[i * 3 + 1] = (float)(R_F64(c, o_tax_last_income)[i] / (double)P.c.tax_period);
         gp[i * 3 + 2] = (float)R_F64(c, o_tax_last_marginal_rate)[i];
       }
     }
-    stream_out(s.tmpl_p, reinterpret_cast<float*>(arena + P.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
+    stream_out(s.tmpl_p, reinterpret_cast<float*>(arena + c.R.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
   }
   // ---- masks ----
   {
@@ -467,7 +467,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
     }
     // single-action: [NO-OP, hours...]; multi-action: [NO-OP, hours...] of the only subspace -- every agent's row is
     // the same; the row template goes through the (now free) agent template area
-    const BufRsrc g = make_rsrc(arena + P.a_obs_a_mask + (int64_t)c.e * n * P.MA * 4, (uint32_t)(n * P.MA * 4));
+    const BufRsrc g = make_rsrc(arena + c.R.a_obs_a_mask + (int64_t)c.e * n * P.MA * 4, (uint32_t)(n * P.MA * 4));
     __syncthreads();
     for (int q = tid; q < P.MA; q += OSE_NT) s.tmpl_a[q] = (q == 0 || P.n_sub_a == 0) ? 1.0f : on;
     __syncthreads();
@@ -479,7 +479,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
     }
     const bool pmulti = P.c.multi_action_mode_planner != 0;
     const float open = (P.n_sub_p && *R_I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
-    float* gp = reinterpret_cast<float*>(arena + P.a_obs_p_mask) + (int64_t)c.e * P.MP;
+    float* gp = reinterpret_cast<float*>(arena + c.R.a_obs_p_mask) + (int64_t)c.e * P.MP;
     for (int q = tid; q < P.MP; q += OSE_NT) {
       int j = -1;  // index of the discretised rate this entry stands for (-1: a NO-OP entry)
       if (P.n_sub_p == 0) j = -1;
@@ -493,7 +493,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
 }
 
 __device__ __forceinline__ void ose_store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m) {
-  uint8_t* g = arena + c.P.a_records + (int64_t)c.e * c.P.rec_bytes;
+  uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
   uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
@@ -519,7 +519,7 @@ __device__ __forceinline__ void ose_reset_body(const Ctx& c, const OseScratch& s
   if (c.ev && tid == 0) c.ev[0] = 0;
   for (int i = tid; i < n; i += OSE_NT) {
     R_F64(c, o_inv_coin)[i] = 0; R_F64(c, o_esc_coin)[i] = 0; R_F64(c, o_labor)[i] = 0;
-    R_F64(c, o_skill)[i] = P.has_labor ? P.c.labor_skills[i] : 0;
+    R_F64(c, o_skill)[i] = P.has_labor ? c.R.c.labor_skills[i] : 0;
     R_F64(c, o_production)[i] = 0;
     if (P.has_tax) {
       R_F64(c, o_tax_last_coin)[i] = 0; R_F64(c, o_tax_last_income)[i] = 0; R_F64(c, o_tax_last_marginal_rate)[i] = 0;
@@ -547,26 +547,28 @@ __device__ __forceinline__ void ose_reset_body(const Ctx& c, const OseScratch& s
   __syncthreads();
   ose_write_observations(c, s, arena, true);
   if (!keep_rewards) {
-    for (int i = tid; i < n; i += OSE_NT) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + i] = 0.0f;
+    for (int i = tid; i < n; i += OSE_NT) reinterpret_cast<float*>(arena + c.R.a_rew_a)[(int64_t)e * n + i] = 0.0f;
     if (tid == 0) {
-      reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.0f;
-      (arena + P.a_done)[e] = 0;
+      reinterpret_cast<float*>(arena + c.R.a_rew_p)[e] = 0.0f;
+      (arena + c.R.a_done)[e] = 0;
     }
   }
   __syncthreads();
 }
 }  // namespace aie
 
-// BaseEnvironment.step (base_env.py:929-1032) for the one-step-economy scenario
-extern "C" __global__ void __launch_bounds__(OSE_NT)
-aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
-  float* __restrict__ rew_log = next.rew_log;  // this step's slot of aie_set_reward_log, or nullptr
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+// BaseEnvironment.step (base_env.py:929-1032) for the one-step-economy scenario.  SPEC >= 0: compile-time instance
+// (constant parameter image, see step_body in aie_kernels.hip), SPEC < 0: the generic kernel.
+template <int SPEC>
+__device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                                              const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
+                                              const NextActions& next, uint8_t* lds) {
   using namespace aie;
-  const aie_params& P = *params;
+  float* __restrict__ rew_log = next.rew_log;  // this step's slot of aie_set_reward_log, or nullptr
+  const aie_params& R = *params;
+  const aie_params& P = aie_spec_params<SPEC>(params);
   OseScratch s;
-  const Ctx c = ose_make_ctx(P, lds, replica_of_block((int)blockIdx.x, P.E), (int)threadIdx.x, s, arena);
+  const Ctx c = ose_make_ctx(P, R, lds, replica_of_block((int)blockIdx.x, R.E), (int)threadIdx.x, s, arena);
   const int n = P.n, tid = c.tid;
   MT m;
   ose_load_record(c, arena, m);
@@ -617,7 +619,7 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   // auto-reset (aie_set_auto_reset): a replica that finishes its episode in this step restarts inside this launch;
   // its terminal observations would be overwritten by the reset's before anything can read them, so they are not
   // written (rewards and `done` are the terminal step's)
-  const bool restart = done && P.auto_reset;
+  const bool restart = done && R.auto_reset;
   if (!restart) ose_write_observations(c, s, arena);
   __syncthreads();
   // compute_reward one_step_economy.py:195-222
@@ -627,14 +629,14 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
     for (int i = tid; i <= n; i += OSE_NT) {
       const double r = s.part[i] - util[i];
       util[i] = s.part[i];
-      if (i < n) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)c.e * n + i] = (float)r;
-      else reinterpret_cast<float*>(arena + P.a_rew_p)[c.e] = (float)r;
+      if (i < n) reinterpret_cast<float*>(arena + c.R.a_rew_a)[(int64_t)c.e * n + i] = (float)r;
+      else reinterpret_cast<float*>(arena + c.R.a_rew_p)[c.e] = (float)r;
       if (rew_log) rew_log[(int64_t)c.e * (n + 2) + i] = (float)r;
     }
   }
   __syncthreads();
   if (tid == 0) {
-    (arena + P.a_done)[c.e] = (uint8_t)done;
+    (arena + c.R.a_done)[c.e] = (uint8_t)done;
     if (rew_log) rew_log[(int64_t)c.e * (n + 2) + n + 1] = done ? 1.0f : 0.0f;
     if (done) *R_I32(c, o_completions) += 1;
   }
@@ -648,6 +650,20 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
 }
 
 extern "C" __global__ void __launch_bounds__(OSE_NT)
+aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                    const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  ose_step_body<-1>(params, arena, act_a, act_p, next, lds);
+}
+template <int SPEC>
+__global__ void __launch_bounds__(OSE_NT)
+aie_ose_step_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                         const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  ose_step_body<SPEC>(params, arena, act_a, act_p, next, lds);
+}
+
+extern "C" __global__ void __launch_bounds__(OSE_NT)
 aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                      const uint8_t* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -656,7 +672,7 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   const int e = replica_of_block((int)blockIdx.x, P.E);
   if (mask && !mask[e]) return;
   OseScratch s;
-  const Ctx c = ose_make_ctx(P, lds, e, (int)threadIdx.x, s, arena);
+  const Ctx c = ose_make_ctx(P, P, lds, e, (int)threadIdx.x, s, arena);
   MT m;
   ose_load_record(c, arena, m);
   __syncthreads();

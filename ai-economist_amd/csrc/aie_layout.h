@@ -197,6 +197,7 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->dev_skip_mask = 0;
   p->dev_trace = 0;
   p->auto_reset = 0;
+  memset(p->c.labor_skills, 0, sizeof(p->c.labor_skills));  /* SimpleLabor's skills are data, read from the run-time block */
 }
 
 typedef struct aie_tensor_table {

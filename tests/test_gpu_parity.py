@@ -722,6 +722,41 @@ def test_compile_time_instance_equals_generic_kernel(n_agents):
     del b_gen, b_other
 
 
+def test_compile_time_instance_equals_generic_kernel_one_step_economy():
+    """BASELINE configs[4] (one-step-economy, 100 agents) has a compile-time instance too (SimpleLabor's skills are
+    run-time data): instance vs generic kernel, bit for bit, across episode ends with and without auto-reset."""
+    import ctypes
+
+    import torch
+
+    rs = np.random.RandomState(11)
+    cfg = dict(scenario_name="one-step-economy", n_agents=100, world_size=[1, 1], episode_length=2,
+               components=[["SimpleLabor", {"skills": [float(x) for x in np.sort(1 + rs.rand(100) * 2)]}],
+                           ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+                                                   "tax_model": "model_wrapper"}]])
+    pair = [make_env(cfg, n_envs=256, device="cuda:0") for _ in range(2)]
+    for env in pair:
+        env.seed(5)
+        env.reset()
+    b_spec, b_ref = pair[0].backend, pair[1].backend
+    b_ref.lib.aie_dev_use_generic_kernel.argtypes = [ctypes.c_void_p]
+    assert b_ref.lib.aie_dev_use_generic_kernel(b_ref.handle) == 0
+    assert b_spec.lib.aie_step_kernel_instance(b_spec.handle) >= 0 and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == -1
+    for t in range(9):
+        if t == 4:
+            b_spec.set_auto_reset(True)
+            b_ref.set_auto_reset(True)
+        a, p = b_ref.sample_random_actions(seed=4)
+        b_ref.step(a, p)
+        b_spec.step(a, p)
+        if t < 4 and bool(b_ref.tensors["done"][0]):
+            b_ref.reset(b_ref.tensors["done"])
+            b_spec.reset(b_spec.tensors["done"])
+        torch.cuda.synchronize()
+        for k in b_ref.tensors:
+            assert torch.equal(b_ref.tensors[k], b_spec.tensors[k]), "step %d: %s differs" % (t + 1, k)
+
+
 def _auto_reset_cases():
     rs = np.random.RandomState(4)
     ose = dict(scenario_name="one-step-economy", n_agents=12, world_size=[1, 1], episode_length=3,

@@ -16,7 +16,7 @@ from helpers import make_env  # noqa: E402
 
 E = 4096
 SKIP = int(os.environ.get("AIE_DEV_SKIP_MASK", "0"))
-env = make_env(dict(bench.WORKLOAD), n_envs=E, device="cuda:0")
+env = make_env(dict(bench.C2_CFG), n_envs=E, device="cuda:0")
 env.seed(1)
 env.reset()
 be = env.backend

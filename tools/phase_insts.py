@@ -15,7 +15,7 @@ import bench  # noqa: E402
 from helpers import make_env  # noqa: E402
 
 MASKS = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 63]
-env = make_env(bench.WORKLOAD, n_envs=4096, device="cuda:0")
+env = make_env(bench.C2_CFG, n_envs=4096, device="cuda:0")
 env.seed(1)
 env.reset()
 be = env.backend

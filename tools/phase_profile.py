@@ -14,7 +14,7 @@ import bench  # noqa: E402
 from helpers import make_env  # noqa: E402
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cfg = dict(bench.WORKLOAD)
+cfg = dict(bench.C2_CFG)
 if len(sys.argv) > 2:
     cfg["n_agents"] = int(sys.argv[2])
 env = make_env(cfg, n_envs=E, device="cuda:0")

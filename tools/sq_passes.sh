@@ -1,0 +1,29 @@
+#!/bin/bash
+# Development: rocprofv3 SQ counter passes (kernel-trace + --pmc only) over a short bench run of one workload;
+# CSVs under gpurun_out/sq_<wl>_<k>/.   usage: tools/sq_passes.sh C5 [extra bench args]
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+WL=$1; shift
+G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"
+G2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
+G3="SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_IFETCH SQ_INSTS_BRANCH"
+k=0
+for G in "$G1" "$G2" "$G3"; do
+  k=$((k+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $R/gpurun_out/sq_${WL}_$k -o s -- \
+    python $R/bench.py --workload $WL --no-cpu-baseline --steps 30 --warmup 5 "$@" > $R/gpurun_out/sq_${WL}_$k.log 2>&1
+  tail -c 200 $R/gpurun_out/sq_${WL}_$k.log
+done
+python3 - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob("$R/gpurun_out/sq_${WL}_*/s_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "step_kernel" in k:
+            acc[k.split("(")[0][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print("   %-26s mean %.4g  (n=%d)" % (c, sum(v) / len(v), len(v)))
+PY
