@@ -128,7 +128,7 @@ class AieConfig(C.Structure):
         ("saez_buffer_size", C.c_int32),
         ("saez_pareto_weight_uniform", C.c_int32),
         ("saez_fixed_elas_given", C.c_int32),
-        ("reserved4_", C.c_int32),
+        ("saez_global_capacity", C.c_int32),
         ("saez_fixed_elas", C.c_double),
     ]
 
@@ -182,6 +182,8 @@ def bind(lib):
     lib.aie_set_reward_log.argtypes = [vp, vp, C.c_int32]
     lib.aie_step_sample_next.restype = C.c_int
     lib.aie_step_sample_next.argtypes = [vp, vp, vp, C.c_uint64, C.c_int64, vp, vp, vp]
+    lib.aie_set_global_saez_buffer.restype = C.c_int
+    lib.aie_set_global_saez_buffer.argtypes = [vp, vp, C.c_int64]
     lib.aie_set_auto_reset.restype = C.c_int
     lib.aie_set_auto_reset.argtypes = [vp, C.c_int]
     lib.aie_step_kernel_instance.restype = C.c_int
@@ -196,5 +198,5 @@ EXPORTED_SYMBOLS = [
     "aie_tensor_at", "aie_get_tensor", "aie_upload", "aie_download", "aie_set_layout",
     "aie_seed", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
     "aie_sample_masked_actions", "aie_step_sample_next", "aie_set_reward_log", "aie_set_auto_reset",
-    "aie_step_kernel_instance",
+    "aie_step_kernel_instance", "aie_set_global_saez_buffer",
 ]

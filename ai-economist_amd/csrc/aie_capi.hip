@@ -418,6 +418,27 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   return AIE_OK;
 }
 
+int aie_set_global_saez_buffer(aie_env* env, const double* d_pairs, int64_t n_pairs) {
+  if (!env || n_pairs < 0 || (n_pairs > 0 && !d_pairs)) return AIE_E_INVALID;
+  if (!env->P.saez_stride) {
+    snprintf(env->err, sizeof(env->err), "the global Saez buffer needs tax_model \"saez\"");
+    return AIE_E_UNSUPPORTED;
+  }
+  if (n_pairs > env->P.saez_global_cap) {
+    snprintf(env->err, sizeof(env->err), "global Saez buffer of %lld pairs exceeds aie_config.saez_global_capacity = %d",
+             (long long)n_pairs, env->P.saez_global_cap);
+    return AIE_E_INVALID;
+  }
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  AIE_HIP_CHECK(env, hipDeviceSynchronize());
+  uint8_t* g = env->arena + env->P.a_saez_global;
+  if (n_pairs > 0)
+    AIE_HIP_CHECK(env, hipMemcpy(g + 16, d_pairs, (size_t)n_pairs * 16, hipMemcpyDeviceToDevice));
+  const int32_t len = (int32_t)n_pairs;
+  AIE_HIP_CHECK(env, hipMemcpy(g, &len, 4, hipMemcpyHostToDevice));
+  return AIE_OK;
+}
+
 int aie_set_auto_reset(aie_env* env, int on) {
   if (!env) return AIE_E_INVALID;
   if (on && env->P.c.scenario == AIE_SCN_GTB && !env->P.c.shared_layout) {

@@ -1339,7 +1339,10 @@ __device__ __forceinline__ void tax_enact(const Ctx& c, Agents& A) {
       }
       len = size;
     }
-    if (i == 0) hdr[0] = len;
+    if (i == 0) {
+      hdr[0] = len;
+      hdr[2] += n;  // _additions_this_episode :541 (only reset_saez_buffers zeroes it)
+    }
   }
 }
 // component_step :945-972 + set_new_period_rates_model :419-434

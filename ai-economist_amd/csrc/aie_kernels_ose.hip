@@ -246,7 +246,10 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
         }
         len = size;
       }
-      if (c.tid == 0) hdr[0] = len;
+      if (c.tid == 0) {
+        hdr[0] = len;
+        hdr[2] += n;  // _additions_this_episode :541
+      }
     }
     pos = 0;
     __syncthreads();

@@ -41,7 +41,13 @@ aie_saez_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ are
   const uint8_t* rec = arena + P.a_records + (int64_t)e * P.rec_bytes;
   int32_t* hdr = reinterpret_cast<int32_t*>(blk);
   if (*reinterpret_cast<const int32_t*>(rec + P.o_tax_cycle_pos) != 1) return;
-  const int len = hdr[0];
+  // the `saez_buffer` property :514-525: the trainer's global buffer (if one was set) followed by the samples this
+  // replica added since the buffers were last reset, else the local buffer
+  const int llen = hdr[0];
+  const uint8_t* gblk = arena + P.a_saez_global;
+  const int glen = P.saez_global_cap ? *reinterpret_cast<const int32_t*>(gblk) : 0;
+  const int tail = glen > 0 ? (hdr[2] < llen ? hdr[2] : llen) : llen;  // local samples in use
+  const int len = glen + tail;
   if (!hdr[1]) {  // :444-449
     if (len < P.c.saez_buffer_size) return;
     if (lane == 0) hdr[1] = 1;
@@ -49,7 +55,9 @@ aie_saez_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ are
   double* el = reinterpret_cast<double*>(blk + AIE_SAEZ_OFF_ELAS);  // elas_t, elas_tm1, log_z0_t, log_z0_tm1
   double* avg = reinterpret_cast<double*>(blk + AIE_SAEZ_OFF_AVG);
   double* next = reinterpret_cast<double*>(blk + AIE_SAEZ_OFF_NEXT);
-  const double* buf = reinterpret_cast<const double*>(blk + AIE_SAEZ_OFF_BUF);
+  const double* lbuf = reinterpret_cast<const double*>(blk + AIE_SAEZ_OFF_BUF) + 2 * (llen - tail);
+  const double* gbuf = reinterpret_cast<const double*>(gblk + 16);
+  auto smp = [&](int k, int j) { return k < glen ? gbuf[2 * k + j] : lbuf[2 * (k - glen) + j]; };
   const double* edges = P.saez_edges;
 
   __shared__ int s_counts[AIE_SAEZ_T];
@@ -62,7 +70,7 @@ aie_saez_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ are
   {
     double cnt = 0, st = 0;
     for (int k = lane; k < len; k += AIE_NT) {
-      const double z = buf[2 * k], tau = buf[2 * k + 1];
+      const double z = smp(k, 0), tau = smp(k, 1);
       if (z > 0 && tau < 1) { cnt += 1; st += tau; }
     }
     const double m = wave_sum_ordered(cnt);
@@ -70,14 +78,14 @@ aie_saez_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ are
       const double mean = wave_sum_ordered(st) / m;
       double sq = 0;
       for (int k = lane; k < len; k += AIE_NT) {
-        const double z = buf[2 * k], tau = buf[2 * k + 1];
+        const double z = smp(k, 0), tau = smp(k, 1);
         if (z > 0 && tau < 1) sq += (tau - mean) * (tau - mean);
       }
       const double sd = sqrt(wave_sum_ordered(sq) / m);
       if (!(sd < 1e-6)) {
         double sxx = 0, sx = 0, sxy = 0, sy = 0;
         for (int k = lane; k < len; k += AIE_NT) {
-          const double z = buf[2 * k], tau = buf[2 * k + 1];
+          const double z = smp(k, 0), tau = smp(k, 1);
           if (z > 0 && tau < 1) {
             double t1 = 1 - tau; if (t1 < 1e-9) t1 = 1e-9;
             double zz = z; if (zz < 1e-9) zz = 1e-9;
@@ -103,7 +111,7 @@ aie_saez_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ are
   __syncthreads();
   double n_below = 0, n_above = 0, w_above = 0, sum_above = 0;
   for (int k = lane; k < len; k += AIE_NT) {
-    const double z = buf[2 * k];
+    const double z = smp(k, 0);
     if (z < edges[0]) n_below += 1;
     else if (z > edges[T]) { n_above += 1; w_above += saez_pareto(P, z); sum_above += z; }
     else {

@@ -128,6 +128,8 @@ typedef struct aie_params {
    * aie_saez_kernel); f64 buffer[saez_cap][2] = (income, marginal rate), oldest first. */
   int64_t a_saez;
   int32_t saez_stride, saez_cap;
+  int64_t a_saez_global; /* shared: int32 len (16 B), then f64 [saez_global_cap][2]: the trainer's cross-replica buffer */
+  int32_t saez_global_cap, saez_pad_;
   int32_t o_tax_saez_rates; /* record: f64 [NB] curr_bracket_tax_rates */
   int32_t o_tax_saez_obs_rates; /* record: f64 [NB] _curr_rates_obs: the rates the "curr_rates" observation shows,
                                    refreshed at period starts and -- BEFORE the running average replaces the
@@ -191,7 +193,7 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->a_obs_p_map = p->a_obs_p_idx = p->a_obs_p_flat = p->a_obs_p_mask = p->a_obs_p_time = p->a_obs_p_agents = 0;
   p->a_rew_a = p->a_rew_p = p->a_done = 0;
   p->arena_bytes = 0;
-  p->a_saez = p->a_events = p->a_metrics = 0;
+  p->a_saez = p->a_events = p->a_metrics = p->a_saez_global = 0;
   p->a_cv_consts = p->a_cv_filters = p->a_cv_hist0 = p->a_cv_lag_obs = p->a_cv_hist = p->a_cv_obs_a = p->a_cv_obs_p = 0;
   p->a_cv_hist0c = p->a_cv_acc0 = 0;
   p->dev_skip_mask = 0;
@@ -473,12 +475,15 @@ static inline void aie__alloc_metrics(aie_params* p, int64_t* a) {
 #define AIE_SAEZ_OFF_NEXT (AIE_SAEZ_OFF_AVG + 8 * AIE_MAX_BRACKETS)
 #define AIE_SAEZ_OFF_BUF (AIE_SAEZ_OFF_NEXT + 8 * AIE_MAX_BRACKETS)
 static inline void aie__alloc_saez(const aie_config* c, aie_params* p, int64_t* a) {
-  p->a_saez = 0; p->saez_stride = 0; p->saez_cap = 0;
+  p->a_saez = 0; p->saez_stride = 0; p->saez_cap = 0; p->a_saez_global = 0; p->saez_global_cap = 0;
   if (!p->has_tax || c->tax_model != AIE_TAX_SAEZ) return;
   p->saez_cap = c->saez_buffer_size + p->n; /* a tax day appends n pairs before the oldest are dropped */
   p->saez_stride = (int32_t)aie__align(AIE_SAEZ_OFF_BUF + (int64_t)p->saez_cap * 16, 64);
   p->a_saez = *a;
   *a = aie__align(*a + (int64_t)p->E * p->saez_stride, 256);
+  p->saez_global_cap = c->saez_global_capacity > 0 ? c->saez_global_capacity : 0;
+  p->a_saez_global = *a;
+  *a = aie__align(*a + 16 + (int64_t)p->saez_global_cap * 16, 256);
   const double top = c->tax_bracket_cutoffs[p->NB - 1], step = top / (double)AIE_SAEZ_BINS;
   for (int i = 0; i <= AIE_SAEZ_BINS; ++i) p->saez_edges[i] = (double)i * step + 0.0; /* np.linspace */
   p->saez_edges[AIE_SAEZ_BINS] = top;
@@ -488,6 +493,10 @@ static inline void aie__add_saez_tensors(const aie_params* p, aie_tensor_table* 
   const int64_t s0 = p->a_saez, ss = p->saez_stride, E = p->E;
   aie__add(tt, "saez_buffer_len", AIE_I32, s0, ss, 0, 0, 0, 0, 0, E);
   aie__add(tt, "saez_reached_min_samples", AIE_I32, s0 + 4, ss, 0, 0, 0, 0, 0, E);
+  aie__add(tt, "saez_additions", AIE_I32, s0 + 8, ss, 0, 0, 0, 0, 0, E);  /* _additions_this_episode :541 */
+  aie__add_shared(tt, "saez_global_len", AIE_I32, p->a_saez_global, 1, 1, 0);
+  if (p->saez_global_cap)
+    aie__add_shared(tt, "saez_global_buffer", AIE_F64, p->a_saez_global + 16, 2, p->saez_global_cap, 2);
   aie__add(tt, "saez_elas", AIE_F64, s0 + AIE_SAEZ_OFF_ELAS, ss, 1, 4, 0, 0, 0, E);
   aie__add(tt, "saez_running_avg_tax_rates", AIE_F64, s0 + AIE_SAEZ_OFF_AVG, ss, 1, p->NB, 0, 0, 0, E);
   aie__add(tt, "saez_next_rates", AIE_F64, s0 + AIE_SAEZ_OFF_NEXT, ss, 1, p->NB, 0, 0, 0, E);

@@ -36,7 +36,7 @@ class BaseEnvironment:
                  flatten_observations=True, flatten_masks=True,
                  allow_observation_scaling=True, dense_log_frequency=None,
                  world_dense_log_frequency=50, collate_agent_step_and_reset_data=False,
-                 seed=None, n_envs=1, device=None, env_offset=0):
+                 seed=None, n_envs=1, device=None, env_offset=0, track_episode_metrics=False):
         assert self.name
         assert isinstance(self.agent_subclasses, (tuple, list)) and len(self.agent_subclasses) > 0
         assert isinstance(self.required_entities, (tuple, list))
@@ -108,6 +108,9 @@ class BaseEnvironment:
 
         self._completions = 0
         self._last_ep_metrics = None
+        # previous_episode_metrics (base_env.py:763-765) costs a device->host copy of every non-observation state
+        # tensor at each full reset that follows an episode: opt in
+        self._track_episode_metrics = bool(track_episode_metrics)
         self._backend = None
         self._pending_seed = None if seed is None else int(seed)
         if seed is not None:
@@ -279,13 +282,11 @@ class BaseEnvironment:
             self._pending_seed = int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31 - 1)) + 1
         if force_dense_logging and self._create_dense_log_every is None:
             raise ValueError("force_dense_logging needs an environment created with dense_log_frequency")
-        if self._backend is not None and env_mask is None and bool(self._backend.tensors["done"].all().item()):
+        if (self._track_episode_metrics and self._backend is not None and env_mask is None
+                and bool(self._backend.tensors["done"].all().item())):
             # the episode that just ended, before its state is replaced (the reference stores the metrics when the
             # last step of an episode finishes, base_env.py:763-765; a full reset is the batch's episode boundary)
-            try:
-                self._last_ep_metrics = {k: np.array(v, copy=True) for k, v in self.metrics.items()}
-            except Exception:  # metrics are a convenience: never let them stand in the way of a reset
-                self._last_ep_metrics = None
+            self._last_ep_metrics = {k: np.array(v, copy=True) for k, v in self.metrics.items()}
         log_replica_resets = self._create_dense_log_every is not None and (
             env_mask is None or bool(env_mask[0].item()))
         if log_replica_resets:
@@ -408,7 +409,8 @@ class BaseEnvironment:
     @property
     def previous_episode_metrics(self):
         """env.metrics as they stood at the end of the last completed episode (captured by the full reset that
-        follows it; None before that and for environments that are only ever reset through a mask)."""
+        follows it; None before that, for environments that are only ever reset through a mask, and unless the
+        environment was created with track_episode_metrics=True)."""
         return self._last_ep_metrics
 
     def metrics_of(self, e):

@@ -123,20 +123,45 @@ class PeriodicBracketTax(BaseComponent):
 
     # ---- Saez sample buffers (redistribution.py:515-546); they live on the device of the owning environment ----
     def reset_saez_buffers(self, env=None):
-        """Empties every replica's sample buffer: random rates again until it refills."""
-        t = (env or self._env).backend.tensors
+        """Empties every replica's sample buffer and the global one: random rates again until they refill
+        (redistribution.py:546-550)."""
+        env = env or self._env
+        t = env.backend.tensors
         t["saez_buffer_len"].zero_()
         t["saez_reached_min_samples"].zero_()
+        t["saez_additions"].zero_()
+        t["saez_global_len"].zero_()
 
     def get_local_saez_buffer(self, env=None):
         """(buffer [E, capacity, 2] of (income, marginal rate) pairs, oldest first; filled lengths [E])."""
         t = (env or self._env).backend.tensors
         return t["saez_buffer"], t["saez_buffer_len"]
 
-    def set_global_saez_buffer(self, global_saez_buffer):
-        raise NotImplementedError(
-            "the cross-replica buffer union belongs to the RLlib trainer (tutorials/rllib/utils/remote.py:56-73), "
-            "not to the environment step; every replica of the batch uses its own buffer")
+    def local_saez_samples(self, env=None):
+        """Every replica's filled samples concatenated in replica order: float64 [sum(len), 2] on the device --
+        what the reference's trainer collects per environment (tutorials/rllib/utils/remote.py:59-66)."""
+        import torch
+
+        buf, n = self.get_local_saez_buffer(env)
+        keep = torch.arange(buf.shape[1], device=buf.device)[None, :] < n[:, None]
+        return buf[keep]
+
+    def set_global_saez_buffer(self, global_saez_buffer, env=None):
+        """redistribution.py:530-533: from now on every replica's period start uses this buffer followed by its own
+        samples added since the buffers were last reset.  `global_saez_buffer`: [G, 2] pairs (tensor / array / list),
+        G <= the capacity fixed at construction (`_global_buffer_capacity`, default n_envs * _buffer_size)."""
+        import torch
+
+        env = env or self._env
+        be = env.backend
+        g = global_saez_buffer
+        if not isinstance(g, torch.Tensor):
+            g = torch.as_tensor(np.asarray(g, np.float64).reshape(-1, 2))
+        g = g.to(device=be.device, dtype=torch.float64).contiguous()
+        assert g.ndim == 2 and g.shape[1] == 2
+        assert g.shape[0] == 0 or g.shape[0] >= int(be.tensors["saez_buffer_len"].max().item()), \
+            "the global buffer must hold at least as many samples as a local one (redistribution.py:532)"
+        be._check(be.lib.aie_set_global_saez_buffer(be.handle, g.data_ptr() if g.shape[0] else None, int(g.shape[0])))
 
     def get_n_actions(self, agent_cls_name):
         if agent_cls_name == "BasicPlanner":
@@ -152,6 +177,9 @@ class PeriodicBracketTax(BaseComponent):
         cfg.tax_rate_max = float(self.rate_max)
         cfg.tax_rate_min = float(self.rate_min)
         cfg.saez_buffer_size = int(self._buffer_size)
+        if self.tax_model == "saez":
+            cap = getattr(self, "_global_buffer_capacity", None)
+            cfg.saez_global_capacity = int(cap if cap is not None else cfg.n_envs * int(self._buffer_size))
         cfg.saez_pareto_weight_uniform = int(self.pareto_weight_type == "uniform")
         cfg.saez_fixed_elas_given = int(self._saez_fixed_elas is not None)
         cfg.saez_fixed_elas = float(self._saez_fixed_elas or 0.0)

@@ -131,3 +131,36 @@ class RewardLogGather:
     def finish(self):
         self._wait(self.block ^ 1)
         self._wait(self.block)
+
+
+def accumulate_and_broadcast_saez_buffers(envs, component_name="PeriodicBracketTax"):
+    """The one algorithmic cross-replica exchange of the reference (tutorials/rllib/utils/remote.py:56-73
+    `accumulate_and_broadcast_saez_buffers`): every environment replica's local Saez sample buffer is concatenated
+    into one global buffer that all of them then use.  Here the replicas of a rank are a batch on one device and
+    ranks are processes: local samples are concatenated in replica order on the device, all-gathered across the
+    process group (RCCL on GPUs; variable lengths are padded to the longest), concatenated rank-major and handed to
+    every environment of this rank (`PeriodicBracketTax.set_global_saez_buffer`).  `envs`: one batched environment or
+    a list of them.  Returns the global buffer (float64 [G, 2])."""
+    import torch
+    import torch.distributed as dist
+
+    if not isinstance(envs, (list, tuple)):
+        envs = [envs]
+    comps = [env.get_component(component_name) for env in envs]
+    local = torch.cat([c.local_saez_samples(env) for c, env in zip(comps, envs)], dim=0)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        world = dist.get_world_size()
+        n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        counts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(counts, n)
+        longest = int(max(int(c.item()) for c in counts))
+        padded = torch.zeros((longest, 2), dtype=torch.float64, device=local.device)
+        padded[: local.shape[0]] = local
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded)
+        glob = torch.cat([p[: int(c.item())] for p, c in zip(parts, counts)], dim=0)
+    else:
+        glob = local
+    for c, env in zip(comps, envs):
+        c.set_global_saez_buffer(glob, env)
+    return glob

@@ -246,7 +246,8 @@ typedef struct aie_config {
   int32_t saez_buffer_size;          /* _buffer_size: samples before the formula is used (500) */
   int32_t saez_pareto_weight_uniform;/* pareto_weight_type: 0 "inverse_income", 1 "uniform" */
   int32_t saez_fixed_elas_given;     /* saez_fixed_elas is not None                        */
-  int32_t reserved4_;
+  int32_t saez_global_capacity;      /* > 0: room (pairs) for the cross-replica sample buffer of the reference's trainer
+                                      * (set_global_saez_buffer, redistribution.py:530-533); 0: feature off        */
   double saez_fixed_elas;
 } aie_config;
 
@@ -362,6 +363,14 @@ int aie_set_reward_log(aie_env* env, float* d_log, int32_t n_slots);
  * right behind the step.  AIE_E_UNSUPPORTED for scenarios whose reset has a host-side part (uniform/, quadrant/,
  * multi_zone/ layouts).  Episode metrics of a finished episode are gone once it restarts. */
 int aie_set_auto_reset(aie_env* env, int on);
+
+/* tax_model "saez": the cross-replica sample buffer (reference: PeriodicBracketTax.set_global_saez_buffer,
+ * redistribution.py:515-533; filled by the trainer with the concatenation of every replica's local buffer,
+ * tutorials/rllib/utils/remote.py:56-73).  d_pairs: n_pairs (income, marginal rate) float64 pairs in DEVICE memory
+ * (n_pairs <= aie_config.saez_global_capacity); n_pairs == 0 clears it.  From then on every replica's period start
+ * uses global + its own samples added since the buffers were last reset (`saez_additions` tensor), as the
+ * reference's `saez_buffer` property does. */
+int aie_set_global_saez_buffer(aie_env* env, const double* d_pairs, int64_t n_pairs);
 
 /* Which step kernel runs this environment: >= 0 = a compile-time instance (the configuration's parameter block folded
  * into the code, csrc/aie_spec_generated.h), -1 = the generic kernel. */

@@ -600,14 +600,34 @@ static void saez_estimate_elasticity(const double* buf, int len, double elas_tm1
   free(zs);
 }
 
+/* the `saez_buffer` property, redistribution.py:514-525: the trainer's global buffer (if set) followed by the local
+ * samples added since the buffers were last reset; else the local buffer.  Returns a malloc'd copy, *len pairs. */
+static double* saez_effective_buffer(ctx_t* c, int* len) {
+  const aie_params* p = c->p;
+  const uint8_t* blk = SAEZ(c);
+  const int32_t* hdr = (const int32_t*)blk;
+  const double* lbuf = (const double*)(blk + AIE_SAEZ_OFF_BUF);
+  const uint8_t* gblk = c->arena + p->a_saez_global;
+  const int glen = p->saez_global_cap ? *(const int32_t*)gblk : 0;
+  const int llen = hdr[0];
+  const int tail = glen > 0 ? (hdr[2] < llen ? hdr[2] : llen) : llen;
+  *len = glen + tail;
+  double* out = (double*)malloc(sizeof(double) * 2 * (size_t)(*len + 1));
+  if (glen > 0) memcpy(out, gblk + 16, sizeof(double) * 2 * (size_t)glen);
+  memcpy(out + 2 * glen, lbuf + 2 * (llen - tail), sizeof(double) * 2 * (size_t)tail);
+  return out;
+}
+
 /* compute_and_set_new_period_rates_from_saez_formula :437-513 (buffer already has >= min samples) */
 static void saez_formula(ctx_t* c, double* rates) {
   const aie_params* p = c->p;
   uint8_t* blk = SAEZ(c);
-  const int len = *(int32_t*)blk, NB = p->NB, T = AIE_SAEZ_BINS;
+  const int NB = p->NB, T = AIE_SAEZ_BINS;
+  int len;
+  double* eff = saez_effective_buffer(c, &len);
   double* el = (double*)(blk + AIE_SAEZ_OFF_ELAS); /* elas_t, elas_tm1, log_z0_t, log_z0_tm1 */
   double* avg = (double*)(blk + AIE_SAEZ_OFF_AVG);
-  const double* buf = (const double*)(blk + AIE_SAEZ_OFF_BUF);
+  const double* buf = eff;
   const double* edges = p->saez_edges;
   el[1] = el[0]; el[3] = el[2];
   double elas_t, log_z0_t;
@@ -673,6 +693,7 @@ static void saez_formula(ctx_t* c, double* rates) {
     } else az[T] = 0.0;
   }
   free(above);
+  free(eff);
   /* get_saez_marginal_rates :754-790 */
   for (int i = 0; i <= T; ++i) taus[i] = (1.0 - gz[i]) / (1.0 - gz[i] + az[i] * elas_t + 1e-9);
   {
@@ -715,7 +736,11 @@ static void saez_set_new_period_rates(ctx_t* c) {
   const aie_params* p = c->p;
   int32_t* hdr = (int32_t*)SAEZ(c);
   double* rates = F64(c, o_tax_saez_rates);
-  if (!hdr[1] && hdr[0] >= p->c.saez_buffer_size) hdr[1] = 1;
+  if (!hdr[1]) {
+    int eff_len;
+    free(saez_effective_buffer(c, &eff_len));
+    if (eff_len >= p->c.saez_buffer_size) hdr[1] = 1;
+  }
   if (!hdr[1]) { /* np.random.uniform(low=rate_min, high=curr_rate_max, size=n_brackets): low + (high - low) * u */
     const double lo = p->c.tax_rate_min, hi = saez_curr_rate_max(c);
     for (int b = 0; b < p->NB; ++b) rates[b] = lo + (hi - lo) * rng_double(c);
@@ -736,6 +761,7 @@ static void saez_update_buffer(ctx_t* c) {
     buf[2 * (hdr[0] + i) + 1] = F64(c, o_tax_last_marginal_rate)[i];
   }
   hdr[0] += p->n;
+  hdr[2] += p->n; /* _additions_this_episode :541 */
   if (hdr[0] > p->c.saez_buffer_size) {
     int drop = hdr[0] - p->c.saez_buffer_size;
     memmove(buf, buf + 2 * drop, sizeof(double) * 2 * (size_t)p->c.saez_buffer_size);

@@ -91,6 +91,12 @@ class OracleEnv:
         if layout_planes is not None and "cell_flags" in self.t:
             self.set_layout(*layout_planes)
 
+    def set_global_saez_buffer(self, pairs):
+        """PeriodicBracketTax.set_global_saez_buffer (redistribution.py:530-533) for every replica of this arena."""
+        pairs = np.asarray(pairs, np.float64).reshape(-1, 2)
+        self.t["saez_global_buffer"][0, : len(pairs)] = pairs
+        self.t["saez_global_len"][...] = len(pairs)
+
     def saez_period_start(self):
         """Runs PeriodicBracketTax's period-start rate update (tax_model "saez") on every replica."""
         lib().aie_oracle_saez_period_start(self._params, self.arena.ctypes.data_as(C.c_void_p))

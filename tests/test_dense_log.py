@@ -118,7 +118,7 @@ def test_dense_log_matches_live_reference(case):
     ref = _ref_env(cfg)
     if cfg["scenario_name"] == "one-step-economy":
         cfg["components"][0][1]["skills"] = [float(x) for x in ref.get_component("SimpleLabor").skills]
-    host = make_env(cfg)
+    host = make_env(cfg, track_episode_metrics=True)
     o = OracleEnv(host.build_config(), host.layout_planes())
     host._backend = OracleBackend(o)
     host.host_pre_reset = lambda mask: oracle_host_pre_reset(host, o)

@@ -537,3 +537,64 @@ def test_oracle_saez_formula_matches_reference_on_synthetic_buffers(case):
                                    err_msg=where)
         ols += int(tc.elas_t != elas[0])
     assert ols >= 30, ols
+
+
+@pytest.mark.parametrize("case", ["inverse_income", "uniform_weights_fixed_elas", "annealed_linear_brackets"])
+def test_oracle_saez_global_buffer_matches_live_reference(case):
+    """set_global_saez_buffer (redistribution.py:514-533; filled by the trainer's union of all replicas' local buffers,
+    tutorials/rllib/utils/remote.py:56-73): two live reference environments pool their samples; from then on one of
+    them is compared, period start by period start, with the restatement given the same global buffer, local
+    buffer and additions counter (the formula as a function of the reference's state, 1e-9)."""
+    from oracle_lib import OracleEnv
+
+    if case not in SAEZ_CASES:
+        pytest.skip("no such saez case")
+    cfg, size = _saez_cfg(case)
+    np.random.seed(9)
+    ref, ref2 = _ref_env(cfg), _ref_env(cfg)
+    tc, tc2 = ref.get_component("PeriodicBracketTax"), ref2.get_component("PeriodicBracketTax")
+    tc._buffer_size = tc2._buffer_size = size
+    host = make_env(cfg)
+    hc = host.get_component("PeriodicBracketTax")
+    hc._buffer_size = size
+    hc._global_buffer_capacity = 4 * size
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    o.seed(1)
+    o.reset()
+    rng = np.random.RandomState(5)
+    checked = with_global = 0
+    for ep in range(6):
+        ref.reset()
+        ref2.reset()
+        if ep in (2, 4):  # the trainer's exchange between episodes
+            glob = list(tc.get_local_saez_buffer()) + list(tc2.get_local_saez_buffer())
+            tc.set_global_saez_buffer(glob)
+            tc2.set_global_saez_buffer(glob)
+            o.set_global_saez_buffer(np.array(glob, np.float64))
+        for t in range(cfg["episode_length"]):
+            at_start = tc.tax_cycle_pos == 1 and (tc._reached_min_samples or len(tc.saez_buffer) >= size)
+            if at_start:
+                buf = np.array(tc._local_saez_buffer, np.float64).reshape(-1, 2)
+                o.t["saez_buffer"][0][: len(buf)] = buf
+                o.t["saez_buffer_len"][0] = len(buf)
+                o.t["saez_additions"][0] = tc._additions_this_episode
+                o.t["saez_reached_min_samples"][0] = int(tc._reached_min_samples)
+                o.t["saez_elas"][0] = [tc.elas_t, tc.elas_tm1, tc.log_z0_t, tc.log_z0_tm1]
+                o.t["saez_running_avg_tax_rates"][0] = tc.running_avg_tax_rates
+                o.t["tax_last_completions"][0] = tc._last_completions
+                n_eff = len(tc.saez_buffer)
+            acts, _, _ = _random_actions(ref, rng, False, True)
+            ref.step(acts)
+            ref2.step(_random_actions(ref2, rng, False, True)[0])
+            if at_start:
+                o.saez_period_start()
+                where = "%s episode %d step %d (%d samples in use)" % (case, ep, t + 1, n_eff)
+                np.testing.assert_allclose(o.t["tax_saez_bracket_rates"][0], tc.curr_bracket_tax_rates,
+                                           rtol=1e-9, atol=1e-9, err_msg=where)
+                np.testing.assert_allclose(o.t["saez_elas"][0], [tc.elas_t, tc.elas_tm1, tc.log_z0_t, tc.log_z0_tm1],
+                                           rtol=1e-9, atol=1e-9, err_msg=where)
+                np.testing.assert_allclose(o.t["saez_running_avg_tax_rates"][0], tc.running_avg_tax_rates,
+                                           rtol=1e-9, atol=1e-12, err_msg=where)
+                checked += 1
+                with_global += int(bool(tc._global_saez_buffer))
+    assert checked >= 20 and with_global >= 10, (checked, with_global)

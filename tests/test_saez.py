@@ -183,3 +183,63 @@ def test_hip_saez_runs_into_the_formula_phase():
     assert be.tensors["saez_reached_min_samples"].cpu().numpy().all()
     m = env.metrics
     assert np.isfinite(m["PeriodicTax/saez/estimated_elasticity"]).all()
+
+
+@pytest.mark.gpu
+def test_hip_saez_global_buffer_union_matches_oracle():
+    """set_global_saez_buffer on the device (aie_set_global_saez_buffer): replicas fill their local buffers, the union
+    of all of them (sharding.accumulate_and_broadcast_saez_buffers, the reference's trainer-side exchange,
+    tutorials/rllib/utils/remote.py:56-73) becomes the global buffer, and the following period starts -- global + each
+    replica's own new samples -- agree with the restatement (which tests/test_oracle_vs_reference.py pins to the live
+    reference) to 1e-9."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    from ai_economist_amd.sharding import accumulate_and_broadcast_saez_buffers
+
+    cfg, size = _cfg("inverse_income")
+    cfg["episode_length"] = 30
+    E = 24
+    host = make_env(cfg, n_envs=E, device="cuda:0")
+    tax = host.get_component("PeriodicBracketTax")
+    tax._buffer_size = size
+    host.seed(5)
+    host.reset()
+    be = host.backend
+    oracle = OracleEnv(host.build_config(), host.layout_planes())
+    oracle.seed(5)
+    oracle.reset()
+    assert be.tensors["saez_global_buffer"].shape[1] == E * size
+
+    def run(steps):
+        for _ in range(steps):
+            a, p = be.sample_random_actions(seed=3)
+            host.step({"a": a, "p": p})
+            torch.cuda.synchronize()
+            oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+            if bool(be.tensors["done"][0]):
+                host.reset(be.tensors["done"])
+                oracle.reset(oracle.t["done"].copy())
+
+    run(30)  # random-rate phase: every replica collects samples
+    n_loc = be.tensors["saez_buffer_len"].cpu().numpy()
+    assert n_loc.min() > 0 and np.array_equal(n_loc, oracle.t["saez_buffer_len"])
+    glob = accumulate_and_broadcast_saez_buffers(host)
+    assert glob.shape == (int(n_loc.sum()), 2) and int(be.tensors["saez_global_len"][0]) == int(n_loc.sum())
+    want = np.concatenate([oracle.t["saez_buffer"][e, : n_loc[e]] for e in range(E)])
+    np.testing.assert_allclose(glob.cpu().numpy(), want, rtol=1e-9, atol=1e-9)
+    oracle.set_global_saez_buffer(want)
+    assert np.array_equal(be.tensors["saez_additions"].cpu().numpy(), oracle.t["saez_additions"])
+    # the global buffer alone holds far more than _buffer_size samples: the very next period start runs the formula
+    for k in range(12):
+        run(1)
+        for name in ("tax_saez_bracket_rates", "saez_elas", "saez_running_avg_tax_rates"):
+            np.testing.assert_allclose(be.tensors[name].cpu().numpy(), oracle.t[name], rtol=1e-9, atol=1e-9,
+                                       err_msg="step %d after the union: %s" % (k + 1, name))
+        assert np.array_equal(be.tensors["saez_reached_min_samples"].cpu().numpy(), oracle.t["saez_reached_min_samples"])
+    assert int(be.tensors["saez_reached_min_samples"].min()) == 1
+    # reset_saez_buffers empties local and global buffers: random rates again
+    tax.reset_saez_buffers()
+    assert int(be.tensors["saez_global_len"][0]) == 0 and int(be.tensors["saez_additions"].abs().sum()) == 0
+    with pytest.raises(ValueError):
+        be._check(be.lib.aie_set_global_saez_buffer(be.handle, glob.data_ptr(), E * size + 1))

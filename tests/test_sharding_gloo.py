@@ -146,3 +146,56 @@ def test_reward_log_gather_single_process_keeps_blocks():
         for k in range(3):
             t = blk * 3 + k
             assert torch.equal(got[0, k, :, 2], -torch.arange(5, dtype=torch.float32) - t)
+
+
+class _FakeTax:
+    """Stands in for PeriodicBracketTax on a rank: E replicas with local Saez buffers of different lengths."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.lens = [3 + rank, 0, 5] if rank == 0 else [2, 4]
+        self.got = None
+
+    def local_saez_samples(self, env=None):
+        rows = []
+        for e, m in enumerate(self.lens):
+            for k in range(m):
+                rows.append([1000.0 * self.rank + 100.0 * e + k, 0.01 * k])
+        return torch.tensor(rows, dtype=torch.float64).reshape(-1, 2)
+
+    def set_global_saez_buffer(self, glob, env=None):
+        self.got = glob.clone()
+
+
+class _FakeEnv:
+    def __init__(self, rank):
+        self.tax = _FakeTax(rank)
+
+    def get_component(self, name):
+        assert name == "PeriodicBracketTax"
+        return self.tax
+
+
+def _saez_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ai_economist_amd.sharding import accumulate_and_broadcast_saez_buffers
+
+    env = _FakeEnv(rank)
+    glob = accumulate_and_broadcast_saez_buffers(env)
+    want = torch.cat([_FakeTax(0).local_saez_samples(), _FakeTax(1).local_saez_samples()], dim=0)  # rank-major
+    out[rank] = bool(torch.equal(glob, want) and torch.equal(env.tax.got, want) and glob.shape == (14, 2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_saez_buffer_union_world2_gloo():
+    """sharding.accumulate_and_broadcast_saez_buffers (reference: tutorials/rllib/utils/remote.py:56-73): ranks with
+    different numbers of local samples end up with the same rank-major, replica-major concatenation."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_saez_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
