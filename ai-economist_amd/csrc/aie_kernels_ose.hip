@@ -659,7 +659,7 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   ose_step_body<-1>(params, arena, act_a, act_p, next, lds);
 }
 template <int SPEC>
-__global__ void __launch_bounds__(OSE_NT)
+__global__ void __launch_bounds__(OSE_NT)  // (capping at 128 VGPRs for 4 waves per SIMD spills: 2.15 vs 2.11 ms at C5)
 aie_ose_step_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                          const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];

@@ -403,7 +403,8 @@ class BaseEnvironment:
         from . import metrics as _metrics
 
         t = {k: v.cpu().numpy() for k, v in self.backend.tensors.items()
-             if not k.startswith("obs_") and not k.startswith("model_") and k not in ("mt", "cells")}
+             if not k.startswith("obs_") and not k.startswith("model_") and not k.startswith("saez_global")
+             and k not in ("mt", "cells")}
         return _metrics.env_metrics(self, t)
 
     @property

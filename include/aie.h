@@ -173,7 +173,7 @@ typedef struct aie_config {
                                       * (uniform/..., dynamic_layout.py:420-431)        */
   int32_t energy_warmup_method;
   int32_t planner_reward_type;
-  int32_t regen_halfwidth[AIE_N_RES];/* must be 0 (bit-exact guarantee)  */
+  int32_t regen_halfwidth[AIE_N_RES];/* 0..3 (dynamic_layout.py:150-153); > 0 needs max_health == 1 */
   int32_t max_health[AIE_N_RES];
   double regen_weight[AIE_N_RES];
   double starting_agent_coin;

@@ -809,6 +809,7 @@ static void wealth_step(ctx_t* c) {
  * spawnable reduces to "is a source block"; rand(H,W) is drawn for Wood, then Stone. */
 static void scenario_step(ctx_t* c) {
   const aie_params* p = c->p;
+  uint8_t* health = NULL;
   for (int q = 0; q < 2; ++q) {
     int rsrc = q == 0 ? 1 : 0; /* ["Wood", "Stone"] */
     unsigned srcbit = rsrc ? AIE_CELL_WOOD_SRC : AIE_CELL_STONE_SRC;
@@ -816,22 +817,29 @@ static void scenario_step(ctx_t* c) {
     int mh = p->c.max_health[rsrc];
     const int hw = p->c.regen_halfwidth[rsrc], d = 1 + 2 * hw;
     const double kern = w / (double)(d * d); /* regen_weight * ones((d, d)) / d**2, dynamic_layout.py:446-449 */
+    if (hw > 0) { /* the plane the reference convolves, BEFORE this resource's respawns: max(map, source blocks) */
+      if (!health) health = (uint8_t*)malloc((size_t)p->HW);
+      for (int cell = 0; cell < p->HW; ++cell) {
+        int m = CB(c, cell, rsrc), src = (C_FLAGS(c, cell) & srcbit) ? 1 : 0;
+        health[cell] = (uint8_t)(m > src ? m : src);
+      }
+    }
     for (int cell = 0; cell < p->HW; ++cell) {
       double u = rng_double(c);
       int m = CB(c, cell, rsrc), src = (C_FLAGS(c, cell) & srcbit) ? 1 : 0;
-      int health = m > src ? m : src;
-      double prob = w * (double)health;
+      int hl = m > src ? m : src;
+      double prob = w * (double)hl;
       if (hw > 0) {
-        /* signal.convolve2d(health, kernel, "same"): zero-padded window sum, one multiply-add per
-         * kernel element (scipy/signal/_firfilter.c pylab_convolve_2d) */
+        /* signal.convolve2d(health, kernel, "same"): zero-filled window, one multiply-add per kernel element in
+         * kernel row-major order, i.e. input rows r0+hw .. r0-hw, within a row columns c0+hw .. c0-hw
+         * (scipy/signal/_firfilter.c pylab_convolve_2d; the order matters once max_health > 1 makes the terms
+         * differ; checked bit for bit against scipy in tests/test_regen_neighbourhood.py) */
         const int r0 = cell / p->W, c0 = cell % p->W;
         prob = 0.0;
-        for (int r = r0 - hw; r <= r0 + hw; ++r)
-          for (int cc = c0 - hw; cc <= c0 + hw; ++cc) {
-            if (r < 0 || r >= p->H || cc < 0 || cc >= p->W) continue;
-            int q2 = r * p->W + cc;
-            int m2 = CB(c, q2, rsrc), s2 = (C_FLAGS(c, q2) & srcbit) ? 1 : 0;
-            prob += (double)(m2 > s2 ? m2 : s2) * kern;
+        for (int r = r0 + hw; r >= r0 - hw; --r)
+          for (int cc = c0 + hw; cc >= c0 - hw; --cc) {
+            if (r < 0 || r >= p->H || cc < 0 || cc >= p->W) continue; /* + kern * 0.0 */
+            prob += kern * (double)health[r * p->W + cc];
           }
       }
       int respawn = (u < prob) && src > 0;
@@ -839,6 +847,7 @@ static void scenario_step(ctx_t* c) {
       CB(c, cell, rsrc) = (uint8_t)(v < mh ? v : mh);
     }
   }
+  free(health);
 }
 
 /* energy_weight :249-267 */

@@ -26,6 +26,8 @@ C2 = dict(scenario_name="layout_from_file/simple_wood_and_stone", n_agents=4, wo
 def _replica(be, e):
     out = {}
     for k, t in be.tensors.items():
+        if t.shape[0] != be.E:  # tensors shared by all replicas (the global Saez buffer)
+            continue
         v = t[e].cpu().numpy()
         if k == "mt":
             v = v.view(np.uint32)
