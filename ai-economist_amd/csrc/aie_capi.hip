@@ -382,7 +382,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
-  else if (env->step_waves == 2 && (env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT ||
+  else if (env->step_waves == 2 && (env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT || env->P.regen_general ||
                                     env->P.dev_skip_mask != 0 || env->P.dev_trace != nullptr))
     hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);

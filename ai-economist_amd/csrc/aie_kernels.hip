@@ -62,6 +62,7 @@ struct Ctx {
   int32_t* srcn;     // LDS [1] number of source doubles found (may exceed AIE_SRC_CAP)
   int32_t* mflags;   // LDS [n] per-agent mask bits
   int32_t* dirty;    // LDS [4 + AIE_DIRTY_CAP/2]: count, moved-agent mask (2 words), pad, uint16 cell list
+  uint8_t* snap;     // LDS [2][HW]: pre-step max(map, source block) per resource (P.regen_general only), else nullptr
   uint8_t* met;      // GLOBAL: this replica's episode accumulators (aie_layout.h: a_metrics), or nullptr
   int32_t* ev;       // GLOBAL: this replica's dense-log event rows (a_events), or nullptr (not logged)
   bool saez;         // tax_model == "saez" (compile-time false in the common step kernel, like ev == nullptr)
@@ -114,6 +115,8 @@ __host__ __device__ inline size_t lds_bytes(const aie_params& P) {
   b += stage_bytes(P);
   b += AIE_SRC_CAP * 2 + 16 + (size_t)pad4(P.n) * 4;
   b += 16 + AIE_DIRTY_CAP * 2;
+  b = (b + 15) / 16 * 16;
+  if (P.regen_general) b += 2 * (((size_t)P.HW + 15) / 16 * 16);
   return (b + 15) / 16 * 16;
 }
 
@@ -136,13 +139,16 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R
   int32_t* mflags = reinterpret_cast<int32_t*>(q);
   q += pad4(P.n) * 4;
   int32_t* dirty = reinterpret_cast<int32_t*>(q);
+  q += 16 + AIE_DIRTY_CAP * 2;
+  q = lds + ((q - lds) + 15) / 16 * 16;
+  uint8_t* snap = P.regen_general ? q : nullptr;
   uint8_t* met = arena ? arena + R.a_metrics + (int64_t)e * P.met_bytes : nullptr;
   // with_events == false is a compile-time constant in the common step kernel: every `if (c.ev)` / `if (c.saez)`
   // folds away (environments with dense-log replicas or tax_model "saez" run aie_step_kernel_log)
   int32_t* ev = (with_events && arena && e < P.ev_replicas)
                     ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * P.ev_stride) : nullptr;
   const bool saez = with_events && P.c.tax_model == AIE_TAX_SAEZ;
-  return Ctx{P, R, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, met, ev, saez, with_events, tid, e};
+  return Ctx{P, R, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, snap, met, ev, saez, with_events, tid, e};
 }
 
 // ------------------------------------------------------------------------------------
@@ -1421,9 +1427,24 @@ __device__ __forceinline__ void regen_cell(const Ctx& c, uint32_t ta, uint32_t t
     const uint32_t health = mval > 1u ? mval : 1u;  // max(map, source block = 1)
     const double u = u53(ta, tb);
     // halfwidth 0: p = regen_weight * health; else regen_p[source blocks in the window] (aie_layout.h: regen_conv)
-    const double p = (c.P.regen_conv && c.P.c.regen_halfwidth[rs] > 0)
-                         ? c.P.regen_p[rs][R_U8(c, o_regen_count)[rs * HW + cell]]
-                         : c.P.c.regen_weight[rs] * (double)health;
+    double p;
+    const int hwid = c.P.regen_conv ? c.P.c.regen_halfwidth[rs] : 0;
+    if (c.full && c.snap && hwid > 0 && c.P.c.max_health[rs] > 1) {
+      // signal.convolve2d(max(map, source blocks), regen_weight / d^2 * ones(d, d), "same") at this cell, one
+      // multiply-add per kernel element in scipy's order (input rows r0+hw .. r0-hw, columns c0+hw .. c0-hw, zeros
+      // outside the world), over the pre-step snapshot (dynamic_layout.py:446-463)
+      const int dd = 1 + 2 * hwid, W = c.P.W, r0 = cell / W, c0 = cell - r0 * W;
+      const double kern = c.P.c.regen_weight[rs] / (double)(dd * dd);
+      const uint8_t* sp = c.snap + rs * ((HW + 15) / 16 * 16);
+      p = 0.0;
+      for (int r = r0 + hwid; r >= r0 - hwid; --r)
+        for (int cc = c0 + hwid; cc >= c0 - hwid; --cc)
+          if (r >= 0 && r < c.P.H && cc >= 0 && cc < W) p += kern * (double)sp[r * W + cc];
+    } else if (hwid > 0) {
+      p = c.P.regen_p[rs][R_U8(c, o_regen_count)[rs * HW + cell]];
+    } else {
+      p = c.P.c.regen_weight[rs] * (double)health;
+    }
     if (u < p && mval < (uint32_t)c.P.c.max_health[rs]) {
       cb[rs] = (uint8_t)(mval + 1);
       dirty_add_lane(c, cell);
@@ -1482,6 +1503,17 @@ __device__ __forceinline__ void scenario_step_regen_rows(const Ctx& c, MT& m) {
 // win0_in_lds: the caller kept the current window's raw words in c.stage (MTL), so the first
 // window needs no dump.
 __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool win0_in_lds = false) {
+  if (c.full && c.snap) {  // P.regen_general: the planes the reference convolves, before any of this step's respawns
+    const int HW = c.P.HW, stride = (HW + 15) / 16 * 16;
+    const uint8_t* cb = reinterpret_cast<const uint8_t*>(R_CELLS(c));
+    for (int q = c.tid; q < HW; q += AIE_NT) {
+      const uint32_t fl = cb[4 * q + 3];
+      const uint8_t s0 = cb[4 * q], s1 = cb[4 * q + 1];
+      c.snap[q] = (fl & AIE_CELL_STONE_SRC) ? (s0 > 1 ? s0 : 1) : s0;
+      c.snap[stride + q] = (fl & AIE_CELL_WOOD_SRC) ? (s1 > 1 ? s1 : 1) : s1;
+    }
+    AIE_WSYNC();
+  }
   const int S = uni(*c.srcn);
   if (S > AIE_SRC_CAP) {
     scenario_step_regen_rows(c, m);

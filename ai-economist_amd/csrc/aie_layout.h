@@ -119,6 +119,9 @@ typedef struct aie_params {
    * probability is regen_p[resource][number of source blocks in the d x d window]; the reset kernel
    * counts the window once per episode into the record plane o_regen_count. */
   int32_t regen_conv;    /* 1: some regen_halfwidth > 0 */
+  int32_t regen_general; /* 1: some resource has regen_halfwidth > 0 AND max_health > 1: the convolved plane changes
+                          * with the map, so its probabilities are true window sums (scipy's accumulation order)
+                          * over a pre-step snapshot of max(map, source blocks); aie_step_kernel_log only */
   int32_t o_regen_count; /* u8 [AIE_N_RES][H*W] */
   double regen_p[AIE_N_RES][50];
   /* tax_model "saez" (redistribution.py:436-823): per-replica block outside the streamed record,
@@ -710,10 +713,6 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   for (int r = 0; gtb && r < AIE_N_RES; ++r) {
     if (c->regen_halfwidth[r] < 0 || c->regen_halfwidth[r] > 3)
       AIE__FAIL("regen_halfwidth must be in [0, 3] (dynamic_layout.py:152-153)");
-    if (c->regen_halfwidth[r] > 0 && c->max_health[r] != 1) {
-      if (err) snprintf(err, errlen, "regen_halfwidth > 0 is supported with max_health == 1 (what the reference's scenarios use)");
-      return AIE_E_UNSUPPORTED;
-    }
     if (!(c->regen_weight[r] >= 0.0 && c->regen_weight[r] <= 1.0)) AIE__FAIL("regen_weight not in [0,1]");
     if (c->max_health[r] < 1 || c->max_health[r] > 255) AIE__FAIL("max_health out of range");
   }
@@ -907,6 +906,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   int32_t cur = 0;
   p->o_cells = aie__rec(&cur, 4 * HW, 16);
   p->regen_conv = c->regen_halfwidth[0] > 0 || c->regen_halfwidth[1] > 0;
+  p->regen_general = (c->regen_halfwidth[0] > 0 && c->max_health[0] > 1) || (c->regen_halfwidth[1] > 0 && c->max_health[1] > 1);
   if (p->regen_conv) p->o_regen_count = aie__rec(&cur, AIE_N_RES * HW, 16);
   for (int r = 0; r < AIE_N_RES; ++r) {
     /* convolve2d accumulates sum += health * kernel over the window: m equal terms k, in sequence */
