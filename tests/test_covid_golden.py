@@ -6,7 +6,8 @@ Tolerances (the reference's own CPU<->CUDA tolerance lives in un-vendored WarpDr
 are ours): the SIR state is float32 arithmetic with IEEE basic operations only and is compared
 at rtol 1e-6 (HIP vs oracle: a few float32 ulps would show a misplaced cast); unemployment /
 productivity go through exp/log and a reordered float64 filter sum: rtol 1e-5; rewards are
-min-max normalised differences of nearly equal float32 numbers: atol 2e-5."""
+min-max normalised differences of nearly equal float32 numbers: atol 1e-5 (the 1e-5 of BASELINE's north star;
+measured at 8192 replicas x 64 days: max 2.4e-6, tests/test_gpu_full_size.py)."""
 import os
 import sys
 
@@ -70,9 +71,9 @@ def check_against_golden(g, t, state, obs, rew_a, rew_p, done, where):
                                            rtol=1e-5, atol=1e-6, err_msg="%s t=%d %s" % (where, t, k))
     if t > 0:
         want = g["rewards"][t - 1]
-        np.testing.assert_allclose(np.asarray(rew_a, np.float64), want[:-1], rtol=0, atol=2e-5,
+        np.testing.assert_allclose(np.asarray(rew_a, np.float64), want[:-1], rtol=0, atol=1e-5,
                                    err_msg="%s t=%d agent rewards" % (where, t))
-        np.testing.assert_allclose(float(rew_p), want[-1], rtol=0, atol=2e-5, err_msg="%s t=%d planner reward" % (where, t))
+        np.testing.assert_allclose(float(rew_p), want[-1], rtol=0, atol=1e-5, err_msg="%s t=%d planner reward" % (where, t))
         assert int(done) == int(g["done"][t - 1]), "%s t=%d done" % (where, t)
 
 
@@ -184,8 +185,8 @@ def test_covid_hip_matches_oracle_on_batched_rollouts(name, E, T):
         p = rng.randint(0, ns + 1, size=(E,)).astype(np.int32)
         env.step({"a": torch.as_tensor(a, device="cuda"), "p": torch.as_tensor(p[:, None], device="cuda")})
         o.step(a, p)
-        np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), o.rew_a, rtol=0, atol=2e-5, err_msg="step %d" % k)
-        np.testing.assert_allclose(t["rewards_p"].cpu().numpy(), o.rew_p, rtol=0, atol=2e-5, err_msg="step %d" % k)
+        np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), o.rew_a, rtol=0, atol=1e-5, err_msg="step %d" % k)
+        np.testing.assert_allclose(t["rewards_p"].cpu().numpy(), o.rew_p, rtol=0, atol=1e-5, err_msg="step %d" % k)
         assert np.array_equal(t["done"].cpu().numpy(), o.done), "done at step %d" % k
         if k % 10 == 0 or k == T:
             compare("step %d" % k)
@@ -227,8 +228,8 @@ def test_covid_hip_matches_oracle_on_random_configs(seed):
         p = rng.randint(0, ns + 1, size=(E,)).astype(np.int32)
         env.step({"a": torch.as_tensor(a, device="cuda"), "p": torch.as_tensor(p[:, None], device="cuda")})
         o.step(a, p)
-        np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), o.rew_a, rtol=0, atol=2e-5, err_msg="step %d" % k)
-        np.testing.assert_allclose(t["rewards_p"].cpu().numpy(), o.rew_p, rtol=0, atol=2e-5, err_msg="step %d" % k)
+        np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), o.rew_a, rtol=0, atol=1e-5, err_msg="step %d" % k)
+        np.testing.assert_allclose(t["rewards_p"].cpu().numpy(), o.rew_p, rtol=0, atol=1e-5, err_msg="step %d" % k)
         assert np.array_equal(t["done"].cpu().numpy(), o.done), "done at step %d" % k
         if k % 15 == 0 or k == T:
             compare("step %d" % k)
@@ -306,6 +307,6 @@ def test_covid_filter_recurrence_vs_exact_window_sums():
             worst = max(worst, float(((u_r - u_x).abs() / u_x.abs().clamp_min(1.0)).max()))
             for name, tol in STATE_TOL.items():
                 np.testing.assert_allclose(tr[name].cpu().numpy(), tx[name].cpu().numpy(), rtol=tol, atol=1e-3, err_msg=name)
-            np.testing.assert_allclose(tr["rewards_a"].cpu().numpy(), tx["rewards_a"].cpu().numpy(), rtol=0, atol=2e-5)
+            np.testing.assert_allclose(tr["rewards_a"].cpu().numpy(), tx["rewards_a"].cpu().numpy(), rtol=0, atol=1e-5)
     assert worst < 4e-6, "unemployed: recurrence vs exact window sums differ by %.3g relative" % worst
     print("covid filter recurrence: max relative deviation of `unemployed` from the exact window sums: %.3g" % worst)

@@ -147,9 +147,9 @@ def test_c4_full_batch_matches_oracle():
     for k in range(1, T + 1):
         env.step({"a": torch.as_tensor(acts_a[k - 1], device="cuda"),
                   "p": torch.as_tensor(acts_p[k - 1][:, None], device="cuda")})
-        np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), want["rew_a"][k - 1], rtol=0, atol=2e-5,
+        np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), want["rew_a"][k - 1], rtol=0, atol=1e-5,
                                    err_msg="C4 day %d agent rewards" % k)
-        np.testing.assert_allclose(t["rewards_p"].cpu().numpy(), want["rew_p"][k - 1], rtol=0, atol=2e-5,
+        np.testing.assert_allclose(t["rewards_p"].cpu().numpy(), want["rew_p"][k - 1], rtol=0, atol=1e-5,
                                    err_msg="C4 day %d planner reward" % k)
         err_a.append(np.abs(t["rewards_a"].cpu().numpy().astype(np.float64) - want["rew_a"][k - 1]).ravel())
         err_p.append(np.abs(t["rewards_p"].cpu().numpy().astype(np.float64) - want["rew_p"][k - 1]).ravel())
@@ -164,7 +164,7 @@ def test_c4_full_batch_matches_oracle():
                 np.testing.assert_allclose(t[name].cpu().numpy().reshape(v.shape), v, rtol=1e-5, atol=1e-6,
                                            err_msg="C4 day %d %s" % (k, name))
     assert not bool(t["done"].any()) and int(t["timestep"].min()) == T
-    # the reward-error distribution behind the 2e-5 tolerance (rewards are min-max normalised differences of nearly
+    # the reward-error distribution behind the 1e-5 tolerance (rewards are min-max normalised differences of nearly
     # equal float32 numbers; the reference's own CPU<->CUDA tolerance is not in its repository)
     ea, ep = np.concatenate(err_a), np.concatenate(err_p)
     q = lambda x: [float(np.quantile(x, p)) for p in (0.5, 0.99, 0.9999, 1.0)]  # noqa: E731
