@@ -385,11 +385,17 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    # warm-up runs the very code path of the timed region (event-bracketed resets included), so that first-use costs
+    # (event creation, cold Python paths) are not charged to a short timed window
+    warm0, warm1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    warm0.record()
     for _ in range(args.warmup):
-        roll.step()
+        roll.step(timed=True)
         if gather is not None:
             gather.after_step()
+    warm1.record()
     torch.cuda.synchronize()
+    roll.reset_events.clear()
     barrier()
     # one pair of HIP events on the launch stream around the whole timed region (K back-to-back step launches)
     # plus one pair around each of the (rare) reset launches inside it: average step-kernel launch period =
