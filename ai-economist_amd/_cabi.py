@@ -5,7 +5,7 @@ by env.py purely as the owner of device memory / streams.
 """
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_AGENTS = 64
 MAX_AGENTS_WIDE = 128
 MAX_COMPONENTS = 8
@@ -20,6 +20,7 @@ COMP_WEALTH_REDISTRIBUTION = 9
 # flag byte of the packed map cell ("cell_flags" tensor; csrc/aie_layout.h: AIE_CELL_*)
 CELL_WATER, CELL_STONE_SRC, CELL_WOOD_SRC = 1, 2, 4
 SCN_GTB, SCN_ONE_STEP_ECONOMY, SCN_COVID = 0, 1, 2
+LAYOUT_FIXED, LAYOUT_UNIFORM, LAYOUT_QUADRANT, LAYOUT_MULTI_ZONE = 0, 1, 2, 3
 COVID_MAX_FILTERS = 8
 MAX_TENSORS = 128  # AIE_MAX_TENSORS (csrc/aie_layout.h)
 AGENT_REWARD = {"coin_minus_labor_cost": 0, "isoelastic_coin_minus_labor": 1}
@@ -130,6 +131,14 @@ class AieConfig(C.Structure):
         ("saez_fixed_elas_given", C.c_int32),
         ("saez_global_capacity", C.c_int32),
         ("saez_fixed_elas", C.c_double),
+        ("layout_gen", C.c_int32),
+        ("layout_checker", C.c_int32),
+        ("layout_coverage", C.c_double * N_RES),
+        ("layout_clump", C.c_double * N_RES),
+        ("mz_rows", C.c_int32),
+        ("mz_cols", C.c_int32),
+        ("mz_zones", C.c_int32 * 3),
+        ("layout_pad_", C.c_int32),
     ]
 
 

@@ -89,7 +89,7 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
   const bool covid = cfg->scenario == AIE_SCN_COVID;
   const bool ose = cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY || covid;  // map-less: no cell words to initialise
   env->lds = covid ? 0 : cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY ? aie::ose_lds_bytes(env->P) : aie::lds_bytes(env->P);
-  if (env->lds > 64 * 1024) {
+  if (env->lds + (covid ? 0 : aie::layout_gen_lds_bytes(env->P)) > 64 * 1024) {
     snprintf(g_create_err, sizeof(g_create_err),
              "per-replica working set (%zu B of LDS) exceeds 64 KiB: reduce max_num_orders / world size", env->lds);
     delete env;
@@ -302,7 +302,7 @@ int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
     hipLaunchKernelGGL(aie_ose_reset_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
   else
-    hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
+    hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds + aie::layout_gen_lds_bytes(env->P),
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask, 0);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
@@ -411,8 +411,9 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
       hipLaunchKernelGGL(aie_covid_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0,
                          static_cast<hipStream_t>(stream), env->d_params, env->arena, done, 1);
     else
-      hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
-                         static_cast<hipStream_t>(stream), env->d_params, env->arena, done, 1);
+      hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT),
+                         env->lds + aie::layout_gen_lds_bytes(env->P), static_cast<hipStream_t>(stream), env->d_params,
+                         env->arena, done, 1);
   }
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
@@ -441,9 +442,10 @@ int aie_set_global_saez_buffer(aie_env* env, const double* d_pairs, int64_t n_pa
 
 int aie_set_auto_reset(aie_env* env, int on) {
   if (!env) return AIE_E_INVALID;
-  if (on && env->P.c.scenario == AIE_SCN_GTB && !env->P.c.shared_layout) {
-    // uniform/, quadrant/, multi_zone/: the layout of the next episode is generated on the host (host_pre_reset)
-    snprintf(env->err, sizeof(env->err), "auto-reset is not available for scenarios whose reset has a host-side part");
+  if (on && env->P.c.scenario == AIE_SCN_GTB && !env->P.c.shared_layout && env->P.c.layout_gen == AIE_LAYOUT_FIXED) {
+    // per-replica layouts supplied from outside (worlds too large for the device-side generator): the next
+    // episode's layout comes from the host
+    snprintf(env->err, sizeof(env->err), "auto-reset is not available when the host supplies a new layout per episode");
     return AIE_E_UNSUPPORTED;
   }
   env->P.auto_reset = on ? 1 : 0;

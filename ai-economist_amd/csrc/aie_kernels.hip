@@ -2321,6 +2321,173 @@ aie_step_kernel_w1(const aie_params* __restrict__ params, uint8_t* __restrict__ 
   step_body<1, true>(params, arena, act_a, act_p, lds, NextActions{nullptr, nullptr, 0, 0, 0, nullptr});
 }
 
+namespace aie {
+// LDS the layout generator needs behind the reset kernel's regular regions: two f64 planes + two byte planes + the
+// multi_zone region grid
+__host__ __device__ inline size_t layout_gen_lds_bytes(const aie_params& P) {
+  if (P.c.layout_gen == AIE_LAYOUT_FIXED) return 0;
+  const size_t hwp = ((size_t)P.HW + 15) / 16 * 16;
+  return 2 * hwp * 8 + 2 * hwp + 256 * 4;
+}
+
+// Source layouts drawn at reset from the replica's own stream: Uniform.reset_starting_layout (dynamic_layout.py:313-392),
+// MultiZone's per-reset zone shuffle (:778-872), Quadrant's empty water lines (:992-1024).  One wavefront; every draw
+// is wave-uniform and in the reference's order (rand / randn planes row-major, the legacy gauss cache included),
+// np.mean of a 0/1 plane is count / size (ballots), signal.convolve2d(x, kernel, "same") is one multiply-add per
+// kernel element in scipy's order over the zero-filled 7x7 window (a zero kernel element adds +-0: skipped).
+// Restated for the checker in oracle/aie_oracle.c (layout_generate), which the CPU tests pin to the live reference.
+__device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8_t* __restrict__ arena, uint8_t* extra) {
+  const aie_params& P = c.P;
+  const aie_config& g = P.c;
+  const int H = P.H, W = P.W, HW = P.HW, lane = c.tid;
+  const int hwp = (HW + 15) / 16 * 16;
+  double* tmp = reinterpret_cast<double*>(extra);
+  double* x = tmp + hwp;
+  uint8_t* mbp[2] = {reinterpret_cast<uint8_t*>(x + hwp), reinterpret_cast<uint8_t*>(x + hwp) + hwp};
+  int32_t* grid = reinterpret_cast<int32_t*>(mbp[1] + hwp);
+  const double* shared_prob = reinterpret_cast<const double*>(arena + c.R.a_layout_prob);
+  const bool mz = g.layout_gen == AIE_LAYOUT_MULTI_ZONE;
+  double mz_scale[2] = {0.0, 0.0};
+  int size_r = 1, size_c = 1;
+  if (mz) {  // np.random.shuffle of the flat zone grid, then prob / np.mean(prob) * Wood's coverage
+    const int regions = g.mz_rows * g.mz_cols;
+    for (int k = lane; k < regions; k += AIE_NT) {
+      int z = -1;
+      if (k < g.mz_zones[0]) z = 0;
+      else if (k < g.mz_zones[0] + g.mz_zones[1]) z = 1;
+      else if (k < g.mz_zones[0] + g.mz_zones[1] + g.mz_zones[2]) z = 2;
+      grid[k] = z;
+    }
+    AIE_WSYNC();
+    for (int i = regions - 1; i >= 1; --i) {
+      const int j = (int)rng_interval(m, lane, (uint32_t)i);
+      if (lane == 0) { const int t = grid[i]; grid[i] = grid[j]; grid[j] = t; }
+      AIE_WSYNC();
+    }
+    size_r = (H + g.mz_rows - 1) / g.mz_rows;
+    size_c = (W + g.mz_cols - 1) / g.mz_cols;
+    for (int rs = 0; rs < 2; ++rs) {
+      const int own = rs == 1 ? 0 : 1;  // zone index: Wood 0, Stone 1, WoodStone 2
+      int cnt = 0;
+      for (int base = 0; base < HW; base += AIE_NT) {
+        const int cell = base + lane;
+        bool in = false;
+        if (cell < HW) {
+          const int r = cell / W, col = cell - r * W;
+          const int z = grid[(r / size_r) * g.mz_cols + col / size_c];
+          in = z == own || z == 2;
+        }
+        cnt += __popcll(__ballot(in));
+      }
+      mz_scale[rs] = (1.0 / ((double)cnt / (double)HW)) * g.layout_coverage[1];
+    }
+  }
+  auto source_prob = [&](int rs, int cell, double clump) -> double {
+    double v;
+    if (mz) {
+      const int r = cell / W, col = cell - r * W;
+      const int z = grid[(r / size_r) * g.mz_cols + col / size_c];
+      v = (z == (rs == 1 ? 0 : 1) || z == 2) ? mz_scale[rs] : 0.0;
+    } else {
+      v = shared_prob[rs * HW + cell];
+    }
+    return v * 0.1 * clump;
+  };
+  bool happy = false;
+  for (int tries = 0; tries < 100 && !happy; ++tries) {
+    for (int q = 0; q < 2; ++q) {
+      const int rs = q == 0 ? 1 : 0;  // ["Wood", "Stone"]
+      const double cov = g.layout_coverage[rs], clump = g.layout_clump[rs];
+      uint8_t* mb = mbp[rs];
+      const uint8_t* other = q == 0 ? nullptr : mbp[1];  // empty = nothing placed on the tile yet
+      for (int cell = 0; cell < HW; ++cell) {  // tmp = rs.rand(H, W)
+        const double u = rng_double(m, lane);
+        if (lane == (cell & 63)) tmp[cell] = u;
+      }
+      AIE_WSYNC();
+      int count = 0;
+      for (int base = 0; base < HW; base += AIE_NT) {
+        const int cell = base + lane;
+        bool on = false;
+        if (cell < HW) {
+          on = (tmp[cell] < source_prob(rs, cell, clump)) && !(other && other[cell]);
+          mb[cell] = on ? 1 : 0;
+        }
+        count += __popcll(__ballot(on));
+      }
+      int n_tries = 0;
+      while ((double)count / (double)HW < cov * clump) {
+        count = 0;
+        for (int base = 0; base < HW; base += AIE_NT) {
+          const int cell = base + lane;
+          bool on = false;
+          if (cell < HW) {
+            const double t = tmp[cell] * 0.9;
+            tmp[cell] = t;
+            on = (t < source_prob(rs, cell, clump)) && !(other && other[cell]);
+            mb[cell] = on ? 1 : 0;
+          }
+          count += __popcll(__ballot(on));
+        }
+        if (++n_tries > 200) break;
+      }
+      AIE_WSYNC();
+      while ((double)count / (double)HW < cov) {
+        uint64_t kmask = 0;  // kernel = rs.randn(7, 7) > 0, row-major
+        for (int k = 0; k < 49; ++k) kmask |= (rng_gauss(c, m) > 0 ? 1ull : 0ull) << k;
+        for (int cell = 0; cell < HW; ++cell) {  // maybe + 0.2 * rs.randn(H, W) - 0.25
+          const double gs = rng_gauss(c, m);
+          if (lane == (cell & 63)) x[cell] = ((double)mb[cell] + (0.2 * gs)) - 0.25;
+        }
+        AIE_WSYNC();
+        count = 0;
+        for (int base = 0; base < HW; base += AIE_NT) {
+          const int cell = base + lane;
+          bool on = false;
+          if (cell < HW) {
+            const int r0 = cell / W, c0 = cell - r0 * W;
+            double sum = 0.0;
+            for (int j = 0; j < 7; ++j) {
+              const int i0 = r0 + 3 - j;
+              if (i0 < 0 || i0 >= H) continue;
+              for (int k = 0; k < 7; ++k) {
+                const int i1 = c0 + 3 - k;
+                if (i1 >= 0 && i1 < W && ((kmask >> (j * 7 + k)) & 1ull)) sum += x[i0 * W + i1];
+              }
+            }
+            on = ((sum > 0) || mb[cell]) && !(other && other[cell]);
+          }
+          const uint64_t b = __ballot(on);
+          count += __popcll(b);
+          if (cell < HW) mb[cell] = on ? 1 : 0;  // (a cell's new value depends on x and its own old value only)
+        }
+        AIE_WSYNC();
+      }
+    }
+    happy = true;
+    for (int q = 0; q < 2; ++q) {
+      const int rs = q == 0 ? 1 : 0;
+      int count = 0;
+      for (int base = 0; base < HW; base += AIE_NT) {
+        const int cell = base + lane;
+        count += __popcll(__ballot(cell < HW && mbp[rs][cell]));
+      }
+      const double ratio = ((double)count / (double)HW) / g.layout_coverage[rs];
+      if (!((1 / 1.4) <= ratio && ratio <= 1.4)) happy = false;
+    }
+  }
+  uint8_t* cb = reinterpret_cast<uint8_t*>(R_CELLS(c));
+  for (int cell = lane; cell < HW; cell += AIE_NT) {
+    const int r = cell / W, col = cell - r * W;
+    bool st = mbp[0][cell] != 0, wd = mbp[1][cell] != 0;
+    if (g.layout_checker && ((r & 1) + (col & 1)) != 1) st = wd = false;
+    if (g.layout_gen == AIE_LAYOUT_QUADRANT && (col == H / 2 || r == W / 2)) st = wd = false;  // nothing on the water lines
+    cb[4 * cell + 3] = (uint8_t)((cb[4 * cell + 3] & AIE_CELL_WATER) | (st ? AIE_CELL_STONE_SRC : 0) | (wd ? AIE_CELL_WOOD_SRC : 0));
+  }
+  AIE_WSYNC();
+}
+}  // namespace aie
+
 // BaseEnvironment.reset, F/base/base_env.py:852-927, with LayoutFromFile
 // reset_starting_layout / reset_agent_states / additional_reset_steps
 // (layout_from_file.py:323-370, 564-593) and the component resets (build.py:224-254,
@@ -2344,6 +2511,10 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   load_record(c, arena, m);
   __syncthreads();
   m.pos = uni(*R_I32(c, o_mt_pos));
+  if (P.c.layout_gen != AIE_LAYOUT_FIXED) {  // a fresh source layout, drawn before anything else of the reset
+    layout_generate(c, m, arena, lds + lds_bytes(P));
+    __syncthreads();
+  }
   {  // layout_from_file.py:323-334: resources back on every source block, no houses
     uint32_t* cells = R_CELLS(c);
     for (int q = tid; q < HW; q += AIE_NT) {

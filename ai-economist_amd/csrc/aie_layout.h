@@ -133,6 +133,8 @@ typedef struct aie_params {
   int32_t saez_stride, saez_cap;
   int64_t a_saez_global; /* shared: int32 len (16 B), then f64 [saez_global_cap][2]: the trainer's cross-replica buffer */
   int32_t saez_global_cap, saez_pad_;
+  int64_t a_layout_prob; /* shared f64 [AIE_N_RES][H*W]: source probability maps of the generated layouts (layout_gen
+                          * UNIFORM / QUADRANT: uploaded once by the host, tensor "layout_source_prob") */
   int32_t o_tax_saez_rates; /* record: f64 [NB] curr_bracket_tax_rates */
   int32_t o_tax_saez_obs_rates; /* record: f64 [NB] _curr_rates_obs: the rates the "curr_rates" observation shows,
                                    refreshed at period starts and -- BEFORE the running average replaces the
@@ -199,6 +201,7 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->a_saez = p->a_events = p->a_metrics = p->a_saez_global = 0;
   p->a_cv_consts = p->a_cv_filters = p->a_cv_hist0 = p->a_cv_lag_obs = p->a_cv_hist = p->a_cv_obs_a = p->a_cv_obs_p = 0;
   p->a_cv_hist0c = p->a_cv_acc0 = 0;
+  p->a_layout_prob = 0;
   p->dev_skip_mask = 0;
   p->dev_trace = 0;
   p->auto_reset = 0;
@@ -716,6 +719,25 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     if (!(c->regen_weight[r] >= 0.0 && c->regen_weight[r] <= 1.0)) AIE__FAIL("regen_weight not in [0,1]");
     if (c->max_health[r] < 1 || c->max_health[r] > 255) AIE__FAIL("max_health out of range");
   }
+  if (c->layout_gen != AIE_LAYOUT_FIXED) {
+    if (!gtb) AIE__FAIL("layout_gen needs a gather-trade-build scenario");
+    if (c->layout_gen < 0 || c->layout_gen > AIE_LAYOUT_MULTI_ZONE) AIE__FAIL("unknown layout_gen %d", c->layout_gen);
+    if (c->shared_layout) AIE__FAIL("generated layouts are per replica: shared_layout must be 0");
+    if (c->world_h * c->world_w > 2304) {
+      if (err) snprintf(err, errlen, "layouts are generated on the device for worlds of up to 2304 cells (48 x 48)");
+      return AIE_E_UNSUPPORTED;
+    }
+    for (int r = 0; r < AIE_N_RES; ++r) {
+      if (!(c->layout_coverage[r] > 0.0 && c->layout_coverage[r] < 1.0)) AIE__FAIL("layout_coverage not in (0, 1)");
+      if (!(c->layout_clump[r] > 0.0 && c->layout_clump[r] <= 1.0)) AIE__FAIL("layout_clump not in (0, 1]");
+    }
+    if (c->layout_gen == AIE_LAYOUT_MULTI_ZONE) {
+      const int regions = c->mz_rows * c->mz_cols, zones = c->mz_zones[0] + c->mz_zones[1] + c->mz_zones[2];
+      if (c->mz_rows < 1 || c->mz_cols < 1 || regions > 256 || zones > regions || c->mz_zones[0] < 0 ||
+          c->mz_zones[1] < 0 || c->mz_zones[2] < 0)
+        AIE__FAIL("multi_zone: partitions / zone counts out of range");
+    }
+  }
   if (!(c->starting_agent_coin >= 0.0)) AIE__FAIL("starting_agent_coin must be >= 0");
   if (!(c->isoelastic_eta >= 0.0 && c->isoelastic_eta <= 1.0)) AIE__FAIL("isoelastic_eta not in [0,1]");
   if (gtb && !(c->energy_cost >= 0.0)) AIE__FAIL("energy_cost must be >= 0");
@@ -987,6 +1009,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   aie__alloc_metrics(p, &a);
   aie__alloc_events(c, p, &a);
   aie__alloc_saez(c, p, &a);
+  p->a_layout_prob = a;
+  if (c->layout_gen != AIE_LAYOUT_FIXED) a = aie__align(a + (int64_t)AIE_N_RES * HW * 8, 256);
   p->arena_bytes = a;
 
   /* ---- tensor table ------------------------------------------------------------ */
@@ -1075,6 +1099,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     aie__add_metrics_tensors(p, tt);
     aie__add_event_tensors(p, tt);
     aie__add_saez_tensors(p, tt);
+    if (c->layout_gen != AIE_LAYOUT_FIXED)
+      aie__add_shared(tt, "layout_source_prob", AIE_F64, p->a_layout_prob, 2, AIE_N_RES, HW);
 #undef DENSE
   }
   return AIE_OK;

@@ -4,13 +4,13 @@ reward kernels as layout_from_file; what differs is the reset: a fresh random so
 layout per episode (no Water), and agents placed in a random order.
 
 The layout generation (dynamic_layout.py:313-392: uniform draws, a shrinking threshold,
-then growth by convolving with random 7x7 kernels) is reset-time host numerics on top of
-NumPy/SciPy primitives.  It is run on the host from each replica's OWN legacy-NumPy
-stream: the replica's MT19937 state is pulled from the device, a RandomState continues
-it exactly where the device left off, and the advanced state goes back together with
-the new source planes -- so an episode reset consumes the stream exactly as the
-reference does.  (Cost: O(ms) of Python per replica per reset; the step path is
-untouched.)
+then growth by convolving with random 7x7 kernels; MultiZone's per-reset zone shuffle,
+Quadrant's empty water lines) runs INSIDE the reset kernel, from each replica's own
+legacy-NumPy stream (csrc/aie_kernels.hip: layout_generate; restated for the checker in
+oracle/aie_oracle.c and pinned there against the live reference): a reset has no host
+round trip.  This module supplies the static source-probability maps and the kwargs.
+`generate_layout*` below is the same procedure on the host (NumPy / SciPy), kept for worlds
+larger than the device path's 2304 cells and as documentation of the reference's steps.
 """
 import numpy as np
 
@@ -150,6 +150,13 @@ class Uniform(LayoutFromFile):
 
         return metrics.gtb_scenario_metrics(self, tensors)
 
+    layout_gen = _cabi.LAYOUT_UNIFORM
+    DEVICE_LAYOUT_MAX_CELLS = 2304  # csrc/aie_layout.h: the generator's planes live in LDS
+
+    @property
+    def layouts_on_device(self):
+        return int(np.prod(self.world_size)) <= self.DEVICE_LAYOUT_MAX_CELLS
+
     def fill_scenario_config(self, cfg):
         super().fill_scenario_config(cfg)
         cfg.has_water = 0
@@ -159,10 +166,26 @@ class Uniform(LayoutFromFile):
             cfg.regen_halfwidth[i] = self.layout_specs[r]["regen_halfwidth"]
             cfg.max_health[i] = self.layout_specs[r]["max_health"]
             cfg.regen_weight[i] = self.layout_specs[r]["regen_weight"]
+            cfg.layout_coverage[i] = float(self.layout_specs[r]["starting_coverage"])
+            cfg.layout_clump[i] = float(1 - np.clip(self.clumpiness[r], 0.0, 0.99))
+        cfg.layout_gen = self.layout_gen if self.layouts_on_device else _cabi.LAYOUT_FIXED
+        cfg.layout_checker = int(self._checker_source_blocks)
+        if cfg.layout_gen != _cabi.LAYOUT_FIXED:
+            # constant tensors that go with this configuration (the device backend uploads them once; the CPU checker
+            # fills its arena from the same attribute)
+            cfg._model_tensors = {"layout_source_prob": np.stack([
+                np.asarray(self.source_prob_maps["Stone"], np.float64),
+                np.asarray(self.source_prob_maps["Wood"], np.float64)]).reshape(1, 2, -1)}
+
+    def upload_model_constants(self, backend):
+        for name, arr in getattr(backend.cfg, "_model_tensors", {}).items():
+            backend.upload(name, arr)
 
     def host_pre_reset(self, env_mask):
         """Generates a fresh source layout for every replica about to be reset, continuing
         that replica's own MT19937 stream."""
+        if self.layouts_on_device:
+            return  # the reset kernel draws the layout itself
         be = self.backend
         torch = __import__("torch")
         torch.cuda.synchronize(be.device)
@@ -237,6 +260,14 @@ class MultiZone(Uniform):
             out[res] = prob * self.layout_specs["Wood"]["starting_coverage"]
         return out
 
+    layout_gen = _cabi.LAYOUT_MULTI_ZONE
+
+    def fill_scenario_config(self, cfg):
+        super().fill_scenario_config(cfg)
+        cfg.mz_rows, cfg.mz_cols = int(self.num_partitions_row), int(self.num_partitions_col)
+        for k, name in enumerate(("Wood", "Stone", "WoodStone")):
+            cfg.mz_zones[k] = int(self.zone_specs[name][1])
+
     def generate_layout_flags(self, rs):
         self.source_prob_maps = self.make_source_prob_maps(rs)  # reset_starting_layout :866-872
         return super().generate_layout_flags(rs)
@@ -284,6 +315,13 @@ class Quadrant(Uniform):
             plane[:, height // 2] = 0
             plane[width // 2, :] = 0
         return ((self._water > 0) * 1 + 2 * stone + 4 * wood).astype(np.uint8)
+
+    layout_gen = _cabi.LAYOUT_QUADRANT
+
+    def layout_planes(self):
+        z = np.zeros([self.n_envs] + list(self.world_size), np.uint8)
+        water = np.broadcast_to((self._water > 0).astype(np.uint8), z.shape).copy()
+        return (z, z, water)
 
     def fill_scenario_config(self, cfg):
         super().fill_scenario_config(cfg)

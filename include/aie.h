@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AIE_ABI_VERSION 6
+#define AIE_ABI_VERSION 7
 
 #define AIE_MAX_AGENTS 64      /* mobile agents per replica, spatial scenarios (one lane each) */
 #define AIE_MAX_AGENTS_WIDE 128 /* mobile agents per replica, map-less one-step-economy        */
@@ -249,7 +249,22 @@ typedef struct aie_config {
   int32_t saez_global_capacity;      /* > 0: room (pairs) for the cross-replica sample buffer of the reference's trainer
                                       * (set_global_saez_buffer, redistribution.py:530-533); 0: feature off        */
   double saez_fixed_elas;
+
+  /* Source layouts drawn at every reset, on the device, from the replica's own stream ("uniform/", "quadrant/",
+   * "multi_zone/simple_wood_and_stone": Uniform.reset_starting_layout, dynamic_layout.py:313-392; MultiZone
+   * :778-872; Quadrant :992-1024).  Index 0 = Stone, 1 = Wood as everywhere else. */
+  int32_t layout_gen;                /* AIE_LAYOUT_FIXED (planes from aie_set_layout), _UNIFORM, _QUADRANT, _MULTI_ZONE */
+  int32_t layout_checker;            /* checker_source_blocks                                                        */
+  double layout_coverage[AIE_N_RES]; /* layout_specs[r]["starting_coverage"] (already doubled under checker)           */
+  double layout_clump[AIE_N_RES];    /* 1 - clip(clumpiness, 0, 0.99)                                                */
+  int32_t mz_rows, mz_cols;          /* multi_zone: num_partitions_row / _col                                        */
+  int32_t mz_zones[3];               /* multi_zone: number of Wood, Stone, Wood+Stone zones                          */
+  int32_t layout_pad_;
 } aie_config;
+#define AIE_LAYOUT_FIXED 0
+#define AIE_LAYOUT_UNIFORM 1
+#define AIE_LAYOUT_QUADRANT 2
+#define AIE_LAYOUT_MULTI_ZONE 3
 
 /* ---- dense-log events: one row of "log_events" int32 [L, cap, AIE_EV_WORDS] ------- */
 #define AIE_EV_WORDS 12 /* [0] type, [1..8] integers, [10..11] one float64 (bit pattern)          */

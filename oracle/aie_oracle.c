@@ -1267,6 +1267,117 @@ static void step_one(const aie_params* p, uint8_t* arena, int e, const int32_t* 
  * (layout_from_file.py:323-370, 564-593) and the component resets
  * (build.py:224-254, move.py:193-210, continuous_double_auction.py:643-668,
  * redistribution.py:1109-1139). */
+/* Source layouts drawn at reset: Uniform.reset_starting_layout (dynamic_layout.py:313-392), with MultiZone's
+ * per-reset zone shuffle (:778-872) and Quadrant's empty water lines (:992-1024).  NumPy / SciPy primitives restated:
+ * rand / randn (legacy gauss with its cache) in row-major order, np.mean of a 0/1 plane = count / size,
+ * signal.convolve2d(x, kernel, "same") = one multiply-add per kernel element in kernel row-major order over the
+ * zero-filled window (checked against scipy bit for bit in tests/test_regen_neighbourhood.py). */
+static void layout_generate(ctx_t* c) {
+  const aie_params* p = c->p;
+  const aie_config* g = &p->c;
+  const int H = p->H, W = p->W, HW = p->HW;
+  const double* shared_prob = (const double*)(c->arena + p->a_layout_prob); /* [2][HW]: Stone, Wood */
+  double* tmp = (double*)malloc(sizeof(double) * 2 * (size_t)HW);
+  double* x = tmp + HW;
+  uint8_t* maybe[2];
+  maybe[0] = (uint8_t*)malloc(2 * (size_t)HW);
+  maybe[1] = maybe[0] + HW;
+  /* multi_zone: which zone type each region is, re-drawn now (np.random.shuffle of the flat grid) */
+  int grid[256];
+  double mz_scale[2] = {0, 0};
+  int size_r = 1, size_c = 1;
+  if (g->layout_gen == AIE_LAYOUT_MULTI_ZONE) {
+    const int regions = g->mz_rows * g->mz_cols;
+    int k = 0;
+    for (int z = 0; z < 3; ++z)
+      for (int q = 0; q < g->mz_zones[z]; ++q) grid[k++] = z; /* np.repeat([0, 1, 2], counts): Wood, Stone, both */
+    while (k < regions) grid[k++] = -1;
+    for (int i = regions - 1; i >= 1; --i) {
+      int j = (int)rng_interval(c, (uint32_t)i);
+      int t = grid[i]; grid[i] = grid[j]; grid[j] = t;
+    }
+    size_r = (H + g->mz_rows - 1) / g->mz_rows;
+    size_c = (W + g->mz_cols - 1) / g->mz_cols;
+    for (int rs = 0; rs < 2; ++rs) { /* prob / np.mean(prob) * Wood's coverage (:846-863) */
+      const int own = rs == 1 ? 0 : 1; /* zone index: Wood 0, Stone 1, WoodStone 2 */
+      int cnt = 0;
+      for (int cell = 0; cell < HW; ++cell) {
+        int z = grid[(cell / W / size_r) * g->mz_cols + (cell % W) / size_c];
+        cnt += (z == own || z == 2);
+      }
+      const double mean = (double)cnt / (double)HW;
+      mz_scale[rs] = (1.0 / mean) * g->layout_coverage[1];
+    }
+  }
+  int happy = 0;
+  for (int tries = 0; tries < 100 && !happy; ++tries) {
+    for (int q = 0; q < 2; ++q) {
+      const int rs = q == 0 ? 1 : 0; /* ["Wood", "Stone"] */
+      const double cov = g->layout_coverage[rs], clump = g->layout_clump[rs];
+      uint8_t* mb = maybe[rs];
+      const uint8_t* other = q == 0 ? NULL : maybe[1]; /* empty = nothing placed yet on the tile */
+#define AIE_SP(cell) ((g->layout_gen == AIE_LAYOUT_MULTI_ZONE                                                    \
+                           ? (((grid[((cell) / W / size_r) * g->mz_cols + ((cell) % W) / size_c] == (rs == 1 ? 0 : 1)) || \
+                               (grid[((cell) / W / size_r) * g->mz_cols + ((cell) % W) / size_c] == 2))           \
+                                  ? mz_scale[rs] : 0.0 * g->layout_coverage[1])                                   \
+                           : shared_prob[rs * HW + (cell)]) * 0.1 * clump)
+      for (int cell = 0; cell < HW; ++cell) tmp[cell] = rng_double(c);
+      int count = 0;
+      for (int cell = 0; cell < HW; ++cell) {
+        mb[cell] = (uint8_t)((tmp[cell] < AIE_SP(cell)) && !(other && other[cell]));
+        count += mb[cell];
+      }
+      int n_tries = 0;
+      while ((double)count / (double)HW < cov * clump) {
+        count = 0;
+        for (int cell = 0; cell < HW; ++cell) {
+          tmp[cell] *= 0.9;
+          mb[cell] = (uint8_t)((tmp[cell] < AIE_SP(cell)) && !(other && other[cell]));
+          count += mb[cell];
+        }
+        if (++n_tries > 200) break;
+      }
+      while ((double)count / (double)HW < cov) {
+        uint8_t kern[49];
+        for (int k = 0; k < 49; ++k) kern[k] = rng_gauss(c) > 0;
+        for (int cell = 0; cell < HW; ++cell) x[cell] = ((double)mb[cell] + (0.2 * rng_gauss(c))) - 0.25;
+        count = 0;
+        for (int cell = 0; cell < HW; ++cell) tmp[cell] = (double)mb[cell]; /* old `maybe`, while mb is rewritten */
+        for (int m = 0; m < H; ++m)
+          for (int n2 = 0; n2 < W; ++n2) {
+            double sum = 0.0;
+            for (int j = 0; j < 7; ++j)
+              for (int k = 0; k < 7; ++k) {
+                const int i0 = m + 3 - j, i1 = n2 + 3 - k;
+                if (i0 >= 0 && i0 < H && i1 >= 0 && i1 < W) sum += (double)kern[j * 7 + k] * x[i0 * W + i1];
+              }
+            const int cell = m * W + n2;
+            mb[cell] = (uint8_t)(((sum > 0) || tmp[cell] != 0.0) && !(other && other[cell]));
+            count += mb[cell];
+          }
+      }
+#undef AIE_SP
+    }
+    happy = 1;
+    for (int q = 0; q < 2; ++q) {
+      const int rs = q == 0 ? 1 : 0;
+      int count = 0;
+      for (int cell = 0; cell < HW; ++cell) count += maybe[rs][cell];
+      const double ratio = ((double)count / (double)HW) / g->layout_coverage[rs];
+      if (!((1 / 1.4) <= ratio && ratio <= 1.4)) happy = 0;
+    }
+  }
+  for (int cell = 0; cell < HW; ++cell) {
+    const int r = cell / W, col = cell % W;
+    int st = maybe[0][cell], wd = maybe[1][cell];
+    if (g->layout_checker && ((r % 2) + (col % 2)) != 1) st = wd = 0;
+    if (g->layout_gen == AIE_LAYOUT_QUADRANT && (col == H / 2 || r == W / 2)) st = wd = 0; /* nothing on the water lines */
+    C_FLAGS(c, cell) = (uint8_t)((C_FLAGS(c, cell) & AIE_CELL_WATER) | (st ? AIE_CELL_STONE_SRC : 0) | (wd ? AIE_CELL_WOOD_SRC : 0));
+  }
+  free(tmp);
+  free(maybe[0]);
+}
+
 static void reset_one(const aie_params* p, uint8_t* arena, int e) {
   ctx_t c;
   make_ctx(&c, p, arena, e);
@@ -1274,6 +1385,7 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
   *I32(&c, o_timestep) = 0;
   memset(MET(&c), 0, (size_t)p->met_bytes); /* component resets clear their episode logs */
   if (EV(&c)) EV(&c)[0] = 0;
+  if (p->c.layout_gen != AIE_LAYOUT_FIXED) layout_generate(&c); /* a fresh source layout from this replica's stream */
   for (int cell = 0; cell < HW; ++cell) { /* layout_from_file.py:323-334 */
     unsigned fl = C_FLAGS(&c, cell);
     CELLS(&c)[cell] = AIE_CELL_PACK((fl & AIE_CELL_STONE_SRC) ? 1 : 0, (fl & AIE_CELL_WOOD_SRC) ? 1 : 0, -1, fl);

@@ -90,6 +90,8 @@ class OracleEnv:
             self.t["saez_elas"][:, 0:2] = 0.5
         if layout_planes is not None and "cell_flags" in self.t:
             self.set_layout(*layout_planes)
+        for name, arr in getattr(cfg, "_model_tensors", {}).items():  # constants that travel with the configuration
+            self.t[name][...] = np.asarray(arr).reshape(self.t[name].shape)
 
     def set_global_saez_buffer(self, pairs):
         """PeriodicBracketTax.set_global_saez_buffer (redistribution.py:530-533) for every replica of this arena."""

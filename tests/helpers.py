@@ -110,8 +110,8 @@ def oracle_host_pre_reset(env, oracle, which=None):
     """What BaseEnvironment.host_pre_reset does on the device, on an OracleEnv: scenarios
     with a host-side reset part (uniform/...: a fresh layout from the replica's own MT19937
     stream) run it here before oracle.reset()."""
-    if not hasattr(env, "generate_layout"):
-        return
+    if not hasattr(env, "generate_layout") or getattr(env, "layouts_on_device", False):
+        return  # fixed layouts, or layouts drawn inside reset (device kernel / restatement alike)
     which = range(oracle.E) if which is None else which
     rs = np.random.RandomState()
     for e in which:
