@@ -48,8 +48,10 @@ def test_arena_bytes_and_validation_without_gpu():
     c = env.build_config()
     c.regen_halfwidth[0] = 1  # one more byte plane pair per record (source blocks per regen window)
     assert lib.aie_arena_bytes(ctypes.byref(c)) > nbytes
-    c.max_health[0] = 2  # neighbourhood regeneration is implemented for max_health == 1
-    assert lib.aie_arena_bytes(ctypes.byref(c)) == _cabi.E_UNSUPPORTED
+    c.max_health[0] = 2  # neighbourhood regeneration with max_health > 1: true window sums (supported since round 2)
+    assert lib.aie_arena_bytes(ctypes.byref(c)) > nbytes
+    c.layout_gen = _cabi.LAYOUT_UNIFORM  # layouts drawn at reset need per-replica planes and coverage settings
+    assert lib.aie_arena_bytes(ctypes.byref(c)) == _cabi.E_INVALID
     c.regen_halfwidth[0] = 4
     assert lib.aie_arena_bytes(ctypes.byref(c)) == _cabi.E_INVALID
     c = env.build_config()

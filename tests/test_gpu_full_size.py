@@ -170,3 +170,48 @@ def test_c4_full_batch_matches_oracle():
     q = lambda x: [float(np.quantile(x, p)) for p in (0.5, 0.99, 0.9999, 1.0)]  # noqa: E731
     print("C4 reward |error| (median, p99, p99.99, max): agents %s of %d, planner %s of %d" % (
         ["%.2e" % v for v in q(ea)], ea.size, ["%.2e" % v for v in q(ep)], ep.size))
+
+
+def test_c1_uniform_layouts_drawn_on_device_full_batch():
+    """BASELINE configs[0]'s scenario (uniform 15x15, Build + Gather) at 4096 replicas: every replica draws its own
+    source layout INSIDE the reset kernel (no host round trip: aie_kernels.hip layout_generate), bit-identical to
+    the restatement's layouts (which the CPU tests pin to the live reference); two episodes with auto-reset."""
+    import time
+
+    import torch
+    from oracle_lib import OracleEnv
+
+    E = 4096
+    cfg = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=4, world_size=[15, 15], episode_length=12,
+               components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10, starting_stone_coverage=0.10,
+               starting_wood_coverage=0.10)
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    env.reset()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(1)
+    oracle.reset()
+    _compare_all(be, oracle, "C1 reset")
+    flags = be.tensors["cell_flags"].reshape(E, -1)
+    assert len({bytes(f.tobytes()) for f in flags[:64].cpu().numpy()}) == 64  # every replica its own layout
+    assert dt < 2.0, "a 4096-replica reset took %.2f s: is the layout generation back on the host?" % dt
+    be.set_auto_reset(True)
+    for t in range(2 * cfg["episode_length"] + 2):
+        a, p = be.sample_random_actions(seed=5)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=NTHREADS)
+        done = oracle.t["done"].copy()
+        rew = oracle.t["rewards_a"].copy()
+        if done.any():
+            oracle.reset(done)
+            oracle.t["done"][...] = done      # auto-reset keeps the terminal step's done / rewards
+            oracle.t["rewards_a"][...] = rew
+        if (t + 1) % 6 == 0:
+            _compare_all(be, oracle, "C1 step %d" % (t + 1))
+    assert int(be.tensors["completions"].min()) == 2
