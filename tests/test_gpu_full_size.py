@@ -207,11 +207,12 @@ def test_c1_uniform_layouts_drawn_on_device_full_batch():
         torch.cuda.synchronize()
         oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=NTHREADS)
         done = oracle.t["done"].copy()
-        rew = oracle.t["rewards_a"].copy()
+        rew, rew_p = oracle.t["rewards_a"].copy(), oracle.t["rewards_p"].copy()
         if done.any():
             oracle.reset(done)
             oracle.t["done"][...] = done      # auto-reset keeps the terminal step's done / rewards
             oracle.t["rewards_a"][...] = rew
+            oracle.t["rewards_p"][...] = rew_p
         if (t + 1) % 6 == 0:
             _compare_all(be, oracle, "C1 step %d" % (t + 1))
     assert int(be.tensors["completions"].min()) == 2
