@@ -157,6 +157,10 @@ class AieTensorDesc(C.Structure):
 def bind(lib):
     """Declares the prototypes of every symbol include/aie.h exports."""
     vp = C.c_void_p
+    lib.aie_sizeof_config.restype = C.c_int
+    if lib.aie_sizeof_config() != C.sizeof(AieConfig):
+        raise RuntimeError("ctypes mirror of aie_config is %d bytes, the library's struct %d: _cabi.py and include/aie.h "
+                           "are out of step" % (C.sizeof(AieConfig), lib.aie_sizeof_config()))
     lib.aie_arena_bytes.restype = C.c_int64
     lib.aie_arena_bytes.argtypes = [C.POINTER(AieConfig)]
     lib.aie_create.restype = C.c_int
@@ -207,5 +211,5 @@ EXPORTED_SYMBOLS = [
     "aie_tensor_at", "aie_get_tensor", "aie_upload", "aie_download", "aie_set_layout",
     "aie_seed", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
     "aie_sample_masked_actions", "aie_step_sample_next", "aie_set_reward_log", "aie_set_auto_reset",
-    "aie_step_kernel_instance", "aie_set_global_saez_buffer",
+    "aie_step_kernel_instance", "aie_set_global_saez_buffer", "aie_sizeof_config",
 ]

@@ -60,6 +60,8 @@ __global__ void aie_set_flags_kernel(const aie_params P, uint8_t* __restrict__ a
 
 extern "C" {
 
+int aie_sizeof_config(void) { return (int)sizeof(aie_config); }
+
 int64_t aie_arena_bytes(const aie_config* cfg) {
   aie_params P;
   int rc = aie_build_params(cfg, &P, nullptr, g_create_err, sizeof(g_create_err));

@@ -387,6 +387,9 @@ int aie_set_auto_reset(aie_env* env, int on);
  * reference's `saez_buffer` property does. */
 int aie_set_global_saez_buffer(aie_env* env, const double* d_pairs, int64_t n_pairs);
 
+/* sizeof(aie_config) as this library was built: a binding checks its mirror of the struct against it. */
+int aie_sizeof_config(void);
+
 /* Which step kernel runs this environment: >= 0 = a compile-time instance (the configuration's parameter block folded
  * into the code, csrc/aie_spec_generated.h), -1 = the generic kernel. */
 int aie_step_kernel_instance(aie_env* env);

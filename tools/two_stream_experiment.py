@@ -14,7 +14,7 @@ import bench  # noqa: E402
 from helpers import make_env  # noqa: E402
 
 E = 4096
-for S in (1, 2, 3, 4):
+for S in (1, 2, 4):
     envs, streams = [], []
     for s in range(S):
         env = make_env(bench.C2_CFG, n_envs=(E // S if S != 3 else [1366, 1365, 1365][s]), device="cuda:0", env_offset=s * 1366)
