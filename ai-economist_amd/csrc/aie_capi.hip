@@ -384,7 +384,17 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
-  else if (env->step_waves == 2 && (env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT || env->P.regen_general ||
+  else if (env->step_waves == 2 && env->spec >= 0 && env->P.dev_trace != nullptr && env->P.dev_skip_mask == 0) {
+    const dim3 g((unsigned)env->P.E), b(2 * AIE_NT);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define AIE_SPEC_LAUNCH_TR(K) \
+  case K: hipLaunchKernelGGL(aie_step_kernel_spec_trace<K>, g, b, env->lds, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); break;
+    switch (env->spec) {
+      AIE_SPEC_LIST_GTB(AIE_SPEC_LAUNCH_TR)
+      default: return AIE_E_INVALID;
+    }
+#undef AIE_SPEC_LAUNCH_TR
+  } else if (env->step_waves == 2 && (env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT || env->P.regen_general ||
                                     env->P.dev_skip_mask != 0 || env->P.dev_trace != nullptr))
     hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
@@ -511,6 +521,18 @@ int aie_step_kernel_instance(aie_env* env) { return env ? env->spec : -2; }
 int aie_dev_use_generic_kernel(aie_env* env) {
   if (!env) return AIE_E_INVALID;
   env->spec = -1;
+  return AIE_OK;
+}
+
+// Development aid (not part of include/aie.h): dynamic LDS bytes of a step workgroup (out[0]) and its parts:
+// record image, location map, f64 scratch, staging area.
+int aie_dev_lds_bytes(aie_env* env, int64_t* out) {
+  if (!env || !out) return AIE_E_INVALID;
+  out[0] = (int64_t)env->lds;
+  out[1] = env->P.o_mt;
+  out[2] = env->P.HW;
+  out[3] = env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY || env->P.c.scenario == AIE_SCN_COVID ? 0 : (int64_t)aie::fscr_doubles(env->P) * 8;
+  out[4] = env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY || env->P.c.scenario == AIE_SCN_COVID ? 0 : (int64_t)aie::stage_bytes(env->P);
   return AIE_OK;
 }
 

@@ -2185,7 +2185,7 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
 // configuration -- every dimension, record offset, component list, mask table and magic divisor folds into the
 // instruction stream (no scalar loads of parameters, fully unrolled per-agent loops) -- and only what depends on
 // the batch (R: E, arena offsets) is read at run time.  SPEC < 0: the generic kernel, P == R == *params.
-template <int NW, bool LOG, int SPEC = -1>
+template <int NW, bool LOG, int SPEC = -1, bool TRACE = LOG>
 __device__ __forceinline__ void step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                                           const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
                                           uint8_t* lds, const NextActions& next) {
@@ -2199,7 +2199,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   MT m;
   Agents A;
   const int skip = c.full ? P.dev_skip_mask : 0;
-  if (LOG && P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x] = wall_clock64();
+  if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x] = wall_clock64();
   if (threadIdx.x == 0) {
     *c.srcn = 0;
     c.dirty[0] = 0;
@@ -2207,11 +2207,11 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     c.dirty[2] = 0;
   }
   __syncthreads();
-  if (LOG && P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
+  if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
   load_record(c, arena, m, wid, NW, /*key_to_lds=*/true);
   if (wid == 0) decode_actions(c, A, act_a, act_p);
   __syncthreads();  // the record is in LDS
-  if (LOG && P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
+  if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
   if (NW == 1 || wid == 1) rebuild_locmap(c);
   MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0, 0u, -AIE_MT_N, 0, 0u, 0u};
   if (wid == 0) {
@@ -2224,7 +2224,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     if (c.tid == 0) *R_I32(c, o_timestep) += 1;
     if (c.ev && c.tid == 0) c.srcn[2] = 0;
     __builtin_amdgcn_s_setprio(3);  // the serial dynamics are the replica's critical path
-    if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 1] = wall_clock64();
+    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 1] = wall_clock64();
     if (!(skip & 1)) {
       for (int k = 0; k < P.c.n_components; ++k) {
         switch (P.c.components[k]) {
@@ -2235,7 +2235,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
           case AIE_COMP_WEALTH_REDISTRIBUTION: wealth_component_step(c, A); break;
           default: break;
         }
-        if (LOG && P.dev_trace && c.tid == 0 && k < 4) P.dev_trace[12 * blockIdx.x + 2 + k] = wall_clock64();
+        if (TRACE && R.dev_trace && c.tid == 0 && k < 4) R.dev_trace[12 * blockIdx.x + 2 + k] = wall_clock64();
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -2247,7 +2247,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       c.dirty[1] = (int32_t)ml.mv0;
       c.dirty[2] = (int32_t)ml.mv1;
     }
-    if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 5] = wall_clock64();
+    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 5] = wall_clock64();
   } else if (next.a || next.p) {
     // the second wave has nothing to do until the components are done: next step's random actions
     const int per_env = P.n * P.act_a_width + P.act_p_width;
@@ -2257,7 +2257,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (wid == 0) {
     // first wave: flat observation vectors (they do not look at the map)
     if (!(skip & 8)) write_flat_observations(c, arena);
-    if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
+    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
     if (!(skip & 16)) compute_rewards(c, arena, next.rew_log);  // utilities do not look at the map either
     AIE_WSYNC();
     if (c.tid == 0) {
@@ -2275,7 +2275,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     mtl_to_regs(mw, m, c.tid);
     if (!(skip & 2)) scenario_step_regen(c, m, /*win0_in_lds=*/true);
     if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
-    if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
+    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
     AIE_WSYNC();
     if (!(skip & 4)) {
       // the map observations of the previous step are still in the arena: update them in place,
@@ -2285,12 +2285,12 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       if (c.tid == 0) *R_I32(c, o_obs_valid) = 1;
     }
     if (!(skip & 8)) write_action_masks(c, arena);
-    if (LOG && P.dev_trace && c.tid == 0) P.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
+    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
     if (NW == 2) __builtin_amdgcn_s_setprio(0);
   }
   __syncthreads();
   if (!(skip & 32)) store_record(c, arena, m, wid, NW, /*key_wave=*/NW - 1);
-  if (LOG && P.dev_trace && threadIdx.x == 0) P.dev_trace[12 * blockIdx.x + 7] = wall_clock64();
+  if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 7] = wall_clock64();
 }
 
 extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -2313,6 +2313,14 @@ aie_step_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict_
                      const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   step_body<2, false, SPEC>(params, arena, act_a, act_p, lds, next);
+}
+// development: the compile-time instances with per-workgroup clock stamps (tools/block_trace.py, aie_dev_set_trace)
+template <int SPEC>
+__global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+aie_step_kernel_spec_trace(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                           const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  step_body<2, false, SPEC, true>(params, arena, act_a, act_p, lds, next);
 }
 extern "C" __global__ void __launch_bounds__(AIE_NT)
 aie_step_kernel_w1(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,

@@ -15,11 +15,18 @@ import bench  # noqa: E402
 from helpers import make_env  # noqa: E402
 
 E = 4096
-SKIP = int(os.environ.get("AIE_DEV_SKIP_MASK", "0"))
-env = make_env(dict(bench.C2_CFG), n_envs=E, device="cuda:0")
+N_AGENTS = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+env = make_env(dict(bench.C2_CFG, n_agents=N_AGENTS), n_envs=E, device="cuda:0")
 env.seed(1)
 env.reset()
 be = env.backend
+if len(sys.argv) > 2 and sys.argv[2] == "generic":
+    be.lib.aie_dev_use_generic_kernel(be.handle)
+print("n_agents", N_AGENTS, "step kernel instance", be.lib.aie_step_kernel_instance(be.handle))
+lds = (ctypes.c_int64 * 5)()
+be.lib.aie_dev_lds_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+be.lib.aie_dev_lds_bytes(be.handle, lds)
+print("LDS bytes per workgroup %d: record %d, location map %d, f64 scratch %d, staging %d" % tuple(lds))
 for _ in range(300):
     a, p = be.sample_random_actions(1234)
     be.step(a, p)
@@ -32,7 +39,8 @@ for rep in range(2):
     torch.cuda.synchronize()
     tr0 = be.tensors["metrics_cda_trades"].cpu().numpy()[:, 0, :, :, 0].sum(axis=(1, 2))
     no0 = be.tensors["cda_n_orders"].cpu().numpy().sum(axis=(1, 2))
-    be.step(a, p)
+    for _ in range(20 if "b2b" in sys.argv else 1):  # b2b: stamps of the last of 20 back-to-back launches
+        be.step(a, p)
     torch.cuda.synchronize()
     tr1 = be.tensors["metrics_cda_trades"].cpu().numpy()[:, 0, :, :, 0].sum(axis=(1, 2))
     no1 = be.tensors["cda_n_orders"].cpu().numpy().sum(axis=(1, 2))
@@ -48,6 +56,10 @@ for rep in range(2):
         np.median(t[:, 9] - t[:, 0]), np.median(t[:, 8] - t[:, 9]), np.median(t[:, 1] - t[:, 8])))
     print("  post-dynamics: flat %.2f | rewards+done+wait %.2f | wave1 spatial+masks %.2f (medians, from regen end)" % (
         np.median(t[:, 10] - t[:, 6]), np.median(t[:, 7] - t[:, 10]), np.median(t[:, 11] - t[:, 6])))
+    h, _ = np.histogram(t[:, 0], bins=np.arange(0, t[:, 0].max() + 1.0, 0.5))
+    print("  start histogram (0.5 us bins):", " ".join(str(v) for v in h))
+    print("  mean start by blockIdx/256:", " ".join("%.1f" % t[k * 256:(k + 1) * 256, 0].mean() for k in range(E // 256)))
+    print("  mean start by blockIdx%8 (XCD):", " ".join("%.1f" % t[k::8, 0].mean() for k in range(8)))
     print("phase durations")
     for k in range(1, 8):
         print("  %-10s            %s" % (names[k], q(t[:, k] - t[:, k - 1])))

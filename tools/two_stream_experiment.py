@@ -14,10 +14,12 @@ import bench  # noqa: E402
 from helpers import make_env  # noqa: E402
 
 E = 4096
+N_AGENTS = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+CFG = dict(bench.C2_CFG, n_agents=N_AGENTS)
 for S in (1, 2, 4):
     envs, streams = [], []
     for s in range(S):
-        env = make_env(bench.C2_CFG, n_envs=(E // S if S != 3 else [1366, 1365, 1365][s]), device="cuda:0", env_offset=s * 1366)
+        env = make_env(CFG, n_envs=(E // S if S != 3 else [1366, 1365, 1365][s]), device="cuda:0", env_offset=s * 1366)
         env.seed(1)
         env.reset()
         envs.append(env)
@@ -43,5 +45,5 @@ for S in (1, 2, 4):
         step_all()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("shards=%d  %.1f us/step  %.1f M agent-steps/s" % (S, dt / K * 1e6, E * 4 * K / dt / 1e6))
+    print("shards=%d  %.1f us/step  %.1f M agent-steps/s" % (S, dt / K * 1e6, E * N_AGENTS * K / dt / 1e6))
     del envs
