@@ -58,6 +58,14 @@ __global__ void aie_set_flags_kernel(const aie_params P, uint8_t* __restrict__ a
   *w = (*w & 0x00ffffffu) | (fl << 24);
 }
 
+// Workgroups of `lds` dynamic LDS bytes a gfx950 CU holds at once: 160 KB, allocated in 1280-byte granules, at most
+// 16 workgroups of two waves (8 waves per SIMD).
+static inline int aie_workgroups_per_cu(size_t lds) {
+  const size_t granules = (lds + 1279) / 1280;
+  const size_t fit = granules ? (size_t)128 / granules : 16;
+  return (int)(fit < 16 ? fit : 16);
+}
+
 extern "C" {
 
 int aie_sizeof_config(void) { return (int)sizeof(aie_config); }
@@ -408,7 +416,10 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
       default: return AIE_E_INVALID;
     }
 #undef AIE_SPEC_LAUNCH
-  } else if (env->step_waves == 2)
+  } else if (env->step_waves == 2 && aie_workgroups_per_cu(env->lds) <= 12)
+    hipLaunchKernelGGL(aie_step_kernel_r6, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
+  else if (env->step_waves == 2)
     hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
   else
@@ -525,10 +536,11 @@ int aie_dev_use_generic_kernel(aie_env* env) {
 }
 
 // Development aid (not part of include/aie.h): dynamic LDS bytes of a step workgroup (out[0]) and its parts:
-// record image, location map, f64 scratch, staging area.
+// record image, location map, f64 scratch, staging area; out[5]: workgroups per CU that size allows.
 int aie_dev_lds_bytes(aie_env* env, int64_t* out) {
   if (!env || !out) return AIE_E_INVALID;
   out[0] = (int64_t)env->lds;
+  out[5] = aie_workgroups_per_cu(env->lds);
   out[1] = env->P.o_mt;
   out[2] = env->P.HW;
   out[3] = env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY || env->P.c.scenario == AIE_SCN_COVID ? 0 : (int64_t)aie::fscr_doubles(env->P) * 8;

@@ -2299,6 +2299,14 @@ aie_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ are
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   step_body<2, false>(params, arena, act_a, act_p, lds, next);
 }
+// the same kernel for records whose LDS footprint keeps a CU at 12 workgroups or fewer anyway (aie_capi.hip:
+// aie_step): 6 waves per SIMD buy 80 VGPRs, i.e. no scratch traffic
+extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
+aie_step_kernel_r6(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                   const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  step_body<2, false>(params, arena, act_a, act_p, lds, next);
+}
 // the same step for environments with dense-log replicas (aie_config.dense_log_replicas > 0): records AIE_EV_* rows
 extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 aie_step_kernel_log(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
@@ -2308,7 +2316,8 @@ aie_step_kernel_log(const aie_params* __restrict__ params, uint8_t* __restrict__
 }
 // compile-time instances for the configurations listed in ai-economist_amd/_specs.py (BASELINE configs[1], [2], ...)
 template <int SPEC>
-__global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(2 * AIE_NT)
+__attribute__((amdgpu_waves_per_eu(aie_spec_image<SPEC>::waves, aie_spec_image<SPEC>::waves)))
 aie_step_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                      const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -2316,7 +2325,8 @@ aie_step_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict_
 }
 // development: the compile-time instances with per-workgroup clock stamps (tools/block_trace.py, aie_dev_set_trace)
 template <int SPEC>
-__global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(2 * AIE_NT)
+__attribute__((amdgpu_waves_per_eu(aie_spec_image<SPEC>::waves, aie_spec_image<SPEC>::waves)))
 aie_step_kernel_spec_trace(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                            const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];

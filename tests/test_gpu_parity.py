@@ -689,7 +689,15 @@ def test_compile_time_instance_equals_generic_kernel(n_agents):
     cfg = dict(C2, n_agents=n_agents, episode_length=150)
     cfg_spec = dict(C2, n_agents=n_agents)
     env_s = make_env(cfg_spec, n_envs=8, device="cuda:0")
-    assert env_s.backend.lib.aie_step_kernel_instance(env_s.backend.handle) >= 0, "no compile-time instance selected"
+    k_inst = env_s.backend.lib.aie_step_kernel_instance(env_s.backend.handle)
+    assert k_inst >= 0, "no compile-time instance selected"
+    # the occupancy the instance is compiled for (_specs.py) is what its LDS footprint lets a CU hold
+    from ai_economist_amd import _specs
+
+    lds = (ctypes.c_int64 * 6)()
+    env_s.backend.lib.aie_dev_lds_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert env_s.backend.lib.aie_dev_lds_bytes(env_s.backend.handle, lds) == 0
+    assert -(-2 * lds[5] // 4) == _specs.SPECS[k_inst][4], "instance %d: %d B of LDS -> %d workgroups per CU" % (k_inst, lds[0], lds[5])
     envs = [make_env(cfg, n_envs=512, device="cuda:0") for _ in range(2)]
     for env in envs:
         env.seed(21)

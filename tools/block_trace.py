@@ -23,10 +23,10 @@ be = env.backend
 if len(sys.argv) > 2 and sys.argv[2] == "generic":
     be.lib.aie_dev_use_generic_kernel(be.handle)
 print("n_agents", N_AGENTS, "step kernel instance", be.lib.aie_step_kernel_instance(be.handle))
-lds = (ctypes.c_int64 * 5)()
+lds = (ctypes.c_int64 * 6)()
 be.lib.aie_dev_lds_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 be.lib.aie_dev_lds_bytes(be.handle, lds)
-print("LDS bytes per workgroup %d: record %d, location map %d, f64 scratch %d, staging %d" % tuple(lds))
+print("LDS bytes per workgroup %d: record %d, location map %d, f64 scratch %d, staging %d -> %d workgroups per CU" % tuple(lds))
 for _ in range(300):
     a, p = be.sample_random_actions(1234)
     be.step(a, p)
