@@ -298,13 +298,17 @@ class BaseEnvironment:
         if log_replica_resets:
             self._dense_log = {"world": [], "states": [], "actions": [], "rewards": []}
             if self._dense_log_this_episode:
-                from .dense_log import DenseLogger
-
                 if self._dense_logger is None:
-                    self._dense_logger = DenseLogger(self, 0)
+                    self._dense_logger = self.make_dense_logger()
                 self._dense_logger.begin_episode()
                 self._dense_log = self._dense_logger.log
         return self._obs()
+
+    def make_dense_logger(self):
+        """The object that assembles replica 0's dense log (scenarios with their own state dictionaries override)."""
+        from .dense_log import DenseLogger
+
+        return DenseLogger(self, 0)
 
     @property
     def dense_log(self):

@@ -190,3 +190,139 @@ class DenseLogger:
                              "effective_rate": float(np.float64(paid) / np.maximum(0.000001, inc)),
                              "lump_sum": lump}
         return entry
+
+
+class CovidDenseLogger(DenseLogger):
+    """Dense log of one replica of CovidAndEconomySimulation: the agents' and the planner's `state`
+    dictionaries as covid19_env.py:848-922 (scenario_step), :1237-1288 (additional_reset_steps), :1124-1161
+    (compute_reward) and covid19_components.py:180-221, 425-443, 615-627 leave them after every step -- rebuilt on the
+    host from the replica's device tensors, one read per logged step.  The world log holds empty dictionaries (the
+    scenario has no maps), the components have no dense logs, rewards are collated ({"a": [...], "p": x}).
+
+    The reference's quirks are kept: fields a reset does not touch ("R0", "Total Unemployed", "New Subsidy Received",
+    "Postsubsidy Productivity", "Current Open Close Stringency Level") carry over from the previous episode of the
+    same environment object and are absent in the first snapshot of its first episode; "New Infections" / "New
+    Deaths" difference against the previous snapshot's integer-cast totals."""
+
+    STICKY = ("R0", "Total Unemployed", "New Subsidy Received", "Postsubsidy Productivity",
+              "Current Open Close Stringency Level")
+
+    def __init__(self, env, e=0):
+        super().__init__(env, e)
+        self.agent_states = None
+        self.planner_state = None
+
+    def begin_episode(self):
+        import datetime
+
+        self.log = {"world": [], "states": [], "actions": [], "rewards": []}
+        self.component_logs = {}
+        env, m = self.env, self.env.model
+        n = env.n_agents
+        rs = m["reset_agent_state"]
+        date = datetime.datetime.strftime(m["start_date"], "%Y-%m-%d")
+        old = self.agent_states
+        self.agent_states = []
+        for i in range(n):
+            st = {"loc": [-1, -1], "inventory": {"Coin": 0}, "escrow": {"Coin": 0}, "endogenous": {"Labor": 0},
+                  "Total Vaccinated": 0, "Vaccines Available": 0}
+            for k in ("Total Susceptible", "New Infections", "Total Infected", "Total Recovered", "New Deaths",
+                      "Total Deaths"):
+                st[k] = int(rs[k][i])
+            st["Health Index"] = [0.0]
+            st["Economic Index"] = [0.0]
+            st["Date"] = date
+            if old is not None:
+                for k in self.STICKY:
+                    if k in old[i]:
+                        st[k] = old[i][k]
+            self.agent_states.append(st)
+        oldp = self.planner_state
+        p = {"inventory": {"Coin": 0}, "escrow": {"Coin": 0}, "endogenous": {}, "Total Subsidy": 0,
+             "Current Subsidy Level": 0}
+        for k in ("Total Susceptible", "New Infections", "Total Infected", "Total Recovered", "New Deaths",
+                  "Total Deaths"):
+            p[k] = int(np.sum([st[k] for st in self.agent_states]).astype(np.int32))
+        p["Total Vaccinated"] = int(np.sum(rs["Total Vaccinated"]).astype(np.int32))
+        p["Health Index"] = [0.0]
+        p["Economic Index"] = [0.0]
+        p["Date"] = date
+        if oldp is not None:
+            for k in ("Total Unemployed", "New Subsidy Provided", "Postsubsidy Productivity"):
+                if k in oldp:
+                    p[k] = oldp[k]
+        self.planner_state = p
+        self._total_subsidy = 0
+
+    def world_snapshot(self):
+        return {}
+
+    def states_snapshot(self):
+        import copy
+
+        out = {str(i): copy.deepcopy(st) for i, st in enumerate(self.agent_states)}
+        out["p"] = copy.deepcopy(self.planner_state)
+        return out
+
+    def after_step(self):
+        import datetime
+
+        env, e, m = self.env, self.e, self.env.model
+        t = env.backend.tensors
+        n = env.n_agents
+        ra, rp = _host(t["rewards_a"], e), t["rewards_p"][e].item()
+        self.log["rewards"].append({"a": [float(x) for x in ra], "p": float(rp)})
+
+        ts = int(t["timestep"][e].item())
+        f32 = {k: _host(t[k], e).astype(np.float32) for k in
+               ("susceptible", "infected", "recovered", "deaths", "vaccinated", "unemployed", "subsidy",
+                "postsubsidy_productivity", "health_index", "economic_index")}
+        level_now = np.asarray(env.stringency_level(e, ts), np.float32)
+        # sir_step (:1477-1497): beta from the stringency level beta_delay days back
+        level_tmk = np.asarray(env.stringency_level(e, ts - int(m["beta_delay"]))).astype(np.int32)
+        beta = (m["beta_intercepts"] * 1 + m["beta_slopes"] * 1 * level_tmk).astype(np.float32)
+        r0 = beta / m["gamma"]
+        date = datetime.datetime.strftime(m["start_date"] + datetime.timedelta(days=ts), "%Y-%m-%d")
+        i32 = lambda x: x.astype(np.int32)  # noqa: E731
+        S, I, R, V, U = (i32(f32[k]) for k in ("susceptible", "infected", "recovered", "vaccinated", "unemployed"))
+        D = f32["deaths"]
+        for i, st in enumerate(self.agent_states):
+            st["Current Open Close Stringency Level"] = float(level_now[i])
+            st["Vaccines Available"] = 0
+            st["R0"] = float(r0[i])
+            st["Total Susceptible"] = int(S[i])
+            st["New Infections"] = int(np.asarray(f32["infected"][i] - st["Total Infected"]).astype(np.int32))
+            st["Total Infected"] = int(I[i])
+            st["Total Recovered"] = int(R[i])
+            st["New Deaths"] = float(D[i] - np.int32(st["Total Deaths"]))
+            st["Total Deaths"] = int(D[i].astype(np.int32))
+            st["Total Vaccinated"] = int(V[i])
+            st["Total Unemployed"] = int(U[i])
+            st["New Subsidy Received"] = float(f32["subsidy"][i])
+            st["Postsubsidy Productivity"] = float(f32["postsubsidy_productivity"][i])
+            st["Date"] = date
+            st["Health Index"] = [float(f32["health_index"][i])]
+            st["Economic Index"] = [float(f32["economic_index"][i])]
+        p = self.planner_state
+        self._total_subsidy = self._total_subsidy + np.sum(f32["subsidy"])
+        p["Total Subsidy"] = float(self._total_subsidy)
+        p["Current Subsidy Level"] = int(t["subsidy_level"][e].item())
+        p["Total Susceptible"] = int(np.sum(f32["susceptible"]).astype(np.int32))
+        p["New Infections"] = int(np.asarray(np.sum(f32["infected"]) - p["Total Infected"]).astype(np.int32))
+        p["Total Infected"] = int(np.sum(f32["infected"]).astype(np.int32))
+        p["Total Recovered"] = int(np.sum(f32["recovered"]).astype(np.int32))
+        p["New Deaths"] = int(np.asarray(np.sum(D) - p["Total Deaths"]).astype(np.int32))
+        p["Total Deaths"] = int(np.sum(D).astype(np.int32))
+        p["Total Vaccinated"] = int(np.sum(f32["vaccinated"]).astype(np.int32))
+        p["Total Unemployed"] = int(np.sum(f32["unemployed"]).astype(np.int32))
+        p["New Subsidy Provided"] = float(np.sum(f32["subsidy"]))
+        p["Postsubsidy Productivity"] = float(np.sum(f32["postsubsidy_productivity"]))
+        p["Date"] = date
+        hp = _host(t["planner_health_economic_index"], e).astype(np.float32)
+        p["Health Index"] = [float(hp[0])]
+        p["Economic Index"] = [float(hp[1])]
+
+    def finalize(self):
+        self.log["world"].append(self.world_snapshot())
+        self.log["states"].append(self.states_snapshot())
+        return self.log

@@ -84,6 +84,18 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
         z = np.zeros(self.world_size, np.uint8)
         return (z, z, z)
 
+    def make_dense_logger(self):
+        from ..dense_log import CovidDenseLogger
+
+        return CovidDenseLogger(self, 0)
+
+    def stringency_level(self, e, day):
+        """Stringency level of every state on day `day` of replica e's episode (day < 0: before the start date;
+        covid19_env.py:1210-1217 pads the time before the data begins with level 1)."""
+        tau = int(day) + int(self.model["filter_len"])
+        assert tau >= 0
+        return self.backend.tensors["stringency_history_chunks"][e, tau // 16, :, tau % 16].cpu().numpy()
+
     def scenario_metrics(self, tensors):
         from .. import metrics
 
@@ -93,6 +105,7 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
         m, v = self.model, cfg.covid
         cfg.scenario = _cabi.SCN_COVID
         cfg.shared_layout = 1
+        cfg.dense_log_replicas = 0  # no device event rows: the three components have no dense logs (dense_log.py)
         v.beta_delay = int(m["beta_delay"])
         v.filter_len = int(m["filter_len"])
         v.num_filters = int(m["num_filters"])

@@ -140,6 +140,17 @@ def build_model(start_date="2020-03-22", pop_between_age_18_65=0.6, infection_to
     m["unemployed_0"] = rw["unemployed"][sidx].astype(F32)
     m["vaccinated_0"] = rw["vaccinated"][sidx].astype(F32)
     m["stringency_0"] = policy[sidx].astype(F32)
+    # agent.state at reset is filled from the table itself, before any float32 cast (:1237-1256; dense logs)
+    prev = max(0, sidx - 1)
+    m["reset_agent_state"] = {
+        "Total Susceptible": rw["susceptible"][sidx].astype(I32),
+        "New Infections": (rw["infected"][sidx] - rw["infected"][prev]).astype(I32),
+        "Total Infected": rw["infected"][sidx].astype(I32),
+        "Total Recovered": rw["recovered"][sidx].astype(I32),
+        "New Deaths": (rw["recovered"][sidx] * m["death_rate"] - rw["recovered"][prev] * m["death_rate"]).astype(I32),
+        "Total Deaths": (rw["recovered"][sidx] * m["death_rate"]).astype(I32),
+        "Total Vaccinated": np.asarray(rw["vaccinated"][sidx]),
+    }
     hist = np.pad(policy[: sidx + 1], [(filter_len, 0), (0, 0)], constant_values=1)[-(filter_len + 1):]
     m["stringency_level_history_0"] = hist  # [filter_len + 1, n]
     # stringency levels of the days before the episode, for the beta delay (:744-760, :951-960)
