@@ -5,7 +5,7 @@ by env.py purely as the owner of device memory / streams.
 """
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_AGENTS = 64
 MAX_AGENTS_WIDE = 128
 MAX_COMPONENTS = 8
@@ -54,7 +54,8 @@ class AieCovidConfig(C.Structure):
             "min_marginal_planner_health_index", "max_marginal_planner_health_index",
             "min_marginal_planner_economic_index", "max_marginal_planner_economic_index",
             "weightage_on_marginal_planner_health_index", "weightage_on_marginal_planner_economic_index",
-            "reward_normalization_factor")] + [("filter_decay", C.c_double * COVID_MAX_FILTERS), ("filter_tail", C.c_double * COVID_MAX_FILTERS)]
+            "reward_normalization_factor")] + [("filter_decay", C.c_double * COVID_MAX_FILTERS), ("filter_tail", C.c_double * COVID_MAX_FILTERS),
+                                             ("replay_policies", C.c_int32), ("replay_data", C.c_int32)]
 
 
 class AieConfig(C.Structure):

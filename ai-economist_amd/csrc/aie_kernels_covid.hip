@@ -117,7 +117,7 @@ __device__ __forceinline__ void cv_write_observations(const aie_params& P, uint8
     oa[AIE_CV_OB_SUBSIDY_LEVEL * n + s] = sub_lvl;
     oa[AIE_CV_OB_T_VACCINE * n + s] = t_vac;
     // generate_masks: NO-OP always allowed; levels only outside the cooldown (:97-108,223-241)
-    const float open = t >= a.cooldown ? 1.0f : 0.0f;
+    const float open = (t >= a.cooldown || V.replay_policies) ? 1.0f : 0.0f;
     oa[AIE_CV_OB_MASK * n + s] = 1.0f;
     for (int k = 1; k <= NL; ++k) oa[(AIE_CV_OB_MASK + k) * n + s] = open;
   }
@@ -128,7 +128,7 @@ __device__ __forceinline__ void cv_write_observations(const aie_params& P, uint8
     op[3] = t_vac;
   }
   // planner mask: subsidy levels selectable only on the first day of an interval (:445-469)
-  const float pm = (t % V.subsidy_interval == 0) ? 1.0f : 0.0f;
+  const float pm = (t % V.subsidy_interval == 0 || V.replay_policies) ? 1.0f : 0.0f;
   for (int k = s; k < P.MP; k += AIE_NT) op[4 + k] = k == 0 ? 1.0f : pm;
 }
 
@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
 
   // ---- ControlUSStateOpenCloseStatus.component_step :180-221 ----
   int act = act_a ? act_a[(int64_t)e * n + sl] : 0;
+  if (V.replay_policies) act = (arena + P.a_cv_replay_a)[(int64_t)(t - 1) * 64 + sl];  // :181-186: yesterday's recorded level
   if (act < 0 || act > NL) act = 0;
   const int prev_level = *cv_hist_at(P, hist, sl, L + t - 1);
   CvLane a;
@@ -275,7 +276,9 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
 
   // ---- FederalGovernmentSubsidy.component_step :393-443 ----
   int sub_level = uni(*reinterpret_cast<const int32_t*>(rec + P.o_cv_subsidy_level));
-  if ((t - 1) % V.subsidy_interval == 0) {
+  if (V.replay_policies) {  // :394-425: the level the recorded subsidies amount to on this day
+    sub_level = uni(reinterpret_cast<const int32_t*>(arena + P.a_cv_replay_p)[t - 1]);
+  } else if ((t - 1) % V.subsidy_interval == 0) {
     int ap = act_p ? uni(act_p[e]) : 0;
     if (ap < 0 || ap > NS) ap = 0;
     sub_level = ap;
@@ -310,6 +313,20 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     a.R = fmaxf(R1 + dR, 0.f);
     a.V = fmaxf(V1 + dV, 0.f);
     a.D = (float)V.death_rate * (a.R - a.V);
+  }
+  // use_real_world_data :734-757: the recorded day (float64 table), clamped at zero; the global state keeps the
+  // float32 cast, the economy step below works on the table values themselves
+  const double* __restrict__ rws = reinterpret_cast<const double*>(arena + P.a_cv_replay_state);
+  const int64_t rw_plane = (int64_t)(T + 1) * 64;
+  double rw_I = 0.0, rw_D = 0.0;
+  if (V.replay_data) {
+    rw_I = fmax(rws[1 * rw_plane + (int64_t)t * 64 + sl], 0.0);
+    rw_D = fmax(rws[4 * rw_plane + (int64_t)t * 64 + sl], 0.0);
+    a.S = (float)fmax(rws[0 * rw_plane + (int64_t)t * 64 + sl], 0.0);
+    a.I = (float)rw_I;
+    a.R = (float)fmax(rws[2 * rw_plane + (int64_t)t * 64 + sl], 0.0);
+    a.V = (float)fmax(rws[3 * rw_plane + (int64_t)t * 64 + sl], 0.0);
+    a.D = (float)rw_D;
   }
 
   // ---- unemployment_step :1374-1441 ----
@@ -392,6 +409,7 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     }
     const double excess = x <= 20.0 ? log(1.0 + exp(x)) : x;  // softplus :1358-1372
     unemployed = ((excess + K[AIE_CV_K_UNEMP_BIAS * 64 + sl]) * pop) / 100.0;
+    if (V.replay_data) unemployed = rws[5 * rw_plane + (int64_t)t * 64 + sl];  // :815-818 (not clamped)
     a.U = (float)unemployed;
   }
 
@@ -399,7 +417,9 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   {
     const float incapacitated = (float)V.infection_too_sick_to_work_rate * a.I + a.D;
     const float p1865 = (float)V.population_between_age_18_65;
-    const double cant_work = (double)(incapacitated * p1865) + unemployed;
+    double cant_work = (double)(incapacitated * p1865) + unemployed;
+    if (V.replay_data)  // float32 scalars times float64 table values: NumPy computes in float64
+      cant_work = ((double)(float)V.infection_too_sick_to_work_rate * rw_I + rw_D) * (double)p1865 + unemployed;
     const double workers = pop * (double)p1865;
     const double diff = workers - cant_work;
     a.prod = (float)((diff > 0.0 ? diff : 0.0) * (double)(float)V.daily_production_per_worker) + a.subsidy;

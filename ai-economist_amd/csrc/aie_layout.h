@@ -180,6 +180,9 @@ typedef struct aie_params {
                           * derived from a_cv_hist0 by aie_covid_prepare_kernel whenever that table is uploaded  */
   int64_t a_cv_acc0;     /* float64 [F][64]: every filter's discounted delta sum at t = 0 (filter_recurrence), ditto */
   int64_t a_cv_lag_obs;  /* uint8 [beta_delay][n]                                          */
+  int64_t a_cv_replay_a; /* uint8 [T][64]: replay_policies: the states' stringency action of step t in row t - 1 */
+  int64_t a_cv_replay_p; /* int32 [T]: replay_policies: the planner's subsidy level of step t at t - 1            */
+  int64_t a_cv_replay_state; /* float64 [6: S, I, R, V, D, U][T + 1][64]: replay_data                             */
   int64_t a_cv_hist;     /* uint8 [E][nch][cv_row]                                         */
   int64_t a_cv_obs_a;    /* float32 [E][cv_nrow_obs][n]                                    */
   int64_t a_cv_obs_p;    /* float32 [E][4 + 1 + NS]                                        */
@@ -201,6 +204,7 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->a_saez = p->a_events = p->a_metrics = p->a_saez_global = 0;
   p->a_cv_consts = p->a_cv_filters = p->a_cv_hist0 = p->a_cv_lag_obs = p->a_cv_hist = p->a_cv_obs_a = p->a_cv_obs_p = 0;
   p->a_cv_hist0c = p->a_cv_acc0 = 0;
+  p->a_cv_replay_a = p->a_cv_replay_p = p->a_cv_replay_state = 0;
   p->a_layout_prob = 0;
   p->dev_skip_mask = 0;
   p->dev_trace = 0;
@@ -327,6 +331,7 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   if (!(v->economic_reward_crra_eta >= 0.0)) AIE__FAIL("economic_reward_crra_eta must be >= 0");
   if (v->economic_reward_crra_eta == 1.0) AIE__FAIL("economic_reward_crra_eta == 1 divides by zero (covid19_env.py:1074)");
   if (!(v->reward_normalization_factor != 0.0)) AIE__FAIL("reward_normalization_factor must be non-zero");
+  if (v->replay_data && !v->replay_policies) AIE__FAIL("replay_data (use_real_world_data) needs replay_policies (covid19_env.py:126-135)");
   if (v->filter_recurrence)
     for (int f = 0; f < v->num_filters; ++f)
       if (!(v->filter_decay[f] > 0.0 && v->filter_decay[f] < 1.0)) AIE__FAIL("filter_decay[%d] must be in (0, 1)", f);
@@ -376,6 +381,14 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   p->a_cv_hist0c = a;  a = aie__align(a + (int64_t)p->cv_nch * p->cv_row, 256);
   p->a_cv_acc0 = a;    a = aie__align(a + (int64_t)AIE_COVID_MAX_FILTERS * 64 * 8, 256);
   p->a_cv_lag_obs = a; a = aie__align(a + (int64_t)v->beta_delay * n, 256);
+  p->a_cv_replay_a = p->a_cv_replay_p = p->a_cv_replay_state = 0;
+  if (v->replay_policies) {
+    p->a_cv_replay_a = a; a = aie__align(a + (int64_t)c->episode_length * 64, 256);
+    p->a_cv_replay_p = a; a = aie__align(a + (int64_t)c->episode_length * 4, 256);
+  }
+  if (v->replay_data) {
+    p->a_cv_replay_state = a; a = aie__align(a + (int64_t)6 * (c->episode_length + 1) * 64 * 8, 256);
+  }
   p->a_cv_hist = a;    a = aie__align(a + E * (int64_t)p->cv_nch * p->cv_row, 256);
   p->a_cv_obs_a = a;   a = aie__align(a + E * no, 256);
   p->a_cv_obs_p = a;   a = aie__align(a + E * po, 256);
@@ -430,6 +443,16 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
     tt->t[tt->n - 1].stride[2] = 8 * (int64_t)p->cv_F;
     aie__add_shared(tt, "model_stringency_level_history_0", AIE_U8, p->a_cv_hist0, 2, p->cv_L + 1, n);
     aie__add_shared(tt, "model_policy_before_start_obs", AIE_U8, p->a_cv_lag_obs, 2, v->beta_delay, n);
+    if (v->replay_policies) {
+      aie__add_shared(tt, "replay_stringency_policy", AIE_U8, p->a_cv_replay_a, 2, c->episode_length, n);
+      tt->t[tt->n - 1].stride[1] = 64;
+      aie__add_shared(tt, "replay_subsidy_level", AIE_I32, p->a_cv_replay_p, 1, c->episode_length, 0);
+    }
+    if (v->replay_data) {
+      aie__add(tt, "replay_state", AIE_F64, p->a_cv_replay_state, 0, 3, 6, c->episode_length + 1, n, 0, 1);
+      tt->t[tt->n - 1].stride[1] = (int64_t)(c->episode_length + 1) * 64 * 8;
+      tt->t[tt->n - 1].stride[2] = 64 * 8;
+    }
 
 #define OBA(name, row, nd, d0) aie__add(tt, name, AIE_F32, p->a_cv_obs_a + (int64_t)(row) * n * 4, no, nd, d0, (nd) == 2 ? n : 0, 0, 0, E)
     OBA("obs_a_world-agent_state", AIE_CV_OB_STATE, 2, 6);

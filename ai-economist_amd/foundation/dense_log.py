@@ -286,10 +286,18 @@ class CovidDenseLogger(DenseLogger):
         i32 = lambda x: x.astype(np.int32)  # noqa: E731
         S, I, R, V, U = (i32(f32[k]) for k in ("susceptible", "infected", "recovered", "vaccinated", "unemployed"))
         D = f32["deaths"]
+        replay_data = bool(getattr(env, "use_real_world_data", False))
+        cc = env.component_constants
+        delivery = (ts >= int(cc["time_when_vaccine_delivery_begins"])
+                    and ts % int(env.get_component("VaccinationCampaign").delivery_interval) == 0)
         for i, st in enumerate(self.agent_states):
             st["Current Open Close Stringency Level"] = float(level_now[i])
-            st["Vaccines Available"] = 0
-            st["R0"] = float(r0[i])
+            if replay_data:  # nothing consumes the deliveries and sir_step (R0) does not run (covid19_env.py:734-757)
+                if delivery:
+                    st["Vaccines Available"] += int(cc["num_vaccines_per_delivery"][i])
+            else:
+                st["Vaccines Available"] = 0
+                st["R0"] = float(r0[i])
             st["Total Susceptible"] = int(S[i])
             st["New Infections"] = int(np.asarray(f32["infected"][i] - st["Total Infected"]).astype(np.int32))
             st["Total Infected"] = int(I[i])

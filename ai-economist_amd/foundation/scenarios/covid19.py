@@ -26,12 +26,13 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
                  economic_reward_crra_eta=2, health_priority_scaling_agents=1,
                  health_priority_scaling_planner=1, reward_normalization_factor=1, exact_filter_sums=False,
                  **base_env_kwargs):
-        if use_real_world_data or use_real_world_policies:
-            # covid19_env.py:126-135, 735-757: replays the recorded data / policies instead of
-            # simulating -- a data-loader mode, not part of the accelerated path.
-            raise NotImplementedError("use_real_world_data / use_real_world_policies are not supported")
-        self.use_real_world_data = False
-        self.use_real_world_policies = False
+        # covid19_env.py:121-135: replaying the recorded data implies replaying the recorded policies
+        self.use_real_world_data = bool(use_real_world_data)
+        self.use_real_world_policies = bool(use_real_world_policies)
+        if self.use_real_world_data:
+            assert self.use_real_world_policies, (
+                "Since the env. config. 'use_real_world_data' is True, please also set 'use_real_world_policies' to True.")
+        self._path_to_data = path_to_data_and_fitted_params
         # extension (not a reference kwarg): True re-sums the whole 600-day filter window every step over the
         # reference's float32 taps, as the reference does; the default updates each filter's discounted delta sum
         # in O(1) per step, exploiting that the taps ARE exp(-age / lambda) (covid19_env.py:242-247) -- the two agree
@@ -77,6 +78,14 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
             {"daily_vaccines_per_million_people": vac.daily_vaccines_per_million_people,
              "delivery_interval": vac.delivery_interval,
              "vaccine_delivery_start_date": vac.vaccine_delivery_start_date.strftime("%Y-%m-%d")})
+        self.replay = None
+        if self.use_real_world_policies:
+            # actions are ignored (covid19_env.py:190 "ignoring external action inputs"): the recorded tables go to the
+            # device once (upload_model_constants) and the step kernel reads its day's row
+            self.replay = covid19_model.replay_tables(
+                m, {"subsidy_interval": sub.subsidy_interval, "num_subsidy_levels": sub.num_subsidy_levels,
+                    "max_annual_subsidy_per_person": sub.max_annual_subsidy_per_person},
+                self.use_real_world_data, self._path_to_data)
         if self.component_constants["time_when_vaccine_delivery_begins"] < 0:
             raise NotImplementedError("vaccine_delivery_start_date before start_date is not supported")
 
@@ -111,6 +120,8 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
         v.num_filters = int(m["num_filters"])
         v.time_when_vaccine_delivery_begins = int(self.component_constants["time_when_vaccine_delivery_begins"])
         v.filter_recurrence = 0 if self.exact_filter_sums else 1
+        v.replay_policies = int(self.use_real_world_policies)
+        v.replay_data = int(self.use_real_world_data)
         for f, lam in enumerate(np.asarray(m["conv_lambdas"], np.float64)):
             r = float(np.exp(-1.0 / lam))
             v.filter_decay[f] = r
@@ -153,5 +164,10 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
             "model_stringency_level_history_0": m["stringency_level_history_0"],
             "model_policy_before_start_obs": m["policy_before_start_obs"],
         }
+        if self.replay is not None:
+            rows["replay_stringency_policy"] = self.replay["stringency_policy"]
+            rows["replay_subsidy_level"] = self.replay["subsidy_level"]
+            if self.use_real_world_data:
+                rows["replay_state"] = self.replay["state"]
         for name, arr in rows.items():
             backend.upload(name, np.asarray(arr)[None])

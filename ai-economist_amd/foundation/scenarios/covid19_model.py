@@ -169,7 +169,50 @@ def build_model(start_date="2020-03-22", pop_between_age_18_65=0.6, infection_to
         pre_obs[k] = policy[sidx - bd + k]
     m["policy_before_start_obs"] = pre_obs
     m["episode_length"] = int(episode_length)
+    m["real_world_policy_length"] = int(len(policy) - sidx)
     return m
+
+
+def replay_tables(m, subsidy_kwargs, use_real_world_data, path_to_data_and_fitted_params=""):
+    """What `use_real_world_policies` / `use_real_world_data` replay (covid19_env.py:188-231, 734-757, 815-818;
+    covid19_components.py:181-186, 394-425), as tables indexed by the episode's day:
+      stringency_policy [T, n]  the action ControlUSStateOpenCloseStatus takes at step t sits in row t - 1
+                                (yesterday's recorded level);
+      subsidy_level [T]         FederalGovernmentSubsidy's level at step t in slot t - 1: every recorded payment is
+                                rounded to a number of levels and spread over the `subsidy_interval` days from its
+                                date on.  (The reference keeps accumulating into the same array in later episodes of
+                                the same object; the table is the first episode's, i.e. what a fresh environment does.)
+      state [6, T + 1, n]       susceptible, infected, recovered, vaccinated, deaths, unemployed of day t (float64: the
+                                global state stores their float32 cast, the economy step works on the table values)."""
+    d = load_data(path_to_data_and_fitted_params or None)
+    T, sidx = int(m["episode_length"]), int(m["start_date_index"])
+    n = len(m["us_state_population"])
+    if T > m["real_world_policy_length"]:
+        raise AssertionError("The real-world policies are only available for {0} timesteps; so the 'episode_length' "
+                             "in the environment configuration can only be at most {0}".format(m["real_world_policy_length"]))
+    policy = np.asarray(d["rw_policy"]).astype(np.int64)[sidx:]
+    out = {"stringency_policy": policy[:T].astype(np.uint8)}
+    assert (out["stringency_policy"] <= m["num_stringency_levels"]).all()
+    interval, levels = int(subsidy_kwargs["subsidy_interval"]), int(subsidy_kwargs["num_subsidy_levels"])
+    per_level = (m["us_population"] * subsidy_kwargs["max_annual_subsidy_per_person"] / levels * interval / 365)
+    subsidy = np.asarray(d["rw_subsidy"], np.float64).reshape(-1)[sidx:]
+    arr = np.zeros(T + 1)
+    for t in range(1, T + 1):
+        amount = subsidy[t - 1]
+        if amount > 0:
+            lvl = np.round(amount / per_level)
+            for k in range(t - 1, min(len(arr), t - 1 + interval)):
+                arr[k] += lvl
+    lv = arr[:T]
+    assert ((0 <= lv) & (lv <= levels)).all(), "recorded subsidies exceed num_subsidy_levels (covid19_components.py:428)"
+    out["subsidy_level"] = lv.astype(np.int32)
+    if use_real_world_data:
+        keys = ("susceptible", "infected", "recovered", "vaccinated", "deaths", "unemployed")
+        if T + 1 > m["real_world_policy_length"]:
+            raise AssertionError("use_real_world_data reads day episode_length of the recorded tables")
+        out["state"] = np.stack([np.asarray(d["rw_" + k], np.float64)[sidx:sidx + T + 1] for k in keys])
+        assert out["state"].shape == (6, T + 1, n)
+    return out
 
 
 def component_constants(m, subsidy_kwargs, vaccine_kwargs):

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AIE_ABI_VERSION 7
+#define AIE_ABI_VERSION 8
 
 #define AIE_MAX_AGENTS 64      /* mobile agents per replica, spatial scenarios (one lane each) */
 #define AIE_MAX_AGENTS_WIDE 128 /* mobile agents per replica, map-less one-step-economy        */
@@ -146,6 +146,15 @@ typedef struct aie_covid_config {
   double reward_normalization_factor;
   double filter_decay[AIE_COVID_MAX_FILTERS]; /* r_f = exp(-1 / CONV_LAMBDAS[f]), used iff filter_recurrence      */
   double filter_tail[AIE_COVID_MAX_FILTERS];  /* r_f^(filter_len - 1): the weight with which a delta leaves the window */
+  int32_t replay_policies;                /* use_real_world_policies (covid19_env.py:56-60, covid19_components.py:181-186,
+                                             394-425): actions are ignored; the states' stringency actions come from tensor
+                                             "replay_stringency_policy" [episode_length][n] (row t-1 acts at step t), the
+                                             planner's subsidy level of every step from "replay_subsidy_level"
+                                             [episode_length]; every action mask is fully open                       */
+  int32_t replay_data;                    /* use_real_world_data (covid19_env.py:52-55, 734-757, 815-818; implies
+                                             replay_policies): susceptible / infected / recovered / vaccinated / deaths /
+                                             unemployed of day t are read from tensor "replay_state" (float64 [6][episode_length + 1][n],
+                                             clamped at 0) instead of being simulated                                 */
 } aie_covid_config;
 
 /* ---- configuration: the kwargs of make_env_instance + component kwargs ---------- */

@@ -33,7 +33,11 @@ def _softplus(x):
 
 class CovidOracle:
     def __init__(self, model, comp, n_envs, action_cooldown_period=28, subsidy_interval=90,
-                 num_subsidy_levels=20, delivery_interval=1, episode_length=540):
+                 num_subsidy_levels=20, delivery_interval=1, episode_length=540, replay=None):
+        # replay: None, or the recorded tables of use_real_world_policies / use_real_world_data
+        # ({"stringency_policy": [T, n], "subsidy_level": [T], optionally "state": [6, T + 1, n]};
+        # covid19_env.py:188-231, 734-757, 815-818, covid19_components.py:181-186, 394-425)
+        self.replay = replay
         self.m = model
         self.c = comp
         self.E = n_envs
@@ -79,13 +83,17 @@ class CovidOracle:
         t = self.t
         a = np.asarray(actions_a, np.int64).reshape(self.E, n)
         ap = np.asarray(actions_p, np.int64).reshape(self.E)
+        if self.replay is not None:  # "Use the action taken in the previous timestep"
+            a = np.repeat(np.asarray(self.replay["stringency_policy"][t - 1], np.int64)[None], self.E, axis=0)
         # ControlUSStateOpenCloseStatus.component_step :180-221
         prev = self.stringency[:, t - 1]
         self.stringency[:, t] = prev * (a == 0) + a
         upd = t == self.cooldown_until + 1
         self.cooldown_until = self.cooldown_until + upd * np.where(a == 0, 1, self.cooldown_period)
         # FederalGovernmentSubsidy.component_step :393-443
-        if (t - 1) % self.subsidy_interval == 0:
+        if self.replay is not None:
+            self.subsidy_level = np.full(self.E, int(self.replay["subsidy_level"][t - 1]), np.int64)
+        elif (t - 1) % self.subsidy_interval == 0:
             self.subsidy_level = ap.copy()
         frac = self.subsidy_level / self.num_subsidy_levels
         self.subsidy[:, t] = frac[:, None] * self.c["max_daily_subsidy_per_state"][None]
@@ -123,6 +131,10 @@ class CovidOracle:
         Rt = np.maximum(R1 + dR, 0)
         Vt = np.maximum(V1 + dV, 0)
         Dt = m["death_rate"] * (Rt - Vt)
+        data = None if self.replay is None else self.replay.get("state")
+        if data is not None:  # :734-757 (float64 table values; economy_step below gets them uncast)
+            St, It, Rt, Vt, Dt = (np.maximum(np.repeat(np.asarray(data[k][t], np.float64)[None], self.E, axis=0), 0)
+                                  for k in range(5))
         self.S[:, t], self.I[:, t], self.R[:, t], self.D[:, t], self.V[:, t] = St, It, Rt, Dt, Vt
         # unemployment_step :1374-1441
         cur = self.stringency[:, t]
@@ -133,6 +145,8 @@ class CovidOracle:
         weighted = x * w[None]
         excess = _softplus(np.sum(weighted * m["unemp_conv_filters"][None, None], axis=(2, 3)))
         unemployed = (excess + m["unemployment_bias"][None]) * m["us_state_population"][None] / 100
+        if data is not None:  # :815-818
+            unemployed = np.repeat(np.asarray(data[5][t], np.float64)[None], self.E, axis=0)
         self.U[:, t] = unemployed
         # economy_step :1444-1475
         incap = (m["infection_too_sick_to_work_rate"] * It) + Dt
@@ -202,8 +216,10 @@ class CovidOracle:
             tv = self.delivery_interval - nt % self.delivery_interval
         o["VaccinationCampaign-t_until_next_vaccines"] = np.full((E, n), tv / self.delivery_interval)
         open_ = (t >= self.cooldown_until).astype(F32)  # generate_masks :97-108
+        if self.replay is not None:
+            open_ = np.ones_like(open_)
         mask_a = np.concatenate([np.ones((E, 1, n), F32), np.repeat(open_[:, None], self.nl, axis=1)], axis=1)
-        pm = 1.0 if t % self.subsidy_interval == 0 else 0.0
+        pm = 1.0 if (t % self.subsidy_interval == 0 or self.replay is not None) else 0.0
         mask_p = np.concatenate([np.ones((E, 1), F32), np.full((E, self.num_subsidy_levels), pm, F32)], axis=1)
         out = {"obs_a_" + k: np.asarray(v, np.float32) for k, v in o.items()}
         out["obs_a_action_mask"] = mask_a

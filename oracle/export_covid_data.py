@@ -30,7 +30,7 @@ for k, v in fp.items():
     if k == "settings":
         continue
     out["fp_" + k] = np.array(v)
-for k in ["policy", "subsidy", "susceptible", "infected", "recovered", "vaccinated", "unemployed"]:
+for k in ["policy", "subsidy", "susceptible", "infected", "recovered", "vaccinated", "unemployed", "deaths"]:
     a = rw[k]
     out["rw_" + k] = a.astype(np.int8) if k == "policy" else a
 np.savez_compressed(DST, **out)

@@ -269,8 +269,8 @@ def test_covid_masked_reset_and_config_errors():
     with pytest.raises(ValueError):
         hip_env(bad, 1)
     bad = dict(cfg)
-    bad["use_real_world_policies"] = True
-    with pytest.raises(NotImplementedError):
+    bad["use_real_world_data"] = True  # covid19_env.py:126-135: needs use_real_world_policies too
+    with pytest.raises(AssertionError):
         hip_env(bad, 1)
 
 
