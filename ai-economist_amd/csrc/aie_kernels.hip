@@ -1539,7 +1539,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool wi
     bool need = false;
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k)
-      need |= (off_a[k] + 1 >= lo) && (off_a[k] < lo + AIE_MT_N);
+      if (k < nchunk) need |= (off_a[k] + 1 >= lo) && (off_a[k] < lo + AIE_MT_N);  // (uniform: the usual map lists < 64 draws)
     if (__ballot(need) == 0) continue;
     if (!(w == 0 && win0_in_lds)) {
       AIE_WSYNC();
@@ -1550,6 +1550,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool wi
     }
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
+      if (k >= nchunk) continue;
       const int ia = off_a[k] - lo, ib = ia + 1;
       if (ia >= 0 && ia < AIE_MT_N) wa[k] = buf[ia];
       if (off_a[k] >= 0 && ib >= 0 && ib < AIE_MT_N) wb[k] = buf[ib];
@@ -1558,7 +1559,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool wi
   m.pos = pos0 + total - last_win * AIE_MT_N;
 #pragma unroll
   for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k)
-    if (off_a[k] >= 0) regen_cell(c, mt_temper(wa[k]), mt_temper(wb[k]), (off_a[k] - pos0) >> 1);
+    if (k < nchunk && off_a[k] >= 0) regen_cell(c, mt_temper(wa[k]), mt_temper(wb[k]), (off_a[k] - pos0) >> 1);
   AIE_WSYNC();  // the dump area is the observation staging area
 }
 
