@@ -41,7 +41,7 @@ __device__ __forceinline__ const aie_params& aie_spec_params(const aie_params* r
 
 #define AIE_NT 64  // threads per replica (one wavefront)
 #define AIE_DIRTY_CAP 64  // map cells one step may change before the incremental map observations give up (= one lane each)
-#define AIE_SRC_CAP 256  // source-block doubles handled by the gather regen (else row regen)
+#define AIE_SRC_CAP 128  // source-block doubles handled by the gather regen (else row regen)
 
 namespace aie {
 
@@ -93,14 +93,19 @@ __host__ __device__ inline int fscr_doubles(const aie_params& P) { return 2 * P.
 // The LDS image of the record stops where the MT19937 key starts (it lives in VGPRs).
 __host__ __device__ inline int rec_lds_bytes(const aie_params& P) { return P.o_mt; }
 
-// staging area: small observation vectors; reused as the 624-word MT19937 dump of regen
+// staging area: the components' draw window (the next tempered MT19937 words, see MTL) and the small
+// observation vectors the flat-vector writer stages
 __host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline int stage_window_words(const aie_params& P) {
-  const int m = pad4(P.n * P.MA) + pad4(P.MP);
-  return m < AIE_MT_N ? AIE_MT_N : m;
+  // words the components of one step draw at most in the common case: two agent-order permutations (n - 1 masked
+  // rejection draws each, < 2 words per draw on average) and a pickup draw per agent and resource; a step that needs
+  // more refills the window from the generator state in HBM (rng_refill)
+  int w = (4 * P.n + 4 * P.n + 63) / 64 * 64;
+  if (w < 128) w = 128;
+  return w > 576 ? 576 : w;
 }
 __host__ __device__ inline size_t stage_bytes(const aie_params& P) {
-  // [0, 624 words): MT19937 window / regeneration dump, later the mask staging;
+  // [0, window): tempered words pos ... of the generator's current window (filled by the wave that holds the state);
   // behind it: the planner's flat vector + per-agent fragments (write_flat_observations)
   const size_t b = (size_t)(stage_window_words(P) + pad4(P.n * P.FPA) + pad4(P.FP)) * 4;
   return (b + 15) / 16 * 16;
@@ -253,9 +258,9 @@ struct MT {
 // the step's 2*H*W np.random.rand values targets Wood cell d (d < HW) or Stone cell d-HW,
 // and only source-block cells can respawn (layout_from_file.py:394-403).
 // *c.srcn must have been zeroed (and a barrier passed) before the call.
-// `wave` of `nwaves` copies every nwaves-th 16-byte unit; wave 0 also takes the MT19937 key.
+// `wave` of `nwaves` copies every nwaves-th 16-byte unit; wave `key_wave` also takes the MT19937 key (registers).
 __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m, int wave = 0,
-                                            int nwaves = 1, bool key_to_lds = false) {
+                                            int nwaves = 1, int key_wave = 0) {
   const uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
   const uint4* src = reinterpret_cast<const uint4*>(g);
   uint4* dst = reinterpret_cast<uint4*>(c.rec);
@@ -283,13 +288,7 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
       }
     }
   }
-  if (key_to_lds) {  // step kernel: the key goes to the LDS window (see MTL), 16 bytes per lane
-    const uint4* ksrc = reinterpret_cast<const uint4*>(g + c.P.o_mt);
-    uint4* kdst = reinterpret_cast<uint4*>(c.stage);
-    for (int q = wave * AIE_NT + c.tid; q < AIE_MT_N / 4; q += nwaves * AIE_NT) kdst[q] = ksrc[q];
-    return;
-  }
-  if (wave != 0) return;
+  if (wave != key_wave) return;
   const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
 #pragma unroll
   for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
@@ -492,44 +491,93 @@ __device__ __forceinline__ int rng_permutation(MT& m, int lane, int n) {
   }
   return p;
 }
-// ---- the same draws for the step kernel's components, with the CURRENT 624-word window of
-// the generator living in LDS (the observation staging area, free until the observations are
-// built) instead of 10 VGPRs: the serial component code is register-starved under the
-// 64-VGPR budget, and a draw becomes one LDS broadcast read.  The regeneration afterwards
-// takes the rows back into registers (mtl_to_regs) to twist them.
+// ---- the same draws for the step kernel's components.  The generator state (624 words) never enters LDS: the
+// wave that regenerates the resources afterwards holds it in 10 VGPRs from the record load on, and publishes the
+// next stage_window_words() TEMPERED words of the stream in a small LDS draw window for the wave that runs the
+// components (register-starved under the 64-VGPR budget): a draw is one LDS broadcast read per 64 draws plus a
+// v_readlane.  A step that draws past the window (many agents) or past word 623 refills it from the state in HBM
+// (rng_refill; a twist there writes the new state back, and the holder of the registers re-reads it).
 struct MTL {
-  uint32_t* w;  // LDS [624] raw (untempered) words of the current window
-  int pos;      // wave-uniform index of the next unused word (624 = twist first)
-  // 64 tempered words in a register (lane j: word cbase + j): a draw is a v_readlane, the LDS read and the
-  // tempering happen once per 64 draws (a step's components draw ~10-30 words)
+  uint32_t* w;  // LDS draw window: tempered words base ... base + avail - 1 of the generator's current window
+  int pos;      // wave-uniform index of the next unused word of the generator's window (624 = twist first)
+  // 64 words of the draw window in a register (lane j: word cbase + j): a draw is a v_readlane
   uint32_t cache;
   int cbase;
   // this step's changes to the maps, kept in registers until the components are done (-> c.dirty):
   int dn;             // cells appended to the change list
   uint32_t mv0, mv1;  // agents that moved
+  int base, avail;    // what the draw window holds
+  int tw;             // twists rng_refill performed this step (-> c.dirty[3])
+  uint32_t* gkey;     // the replica's generator state in HBM (record + o_mt)
+  int cap;            // capacity of the draw window in words
 };
-__device__ __forceinline__ void mtl_to_regs(const MTL& l, MT& m, int lane) {
+// Tempered words [pos, pos + avail) of the state in m -> w[0, avail); returns avail = min(cap, 624 - pos).
+__device__ __forceinline__ int draw_window_publish(uint32_t* w, int cap, const MT& m, int pos, int lane) {
+  const int avail = cap < AIE_MT_N - pos ? cap : AIE_MT_N - pos;
+  const int r0 = pos >> 6;
+  for (int d = 0; d * 64 < cap + 64; ++d) {  // lane l of row r holds word 64 r + l
+    const int r = r0 + d;
+    if (r > 9) break;
+    uint32_t v = m.r[0];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) m.r[j] = l.w[64 * j + lane];
-  m.r[9] = lane < 48 ? l.w[576 + lane] : 0u;
-  m.pos = l.pos;
+    for (int j = 1; j < 10; ++j) v = (r == j) ? m.r[j] : v;
+    const int slot = 64 * r + lane - pos;
+    if (slot >= 0 && slot < avail) w[slot] = mt_temper(v);
+  }
+  AIE_WSYNC();
+  return avail;
+}
+// The same from the state in HBM: only the rows the window covers are fetched (step start: the wave that will hold
+// the state later has nothing but the record copy to do, and the fetch rides behind it).
+__device__ __forceinline__ int draw_window_publish_from_hbm(uint32_t* w, int cap, const uint32_t* __restrict__ gkey, int pos,
+                                                            int lane) {
+  const int avail = cap < AIE_MT_N - pos ? cap : AIE_MT_N - pos;
+  const int r0 = pos >> 6;
+  for (int d = 0; d * 64 < cap + 64; ++d) {
+    const int r = r0 + d, i = 64 * r + lane;
+    if (r > 9) break;
+    const int slot = i - pos;
+    if (slot >= 0 && slot < avail) w[slot] = mt_temper(gkey[i]);  // (slot < avail implies i < 624)
+  }
+  return avail;
+}
+__device__ __forceinline__ void mt_rows_from_hbm(MT& m, const uint32_t* gkey, int lane) {
+  // agent-scope loads: the rows may have been rewritten by the other wave of the workgroup during this launch
+#pragma unroll
+  for (int j = 0; j < 9; ++j) m.r[j] = __hip_atomic_load(gkey + 64 * j + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  m.r[9] = lane < 48 ? __hip_atomic_load(gkey + 576 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
+struct Refill { int pos, avail, twisted; };
+// Out of line (rare: a step in ~30 crosses word 623 with 4 agents; steps with ~100 agents outrun the window): the
+// state comes from HBM -- the record's copy, or what an earlier refill of this step wrote back.
+__device__ __attribute__((noinline, cold)) Refill rng_refill(uint32_t* gkey, uint32_t* w, int cap, int pos, int lane) {
+  MT m;
+  mt_rows_from_hbm(m, gkey, lane);
+  int twisted = 0;
+  if (pos >= AIE_MT_N) {
+    mt_twist_body(m, lane);
+    pos = 0;
+    twisted = 1;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) __hip_atomic_store(gkey + 64 * j + lane, m.r[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < 48) __hip_atomic_store(gkey + 576 + lane, m.r[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int avail = draw_window_publish(w, cap, m, pos, lane);
+  return Refill{pos, avail, twisted};
 }
 __device__ __forceinline__ uint32_t rng_u32(MTL& l, int lane) {
-  if (l.pos >= AIE_MT_N) {  // rare inside the components: ~10 of a step's ~2510 words are drawn here
-    MT m;
-    mtl_to_regs(l, m, lane);
-    mt_twist(m, lane);
-#pragma unroll
-    for (int j = 0; j < 9; ++j) l.w[64 * j + lane] = m.r[j];
-    if (lane < 48) l.w[576 + lane] = m.r[9];
-    AIE_WSYNC();
-    l.pos = 0;
+  if (__builtin_expect(l.pos >= l.base + l.avail, 0)) {
+    const Refill r = rng_refill(l.gkey, l.w, l.cap, l.pos, lane);
+    l.pos = uni(r.pos);  // (a function's results come back in vector registers: keep the bookkeeping scalar)
+    l.base = l.pos;
+    l.avail = uni(r.avail);
+    l.tw += uni(r.twisted);
     l.cbase = -AIE_MT_N;
   }
   int k = l.pos - l.cbase;
-  if ((unsigned)k >= (unsigned)AIE_NT) {  // refill: words [pos, pos + 64) of the window
-    const int idx = l.pos + lane;
-    l.cache = mt_temper(l.w[idx < AIE_MT_N ? idx : AIE_MT_N - 1]);
+  if ((unsigned)k >= (unsigned)AIE_NT) {  // the next (up to) 64 words of the draw window
+    const int idx = l.pos - l.base + lane;
+    l.cache = l.w[idx < l.avail ? idx : l.avail - 1];
     l.cbase = l.pos;
     k = 0;
   }
@@ -1496,13 +1544,21 @@ __device__ __forceinline__ void scenario_step_regen_rows(const Ctx& c, MT& m) {
   }
 }
 
-// Sparse variant (the normal case: a few dozen source blocks): lane j owns source double
-// d_j and needs stream words pos+2*d_j, +1.  The state is advanced window by window (one
-// twist each); in every window the 624 raw words are dumped to LDS and each lane picks the
-// word(s) that fall into it.  ~800 instructions per step instead of ~2200.
-// win0_in_lds: the caller kept the current window's raw words in c.stage (MTL), so the first
-// window needs no dump.
-__device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool win0_in_lds = false) {
+// Sparse variant (the normal case: a few dozen source blocks): lane j owns source double d_j and needs stream words
+// pos+2*d_j, +1.  The state is advanced window by window (one twist each) in registers; in every window each lane
+// fetches the word(s) that fall into it straight from the row registers: one permute per row, the lane keeps the
+// one of its own row (word i of a window sits in row i >> 6, lane i & 63).  No LDS copy of the window.
+__device__ __forceinline__ uint32_t mt_window_word(const MT& m, int idx) {
+  const int row = idx >> 6, ln = idx & 63;
+  uint32_t v = 0;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t t = lane_get(m.r[r], ln);
+    v = (row == r) ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
   if (c.full && c.snap) {  // P.regen_general: the planes the reference convolves, before any of this step's respawns
     const int HW = c.P.HW, stride = (HW + 15) / 16 * 16;
     const uint8_t* cb = reinterpret_cast<const uint8_t*>(R_CELLS(c));
@@ -1521,7 +1577,6 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool wi
   }
   const int lane = c.tid;
   const int total = 4 * c.P.HW;
-  uint32_t* buf = reinterpret_cast<uint32_t*>(c.stage);
   const int pos0 = m.pos;  // <= 624
   const int nchunk = (S + AIE_NT - 1) / AIE_NT;
   int off_a[AIE_SRC_CAP / AIE_NT];
@@ -1534,33 +1589,24 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, bool wi
   }
   const int last_win = (pos0 + total - 1) / AIE_MT_N;
   for (int w = 0; w <= last_win; ++w) {
-    if (w > 0 && !(c.full && (c.P.dev_skip_mask & 65536))) mt_twist_body(m, lane);  // the hot site: inlined (4 twists per step)
+    if (w > 0) mt_twist_body(m, lane);  // the hot site: inlined (4 twists per step)
     const int lo = w * AIE_MT_N;
-    bool need = false;
-#pragma unroll
-    for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k)
-      if (k < nchunk) need |= (off_a[k] + 1 >= lo) && (off_a[k] < lo + AIE_MT_N);  // (uniform: the usual map lists < 64 draws)
-    if (__ballot(need) == 0) continue;
-    if (!(w == 0 && win0_in_lds)) {
-      AIE_WSYNC();
-#pragma unroll
-      for (int j = 0; j < 9; ++j) buf[64 * j + lane] = m.r[j];
-      if (lane < 48) buf[576 + lane] = m.r[9];
-      AIE_WSYNC();
-    }
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
-      if (k >= nchunk) continue;
+      if (k >= nchunk) continue;  // (uniform: the usual map lists < 64 draws)
       const int ia = off_a[k] - lo, ib = ia + 1;
-      if (ia >= 0 && ia < AIE_MT_N) wa[k] = buf[ia];
-      if (off_a[k] >= 0 && ib >= 0 && ib < AIE_MT_N) wb[k] = buf[ib];
+      const bool ha = ia >= 0 && ia < AIE_MT_N, hb = off_a[k] >= 0 && ib >= 0 && ib < AIE_MT_N;
+      if (__ballot(ha || hb) == 0) continue;
+      const uint32_t va = mt_window_word(m, ha ? ia : 0), vb = mt_window_word(m, hb ? ib : 0);
+      if (ha) wa[k] = va;
+      if (hb) wb[k] = vb;
     }
   }
   m.pos = pos0 + total - last_win * AIE_MT_N;
 #pragma unroll
   for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k)
     if (k < nchunk && off_a[k] >= 0) regen_cell(c, mt_temper(wa[k]), mt_temper(wb[k]), (off_a[k] - pos0) >> 1);
-  AIE_WSYNC();  // the dump area is the observation staging area
+  AIE_WSYNC();
 }
 
 // ------------------------------------------------------------------------------------
@@ -2071,10 +2117,6 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
 __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __restrict__ arena) {
   const aie_params& P = c.P;
   const int n = P.n, tid = c.tid, Pp = P.P;
-  // staged in the MT19937 window area of the staging buffer: free once this wave's regeneration
-  // is done (step kernel) / unused (reset kernel)
-  float* s_amask = c.stage;
-  float* s_pmask = s_amask + pad4(n * P.MA);
   const int skip = c.full ? P.dev_skip_mask : 0;
   if (skip & 512) return;
   if (tid < n) {
@@ -2105,17 +2147,25 @@ __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __rest
   AIE_WSYNC();
   // ---- masks: _generate_masks base_env.py:706-756 + flatten_masks base_agent.py:440-460,
   // planner PeriodicBracketTax.generate_masks redistribution.py:1025-1104 ----
-  if (!(skip & 512)) {
-    // Element m of the flattened mask means the same thing for every agent: one host-built
-    // (shift, mask, threshold) test against each agent's mask bits.
-    for (int m = tid; m < P.MA; m += AIE_NT) {
+  // Element m of the flattened mask means the same thing for every agent: one host-built (shift, mask, threshold)
+  // test against each agent's mask bits.  Written straight from registers: lane q owns elements 4q .. 4q + 3 of the
+  // replica's [n][MA] block (dword-aligned 16-byte stores).
+  {
+    float* dst = reinterpret_cast<float*>(arena + c.R.a_obs_a_mask) + (int64_t)c.e * n * P.MA;
+    const int count = n * P.MA;
+    auto elem = [&](int idx) -> float {
+      const int i = udiv(idx, P.MA, P.mg_MA), m = idx - i * P.MA;
       const uint32_t t = P.mask_test[m];  // host-built test for element m (aie_layout.h)
       const uint32_t sh = t & 31u, msk = (t >> 8) & 0xffu, thr = t >> 16;
-      for (int i = 0; i < n; ++i) {
-        const uint32_t mf = (uint32_t)c.mflags[i];
-        s_amask[i * P.MA + m] = ((mf >> sh) & msk) >= thr ? 1.0f : 0.0f;
-      }
+      return (((uint32_t)c.mflags[i] >> sh) & msk) >= thr ? 1.0f : 0.0f;
+    };
+    const int n4 = count >> 2;
+    for (int q = tid; q < n4; q += AIE_NT) {
+      f32x4_a4 o = {elem(4 * q), elem(4 * q + 1), elem(4 * q + 2), elem(4 * q + 3)};
+      reinterpret_cast<f32x4_a4*>(dst)[q] = o;
     }
+    for (int q = 4 * n4 + tid; q < count; q += AIE_NT) dst[q] = elem(q);
+    float* pdst = reinterpret_cast<float*>(arena + c.R.a_obs_p_mask) + (int64_t)c.e * P.MP;
     const bool pmulti = P.c.multi_action_mode_planner != 0;
     const float open = (P.n_sub_p && *R_I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
     for (int q = tid; q < P.MP; q += AIE_NT) {
@@ -2126,13 +2176,8 @@ __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __rest
       else if (q > 0) j = (q - 1) - udiv(q - 1, P.sub_p_dim, P.mg_sub_p_dim) * P.sub_p_dim;
       if (j < 0) v = 1.0f;
       else v = (open != 0.0f && tax_rate_action_visible(c, j)) ? 1.0f : 0.0f;
-      s_pmask[q] = v;
+      pdst[q] = v;
     }
-  }
-  AIE_WSYNC();
-  if (!(skip & 1024)) {
-    stream_out(s_amask, reinterpret_cast<float*>(arena + c.R.a_obs_a_mask) + (int64_t)c.e * n * P.MA, n * P.MA, tid);
-    stream_out(s_pmask, reinterpret_cast<float*>(arena + c.R.a_obs_p_mask) + (int64_t)c.e * P.MP, P.MP, tid);
   }
 }
 
@@ -2206,17 +2251,26 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     c.dirty[0] = 0;
     c.dirty[1] = 0;
     c.dirty[2] = 0;
+    c.dirty[3] = 0;
   }
   __syncthreads();
   if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
-  load_record(c, arena, m, wid, NW, /*key_to_lds=*/true);
+  uint8_t* grec = arena + R.a_records + (int64_t)c.e * P.rec_bytes;
+  uint32_t* gkey = reinterpret_cast<uint32_t*>(grec + P.o_mt);
+  MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0, 0u, -AIE_MT_N, 0, 0u, 0u, 0, 0, 0, gkey, stage_window_words(P)};
+  // the generator's position, ahead of the record: the last wave turns the words the components will draw into the
+  // LDS draw window while the record copy is in flight
+  int gpos = 0;
+  if (wid == NW - 1) gpos = *reinterpret_cast<const int32_t*>(grec + P.o_mt_pos);
+  load_record(c, arena, m, wid, NW, /*key_wave=*/-1);  // the generator state stays in HBM for now
+  if (wid == NW - 1) draw_window_publish_from_hbm(ml.w, ml.cap, gkey, uni(gpos), c.tid);
   if (wid == 0) decode_actions(c, A, act_a, act_p);
   __syncthreads();  // the record is in LDS
   if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
   if (NW == 1 || wid == 1) rebuild_locmap(c);
-  MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0, 0u, -AIE_MT_N, 0, 0u, 0u};
   if (wid == 0) {
-    ml.pos = uni(*R_I32(c, o_mt_pos));
+    ml.pos = ml.base = uni(*R_I32(c, o_mt_pos));
+    ml.avail = ml.cap < AIE_MT_N - ml.pos ? ml.cap : AIE_MT_N - ml.pos;  // what draw_window_publish_from_hbm left
     agents_load(c, A);
     if (P.has_cda && !(skip & 1)) cda_decay_price_history(c);
   }
@@ -2247,12 +2301,20 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       c.dirty[0] = ml.dn;
       c.dirty[1] = (int32_t)ml.mv0;
       c.dirty[2] = (int32_t)ml.mv1;
+      c.dirty[3] = ml.tw;
     }
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 5] = wall_clock64();
-  } else if (next.a || next.p) {
-    // the second wave has nothing to do until the components are done: next step's random actions
-    const int per_env = P.n * P.act_a_width + P.act_p_width;
-    for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, c.e, j, next.a, next.p);
+  } else {
+    // the second wave has nothing to do until the components are done: next step's random actions ...
+    if (next.a || next.p) {
+      const int per_env = P.n * P.act_a_width + P.act_p_width;
+      for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, c.e, j, next.a, next.p);
+    }
+    // ... and the generator state for the regeneration (rows -> registers; re-read below if the components twisted it)
+    const uint32_t* key = gkey;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
+    m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
   }
   __syncthreads();  // components done; the generator's window (LDS) and position are final
   if (wid == 0) {
@@ -2272,9 +2334,10 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     // second wave: resource regeneration (rows back into registers for the twists), then what
     // depends on the map: incremental map observations, action masks
     if (NW == 2) __builtin_amdgcn_s_setprio(2);  // from here on this wave is the critical one (the first has slack)
-    MTL mw{reinterpret_cast<uint32_t*>(c.stage), uni(*R_I32(c, o_mt_pos))};
-    mtl_to_regs(mw, m, c.tid);
-    if (!(skip & 2)) scenario_step_regen(c, m, /*win0_in_lds=*/true);
+    // a refill that twisted (components drew past word 623) left the new state in HBM
+    if (NW == 1 || uni(c.dirty[3]) != 0) mt_rows_from_hbm(m, gkey, c.tid);
+    m.pos = uni(*R_I32(c, o_mt_pos));
+    if (!(skip & 2)) scenario_step_regen(c, m);
     if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
     AIE_WSYNC();
