@@ -572,6 +572,18 @@ int aie_dev_set_lds_pad(aie_env* env, int bytes) {
   return AIE_OK;
 }
 
+// Development aid (not part of include/aie.h): a smaller draw window for the components (the environment then runs
+// aie_step_kernel_log), so that tests reach the refill path on every step.
+int aie_dev_set_draw_window(aie_env* env, int words) {
+  if (!env || words < 0) return AIE_E_INVALID;
+  env->P.dev_draw_window = words;
+  env->P.dev_skip_mask = words ? (env->P.dev_skip_mask | (1 << 20)) : (env->P.dev_skip_mask & ~(1 << 20));
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  AIE_HIP_CHECK(env, hipDeviceSynchronize());
+  AIE_HIP_CHECK(env, hipMemcpy(env->d_params, &env->P, sizeof(aie_params), hipMemcpyHostToDevice));
+  return AIE_OK;
+}
+
 // Development aid (not part of include/aie.h): phases of the step kernel to skip.
 int aie_dev_set_skip_mask(aie_env* env, int mask) {
   if (!env) return AIE_E_INVALID;

@@ -2258,6 +2258,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   uint8_t* grec = arena + R.a_records + (int64_t)c.e * P.rec_bytes;
   uint32_t* gkey = reinterpret_cast<uint32_t*>(grec + P.o_mt);
   MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0, 0u, -AIE_MT_N, 0, 0u, 0u, 0, 0, 0, gkey, stage_window_words(P)};
+  if (LOG && R.dev_draw_window > 0 && R.dev_draw_window < ml.cap) ml.cap = R.dev_draw_window;  // tests: force refills
   // the generator's position, ahead of the record: the last wave turns the words the components will draw into the
   // LDS draw window while the record copy is in flight
   int gpos = 0;

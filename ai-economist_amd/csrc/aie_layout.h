@@ -187,6 +187,8 @@ typedef struct aie_params {
   int64_t a_cv_obs_a;    /* float32 [E][cv_nrow_obs][n]                                    */
   int64_t a_cv_obs_p;    /* float32 [E][4 + 1 + NS]                                        */
   int32_t auto_reset;    /* run-time switch (aie_set_auto_reset): replicas restart inside the launch that ends their episode */
+  int32_t dev_draw_window; /* development (tests): capacity of the components' draw window in words, 0 = stage_window_words();
+                            * honoured by aie_step_kernel_log only */
 } aie_params;
 
 /* Compile-time instances of the step kernel (aie_spec_generated.h) bake a CONSTANT image of aie_params into the code;
@@ -208,6 +210,7 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->a_layout_prob = 0;
   p->dev_skip_mask = 0;
   p->dev_trace = 0;
+  p->dev_draw_window = 0;
   p->auto_reset = 0;
   memset(p->c.labor_skills, 0, sizeof(p->c.labor_skills));  /* SimpleLabor's skills are data, read from the run-time block */
 }

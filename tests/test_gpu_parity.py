@@ -732,6 +732,36 @@ def test_compile_time_instance_equals_generic_kernel(n_agents):
     del b_gen, b_other
 
 
+@pytest.mark.parametrize("words", [8, 64])
+def test_draw_window_refills_do_not_change_the_stream(words):
+    """The components draw from a small LDS window of tempered MT19937 words; running past it refills it from the
+    state in HBM (with a twist when word 623 is passed).  With the window cut down to `words` every step of a 10-agent
+    environment refills several times: the arena must stay bit-identical to the default window's."""
+    import ctypes
+
+    import torch
+
+    cfg = dict(C2, n_agents=10, episode_length=60)
+    ref, small = (make_env(cfg, n_envs=192, device="cuda:0") for _ in range(2))
+    for env in (ref, small):
+        env.seed(8)
+        env.reset()
+    lib = small.backend.lib
+    lib.aie_dev_set_draw_window.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert lib.aie_dev_set_draw_window(small.backend.handle, words) == 0
+    for t in range(130):  # two episode ends
+        a, p = ref.backend.sample_random_actions(seed=9)
+        ref.backend.step(a, p)
+        small.backend.step(a, p)
+        if t % 60 == 59:
+            ref.reset(ref.backend.tensors["done"])
+            small.reset(small.backend.tensors["done"])
+        if t in (0, 1, 2, 29, 59, 60, 129):
+            torch.cuda.synchronize()
+            for k in ref.backend.tensors:
+                assert torch.equal(ref.backend.tensors[k], small.backend.tensors[k]), "step %d: %s differs" % (t + 1, k)
+
+
 def test_compile_time_instance_equals_generic_kernel_one_step_economy():
     """BASELINE configs[4] (one-step-economy, 100 agents) has a compile-time instance too (SimpleLabor's skills are
     run-time data): instance vs generic kernel, bit for bit, across episode ends with and without auto-reset."""
