@@ -20,7 +20,6 @@ struct aie_env {
   bool owns_arena;
   int device;
   size_t lds;
-  int step_waves;  // wavefronts per replica in aie_step_kernel (2; 1 = original schedule)
   int spec;        // >= 0: the compile-time instance aie_step_kernel_spec<spec> runs this configuration; -1: generic
   int64_t sample_t;
   float* rew_log;        // aie_set_reward_log: caller's ring of n_slots step slots, or nullptr
@@ -87,7 +86,6 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
   int rc = aie_build_params(cfg, &env->P, &env->tt, g_create_err, sizeof(g_create_err));
   if (rc != AIE_OK) { delete env; return rc; }
   env->device = device;
-  env->step_waves = 2;
   env->spec = -1;
   if (cfg->scenario != AIE_SCN_COVID) {  // a compile-time instance exists for exactly this parameter block?
     static aie_params norm;
@@ -323,9 +321,9 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
 
 int aie_set_reward_log(aie_env* env, float* d_log, int32_t n_slots) {
   if (!env) return AIE_E_INVALID;
-  if (d_log && (n_slots < 1 || env->step_waves != 2)) {
-    snprintf(env->err, sizeof(env->err), "aie_set_reward_log: needs n_slots >= 1 and a gather-trade-build environment");
-    return d_log && n_slots < 1 ? AIE_E_INVALID : AIE_E_UNSUPPORTED;
+  if (d_log && n_slots < 1) {
+    snprintf(env->err, sizeof(env->err), "aie_set_reward_log: needs n_slots >= 1");
+    return AIE_E_INVALID;
   }
   env->rew_log = d_log;
   env->rew_log_slots = d_log ? n_slots : 0;
@@ -343,11 +341,6 @@ int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t
   if ((d_next_a && d_next_a == d_actions_a) || (d_next_p && d_next_p == d_actions_p)) {
     snprintf(env->err, sizeof(env->err), "aie_step_sample_next: the next-action buffers must differ from the current ones");
     return AIE_E_INVALID;
-  }
-  if (env->step_waves != 2) {  // development schedule without the fused draw: two launches
-    int rc = aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{nullptr, nullptr, 0, 0, 0, nullptr});
-    if (rc != AIE_OK) return rc;
-    return aie_sample_random_actions(env, seed, global_env_offset, d_next_a, d_next_p, stream);
   }
   const NextActions next{d_next_a, d_next_p, seed, global_env_offset, env->sample_t, nullptr};
   env->sample_t += 1;
@@ -392,7 +385,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
-  else if (env->step_waves == 2 && env->spec >= 0 && env->P.dev_trace != nullptr && env->P.dev_skip_mask == 0) {
+  else if (env->spec >= 0 && env->P.dev_trace != nullptr && env->P.dev_skip_mask == 0) {
     const dim3 g((unsigned)env->P.E), b(2 * AIE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define AIE_SPEC_LAUNCH_TR(K) \
@@ -402,11 +395,11 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
       default: return AIE_E_INVALID;
     }
 #undef AIE_SPEC_LAUNCH_TR
-  } else if (env->step_waves == 2 && (env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT || env->P.regen_general ||
+  } else if ((env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT || env->P.regen_general ||
                                     env->P.dev_skip_mask != 0 || env->P.dev_trace != nullptr))
     hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
-  else if (env->step_waves == 2 && env->spec >= 0) {
+  else if (env->spec >= 0) {
     const dim3 g((unsigned)env->P.E), b(2 * AIE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define AIE_SPEC_LAUNCH(K) \
@@ -416,15 +409,12 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
       default: return AIE_E_INVALID;
     }
 #undef AIE_SPEC_LAUNCH
-  } else if (env->step_waves == 2 && aie_workgroups_per_cu(env->lds) <= 12)
+  } else if (aie_workgroups_per_cu(env->lds) <= 12)
     hipLaunchKernelGGL(aie_step_kernel_r6, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
-  else if (env->step_waves == 2)
+  else
     hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
-  else
-    hipLaunchKernelGGL(aie_step_kernel_w1, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds,
-                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p);
   if (env->P.auto_reset && env->P.c.scenario != AIE_SCN_ONE_STEP_ECONOMY) {
     // auto-reset: the replicas this step finished restart right behind it on the same stream (mask = the `done`
     // tensor the step just wrote; the reset keeps the terminal rewards / done).  one-step-economy does it inside the
@@ -545,13 +535,6 @@ int aie_dev_lds_bytes(aie_env* env, int64_t* out) {
   out[2] = env->P.HW;
   out[3] = env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY || env->P.c.scenario == AIE_SCN_COVID ? 0 : (int64_t)aie::fscr_doubles(env->P) * 8;
   out[4] = env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY || env->P.c.scenario == AIE_SCN_COVID ? 0 : (int64_t)aie::stage_bytes(env->P);
-  return AIE_OK;
-}
-
-// Development aid (not part of include/aie.h): wavefronts per replica of the step kernel.
-int aie_dev_set_step_waves(aie_env* env, int waves) {
-  if (!env || (waves != 1 && waves != 2)) return AIE_E_INVALID;
-  env->step_waves = waves;
   return AIE_OK;
 }
 

@@ -2397,12 +2397,6 @@ aie_step_kernel_spec_trace(const aie_params* __restrict__ params, uint8_t* __res
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   step_body<2, false, SPEC, true>(params, arena, act_a, act_p, lds, next);
 }
-extern "C" __global__ void __launch_bounds__(AIE_NT)
-aie_step_kernel_w1(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                   const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  step_body<1, true>(params, arena, act_a, act_p, lds, NextActions{nullptr, nullptr, 0, 0, 0, nullptr});
-}
 
 namespace aie {
 // LDS the layout generator needs behind the reset kernel's regular regions: two f64 planes + two byte planes + the
