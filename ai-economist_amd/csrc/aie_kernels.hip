@@ -2401,10 +2401,103 @@ aie_step_kernel_spec_trace(const aie_params* __restrict__ params, uint8_t* __res
 namespace aie {
 // LDS the layout generator needs behind the reset kernel's regular regions: two f64 planes + two byte planes + the
 // multi_zone region grid
+// ---- lane-parallel reads of the stream (reset-time layout generation): lane l wants the words at stream offsets
+// o_l .. relative to the START of the generator's current window, up to one window ahead.  `nxt` is the twisted copy
+// of `cur` (valid iff have_nxt); consuming words moves `cur.pos`, and the windows shift when it passes 624.
+struct MT2 {
+  MT cur, nxt;
+  bool have_nxt;
+};
+__device__ __forceinline__ void mt2_need_next(MT2& s, int lane) {
+  if (s.have_nxt) return;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) s.nxt.r[j] = s.cur.r[j];
+  mt_twist(s.nxt, lane);
+  s.have_nxt = true;
+}
+__device__ __forceinline__ uint32_t mt2_word(const MT2& s, int o) {  // tempered word at offset o (per lane), o < 1248
+  const bool second = o >= AIE_MT_N;
+  const int i = second ? o - AIE_MT_N : o;
+  const uint32_t a = mt_window_word(s.cur, i), b = mt_window_word(s.nxt, i);
+  return mt_temper(second ? b : a);
+}
+__device__ __forceinline__ void mt2_consume(MT2& s, int nwords, int lane) {  // nwords <= 624
+  s.cur.pos += nwords;
+  if (s.cur.pos >= AIE_MT_N) {
+    mt2_need_next(s, lane);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) s.cur.r[j] = s.nxt.r[j];
+    s.cur.pos -= AIE_MT_N;
+    s.have_nxt = false;
+  }
+}
+// tmp[0 .. count) = rs.rand(count): 64 doubles per pass, lane l takes words pos + 2 l, + 1
+__device__ __forceinline__ void mt2_rand_plane(MT2& s, double* out, int count, int lane) {
+  for (int base = 0; base < count; base += AIE_NT) {
+    const int nb = count - base < AIE_NT ? count - base : AIE_NT;
+    if (s.cur.pos + 2 * nb > AIE_MT_N) mt2_need_next(s, lane);
+    const int o = s.cur.pos + 2 * lane;
+    const uint32_t a = mt2_word(s, lane < nb ? o : s.cur.pos), b = mt2_word(s, lane < nb ? o + 1 : s.cur.pos);
+    if (lane < nb) out[base + lane] = u53(a, b);
+    mt2_consume(s, 2 * nb, lane);
+  }
+}
+// The next `count` values of legacy_gauss (polar Box-Muller with a one-value cache, as rng_gauss): emit(k, value) is
+// called once for k = 0 .. count - 1, from the lane that owns the value.  64 attempts per pass: attempt a reads the
+// four words at pos + 4 a; its acceptance does not depend on the others, so the pass evaluates all of them, ranks
+// the accepted ones with a ballot and stops behind the attempt that completes the request; an accepted attempt
+// yields f * x2 and then (cached) f * x1.
+template <typename Emit>
+__device__ __forceinline__ void mt2_gauss(const Ctx& c, MT2& s, int count, int lane, Emit emit) {
+  int32_t* has = R_I32(c, o_mt_has_gauss);
+  double* cache = R_F64(c, o_mt_gauss);
+  int produced = 0;
+  if (count > 0 && uni(*has)) {
+    if (lane == 0) {
+      emit(0, *cache);
+      *has = 0;
+      *cache = 0.0;
+    }
+    AIE_WSYNC();
+    produced = 1;
+  }
+  while (produced < count) {
+    const int pairs = (count - produced + 1) >> 1;  // accepted attempts still needed
+    if (s.cur.pos + 4 * AIE_NT > AIE_MT_N) mt2_need_next(s, lane);
+    const int o = s.cur.pos + 4 * lane;
+    const double x1 = 2.0 * u53(mt2_word(s, o), mt2_word(s, o + 1)) - 1.0;
+    const double x2 = 2.0 * u53(mt2_word(s, o + 2), mt2_word(s, o + 3)) - 1.0;
+    const double r2 = x1 * x1 + x2 * x2;
+    const bool acc = !(r2 >= 1.0 || r2 == 0.0);
+    const uint64_t am = __ballot(acc);
+    const int rank = __popcll(am & lanemask_lt(lane));
+    int used = AIE_NT;  // attempts consumed by this pass
+    if (__popcll(am) >= pairs) {  // the attempt holding the pairs-th set bit ends the request
+      uint64_t t = am;
+      for (int k = 1; k < pairs; ++k) t &= t - 1;
+      used = __ffsll((unsigned long long)t);
+    }
+    if (acc && lane < used) {
+      const double f = sqrt(-2.0 * aie_log_glibc(r2) / r2);  // libm's log bit for bit; sqrt and / are IEEE-exact
+      const int k = produced + 2 * rank;
+      emit(k, f * x2);
+      if (k + 1 < count) emit(k + 1, f * x1);
+      else {  // the request ends on the first value of the pair: the second one stays cached
+        *cache = f * x1;
+        *has = 1;
+      }
+    }
+    AIE_WSYNC();
+    const int got = 2 * __popcll(am & (used >= 64 ? ~0ull : ((1ull << used) - 1ull)));
+    produced += got;  // (may exceed count by one: the cached value)
+    mt2_consume(s, 4 * used, lane);
+  }
+}
+
 __host__ __device__ inline size_t layout_gen_lds_bytes(const aie_params& P) {
   if (P.c.layout_gen == AIE_LAYOUT_FIXED) return 0;
   const size_t hwp = ((size_t)P.HW + 15) / 16 * 16;
-  return 2 * hwp * 8 + 2 * hwp + 256 * 4;
+  return 2 * hwp * 8 + 2 * hwp + 256 * 4 + 16;  // tmp, x (f64), two byte planes, the zone grid, the kernel's sign bits
 }
 
 // Source layouts drawn at reset from the replica's own stream: Uniform.reset_starting_layout (dynamic_layout.py:313-392),
@@ -2470,6 +2563,12 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
     }
     return v * 0.1 * clump;
   };
+  uint32_t* kbits = reinterpret_cast<uint32_t*>(grid) + 256;  // two words behind the zone grid
+  MT2 s2;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) s2.cur.r[j] = m.r[j];
+  s2.cur.pos = m.pos;
+  s2.have_nxt = false;
   bool happy = false;
   for (int tries = 0; tries < 100 && !happy; ++tries) {
     for (int q = 0; q < 2; ++q) {
@@ -2477,10 +2576,7 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
       const double cov = g.layout_coverage[rs], clump = g.layout_clump[rs];
       uint8_t* mb = mbp[rs];
       const uint8_t* other = q == 0 ? nullptr : mbp[1];  // empty = nothing placed on the tile yet
-      for (int cell = 0; cell < HW; ++cell) {  // tmp = rs.rand(H, W)
-        const double u = rng_double(m, lane);
-        if (lane == (cell & 63)) tmp[cell] = u;
-      }
+      mt2_rand_plane(s2, tmp, HW, lane);  // tmp = rs.rand(H, W)
       AIE_WSYNC();
       int count = 0;
       for (int base = 0; base < HW; base += AIE_NT) {
@@ -2510,13 +2606,19 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
       }
       AIE_WSYNC();
       while ((double)count / (double)HW < cov) {
-        uint64_t kmask = 0;  // kernel = rs.randn(7, 7) > 0, row-major
-        for (int k = 0; k < 49; ++k) kmask |= (rng_gauss(c, m) > 0 ? 1ull : 0ull) << k;
-        for (int cell = 0; cell < HW; ++cell) {  // maybe + 0.2 * rs.randn(H, W) - 0.25
-          const double gs = rng_gauss(c, m);
-          if (lane == (cell & 63)) x[cell] = ((double)mb[cell] + (0.2 * gs)) - 0.25;
-        }
+        // kernel = rs.randn(7, 7) > 0 (row-major), then maybe + 0.2 * rs.randn(H, W) - 0.25: one request of 49 + HW values
+        if (lane < 2) kbits[lane] = 0;
         AIE_WSYNC();
+        mt2_gauss(c, s2, 49 + HW, lane, [&](int k, double gs) {
+          if (k < 49) {
+            if (gs > 0) atomicOr(&kbits[k >> 5], 1u << (k & 31));
+          } else {
+            const int cell = k - 49;
+            x[cell] = ((double)mb[cell] + (0.2 * gs)) - 0.25;
+          }
+        });
+        AIE_WSYNC();
+        const uint64_t kmask = (uint64_t)kbits[0] | ((uint64_t)kbits[1] << 32);
         count = 0;
         for (int base = 0; base < HW; base += AIE_NT) {
           const int cell = base + lane;
@@ -2553,6 +2655,9 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
       if (!((1 / 1.4) <= ratio && ratio <= 1.4)) happy = false;
     }
   }
+#pragma unroll
+  for (int j = 0; j < 10; ++j) m.r[j] = s2.cur.r[j];
+  m.pos = s2.cur.pos;
   uint8_t* cb = reinterpret_cast<uint8_t*>(R_CELLS(c));
   for (int cell = lane; cell < HW; cell += AIE_NT) {
     const int r = cell / W, col = cell - r * W;
