@@ -76,7 +76,14 @@ def _c4_cfg():
 
 # name -> (description, cfg builder, replicas per GPU, SURVEY 8(d) B_alg per unit, units per replica-step,
 #          kernel, counted agents)
+C1_CFG = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=4, world_size=[15, 15], episode_length=1000,
+              components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10, starting_stone_coverage=0.10,
+              starting_wood_coverage=0.10)
 WORKLOADS = {
+    "C1": dict(desc="BASELINE configs[0]'s scenario batched: uniform/simple_wood_and_stone 15x15, 4 agents + planner, "
+                    "Build+Gather (no auction, no taxes), episode_length 1000; every reset draws a new source layout on "
+                    "the device",
+               cfg=lambda: dict(C1_CFG), envs=4096, survey_bytes=5303.0, kernel="aie_step_kernel"),
     "C2": dict(desc="BASELINE configs[1]: gather-trade-build 25x25 quadrant layout, 4 agents + planner, Build+"
                     "ContinuousDoubleAuction(max_num_orders=5)+Gather+PeriodicBracketTax, episode_length 1000",
                cfg=lambda: dict(C2_CFG), envs=4096, survey_bytes=10984.0, kernel="aie_step_kernel"),
@@ -464,7 +471,8 @@ def main():
                  "the map observations stay in place and only changed cells are rewritten, hence traffic < algorithmic")
         agent_steps = world * E * n * args.steps
         out = {
-            "metric": "agent-steps/sec, %s" % {"C2": "gather-trade-build 25x25 4-agent batched envs",
+            "metric": "agent-steps/sec, %s" % {"C1": "simple_wood_and_stone 15x15 4-agent Gather+Build batched envs",
+                                                "C2": "gather-trade-build 25x25 4-agent batched envs",
                                                 "C3": "gather-trade-build 25x25 10-agent batched envs",
                                                 "C4": "covid19_env 51 US-state agents + planner",
                                                 "C5": "one_step_economy 100 agents + SimpleLabor + planner tax"}[wl],
@@ -506,7 +514,7 @@ def main():
                 ref = cpu_reference_baseline(cfg)
             except Exception as exc:  # the reference leg must not take the GPU line down
                 out["cpu_baseline_error"] = repr(exc)
-            if wl in ("C2", "C3"):
+            if wl in ("C1", "C2", "C3"):
                 port = cpu_port_baseline(cfg)
                 if ref is not None:
                     out["cpu_baseline"], out["cpu_port"] = ref, port
