@@ -678,7 +678,12 @@ def test_error_flags_for_what_the_reference_raises():
         env.step({"0": 3, "1": 0, "p": [0] * 7})
 
 
-@pytest.mark.parametrize("n_agents", [4, 10])
+C1_INSTANCE = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=4, world_size=[15, 15], episode_length=1000,
+                   components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10, starting_stone_coverage=0.10,
+                   starting_wood_coverage=0.10)
+
+
+@pytest.mark.parametrize("n_agents", [4, 10, "c1"])
 def test_compile_time_instance_equals_generic_kernel(n_agents):
     """BASELINE configs[1] / [2] run on a compile-time instance of the step kernel (aie_spec_generated.h: the parameter
     block folded into the code); the generic kernel on the same replicas must produce the same arena, bit for bit."""
@@ -686,8 +691,9 @@ def test_compile_time_instance_equals_generic_kernel(n_agents):
 
     import torch
 
-    cfg = dict(C2, n_agents=n_agents, episode_length=150)
-    cfg_spec = dict(C2, n_agents=n_agents)
+    base = dict(C1_INSTANCE) if n_agents == "c1" else dict(C2, n_agents=n_agents)
+    cfg = dict(base, episode_length=150)
+    cfg_spec = dict(base)
     env_s = make_env(cfg_spec, n_envs=8, device="cuda:0")
     k_inst = env_s.backend.lib.aie_step_kernel_instance(env_s.backend.handle)
     assert k_inst >= 0, "no compile-time instance selected"
