@@ -80,6 +80,10 @@ class BaseEnvironment:
         self._dense_logger = None
         self._dense_log = {"world": [], "states": [], "actions": [], "rewards": []}
         self._last_ep_dense_log = dict(self._dense_log)
+        # replay log of the logged replica (base_env.py:359-360, 445-471): the RNG state at reset and before every
+        # step plus the actions -- recorded for the episodes that are dense-logged (a per-step device read)
+        self._replay_log = {"reset": dict(seed_state=None), "step": []}
+        self._last_ep_replay_log = dict(self._replay_log)
         self.collate_agent_step_and_reset_data = True
         self.n_envs = int(n_envs)
         assert self.n_envs >= 1
@@ -270,7 +274,43 @@ class BaseEnvironment:
                                   for key, off, size, scalar in tab["pa"]}
         return out
 
-    def reset(self, env_mask=None, force_dense_logging=False):
+    # ---- RNG state of one replica in np.random.get_state() form (reset / step(seed_state=...), replay logs) ----
+    def rng_state(self, e=0):
+        t = self.backend.tensors
+        if "mt" not in t:  # a scenario without random draws
+            return None
+        return ("MT19937", t["mt"][e].cpu().numpy().view(np.uint32).copy(), int(t["mt_pos"][e].item()),
+                int(t["mt_has_gauss"][e].item()), float(t["mt_gauss"][e].item()))
+
+    def set_replica_rng_state(self, seed_state, e=0):
+        """base_env.py:871-881 / 968-978 for replica e."""
+        import torch
+
+        assert isinstance(seed_state, (tuple, list))
+        assert len(seed_state) == 5
+        t = self.backend.tensors
+        if "mt" not in t:
+            return
+        key = np.array(seed_state[1], dtype=np.uint32)
+        assert key.shape == (624,) and str(seed_state[0]) == "MT19937"
+        t["mt"][e].copy_(torch.from_numpy(key.view(np.int32).copy()))
+        t["mt_pos"][e] = int(seed_state[2])
+        t["mt_has_gauss"][e] = int(seed_state[3])
+        t["mt_gauss"][e] = float(seed_state[4])
+
+    @property
+    def replay_log(self):
+        """The (possibly still growing) replay log of the logged replica's current episode."""
+        return self._replay_log
+
+    @property
+    def previous_episode_replay_log(self):
+        """Replay log of the logged replica's most recent completed, logged episode: feeding
+        `reset(force_dense_logging=True, **log["reset"])` and `step(**s) for s in log["step"]` to a one-replica
+        environment reproduces the episode (base_env.py:455-471)."""
+        return self._last_ep_replay_log
+
+    def reset(self, env_mask=None, force_dense_logging=False, seed_state=None):
         """Resets all replicas (or those selected by the uint8/bool device tensor
         `env_mask`, e.g. the `done` tensor) and returns batched observations.
         force_dense_logging: log the coming episode of replica 0 even if it is not one of the
@@ -289,10 +329,15 @@ class BaseEnvironment:
             self._last_ep_metrics = {k: np.array(v, copy=True) for k, v in self.metrics.items()}
         log_replica_resets = self._create_dense_log_every is not None and (
             env_mask is None or bool(env_mask[0].item()))
+        if seed_state is not None:  # the logged replica's stream, before the reset draws from it
+            self.set_replica_rng_state(seed_state, 0)
         if log_replica_resets:
             # completed episodes of the logged replica, before this reset (base_env.py:885-891)
             done_eps = int(self.backend.tensors["completions"][0].item()) if self._backend is not None else 0
             self._dense_log_this_episode = bool(force_dense_logging) or done_eps % self._create_dense_log_every == 0
+        if log_replica_resets:
+            self._replay_log = {"reset": dict(seed_state=self.rng_state(0) if self._dense_log_this_episode else None),
+                                "step": []}
         self.host_pre_reset(env_mask)
         self.backend.reset(env_mask)
         if log_replica_resets:
@@ -344,13 +389,37 @@ class BaseEnvironment:
         random layout per episode).  Default: nothing."""
         return None
 
-    def step(self, actions=None):
+    def _from_reference_actions(self, actions):
+        """A reference-style {"0": action or [sub-actions], ..., "p": ...} dictionary (base_env.py:929-945) as the
+        batched tensors of a ONE-replica environment; missing actors do nothing."""
+        import torch
+
+        be = self.backend
+        wa, wp = be.act_a_numel // self.n_agents, max(1, be.act_p_numel)  # (one replica)
+        a = np.zeros((1, self.n_agents, wa), np.int32)
+        p = np.zeros((1, wp), np.int32)
+        for k, v in actions.items():
+            v = np.asarray(v, np.int32).reshape(-1)
+            if str(k) == "p":
+                p[0, :v.size] = v
+            else:
+                a[0, int(k), :v.size] = v
+        return torch.from_numpy(a).to(be.device), torch.from_numpy(p).to(be.device)
+
+    def step(self, actions=None, seed_state=None):
         """actions: None (all NO-OP), or {"a": int32 [E, n_agents(, n_subspaces)],
-        "p": int32 [E, n_planner_subspaces]} device tensors.  Returns the batched
-        (obs, rew, done, info) of base_env.py:929-1032."""
+        "p": int32 [E, n_planner_subspaces]} device tensors; a one-replica environment also takes the reference's
+        per-actor dictionary.  seed_state: RNG state to give replica 0 before the step (base_env.py:968-978).
+        Returns the batched (obs, rew, done, info) of base_env.py:929-1032."""
         a = p = None
+        if seed_state is not None:
+            self.set_replica_rng_state(seed_state, 0)
         if actions is not None:
             assert isinstance(actions, dict)
+            if self.n_envs == 1 and actions and all(str(k) == "p" or str(k).isdigit() for k in actions) and (
+                    any(str(k).isdigit() for k in actions) or not hasattr(actions.get("p"), "data_ptr")):
+                a, p = self._from_reference_actions(actions)
+                actions = {"a": a, "p": p}
             unknown = [k for k in actions if k not in ("a", "p")]
             if unknown:
                 # a reference-style {"0": 3, "1": 0, ..., "p": [...]} dict would silently turn into NO-OPs
@@ -361,12 +430,15 @@ class BaseEnvironment:
         logging = self._dense_log_this_episode and self._dense_logger is not None
         if logging:
             self._dense_logger.before_step(a, p)
+            self._replay_log["step"].append(dict(actions=self._dense_logger.reference_actions(a, p),
+                                                 seed_state=self.rng_state(0)))
         self.backend.step(a, p)
         t = self.backend.tensors
         if logging:
             self._dense_logger.after_step()
             if bool(t["done"][0].item()):  # _finalize_logs, base_env.py:763-814
                 self._last_ep_dense_log = self._dense_logger.finalize()
+                self._last_ep_replay_log = self._replay_log
                 self._dense_log_this_episode = False
         rew = {"a": t["rewards_a"], "p": t["rewards_p"]}
         done = {"__all__": t["done"]}

@@ -116,6 +116,24 @@ class DenseLogger:
         acts["p"] = self._decode(self.names_p, p, env.multi_action_mode_planner)
         self.log["actions"].append(acts)
 
+    def reference_actions(self, actions_a, actions_p):
+        """The logged replica's actions as the dictionary the reference's step() takes: {"0": index or list of
+        sub-action indices, ..., "p": ...}."""
+        env, e = self.env, self.e
+        out = {}
+        a = None if actions_a is None else actions_a[e].cpu().numpy().reshape(env.n_agents, -1)
+        p = None if actions_p is None else actions_p[e].cpu().numpy().reshape(-1)
+        for i in range(env.n_agents):
+            if a is None:
+                out[str(i)] = 0
+            else:
+                out[str(i)] = [int(x) for x in a[i]] if env.multi_action_mode_agents else int(a[i, 0])
+        if p is None:
+            out["p"] = 0
+        else:
+            out["p"] = [int(x) for x in p] if env.multi_action_mode_planner else int(p[0])
+        return out
+
     @staticmethod
     def _decode(names, vec, multi):
         """{subspace name: chosen index > 0} (base_agent.py:97-114, 407-438)."""

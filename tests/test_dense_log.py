@@ -159,6 +159,68 @@ def test_dense_log_matches_live_reference(case):
             np.testing.assert_allclose(g, float(v), rtol=1e-9, atol=1e-12, err_msg=k)
 
 
+class ReplayOracleBackend(OracleBackend):
+    """OracleBackend plus what replaying needs: the generator state as (int32-bit) tensors sharing the oracle's
+    memory, and the action-buffer geometry of a one-replica DeviceBackend."""
+
+    def __init__(self, oracle, env):
+        import torch
+
+        super().__init__(oracle)
+        self.tensors["mt"] = torch.from_numpy(oracle.t["mt"].view(np.int32))
+        self.E, self.n, self.device = 1, env.n_agents, torch.device("cpu")
+        names_a, names_p = env.action_subspace_names()
+        self.act_a_numel = env.n_agents * (len(names_a) if env.multi_action_mode_agents else 1)
+        self.act_p_numel = max(1, len(names_p)) if env.multi_action_mode_planner else 1
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("case", ["gtb_5ag", "gtb_multi_action_fixed_tax"])
+def test_replay_log_reproduces_reference_episode(case):
+    """base_env.py:455-471: an episode is reproduced from its replay log (RNG state at reset and before every step +
+    the actions).  The reference's replay log of a random episode, fed to a one-replica environment through
+    reset(force_dense_logging=True, **log["reset"]) / step(**entry), gives the reference's dense log; and the replay
+    log that environment records itself equals the one it was fed."""
+    from helpers import oracle_host_pre_reset
+    from oracle_lib import OracleEnv
+    from test_oracle_vs_reference import _ref_env
+
+    cfg = dict(CASES[case])
+    np.random.seed(5)
+    ref = _ref_env(cfg)
+    host = make_env(cfg)
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    host._backend = ReplayOracleBackend(o, host)
+    host.host_pre_reset = lambda mask: oracle_host_pre_reset(host, o)
+    rng = np.random.RandomState(11)
+    np.random.seed(123)
+    ref.reset(force_dense_logging=True)
+    for t in range(cfg["episode_length"]):
+        a, p = _random_action_arrays(host, rng)
+        _, _, done, _ = ref.step(_as_ref_actions(host, a, p))
+    assert done["__all__"]
+    want_log, replay = ref.previous_episode_dense_log, ref.previous_episode_replay_log
+    assert len(replay["step"]) == cfg["episode_length"]
+
+    host.reset(force_dense_logging=True, **replay["reset"])
+    for entry in replay["step"]:
+        host.step(**entry)
+    assert bool(o.t["done"][0])
+    assert_logs_equal(host.previous_episode_dense_log, want_log)
+    got = host.previous_episode_replay_log
+
+    def same_state(x, y):
+        return (str(x[0]) == str(y[0]) and np.array_equal(np.asarray(x[1], np.uint32), np.asarray(y[1], np.uint32))
+                and int(x[2]) == int(y[2]) and int(x[3]) == int(y[3]) and float(x[4]) == float(y[4]))
+
+    assert same_state(got["reset"]["seed_state"], replay["reset"]["seed_state"])
+    assert len(got["step"]) == len(replay["step"])
+    for g, w in zip(got["step"], replay["step"]):
+        assert same_state(g["seed_state"], w["seed_state"])
+        assert {k: (list(v) if isinstance(v, (list, tuple, np.ndarray)) else int(v)) for k, v in g["actions"].items()} == \
+            {str(k): (list(v) if isinstance(v, (list, tuple, np.ndarray)) else int(v)) for k, v in w["actions"].items()}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_hip_dense_log_matches_oracle(case):
@@ -197,6 +259,33 @@ def test_hip_dense_log_matches_oracle(case):
                                            np.ascontiguousarray(want[:, 10:]).view(np.float64), rtol=1e-9, atol=1e-9)
         assert bool(be.tensors["done"][0])
         assert_logs_equal(env.previous_episode_dense_log, twin.previous_episode_dense_log, tol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_replay_log_reproduces_the_logged_replica():
+    """Replica 0 of a 6-replica batch is dense-logged; its replay log, fed to a fresh ONE-replica environment (the
+    reference's per-actor action dictionaries, seed states injected), reproduces its dense log and metrics."""
+    import torch
+
+    cfg = dict(CASES["gtb_5ag"])
+    env = make_env(cfg, n_envs=6, device="cuda:0", track_episode_metrics=True)
+    env.seed(19)
+    env.reset(force_dense_logging=True)
+    rng = np.random.RandomState(2)
+    for t in range(cfg["episode_length"]):
+        acts = [_random_action_arrays(env, rng) for _ in range(6)]
+        a = torch.from_numpy(np.stack([x[0] for x in acts])).to("cuda:0")
+        p = torch.from_numpy(np.stack([x[1] for x in acts])).to("cuda:0")
+        env.step({"a": a, "p": p})
+    want, replay = env.previous_episode_dense_log, env.previous_episode_replay_log
+    assert len(replay["step"]) == cfg["episode_length"] and replay["reset"]["seed_state"] is not None
+
+    one = make_env(cfg, n_envs=1, device="cuda:0")
+    one.seed(1234)  # irrelevant: every draw of the episode comes from the injected states
+    one.reset(force_dense_logging=True, **replay["reset"])
+    for entry in replay["step"]:
+        one.step(**entry)
+    assert_logs_equal(one.previous_episode_dense_log, want)
 
 
 def test_episode_log_file_round_trip(tmp_path, monkeypatch):
