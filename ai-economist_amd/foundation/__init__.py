@@ -20,7 +20,13 @@ from . import utils  # save_episode_log / load_episode_log (F/utils.py)
 from .scenarios import scenario_registry as scenarios
 
 
-def make_env_instance(scenario_name, **kwargs):
-    """Looks the scenario up by name and constructs it (F/__init__.py:16-18)."""
+def make_env_instance(scenario_name, reference_format=False, **kwargs):
+    """Looks the scenario up by name and constructs it (F/__init__.py:16-18).
+    reference_format=True: a one-replica environment behind the reference's single-environment surface (per-actor
+    dictionaries, env.world.agents, ...; foundation/reference_view.py) instead of the batched one."""
     scenario_class = scenarios.get(scenario_name)
+    if reference_format:
+        from .reference_view import ReferenceFormatEnv
+
+        return ReferenceFormatEnv(scenario_class(**dict(kwargs, n_envs=1)))
     return scenario_class(**kwargs)
