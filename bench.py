@@ -522,7 +522,13 @@ def main():
                     out["cpu_baseline"] = port
             elif ref is not None:
                 out["cpu_baseline"] = ref
-        print(json.dumps(out))
+        try:  # whatever native libraries (RCCL's version banner) left in the C stdio buffer goes out first, so that
+            import ctypes  # the JSON line is the last line on stdout
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
