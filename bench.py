@@ -442,6 +442,16 @@ def main():
         torch.distributed.all_gather(allt, tt)
         per_rank = [float(x.item()) for x in allt]
         elapsed = max(per_rank)
+        # every rank empties its native stdio buffers (RCCL's version banner) before rank 0 prints the JSON line, so
+        # that nothing follows it on the job's stdout
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        torch.distributed.barrier()
 
     if rank == 0:
         region_ms = ev0.elapsed_time(ev1)
