@@ -300,6 +300,23 @@ int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos) {
   return aie_upload(env, "mt_gauss", zd.data(), E * 8);
 }
 
+// gather-trade-build reset: the compile-time instance of the environment's configuration if it has one
+static void aie_launch_gtb_reset(aie_env* env, const uint8_t* d_mask, int keep_rewards, void* stream) {
+  const dim3 g((unsigned)env->P.E), b(AIE_NT);
+  const size_t lds = env->lds + aie::layout_gen_lds_bytes(env->P);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define AIE_SPEC_LAUNCH_RESET(K) \
+  case K: hipLaunchKernelGGL(aie_reset_kernel_spec<K>, g, b, lds, st, env->d_params, env->arena, d_mask, keep_rewards); return;
+  if (env->spec >= 0 && env->P.dev_skip_mask == 0) {
+    switch (env->spec) {
+      AIE_SPEC_LIST_GTB(AIE_SPEC_LAUNCH_RESET)
+      default: break;
+    }
+  }
+#undef AIE_SPEC_LAUNCH_RESET
+  hipLaunchKernelGGL(aie_reset_kernel, g, b, lds, st, env->d_params, env->arena, d_mask, keep_rewards);
+}
+
 int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
   if (!env) return AIE_E_INVALID;
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
@@ -310,8 +327,7 @@ int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
     hipLaunchKernelGGL(aie_ose_reset_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask);
   else
-    hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), env->lds + aie::layout_gen_lds_bytes(env->P),
-                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask, 0);
+    aie_launch_gtb_reset(env, d_env_mask, 0, stream);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
 }
@@ -424,9 +440,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
       hipLaunchKernelGGL(aie_covid_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0,
                          static_cast<hipStream_t>(stream), env->d_params, env->arena, done, 1);
     else
-      hipLaunchKernelGGL(aie_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT),
-                         env->lds + aie::layout_gen_lds_bytes(env->P), static_cast<hipStream_t>(stream), env->d_params,
-                         env->arena, done, 1);
+      aie_launch_gtb_reset(env, done, 1, stream);
   }
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;

@@ -2675,15 +2675,15 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
 // (layout_from_file.py:323-370, 564-593) and the component resets (build.py:224-254,
 // move.py:193-210, continuous_double_auction.py:643-668, redistribution.py:1109-1139).
 // Runs once per episode: the sequential part is executed wave-uniformly out of LDS.
-extern "C" __global__ void __launch_bounds__(AIE_NT)
-aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                 const uint8_t* __restrict__ mask, int keep_rewards) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  using namespace aie;
-  const aie_params& P = *params;
-  const int e = replica_of_block((int)blockIdx.x, P.E);
+namespace aie {
+template <int SPEC>
+__device__ __forceinline__ void reset_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                                           const uint8_t* __restrict__ mask, int keep_rewards, uint8_t* lds) {
+  const aie_params& R = *params;                      // run-time block: replica count, arena offsets
+  const aie_params& P = aie_spec_params<SPEC>(params);  // the configuration: a constant image in the instances
+  const int e = replica_of_block((int)blockIdx.x, R.E);
   if (mask && !mask[e]) return;
-  const Ctx c = make_ctx(P, P, lds, e, (int)threadIdx.x, arena);
+  const Ctx c = make_ctx(P, R, lds, e, (int)threadIdx.x, arena);
   const int n = P.n, HW = P.HW, tid = c.tid;
   for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
   if (c.ev && tid == 0) c.ev[0] = 0;
@@ -2866,14 +2866,30 @@ aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ ar
   AIE_WSYNC();
   write_action_masks(c, arena);
   if (!keep_rewards) {  // (auto-reset right behind the step that ended the episode: its rewards / done stay)
-    if (tid < n) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + tid] = 0.0f;
+    if (tid < n) reinterpret_cast<float*>(arena + R.a_rew_a)[(int64_t)e * n + tid] = 0.0f;
     if (tid == 0) {
-      reinterpret_cast<float*>(arena + P.a_rew_p)[e] = 0.0f;
-      (arena + P.a_done)[e] = 0;
+      reinterpret_cast<float*>(arena + R.a_rew_p)[e] = 0.0f;
+      (arena + R.a_done)[e] = 0;
     }
   }
   __syncthreads();
   store_record(c, arena, m);
+}
+}  // namespace aie
+
+extern "C" __global__ void __launch_bounds__(AIE_NT)
+aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                 const uint8_t* __restrict__ mask, int keep_rewards) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  aie::reset_body<-1>(params, arena, mask, keep_rewards, lds);
+}
+// compile-time instances (aie_spec_generated.h), as for the step kernel
+template <int SPEC>
+__global__ void __launch_bounds__(AIE_NT)
+aie_reset_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                      const uint8_t* __restrict__ mask, int keep_rewards) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  aie::reset_body<SPEC>(params, arena, mask, keep_rewards, lds);
 }
 
 // np.random.seed(base_seed + e): init_genrand (Knuth LCG), pos = 624.
