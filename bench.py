@@ -511,7 +511,7 @@ def main():
                 "dev_switches": [],
             },
             "per_rank_seconds": per_rank,
-            "host_issue_seconds": t_issue,
+            "host_issue_seconds": t_issue, "gpu_region_seconds": region_ms * 1e-3,
             "exchange_ok": (gather is not None) if (world > 1 or args.force_gather) else None,
             "roofline": roof,
         }
