@@ -386,6 +386,11 @@ def main():
     be = env.backend
     n = env.n_agents
     roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger, auto_reset=not args.no_auto_reset)
+    import gc
+
+    gc.collect()
+    gc.disable()  # no collector pause between here and the end of the timed window (it may be as short as 20 launches);
+    #               collected now, while the GPU has nothing queued: a pause later would let it run dry before the window
     prologue_steps = roll.prologue()
 
     # N > 1: (reward, done) of every step travel to the learner rank, 64 steps per collective, straight from the
@@ -402,27 +407,39 @@ def main():
     # warm-up runs the very code path of the timed region (event-bracketed resets included), so that first-use costs
     # (event creation, cold Python paths) are not charged to a short timed window
     warm0, warm1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # one pair of HIP events on the launch stream around the whole timed region (K back-to-back step launches)
+    # plus one pair around each of the (rare) reset launches inside it: average step-kernel launch period =
+    # (region - resets) / K.  Bracketing every step launch would add ~4 us of queue packets per step.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if not roll.auto_reset:
         roll.warm_reset_path()
+    ev0.record()  # (a torch event creates its HIP event at the first record(): not inside the window)
+    ev1.record()
     warm0.record()
     for _ in range(args.warmup):
         roll.step(timed=True)
         if gather is not None:
             gather.after_step()
     warm1.record()
-    torch.cuda.synchronize()
-    roll.reset_events.clear()
+    # The opening bracket (barrier + synchronize) leaves the GPU idle; everything the host has to do before the first
+    # timed launch is done BEFORE it (events exist, the reset-event list is cleared inside the window's bookkeeping),
+    # so that the idle gap -- during which the clocks start to drop -- is as short as the bracket itself.
+    n_warm_resets = len(roll.reset_events)
+    # drain the GPU by polling: a blocking wait puts the host core to sleep for the ~30 ms the prologue still needs,
+    # and the first calls after the wake-up (the window's first launches) run several times slower
+    while not warm1.query():
+        pass
     barrier()
-    # one pair of HIP events on the launch stream around the whole timed region (K back-to-back step launches)
-    # plus one pair around each of the (rare) reset launches inside it: average step-kernel launch period =
-    # (region - resets) / K.  Bracketing every step launch would add ~4 us of queue packets per step.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
+    _dbg = [time.perf_counter() - t0]
     for _ in range(args.steps):
         roll.step(timed=True)
         if gather is not None:
             gather.after_step()
+        if len(_dbg) < 3:
+            _dbg.append(time.perf_counter() - t0)
     ev1.record()
     t_issue = time.perf_counter() - t0
     if gather is not None:
@@ -431,9 +448,14 @@ def main():
     # closing event first, so that a 20-step window is not dominated by the wake-up latency of its closing bracket
     while not ev1.query():
         pass
+    _dbg.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
+    _dbg.append(time.perf_counter() - t0)
     barrier()
     elapsed_local = time.perf_counter() - t0
+    if os.environ.get("BENCH_TIMELINE"):
+        sys.stderr.write("timeline us: " + " ".join("%.1f" % (x * 1e6) for x in _dbg) + " issue %.1f\n" % (t_issue * 1e6))
+    gc.enable()
     elapsed = elapsed_local
     per_rank = [elapsed_local]
     if world > 1:
@@ -455,7 +477,8 @@ def main():
 
     if rank == 0:
         region_ms = ev0.elapsed_time(ev1)
-        reset_ms = sum(a.elapsed_time(b) for a, b in roll.reset_events)
+        timed_resets = roll.reset_events[n_warm_resets:]
+        reset_ms = sum(a.elapsed_time(b) for a, b in timed_resets)
         avg_ms = (region_ms - reset_ms) / args.steps
         lay = layout_bytes_per_env_step(be, wl)
         units = (n + 1) if wl == "C4" else n  # C4's per-unit figure counts the planner
@@ -472,7 +495,7 @@ def main():
             unit_of_work="agent-step incl. planner" if wl == "C4" else "agent-step",
             achieved_final_layout=achieved_layout, frac_final_layout=achieved_layout / HBM_PEAK_GBS,
             final_layout_bytes_per_launch=layout_per_launch, final_layout_bytes_per_env_step=lay,
-            avg_launch_ms=avg_ms, launches_timed=args.steps, reset_launches_in_region=len(roll.reset_events),
+            avg_launch_ms=avg_ms, launches_timed=args.steps, reset_launches_in_region=len(timed_resets),
             reset_ms_in_region=reset_ms,
             note="achieved/frac price SURVEY.md 8(d)'s algorithmic bytes per launch against the HBM peak; "
                  "*_final_layout does the same with the bytes of the layouts actually used (u32 map cells, 2.5 KB "
