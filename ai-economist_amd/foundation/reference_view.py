@@ -38,6 +38,8 @@ class AgentView:
         """The actor's `state` dictionary as the dense log would record it now (a host read of the replica's record).
         Scenarios whose state dictionaries are accumulated step by step (COVID) have one only while the episode is
         being dense-logged."""
+        if self._env is None:
+            raise AttributeError("this agent view describes action spaces only (no environment attached)")
         b = self._env.batched
         if b._dense_log_this_episode and b._dense_logger is not None:
             return b._dense_logger.states_snapshot()[str(self.idx)]
@@ -69,6 +71,8 @@ class ReferenceFormatEnv:
         self.world = _World(agents, planner)
 
     def __getattr__(self, name):  # n_agents, components, get_component, metrics of the batch, dense logs, ...
+        if name == "batched":  # (not set yet: do not recurse)
+            raise AttributeError(name)
         return getattr(self.batched, name)
 
     @property
