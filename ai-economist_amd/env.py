@@ -150,6 +150,12 @@ class DeviceBackend:
         self._check(self.lib.aie_set_reward_log(self.handle, C.c_void_p(self.reward_log.data_ptr()), int(n_slots)))
         return self.reward_log
 
+    def rewind_reward_log(self):
+        """The next step fills slot 0 of the current reward log again."""
+        if self.reward_log is not None:
+            self._check(self.lib.aie_set_reward_log(self.handle, C.c_void_p(self.reward_log.data_ptr()),
+                                                    int(self.reward_log.shape[0])))
+
     def set_auto_reset(self, on=True):
         """Replicas restart inside / right behind the step that ends their episode (include/aie.h:
         aie_set_auto_reset): `done` and the rewards are the terminal step's, state and observations the new episode's."""

@@ -81,6 +81,7 @@ class RewardLogGather:
         self.dst, self.K, self.keep = dst, int(steps_per_gather), keep
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.backend = backend
         self.log = backend.set_reward_log(2 * self.K)  # [2K, E, n + 2]
         self.filled = 0   # steps written into the current block
         self.block = 0    # block being written (0 / 1)
@@ -94,6 +95,12 @@ class RewardLogGather:
         self.n_collectives = 0
         self.bytes_per_collective = int(self.log[: self.K].numel() * self.log.element_size())
         self.wait_seconds = 0.0  # host time spent waiting for a collective before its log block could be reused
+        if self.collective:
+            # the communicator is created by the first collective (hundreds of milliseconds): here, not inside
+            # somebody's rollout
+            warm = self.log[:1, :1].clone()
+            self.dist.gather(warm, [torch.empty_like(warm) for _ in range(self.world)] if self.rank == dst else None,
+                             dst=dst)
 
     def after_step(self):
         """Call once after every step; returns True when a block was handed to the collective."""
@@ -129,8 +136,30 @@ class RewardLogGather:
             self.received.append(self.torch.stack(self.recv[b]).clone())
 
     def finish(self):
+        """Ships what the current block holds (a rollout need not end on a block boundary) and waits for everything
+        outstanding.  The partial block arrives as [W, filled, E, n + 2]."""
         self._wait(self.block ^ 1)
         self._wait(self.block)
+        if self.filled:
+            b, f = self.block, self.filled
+            view = self.log[b * self.K: b * self.K + f]
+            if self.collective:
+                w = self.dist.gather(view, [r[:f] for r in self.recv[b]] if self.rank == self.dst else None,
+                                     dst=self.dst, async_op=True)
+                self.n_collectives += 1
+                import time
+
+                t0 = time.perf_counter()
+                w.wait()
+                self.wait_seconds += time.perf_counter() - t0
+                if self.keep and self.rank == self.dst:
+                    self.received.append(self.torch.stack([r[:f] for r in self.recv[b]]).clone())
+            elif self.keep:
+                self.received.append(view.clone()[None])
+            self.filled = 0
+            # the next step writes slot 0 again (the writer's slot counter lives in the library)
+            self.backend.rewind_reward_log()
+            self.block = 0
 
 
 def accumulate_and_broadcast_saez_buffers(envs, component_name="PeriodicBracketTax"):

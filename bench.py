@@ -420,6 +420,8 @@ def main():
         roll.step(timed=True)
         if gather is not None:
             gather.after_step()
+    if gather is not None:
+        gather.finish()  # the warm-up's (reward, done) rows leave before the window; the window ships its own
     warm1.record()
     # The opening bracket (barrier + synchronize) leaves the GPU idle; everything the host has to do before the first
     # timed launch is done BEFORE it (events exist, the reset-event list is cleared inside the window's bookkeeping),

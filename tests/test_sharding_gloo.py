@@ -78,8 +78,11 @@ class _FakeBackend:
         self.log = torch.zeros((n_slots, self.E, self.n + 2))
         return self.log
 
+    def rewind_reward_log(self):
+        self.slot0 = self.t
+
     def step(self, lo):
-        slot = self.t % self.log.shape[0]
+        slot = (self.t - getattr(self, "slot0", 0)) % self.log.shape[0]
         gid = torch.arange(lo, lo + self.E, dtype=torch.float32)
         self.log[slot, :, : self.n] = gid[:, None] * 10 + torch.arange(self.n)[None, :] + 1000 * self.t
         self.log[slot, :, self.n] = -gid - self.t
@@ -94,7 +97,7 @@ def _log_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ai_economist_amd.sharding import RewardLogGather, shard_range
 
-    E_total, n, K, T = 12, 3, 4, 20
+    E_total, n, K, T = 12, 3, 4, 22  # the rollout ends inside a block: finish() ships the two leftover steps
     lo, hi = shard_range(E_total, rank, world)
     be = _FakeBackend(hi - lo, n)
     g = RewardLogGather(be, steps_per_gather=K, dst=0, keep=True)
@@ -105,11 +108,12 @@ def _log_worker(rank, world, port, out):
     g.finish()
     ok = launched == T // K
     if rank == 0:
-        ok &= len(g.received) == T // K
+        ok &= len(g.received) == T // K + 1 and g.received[-1].shape[1] == T % K
         gid = torch.arange(E_total, dtype=torch.float32)
-        for blk, got in enumerate(g.received):  # [W, K, E, n + 2]
-            full = got.permute(1, 0, 2, 3).reshape(K, E_total, n + 2)  # rank-major replica order
-            for k in range(K):
+        for blk, got in enumerate(g.received):  # [W, K (or the leftover), E, n + 2]
+            steps = got.shape[1]
+            full = got.permute(1, 0, 2, 3).reshape(steps, E_total, n + 2)  # rank-major replica order
+            for k in range(steps):
                 t = blk * K + k
                 ok &= torch.equal(full[k, :, :n], gid[:, None] * 10 + torch.arange(n)[None, :] + 1000 * t)
                 ok &= torch.equal(full[k, :, n], -gid - t)
@@ -140,8 +144,9 @@ def test_reward_log_gather_single_process_keeps_blocks():
         be.step(0)
         g.after_step()
     g.finish()
-    assert len(g.received) == 3  # steps 0-2, 3-5, 6-8; step 9 still sits in the log
-    for blk, got in enumerate(g.received):
+    assert len(g.received) == 4 and tuple(g.received[3].shape) == (1, 1, 5, 4)  # steps 0-2, 3-5, 6-8 and the leftover 9
+    assert torch.equal(g.received[3][0, 0, :, 2], -torch.arange(5, dtype=torch.float32) - 9)
+    for blk, got in enumerate(g.received[:3]):
         assert tuple(got.shape) == (1, 3, 5, 4)
         for k in range(3):
             t = blk * 3 + k
