@@ -1965,8 +1965,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
   const double isc = P.c.allow_observation_scaling ? 0.01 : 1.0;
   // The agents' vectors (n x FA floats) go straight to HBM through a buffer descriptor; only the
   // planner's vector (read back by the agents' CDA fragment) and its per-agent fragments are
-  // staged in LDS -- behind the 624-word MT19937 window, which the regeneration may still be
-  // using on the other wave (see step_body).
+  // staged in LDS, behind the components' draw window (the first region of the staging area, see step_body).
   float* s_pag = c.stage + stage_window_words(P);
   float* s_pflat = s_pag + pad4(n * P.FPA);
   const BufRsrc aflat = make_rsrc(arena + c.R.a_obs_a_flat + (int64_t)c.e * n * P.FA * 4, (uint32_t)(n * P.FA * 4));
@@ -2317,7 +2316,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
     m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
   }
-  __syncthreads();  // components done; the generator's window (LDS) and position are final
+  __syncthreads();  // components done; the generator's position (and, after a refill that twisted, its state in HBM) is final
   if (wid == 0) {
     // first wave: flat observation vectors (they do not look at the map)
     if (!(skip & 8)) write_flat_observations(c, arena);
@@ -2332,7 +2331,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     }
   }
   if (NW == 1 || wid == 1) {
-    // second wave: resource regeneration (rows back into registers for the twists), then what
+    // second wave: resource regeneration (the generator's rows are in its registers), then what
     // depends on the map: incremental map observations, action masks
     if (NW == 2) __builtin_amdgcn_s_setprio(2);  // from here on this wave is the critical one (the first has slack)
     // a refill that twisted (components drew past word 623) left the new state in HBM
