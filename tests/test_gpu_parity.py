@@ -406,6 +406,44 @@ def test_hip_matches_oracle_on_random_configs(seed):
             _compare_all(be, oracle, "%s reset after step %d" % (where0, t + 1))
 
 
+def test_dense_source_layouts_take_the_row_by_row_regeneration():
+    """More than 128 source doubles per replica (here: uniform layouts drawn with 22 % coverage per resource on
+    20 x 20) leave the sparse gather regeneration for the row-by-row fallback (aie_kernels.hip:
+    scenario_step_regen_rows): same stream, same respawns as the oracle."""
+    import torch
+    from helpers import oracle_host_pre_reset
+    from oracle_lib import OracleEnv
+
+    cfg = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=5, world_size=[20, 20], episode_length=25,
+               components=[["Build", {}], ["Gather", {}]], starting_agent_coin=3, starting_stone_coverage=0.22,
+               starting_wood_coverage=0.22, wood_regen_weight=0.3, stone_regen_weight=0.2)
+    E = 16
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(4)
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(4)
+    env.reset()
+    oracle_host_pre_reset(env, oracle)
+    oracle.reset()
+    _compare_all(be, oracle, "dense layout reset")
+    flags = be.tensors["cell_flags"].reshape(E, -1).cpu().numpy()
+    n_src = ((flags & 2) != 0).sum(axis=1) + ((flags & 4) != 0).sum(axis=1)
+    assert (n_src > 128).all(), n_src  # every replica is on the fallback
+    for t in range(40):
+        a, p = be.sample_random_actions(seed=23)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+        if t % 6 == 5 or t == 24:
+            _compare_all(be, oracle, "dense layout step %d" % (t + 1))
+        if t == 24:
+            env.reset(be.tensors["done"])
+            oracle_host_pre_reset(env, oracle)
+            oracle.reset(oracle.t["done"].copy())
+            _compare_all(be, oracle, "dense layout second reset")
+
+
 @pytest.mark.parametrize("variant", sorted(OSE_VARIANTS))
 def test_hip_matches_oracle_one_step_economy(variant):
     """BASELINE configs[4] family: one-step-economy + SimpleLabor + PeriodicBracketTax."""
