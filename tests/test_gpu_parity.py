@@ -406,6 +406,40 @@ def test_hip_matches_oracle_on_random_configs(seed):
             _compare_all(be, oracle, "%s reset after step %d" % (where0, t + 1))
 
 
+def test_maximum_agent_count_matches_oracle():
+    """62 mobile agents (the spatial scenarios' limit: one lane each + the planner's bookkeeping) on the 40 x 40
+    quadrant map with all four components: 310-slot order books (the LDS book path), a 496-word draw window, a
+    record that leaves room for 3-4 workgroups per CU; 63 agents are refused at construction."""
+    import torch
+    from oracle_lib import OracleEnv
+    from test_oracle_vs_reference import BASE, GTB
+
+    cfg = dict(BASE, components=GTB, n_agents=62, world_size=[40, 40], env_layout_file="quadrant_40x40_50each.txt",
+               episode_length=30)
+    E = 6
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(9)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(9)
+    oracle.reset()
+    _compare_all(be, oracle, "62 agents reset")
+    for t in range(45):
+        a, p = be.sample_random_actions(seed=31)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+        if t % 5 == 4 or t == 29:
+            _compare_all(be, oracle, "62 agents step %d" % (t + 1))
+        if t == 29:
+            env.reset(be.tensors["done"])
+            oracle.reset(oracle.t["done"].copy())
+            _compare_all(be, oracle, "62 agents second reset")
+    with pytest.raises(Exception, match="n_agents"):
+        make_env(dict(cfg, n_agents=63), n_envs=2, device="cuda:0").reset()
+
+
 def test_dense_source_layouts_take_the_row_by_row_regeneration():
     """More than 128 source doubles per replica (here: uniform layouts drawn with 22 % coverage per resource on
     20 x 20) leave the sparse gather regeneration for the row-by-row fallback (aie_kernels.hip:
