@@ -440,6 +440,41 @@ def test_maximum_agent_count_matches_oracle():
         make_env(dict(cfg, n_agents=63), n_envs=2, device="cuda:0").reset()
 
 
+def test_large_uniform_world_uses_the_host_layout_procedure():
+    """uniform/ on 52 x 52 (more cells than the reset kernel's layout generator handles in LDS): the layouts come from
+    the host-side procedure (dynamic_layout.py: generate_layout, each replica's own stream), the 10 816-word
+    regeneration sweep crosses 17 generator windows per step; HIP vs oracle over an episode boundary."""
+    import torch
+    from helpers import oracle_host_pre_reset
+    from oracle_lib import OracleEnv
+
+    cfg = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=3, world_size=[52, 52], episode_length=8,
+               components=[["Build", {}], ["Gather", {}]], starting_agent_coin=3, starting_stone_coverage=0.03,
+               starting_wood_coverage=0.03)
+    E = 3
+    np.random.seed(77)
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(6)
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(6)
+    env.reset()
+    oracle_host_pre_reset(env, oracle)
+    oracle.reset()
+    _compare_all(be, oracle, "52x52 reset")
+    for t in range(12):
+        a, p = be.sample_random_actions(seed=2)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=3)
+        _compare_all(be, oracle, "52x52 step %d" % (t + 1))
+        if t == 7:
+            env.reset(be.tensors["done"])
+            oracle_host_pre_reset(env, oracle)
+            oracle.reset(oracle.t["done"].copy())
+            _compare_all(be, oracle, "52x52 second reset")
+
+
 def test_dense_source_layouts_take_the_row_by_row_regeneration():
     """More than 128 source doubles per replica (here: uniform layouts drawn with 22 % coverage per resource on
     20 x 20) leave the sparse gather regeneration for the row-by-row fallback (aie_kernels.hip:
