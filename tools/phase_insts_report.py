@@ -9,7 +9,7 @@ NAMES = {0: "full", 1: "-components", 2: "-regen", 4: "-spatial", 8: "-flat+mask
          4096: "-cda", 8192: "-gather", 16384: "-tax", 63: "base only"}
 rows = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if r["Kernel_Name"] == "aie_step_kernel":
+    if r["Kernel_Name"].startswith("aie_step_kernel"):
         rows[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 for name, v in rows.items():
     v.sort()
