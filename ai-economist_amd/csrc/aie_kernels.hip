@@ -2305,16 +2305,17 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     }
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 5] = wall_clock64();
   } else {
-    // the second wave has nothing to do until the components are done: next step's random actions ...
-    if (next.a || next.p) {
-      const int per_env = P.n * P.act_a_width + P.act_p_width;
-      for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, c.e, j, next.a, next.p);
-    }
-    // ... and the generator state for the regeneration (rows -> registers; re-read below if the components twisted it)
+    // the second wave has nothing to do until the components are done: the generator state for the regeneration
+    // (rows -> registers, the loads go out first; re-read below if the components twisted it) ...
     const uint32_t* key = gkey;
 #pragma unroll
     for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
     m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
+    // ... and the next step's random actions
+    if (next.a || next.p) {
+      const int per_env = P.n * P.act_a_width + P.act_p_width;
+      for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, c.e, j, next.a, next.p);
+    }
   }
   __syncthreads();  // components done; the generator's position (and, after a refill that twisted, its state in HBM) is final
   if (wid == 0) {
