@@ -2201,22 +2201,22 @@ __device__ __forceinline__ void rebuild_locmap(const Ctx& c) {
 // BaseEnvironment.step, F/base/base_env.py:929-1032: parse actions, timestep += 1,
 // components in list order, scenario_step, observations, masks, rewards, done.
 //
-// NW = 2 (default): a replica is a workgroup of TWO wavefronts sharing the LDS record.
-//   both   record HBM -> LDS (alternate 16-byte units; the MT19937 key goes to the LDS window)
+// A replica is a workgroup of TWO wavefronts sharing the LDS record (NW = 2; the template parameter remains from the
+// one-wave schedule the kernel started with).
+//   both   record HBM -> LDS (alternate 16-byte units)  ||  wave 1 also: the next 128+ tempered MT19937 words ->
+//                                                        ||         the LDS draw window (rows fetched from HBM)
 //   wave 0 action decode, price-history decay          ||  wave 1 occupancy map
-//   wave 0 components (draws read the LDS window)      ||  wave 1 next step's random actions (opt.)
-//   wave 0 flat observation vectors, rewards, done     ||  wave 1 regeneration (rows in registers,
-//          (none of them looks at the map)             ||         4 twists), incremental map
-//                                                      ||         observations, action masks
+//   wave 0 components (draws read the draw window)     ||  wave 1 generator rows HBM -> registers, next step's
+//                                                      ||         random actions (opt.)
+//   wave 0 flat observation vectors, rewards, done     ||  wave 1 regeneration (rows in registers, 4 twists),
+//          (none of them looks at the map)             ||         incremental map observations, action masks
 //   both   record LDS -> HBM (wave 1 also the generator's rows)
 // After the components the two halves touch disjoint state: wave 0 reads agents / auction / tax
 // fields and writes util + warm-up counters, wave 1 reads and writes the map cells and the
-// generator.  With <= 64 VGPRs all 2 x 4096 waves of the C2 batch are resident at once (8 per
-// SIMD) instead of 4 per SIMD.
+// generator.  With <= 64 VGPRs all 2 x 4096 waves of the C2 / C3 batch are resident at once (8 per SIMD).
 // (Tried and dropped: writing the map observations speculatively during the dynamics and
 // repairing the changed cells afterwards -- parity-clean, but the co-resident second waves'
 // instruction stream slows the serial dynamics of the first waves by as much as it saves.)
-// NW = 1 is the original one-wave-per-replica schedule (kept for A/B measurements).
 struct NextActions {  // aie_step_sample_next: where and how to sample the next step's random actions
   int32_t* a;
   int32_t* p;
