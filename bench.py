@@ -489,8 +489,14 @@ def main():
         achieved = survey_per_launch / (avg_ms * 1e-3) / 1e9
         achieved_layout = layout_per_launch / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(wl, E)
+        inst = int(be.lib.aie_step_kernel_instance(be.handle))
+        kernel_name = W["kernel"]  # the name rocprofv3 lists: compile-time instances are template instantiations
+        if inst >= 0 and wl != "C4":
+            kernel_name = "%s_spec<%d>" % (W["kernel"], inst)
+        elif wl == "C4":
+            kernel_name = "aie_covid_step_kernel<%d, %s>" % (env.model["num_filters"], "false" if env.exact_filter_sums else "true")
         roof = dict(
-            bound="latency/issue", roof="hbm", kernel=W["kernel"], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+            bound="latency/issue", roof="hbm", kernel=kernel_name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
             hbm_traffic_frac=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             algorithmic_bytes_per_launch=survey_per_launch, algorithmic_bytes_per_unit=W["survey_bytes"],
