@@ -83,9 +83,20 @@ class FoundationEnvWrapper:
         """Per-actor keys "0" ... "p" over the batched tensors: obs["3"][key] is the [E, ...] slice of agent 3 (a
         view, nothing is copied)."""
         out = {}
-        for i in range(self.env.n_agents):
-            out[str(i)] = {k: v[:, i] for k, v in obs["a"].items() if hasattr(v, "shape") and v.dim() >= 2
-                           and v.shape[1] == self.env.n_agents}
+        n = self.env.n_agents
+        # gather-trade-build / one-step-economy tensors carry the agent axis right behind the replica axis; the COVID
+        # scenario keeps the reference's collated layout, agent axis last (F/env_wrapper.py:387-396)
+        last = getattr(self.env, "supports_unflattened_observations", False)
+        for i in range(n):
+            d = {}
+            for k, v in obs["a"].items():
+                if not hasattr(v, "shape") or v.dim() < 2:
+                    continue
+                if last and v.shape[-1] == n:
+                    d[k] = v[..., i]
+                elif not last and v.shape[1] == n:
+                    d[k] = v[:, i]
+            out[str(i)] = d
         out["p"] = {k: v for k, v in obs["p"].items() if hasattr(v, "shape")}
         return out
 
