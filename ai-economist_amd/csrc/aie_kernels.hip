@@ -2418,8 +2418,12 @@ __device__ __forceinline__ void mt2_need_next(MT2& s, int lane) {
 __device__ __forceinline__ uint32_t mt2_word(const MT2& s, int o) {  // tempered word at offset o (per lane), o < 1248
   const bool second = o >= AIE_MT_N;
   const int i = second ? o - AIE_MT_N : o;
-  const uint32_t a = mt_window_word(s.cur, i), b = mt_window_word(s.nxt, i);
-  return mt_temper(second ? b : a);
+  uint32_t v = mt_window_word(s.cur, i);
+  if (__ballot(second) != 0) {  // (uniform: most passes stay inside the current window)
+    const uint32_t b = mt_window_word(s.nxt, i);
+    v = second ? b : v;
+  }
+  return mt_temper(v);
 }
 __device__ __forceinline__ void mt2_consume(MT2& s, int nwords, int lane) {  // nwords <= 624
   s.cur.pos += nwords;
@@ -2626,13 +2630,10 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
           if (cell < HW) {
             const int r0 = cell / W, c0 = cell - r0 * W;
             double sum = 0.0;
-            for (int j = 0; j < 7; ++j) {
-              const int i0 = r0 + 3 - j;
-              if (i0 < 0 || i0 >= H) continue;
-              for (int k = 0; k < 7; ++k) {
-                const int i1 = c0 + 3 - k;
-                if (i1 >= 0 && i1 < W && ((kmask >> (j * 7 + k)) & 1ull)) sum += x[i0 * W + i1];
-              }
+            for (uint64_t bits = kmask; bits; bits &= bits - 1) {  // the kernel's ones, row-major (wave-uniform loop)
+              const int t = __ffsll((unsigned long long)bits) - 1, j = t / 7, k = t - 7 * j;
+              const int i0 = r0 + 3 - j, i1 = c0 + 3 - k;
+              if (i0 >= 0 && i0 < H && i1 >= 0 && i1 < W) sum += x[i0 * W + i1];
             }
             on = ((sum > 0) || mb[cell]) && !(other && other[cell]);
           }
