@@ -210,3 +210,36 @@ def test_reference_format_view_without_a_gpu():
     assert obs.keys() == reward.keys() == info.keys() and "__all__" in done
     assert int(o.t["timestep"][0]) == 1
     assert env.get_agent("1").action_spaces == 50
+
+
+def test_foundation_env_wrapper_without_a_gpu():
+    """FoundationEnvWrapper(env_obj=...) around a host environment whose backend is the CPU oracle."""
+    import numpy as np
+    import torch
+    from ai_economist_amd import foundation
+    from ai_economist_amd.foundation.env_wrapper import FoundationEnvWrapper
+    from helpers import oracle_host_pre_reset
+    from oracle_lib import OracleEnv
+    from test_dense_log import ReplayOracleBackend
+
+    cfg = dict(ENV_CONFIG, scenario_name="layout_from_file/simple_wood_and_stone", world_size=[25, 25],
+               env_layout_file="quadrant_25x25_20each_30clump.txt", flatten_observations=True, episode_length=3)
+    for k in ("starting_stone_coverage", "starting_wood_coverage"):
+        cfg.pop(k)
+    scen = cfg.pop("scenario_name")
+    host = foundation.make_env_instance(scen, n_envs=1, **cfg)
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    host._backend = ReplayOracleBackend(o, host)
+    host.host_pre_reset = lambda mask: oracle_host_pre_reset(host, o)
+    o.seed(4)
+    w = FoundationEnvWrapper(env_obj=host)
+    n = cfg["n_agents"]
+    assert w.n_agents == n + 1 and sorted(host.action_space) == sorted(host.observation_space)
+    assert host.action_space["0"].n == 50 and tuple(host.observation_space["0"]["flat"].shape) == (121,)  # no tax component here
+    w.reset_all_envs()
+    a = torch.ones((1, n, 1), dtype=torch.int32)
+    for _ in range(3):
+        w.step_all_envs({"a": a})
+    assert bool(o.t["done"][0])
+    w.reset_only_done_envs()
+    assert int(o.t["timestep"][0]) == 0
