@@ -238,8 +238,9 @@ def test_foundation_env_wrapper_without_a_gpu():
     assert host.action_space["0"].n == 50 and tuple(host.observation_space["0"]["flat"].shape) == (121,)  # no tax component here
     w.reset_all_envs()
     a = torch.ones((1, n, 1), dtype=torch.int32)
+    p = torch.zeros((1, 1), dtype=torch.int32)  # (the CPU stand-in wants both buffers)
     for _ in range(3):
-        w.step_all_envs({"a": a})
+        w.step_all_envs({"a": a, "p": p})
     assert bool(o.t["done"][0])
     w.reset_only_done_envs()
     assert int(o.t["timestep"][0]) == 0
