@@ -244,3 +244,48 @@ def test_foundation_env_wrapper_without_a_gpu():
     assert bool(o.t["done"][0])
     w.reset_only_done_envs()
     assert int(o.t["timestep"][0]) == 0
+
+
+def test_reference_action_dictionaries_in_multi_action_mode_without_a_gpu():
+    """{"0": [sub-action per subspace], "p": [one per bracket]}: lists land in the per-subspace slots of replica 0;
+    a seed_state that is not a NumPy MT19937 state tuple is refused as in the reference (base_env.py:969-970)."""
+    import numpy as np
+    from ai_economist_amd import foundation
+    from helpers import oracle_host_pre_reset
+    from oracle_lib import OracleEnv
+    from test_dense_log import ReplayOracleBackend
+
+    cfg = dict(ENV_CONFIG, scenario_name="layout_from_file/simple_wood_and_stone", world_size=[25, 25],
+               env_layout_file="quadrant_25x25_20each_30clump.txt", flatten_observations=True,
+               multi_action_mode_agents=True,
+               components=[{"Build": {}}, {"ContinuousDoubleAuction": {"max_num_orders": 5}}, {"Gather": {}},
+                           {"PeriodicBracketTax": {}}])
+    for k in ("starting_stone_coverage", "starting_wood_coverage"):
+        cfg.pop(k)
+    scen = cfg.pop("scenario_name")
+    host = foundation.make_env_instance(scen, n_envs=1, **cfg)
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    be = ReplayOracleBackend(o, host)
+    host._backend = be
+    host.host_pre_reset = lambda mask: oracle_host_pre_reset(host, o)
+    o.seed(2)
+    host.reset()
+    names_a, names_p = host.action_subspace_names()
+    seen = {}
+    orig = be.step
+
+    def spy(a, p):
+        seen["a"], seen["p"] = a.numpy().copy(), p.numpy().copy()
+        return orig(a, p)
+
+    be.step = spy
+    acts = {"1": [0] * len(names_a), "p": [2] + [0] * (len(names_p) - 1)}
+    acts["1"][-1] = 3  # last subspace (Gather): move
+    host.step(acts)
+    assert seen["a"].shape == (1, cfg["n_agents"], len(names_a)) and seen["a"][0, 1, -1] == 3 and seen["a"].sum() == 3
+    assert seen["p"].shape == (1, len(names_p)) and seen["p"][0, 0] == 2
+    with pytest.raises(AssertionError):
+        host.step(acts, seed_state=("MT19937", np.zeros(624, np.uint32), 0))
+    st = host.rng_state(0)
+    host.step(acts, seed_state=st)  # a valid state passes through
+    assert host.rng_state(0)[0] == "MT19937"
