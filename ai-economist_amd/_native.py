@@ -5,19 +5,20 @@ import os
 
 from . import _build, _cabi
 
-_LIB = None
+_LIBS = {}
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        if not os.path.exists(_build.LIB):
-            raise RuntimeError(
-                "HIP extension {} is not built; run `python -c 'import __graft_entry__ as g; "
-                "g.build()'` (needs hipcc). There is no CPU fallback.".format(_build.LIB))
-        if _build.is_stale() and _build.have_hipcc():
+def lib(dev=False):
+    """The shipping library; dev=True: the -DAIE_DEV build with the development hooks (tools/, a few tests)."""
+    if dev not in _LIBS:
+        path = _build.LIB_DEV if dev else _build.LIB
+        if _build.is_stale(path) and _build.have_hipcc():
             # sources newer than the binary: never run an old kernel silently (on a box without hipcc -- the GPU box
             # receives the prebuilt library -- there is nothing to rebuild with, and file times there are the copy's)
-            _build.build()
-        _LIB = _cabi.bind(ctypes.CDLL(_build.LIB))
-    return _LIB
+            _build.build(dev=dev)
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "HIP extension {} is not built; run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (needs hipcc). There is no CPU fallback.".format(path))
+        _LIBS[dev] = _cabi.bind(ctypes.CDLL(path))
+    return _LIBS[dev]

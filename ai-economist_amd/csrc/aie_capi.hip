@@ -21,6 +21,7 @@ struct aie_env {
   int device;
   size_t lds;
   int spec;        // >= 0: the compile-time instance aie_step_kernel_spec<spec> runs this configuration; -1: generic
+  int spec_match;  // the instance that matches the configuration (what AIE_KERNEL_AUTO selects), or -1
   int64_t sample_t;
   float* rew_log;        // aie_set_reward_log: caller's ring of n_slots step slots, or nullptr
   int32_t rew_log_slots, rew_log_next;
@@ -28,6 +29,8 @@ struct aie_env {
 };
 
 static thread_local char g_create_err[512] = "";
+
+#define AIE_DEV_API __attribute__((visibility("default")))
 
 #define AIE_HIP_CHECK(env, expr)                                                          \
   do {                                                                                    \
@@ -94,6 +97,7 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
     for (int k = 0; k < AIE_N_SPECS; ++k)
       if (memcmp(&norm, aie_spec_table[k], sizeof(aie_params)) == 0) env->spec = k;
   }
+  env->spec_match = env->spec;
   const bool covid = cfg->scenario == AIE_SCN_COVID;
   const bool ose = cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY || covid;  // map-less: no cell words to initialise
   env->lds = covid ? 0 : cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY ? aie::ose_lds_bytes(env->P) : aie::lds_bytes(env->P);
@@ -401,6 +405,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY)
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
+#ifdef AIE_DEV
   else if (env->spec >= 0 && env->P.dev_trace != nullptr && env->P.dev_skip_mask == 0) {
     const dim3 g((unsigned)env->P.E), b(2 * AIE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -411,7 +416,9 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
       default: return AIE_E_INVALID;
     }
 #undef AIE_SPEC_LAUNCH_TR
-  } else if ((env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT || env->P.regen_general ||
+  }
+#endif
+  else if ((env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT || env->P.regen_general ||
                                     env->P.dev_skip_mask != 0 || env->P.dev_trace != nullptr))
     hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
@@ -514,15 +521,32 @@ int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_of
   return AIE_OK;
 }
 
-// Test hook (not part of include/aie.h): evaluates the device build of aie_glibc_math.h on arrays, so that a GPU test
-// can compare it with the host's libm bit for bit.  fn 0: out = pow(x, y); fn 1: out = exp(x); fn 2: out = log(x).
+// Which step kernel runs this environment: >= 0 = compile-time instance (index into aie_spec_generated.h), -1 = generic.
+int aie_step_kernel_instance(aie_env* env) { return env ? env->spec : -2; }
+
+int aie_select_step_kernel(aie_env* env, int which) {
+  if (!env) return AIE_E_INVALID;
+  if (which != AIE_KERNEL_AUTO && which != AIE_KERNEL_GENERIC) {
+    snprintf(env->err, sizeof(env->err), "aie_select_step_kernel: unknown kernel %d", which);
+    return AIE_E_INVALID;
+  }
+  env->spec = which == AIE_KERNEL_GENERIC ? -1 : env->spec_match;
+  return AIE_OK;
+}
+
+#ifdef AIE_DEV
+// ---- development hooks: compiled only into libaie_hip_dev.so (-DAIE_DEV; tools/ and the tests that need to reach
+// inside a launch load that build), never into the shipping library; not part of include/aie.h ----
+
+// Evaluates the device build of aie_glibc_math.h on arrays, so that a GPU test can compare it with the host's libm
+// bit for bit.  fn 0: out = pow(x, y); fn 1: out = exp(x); fn 2: out = log(x).
 __global__ void aie_test_glibc_math_kernel(int fn, const double* __restrict__ x, const double* __restrict__ y,
                                            double* __restrict__ out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   out[i] = fn == 0 ? aie_pow_glibc(x[i], y[i]) : fn == 1 ? aie_exp_glibc(x[i]) : aie_log_glibc(x[i]);
 }
-int aie_test_glibc_math(int fn, const void* d_x, const void* d_y, void* d_out, int64_t n, void* stream) {
+AIE_DEV_API int aie_test_glibc_math(int fn, const void* d_x, const void* d_y, void* d_out, int64_t n, void* stream) {
   if (n <= 0 || !d_x || !d_out || (fn == 0 && !d_y) || fn < 0 || fn > 2) return AIE_E_INVALID;
   hipLaunchKernelGGL(aie_test_glibc_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), fn, static_cast<const double*>(d_x),
@@ -530,18 +554,9 @@ int aie_test_glibc_math(int fn, const void* d_x, const void* d_y, void* d_out, i
   return hipGetLastError() == hipSuccess ? AIE_OK : AIE_E_HIP;
 }
 
-// Which step kernel runs this environment: >= 0 = compile-time instance (index into aie_spec_generated.h), -1 = generic.
-int aie_step_kernel_instance(aie_env* env) { return env ? env->spec : -2; }
-// Development aid (not part of include/aie.h): force the generic step kernel (A/B runs, parity tests of both).
-int aie_dev_use_generic_kernel(aie_env* env) {
-  if (!env) return AIE_E_INVALID;
-  env->spec = -1;
-  return AIE_OK;
-}
-
-// Development aid (not part of include/aie.h): dynamic LDS bytes of a step workgroup (out[0]) and its parts:
-// record image, location map, f64 scratch, staging area; out[5]: workgroups per CU that size allows.
-int aie_dev_lds_bytes(aie_env* env, int64_t* out) {
+// dynamic LDS bytes of a step workgroup (out[0]) and its parts: record image, location map, f64 scratch, staging
+// area; out[5]: workgroups per CU that size allows.
+AIE_DEV_API int aie_dev_lds_bytes(aie_env* env, int64_t* out) {
   if (!env || !out) return AIE_E_INVALID;
   out[0] = (int64_t)env->lds;
   out[5] = aie_workgroups_per_cu(env->lds);
@@ -552,43 +567,42 @@ int aie_dev_lds_bytes(aie_env* env, int64_t* out) {
   return AIE_OK;
 }
 
-// Development aid (not part of include/aie.h): device buffer of 12*E uint64 clock stamps per launch.
-int aie_dev_set_trace(aie_env* env, void* d_buf) {
-  if (!env) return AIE_E_INVALID;
-  env->P.dev_trace = static_cast<uint64_t*>(d_buf);
+static int aie_dev_push_params(aie_env* env) {
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   AIE_HIP_CHECK(env, hipDeviceSynchronize());
   AIE_HIP_CHECK(env, hipMemcpy(env->d_params, &env->P, sizeof(aie_params), hipMemcpyHostToDevice));
   return AIE_OK;
 }
 
-// Development aid (not part of include/aie.h): extra dynamic LDS per workgroup (lowers residency).
-int aie_dev_set_lds_pad(aie_env* env, int bytes) {
+// device buffer of 12*E uint64 clock stamps per launch
+AIE_DEV_API int aie_dev_set_trace(aie_env* env, void* d_buf) {
+  if (!env) return AIE_E_INVALID;
+  env->P.dev_trace = static_cast<uint64_t*>(d_buf);
+  return aie_dev_push_params(env);
+}
+
+// extra dynamic LDS per workgroup (lowers residency)
+AIE_DEV_API int aie_dev_set_lds_pad(aie_env* env, int bytes) {
   if (!env || bytes < 0) return AIE_E_INVALID;
   env->lds += (size_t)bytes;
   return AIE_OK;
 }
 
-// Development aid (not part of include/aie.h): a smaller draw window for the components (the environment then runs
-// aie_step_kernel_log), so that tests reach the refill path on every step.
-int aie_dev_set_draw_window(aie_env* env, int words) {
+// a smaller draw window for the components (the environment then runs aie_step_kernel_log), so that tests reach the
+// refill path on every step
+AIE_DEV_API int aie_dev_set_draw_window(aie_env* env, int words) {
   if (!env || words < 0) return AIE_E_INVALID;
   env->P.dev_draw_window = words;
   env->P.dev_skip_mask = words ? (env->P.dev_skip_mask | (1 << 20)) : (env->P.dev_skip_mask & ~(1 << 20));
-  AIE_HIP_CHECK(env, hipSetDevice(env->device));
-  AIE_HIP_CHECK(env, hipDeviceSynchronize());
-  AIE_HIP_CHECK(env, hipMemcpy(env->d_params, &env->P, sizeof(aie_params), hipMemcpyHostToDevice));
-  return AIE_OK;
+  return aie_dev_push_params(env);
 }
 
-// Development aid (not part of include/aie.h): phases of the step kernel to skip.
-int aie_dev_set_skip_mask(aie_env* env, int mask) {
+// phases of the step kernel to skip
+AIE_DEV_API int aie_dev_set_skip_mask(aie_env* env, int mask) {
   if (!env) return AIE_E_INVALID;
   env->P.dev_skip_mask = mask;
-  AIE_HIP_CHECK(env, hipSetDevice(env->device));
-  AIE_HIP_CHECK(env, hipDeviceSynchronize());
-  AIE_HIP_CHECK(env, hipMemcpy(env->d_params, &env->P, sizeof(aie_params), hipMemcpyHostToDevice));
-  return AIE_OK;
+  return aie_dev_push_params(env);
 }
+#endif  // AIE_DEV
 
 }  // extern "C"

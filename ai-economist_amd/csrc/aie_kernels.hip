@@ -2388,6 +2388,7 @@ aie_step_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict_
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   step_body<2, false, SPEC>(params, arena, act_a, act_p, lds, next);
 }
+#ifdef AIE_DEV
 // development: the compile-time instances with per-workgroup clock stamps (tools/block_trace.py, aie_dev_set_trace)
 template <int SPEC>
 __global__ void __launch_bounds__(2 * AIE_NT)
@@ -2397,6 +2398,7 @@ aie_step_kernel_spec_trace(const aie_params* __restrict__ params, uint8_t* __res
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   step_body<2, false, SPEC, true>(params, arena, act_a, act_p, lds, next);
 }
+#endif
 
 namespace aie {
 // LDS the layout generator needs behind the reset kernel's regular regions: two f64 planes + two byte planes + the

@@ -30,7 +30,10 @@ class DeviceBackend:
         torch = _torch()
         if not torch.cuda.is_available():
             raise AieError("no HIP device visible: the batched env has no CPU fallback")
-        self.lib = _native.lib()
+        # AIE_DEV_LIB=1: the -DAIE_DEV build with the development hooks (tools/, a few tests); never the default
+        import os
+
+        self.lib = _native.lib(dev=os.environ.get("AIE_DEV_LIB") == "1")
         self.cfg = cfg
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())

@@ -31,6 +31,20 @@ class WealthRedistribution(BaseComponent):
         pass
 
 
+def _default_world_size():
+    """Ranks whose replicas pool their Saez samples: the initialised process group, else the launcher's WORLD_SIZE."""
+    import os
+
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return int(dist.get_world_size())
+    except ImportError:
+        pass
+    return max(1, int(os.environ.get("WORLD_SIZE", "1")))
+
+
 @component_registry.add
 class PeriodicBracketTax(BaseComponent):
     name = "PeriodicBracketTax"
@@ -59,6 +73,10 @@ class PeriodicBracketTax(BaseComponent):
             assert self._saez_fixed_elas >= 0
         # samples a replica collects before the formula replaces random rates (redistribution.py:276)
         self._buffer_size = 500
+        # pairs the pooled (global) buffer can hold: None = every replica of every rank with a full local buffer
+        # (world_size * n_envs * _buffer_size, see pooled_saez_capacity); set it before the first reset() to pool
+        # several environments per rank
+        self._global_buffer_capacity = None
         self.tax_annealing_schedule = tax_annealing_schedule
         if tax_annealing_schedule is not None:  # redistribution.py:317-325
             assert isinstance(self.tax_annealing_schedule, (tuple, list))
@@ -149,7 +167,8 @@ class PeriodicBracketTax(BaseComponent):
     def set_global_saez_buffer(self, global_saez_buffer, env=None):
         """redistribution.py:530-533: from now on every replica's period start uses this buffer followed by its own
         samples added since the buffers were last reset.  `global_saez_buffer`: [G, 2] pairs (tensor / array / list),
-        G <= the capacity fixed at construction (`_global_buffer_capacity`, default n_envs * _buffer_size)."""
+        G <= the capacity fixed at construction (`_global_buffer_capacity`, default world_size * n_envs * _buffer_size:
+        what every replica of every rank can pool)."""
         import torch
 
         env = env or self._env
@@ -159,9 +178,22 @@ class PeriodicBracketTax(BaseComponent):
             g = torch.as_tensor(np.asarray(g, np.float64).reshape(-1, 2))
         g = g.to(device=be.device, dtype=torch.float64).contiguous()
         assert g.ndim == 2 and g.shape[1] == 2
+        cap = self.pooled_saez_capacity(env)
+        if g.shape[0] > cap:
+            raise ValueError("global Saez buffer of %d pairs exceeds the capacity this environment was built with (%d = "
+                             "_global_buffer_capacity, default world_size * n_envs * _buffer_size): set "
+                             "PeriodicBracketTax._global_buffer_capacity before the first reset()" % (g.shape[0], cap))
         assert g.shape[0] == 0 or g.shape[0] >= int(be.tensors["saez_buffer_len"].max().item()), \
             "the global buffer must hold at least as many samples as a local one (redistribution.py:532)"
         be._check(be.lib.aie_set_global_saez_buffer(be.handle, g.data_ptr() if g.shape[0] else None, int(g.shape[0])))
+
+    def pooled_saez_capacity(self, env=None):
+        """Pairs the global buffer of `env` holds (fixed when its device arena is built)."""
+        env = env or self._env
+        cap = self._global_buffer_capacity
+        if cap is not None:
+            return int(cap)
+        return _default_world_size() * int(env.n_envs) * int(self._buffer_size)
 
     def get_n_actions(self, agent_cls_name):
         if agent_cls_name == "BasicPlanner":
@@ -178,8 +210,10 @@ class PeriodicBracketTax(BaseComponent):
         cfg.tax_rate_min = float(self.rate_min)
         cfg.saez_buffer_size = int(self._buffer_size)
         if self.tax_model == "saez":
-            cap = getattr(self, "_global_buffer_capacity", None)
-            cfg.saez_global_capacity = int(cap if cap is not None else cfg.n_envs * int(self._buffer_size))
+            # every replica of every rank may pool a full local buffer (sharding.accumulate_and_broadcast_saez_buffers)
+            cap = self._global_buffer_capacity
+            cfg.saez_global_capacity = int(cap if cap is not None
+                                           else _default_world_size() * cfg.n_envs * int(self._buffer_size))
         cfg.saez_pareto_weight_uniform = int(self.pareto_weight_type == "uniform")
         cfg.saez_fixed_elas_given = int(self._saez_fixed_elas is not None)
         cfg.saez_fixed_elas = float(self._saez_fixed_elas or 0.0)

@@ -177,6 +177,15 @@ def accumulate_and_broadcast_saez_buffers(envs, component_name="PeriodicBracketT
         envs = [envs]
     comps = [env.get_component(component_name) for env in envs]
     local = torch.cat([c.local_saez_samples(env) for c, env in zip(comps, envs)], dim=0)
+    # capacity check up front: the pooled buffer can reach (ranks) x (replicas of every listed environment) x (local
+    # buffer size) once the local buffers are full -- fail now, with the remedy, not in the middle of training
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    worst = world * sum(int(env.n_envs) * int(c._buffer_size) for c, env in zip(comps, envs))
+    for c, env in zip(comps, envs):
+        if c.pooled_saez_capacity(env) < worst:
+            raise ValueError("pooling %d rank(s) x %d environment(s) can reach %d Saez samples, but an environment's global "
+                             "buffer holds %d: set PeriodicBracketTax._global_buffer_capacity = %d on the component before "
+                             "the first reset()" % (world, len(envs), worst, c.pooled_saez_capacity(env), worst))
     if dist.is_initialized() and dist.get_world_size() > 1:
         world = dist.get_world_size()
         n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)

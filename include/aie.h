@@ -39,6 +39,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported
+ * (tests/test_cabi_symbols.py compares `nm -D` with this file). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define AIE_ABI_VERSION 8
 
@@ -384,8 +389,10 @@ int aie_set_reward_log(aie_env* env, float* d_log, int32_t n_slots);
  * its state and observations are those of the fresh episode, `done` and the rewards stay the terminal step's.
  * one-step-economy does it inside the step launch (the terminal observations, which nothing could read before they
  * are overwritten, are not written at all); the other scenarios enqueue their reset kernel, masked with `done`,
- * right behind the step.  AIE_E_UNSUPPORTED for scenarios whose reset has a host-side part (uniform/, quadrant/,
- * multi_zone/ layouts).  Episode metrics of a finished episode are gone once it restarts. */
+ * right behind the step (uniform/, quadrant/ and multi_zone/ layouts are drawn inside that reset kernel).
+ * AIE_E_UNSUPPORTED only when the HOST supplies a new layout per episode (per-replica layouts passed to
+ * aie_set_layout: worlds too large for the device-side generator).  Episode metrics of a finished episode are gone
+ * once it restarts. */
 int aie_set_auto_reset(aie_env* env, int on);
 
 /* tax_model "saez": the cross-replica sample buffer (reference: PeriodicBracketTax.set_global_saez_buffer,
@@ -403,6 +410,14 @@ int aie_sizeof_config(void);
  * into the code, csrc/aie_spec_generated.h), -1 = the generic kernel. */
 int aie_step_kernel_instance(aie_env* env);
 
+/* Chooses between the step kernels that can run this environment: AIE_KERNEL_AUTO (default) = the specialised
+ * instance when one matches the configuration, AIE_KERNEL_GENERIC = the generic kernel that reads the parameter block
+ * at run time.  Both produce the same arena bit for bit (tests/test_gpu_parity.py steps them side by side); the
+ * switch exists so that a user can check exactly that on their own configuration. */
+#define AIE_KERNEL_AUTO 0
+#define AIE_KERNEL_GENERIC 1
+int aie_select_step_kernel(aie_env* env, int which);
+
 /* Same counter RNG, but each sub-action is drawn uniformly among the entries that the
  * CURRENT action masks allow (obs_a_action_mask / obs_p_action_mask; NO-OP is always
  * allowed).  This is the random policy a trainer starts from when it applies the
@@ -411,6 +426,9 @@ int aie_step_kernel_instance(aie_env* env);
 int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_offset, int32_t* d_actions_a,
                               int32_t* d_actions_p, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

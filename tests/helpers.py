@@ -1,5 +1,6 @@
 """Shared test helpers: golden fixtures, config building, state comparison."""
 import glob
+import contextlib
 import json
 import os
 
@@ -65,6 +66,21 @@ def make_env(cfg, n_envs=1, **extra):
     kw["components"] = [tuple(c) for c in kw["components"]]
     kw.update(extra)
     return foundation.make_env_instance(scenario, n_envs=n_envs, **kw)
+
+
+@contextlib.contextmanager
+def dev_library():
+    """Environments whose device backend is created inside this block load libaie_hip_dev.so (the -DAIE_DEV build:
+    aie_dev_* hooks, traced kernels); everything else in the process stays on the shipping library."""
+    old = os.environ.get("AIE_DEV_LIB")
+    os.environ["AIE_DEV_LIB"] = "1"
+    try:
+        yield
+    finally:
+        if old is None:
+            del os.environ["AIE_DEV_LIB"]
+        else:
+            os.environ["AIE_DEV_LIB"] = old
 
 
 def state_from_golden(g, prefix, t=None):

@@ -27,6 +27,15 @@ def test_library_exports_every_declared_symbol():
     from ai_economist_amd import _cabi
 
     assert set(_cabi.EXPORTED_SYMBOLS) == declared
+    # ... and nothing else: the shipping library is built with -fvisibility=hidden, so no kernel stub, development
+    # hook (aie_dev_*, -DAIE_DEV build only) or helper leaks into its dynamic symbol table
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    exported -= {"_init", "_fini", "__bss_start", "_edata", "_end"}
+    assert exported == declared, "undeclared exports: %s; missing: %s" % (sorted(exported - declared),
+                                                                          sorted(declared - exported))
 
 
 def test_arena_bytes_and_validation_without_gpu():

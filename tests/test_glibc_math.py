@@ -108,7 +108,7 @@ def test_device_pow_exp_equal_host_libm_bit_for_bit():
 
     from ai_economist_amd import _native
 
-    lib = _native.lib()
+    lib = _native.lib(dev=True)  # the hook lives in the -DAIE_DEV build only
     vp = ctypes.c_void_p
     lib.aie_test_glibc_math.restype = ctypes.c_int
     lib.aie_test_glibc_math.argtypes = [ctypes.c_int, vp, vp, vp, ctypes.c_int64, vp]

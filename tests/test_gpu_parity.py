@@ -6,7 +6,7 @@ import zlib
 import numpy as np
 import pytest
 
-from helpers import (F64_FIELDS, INT_FIELDS, compare_state, golden_names, load_golden, make_env,
+from helpers import (F64_FIELDS, INT_FIELDS, compare_state, dev_library, golden_names, load_golden, make_env,
                      state_from_golden)
 
 pytestmark = pytest.mark.gpu
@@ -801,7 +801,9 @@ def test_compile_time_instance_equals_generic_kernel(n_agents):
     base = dict(C1_INSTANCE) if n_agents == "c1" else dict(C2, n_agents=n_agents)
     cfg = dict(base, episode_length=150)
     cfg_spec = dict(base)
-    env_s = make_env(cfg_spec, n_envs=8, device="cuda:0")
+    with dev_library():  # aie_dev_lds_bytes below is a development hook
+        env_s = make_env(cfg_spec, n_envs=8, device="cuda:0")
+        env_s.backend
     k_inst = env_s.backend.lib.aie_step_kernel_instance(env_s.backend.handle)
     assert k_inst >= 0, "no compile-time instance selected"
     # the occupancy the instance is compiled for (_specs.py) is what its LDS footprint lets a CU hold
@@ -824,8 +826,7 @@ def test_compile_time_instance_equals_generic_kernel(n_agents):
         env.seed(21)
         env.reset()
     b_spec, b_ref = pair[0].backend, pair[1].backend
-    b_ref.lib.aie_dev_use_generic_kernel.argtypes = [ctypes.c_void_p]
-    assert b_ref.lib.aie_dev_use_generic_kernel(b_ref.handle) == 0
+    assert b_ref.lib.aie_select_step_kernel(b_ref.handle, 1) == 0  # AIE_KERNEL_GENERIC
     assert b_spec.lib.aie_step_kernel_instance(b_spec.handle) >= 0 and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == -1
     cur_s = b_spec.sample_random_actions(seed=4, slot=0)
     slot = 0
@@ -855,10 +856,11 @@ def test_draw_window_refills_do_not_change_the_stream(words):
     import torch
 
     cfg = dict(C2, n_agents=10, episode_length=60)
-    ref, small = (make_env(cfg, n_envs=192, device="cuda:0") for _ in range(2))
-    for env in (ref, small):
-        env.seed(8)
-        env.reset()
+    with dev_library():  # aie_dev_set_draw_window is a development hook
+        ref, small = [make_env(cfg, n_envs=192, device="cuda:0") for _ in range(2)]
+        for env in (ref, small):
+            env.seed(8)
+            env.reset()
     lib = small.backend.lib
     lib.aie_dev_set_draw_window.argtypes = [ctypes.c_void_p, ctypes.c_int]
     assert lib.aie_dev_set_draw_window(small.backend.handle, words) == 0
@@ -892,8 +894,7 @@ def test_compile_time_instance_equals_generic_kernel_one_step_economy():
         env.seed(5)
         env.reset()
     b_spec, b_ref = pair[0].backend, pair[1].backend
-    b_ref.lib.aie_dev_use_generic_kernel.argtypes = [ctypes.c_void_p]
-    assert b_ref.lib.aie_dev_use_generic_kernel(b_ref.handle) == 0
+    assert b_ref.lib.aie_select_step_kernel(b_ref.handle, 1) == 0  # AIE_KERNEL_GENERIC
     assert b_spec.lib.aie_step_kernel_instance(b_spec.handle) >= 0 and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == -1
     for t in range(9):
         if t == 4:

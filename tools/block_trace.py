@@ -3,6 +3,8 @@
 to see launch stagger / tail effects.  GPU only."""
 import ctypes
 import os
+
+os.environ["AIE_DEV_LIB"] = "1"  # the aie_dev_* hooks live in libaie_hip_dev.so (-DAIE_DEV) only
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +23,7 @@ env.seed(1)
 env.reset()
 be = env.backend
 if len(sys.argv) > 2 and sys.argv[2] == "generic":
-    be.lib.aie_dev_use_generic_kernel(be.handle)
+    be.lib.aie_select_step_kernel(be.handle, 1)
 print("n_agents", N_AGENTS, "step kernel instance", be.lib.aie_step_kernel_instance(be.handle))
 lds = (ctypes.c_int64 * 6)()
 be.lib.aie_dev_lds_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

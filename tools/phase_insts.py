@@ -4,6 +4,8 @@
 counts to phases (parse with tools/phase_insts_report.py)."""
 import ctypes
 import os
+
+os.environ["AIE_DEV_LIB"] = "1"  # the aie_dev_* hooks live in libaie_hip_dev.so (-DAIE_DEV) only
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

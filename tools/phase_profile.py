@@ -3,6 +3,8 @@
 (aie_dev_set_skip_mask) to see where a launch spends its time.  GPU only."""
 import ctypes
 import os
+
+os.environ["AIE_DEV_LIB"] = "1"  # the aie_dev_* hooks live in libaie_hip_dev.so (-DAIE_DEV) only
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,8 @@
 """Experiment: step time against workgroups per CU (extra dynamic LDS lowers the residency): is one full round plus
 a tail better or worse than balanced rounds?  usage: residency_experiment.py N_AGENTS PAD_BYTES..."""
 import os
+
+os.environ["AIE_DEV_LIB"] = "1"  # the aie_dev_* hooks live in libaie_hip_dev.so (-DAIE_DEV) only
 import sys
 import time
 

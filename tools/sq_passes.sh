@@ -15,15 +15,32 @@ for G in "$G1" "$G2" "$G3"; do
   tail -c 200 $R/gpurun_out/sq_${WL}_$k.log
 done
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, json
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
 for f in sorted(glob.glob("$R/gpurun_out/sq_${WL}_*/s_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "step_kernel" in k:
-            acc[k.split("(")[0][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[k.split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in sorted(glob.glob("$R/gpurun_out/sq_${WL}_*/s_kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "step_kernel" in k:
+            dur[k.split("(")[0][:60]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+out = {}
 for k, d in acc.items():
+    c = {name: sum(v) / len(v) for name, v in sorted(d.items())}
+    insts = sum(c.get(x, 0.0) for x in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_WR",
+                                        "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH"))
+    out[k] = {"counters": c, "launches_per_pass": len(next(iter(d.values()))),
+              "launch_ns_under_counters_mean": (sum(dur[k]) / len(dur[k])) if dur.get(k) else None,
+              "wave_instructions_per_launch": insts,
+              "note": "mean per launch; rocprofv3 --kernel-trace --pmc, one counter group per pass (tools/sq_passes.sh); "
+                      "cycle counters (SQ_*_CYCLES, SQ_WAIT_*, SQ_ACTIVE_*) in units of 4 clocks; launches run slower "
+                      "under counter collection than in the timed bench"}
     print(k)
-    for c, v in sorted(d.items()):
-        print("   %-26s mean %.4g  (n=%d)" % (c, sum(v) / len(v), len(v)))
+    for name, v in c.items():
+        print("   %-26s mean %.4g" % (name, v))
+json.dump(out, open("$R/gpurun_out/r03_${WL}_sq_counters.json", "w"), indent=1)
 PY
