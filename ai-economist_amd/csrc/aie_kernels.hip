@@ -252,6 +252,7 @@ __device__ __forceinline__ void sample_action_slot(const aie_params& P, uint64_t
 struct MT {
   uint32_t r[10];  // word 64*j + lane (row 9: lanes 0..47)
   int pos;         // wave-uniform index of the next unused word (624 = twist first)
+  int twists;      // mt_twist calls since the owner zeroed it (one-step-economy: the rows go back to HBM only then)
 };
 
 // Also collects, with LDS atomics, the list of regeneration draws that matter: double d of
@@ -388,6 +389,7 @@ __device__ __forceinline__ void mt_twist(MT& m, int lane) {
   t = mt_twist_rows(t, lane);
 #pragma unroll
   for (int j = 0; j < 10; ++j) m.r[j] = t.r[j];
+  m.twists += 1;
 }
 
 // sequential draws (wave-uniform: every lane gets the same value)

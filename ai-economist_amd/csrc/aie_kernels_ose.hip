@@ -16,10 +16,43 @@
 // limited by one wave's store issue rate, so one wave (and 13 replicas per CU) it stays.
 #define OSE_NT 64
 
+// development (libaie_hip_dev.so only): per-workgroup clock stamps of the step's phases (tools/ose_trace.py)
+#ifdef AIE_DEV
+#define OSE_STAMP(c, k)                                                                                        \
+  do {                                                                                                         \
+    if ((c).R.dev_trace && (c).tid == 0) (c).R.dev_trace[12 * blockIdx.x + (k)] = wall_clock64();              \
+  } while (0)
+// ablations (tools/ose_ablate.py): bits of aie_dev_set_skip_mask -- 1 flat rows, 2 mask rows, 4 metrics atomics,
+// 8 the small observation tensors, 16 record store, 32 record load (the LDS image is then garbage: timing only)
+#define OSE_SKIP(c, bit) (((c).R.dev_skip_mask & (bit)) != 0)
+#else
+#define OSE_STAMP(c, k) do { } while (0)
+#define OSE_SKIP(c, bit) false
+#endif
+
 namespace aie {
 
+// Per-lane registers of a replica's wave: lane l owns agents l and l + 64 (n <= 128).  The decoded SimpleLabor
+// actions and the two per-agent fields a step only reads -- skill and the escrow account (aie_layout.h keeps them
+// behind the generator key, outside the LDS image) -- never touch LDS.
+struct OseLane {  // scalars, not arrays: an array indexed by a loop variable ends up in scratch unless the loop unrolls
+  int act0, act1;
+  double skill0, skill1, esc0, esc1;
+  // this replica's per-agent episode accumulators behind env.metrics (mo_tax_income / mo_tax_paid), fetched with the
+  // record: a tax day adds to them and stores them back with plain stores -- the wave owns its replica's block, and
+  // 300 no-return atomics per replica-step (20 M per launch at BASELINE configs[4]) cost 0.31 of a 1.93 ms launch
+  double met_inc0, met_inc1, met_paid0, met_paid1;
+  float skobs0, skobs1;  // the SimpleLabor-skill observation (float)(skill / pmsm): the doubles die with the labor step
+  __device__ __forceinline__ float skobs(int k) const { return k ? skobs1 : skobs0; }
+  __device__ __forceinline__ int act(int k) const { return k ? act1 : act0; }
+  __device__ __forceinline__ double skill(int k) const { return k ? skill1 : skill0; }
+  __device__ __forceinline__ double esc(int k) const { return k ? esc1 : esc0; }
+};
+
+// the (at most two) agents of the calling lane: k = 0, 1 <-> agent i = tid, tid + 64
+#define OSE_MY_AGENTS(k, i, n) _Pragma("unroll") for (int k = 0, i = c.tid; k < 2; ++k, i += OSE_NT) if (i < (n))
+
 struct OseScratch {
-  int32_t* act;      // [n] SimpleLabor action per agent
   double* sorted;    // [n] sorted incomes / sorted coin
   double* coin;      // [n]
   double* tmp;       // [n]
@@ -30,7 +63,7 @@ struct OseScratch {
 
 __host__ __device__ inline size_t ose_lds_bytes(const aie_params& P) {
   size_t b = (size_t)rec_lds_bytes(P);
-  b += AIE_MAX_BRACKETS * 4 + (size_t)P.n * 4;
+  b += AIE_MAX_BRACKETS * 4;
   b = (b + 15) / 16 * 16;
   b += (size_t)(4 * P.n + 2) * 8;
   b += (size_t)(pad4(P.FA > P.MA ? P.FA : P.MA) + pad4(P.FP)) * 4;  // agent row template (flat vector, then mask) + planner's
@@ -42,8 +75,6 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, const aie_param
   uint8_t* q = lds + rec_lds_bytes(P);
   int32_t* act_p = reinterpret_cast<int32_t*>(q);
   q += AIE_MAX_BRACKETS * 4;
-  s.act = reinterpret_cast<int32_t*>(q);
-  q += P.n * 4;
   q = lds + ((q - lds) + 15) / 16 * 16;
   s.sorted = reinterpret_cast<double*>(q);
   s.coin = s.sorted + P.n;
@@ -57,24 +88,64 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, const aie_param
   return Ctx{P, R, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e};
 }
 
-__device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m) {
+// Record HBM -> LDS (the image before the generator key), key -> registers, cold per-agent fields -> registers.
+// Every load of a lane is issued before the first one is waited for: a replica starts while the other ~2800 resident
+// waves are streaming their observation rows out, and under that store traffic a load round trip takes several
+// microseconds -- the copy loop with one round trip per 16 bytes per lane cost 22 of a wave's 93 us (tools/ose_trace.py).
+__device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m, OseLane& L) {
   const uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
   const uint4* src = reinterpret_cast<const uint4*>(g);
   uint4* dst = reinterpret_cast<uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
-  for (int q = c.tid; q < nq; q += OSE_NT) dst[q] = src[q];
-  const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
   const int lane = c.tid & 63;
+  const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
+  const double* gs = reinterpret_cast<const double*>(g + c.P.o_skill);
+  const double* ge = reinterpret_cast<const double*>(g + c.P.o_esc_coin);
 #pragma unroll
   for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + lane];
   m.r[9] = lane < 48 ? key[576 + lane] : 0u;
+  m.twists = 0;
+  L.skill0 = c.tid < c.P.n ? gs[c.tid] : 0.0;
+  L.esc0 = c.tid < c.P.n ? ge[c.tid] : 0.0;
+  L.skill1 = c.tid + OSE_NT < c.P.n ? gs[c.tid + OSE_NT] : 0.0;
+  L.esc1 = c.tid + OSE_NT < c.P.n ? ge[c.tid + OSE_NT] : 0.0;
+  L.skobs0 = (float)(L.skill0 / c.P.c.labor_pmsm);
+  L.skobs1 = (float)(L.skill1 / c.P.c.labor_pmsm);
+  L.met_inc0 = L.met_inc1 = L.met_paid0 = L.met_paid1 = 0.0;
+  if (c.P.has_tax && c.met) {
+    const double* mi = reinterpret_cast<const double*>(c.met + c.P.mo_tax_income);
+    const double* mp = reinterpret_cast<const double*>(c.met + c.P.mo_tax_paid);
+    if (c.tid < c.P.n) { L.met_inc0 = mi[c.tid]; L.met_paid0 = mp[c.tid]; }
+    if (c.tid + OSE_NT < c.P.n) { L.met_inc1 = mi[c.tid + OSE_NT]; L.met_paid1 = mp[c.tid + OSE_NT]; }
+  }
+  // eight 16-byte loads in flight per lane and batch (one batch covers records up to 8 KiB); scalars rather than an
+  // array: the array stayed in scratch memory
+  // Fields every step overwrites before it reads them are not fetched: with tax_period == 1 every step is a tax day,
+  // which rewrites last_income / last_marginal_rate (adjacent in the record) before the observations look at them.
+  // HBM reads mixed into the launch's store stream cost about twice their byte share (tools/phase_overlap.hip).
+  const bool dead = c.P.has_tax && c.P.c.tax_period == 1;
+  const int dead_lo = (c.P.o_tax_last_income + 15) >> 4, dead_hi = (c.P.o_tax_last_marginal_rate + 8 * c.P.n) >> 4;
+  for (int q0 = c.tid; q0 < (OSE_SKIP(c, 32) ? 0 : nq); q0 += 8 * OSE_NT) {
+    uint4 v0, v1, v2, v3, v4, v5, v6, v7;
+#define OSE_LIVE(k) (q0 + (k) * OSE_NT < nq && !(dead && q0 + (k) * OSE_NT >= dead_lo && q0 + (k) * OSE_NT < dead_hi))
+#define OSE_LD(k) if (OSE_LIVE(k)) v##k = src[q0 + (k) * OSE_NT];
+#define OSE_ST(k) if (OSE_LIVE(k)) dst[q0 + (k) * OSE_NT] = v##k;
+    OSE_LD(0) OSE_LD(1) OSE_LD(2) OSE_LD(3) OSE_LD(4) OSE_LD(5) OSE_LD(6) OSE_LD(7)
+    OSE_ST(0) OSE_ST(1) OSE_ST(2) OSE_ST(3) OSE_ST(4) OSE_ST(5) OSE_ST(6) OSE_ST(7)
+#undef OSE_LD
+#undef OSE_ST
+#undef OSE_LIVE
+  }
 }
 
 // The draws of np.random.permutation(n) (World.get_random_order_agents, world.py:418-422) for a caller that never
 // looks at the order: only the position of the stream afterwards matters.  Fisher-Yates index i = n-1 .. 1 consumes
-// 32-bit words until one satisfies (word & mask(i)) <= i.  Instead of one word per loop trip on one lane, a block of
-// up to 64 consecutive words of the generator window is tempered at once (lane l: word pos + l) and every index is one
-// ballot over the not yet consumed lanes + find-first-set.
+// 32-bit words until one satisfies (word & mask(i)) <= i.  A block of up to 64 consecutive words of the generator
+// window is tempered at once (lane l: word pos + l) and all indices that share a mask (i in [2^k, 2^(k+1))) are
+// resolved together: word l of the block is accepted iff (w_l & mask) <= i0 - (accepted words before l) -- a fixed
+// point over the lanes (A -> ballot(v_l <= i0 - popcount(A below l))); its solution is unique (induction over l) and
+// equals the sequential loop's accept set, and the iteration reaches it because after k rounds the first k lanes are
+// final.  ~40 instructions per (block, mask group) instead of ~12 per index: 10 us -> 3 us of a C5 wave's step.
 __device__ __forceinline__ void rng_skip_permutation(MT& m, int lane, int n) {
   int i = n - 1;
   while (i >= 1) {
@@ -93,32 +164,48 @@ __device__ __forceinline__ void rng_skip_permutation(MT& m, int lane, int n) {
     }
     const uint32_t wa = lane_get(ra, src), wb = lane_get(rb, src);
     const uint32_t w = mt_temper((pos & 63) + lane < 64 ? wa : wb);
-    uint64_t open = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);  // lanes whose word is still unconsumed
-    while (i >= 1) {
+    int start = 0;  // first word of the block not consumed yet
+    while (i >= 1 && start < cnt) {
       uint32_t mask = (uint32_t)i;
       mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8;
-      const uint64_t acc = __ballot((w & mask) <= (uint32_t)i) & open;
-      if (acc == 0) { open = 0; break; }     // every remaining word of the block rejected for this index
-      const int p = __ffsll((unsigned long long)acc) - 1;
-      open &= ~((2ull << p) - 1ull);         // words up to and including p are consumed
-      --i;
-      if (open == 0) break;
+      const int g_lo = (int)(mask >> 1) + 1;  // the smallest index with this mask
+      const int need = i - g_lo + 1;          // accepted words that finish the group
+      const bool valid = lane >= start && lane < cnt;
+      const int v = (int)(w & mask);
+      uint64_t A = __ballot(valid && v <= i);
+      for (;;) {
+        const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(A >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)A, 0u));
+        const uint64_t A2 = __ballot(valid && v <= i - before);
+        if (A2 == A) break;
+        A = A2;
+      }
+      const int total = __popcll(A);
+      if (total >= need) {  // the group ends inside the block: behind its need-th accepted word
+        const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(A >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)A, 0u));
+        const uint64_t last = __ballot(((A >> lane) & 1ull) && before == need - 1);
+        start = __ffsll((unsigned long long)last);  // (index of that word) + 1
+        i = g_lo - 1;
+      } else {
+        i -= total;
+        start = cnt;
+      }
     }
-    m.pos = pos + (open == 0 ? cnt : (__ffsll((unsigned long long)open) - 1));
+    m.pos = pos + start;
   }
 }
 
 // SimpleLabor.component_step simple_labor.py:105-126.  The random agent order
 // (world.py:418-422) is drawn -- it advances the stream -- but the result does not depend
 // on it, so the update itself runs one lane per agent.
-__device__ __forceinline__ void labor_component_step(const Ctx& c, const OseScratch& s, MT& m) {
+__device__ __forceinline__ void labor_component_step(const Ctx& c, const OseScratch& s, MT& m, const OseLane& L) {
   const int n = c.P.n;
   rng_skip_permutation(m, c.tid & 63, n);
-  for (int i = c.tid; i < n; i += OSE_NT) {
-    const int a = s.act[i];
-    if (a != 0) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = c.tid + OSE_NT * k, a = L.act(k);
+    if (i < n && a != 0) {
       R_F64(c, o_labor)[i] = (double)a;  // hours worked this step (set, not accumulated)
-      const double payoff = (double)a * R_F64(c, o_skill)[i];
+      const double payoff = (double)a * L.skill(k);
       R_F64(c, o_production)[i] += payoff;
       R_F64(c, o_inv_coin)[i] += payoff;
     }
@@ -127,18 +214,18 @@ __device__ __forceinline__ void labor_component_step(const Ctx& c, const OseScra
 }
 
 // WealthRedistribution.component_step, F/components/redistribution.py:46-65
-__device__ __forceinline__ void ose_wealth_component_step(const Ctx& c, const OseScratch& s) {
+__device__ __forceinline__ void ose_wealth_component_step(const Ctx& c, const OseScratch& s, const OseLane& L) {
   const int n = c.P.n;
   __syncthreads();
-  for (int i = c.tid; i < n; i += OSE_NT) s.tmp[i] = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
+  OSE_MY_AGENTS(k, i, n) s.tmp[i] = R_F64(c, o_inv_coin)[i] + L.esc(k);
   __syncthreads();
   const double share = np_sum_small(s.tmp, n) / (double)n;  // every lane, same value
-  for (int i = c.tid; i < n; i += OSE_NT) R_F64(c, o_inv_coin)[i] = share - R_F64(c, o_esc_coin)[i];
+  OSE_MY_AGENTS(k, i, n) R_F64(c, o_inv_coin)[i] = share - L.esc(k);
   __syncthreads();
 }
 
 // PeriodicBracketTax.component_step :945-972 with enact_taxes :853-915
-__device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseScratch& s, MT& m) {
+__device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseScratch& s, MT& m, OseLane& L) {
   const int n = c.P.n;
   int pos = uni(*R_I32(c, o_tax_cycle_pos));
   if (pos == 1 && c.saez) {  // compute_and_set_new_period_rates_from_saez_formula (see tax_component_step)
@@ -165,9 +252,10 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
     __syncthreads();
   }
   if (pos >= c.P.c.tax_period) {
-    for (int i = c.tid; i < n; i += OSE_NT) {
+    int bin0 = -1, bin1 = -1;  // income bracket of this lane's agents (-1: no such agent)
+    OSE_MY_AGENTS(k, i, n) {
       const double coin = R_F64(c, o_inv_coin)[i];
-      const double income = (coin + R_F64(c, o_esc_coin)[i]) - R_F64(c, o_tax_last_coin)[i];
+      const double income = (coin + L.esc(k)) - R_F64(c, o_tax_last_coin)[i];
       const double due = tax_due(c, income);
       const double eff = coin < due ? coin : due;
       R_F64(c, o_tax_last_marginal_rate)[i] = tax_marginal_rate(c, income);
@@ -181,14 +269,25 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
         *reinterpret_cast<double*>(row + 10) = eff;
         if (i == 0) c.ev[0] = c.P.NB + n;
       }
-      // episode accumulators for get_metrics :1141-1186 (no-return atomics)
-      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_income) + i, income > 0 ? income : 0.0);
-      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_paid) + i, eff);
+      // episode accumulators for get_metrics :1141-1186: plain read-modify-write of the values fetched with the record
       int bin = 0;  // income_bin :828-835
       if (income >= 0)
         for (int b = 0; b < c.P.NB; ++b)
           if (income >= c.P.c.tax_bracket_cutoffs[b] && (b + 1 == c.P.NB || income < c.P.c.tax_bracket_cutoffs[b + 1])) { bin = b; break; }
-      atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_occ) + bin, 1);
+      if (k) { L.met_inc1 += income > 0 ? income : 0.0; L.met_paid1 += eff; bin1 = bin; }
+      else { L.met_inc0 += income > 0 ? income : 0.0; L.met_paid0 += eff; bin0 = bin; }
+      if (!OSE_SKIP(c, 4)) {
+        reinterpret_cast<double*>(c.met + c.P.mo_tax_income)[i] = k ? L.met_inc1 : L.met_inc0;
+        reinterpret_cast<double*>(c.met + c.P.mo_tax_paid)[i] = k ? L.met_paid1 : L.met_paid0;
+      }
+    }
+    {  // bracket occupancy: one ballot per bracket, lane b adds its bracket's count (NB no-return atomics per replica)
+      int mine = 0;
+      for (int b = 0; b < c.P.NB; ++b) {
+        const int cnt = __popcll(__ballot(bin0 == b)) + __popcll(__ballot(bin1 == b));
+        mine = c.tid == b ? cnt : mine;
+      }
+      if (c.tid < c.P.NB && mine && !OSE_SKIP(c, 4)) atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_occ) + c.tid, mine);
     }
     if (c.tid < c.P.NB) unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_sched) + c.tid, tax_rate(c, c.tid));
     if (c.ev && c.tid < c.P.NB) {  // the day's schedule: AIE_EV_TAX_BRACKET rows first
@@ -216,10 +315,10 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
       atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_days), 1);
     }
     const double lump = net / (double)n;
-    for (int i = c.tid; i < n; i += OSE_NT) {
+    OSE_MY_AGENTS(k, i, n) {
       const double v = R_F64(c, o_inv_coin)[i] + lump;
       R_F64(c, o_inv_coin)[i] = v;
-      R_F64(c, o_tax_last_coin)[i] = v + R_F64(c, o_esc_coin)[i];
+      R_F64(c, o_tax_last_coin)[i] = v + L.esc(k);
     }
     if (c.tid == 0) *R_F64(c, o_tax_total_collected) += net;
     if (c.saez) {  // _update_saez_buffer :533-541 (one wavefront per replica: OSE_NT == 64)
@@ -321,11 +420,11 @@ __device__ __forceinline__ double ose_gini(const OseScratch& s, double* cs, int 
 }
 
 // get_current_optimization_metrics one_step_economy.py:280-336 -> s.part[0..n]
-__device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s) {
+__device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s, const OseLane& L) {
   const aie_params& P = c.P;
   const int n = P.n;
-  for (int i = c.tid; i < n; i += OSE_NT) {
-    const double coin = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
+  OSE_MY_AGENTS(k, i, n) {
+    const double coin = R_F64(c, o_inv_coin)[i] + L.esc(k);
     const double labor = R_F64(c, o_labor)[i];
     s.coin[i] = coin;
     double u;
@@ -411,8 +510,26 @@ __device__ __forceinline__ void ose_store_rows(BufRsrc g, int n, int F, const fl
 
 // Observations + masks (one_step_economy.py:120-176, simple_labor.py:97-103,128-134,
 // redistribution.py:974-1104), flat vectors in sorted-key order (base_env.py:561-612).
+// The agents' action masks (simple_labor.py:97-103 through base_env.py:706-756): [NO-OP, hours...] (single-action) /
+// [NO-OP, hours...] of the only subspace (multi-action) -- every agent's row is the same, and it depends on nothing but
+// "is this the episode's first observation" (labor_mask_first_step).  The step kernel therefore issues these
+// n x MA floats (40 KB of a replica's 88 KB at BASELINE configs[4]) right after the record arrived, so that they drain
+// while the wave computes, instead of behind the flat vectors at the end of its life.
+__device__ __forceinline__ void ose_store_agent_masks(const Ctx& c, const OseScratch& s, uint8_t* __restrict__ arena,
+                                                      bool first_observation) {
+  const aie_params& P = c.P;
+  const float on = (first_observation && P.c.labor_mask_first_step) ? 0.0f : 1.0f;
+  const BufRsrc g = make_rsrc(arena + c.R.a_obs_a_mask + (int64_t)c.e * P.n * P.MA * 4, (uint32_t)(P.n * P.MA * 4));
+  __syncthreads();  // the row template goes through the agent template area
+  for (int q = c.tid; q < P.MA; q += OSE_NT) s.tmpl_a[q] = (q == 0 || P.n_sub_a == 0) ? 1.0f : on;
+  __syncthreads();
+  if (!OSE_SKIP(c, 2)) ose_store_rows(g, P.n, P.MA, s.tmpl_a, c.tid, -1, nullptr, -1, nullptr);
+  __syncthreads();
+}
+
 __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseScratch& s, uint8_t* __restrict__ arena,
-                                                       bool at_reset = false) {
+                                                       const OseLane& L, bool at_reset = false,
+                                                       bool agent_masks_done = false) {
   const aie_params& P = c.P;
   const int n = P.n, NB = P.NB, tid = c.tid;
   const int t = *R_I32(c, o_timestep);
@@ -437,8 +554,8 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
       else if (j == NB + 3 + n) s.tmpl_p[P.fp_tax + NB + 2 + n] = v;
     }
   }
-  for (int i = tid; i < n; i += OSE_NT) {
-    const double coin = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
+  OSE_MY_AGENTS(k, i, n) {
+    const double coin = R_F64(c, o_inv_coin)[i] + L.esc(k);
     s.coin[i] = coin;
     if (P.has_tax) s.tmp[i] = tax_marginal_rate(c, coin - R_F64(c, o_tax_last_coin)[i]);
   }
@@ -448,6 +565,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
     reinterpret_cast<float*>(arena + c.R.a_obs_p_time)[c.e] = tval;
   }
   __syncthreads();
+  OSE_STAMP(c, 4);
   // planner world-equality / world-normalized_per_capita_productivity (:161-172)
   if (n >= 30) rank_sort(s.coin, s.sorted, n, tid);
   __syncthreads();
@@ -457,19 +575,20 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
     s.tmpl_p[P.fp_world + 1] = (float)(np_sum_small(s.coin, n) / n / 1000);
   }
   __syncthreads();
+  OSE_STAMP(c, 5);
   // ---- agent flat vectors: the shared template with two per-agent entries ----
   {
     const BufRsrc g = make_rsrc(arena + c.R.a_obs_a_flat + (int64_t)c.e * n * P.FA * 4, (uint32_t)(n * P.FA * 4));
     const int i_mr = P.has_tax ? P.fa_tax + NB + 2 + n : -1;
     const int i_sk = P.has_labor ? P.fa_labor : -1;
     if (i_sk >= 0) {  // SimpleLabor-skill = skill / pmsm: n divisions, one lane per agent (s.part is free until the rewards)
-      for (int i = tid; i < n; i += OSE_NT) s.part[i] = R_F64(c, o_skill)[i] / P.c.labor_pmsm;
+      OSE_MY_AGENTS(k, i, n) s.part[i] = (double)L.skobs(k);  // (float)(skill / pmsm), simple_labor.py:128-134
       __syncthreads();
     }
-    ose_store_rows(g, n, P.FA, s.tmpl_a, tid, i_mr, s.tmp, i_sk, s.part);
+    if (!OSE_SKIP(c, 1)) ose_store_rows(g, n, P.FA, s.tmpl_a, tid, i_mr, s.tmp, i_sk, s.part);
     float* gt = reinterpret_cast<float*>(arena + c.R.a_obs_a_time) + (int64_t)c.e * n;
-    for (int i = tid; i < n; i += OSE_NT) gt[i] = tval;
-    if (P.FPA) {
+    if (!OSE_SKIP(c, 8)) for (int i = tid; i < n; i += OSE_NT) gt[i] = tval;
+    if (P.FPA && !OSE_SKIP(c, 8)) {
       float* gp = reinterpret_cast<float*>(arena + c.R.a_obs_p_agents) + (int64_t)c.e * n * P.FPA;
       for (int i = tid; i < n; i += OSE_NT) {
         gp[i * 3 + 0] = (float)s.tmp[i];
@@ -477,22 +596,15 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
         gp[i * 3 + 2] = (float)R_F64(c, o_tax_last_marginal_rate)[i];
       }
     }
-    stream_out(s.tmpl_p, reinterpret_cast<float*>(arena + c.R.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
+    if (!OSE_SKIP(c, 8)) stream_out(s.tmpl_p, reinterpret_cast<float*>(arena + c.R.a_obs_p_flat) + (int64_t)c.e * P.FP, P.FP, tid);
   }
+  OSE_STAMP(c, 6);
   // ---- masks ----
   {
-    float on = 1.0f;
-    if (P.has_labor) {
-      const int first = *R_I32(c, o_first_step);
-      if (first && P.c.labor_mask_first_step) on = 0.0f;
+    if (!agent_masks_done) {
+      const bool first = P.has_labor && *R_I32(c, o_first_step) != 0;
+      ose_store_agent_masks(c, s, arena, first);
     }
-    // single-action: [NO-OP, hours...]; multi-action: [NO-OP, hours...] of the only subspace -- every agent's row is
-    // the same; the row template goes through the (now free) agent template area
-    const BufRsrc g = make_rsrc(arena + c.R.a_obs_a_mask + (int64_t)c.e * n * P.MA * 4, (uint32_t)(n * P.MA * 4));
-    __syncthreads();
-    for (int q = tid; q < P.MA; q += OSE_NT) s.tmpl_a[q] = (q == 0 || P.n_sub_a == 0) ? 1.0f : on;
-    __syncthreads();
-    ose_store_rows(g, n, P.MA, s.tmpl_a, tid, -1, nullptr, -1, nullptr);
     if (at_reset && P.has_tax && P.c.tax_annealing) {  // generate_masks refreshes _last_completions after the reset's observations
       __syncthreads();
       if (tid == 0) *R_I32(c, o_tax_last_completions) = *R_I32(c, o_completions);
@@ -510,20 +622,26 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
     }
   }
   __syncthreads();
+  OSE_STAMP(c, 7);
   if (tid == 0 && P.has_labor) *R_I32(c, o_first_step) = 0;
 }
 
-__device__ __forceinline__ void ose_store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m) {
+// The generator's rows go back to HBM only when the step twisted them (a step draws ~130 of a window's 624 words;
+// the position is a record field), and as soon as the components are done: ten registers less for the rest of the step.
+__device__ __forceinline__ void ose_store_key(const Ctx& c, uint8_t* __restrict__ arena, const MT& m) {
+  if (m.twists == 0 || c.tid >= 64) return;  // (wave-uniform; every wave holds the same rows)
+  uint32_t* key = reinterpret_cast<uint32_t*>(arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes + c.P.o_mt);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
+  if (c.tid < 48) key[576 + c.tid] = m.r[9];
+}
+__device__ __forceinline__ void ose_store_record(const Ctx& c, uint8_t* __restrict__ arena) {
   uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
   uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
+  if (OSE_SKIP(c, 16)) return;
   for (int q = c.tid; q < nq; q += OSE_NT) dst[q] = src[q];
-  uint32_t* key = reinterpret_cast<uint32_t*>(g + c.P.o_mt);
-  if (c.tid >= 64) return;  // every wave holds the same rows
-#pragma unroll
-  for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
-  if (c.tid < 48) key[576 + c.tid] = m.r[9];
 }
 
 }  // namespace aie
@@ -533,14 +651,19 @@ __device__ __forceinline__ void ose_store_record(const Ctx& c, uint8_t* __restri
 // kernel for a replica that just finished its episode (auto-reset): the terminal step's rewards / done stay.
 namespace aie {
 __device__ __forceinline__ void ose_reset_body(const Ctx& c, const OseScratch& s, uint8_t* __restrict__ arena,
-                                               bool keep_rewards) {
+                                               OseLane& L, bool keep_rewards, bool agent_masks_done = false) {
   const aie_params& P = c.P;
   const int n = P.n, tid = c.tid, e = c.e;
   for (int q = tid; q < (P.met_bytes >> 2); q += OSE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
   if (c.ev && tid == 0) c.ev[0] = 0;
-  for (int i = tid; i < n; i += OSE_NT) {
-    R_F64(c, o_inv_coin)[i] = 0; R_F64(c, o_esc_coin)[i] = 0; R_F64(c, o_labor)[i] = 0;
-    R_F64(c, o_skill)[i] = P.has_labor ? c.R.c.labor_skills[i] : 0;
+  uint8_t* grec = arena + c.R.a_records + (int64_t)e * P.rec_bytes;  // skill / escrow live behind the LDS image
+  OSE_MY_AGENTS(k, i, n) {
+    R_F64(c, o_inv_coin)[i] = 0; R_F64(c, o_labor)[i] = 0;
+    const double sk = P.has_labor ? c.R.c.labor_skills[i] : 0;
+    const float so = (float)(sk / P.c.labor_pmsm);
+    if (k) { L.esc1 = 0; L.skill1 = sk; L.skobs1 = so; } else { L.esc0 = 0; L.skill0 = sk; L.skobs0 = so; }
+    reinterpret_cast<double*>(grec + P.o_esc_coin)[i] = 0;
+    reinterpret_cast<double*>(grec + P.o_skill)[i] = sk;
     R_F64(c, o_production)[i] = 0;
     if (P.has_tax) {
       R_F64(c, o_tax_last_coin)[i] = 0; R_F64(c, o_tax_last_income)[i] = 0; R_F64(c, o_tax_last_marginal_rate)[i] = 0;
@@ -563,10 +686,10 @@ __device__ __forceinline__ void ose_reset_body(const Ctx& c, const OseScratch& s
     if (tid < P.NB) R_F64(c, o_tax_saez_rates)[tid] = reinterpret_cast<const double*>(saez_block(c) + AIE_SAEZ_OFF_AVG)[tid];
     __syncthreads();
   }
-  ose_metrics(c, s);
+  ose_metrics(c, s, L);
   for (int i = tid; i <= n; i += OSE_NT) R_F64(c, o_util)[i] = s.part[i];
   __syncthreads();
-  ose_write_observations(c, s, arena, true);
+  ose_write_observations(c, s, arena, L, true, agent_masks_done);
   if (!keep_rewards) {
     for (int i = tid; i < n; i += OSE_NT) reinterpret_cast<float*>(arena + c.R.a_rew_a)[(int64_t)e * n + i] = 0.0f;
     if (tid == 0) {
@@ -592,18 +715,22 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
   const Ctx c = ose_make_ctx(P, R, lds, replica_of_block((int)blockIdx.x, R.E), (int)threadIdx.x, s, arena);
   const int n = P.n, tid = c.tid;
   MT m;
-  ose_load_record(c, arena, m);
+  OseLane L;
+  OSE_STAMP(c, 0);
+  ose_load_record(c, arena, m, L);
   // parse_actions (base_agent.py:407-438)
   bool bad_a = false, bad_p = false;  // out-of-range indices: NO-OP here, an exception in the reference (AIE_ERR_*)
-  for (int i = tid; i < n; i += OSE_NT) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = tid + OSE_NT * k;
     int a = 0;
-    if (act_a && P.n_sub_a) {
+    if (i < n && act_a && P.n_sub_a) {
       const int v = act_a[((int64_t)c.e * n + i) * P.act_a_width];
       bad_a |= v < 0 || v > P.sub_a_dim[0];
       if (P.c.multi_action_mode_agents) a = (v >= 0 && v <= P.sub_a_dim[0]) ? v : 0;
       else a = (v >= 1 && v < 1 + P.sub_a_dim[0]) ? v : 0;
     }
-    s.act[i] = a;
+    if (k) L.act1 = a; else L.act0 = a;
   }
   if (tid < AIE_MAX_BRACKETS) {
     int v = 0;
@@ -626,25 +753,33 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
     if (err && tid == 0) atomicOr(R_I32(c, o_error_flags), err);
   }
   __syncthreads();
+  OSE_STAMP(c, 1);
+  // the observations this launch leaves behind: the step's, or -- auto-reset, episode over -- the next episode's first
+  const bool will_restart = R.auto_reset && uni(*R_I32(c, o_timestep)) + 1 >= P.c.episode_length;
+  ose_store_agent_masks(c, s, arena, will_restart || (P.has_labor && uni(*R_I32(c, o_first_step)) != 0));
   m.pos = uni(*R_I32(c, o_mt_pos));
   if (tid == 0) *R_I32(c, o_timestep) += 1;
   if (c.ev && tid == 0) c.ev[0] = 0;
   for (int k = 0; k < P.c.n_components; ++k) {
-    if (P.c.components[k] == AIE_COMP_SIMPLE_LABOR) labor_component_step(c, s, m);
-    else if (P.c.components[k] == AIE_COMP_TAX) ose_tax_component_step(c, s, m);
-    else if (P.c.components[k] == AIE_COMP_WEALTH_REDISTRIBUTION) ose_wealth_component_step(c, s);
+    if (P.c.components[k] == AIE_COMP_SIMPLE_LABOR) labor_component_step(c, s, m, L);
+    else if (P.c.components[k] == AIE_COMP_TAX) ose_tax_component_step(c, s, m, L);
+    else if (P.c.components[k] == AIE_COMP_WEALTH_REDISTRIBUTION) ose_wealth_component_step(c, s, L);
+    OSE_STAMP(c, 2 + (k < 2 ? k : 1));
   }
   if (tid == 0) *R_I32(c, o_mt_pos) = m.pos;
+  ose_store_key(c, arena, m);
   __syncthreads();
   const bool done = uni(*R_I32(c, o_timestep)) >= P.c.episode_length;
   // auto-reset (aie_set_auto_reset): a replica that finishes its episode in this step restarts inside this launch;
   // its terminal observations would be overwritten by the reset's before anything can read them, so they are not
   // written (rewards and `done` are the terminal step's)
   const bool restart = done && R.auto_reset;
-  if (!restart) ose_write_observations(c, s, arena);
+  if (!restart) ose_write_observations(c, s, arena, L, false, true);
   __syncthreads();
+  OSE_STAMP(c, 8);
   // compute_reward one_step_economy.py:195-222
-  ose_metrics(c, s);
+  ose_metrics(c, s, L);
+  OSE_STAMP(c, 9);
   {
     double* util = R_F64(c, o_util);
     for (int i = tid; i <= n; i += OSE_NT) {
@@ -662,12 +797,14 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
     if (done) *R_I32(c, o_completions) += 1;
   }
   __syncthreads();
-  if (restart) ose_reset_body(c, s, arena, true);
+  OSE_STAMP(c, 10);
+  if (restart) ose_reset_body(c, s, arena, L, true, true);
   if (next.a || next.p) {  // aie_step_sample_next: the uniform random policy's draw for the next step
     const int per_env = P.n * P.act_a_width + P.act_p_width;
     for (int j = tid; j < per_env; j += OSE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, c.e, j, next.a, next.p);
   }
-  ose_store_record(c, arena, m);
+  ose_store_record(c, arena);
+  OSE_STAMP(c, 11);
 }
 
 extern "C" __global__ void __launch_bounds__(OSE_NT)
@@ -677,7 +814,8 @@ aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__
   ose_step_body<-1>(params, arena, act_a, act_p, next, lds);
 }
 template <int SPEC>
-__global__ void __launch_bounds__(OSE_NT)  // (capping at 128 VGPRs for 4 waves per SIMD spills: 2.15 vs 2.11 ms at C5)
+__global__ void __launch_bounds__(OSE_NT)
+__attribute__((amdgpu_waves_per_eu(aie_spec_image<SPEC>::waves, aie_spec_image<SPEC>::waves)))
 aie_ose_step_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                          const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -695,8 +833,9 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   OseScratch s;
   const Ctx c = ose_make_ctx(P, P, lds, e, (int)threadIdx.x, s, arena);
   MT m;
-  ose_load_record(c, arena, m);
+  OseLane L;
+  ose_load_record(c, arena, m, L);
   __syncthreads();
-  ose_reset_body(c, s, arena, false);
-  ose_store_record(c, arena, m);
+  ose_reset_body(c, s, arena, L, false);
+  ose_store_record(c, arena);
 }

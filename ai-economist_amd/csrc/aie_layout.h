@@ -596,9 +596,7 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
 
   int32_t cur = 0;
   p->o_inv_coin = aie__rec(&cur, 8 * n, 16);
-  p->o_esc_coin = aie__rec(&cur, 8 * n, 8);
   p->o_labor = aie__rec(&cur, 8 * n, 8);
-  p->o_skill = aie__rec(&cur, 8 * n, 8);
   p->o_production = aie__rec(&cur, 8 * n, 8);
   p->o_util = aie__rec(&cur, 8 * (n + 1), 8);
   if (p->has_tax) {
@@ -623,6 +621,11 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
   p->o_mt_pos = aie__rec(&cur, 4, 4);
   p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
   p->o_mt = aie__rec(&cur, 4 * AIE_MT_N, 16);
+  /* behind the generator: per-agent fields a step only reads (SimpleLabor's skills; the escrow account, which no
+   * component of this scenario moves) -- the kernels keep them in registers, they are not part of the LDS image
+   * (everything before o_mt), which is what decides how many replicas a CU holds at once */
+  p->o_skill = aie__rec(&cur, 8 * n, 16);
+  p->o_esc_coin = aie__rec(&cur, 8 * n, 8);
   p->rec_bytes = (int32_t)aie__align(cur, 16);
 
   const int64_t E = p->E;

@@ -96,10 +96,16 @@ def test_covid_oracle_matches_reference_golden(name):
 # ------------------------------------------------------------------------------------------
 # GPU: the HIP path through the C ABI
 # ------------------------------------------------------------------------------------------
-def hip_env(cfg, n_envs):
+def hip_env(cfg, n_envs, **extra):
     from ai_economist_amd import foundation
 
-    return foundation.make_env_instance("CovidAndEconomySimulation", n_envs=n_envs, **cfg)
+    return foundation.make_env_instance("CovidAndEconomySimulation", n_envs=n_envs, **dict(cfg, **extra))
+
+
+# Both instantiations of the step kernel are compared with the oracle / the reference's fixtures: the default
+# (aie_covid_step_kernel<F, false>: the reference's 600-tap window sums) and the opt-in O(1) recurrence
+# (filter_recurrence=True, <F, true>: what bench.py's C4 line runs).
+FILTER_MODES = pytest.mark.parametrize("recurrence", [False, True], ids=["window-sums", "recurrence"])
 
 
 def hip_state(env, e):
@@ -117,12 +123,14 @@ def hip_obs(env, e):
 
 
 @pytest.mark.gpu
+@FILTER_MODES
 @pytest.mark.parametrize("name", covid_golden_names())
-def test_covid_hip_matches_reference_golden(name):
+def test_covid_hip_matches_reference_golden(name, recurrence):
     import torch
 
     g = load_covid_golden(name)
-    env = hip_env(g["cfg"], n_envs=3)
+    env = hip_env(g["cfg"], n_envs=3, filter_recurrence=recurrence)
+    assert ("filter_discounted_delta_sums" in env.tensors) == recurrence
     env.reset()
     t = env.tensors
     steps = len(g["actions_p"])
@@ -140,14 +148,15 @@ def test_covid_hip_matches_reference_golden(name):
 
 
 @pytest.mark.gpu
+@FILTER_MODES
 @pytest.mark.parametrize("name,E,T", [("c4_covid_51ag", 64, 130), ("c4_covid_variant", 33, 100)])
-def test_covid_hip_matches_oracle_on_batched_rollouts(name, E, T):
+def test_covid_hip_matches_oracle_on_batched_rollouts(name, E, T, recurrence):
     """Every replica gets its own action stream; masked resets mid-run; HIP vs oracle."""
     import torch
 
     g = load_covid_golden(name)
     cfg = g["cfg"]
-    env = hip_env(cfg, n_envs=E)
+    env = hip_env(cfg, n_envs=E, filter_recurrence=recurrence)
     o = make_oracle(cfg, n_envs=E)
     env.reset()
     o.reset()
@@ -193,8 +202,9 @@ def test_covid_hip_matches_oracle_on_batched_rollouts(name, E, T):
 
 
 @pytest.mark.gpu
+@FILTER_MODES
 @pytest.mark.parametrize("seed", range(10))
-def test_covid_hip_matches_oracle_on_random_configs(seed):
+def test_covid_hip_matches_oracle_on_random_configs(seed, recurrence):
     """helpers.random_covid_config (seeds 0..7 are pinned against the live reference on CPU):
     HIP vs oracle over a whole episode, then a masked reset and a few more days."""
     import torch
@@ -202,7 +212,7 @@ def test_covid_hip_matches_oracle_on_random_configs(seed):
 
     cfg = random_covid_config(seed)
     E = 12
-    env = hip_env(cfg, n_envs=E)
+    env = hip_env(cfg, n_envs=E, filter_recurrence=recurrence)
     o = make_oracle(cfg, n_envs=E)
     env.reset()
     o.reset()
@@ -237,6 +247,55 @@ def test_covid_hip_matches_oracle_on_random_configs(seed):
     env.reset(t["done"])
     o.reset()
     compare("second reset")
+
+
+@pytest.mark.gpu
+@FILTER_MODES
+def test_covid_hip_follows_the_reference_consistency_procedure(recurrence):
+    """The reference's CPU<->GPU consistency check (tests/run_covid19_cpu_gpu_consistency_checks.py:43-101: run config
+    covid_and_economy_environment.yaml, 3 environments x 2 episodes x 540 steps, uniform random actions), with this
+    library in the place of its CUDA path and the NumPy oracle -- which tests/test_covid_reference.py follows through
+    the same procedure beside the LIVE reference -- in the place of its CPU path.  Its comparator's tolerance lives in
+    un-vendored WarpDrive; ours are the module docstring's."""
+    import torch
+
+    cfg = load_covid_golden("c4_covid_51ag")["cfg"]
+    assert cfg["episode_length"] == 540
+    E, EPISODES, T = 3, 2, 540
+    env = hip_env(cfg, n_envs=E, filter_recurrence=recurrence)
+    o = make_oracle(cfg, n_envs=E)
+    env.reset()
+    o.reset()
+    t = env.tensors
+    rng = np.random.RandomState(17)
+
+    def compare(where):
+        st = o.state()
+        for k, tol in STATE_TOL.items():
+            np.testing.assert_allclose(t[k].cpu().numpy().astype(np.float64), st[k], rtol=tol, atol=1e-3,
+                                       err_msg="%s %s" % (where, k))
+        assert np.array_equal(t["cooldown_until"].cpu().numpy(), st["cooldown_until"]), where
+        assert np.array_equal(t["subsidy_level"].cpu().numpy(), st["subsidy_level"]), where
+        for k, v in o.observe().items():
+            np.testing.assert_allclose(t[k].cpu().numpy().reshape(v.shape), v, rtol=1e-5, atol=1e-6,
+                                       err_msg="%s %s" % (where, k))
+
+    for ep in range(EPISODES):
+        compare("episode %d reset" % ep)
+        for k in range(1, T + 1):
+            a = rng.randint(0, 11, size=(E, 51)).astype(np.int32)
+            p = rng.randint(0, 21, size=(E,)).astype(np.int32)
+            env.step({"a": torch.as_tensor(a, device="cuda"), "p": torch.as_tensor(p[:, None], device="cuda")})
+            o.step(a, p)
+            np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), o.rew_a, rtol=0, atol=1e-5,
+                                       err_msg="episode %d day %d" % (ep, k))
+            np.testing.assert_allclose(t["rewards_p"].cpu().numpy(), o.rew_p, rtol=0, atol=1e-5,
+                                       err_msg="episode %d day %d" % (ep, k))
+            assert np.array_equal(t["done"].cpu().numpy(), o.done) and bool(o.done.all()) == (k == T)
+            if k % 30 == 0 or k == T:
+                compare("episode %d day %d" % (ep, k))
+        env.reset(t["done"])
+        o.reset()
 
 
 @pytest.mark.gpu
@@ -276,8 +335,8 @@ def test_covid_masked_reset_and_config_errors():
 
 @pytest.mark.gpu
 def test_covid_filter_recurrence_vs_exact_window_sums():
-    """The default step updates each unemployment filter's discounted delta sum in O(1) (the taps are exp(-age/lambda),
-    covid19_env.py:242-247); `exact_filter_sums=True` re-sums the 600-day window over the reference's float32 taps.
+    """`filter_recurrence=True` updates each unemployment filter's discounted delta sum in O(1) (the taps are
+    exp(-age/lambda), covid19_env.py:242-247); the default re-sums the 600-day window over the reference's float32 taps.
     Same actions through both: identical integer state, `unemployed` within 4e-6 relative (the reference's taps are
     float32 exp(-float32(age) / lambda): up to ~1.3e-6 off the exponential law they sample), everything downstream
     within the suite's tolerances."""
@@ -286,8 +345,9 @@ def test_covid_filter_recurrence_vs_exact_window_sums():
     g = load_covid_golden("c4_covid_51ag")
     cfg = g["cfg"]
     E, T = 96, 200
-    env_r = hip_env(cfg, n_envs=E)
-    env_x = hip_env(dict(cfg, exact_filter_sums=True), n_envs=E)
+    env_r = hip_env(cfg, n_envs=E, filter_recurrence=True)
+    env_x = hip_env(cfg, n_envs=E)  # the default: window sums
+    assert env_x.exact_filter_sums and not env_r.exact_filter_sums
     assert "filter_discounted_delta_sums" in env_r.tensors and "filter_discounted_delta_sums" not in env_x.tensors
     env_r.reset()
     env_x.reset()

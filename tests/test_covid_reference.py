@@ -174,6 +174,59 @@ def test_oracle_tracks_live_reference_covid(start_date, steps):
             check_metrics("step %d" % (t + 1))
 
 
+def test_oracle_follows_the_reference_consistency_procedure():
+    """The reference's own CPU<->GPU check (tests/run_covid19_cpu_gpu_consistency_checks.py:43-101: cfg =
+    run_configs/covid_and_economy_environment.yaml, 3 environments x 2 episodes x 540 steps, random actions) with the
+    oracle in the place of its CUDA path: three live reference environments with their own action streams beside one
+    3-replica oracle, through BOTH 540-day episodes (the second one starts from the reference's own reset)."""
+    from covid_oracle import CovidOracle
+
+    E, EPISODES, T = 3, 2, 540
+    envs = [ref_env(episode_length=T) for _ in range(E)]
+    obs = [env.reset() for env in envs]
+    o = CovidOracle(model_from_reference(envs[0]), comp_from_reference(envs[0]), n_envs=E, episode_length=T)
+    oo = o.reset()
+    rng = np.random.RandomState(17)
+
+    def check(where, obs, oo, rews=None):
+        for e in range(E):
+            for grp in ("a", "p"):
+                for k, v in obs[e][grp].items():
+                    if k == "world-agent_index":
+                        continue
+                    np.testing.assert_allclose(oo["obs_%s_%s" % (grp, k)][e], np.asarray(v, np.float64), rtol=2e-6, atol=1e-7,
+                                               err_msg="%s replica %d obs %s/%s" % (where, e, grp, k))
+            if rews is not None:
+                np.testing.assert_allclose(o.rew_a[e], np.asarray(rews[e]["a"], np.float64), rtol=1e-6, atol=1e-7, err_msg=where)
+                np.testing.assert_allclose(o.rew_p[e], float(rews[e]["p"]), rtol=1e-6, atol=1e-7, err_msg=where)
+            gs, st = envs[e].world.global_state, o.state()
+            for name, key in (("susceptible", "Susceptible"), ("infected", "Infected"), ("recovered", "Recovered"),
+                              ("deaths", "Deaths"), ("vaccinated", "Vaccinated"), ("unemployed", "Unemployed"),
+                              ("postsubsidy_productivity", "Postsubsidy Productivity")):
+                np.testing.assert_allclose(st[name][e], gs[key][envs[e].world.timestep], rtol=2e-6, atol=1e-3,
+                                           err_msg="%s replica %d state %s" % (where, e, name))
+
+    for ep in range(EPISODES):
+        check("episode %d reset" % ep, obs, oo)
+        for t in range(T):
+            a = rng.randint(0, 11, size=(E, 51))
+            p = rng.randint(0, 21, size=E)
+            rews, dones = [], []
+            for e, env in enumerate(envs):
+                acts = {str(i): int(a[e, i]) for i in range(51)}
+                acts["p"] = int(p[e])
+                ob, rew, done, _ = env.step(acts)
+                obs[e] = ob
+                rews.append(rew)
+                dones.append(bool(done["__all__"]))
+            oo = o.step(a, p)
+            assert dones == [bool(d) for d in o.done] == [t + 1 == T] * E
+            if t < 40 or t % 9 == 0 or t >= T - 3:
+                check("episode %d day %d" % (ep, t + 1), obs, oo, rews)
+        obs = [env.reset() for env in envs]
+        oo = o.reset()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_oracle_and_host_model_track_live_reference_random_covid_configs(seed):
     """Random scenario / component kwargs (helpers.random_covid_config): the NumPy oracle, driven by

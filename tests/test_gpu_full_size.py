@@ -122,10 +122,15 @@ def test_c5_full_batch_matches_oracle():
             compare("C5 episode reset")
 
 
-def test_c4_full_batch_matches_oracle():
+_C4_ORACLE = {}
+
+
+@pytest.mark.parametrize("recurrence", [False, True], ids=["window-sums", "recurrence"])
+def test_c4_full_batch_matches_oracle(recurrence):
     """BASELINE configs[3]: COVID, 51 states + planner, 8192 replicas, 64 days, every replica its own action
-    stream.  The NumPy oracle materialises the reference's [n, filters, 600] signal tensor per replica, so it runs
-    in cache-sized blocks of 8 replicas on worker subprocesses (tests/covid_pool.py)."""
+    stream; both instantiations of the step kernel (the default window sums and the O(1) recurrence that bench.py's
+    C4 line runs).  The NumPy oracle materialises the reference's [n, filters, 600] signal tensor per replica, so it
+    runs in cache-sized blocks of 8 replicas on worker subprocesses (tests/covid_pool.py), once for both."""
     import torch
     from covid_pool import run_blocks
     from helpers import load_covid_golden
@@ -134,7 +139,7 @@ def test_c4_full_batch_matches_oracle():
     E, T, B = 8192, 64, 8
     cfg = load_covid_golden("c4_covid_51ag")["cfg"]
     ns = dict(cfg["components"])["FederalGovernmentSubsidy"]["num_subsidy_levels"]
-    env = hip_env(cfg, n_envs=E)
+    env = hip_env(cfg, n_envs=E, filter_recurrence=recurrence)
     env.reset()
     t = env.tensors
     rng = np.random.RandomState(8)
@@ -142,7 +147,9 @@ def test_c4_full_batch_matches_oracle():
     acts_a[rng.rand(T, E, 51) < 0.5] = 0
     acts_p = rng.randint(0, ns + 1, size=(T, E)).astype(np.int32)
     check_at = (1, 30, T)
-    want = run_blocks(cfg, acts_a, acts_p, B, check_at, workers=min(16, NTHREADS))
+    if "want" not in _C4_ORACLE:
+        _C4_ORACLE["want"] = run_blocks(cfg, acts_a, acts_p, B, check_at, workers=min(16, NTHREADS))
+    want = _C4_ORACLE["want"]
     err_a, err_p = [], []
     for k in range(1, T + 1):
         env.step({"a": torch.as_tensor(acts_a[k - 1], device="cuda"),
@@ -168,8 +175,9 @@ def test_c4_full_batch_matches_oracle():
     # equal float32 numbers; the reference's own CPU<->CUDA tolerance is not in its repository)
     ea, ep = np.concatenate(err_a), np.concatenate(err_p)
     q = lambda x: [float(np.quantile(x, p)) for p in (0.5, 0.99, 0.9999, 1.0)]  # noqa: E731
-    print("C4 reward |error| (median, p99, p99.99, max): agents %s of %d, planner %s of %d" % (
-        ["%.2e" % v for v in q(ea)], ea.size, ["%.2e" % v for v in q(ep)], ep.size))
+    print("C4 (%s) reward |error| (median, p99, p99.99, max): agents %s of %d, planner %s of %d" % (
+        "recurrence" if recurrence else "window sums", ["%.2e" % v for v in q(ea)], ea.size,
+        ["%.2e" % v for v in q(ep)], ep.size))
 
 
 def test_c1_uniform_layouts_drawn_on_device_full_batch():
