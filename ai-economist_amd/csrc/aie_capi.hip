@@ -306,7 +306,8 @@ int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos) {
 
 // gather-trade-build reset: the compile-time instance of the environment's configuration if it has one
 static void aie_launch_gtb_reset(aie_env* env, const uint8_t* d_mask, int keep_rewards, void* stream) {
-  const dim3 g((unsigned)env->P.E), b(AIE_NT);
+  // LG_NW wavefronts per replica when the reset draws a new source layout (aie_kernels.hip: layout_generate), else one
+  const dim3 g((unsigned)env->P.E), b(env->P.c.layout_gen != AIE_LAYOUT_FIXED ? LG_NW * AIE_NT : AIE_NT);
   const size_t lds = env->lds + aie::layout_gen_lds_bytes(env->P);
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define AIE_SPEC_LAUNCH_RESET(K) \
@@ -318,7 +319,10 @@ static void aie_launch_gtb_reset(aie_env* env, const uint8_t* d_mask, int keep_r
     }
   }
 #undef AIE_SPEC_LAUNCH_RESET
-  hipLaunchKernelGGL(aie_reset_kernel, g, b, lds, st, env->d_params, env->arena, d_mask, keep_rewards);
+  if (env->P.c.layout_gen != AIE_LAYOUT_FIXED)
+    hipLaunchKernelGGL(aie_reset_kernel_layout, g, b, lds, st, env->d_params, env->arena, d_mask, keep_rewards);
+  else
+    hipLaunchKernelGGL(aie_reset_kernel, g, b, lds, st, env->d_params, env->arena, d_mask, keep_rewards);
 }
 
 int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {

@@ -194,9 +194,15 @@ __device__ __forceinline__ void buf_store_u32x2(BufRsrc r, uint32_t a, uint32_t 
   const u32x2 v = {a, b};
   __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
+// 16-byte buffer stores never carry a scalar offset REGISTER: measured on MI355X (round 3), `buffer_store_dwordx4
+// v[6:9], v25, s[8:11], s7 offen` followed directly by `v_mov_b32 v6, 2` stored the 2 in lanes 12-15 of every 16 --
+// the ">64-bit store data, then VALU write of those VGPRs" hazard exists on this part with an SGPR soffset too, while
+// the compiler (ROCm 7.2 clang, GCNHazardRecognizer::createsVALUHazard) only spaces the pair out when soffset is an
+// immediate.  With the offset folded into the vector offset and soffset = 0 the compiler inserts the wait state.
+// (tests/test_gpu_parity.py::test_reset_is_deterministic_across_environments is the check that found it.)
 __device__ __forceinline__ void buf_store_f32x4(BufRsrc r, float a, float b, float c, float d, int voff, int soff) {
   const u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, 0);
 }
 // 16 bytes with dword alignment: global dwordx4 accesses need no more on gfx950
 struct __attribute__((packed, aligned(4))) f32x4_a4 { float x, y, z, w; };
@@ -2403,91 +2409,216 @@ aie_step_kernel_spec_trace(const aie_params* __restrict__ params, uint8_t* __res
 #endif
 
 namespace aie {
-// LDS the layout generator needs behind the reset kernel's regular regions: two f64 planes + two byte planes + the
-// multi_zone region grid
-// ---- lane-parallel reads of the stream (reset-time layout generation): lane l wants the words at stream offsets
-// o_l .. relative to the START of the generator's current window, up to one window ahead.  `nxt` is the twisted copy
-// of `cur` (valid iff have_nxt); consuming words moves `cur.pos`, and the windows shift when it passes 624.
-struct MT2 {
-  MT cur, nxt;
-  bool have_nxt;
+// ------------------------------------------------------------------------------------------------------------------
+// Reset-time source layouts (uniform/, quadrant/, multi_zone/): FOUR wavefronts per replica.
+//
+// The algorithm (dynamic_layout.py:313-392) is a chain of whole-plane passes -- rand plane, threshold search, growth by
+// 7x7 random-kernel convolutions, coverage check, retry -- whose lengths depend on the draws, so one replica's
+// generation cannot be cut shorter than its chain; a masked reset lasts as long as its slowest replica (82 of 4096
+// replicas per reset at BASELINE configs[0]'s scenario: round 2's single wave took 0.26 ms on average and 1.2 ms for
+// the slowest).  What shortens the chain is running every plane pass cell-parallel over LG_NW x 64 lanes:
+//   * every wave keeps its own copy of the generator (three consecutive windows in registers) and advances it
+//     identically, so no random word ever crosses a wave boundary;
+//   * rand planes: 256 doubles per pass; legacy_gauss: 256 polar attempts per pass (an attempt's acceptance does not
+//     depend on the others; the waves exchange their 64-bit accept masks through LDS, rank the accepted attempts with
+//     a prefix over the masks and stop behind the attempt that completes the request, cache semantics included);
+//   * the threshold search ("tmp *= 0.9 until enough cells pass") advances every cell eight iterations at a time in
+//     registers and finds the stopping iteration from eight per-iteration counters: one barrier pair per eight
+//     iterations instead of an LDS round trip + ballot per iteration;
+//   * convolutions and coverage counts: one cell per lane (15x15: 225 of 256 lanes), counts meet in LDS.
+// Results are bit-identical to the sequential restatement (oracle/aie_oracle.c: layout_generate), which the CPU tests
+// pin to the live reference: every draw is consumed at the same stream offset, np.mean of a 0/1 plane is count / size,
+// signal.convolve2d(x, kernel, "same") is one add per kernel one in scipy's order over the zero-filled 7x7 window.
+// ------------------------------------------------------------------------------------------------------------------
+#define LG_NW 4
+#ifdef AIE_DEV  // per-replica phase clocks of layout_generate (tools/c1_reset_trace.py): dev_trace[12 e + k]
+#define LG_T0() const uint64_t lg_t0_ = wall_clock64()
+#define LG_ACC(k) do { lg_acc[k] += wall_clock64() - lg_t0_; } while (0)
+#define LG_CNT(k) do { lg_acc[k] += 1; } while (0)
+#else
+#define LG_T0() do { } while (0)
+#define LG_ACC(k) do { } while (0)
+#define LG_CNT(k) do { } while (0)
+#endif
+
+// Lane-parallel reads of the stream: a lane wants the word at stream offset o (counted from the start of window 0,
+// o < 3 * 624).  Window k + 1 is the twisted copy of window k (valid for k < have); consuming words moves `pos`
+// and shifts the windows down when it passes 624.  Everything here is wave-uniform except `o`.
+struct MT3 {
+  MT w[3];
+  int have;  // valid windows (>= 1)
+  int pos;   // next unused word of window 0
 };
-__device__ __forceinline__ void mt2_need_next(MT2& s, int lane) {
-  if (s.have_nxt) return;
+__device__ __forceinline__ void mt3_need(MT3& s, int k, int lane) {  // make windows 0..k valid (k <= 2)
+  if (s.have <= 1 && k >= 1) {
 #pragma unroll
-  for (int j = 0; j < 10; ++j) s.nxt.r[j] = s.cur.r[j];
-  mt_twist(s.nxt, lane);
-  s.have_nxt = true;
+    for (int j = 0; j < 10; ++j) s.w[1].r[j] = s.w[0].r[j];
+    mt_twist(s.w[1], lane);
+    s.have = 2;
+  }
+  if (s.have <= 2 && k >= 2) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) s.w[2].r[j] = s.w[1].r[j];
+    mt_twist(s.w[2], lane);
+    s.have = 3;
+  }
 }
-__device__ __forceinline__ uint32_t mt2_word(const MT2& s, int o) {  // tempered word at offset o (per lane), o < 1248
-  const bool second = o >= AIE_MT_N;
-  const int i = second ? o - AIE_MT_N : o;
-  uint32_t v = mt_window_word(s.cur, i);
-  if (__ballot(second) != 0) {  // (uniform: most passes stay inside the current window)
-    const uint32_t b = mt_window_word(s.nxt, i);
-    v = second ? b : v;
+// raw word i of one window for the lanes in `want` (a ballot; the lanes' rows lie in [rlo, rhi], wave-uniform)
+__device__ __forceinline__ uint32_t mt3_window_word(const MT& m, int i, uint32_t v, bool mine, int rlo, int rhi) {
+  const int row = i >> 6, ln = i & 63;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    if (r >= rlo && r <= rhi) {  // (wave-uniform)
+      const uint32_t t = lane_get(m.r[r], ln);
+      v = (mine && row == r) ? t : v;
+    }
+  }
+  return v;
+}
+// tempered word at offset o; o must be non-decreasing in the lane index (all call sites: o = base + stride * lane)
+__device__ __forceinline__ uint32_t mt3_word(const MT3& s, int o) {
+  const int win = o >= 2 * AIE_MT_N ? 2 : (o >= AIE_MT_N ? 1 : 0);
+  const int i = o - win * AIE_MT_N;
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint64_t want = __ballot(win == k);
+    if (want) {  // (wave-uniform) the first / last lane that reads this window bound the rows it touches
+      const int first = __ffsll((unsigned long long)want) - 1, last = 63 - __clzll((long long)want);
+      const int rlo = bcast(i, first) >> 6, rhi = bcast(i, last) >> 6;
+      v = mt3_window_word(s.w[k], i, v, win == k, rlo, rhi);
+    }
   }
   return mt_temper(v);
 }
-__device__ __forceinline__ void mt2_consume(MT2& s, int nwords, int lane) {  // nwords <= 624
-  s.cur.pos += nwords;
-  if (s.cur.pos >= AIE_MT_N) {
-    mt2_need_next(s, lane);
+// the four tempered words o .. o + 3 (one polar attempt): the window / row bookkeeping once for all four
+__device__ __forceinline__ void mt3_words4(const MT3& s, int o, uint32_t out[4]) {
+  uint32_t v[4] = {0, 0, 0, 0};
+  int win[4], idx[4];
 #pragma unroll
-    for (int j = 0; j < 10; ++j) s.cur.r[j] = s.nxt.r[j];
-    s.cur.pos -= AIE_MT_N;
-    s.have_nxt = false;
+  for (int j = 0; j < 4; ++j) {
+    win[j] = o + j >= 2 * AIE_MT_N ? 2 : (o + j >= AIE_MT_N ? 1 : 0);
+    idx[j] = o + j - win[j] * AIE_MT_N;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint64_t want = __ballot(win[0] == k || win[3] == k);  // (offsets are monotone in the lane and in j)
+    if (want) {
+      const int first = __ffsll((unsigned long long)want) - 1, last = 63 - __clzll((long long)want);
+      // rows touched in window k: from the first lane's first word that lies in it to the last lane's last word
+      const int lo_i = bcast(win[0], first) == k ? bcast(idx[0], first) : 0;
+      const int hi_i = bcast(win[3], last) == k ? bcast(idx[3], last) : AIE_MT_N - 1;
+      const int rlo = lo_i >> 6, rhi = hi_i >> 6;
+#pragma unroll
+      for (int r = 0; r < 10; ++r) {
+        if (r >= rlo && r <= rhi) {  // (wave-uniform)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t t = lane_get(s.w[k].r[r], idx[j] & 63);
+            v[j] = (win[j] == k && (idx[j] >> 6) == r) ? t : v[j];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[j] = mt_temper(v[j]);
+}
+__device__ __forceinline__ void mt3_consume(MT3& s, int nwords, int lane) {  // nwords <= 2 * 624
+  s.pos += nwords;
+  while (s.pos >= AIE_MT_N) {
+    mt3_need(s, 1, lane);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      s.w[0].r[j] = s.w[1].r[j];
+      s.w[1].r[j] = s.w[2].r[j];
+    }
+    s.have -= 1;
+    s.pos -= AIE_MT_N;
   }
 }
-// tmp[0 .. count) = rs.rand(count): 64 doubles per pass, lane l takes words pos + 2 l, + 1
-__device__ __forceinline__ void mt2_rand_plane(MT2& s, double* out, int count, int lane) {
-  for (int base = 0; base < count; base += AIE_NT) {
-    const int nb = count - base < AIE_NT ? count - base : AIE_NT;
-    if (s.cur.pos + 2 * nb > AIE_MT_N) mt2_need_next(s, lane);
-    const int o = s.cur.pos + 2 * lane;
-    const uint32_t a = mt2_word(s, lane < nb ? o : s.cur.pos), b = mt2_word(s, lane < nb ? o + 1 : s.cur.pos);
-    if (lane < nb) out[base + lane] = u53(a, b);
-    mt2_consume(s, 2 * nb, lane);
-  }
+
+struct LgShared {      // cross-wave scratch in LDS (behind the planes)
+  int32_t cnt[2][LG_NW];    // block_count: per-wave counts, two parities
+  uint32_t am[2][LG_NW][2]; // gauss: per-wave accept masks, two parities
+  int32_t thr[32];          // threshold search: cells on after iteration k of the current block
+  uint32_t kbits[2];        // growth kernel: sign bits of the 49 randn values
+};
+__host__ __device__ inline size_t layout_gen_lds_bytes(const aie_params& P) {
+  if (P.c.layout_gen == AIE_LAYOUT_FIXED) return 0;
+  const size_t hwp = ((size_t)P.HW + 15) / 16 * 16;
+  // tmp, x (f64), two byte planes, the multi_zone grid, the cross-wave scratch
+  return 2 * hwp * 8 + 2 * hwp + 256 * 4 + ((sizeof(LgShared) + 15) / 16 * 16);
 }
+// number of lanes of the whole workgroup for which `on` holds (every wave calls it; one barrier)
+__device__ __forceinline__ int lg_block_count(bool on, LgShared* sh, int& par, int wave, int lane) {
+  const int c = __popcll(__ballot(on));
+  if (lane == 0) sh->cnt[par][wave] = c;
+  __syncthreads();
+  int tot = 0;
+#pragma unroll
+  for (int w = 0; w < LG_NW; ++w) tot += sh->cnt[par][w];
+  par ^= 1;
+  return uni(tot);
+}
+// position (0-based) of the k-th set bit (k >= 1) of a wave-uniform mask, computed by the lanes
+__device__ __forceinline__ int lg_kth_bit(uint64_t mask, int k, int lane) {
+  const int before = __popcll(mask & lanemask_lt(lane));
+  const uint64_t hit = __ballot(((mask >> lane) & 1ull) && before == k - 1);
+  return __ffsll((unsigned long long)hit) - 1;
+}
+
 // The next `count` values of legacy_gauss (polar Box-Muller with a one-value cache, as rng_gauss): emit(k, value) is
-// called once for k = 0 .. count - 1, from the lane that owns the value.  64 attempts per pass: attempt a reads the
-// four words at pos + 4 a; its acceptance does not depend on the others, so the pass evaluates all of them, ranks
-// the accepted ones with a ballot and stops behind the attempt that completes the request; an accepted attempt
-// yields f * x2 and then (cached) f * x1.
+// called once for k = 0 .. count - 1 by the lane that owns the value.  LG_NW x 64 attempts per pass: attempt a reads
+// the four words at pos + 4 a.  Called by all waves; contains barriers.
 template <typename Emit>
-__device__ __forceinline__ void mt2_gauss(const Ctx& c, MT2& s, int count, int lane, Emit emit) {
+__device__ __forceinline__ void lg_gauss(const Ctx& c, MT3& s, int count, LgShared* sh, int& par, int wave, int lane, Emit emit) {
   int32_t* has = R_I32(c, o_mt_has_gauss);
   double* cache = R_F64(c, o_mt_gauss);
   int produced = 0;
-  if (count > 0 && uni(*has)) {
-    if (lane == 0) {
+  const bool cached = count > 0 && uni(*has) != 0;
+  __syncthreads();  // every wave has looked at the cache flag before anybody changes it
+  if (cached) {
+    if (wave == 0 && lane == 0) {
       emit(0, *cache);
       *has = 0;
       *cache = 0.0;
     }
-    AIE_WSYNC();
     produced = 1;
   }
   while (produced < count) {
     const int pairs = (count - produced + 1) >> 1;  // accepted attempts still needed
-    if (s.cur.pos + 4 * AIE_NT > AIE_MT_N) mt2_need_next(s, lane);
-    const int o = s.cur.pos + 4 * lane;
-    const double x1 = 2.0 * u53(mt2_word(s, o), mt2_word(s, o + 1)) - 1.0;
-    const double x2 = 2.0 * u53(mt2_word(s, o + 2), mt2_word(s, o + 3)) - 1.0;
+    mt3_need(s, (s.pos + 4 * LG_NW * AIE_NT - 1) / AIE_MT_N, lane);
+    const int a = wave * AIE_NT + lane, o = s.pos + 4 * a;
+    uint32_t w4[4];
+    mt3_words4(s, o, w4);
+    const double x1 = 2.0 * u53(w4[0], w4[1]) - 1.0;
+    const double x2 = 2.0 * u53(w4[2], w4[3]) - 1.0;
     const double r2 = x1 * x1 + x2 * x2;
     const bool acc = !(r2 >= 1.0 || r2 == 0.0);
     const uint64_t am = __ballot(acc);
-    const int rank = __popcll(am & lanemask_lt(lane));
-    int used = AIE_NT;  // attempts consumed by this pass
-    if (__popcll(am) >= pairs) {  // the attempt holding the pairs-th set bit ends the request
-      uint64_t t = am;
-      for (int k = 1; k < pairs; ++k) t &= t - 1;
-      used = __ffsll((unsigned long long)t);
+    if (lane == 0) {
+      sh->am[par][wave][0] = (uint32_t)am;
+      sh->am[par][wave][1] = (uint32_t)(am >> 32);
     }
-    if (acc && lane < used) {
+    __syncthreads();
+    int before_wave = 0, total = 0, used = LG_NW * AIE_NT;  // attempts consumed by this pass
+    bool found = false;
+#pragma unroll
+    for (int w = 0; w < LG_NW; ++w) {
+      const uint64_t mw = (uint64_t)sh->am[par][w][0] | ((uint64_t)sh->am[par][w][1] << 32);
+      const int cw = __popcll(mw);
+      if (w == wave) before_wave = total;
+      if (!found && total + cw >= pairs) {  // the attempt holding the pairs-th accepted one ends the request
+        used = w * AIE_NT + lg_kth_bit(mw, pairs - total, lane) + 1;
+        found = true;
+      }
+      total += cw;
+    }
+    par ^= 1;
+    if (acc && a < used) {
       const double f = sqrt(-2.0 * aie_log_glibc(r2) / r2);  // libm's log bit for bit; sqrt and / are IEEE-exact
-      const int k = produced + 2 * rank;
+      const int k = produced + 2 * (before_wave + __popcll(am & lanemask_lt(lane)));
       emit(k, f * x2);
       if (k + 1 < count) emit(k + 1, f * x1);
       else {  // the request ends on the first value of the pair: the second one stays cached
@@ -2495,67 +2626,62 @@ __device__ __forceinline__ void mt2_gauss(const Ctx& c, MT2& s, int count, int l
         *has = 1;
       }
     }
-    AIE_WSYNC();
-    const int got = 2 * __popcll(am & (used >= 64 ? ~0ull : ((1ull << used) - 1ull)));
-    produced += got;  // (may exceed count by one: the cached value)
-    mt2_consume(s, 4 * used, lane);
+    produced += 2 * (found ? pairs : total);  // (may exceed count by one: the cached value)
+    mt3_consume(s, 4 * used, lane);
   }
-}
-
-__host__ __device__ inline size_t layout_gen_lds_bytes(const aie_params& P) {
-  if (P.c.layout_gen == AIE_LAYOUT_FIXED) return 0;
-  const size_t hwp = ((size_t)P.HW + 15) / 16 * 16;
-  return 2 * hwp * 8 + 2 * hwp + 256 * 4 + 16;  // tmp, x (f64), two byte planes, the zone grid, the kernel's sign bits
+  __syncthreads();  // emitted values / cache visible to every wave
 }
 
 // Source layouts drawn at reset from the replica's own stream: Uniform.reset_starting_layout (dynamic_layout.py:313-392),
-// MultiZone's per-reset zone shuffle (:778-872), Quadrant's empty water lines (:992-1024).  One wavefront; every draw
-// is wave-uniform and in the reference's order (rand / randn planes row-major, the legacy gauss cache included),
-// np.mean of a 0/1 plane is count / size (ballots), signal.convolve2d(x, kernel, "same") is one multiply-add per
-// kernel element in scipy's order over the zero-filled 7x7 window (a zero kernel element adds +-0: skipped).
-// Restated for the checker in oracle/aie_oracle.c (layout_generate), which the CPU tests pin to the live reference.
-__device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8_t* __restrict__ arena, uint8_t* extra) {
+// MultiZone's per-reset zone shuffle (:778-872), Quadrant's empty water lines (:992-1024).  Called by all LG_NW waves
+// of the replica's workgroup (gtid = 0 .. LG_NW * 64 - 1); `m` is every wave's copy of the generator, advanced
+// identically.  c.tid is the lane.
+__device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8_t* __restrict__ arena, uint8_t* extra, int gtid) {
   const aie_params& P = c.P;
   const aie_config& g = P.c;
-  const int H = P.H, W = P.W, HW = P.HW, lane = c.tid;
+  const int H = P.H, W = P.W, HW = P.HW, lane = gtid & 63, wave = gtid >> 6;
+  constexpr int NT = LG_NW * AIE_NT;
   const int hwp = (HW + 15) / 16 * 16;
   double* tmp = reinterpret_cast<double*>(extra);
   double* x = tmp + hwp;
   uint8_t* mbp[2] = {reinterpret_cast<uint8_t*>(x + hwp), reinterpret_cast<uint8_t*>(x + hwp) + hwp};
   int32_t* grid = reinterpret_cast<int32_t*>(mbp[1] + hwp);
+  LgShared* sh = reinterpret_cast<LgShared*>(grid + 256);
+  int par = 0, gpar = 0;
   const double* shared_prob = reinterpret_cast<const double*>(arena + c.R.a_layout_prob);
   const bool mz = g.layout_gen == AIE_LAYOUT_MULTI_ZONE;
   double mz_scale[2] = {0.0, 0.0};
   int size_r = 1, size_c = 1;
   if (mz) {  // np.random.shuffle of the flat zone grid, then prob / np.mean(prob) * Wood's coverage
     const int regions = g.mz_rows * g.mz_cols;
-    for (int k = lane; k < regions; k += AIE_NT) {
+    for (int k = gtid; k < regions; k += NT) {
       int z = -1;
       if (k < g.mz_zones[0]) z = 0;
       else if (k < g.mz_zones[0] + g.mz_zones[1]) z = 1;
       else if (k < g.mz_zones[0] + g.mz_zones[1] + g.mz_zones[2]) z = 2;
       grid[k] = z;
     }
-    AIE_WSYNC();
-    for (int i = regions - 1; i >= 1; --i) {
+    __syncthreads();
+    for (int i = regions - 1; i >= 1; --i) {  // every wave draws; the first one swaps (nobody else reads the grid yet)
       const int j = (int)rng_interval(m, lane, (uint32_t)i);
-      if (lane == 0) { const int t = grid[i]; grid[i] = grid[j]; grid[j] = t; }
+      if (gtid == 0) { const int t = grid[i]; grid[i] = grid[j]; grid[j] = t; }
       AIE_WSYNC();
     }
+    __syncthreads();
     size_r = (H + g.mz_rows - 1) / g.mz_rows;
     size_c = (W + g.mz_cols - 1) / g.mz_cols;
     for (int rs = 0; rs < 2; ++rs) {
       const int own = rs == 1 ? 0 : 1;  // zone index: Wood 0, Stone 1, WoodStone 2
       int cnt = 0;
-      for (int base = 0; base < HW; base += AIE_NT) {
-        const int cell = base + lane;
+      for (int base = 0; base < HW; base += NT) {
+        const int cell = base + gtid;
         bool in = false;
         if (cell < HW) {
           const int r = cell / W, col = cell - r * W;
           const int z = grid[(r / size_r) * g.mz_cols + col / size_c];
           in = z == own || z == 2;
         }
-        cnt += __popcll(__ballot(in));
+        cnt += lg_block_count(in, sh, par, wave, lane);
       }
       mz_scale[rs] = (1.0 / ((double)cnt / (double)HW)) * g.layout_coverage[1];
     }
@@ -2571,107 +2697,216 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
     }
     return v * 0.1 * clump;
   };
-  uint32_t* kbits = reinterpret_cast<uint32_t*>(grid) + 256;  // two words behind the zone grid
-  MT2 s2;
+#ifdef AIE_DEV
+  uint64_t lg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint64_t lg_start = wall_clock64();
+#endif
+  MT3 s3;
 #pragma unroll
-  for (int j = 0; j < 10; ++j) s2.cur.r[j] = m.r[j];
-  s2.cur.pos = m.pos;
-  s2.have_nxt = false;
+  for (int j = 0; j < 10; ++j) s3.w[0].r[j] = m.r[j];
+  s3.pos = m.pos;
+  s3.have = 1;  // (pos == 624, a freshly seeded generator: every word then comes from window 1, the first twist)
   bool happy = false;
   for (int tries = 0; tries < 100 && !happy; ++tries) {
+    LG_CNT(5);
     for (int q = 0; q < 2; ++q) {
       const int rs = q == 0 ? 1 : 0;  // ["Wood", "Stone"]
       const double cov = g.layout_coverage[rs], clump = g.layout_clump[rs];
       uint8_t* mb = mbp[rs];
       const uint8_t* other = q == 0 ? nullptr : mbp[1];  // empty = nothing placed on the tile yet
-      mt2_rand_plane(s2, tmp, HW, lane);  // tmp = rs.rand(H, W)
-      AIE_WSYNC();
+      // tmp = rs.rand(H, W): NT doubles per pass, thread t takes words pos + 2 t, + 1
+      { LG_T0();
+      for (int base = 0; base < HW; base += NT) {
+        const int nb = HW - base < NT ? HW - base : NT;
+        mt3_need(s3, (s3.pos + 2 * nb - 1) / AIE_MT_N, lane);
+        const int o = s3.pos + 2 * (gtid < nb ? gtid : nb - 1);  // (idle threads repeat the last one's words: offsets stay monotone)
+        const uint32_t a = mt3_word(s3, o), b = mt3_word(s3, o + 1);
+        if (gtid < nb) tmp[base + gtid] = u53(a, b);
+        mt3_consume(s3, 2 * nb, lane);
+      }
+      __syncthreads();
+      LG_ACC(1); }
       int count = 0;
-      for (int base = 0; base < HW; base += AIE_NT) {
-        const int cell = base + lane;
+      for (int base = 0; base < HW; base += NT) {
+        const int cell = base + gtid;
         bool on = false;
         if (cell < HW) {
           on = (tmp[cell] < source_prob(rs, cell, clump)) && !(other && other[cell]);
           mb[cell] = on ? 1 : 0;
         }
-        count += __popcll(__ballot(on));
+        count += lg_block_count(on, sh, par, wave, lane);
       }
+      // while np.mean(maybe) < coverage * clump: tmp *= 0.9; maybe = (tmp < prob) * empty; stop after 201 rounds --
+      // eight rounds at a time: a cell's eight outcomes become a bit mask (parked in its `maybe` byte), the rounds'
+      // counts meet in sh->thr, and the first round that reaches the target is the one the loop would have stopped at
       int n_tries = 0;
-      while ((double)count / (double)HW < cov * clump) {
-        count = 0;
-        for (int base = 0; base < HW; base += AIE_NT) {
-          const int cell = base + lane;
-          bool on = false;
-          if (cell < HW) {
-            const double t = tmp[cell] * 0.9;
-            tmp[cell] = t;
-            on = (t < source_prob(rs, cell, clump)) && !(other && other[cell]);
-            mb[cell] = on ? 1 : 0;
+      if (HW <= NT) {  // one cell per thread: the cell's value, threshold and "tile still free" stay in registers, 32 rounds a block
+        const int cell = gtid < HW ? gtid : HW - 1;
+        double t = tmp[cell];
+        const double sp = source_prob(rs, cell, clump);
+        const bool free_tile = gtid < HW && !(other && other[cell]);
+        while ((double)count / (double)HW < cov * clump && n_tries <= 200) {
+          LG_T0();
+          LG_CNT(7);
+          const int B = 201 - n_tries < 32 ? 201 - n_tries : 32;
+          if (gtid < 32) sh->thr[gtid] = 0;
+          __syncthreads();
+          // tmp only shrinks, so a cell that passes stays on: its rounds are summed up by the FIRST round it passes
+          // in (32 = not in this block); the rounds' counts are the prefix sums of that histogram
+          int first_on = 32;
+          {
+            double tk = t;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+              tk = tk * 0.9;
+              first_on = (first_on == 32 && (tk < sp) && k < B) ? k : first_on;
+            }
+            t = tk;
           }
-          count += __popcll(__ballot(on));
+          if (!free_tile) first_on = 32;
+          if (first_on < 32) atomicAdd(&sh->thr[first_on], 1);
+          __syncthreads();
+          int mine = lane < 32 ? sh->thr[lane] : 0;  // lane k: cells whose first round is k ...
+#pragma unroll
+          for (int d = 1; d < 32; d <<= 1) {         // ... inclusive prefix over lanes 0..31: cells on after round k
+            const int up = __shfl_up(mine, d, 64);
+            mine += lane >= d ? up : 0;
+          }
+          const uint64_t reached = __ballot(lane < B && !((double)mine / (double)HW < cov * clump));
+          const int stop = reached ? __ffsll((unsigned long long)reached) - 1 : B - 1;  // the earliest round that reaches the target
+          count = bcast(mine, stop);
+          const uint32_t bits = first_on <= stop ? ~0u : 0u;
+          n_tries += stop + 1;
+          if (gtid < HW) mb[gtid] = (bits >> stop) & 1u;
+          __syncthreads();
+          LG_ACC(2);
         }
-        if (++n_tries > 200) break;
+      } else
+      while ((double)count / (double)HW < cov * clump && n_tries <= 200) {
+        LG_T0();
+        LG_CNT(7);
+        const int B = 201 - n_tries < 8 ? 201 - n_tries : 8;
+        if (gtid < 8) sh->thr[gtid] = 0;
+        __syncthreads();
+        for (int base = 0; base < HW; base += NT) {
+          const int cell = base + gtid;
+          uint32_t bits = 0;
+          if (cell < HW) {
+            double t = tmp[cell];
+            const double sp = source_prob(rs, cell, clump);
+            const bool free_tile = !(other && other[cell]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              t = t * 0.9;
+              bits |= ((t < sp) && free_tile && k < B) ? (1u << k) : 0u;
+            }
+            tmp[cell] = t;  // (rounds past the stopping one included: tmp is dead once the search ends)
+            mb[cell] = (uint8_t)bits;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int ck = __popcll(__ballot((bits >> k) & 1u));
+            if (lane == 0 && ck) atomicAdd(&sh->thr[k], ck);
+          }
+        }
+        __syncthreads();
+        int stop = B - 1;  // the round whose outcome stands
+        for (int k = B - 1; k >= 0; --k)
+          if (!((double)sh->thr[k] / (double)HW < cov * clump)) stop = k;  // the earliest round that reaches the target
+        stop = uni(stop);
+        count = uni(sh->thr[stop]);
+        n_tries += stop + 1;
+        for (int base = 0; base < HW; base += NT) {
+          const int cell = base + gtid;
+          if (cell < HW) mb[cell] = (mb[cell] >> stop) & 1u;
+        }
+        __syncthreads();
+        LG_ACC(2);
       }
-      AIE_WSYNC();
       while ((double)count / (double)HW < cov) {
         // kernel = rs.randn(7, 7) > 0 (row-major), then maybe + 0.2 * rs.randn(H, W) - 0.25: one request of 49 + HW values
-        if (lane < 2) kbits[lane] = 0;
-        AIE_WSYNC();
-        mt2_gauss(c, s2, 49 + HW, lane, [&](int k, double gs) {
+        LG_CNT(6);
+        if (gtid < 2) sh->kbits[gtid] = 0;
+        { LG_T0();
+        lg_gauss(c, s3, 49 + HW, sh, gpar, wave, lane, [&](int k, double gs) {
           if (k < 49) {
-            if (gs > 0) atomicOr(&kbits[k >> 5], 1u << (k & 31));
+            if (gs > 0) atomicOr(&sh->kbits[k >> 5], 1u << (k & 31));
           } else {
             const int cell = k - 49;
             x[cell] = ((double)mb[cell] + (0.2 * gs)) - 0.25;
           }
         });
-        AIE_WSYNC();
-        const uint64_t kmask = (uint64_t)kbits[0] | ((uint64_t)kbits[1] << 32);
+        LG_ACC(3); }
+        LG_T0();
+        const uint64_t kmask = (uint64_t)sh->kbits[0] | ((uint64_t)sh->kbits[1] << 32);
         count = 0;
-        for (int base = 0; base < HW; base += AIE_NT) {
-          const int cell = base + lane;
+        for (int base = 0; base < HW; base += NT) {
+          const int cell = base + gtid;
           bool on = false;
           if (cell < HW) {
             const int r0 = cell / W, c0 = cell - r0 * W;
+            // the 7x7 window first (49 LDS reads in flight at once: the additions below are a dependent chain, the
+            // reads need not be), then one add per kernel one in scipy's order; window cells outside the world add nothing
+            double win[49];
+            uint32_t rowok = 0, colok = 0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+              rowok |= (r0 + 3 - j >= 0 && r0 + 3 - j < H) ? (1u << j) : 0u;
+              colok |= (c0 + 3 - j >= 0 && c0 + 3 - j < W) ? (1u << j) : 0u;
+            }
+#pragma unroll
+            for (int t = 0; t < 49; ++t) {
+              const int j = t / 7, k = t - 7 * j;
+              const bool inb = ((rowok >> j) & 1u) && ((colok >> k) & 1u);
+              win[t] = inb ? x[cell + (3 - j) * W + (3 - k)] : 0.0;
+            }
             double sum = 0.0;
-            for (uint64_t bits = kmask; bits; bits &= bits - 1) {  // the kernel's ones, row-major (wave-uniform loop)
-              const int t = __ffsll((unsigned long long)bits) - 1, j = t / 7, k = t - 7 * j;
-              const int i0 = r0 + 3 - j, i1 = c0 + 3 - k;
-              if (i0 >= 0 && i0 < H && i1 >= 0 && i1 < W) sum += x[i0 * W + i1];
+#pragma unroll
+            for (int t = 0; t < 49; ++t) {
+              const int j = t / 7, k = t - 7 * j;
+              if ((kmask >> t) & 1ull) {  // (wave-uniform)
+                const bool inb = ((rowok >> j) & 1u) && ((colok >> k) & 1u);
+                sum = inb ? sum + win[t] : sum;
+              }
             }
             on = ((sum > 0) || mb[cell]) && !(other && other[cell]);
+            mb[cell] = on ? 1 : 0;  // (a cell's new value depends on x and its own old value only; the count's barrier publishes it)
           }
-          const uint64_t b = __ballot(on);
-          count += __popcll(b);
-          if (cell < HW) mb[cell] = on ? 1 : 0;  // (a cell's new value depends on x and its own old value only)
+          count += lg_block_count(on, sh, par, wave, lane);
         }
-        AIE_WSYNC();
+        LG_ACC(4);
       }
     }
     happy = true;
     for (int q = 0; q < 2; ++q) {
       const int rs = q == 0 ? 1 : 0;
       int count = 0;
-      for (int base = 0; base < HW; base += AIE_NT) {
-        const int cell = base + lane;
-        count += __popcll(__ballot(cell < HW && mbp[rs][cell]));
+      for (int base = 0; base < HW; base += NT) {
+        const int cell = base + gtid;
+        count += lg_block_count(cell < HW && mbp[rs][cell], sh, par, wave, lane);
       }
       const double ratio = ((double)count / (double)HW) / g.layout_coverage[rs];
       if (!((1 / 1.4) <= ratio && ratio <= 1.4)) happy = false;
     }
   }
 #pragma unroll
-  for (int j = 0; j < 10; ++j) m.r[j] = s2.cur.r[j];
-  m.pos = s2.cur.pos;
+  for (int j = 0; j < 10; ++j) m.r[j] = s3.w[0].r[j];
+  m.pos = s3.pos;
   uint8_t* cb = reinterpret_cast<uint8_t*>(R_CELLS(c));
-  for (int cell = lane; cell < HW; cell += AIE_NT) {
+  for (int cell = gtid; cell < HW; cell += NT) {
     const int r = cell / W, col = cell - r * W;
     bool st = mbp[0][cell] != 0, wd = mbp[1][cell] != 0;
     if (g.layout_checker && ((r & 1) + (col & 1)) != 1) st = wd = false;
     if (g.layout_gen == AIE_LAYOUT_QUADRANT && (col == H / 2 || r == W / 2)) st = wd = false;  // nothing on the water lines
     cb[4 * cell + 3] = (uint8_t)((cb[4 * cell + 3] & AIE_CELL_WATER) | (st ? AIE_CELL_STONE_SRC : 0) | (wd ? AIE_CELL_WOOD_SRC : 0));
   }
-  AIE_WSYNC();
+  __syncthreads();
+#ifdef AIE_DEV
+  if (c.R.dev_trace && gtid == 0) {
+    lg_acc[0] = wall_clock64() - lg_start;
+    for (int k = 0; k < 8; ++k) c.R.dev_trace[12 * c.e + k] = lg_acc[k];
+  }
+#endif
 }
 }  // namespace aie
 
@@ -2681,26 +2916,32 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
 // move.py:193-210, continuous_double_auction.py:643-668, redistribution.py:1109-1139).
 // Runs once per episode: the sequential part is executed wave-uniformly out of LDS.
 namespace aie {
-template <int SPEC>
+template <int SPEC, bool LAYOUT = true>  // LAYOUT == false: compiled without the layout generator (fixed layouts only)
 __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                                            const uint8_t* __restrict__ mask, int keep_rewards, uint8_t* lds) {
   const aie_params& R = *params;                      // run-time block: replica count, arena offsets
   const aie_params& P = aie_spec_params<SPEC>(params);  // the configuration: a constant image in the instances
   const int e = replica_of_block((int)blockIdx.x, R.E);
   if (mask && !mask[e]) return;
-  const Ctx c = make_ctx(P, R, lds, e, (int)threadIdx.x, arena);
+  // One wavefront resets a replica; environments whose reset draws a new source layout (uniform/, quadrant/,
+  // multi_zone/) are launched with LG_NW wavefronts per replica: all of them generate the layout, then the first
+  // one carries on alone (a barrier only waits for the waves of a workgroup that are still running).
+  const int gtid = (int)threadIdx.x, wave = gtid >> 6, nwaves = (int)blockDim.x >> 6;
+  const Ctx c = make_ctx(P, R, lds, e, gtid & 63, arena);
   const int n = P.n, HW = P.HW, tid = c.tid;
-  for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
-  if (c.ev && tid == 0) c.ev[0] = 0;
+  if (wave == 0) {
+    for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
+    if (c.ev && tid == 0) c.ev[0] = 0;
+  }
   MT m;
-  if (tid == 0) *c.srcn = 0;
+  if (gtid == 0) *c.srcn = 0;
   __syncthreads();
-  load_record(c, arena, m);
+  load_record(c, arena, m, wave, nwaves, wave);  // every wave takes its own copy of the generator's rows
   __syncthreads();
   m.pos = uni(*R_I32(c, o_mt_pos));
-  if (P.c.layout_gen != AIE_LAYOUT_FIXED) {  // a fresh source layout, drawn before anything else of the reset
-    layout_generate(c, m, arena, lds + lds_bytes(P));
-    __syncthreads();
+  if (LAYOUT && P.c.layout_gen != AIE_LAYOUT_FIXED) {  // a fresh source layout, drawn before anything else of the reset
+    layout_generate(c, m, arena, lds + lds_bytes(P), gtid);
+    if (wave != 0) return;
   }
   {  // layout_from_file.py:323-334: resources back on every source block, no houses
     uint32_t* cells = R_CELLS(c);
@@ -2886,11 +3127,18 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
 aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                  const uint8_t* __restrict__ mask, int keep_rewards) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  aie::reset_body<-1>(params, arena, mask, keep_rewards, lds);
+  aie::reset_body<-1, false>(params, arena, mask, keep_rewards, lds);
+}
+// environments whose reset draws a new source layout (uniform/, quadrant/, multi_zone/): LG_NW wavefronts per replica
+extern "C" __global__ void __launch_bounds__(LG_NW * AIE_NT)
+aie_reset_kernel_layout(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                        const uint8_t* __restrict__ mask, int keep_rewards) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  aie::reset_body<-1, true>(params, arena, mask, keep_rewards, lds);
 }
 // compile-time instances (aie_spec_generated.h), as for the step kernel
 template <int SPEC>
-__global__ void __launch_bounds__(AIE_NT)
+__global__ void __launch_bounds__(LG_NW * AIE_NT)
 aie_reset_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                       const uint8_t* __restrict__ mask, int keep_rewards) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
