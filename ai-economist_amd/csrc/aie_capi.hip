@@ -510,10 +510,6 @@ int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_of
 int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_offset, int32_t* d_actions_a,
                               int32_t* d_actions_p, void* stream) {
   if (!env) return AIE_E_INVALID;
-  if (env->P.c.scenario == AIE_SCN_COVID) {
-    snprintf(env->err, sizeof(env->err), "masked sampling is not implemented for the COVID scenario");
-    return AIE_E_UNSUPPORTED;
-  }
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   const aie_params& P = env->P;
   const int64_t tot = (int64_t)P.E * (P.n * P.act_a_width + P.act_p_width);

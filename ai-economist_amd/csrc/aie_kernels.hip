@@ -3187,25 +3187,32 @@ extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, 
   const int j = (int)(q - (int64_t)e * per_env);
   const uint32_t u = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)j);
   const float* mask;
-  int lo, len;
+  int lo, len, stride = 1;  // mask entry k of the slot's subspace: mask[(lo + k) * stride]
   int32_t* dst;
+  const bool covid = P.c.scenario == AIE_SCN_COVID;
   if (j < P.n * P.act_a_width) {
     if (!act_a) return;
     const int i = j / P.act_a_width, s = j - i * P.act_a_width;
-    mask = reinterpret_cast<const float*>(arena + P.a_obs_a_mask) + ((int64_t)e * P.n + i) * P.MA;
+    if (covid) {  // collated observations: the states' masks are rows [1 + levels][n] of the replica's block
+      mask = reinterpret_cast<const float*>(arena + P.a_cv_obs_a) + ((int64_t)e * P.cv_nrow_obs + AIE_CV_OB_MASK) * P.n + i;
+      stride = P.n;
+    } else {
+      mask = reinterpret_cast<const float*>(arena + P.a_obs_a_mask) + ((int64_t)e * P.n + i) * P.MA;
+    }
     if (P.c.multi_action_mode_agents) {
       lo = 0;
       for (int k = 0; k < s; ++k) lo += 1 + P.sub_a_dim[k];
       len = P.n_sub_a ? 1 + P.sub_a_dim[s] : 1;
     } else {
       lo = 0;
-      len = P.MA;
+      len = covid ? 1 + P.cv_NL : P.MA;
     }
     dst = act_a + (int64_t)e * P.n * P.act_a_width + j;
   } else {
     if (!act_p) return;
     const int s = j - P.n * P.act_a_width;
-    mask = reinterpret_cast<const float*>(arena + P.a_obs_p_mask) + (int64_t)e * P.MP;
+    if (covid) mask = reinterpret_cast<const float*>(arena + P.a_cv_obs_p) + (int64_t)e * (4 + P.MP) + 4;
+    else mask = reinterpret_cast<const float*>(arena + P.a_obs_p_mask) + (int64_t)e * P.MP;
     if (P.c.multi_action_mode_planner) {
       lo = s * (1 + P.sub_p_dim);
       len = P.n_sub_p ? 1 + P.sub_p_dim : 1;
@@ -3216,12 +3223,12 @@ extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, 
     dst = act_p + (int64_t)e * P.act_p_width + s;
   }
   int count = 0;
-  for (int k = 0; k < len; ++k) count += mask[lo + k] > 0.5f ? 1 : 0;
+  for (int k = 0; k < len; ++k) count += mask[(lo + k) * stride] > 0.5f ? 1 : 0;
   if (count == 0) { *dst = 0; return; }
   int pick = (int)(((uint64_t)u * (uint64_t)count) >> 32);
   int chosen = 0;
   for (int k = 0; k < len; ++k) {
-    if (mask[lo + k] > 0.5f) {
+    if (mask[(lo + k) * stride] > 0.5f) {
       if (pick == 0) { chosen = k; break; }
       --pick;
     }

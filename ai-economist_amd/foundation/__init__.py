@@ -28,5 +28,8 @@ def make_env_instance(scenario_name, reference_format=False, **kwargs):
     if reference_format:
         from .reference_view import ReferenceFormatEnv
 
+        # the reference fills previous_episode_metrics at every episode end (base_env.py:763-765); a one-replica
+        # environment can afford the device->host read that costs
+        kwargs.setdefault("track_episode_metrics", True)
         return ReferenceFormatEnv(scenario_class(**dict(kwargs, n_envs=1)))
     return scenario_class(**kwargs)

@@ -61,9 +61,10 @@ class BaseEnvironment:
         self.multi_action_mode_agents = bool(multi_action_mode_agents)
         self.multi_action_mode_planner = bool(multi_action_mode_planner)
         self._allow_observation_scaling = bool(allow_observation_scaling)
-        if not flatten_masks:
-            raise NotImplementedError("the batched backend always produces flattened masks (the reference's "
-                                      "recommended setting, tests/test_env.py:41-44)")
+        # flatten_masks=False (base_env.py:706-756): the kernels still write the flattened masks; the observation dicts
+        # then carry {"<Component>[.<sub-action>]": view} instead of the vector (foundation/obs_keys.py: mask_keys)
+        self._flatten_masks = bool(flatten_masks)
+        self._mask_key_views = None
         # flatten_observations=False (base_env.py:591-612): the kernels still write the packed `flat` vectors; the
         # observation dicts then hand out every key as a zero-copy slice of them (foundation/obs_keys.py)
         self._flatten_observations = bool(flatten_observations)
@@ -237,11 +238,36 @@ class BaseEnvironment:
     def tensors(self):
         return self.backend.tensors
 
+    # axis of the agents' mask tensor that runs over the action entries: the last one ([E, n, A]); the collated COVID
+    # observations are [E, 1 + levels, n] (covid19_env.py: masks stacked along axis 0)
+    mask_axis_agents = -1
+
     def _obs(self):
         obs = self._obs_raw()
         if not self._flatten_observations and not self.supports_unflattened_observations:
             obs = self._unflatten(obs)
+        if not self._flatten_masks:
+            obs = self._unflatten_masks(obs)
         return obs
+
+    def _unflatten_masks(self, obs):
+        """The reference's `flatten_masks=False` form (base_env.py:749-756): obs[...]["action_mask"] is a dictionary
+        {"<Component>" or "<Component>.<sub-action>": mask of that subspace}, here zero-copy views of the flattened
+        mask tensors (float32 0 / 1 where the reference holds uint8 lists), NO-OP entries left out as in the reference."""
+        if self._mask_key_views is None:
+            from .obs_keys import mask_keys
+
+            self._mask_key_views = mask_keys(self)
+            t = self.backend.tensors
+            ax = self.mask_axis_agents
+            assert self._mask_key_views["sizes"]["a"] == t["obs_a_action_mask"].shape[ax], "agent mask table vs tensor"
+            assert self._mask_key_views["sizes"]["p"] == t["obs_p_action_mask"].shape[-1], "planner mask table vs tensor"
+        tab = self._mask_key_views
+        out = {who: dict(d) for who, d in obs.items()}
+        ma, mp = obs["a"]["action_mask"], obs["p"]["action_mask"]
+        out["a"]["action_mask"] = {key: ma.narrow(self.mask_axis_agents, off, size) for key, off, size in tab["a"]}
+        out["p"]["action_mask"] = {key: mp.narrow(-1, off, size) for key, off, size in tab["p"]}
+        return out
 
     def _unflatten(self, obs):
         """The reference's `flatten_observations=False` form: every scalar / vector observation under its own key

@@ -66,3 +66,31 @@ def flat_keys(env):
     tp, npl = table(p)
     tpa, npa = table(pa)
     return {"a": ta, "p": tp, "pa": tpa, "sizes": {"a": na, "p": npl, "pa": npa}}
+
+
+def mask_keys(env):
+    """The flattened action masks as a key table: {"a": [(key, offset, size)], "p": [...], "sizes": {...}}.
+
+    The reference's `_generate_masks` (base_env.py:706-756) collects one mask per action subspace -- key
+    "<Component>" or "<Component>.<sub-action>" -- and `flatten_masks` (base_agent.py:440-460; the collated branch
+    base_env.py:729-748) concatenates them in action-subspace order, with ONE leading NO-OP entry in single-action mode
+    and one NO-OP entry in front of EVERY subspace in multi-action mode.  The kernels always write that flattened
+    vector; `flatten_masks=False` hands out each subspace's slice (without the NO-OP entries) under its key.
+    Pinned against the live reference in tests/test_obs_keys.py."""
+    names_a, names_p = env.action_subspace_names()
+    out, sizes = {}, {}
+    for who, names, multi in (("a", names_a, env.multi_action_mode_agents), ("p", names_p, env.multi_action_mode_planner)):
+        tab, off = [], 0
+        if not multi and names:
+            off = 1  # the single NO-OP entry in front
+        for name, dim in names:
+            if multi:
+                off += 1  # this subspace's own NO-OP entry
+            tab.append((name, off, int(dim)))
+            off += int(dim)
+        if not names:
+            off = 1  # an agent class without actions: the lone NO-OP entry
+        out[who] = tab
+        sizes[who] = off
+    out["sizes"] = sizes
+    return out

@@ -19,6 +19,7 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
     agent_subclasses = ["BasicMobileAgent", "BasicPlanner"]
     required_entities = []
     supports_unflattened_observations = True
+    mask_axis_agents = 1  # obs_a_action_mask is [E, 1 + levels, n_states] (masks stacked along axis 0, covid19_env.py)
 
     def __init__(self, *base_env_args, use_real_world_data=False, use_real_world_policies=False,
                  path_to_data_and_fitted_params="", start_date="2020-03-22", pop_between_age_18_65=0.6,

@@ -56,6 +56,47 @@ class RewardDoneGather:
         return full[:, : self.n], full[:, self.n], full[:, self.n + 1] > 0.5
 
 
+class ObservationGather:
+    """Opt-in: the CURRENT observations of every rank's replicas on the learner rank -- BASELINE's north star names an
+    "RCCL gather of (obs, reward, done)".  The default deployment keeps observations resident on the GPU that produced
+    them (policy inference is data-parallel too; SURVEY.md 8(e): a full gather is 267 MB per GPU per step at C3);
+    a learner that wants them anyway asks for the tensors by name:
+
+        og = ObservationGather(backend, keys=("obs_a_flat", "obs_a_action_mask"))   # after env.reset()
+        obs = og()      # dst: {key: tensor [W * E, ...]} (rank-major => global replica id = rank * E + e); others: None
+
+    One collective per key and call (the tensors are contiguous [E, ...] blocks of the arena: no packing pass)."""
+
+    def __init__(self, backend, keys=("obs_a_flat", "obs_a_action_mask", "obs_p_flat", "obs_p_action_mask"), dst=0):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.dst = torch, dist, dst
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.backend = backend
+        self.keys = [k for k in keys if k in backend.tensors]
+        missing = [k for k in keys if k not in backend.tensors]
+        if missing:
+            raise KeyError("ObservationGather: the environment has no tensor(s) %s" % missing)
+        self.recv = None
+        if self.rank == dst and self.world > 1:
+            self.recv = {k: [torch.empty_like(backend.tensors[k].contiguous()) for _ in range(self.world)] for k in self.keys}
+        self.bytes_per_call = sum(int(backend.tensors[k].numel() * backend.tensors[k].element_size()) for k in self.keys)
+
+    def __call__(self):
+        out = {}
+        for k in self.keys:
+            t = self.backend.tensors[k].contiguous()
+            if self.world > 1:
+                self.dist.gather(t, self.recv[k] if self.rank == self.dst else None, dst=self.dst)
+                if self.rank == self.dst:
+                    out[k] = self.torch.cat(self.recv[k], dim=0)
+            else:
+                out[k] = t
+        return out if self.rank == self.dst else None
+
+
 class RewardLogGather:
     """The same exchange, sized for xGMI: instead of one small collective per 40-microsecond step, the step
     kernel itself appends (rewards, done) of every step to a device-side log (aie_set_reward_log: slots of
@@ -71,9 +112,13 @@ class RewardLogGather:
 
     On the destination rank `g.received` is the list of gathered blocks, each f32
     [W, steps_per_gather, E, n + 2] (rank-major => global replica id = rank * E + e), if `keep` is set.
+
+    `gather_obs=(names...)` (opt-in): every completed block ALSO ships the observations the replicas hold at that
+    moment -- what a learner on `dst` needs to act on / bootstrap from after it has consumed the block's rewards
+    (`g.received_obs`: one {name: [W * E, ...]} dict per block on `dst`, ObservationGather).
     """
 
-    def __init__(self, backend, steps_per_gather=64, dst=0, keep=False, force_collective=False):
+    def __init__(self, backend, steps_per_gather=64, dst=0, keep=False, force_collective=False, gather_obs=None):
         import torch
         import torch.distributed as dist
 
@@ -92,6 +137,8 @@ class RewardLogGather:
         if self.rank == dst and self.collective:
             self.recv = [[torch.empty_like(self.log[: self.K]) for _ in range(self.world)] for _ in range(2)]
         self.received = []
+        self.obs_gather = ObservationGather(backend, gather_obs, dst) if gather_obs else None
+        self.received_obs = []
         self.n_collectives = 0
         self.bytes_per_collective = int(self.log[: self.K].numel() * self.log.element_size())
         self.wait_seconds = 0.0  # host time spent waiting for a collective before its log block could be reused
@@ -117,6 +164,10 @@ class RewardLogGather:
             self.n_collectives += 1
         elif self.keep:
             self.received.append(view.clone()[None])
+        if self.obs_gather is not None:
+            obs = self.obs_gather()
+            if obs is not None:
+                self.received_obs.append({k: v.clone() for k, v in obs.items()})
         self.filled = 0
         self.block ^= 1
         self._wait(self.block)  # the block about to be overwritten must have left

@@ -1,10 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- random-policy rollout throughput of the batched Foundation env.step().
 
-    python bench.py --gpus N --steps K --warmup W [--workload C2|C3|C4|C5]
+    python bench.py --gpus N --steps K --warmup W [--workload C1|C2|C3|C4|C4x|C5] [--no-workloads]
 
-Workloads = BASELINE.json configs[1..4]; the default, C2, is the configuration the metric
-is quoted on: layout_from_file/simple_wood_and_stone, 25x25 quadrant layout, 4 mobile agents + planner, Build +
+Workloads = BASELINE.json configs[0..4].  The default run (1 GPU, C2) is the headline line and
+ALSO times every other BASELINE configuration in a short window of the same invocation (`"workloads": {C1, C3, C4, C4x,
+C5: {value, ms_per_step, roofline}}`), so that all of them are measured under the caller's clock.  C2 is the
+configuration the metric is quoted on: layout_from_file/simple_wood_and_stone, 25x25 quadrant layout, 4 mobile agents + planner, Build +
 ContinuousDoubleAuction(max_num_orders 5) + Gather + PeriodicBracketTax (model_wrapper, us-federal, period 100),
 starting_agent_coin 10, episode_length 1000, 4096 replicas PER GPU (weak scaling), uniform random actions from a
 counter RNG keyed (seed, global replica, t, slot).
@@ -15,12 +17,15 @@ before the timed region.  The replicas are DE-PHASED before the timed region: bl
 staggered points of a prologue, so that any window of the rollout -- including a 20-step one -- contains tax days,
 order expiries, mid-episode order books and episode ends in their long-run proportions.
 
-`--gpus N` with N > 1 started as a plain process re-executes itself under torch.distributed.run (one rank per GPU).
+`--gpus N` with N > 1 started as a plain process re-executes itself under torch.distributed.run (one rank per GPU);
+`--launcher torchrun` takes that path with --gpus 1 too (the N > 1 launch code on a one-GPU box).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline      dominant kernel: algorithmic bytes per launch (SURVEY.md 8(d) figure, and the figure recomputed from
                 the final layouts) / average launch duration measured live with HIP events on the launch stream;
-                measured HBM traffic from the committed rocprofv3 PMC summary of the same command
+                measured HBM traffic and issued wave-instructions from the committed rocprofv3 PMC summaries of the
+                same command (-> hbm_traffic_frac, issue_frac, and `bound` derived from them); C5: the box's own
+                pure-store roof measured live
   cpu_baseline  the UNMODIFIED reference env.step (oracle/_ref, kind "reference") on this host's cores, P pinned
                 processes timed concurrently on a bounded window; `cpu_port` = the C restatement (oracle/) beside it
 """
@@ -94,8 +99,13 @@ WORKLOADS = {
     "C3": dict(desc="BASELINE configs[2], one GPU's share (32768 replicas over 8 GPUs = 4096 each): as C2 with 10 agents",
                cfg=lambda: dict(C2_CFG, n_agents=10), envs=4096, survey_bytes=7666.0, kernel="aie_step_kernel"),
     "C4": dict(desc="BASELINE configs[3]: CovidAndEconomySimulation, 51 US-state agents + planner, run config "
-                    "covid_and_economy_environment.yaml, episode_length 540",
+                    "covid_and_economy_environment.yaml, episode_length 540; filter_recurrence=True (opt-in O(1) update of "
+                    "the unemployment filter bank, `unemployed` within 1.5e-6 relative of the default window sums)",
                cfg=_c4_cfg, envs=8192, survey_bytes=1580.0, kernel="aie_covid_step_kernel"),
+    "C4x": dict(desc="BASELINE configs[3] with the default unemployment filter bank (the reference's 600-tap window sums; "
+                     "C4 runs the opt-in O(1) recurrence)",
+                cfg=lambda: dict(_c4_cfg(), filter_recurrence=False), envs=8192, survey_bytes=1580.0,
+                kernel="aie_covid_step_kernel"),
     "C5": dict(desc="BASELINE configs[4]: one-step-economy, 100 agents + SimpleLabor + PeriodicBracketTax(period 1), "
                     "episode_length 2",
                cfg=_c5_cfg, envs=65536, survey_bytes=987.0, kernel="aie_ose_step_kernel"),
@@ -118,7 +128,7 @@ def layout_bytes_per_env_step(be, wl):
     rewards/done."""
     obs = sum(t[0].numel() * t.element_size() for k, t in be.tensors.items() if k.startswith("obs_"))
     n = be.n
-    if wl == "C4":
+    if wl.startswith("C4"):
         L, F = int(be.cfg.covid.filter_len), int(be.cfg.covid.num_filters)
         state_rw = 2 * (8 + 1) * n * 4 + n
         if be.cfg.covid.filter_recurrence:  # O(1) filter update: F float64 sums per state r+w, 5 history bytes per state
@@ -145,6 +155,8 @@ def measured_traffic(wl, envs_per_gpu):
         return [int(x) for x in re.findall(r"\d+", os.path.basename(path))]
 
     tag = wl.lower()
+    if wl not in WORKLOADS:
+        return None, None
     files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")) if ("_%s_" % tag) in os.path.basename(f)]
     if wl == "C2":
         files += [f for f in glob.glob(os.path.join(ROOT, "profiles", "r01_v*_pmc.json"))]
@@ -254,7 +266,7 @@ def self_launch(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(max(1, args.gpus)),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -342,44 +354,56 @@ class Rollout:
             self.be.reset(mask)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="C2")
-    ap.add_argument("--envs-per-gpu", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stagger", action="store_true", help="keep all replicas in lock-step (round-1 behaviour)")
-    ap.add_argument("--no-auto-reset", action="store_true",
-                    help="C5: separate reset launches instead of restarting replicas inside the step launch")
-    ap.add_argument("--force-gather", action="store_true",
-                    help="run the N > 1 reward-log gather in a 1-rank group (exercises the RCCL path on one GPU)")
-    args = ap.parse_args()
+SM_CLOCK_HZ = 2.4e9   # MI355X peak engine clock (MI355X_MICROARCH.md): the issue roof is one wave-instruction per SIMD and clock
+N_SIMDS = 256 * 4
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args))
+
+def issue_counters(wl):
+    """Wave-instructions the dominant kernel issues per launch, from the newest committed SQ-counter summary of this
+    workload (profiles/*_<wl>_sq_counters.json: rocprofv3 --pmc SQ_INSTS_* passes of this same command, tools/sq_passes.sh)."""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_sq_counters.json" % wl.lower())),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    best = None
+    for name, v in d.items():
+        if isinstance(v, dict) and "reset" not in name and v.get("wave_instructions_per_launch"):
+            if best is None or v["wave_instructions_per_launch"] > best[1]:
+                best = (name, v["wave_instructions_per_launch"])
+    return (best[1] if best else None), os.path.relpath(files[-1], ROOT)
+
+
+def store_roof_gbs(device, nbytes=4 << 30):
+    """Pure-store roof of THIS box, measured live: a device fill of 4 GiB (launch times of the store-bound
+    one-step-economy kernel move by +-6 % between boxes, so the roof it is held against has to come from the same box)."""
+    import torch
+
+    buf = torch.empty(nbytes // 4, dtype=torch.int32, device=device)
+    best = 0.0
+    for _ in range(4):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        buf.fill_(7)
+        ev1.record()
+        torch.cuda.synchronize()
+        best = max(best, nbytes / (ev0.elapsed_time(ev1) * 1e-3) / 1e9)
+    del buf
+    return best
+
+
+def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
+    """One workload's rollout on this rank: environment, de-phasing prologue, warm-up, the timed window.  Returns the
+    JSON fields of the workload (rank 0) or None."""
+    import gc
 
     import torch
 
-    from ai_economist_amd.sharding import RewardLogGather, dist_info
+    from ai_economist_amd.sharding import RewardLogGather
 
-    dev_env = sorted(k for k in os.environ if k.startswith("AIE_DEV_"))
-    if dev_env:
-        sys.exit("bench.py refuses to run with development switches set: %s" % dev_env)
-
-    rank, local_rank, world = dist_info()
-    if args.gpus > 1 or world > 1 or args.force_gather:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29513")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        assert world == max(1, args.gpus), "world size %d != --gpus %d" % (world, args.gpus)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-
-    wl = args.workload
     W = WORKLOADS[wl]
     cfg = W["cfg"]()
     E = args.envs_per_gpu or W["envs"]
@@ -390,8 +414,6 @@ def main():
     be = env.backend
     n = env.n_agents
     roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger, auto_reset=not args.no_auto_reset)
-    import gc
-
     gc.collect()
     gc.disable()  # no collector pause between here and the end of the timed window (it may be as short as 20 launches);
     #               collected now, while the GPU has nothing queued: a pause later would let it run dry before the window
@@ -410,7 +432,7 @@ def main():
 
     # warm-up runs the very code path of the timed region (event-bracketed resets included), so that first-use costs
     # (event creation, cold Python paths) are not charged to a short timed window
-    warm0, warm1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    warm1 = torch.cuda.Event(enable_timing=True)
     # one pair of HIP events on the launch stream around the whole timed region (K back-to-back step launches)
     # plus one pair around each of the (rare) reset launches inside it: average step-kernel launch period =
     # (region - resets) / K.  Bracketing every step launch would add ~4 us of queue packets per step.
@@ -419,8 +441,7 @@ def main():
         roll.warm_reset_path()
     ev0.record()  # (a torch event creates its HIP event at the first record(): not inside the window)
     ev1.record()
-    warm0.record()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         roll.step(timed=True)
         if gather is not None:
             gather.after_step()
@@ -440,21 +461,17 @@ def main():
     t0 = time.perf_counter()
     # The first timed launch goes out before anything else; the event pair that measures the launch period on the GPU
     # brackets launches 2..K (K > 1): an event record ahead of the first launch would only delay it.
-    first_outside = args.steps > 1
-    _dbg = []
+    first_outside = steps > 1
     if first_outside:
         roll.step(timed=True)
         if gather is not None:
             gather.after_step()
         n_warm_resets = len(roll.reset_events)  # a reset issued with the first step lies outside the event pair
     ev0.record()
-    _dbg.append(time.perf_counter() - t0)
-    for _ in range(args.steps - (1 if first_outside else 0)):
+    for _ in range(steps - (1 if first_outside else 0)):
         roll.step(timed=True)
         if gather is not None:
             gather.after_step()
-        if len(_dbg) < 3:
-            _dbg.append(time.perf_counter() - t0)
     ev1.record()
     t_issue = time.perf_counter() - t0
     if gather is not None:
@@ -463,13 +480,9 @@ def main():
     # closing event first, so that a 20-step window is not dominated by the wake-up latency of its closing bracket
     while not ev1.query():
         pass
-    _dbg.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
-    _dbg.append(time.perf_counter() - t0)
     barrier()
     elapsed_local = time.perf_counter() - t0
-    if os.environ.get("BENCH_TIMELINE"):
-        sys.stderr.write("timeline us: " + " ".join("%.1f" % (x * 1e6) for x in _dbg) + " issue %.1f\n" % (t_issue * 1e6))
     gc.enable()
     elapsed = elapsed_local
     per_rank = [elapsed_local]
@@ -479,25 +492,16 @@ def main():
         torch.distributed.all_gather(allt, tt)
         per_rank = [float(x.item()) for x in allt]
         elapsed = max(per_rank)
-        # every rank empties its native stdio buffers (RCCL's version banner) before rank 0 prints the JSON line, so
-        # that nothing follows it on the job's stdout
-        try:
-            import ctypes
 
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
-        torch.distributed.barrier()
-
+    out = None
     if rank == 0:
         region_ms = ev0.elapsed_time(ev1)
         timed_resets = roll.reset_events[n_warm_resets:]
         reset_ms = sum(a.elapsed_time(b) for a, b in timed_resets)
-        launches_in_region = args.steps - (1 if first_outside else 0)
+        launches_in_region = steps - (1 if first_outside else 0)
         avg_ms = (region_ms - reset_ms) / launches_in_region
         lay = layout_bytes_per_env_step(be, wl)
-        units = (n + 1) if wl == "C4" else n  # C4's per-unit figure counts the planner
+        units = (n + 1) if wl.startswith("C4") else n  # C4's per-unit figure counts the planner
         survey_per_launch = W["survey_bytes"] * units * E
         layout_per_launch = lay["total"] * E
         achieved = survey_per_launch / (avg_ms * 1e-3) / 1e9
@@ -505,36 +509,59 @@ def main():
         traffic, traffic_src = measured_traffic(wl, E)
         inst = int(be.lib.aie_step_kernel_instance(be.handle))
         kernel_name = W["kernel"]  # the name rocprofv3 lists: compile-time instances are template instantiations
-        if inst >= 0 and wl != "C4":
+        if inst >= 0 and not wl.startswith("C4"):
             kernel_name = "%s_spec<%d>" % (W["kernel"], inst)
-        elif wl == "C4":
+        elif wl.startswith("C4"):
             kernel_name = "aie_covid_step_kernel<%d, %s>" % (env.model["num_filters"], "false" if env.exact_filter_sums else "true")
+        traffic_frac = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None
+        insts, insts_src = issue_counters(wl)
+        issue_frac = (insts / (N_SIMDS * SM_CLOCK_HZ * avg_ms * 1e-3)) if (insts and E == W["envs"]) else None
+        store_roof = store_roof_gbs(device) if wl == "C5" else None
+        store_frac = None
+        if store_roof and traffic:
+            store_frac = (traffic / (avg_ms * 1e-3) / 1e9) / store_roof
+        # what the counters say binds the launch: the memory system (measured traffic against the box's own store roof
+        # / the HBM peak), instruction issue, or neither (dependent chains of too few resident waves)
+        if (store_frac or 0) >= 0.7 or (traffic_frac or 0) >= 0.7:
+            bound = "hbm"
+        elif (issue_frac or 0) >= 0.6:
+            bound = "issue"
+        else:
+            bound = "latency"
         roof = dict(
-            bound="latency/issue", roof="hbm", kernel=kernel_name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-            frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-            hbm_traffic_frac=(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            bound=bound, roof="hbm", kernel=kernel_name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+            frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, hbm_traffic_frac=traffic_frac,
+            issue_frac=issue_frac, wave_instructions_per_launch=insts, issue_source=insts_src,
+            issue_roof="1 wave-instruction per SIMD and clock: %d SIMDs x %.1f GHz" % (N_SIMDS, SM_CLOCK_HZ / 1e9),
             algorithmic_bytes_per_launch=survey_per_launch, algorithmic_bytes_per_unit=W["survey_bytes"],
-            unit_of_work="agent-step incl. planner" if wl == "C4" else "agent-step",
+            unit_of_work="agent-step incl. planner" if wl.startswith("C4") else "agent-step",
             achieved_final_layout=achieved_layout, frac_final_layout=achieved_layout / HBM_PEAK_GBS,
             final_layout_bytes_per_launch=layout_per_launch, final_layout_bytes_per_env_step=lay,
             avg_launch_ms=avg_ms, launches_timed=launches_in_region, reset_launches_in_region=len(timed_resets),
             reset_ms_in_region=reset_ms,
             note="achieved/frac price SURVEY.md 8(d)'s algorithmic bytes per launch against the HBM peak; "
-                 "*_final_layout does the same with the bytes of the layouts actually used (u32 map cells, 2.5 KB "
-                 "MT19937 key per replica); hbm_traffic_frac = measured HBM bytes / time / peak. The kernel is NOT "
-                 "HBM-bound: it is limited by per-wave instruction issue and dependent-chain latency (DESIGN.md 4); "
-                 "the map observations stay in place and only changed cells are rewritten, hence traffic < algorithmic")
-        agent_steps = world * E * n * args.steps
+                 "*_final_layout does the same with the bytes of the layouts actually used; hbm_traffic_frac = measured "
+                 "HBM bytes (committed rocprofv3 FETCH_SIZE/WRITE_SIZE summary of this command) / live launch time / "
+                 "peak; issue_frac = wave-instructions per launch (committed SQ_INSTS_* summary) / (SIMDs x clock x live "
+                 "launch time); `bound` is derived from those fractions, not asserted")
+        if store_roof:
+            roof["store_roof_GBps_this_box"] = store_roof
+            roof["traffic_frac_of_store_roof"] = store_frac
+            roof["store_roof_note"] = ("pure-store roof measured live on this box (4 GiB device fill); "
+                                       "profiles/r03_store_roof.json has the per-pattern roofs (tools/store_roof.hip)")
+        agent_steps = world * E * n * steps
         out = {
             "metric": "agent-steps/sec, %s" % {"C1": "simple_wood_and_stone 15x15 4-agent Gather+Build batched envs",
                                                 "C2": "gather-trade-build 25x25 4-agent batched envs",
                                                 "C3": "gather-trade-build 25x25 10-agent batched envs",
                                                 "C4": "covid19_env 51 US-state agents + planner",
+                                                "C4x": "covid19_env 51 US-state agents + planner",
                                                 "C5": "one_step_economy 100 agents + SimpleLabor + planner tax"}[wl],
-            "value": agent_steps / elapsed, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "value": agent_steps / elapsed, "unit": "agent-steps/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"C4": "f32 state, f64 filter bank (f32 observations)"}.get(
+            "dtype": {"C4": "f32 state, f64 filter bank (f32 observations)",
+                      "C4x": "f32 state, f64 filter bank (f32 observations)"}.get(
                 wl, "u8/i32 state + f64 coin/utility (f32 observations)"),
             "data": "synthetic",
             "config": {
@@ -563,6 +590,94 @@ def main():
         if gather is not None:
             out["gather"] = {"collectives": gather.n_collectives, "bytes_per_collective": gather.bytes_per_collective,
                              "wait_seconds": gather.wait_seconds}
+        out["_cfg"] = cfg
+    del roll, gather, be, env
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+# the other BASELINE configurations a default run also times, in short windows: (workload, steps, warm-up)
+SIDE_WORKLOADS = [("C1", 200, 20), ("C3", 200, 20), ("C4", 200, 20), ("C4x", 100, 10), ("C5", 60, 6)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="C2")
+    ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="headline workload only (default: a 1-GPU C2 run also times C1, C3, C4, C4x, C5 in short windows)")
+    ap.add_argument("--no-stagger", action="store_true", help="keep all replicas in lock-step (round-1 behaviour)")
+    ap.add_argument("--no-auto-reset", action="store_true",
+                    help="C5: separate reset launches instead of restarting replicas inside the step launch")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the N > 1 reward-log gather in a 1-rank group (exercises the RCCL path on one GPU)")
+    ap.add_argument("--launcher", choices=["auto", "torchrun"], default="auto",
+                    help="torchrun: re-execute under torch.distributed.run even with --gpus 1 (the N > 1 launch path on one GPU)")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.launcher == "torchrun"):
+        if args.gpus > 1:  # a clear error instead of N ranks fighting over fewer devices
+            import torch
+
+            have = torch.cuda.device_count()
+            if args.gpus > have:
+                sys.exit("bench.py: --gpus %d, but only %d HIP device(s) are visible on this node" % (args.gpus, have))
+        sys.exit(self_launch(args))
+
+    import torch
+
+    from ai_economist_amd.sharding import dist_info
+
+    dev_env = sorted(k for k in os.environ if k.startswith("AIE_DEV_"))
+    if dev_env:
+        sys.exit("bench.py refuses to run with development switches set: %s" % dev_env)
+
+    rank, local_rank, world = dist_info()
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d wants HIP device %d, but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
+    if args.gpus > 1 or world > 1 or args.force_gather or args.launcher == "torchrun":
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        assert world == max(1, args.gpus), "world size %d != --gpus %d" % (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    out = run_workload(args.workload, args, args.steps, args.warmup, rank, local_rank, world, device)
+    if world > 1:
+        # every rank empties its native stdio buffers (RCCL's version banner) before rank 0 prints the JSON line, so
+        # that nothing follows it on the job's stdout
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        torch.distributed.barrier()
+
+    if rank == 0:
+        cfg = out.pop("_cfg")
+        wl = args.workload
+        if world == 1 and wl == "C2" and not args.no_workloads and not args.envs_per_gpu:
+            # every BASELINE configuration under the same clock, in the same invocation (short windows)
+            sides = {}
+            for swl, ssteps, swarm in SIDE_WORKLOADS:
+                try:
+                    r = run_workload(swl, args, ssteps, swarm, rank, local_rank, world, device)
+                    r.pop("_cfg", None)
+                    sides[swl] = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype",
+                                                    "config", "roofline")}
+                except Exception as exc:  # a side line must not take the headline down
+                    sides[swl] = {"error": repr(exc)}
+            out["workloads"] = sides
         if not args.no_cpu_baseline and world == 1:
             ref = None
             try:

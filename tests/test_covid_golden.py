@@ -299,6 +299,48 @@ def test_covid_hip_follows_the_reference_consistency_procedure(recurrence):
 
 
 @pytest.mark.gpu
+def test_covid_masked_action_sampler_respects_masks():
+    """aie_sample_masked_actions on the collated COVID observations (states' masks are rows [1 + levels, n] of the
+    replica's block, base_env.py:141-145 semantics): a stringency level under cool-down is never drawn, the planner's
+    subsidy level only on the days its mask opens, every allowed entry is reached, and the masked rollout still
+    follows the oracle."""
+    import torch
+
+    g = load_covid_golden("c4_covid_variant")
+    cfg = g["cfg"]
+    E, T = 48, 70
+    env = hip_env(cfg, n_envs=E)
+    o = make_oracle(cfg, n_envs=E)
+    env.reset()
+    o.reset()
+    t = env.tensors
+    be = env.backend
+    seen_a = np.zeros(t["obs_a_action_mask"].shape[1], bool)
+    seen_p = np.zeros(t["obs_p_action_mask"].shape[1], bool)
+    closed_some_day = False
+    for k in range(1, T + 1):
+        a, p = be.sample_masked_actions(seed=11)
+        torch.cuda.synchronize()
+        ma = t["obs_a_action_mask"].cpu().numpy()  # [E, 1 + levels, n]
+        mp = t["obs_p_action_mask"].cpu().numpy()  # [E, 1 + subsidy levels]
+        an, pn = a.cpu().numpy()[:, :, 0], p.cpu().numpy()[:, 0]
+        sel = np.take_along_axis(ma, an[:, None, :], axis=1)[:, 0, :]
+        assert np.all(sel == 1.0), "day %d: a masked stringency level was sampled" % k
+        assert np.all(np.take_along_axis(mp, pn[:, None], axis=1) == 1.0), "day %d: a masked subsidy level was sampled" % k
+        closed_some_day |= bool((ma[:, 1:, :] == 0).any())
+        seen_a[np.unique(an)] = True
+        seen_p[np.unique(pn)] = True
+        env.step({"a": a, "p": p})
+        o.step(an.astype(np.int32), pn.astype(np.int32))
+        np.testing.assert_allclose(t["rewards_a"].cpu().numpy(), o.rew_a, rtol=0, atol=1e-5, err_msg="day %d" % k)
+    assert closed_some_day, "the rollout never met a closed mask entry"
+    assert seen_a.all() and seen_p.all(), "entries never sampled: %s %s" % (np.where(~seen_a)[0], np.where(~seen_p)[0])
+    st = o.state()
+    assert np.array_equal(t["cooldown_until"].cpu().numpy(), st["cooldown_until"])
+    assert np.array_equal(t["subsidy_level"].cpu().numpy(), st["subsidy_level"])
+
+
+@pytest.mark.gpu
 def test_covid_masked_reset_and_config_errors():
     import torch
 

@@ -64,3 +64,38 @@ def test_key_tables_match_reference(case):
         _check(tab["pa"], raw["p"]["p1"], np.asarray(packed["p"]["p1"]), case + " planner p1")
     else:
         assert "p1" not in raw["p"]
+
+
+def _ref_masks(cfg, flatten_masks):
+    from ref_harness import load_reference_foundation
+
+    kw = dict(cfg, flatten_observations=True, flatten_masks=flatten_masks)
+    scenario = kw.pop("scenario_name")
+    kw["components"] = [tuple(c) for c in kw["components"]]
+    np.random.seed(5)
+    env = load_reference_foundation().make_env_instance(scenario, **kw)
+    env.seed(3)
+    obs = env.reset()
+    for t in range(3):
+        obs, _, _, _ = env.step({})
+    return obs
+
+
+@pytest.mark.parametrize("case", sorted(CASES) + ["one_step_economy"])
+def test_mask_key_tables_match_reference(case):
+    """`flatten_masks=False` (base_env.py:706-756): the reference's per-subspace mask dictionary against the slices
+    our key table cuts out of the reference's own flattened mask, for an agent and the planner."""
+    from ai_economist_amd.foundation.obs_keys import mask_keys
+
+    cfg = dict(OSE) if case == "one_step_economy" else dict(BASE, **CASES[case])
+    raw = _ref_masks(cfg, False)
+    flat = _ref_masks(cfg, True)
+    env = make_env(dict(cfg, flatten_masks=False), n_envs=1)
+    tab = mask_keys(env)
+    for who, actor in (("a", "0"), ("p", "p")):
+        d, vec = raw[actor]["action_mask"], np.asarray(flat[actor]["action_mask"], np.float32)
+        assert isinstance(d, dict) and sorted(d) == sorted(k for k, _, _ in tab[who]), "%s %s: key set" % (case, who)
+        assert tab["sizes"][who] == vec.size, "%s %s: flattened length" % (case, who)
+        for key, off, size in tab[who]:
+            np.testing.assert_array_equal(vec[off:off + size], np.asarray(d[key], np.float32).reshape(-1),
+                                          err_msg="%s %s: slice of %s" % (case, who, key))

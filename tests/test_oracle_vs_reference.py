@@ -415,6 +415,73 @@ def test_oracle_tracks_live_reference_saez_random_rate_phase(case):
     assert o.t["saez_buffer_len"][0] > 100
 
 
+SAEZ_NO_AUCTION = dict(BASE, episode_length=70, starting_agent_coin=20, n_agents=5, components=[
+    ["Build", {"skill_dist": "pareto", "payment_max_skill_multiplier": 3}], ["Gather", {"skill_dist": "pareto"}],
+    ["PeriodicBracketTax", {"tax_model": "saez", "period": 5}]])
+SAEZ_NO_AUCTION_BUFFER = 30
+
+
+def test_oracle_tracks_live_reference_saez_trajectory_without_auction():
+    """A Saez TRAJECTORY side by side with the live reference, through the formula phase.  With an auction, incomes
+    that are rounding residue (+-1e-15 after coin moved into escrow and back) pass or fail the formula's `z_t > 0`
+    filter depending on the last bit, so trajectories are only meaningful function-by-function (tests above).  Without
+    one -- Build + Gather + PeriodicBracketTax("saez") -- an income is a sum of build payments minus taxes plus lump
+    sums and either exactly 0 or well away from it: the restatement follows the reference step by step across the
+    random-rate phase AND at least three formula periods (buffer of 30 samples), float state within 1e-9, integer
+    state and the MT19937 stream exact, observations / rewards at the suite's tolerances."""
+    from oracle_lib import OracleEnv
+    from ref_extract import extract_obs, extract_state, rewards_array
+
+    cfg, size = dict(SAEZ_NO_AUCTION), SAEZ_NO_AUCTION_BUFFER
+    np.random.seed(9)
+    ref = _ref_env(cfg)
+    tc = ref.get_component("PeriodicBracketTax")
+    tc._buffer_size = size
+    host = make_env(cfg)
+    host.get_component("PeriodicBracketTax")._buffer_size = size
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    np.random.seed(31)
+    st = np.random.get_state()
+    o.t["mt"][0] = st[1]
+    o.t["mt_pos"][0] = st[2]
+    rng = np.random.RandomState(5)
+
+    def check(where, obs, rew=None):
+        compare_state({k: v[0] for k, v in o.t.items()}, extract_state(ref), where=where, f64_tol=1e-9)
+        assert np.array_equal(o.t["mt"][0], np.random.get_state()[1]), where + ": MT19937 state"
+        for k, want in extract_obs(ref, obs).items():
+            got = o.t[k][0]
+            if want.dtype.kind in "iu":
+                assert np.array_equal(got, want), "%s: obs %s" % (where, k)
+            else:
+                np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6, err_msg="%s: obs %s" % (where, k))
+        if rew is not None:
+            got = np.concatenate([o.t["rewards_a"][0], o.t["rewards_p"][[0]]])
+            np.testing.assert_allclose(got, rewards_array(ref, rew), rtol=0, atol=1e-5, err_msg=where)
+
+    formula_periods = 0
+    for ep in range(3):
+        obs = ref.reset()
+        o.reset()
+        check("reset %d" % ep, obs)
+        for t in range(cfg["episode_length"]):
+            at_start = tc.tax_cycle_pos == 1 and (tc._reached_min_samples or len(tc.saez_buffer) >= size)
+            acts, aa, pa = _random_actions(ref, rng, False, True)
+            # more builds than a uniform policy makes: incomes for the formula to chew on
+            for i in range(ref.n_agents):
+                if rng.rand() < 0.35:
+                    acts[str(i)] = 1
+                    aa[i] = 1
+            obs, rew, done, _ = ref.step(acts)
+            o.step(aa[None], pa[None])
+            formula_periods += int(at_start)
+            check("episode %d step %d (formula periods so far: %d)" % (ep, t + 1, formula_periods), obs, rew)
+        check_metrics(ref, host, o, "episode %d" % ep)
+    assert formula_periods >= 3, formula_periods
+    assert tc._reached_min_samples and o.t["saez_reached_min_samples"][0] == 1
+    assert np.abs(o.t["tax_saez_bracket_rates"][0]).max() > 0
+
+
 @pytest.mark.parametrize("case", sorted(SAEZ_CASES))
 def test_oracle_saez_formula_matches_live_reference(case):
     """The Saez formula itself (elasticity OLS, binned welfare weights / Pareto parameters, marginal

@@ -243,3 +243,45 @@ def test_hip_saez_global_buffer_union_matches_oracle():
     assert int(be.tensors["saez_global_len"][0]) == 0 and int(be.tensors["saez_additions"].abs().sum()) == 0
     with pytest.raises(ValueError):
         be._check(be.lib.aie_set_global_saez_buffer(be.handle, glob.data_ptr(), E * size + 1))
+
+
+@pytest.mark.gpu
+def test_hip_saez_trajectory_without_auction_matches_oracle():
+    """The no-auction Saez configuration whose TRAJECTORY the restatement follows beside the live reference through
+    the formula phase (tests/test_oracle_vs_reference.py::test_oracle_tracks_live_reference_saez_trajectory_without_auction):
+    the device against the restatement, 32 replicas with their own streams, three episodes -- random-rate phase, then
+    formula periods; float state 1e-9, integer state and the MT19937 stream exact every step."""
+    import torch
+    from oracle_lib import OracleEnv
+    from test_gpu_parity import _compare_all
+    from test_oracle_vs_reference import SAEZ_NO_AUCTION, SAEZ_NO_AUCTION_BUFFER
+
+    cfg, size = dict(SAEZ_NO_AUCTION), SAEZ_NO_AUCTION_BUFFER
+    E = 32
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.get_component("PeriodicBracketTax")._buffer_size = size
+    env.seed(13)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(13)
+    oracle.reset()
+    _compare_all(be, oracle, "reset")
+    rs = np.random.RandomState(2)
+    T = 3 * cfg["episode_length"]
+    for t in range(T):
+        a, p = be.sample_random_actions(seed=3)
+        an = a.cpu().numpy().copy()
+        an[rs.rand(*an.shape) < 0.35] = 1  # builds: incomes for the formula
+        a = torch.as_tensor(an, device=a.device)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(an, p.cpu().numpy(), nthreads=4)
+        _compare_all(be, oracle, "step %d" % (t + 1))
+        _compare_saez_buffer(be, oracle, "step %d buffer" % (t + 1))
+        if bool(be.tensors["done"][0]):
+            env.reset(be.tensors["done"])
+            oracle.reset(oracle.t["done"].copy())
+            _compare_all(be, oracle, "reset after step %d" % (t + 1))
+    assert oracle.t["saez_reached_min_samples"].all(), "every replica should be in the formula phase by now"
+    assert np.abs(oracle.t["tax_saez_bracket_rates"]).max() > 0

@@ -69,10 +69,12 @@ def test_shard_ranges_cover_all_replicas():
 
 
 class _FakeBackend:
-    """What RewardLogGather needs from a DeviceBackend: set_reward_log + something that fills the slots."""
+    """What RewardLogGather needs from a DeviceBackend: set_reward_log + something that fills the slots (+ `tensors`
+    with the current observations for the opt-in observation gather)."""
 
     def __init__(self, E, n):
         self.E, self.n, self.t, self.log = E, n, 0, None
+        self.tensors = {"obs_a_flat": torch.zeros((E, n, 5)), "obs_a_action_mask": torch.zeros((E, n, 3))}
 
     def set_reward_log(self, n_slots):
         self.log = torch.zeros((n_slots, self.E, self.n + 2))
@@ -87,6 +89,10 @@ class _FakeBackend:
         self.log[slot, :, : self.n] = gid[:, None] * 10 + torch.arange(self.n)[None, :] + 1000 * self.t
         self.log[slot, :, self.n] = -gid - self.t
         self.log[slot, :, self.n + 1] = ((torch.arange(lo, lo + self.E) + self.t) % 3 == 0).float()
+        # the observations the replicas hold after this step: a function of (global replica, agent, t)
+        self.tensors["obs_a_flat"][...] = (gid[:, None, None] * 100 + torch.arange(self.n)[None, :, None] * 10
+                                           + torch.arange(5)[None, None, :] + 0.5 * self.t)
+        self.tensors["obs_a_action_mask"][...] = ((gid[:, None, None] + torch.arange(3)[None, None, :] + self.t) % 2)
         self.t += 1
 
 
@@ -266,4 +272,57 @@ def test_saez_pooled_capacity_covers_full_buffers_of_every_rank_world2_gloo():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_saez_capacity_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def _obs_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ai_economist_amd.sharding import ObservationGather, RewardLogGather, shard_range
+
+    E_total, n, K, T = 10, 2, 3, 7
+    lo, hi = shard_range(E_total, rank, world)
+    be = _FakeBackend(hi - lo, n)
+    g = RewardLogGather(be, steps_per_gather=K, dst=0, keep=True, gather_obs=("obs_a_flat", "obs_a_action_mask"))
+    for t in range(T):
+        be.step(lo)
+        g.after_step()
+    g.finish()
+    og = ObservationGather(be, keys=("obs_a_flat",))
+    now = og()
+    ok = True
+    gid = torch.arange(E_total, dtype=torch.float32)
+
+    def want_flat(t):
+        return gid[:, None, None] * 100 + torch.arange(n)[None, :, None] * 10 + torch.arange(5)[None, None, :] + 0.5 * t
+
+    if rank == 0:
+        ok &= len(g.received_obs) == T // K  # one observation set per completed block: steps 2 and 5
+        for blk, obs in enumerate(g.received_obs):
+            t = (blk + 1) * K - 1
+            ok &= torch.equal(obs["obs_a_flat"], want_flat(t))
+            ok &= torch.equal(obs["obs_a_action_mask"],
+                              ((gid[:, None, None] + torch.arange(3)[None, None, :] + t) % 2).expand(E_total, n, 3))
+        ok &= torch.equal(now["obs_a_flat"], want_flat(T - 1)) and tuple(now["obs_a_flat"].shape) == (E_total, n, 5)
+    else:
+        ok &= g.received_obs == [] and now is None
+    try:
+        ObservationGather(be, keys=("obs_a_nope",))
+        ok = False
+    except KeyError:
+        pass
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_observation_gather_world2_gloo():
+    """Opt-in gather of the observations (BASELINE north star: "(obs, reward, done)"): per block with the reward log,
+    and on demand; rank-major replica order on the learner rank."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_obs_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
