@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libaie_hip.so")
 LIB_DEV = os.path.join(CSRC, "libaie_hip_dev.so")
 SOURCES = ["aie_capi.hip", "aie_kernels.hip", "aie_kernels_ose.hip", "aie_kernels_saez.hip", "aie_kernels_covid.hip",
-           "aie_layout.h", "aie_glibc_math.h", "aie_glibc_tables.h", "aie_spec_generated.h"]
+           "aie_layout.h", "aie_glibc_math.h", "aie_glibc_tables.h", "aie_spec_generated.h", "aie_jit.h"]
 
 
 def hipcc_path():

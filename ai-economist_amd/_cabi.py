@@ -206,6 +206,8 @@ def bind(lib):
     lib.aie_sample_masked_actions.argtypes = [vp, C.c_uint64, C.c_int64, vp, vp, vp]
     lib.aie_select_step_kernel.restype = C.c_int
     lib.aie_select_step_kernel.argtypes = [vp, C.c_int]
+    lib.aie_specialize.restype = C.c_int
+    lib.aie_specialize.argtypes = [vp]
     return lib
 
 
@@ -214,6 +216,7 @@ EXPORTED_SYMBOLS = [
     "aie_tensor_at", "aie_get_tensor", "aie_upload", "aie_download", "aie_set_layout",
     "aie_seed", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
     "aie_sample_masked_actions", "aie_step_sample_next", "aie_set_reward_log", "aie_set_auto_reset",
-    "aie_step_kernel_instance", "aie_select_step_kernel", "aie_set_global_saez_buffer", "aie_sizeof_config",
+    "aie_step_kernel_instance", "aie_select_step_kernel", "aie_specialize", "aie_set_global_saez_buffer", "aie_sizeof_config",
 ]
 KERNEL_AUTO, KERNEL_GENERIC = 0, 1
+KERNEL_INSTANCE_JIT = 1000

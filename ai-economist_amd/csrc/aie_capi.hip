@@ -11,6 +11,7 @@
 #include "aie_kernels_ose.hip"
 #include "aie_kernels_saez.hip"
 #include "aie_kernels_covid.hip"  // last: switches FP contraction off for the rest of the TU
+#include "aie_jit.h"
 
 struct aie_env {
   aie_params P;
@@ -22,6 +23,8 @@ struct aie_env {
   size_t lds;
   int spec;        // >= 0: the compile-time instance aie_step_kernel_spec<spec> runs this configuration; -1: generic
   int spec_match;  // the instance that matches the configuration (what AIE_KERNEL_AUTO selects), or -1
+  hipModule_t jit_mod;              // aie_specialize: the code object compiled for this configuration, or nullptr
+  hipFunction_t jit_step, jit_reset;  // its entry points; the environment then runs as instance AIE_KERNEL_INSTANCE_JIT
   int64_t sample_t;
   float* rew_log;        // aie_set_reward_log: caller's ring of n_slots step slots, or nullptr
   int32_t rew_log_slots, rew_log_next;
@@ -168,6 +171,7 @@ int aie_destroy(aie_env* env) {
   (void)hipDeviceSynchronize();
   if (env->owns_arena && env->arena) (void)hipFree(env->arena);
   if (env->d_params) (void)hipFree(env->d_params);
+  if (env->jit_mod) (void)hipModuleUnload(env->jit_mod);
   delete env;
   return AIE_OK;
 }
@@ -310,6 +314,13 @@ static void aie_launch_gtb_reset(aie_env* env, const uint8_t* d_mask, int keep_r
   const dim3 g((unsigned)env->P.E), b(env->P.c.layout_gen != AIE_LAYOUT_FIXED ? LG_NW * AIE_NT : AIE_NT);
   const size_t lds = env->lds + aie::layout_gen_lds_bytes(env->P);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (env->spec == AIE_KERNEL_INSTANCE_JIT && env->P.dev_skip_mask == 0) {
+    const aie_params* dp = env->d_params;
+    uint8_t* ar = env->arena;
+    void* args[] = {&dp, &ar, &d_mask, &keep_rewards};
+    (void)hipModuleLaunchKernel(env->jit_reset, g.x, 1, 1, b.x, 1, 1, (unsigned)lds, st, args, nullptr);
+    return;
+  }
 #define AIE_SPEC_LAUNCH_RESET(K) \
   case K: hipLaunchKernelGGL(aie_reset_kernel_spec<K>, g, b, lds, st, env->d_params, env->arena, d_mask, keep_rewards); return;
   if (env->spec >= 0 && env->P.dev_skip_mask == 0) {
@@ -426,7 +437,14 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
                                     env->P.dev_skip_mask != 0 || env->P.dev_trace != nullptr))
     hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
-  else if (env->spec >= 0) {
+  else if (env->spec == AIE_KERNEL_INSTANCE_JIT) {
+    const aie_params* dp = env->d_params;
+    uint8_t* ar = env->arena;
+    NextActions nx = next;
+    void* args[] = {&dp, &ar, &d_actions_a, &d_actions_p, &nx};
+    AIE_HIP_CHECK(env, hipModuleLaunchKernel(env->jit_step, (unsigned)env->P.E, 1, 1, 2 * AIE_NT, 1, 1, (unsigned)env->lds,
+                                             static_cast<hipStream_t>(stream), args, nullptr));
+  } else if (env->spec >= 0) {
     const dim3 g((unsigned)env->P.E), b(2 * AIE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define AIE_SPEC_LAUNCH(K) \
@@ -531,6 +549,51 @@ int aie_select_step_kernel(aie_env* env, int which) {
     return AIE_E_INVALID;
   }
   env->spec = which == AIE_KERNEL_GENERIC ? -1 : env->spec_match;
+  return AIE_OK;
+}
+
+int aie_specialize(aie_env* env) {
+  if (!env) return AIE_E_INVALID;
+  // already on a specialised kernel (a compile-time instance, or an earlier call); AIE_JIT_FORCE=1 compiles anyway
+  // (A/B of a run-time against a compile-time instance, tools/jit_timing.py)
+  if (env->spec_match >= 0 && !(getenv("AIE_JIT_FORCE") && env->spec_match != AIE_KERNEL_INSTANCE_JIT)) {
+    env->spec = env->spec_match;
+    return AIE_OK;
+  }
+  const aie_params& P = env->P;
+  if (P.c.scenario != AIE_SCN_GTB || P.ev_replicas > 0 || P.saez_stride || P.M > AIE_NT || P.regen_general) {
+    snprintf(env->err, sizeof(env->err), "aie_specialize: this configuration runs the full-featured step kernel (dense-log "
+             "replicas, tax_model \"saez\", order books beyond a wavefront, general regeneration) or is not gather-trade-build");
+    return AIE_E_UNSUPPORTED;
+  }
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  hipDeviceProp_t prop;
+  AIE_HIP_CHECK(env, hipGetDeviceProperties(&prop, env->device));
+  std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
+  arch = arch.substr(0, arch.find(':'));
+  static aie_params norm;
+  norm = env->P;
+  aie_spec_normalize(&norm);
+  const int wg = aie_workgroups_per_cu(env->lds);
+  const int waves = (2 * wg + 3) / 4 < 8 ? (2 * wg + 3) / 4 : 8;  // two waves per workgroup on four SIMDs
+  std::string code, err;
+  bool cached = false;
+  if (!aie_jit::code_object(&norm, sizeof(norm), waves, arch.c_str(), code, err, &cached)) {
+    snprintf(env->err, sizeof(env->err), "aie_specialize: %s", err.c_str());
+    return AIE_E_UNSUPPORTED;
+  }
+  hipModule_t mod = nullptr;
+  hipFunction_t fs = nullptr, fr = nullptr;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fs, mod, "aie_jit_step") != hipSuccess ||
+      hipModuleGetFunction(&fr, mod, "aie_jit_reset") != hipSuccess) {
+    if (mod) (void)hipModuleUnload(mod);
+    snprintf(env->err, sizeof(env->err), "aie_specialize: the compiled code object could not be loaded");
+    return AIE_E_UNSUPPORTED;
+  }
+  env->jit_mod = mod;
+  env->jit_step = fs;
+  env->jit_reset = fr;
+  env->spec = env->spec_match = AIE_KERNEL_INSTANCE_JIT;
   return AIE_OK;
 }
 

@@ -32,7 +32,13 @@
 // fuses them (aie_glibc_math.h, written out with __builtin_fma).
 #pragma clang fp contract(off)
 
-#include "aie_spec_generated.h"  // constant images of the parameter block for the compile-time step-kernel instances
+// constant images of the parameter block: the build's compile-time instances (aie_spec_generated.h), or -- in a
+// run-time specialisation (AIE_JIT, aie_specialize() in aie_capi.hip) -- the one image of the caller's environment
+#ifdef AIE_JIT
+#include "aie_jit_image.h"
+#else
+#include "aie_spec_generated.h"
+#endif
 template <int SPEC>
 __device__ __forceinline__ const aie_params& aie_spec_params(const aie_params* run_time) {
   if constexpr (SPEC < 0) return *run_time;
@@ -1299,7 +1305,7 @@ __device__ __forceinline__ double tax_marginal_rate(const Ctx& c, double income)
   const int NB = c.P.NB;
   for (int b = 0; b < NB; ++b) {
     const double lo = c.P.c.tax_bracket_cutoffs[b];
-    const bool under = (b + 1 < NB) ? (income < c.P.c.tax_bracket_cutoffs[b + 1]) : (income < INFINITY);
+    const bool under = (b + 1 < NB) ? (income < c.P.c.tax_bracket_cutoffs[b + 1]) : (income < __builtin_huge_val());
     if (income >= lo && under) return tax_rate(c, b);
   }
   return tax_rate(c, 0);
@@ -1307,7 +1313,7 @@ __device__ __forceinline__ double tax_marginal_rate(const Ctx& c, double income)
 __device__ __forceinline__ double tax_bin(const Ctx& c, double income, int b) {
   const int NB = c.P.NB;
   const double cut = c.P.c.tax_bracket_cutoffs[b];
-  const double size = (b + 1 < NB) ? c.P.c.tax_bracket_cutoffs[b + 1] - cut : INFINITY;
+  const double size = (b + 1 < NB) ? c.P.c.tax_bracket_cutoffs[b + 1] - cut : __builtin_huge_val();
   double past = income - cut;
   if (past < 0) past = 0;
   return tax_rate(c, b) * (size < past ? size : past);
@@ -2366,6 +2372,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 7] = wall_clock64();
 }
 
+#ifndef AIE_JIT  // (a run-time specialisation compiles the two entry points at the end of this file only)
 extern "C" __global__ void __launch_bounds__(2 * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 aie_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                 const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
@@ -2407,6 +2414,7 @@ aie_step_kernel_spec_trace(const aie_params* __restrict__ params, uint8_t* __res
   step_body<2, false, SPEC, true>(params, arena, act_a, act_p, lds, next);
 }
 #endif
+#endif  // !AIE_JIT
 
 namespace aie {
 // ------------------------------------------------------------------------------------------------------------------
@@ -3123,6 +3131,7 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
 }
 }  // namespace aie
 
+#ifndef AIE_JIT
 extern "C" __global__ void __launch_bounds__(AIE_NT)
 aie_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                  const uint8_t* __restrict__ mask, int keep_rewards) {
@@ -3235,3 +3244,23 @@ extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, 
   }
   *dst = chosen;
 }
+#endif  // !AIE_JIT
+
+#ifdef AIE_JIT
+// Run-time specialisation (aie_specialize): the step and reset kernels with THIS environment's parameter block as the
+// constant image (aie_jit_image.h is generated per configuration), exactly what the build's compile-time instances
+// are for the BASELINE configurations.
+extern "C" __global__ void __launch_bounds__(2 * AIE_NT)
+__attribute__((amdgpu_waves_per_eu(aie_spec_image<0>::waves, aie_spec_image<0>::waves)))
+aie_jit_step(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+             const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  step_body<2, false, 0>(params, arena, act_a, act_p, lds, next);
+}
+extern "C" __global__ void __launch_bounds__(LG_NW * AIE_NT)
+aie_jit_reset(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+              const uint8_t* __restrict__ mask, int keep_rewards) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  aie::reset_body<0>(params, arena, mask, keep_rewards, lds);
+}
+#endif  // AIE_JIT

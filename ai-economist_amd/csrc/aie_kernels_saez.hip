@@ -200,7 +200,7 @@ aie_saez_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ are
       const double income = P.c.tax_bracket_cutoffs[b + 1];
       for (int i = lane; i <= T; i += AIE_NT) {
         double past = income - edges[i]; if (past < 0) past = 0;
-        const double size = i < T ? edges[i + 1] - edges[i] : INFINITY;
+        const double size = i < T ? edges[i + 1] - edges[i] : __builtin_huge_val();
         s_bt[i] = s_taus[i] * (size < past ? size : past);
       }
       __syncthreads();

@@ -176,6 +176,15 @@ class DeviceBackend:
             C.c_void_p(na.data_ptr()), C.c_void_p(np_.data_ptr()), self._stream()))
         return na, np_
 
+    def specialize(self, required=False):
+        """aie_specialize: kernels compiled for this configuration at run time (hiprtc, cached).  Returns True when the
+        environment now runs on specialised kernels; False (or, with required=True, an exception) when that is not
+        possible here -- the generic kernel keeps running, with identical results."""
+        rc = self.lib.aie_specialize(self.handle)
+        if rc != 0 and required:
+            raise self._err(self.handle, rc)
+        return rc == 0
+
     def sample_masked_actions(self, seed, env_offset=0, slot=0):
         """Like sample_random_actions, but every sub-action is drawn uniformly among the
         entries the current `action_mask` observations allow."""

@@ -217,6 +217,12 @@ class BaseEnvironment:
                 self._backend.seed(self._pending_seed + self.env_offset)
         return self._backend
 
+    def specialize(self, required=False):
+        """Kernels compiled for THIS configuration at run time (aie_specialize: hiprtc, cached on disk), the way the
+        build specialises the BASELINE configurations.  True when the environment now runs on them; results are
+        bit-identical either way."""
+        return self.backend.specialize(required=required)
+
     def seed(self, seed):
         """Replica e gets the NumPy legacy stream of `np.random.seed(seed + env_offset + e)`
         (reference: BaseEnvironment.seed, base_env.py:481-494)."""

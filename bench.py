@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- random-policy rollout throughput of the batched Foundation env.step().
 
-    python bench.py --gpus N --steps K --warmup W [--workload C1|C2|C3|C4|C4x|C5] [--no-workloads]
+    python bench.py --gpus N --steps K --warmup W [--workload C1|C2|C2p|C3|C4|C4x|C5] [--no-workloads]
 
 Workloads = BASELINE.json configs[0..4].  The default run (1 GPU, C2) is the headline line and
 ALSO times every other BASELINE configuration in a short window of the same invocation (`"workloads": {C1, C3, C4, C4x,
@@ -96,6 +96,11 @@ WORKLOADS = {
     "C2": dict(desc="BASELINE configs[1]: gather-trade-build 25x25 quadrant layout, 4 agents + planner, Build+"
                     "ContinuousDoubleAuction(max_num_orders=5)+Gather+PeriodicBracketTax, episode_length 1000",
                cfg=lambda: dict(C2_CFG), envs=4096, survey_bytes=10984.0, kernel="aie_step_kernel"),
+    "C2p": dict(desc="SURVEY 8(d) C2'': BASELINE configs[1] with planner_gets_spatial_info=False (the reference's phase-2 "
+                     "training YAML, tutorials/rllib/phase2/config.yaml); no compile-time instance exists for it: the "
+                     "kernels are specialised at run time (aie_specialize: hiprtc, cached)",
+                cfg=lambda: dict(C2_CFG, planner_gets_spatial_info=False), envs=4096, survey_bytes=6601.0,
+                kernel="aie_step_kernel", specialize=True),
     "C3": dict(desc="BASELINE configs[2], one GPU's share (32768 replicas over 8 GPUs = 4096 each): as C2 with 10 agents",
                cfg=lambda: dict(C2_CFG, n_agents=10), envs=4096, survey_bytes=7666.0, kernel="aie_step_kernel"),
     "C4": dict(desc="BASELINE configs[3]: CovidAndEconomySimulation, 51 US-state agents + planner, run config "
@@ -413,6 +418,7 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
     env.reset()
     be = env.backend
     n = env.n_agents
+    specialised = bool(W.get("specialize")) and env.specialize()  # (False: hiprtc / sources missing -> generic kernel)
     roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger, auto_reset=not args.no_auto_reset)
     gc.collect()
     gc.disable()  # no collector pause between here and the end of the timed window (it may be as short as 20 launches);
@@ -509,7 +515,9 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
         traffic, traffic_src = measured_traffic(wl, E)
         inst = int(be.lib.aie_step_kernel_instance(be.handle))
         kernel_name = W["kernel"]  # the name rocprofv3 lists: compile-time instances are template instantiations
-        if inst >= 0 and not wl.startswith("C4"):
+        if inst == 1000:
+            kernel_name = "aie_jit_step"  # run-time specialisation (aie_specialize)
+        elif inst >= 0 and not wl.startswith("C4"):
             kernel_name = "%s_spec<%d>" % (W["kernel"], inst)
         elif wl.startswith("C4"):
             kernel_name = "aie_covid_step_kernel<%d, %s>" % (env.model["num_filters"], "false" if env.exact_filter_sums else "true")
@@ -553,6 +561,7 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
         out = {
             "metric": "agent-steps/sec, %s" % {"C1": "simple_wood_and_stone 15x15 4-agent Gather+Build batched envs",
                                                 "C2": "gather-trade-build 25x25 4-agent batched envs",
+                                                "C2p": "gather-trade-build 25x25 4-agent batched envs, planner without maps",
                                                 "C3": "gather-trade-build 25x25 10-agent batched envs",
                                                 "C4": "covid19_env 51 US-state agents + planner",
                                                 "C4x": "covid19_env 51 US-state agents + planner",
@@ -581,6 +590,8 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
                                 "RCCL, 64 steps per collective, overlapped with the steps" % world)
                 if world > 1 else "single GPU",
                 "dev_switches": [],
+                "kernel_specialisation": ("run time (aie_specialize)" if inst == 1000 else
+                                          "compile time" if inst >= 0 else "none (generic kernel)"),
             },
             "per_rank_seconds": per_rank,
             "host_issue_seconds": t_issue, "gpu_region_seconds": region_ms * 1e-3,
@@ -598,7 +609,7 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
 
 
 # the other BASELINE configurations a default run also times, in short windows: (workload, steps, warm-up)
-SIDE_WORKLOADS = [("C1", 200, 20), ("C3", 200, 20), ("C4", 200, 20), ("C4x", 100, 10), ("C5", 60, 6)]
+SIDE_WORKLOADS = [("C1", 200, 20), ("C2p", 200, 20), ("C3", 200, 20), ("C4", 200, 20), ("C4x", 100, 10), ("C5", 60, 6)]
 
 
 def main():

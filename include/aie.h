@@ -418,6 +418,17 @@ int aie_step_kernel_instance(aie_env* env);
 #define AIE_KERNEL_GENERIC 1
 int aie_select_step_kernel(aie_env* env, int which);
 
+/* Specialises the step and reset kernels on THIS environment's configuration at run time, the way the build does for
+ * the BASELINE configurations: the parameter block becomes a compile-time constant of the kernels (hiprtc compiles
+ * csrc/aie_kernels.hip with the block as a constant image, ~5 s once; the code object is cached under
+ * $AIE_JIT_CACHE / ~/.cache/ai_economist_amd, keyed by the block and the sources).  Afterwards AIE_KERNEL_AUTO runs
+ * the specialised kernels (aie_step_kernel_instance() == AIE_KERNEL_INSTANCE_JIT); results are bit-identical to the
+ * generic kernel's.  Gather-trade-build environments only.  AIE_E_UNSUPPORTED -- and the environment simply keeps the
+ * generic kernel -- when hiprtc, the kernel sources beside the library ($AIE_JIT_SOURCE_DIR) or the toolchain headers
+ * are not there, or when the configuration needs the full-featured kernel (dense-log replicas, tax_model "saez"). */
+#define AIE_KERNEL_INSTANCE_JIT 1000
+int aie_specialize(aie_env* env);
+
 /* Same counter RNG, but each sub-action is drawn uniformly among the entries that the
  * CURRENT action masks allow (obs_a_action_mask / obs_p_action_mask; NO-OP is always
  * allowed).  This is the random policy a trainer starts from when it applies the

@@ -878,6 +878,51 @@ def test_compile_time_instance_equals_generic_kernel(n_agents):
     del b_gen, b_other
 
 
+JIT_CASES = {
+    # the reference's phase-2 training setting (tutorials/rllib/phase2/config.yaml: the planner sees no maps)
+    "phase2_planner_blind": dict(C2, planner_gets_spatial_info=False),
+    "uniform_layout_6_agents": dict(C2, n_agents=6, env_layout_file="uniform_25x25_25each_65clump.txt", episode_length=150),
+    "build_gather_halfwidth": dict(scenario_name="uniform/simple_wood_and_stone", n_agents=5, world_size=[15, 15],
+                                   episode_length=90, components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10,
+                                   starting_stone_coverage=0.10, starting_wood_coverage=0.10),
+}
+
+
+@pytest.mark.parametrize("case", sorted(JIT_CASES))
+def test_runtime_specialisation_equals_generic_kernel(case):
+    """aie_specialize: configurations without a compile-time instance get step / reset kernels compiled for them at
+    run time (hiprtc, the parameter block as a constant image).  The specialised environment and one on the generic
+    kernel, same seed and actions: every tensor bit for bit across masked resets and an episode end."""
+    import torch
+
+    cfg = dict(JIT_CASES[case])
+    pair = [make_env(cfg, n_envs=384, device="cuda:0") for _ in range(2)]
+    b_jit, b_ref = pair[0].backend, pair[1].backend
+    assert b_jit.lib.aie_step_kernel_instance(b_jit.handle) == -1, "the case must not have a compile-time instance"
+    assert pair[0].specialize(required=True)
+    assert b_jit.lib.aie_step_kernel_instance(b_jit.handle) == 1000 and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == -1
+    for env in pair:
+        env.seed(4)
+        env.reset()
+    T = int(cfg["episode_length"]) + 20 if cfg["episode_length"] <= 200 else 160
+    for t in range(T):
+        a, p = b_ref.sample_random_actions(seed=8)
+        b_ref.step(a, p)
+        b_jit.step(a, p)
+        if t % 40 == 39:
+            mask = (torch.arange(384, device="cuda") % 7 == (t // 40) % 7).to(torch.uint8) | b_ref.tensors["done"]
+            b_ref.reset(mask)
+            b_jit.reset(mask)
+        if t in (0, 1, 39, 40, T - 1) or bool(b_ref.tensors["done"][0]):
+            torch.cuda.synchronize()
+            for k in b_ref.tensors:
+                assert torch.equal(b_ref.tensors[k], b_jit.tensors[k]), "%s step %d: %s differs" % (case, t + 1, k)
+    # the switch works both ways, and a second environment of the same configuration finds the cached code object
+    assert b_jit.lib.aie_select_step_kernel(b_jit.handle, 1) == 0 and b_jit.lib.aie_step_kernel_instance(b_jit.handle) == -1
+    assert b_jit.lib.aie_select_step_kernel(b_jit.handle, 0) == 0 and b_jit.lib.aie_step_kernel_instance(b_jit.handle) == 1000
+    assert pair[1].specialize(required=True)
+
+
 def test_reset_is_deterministic_across_environments():
     """Three environments of BASELINE configs[0]'s scenario (every reset draws its source layouts on the device, four
     wavefronts per replica), same seed: every tensor of the three arenas is identical after reset, and again after a

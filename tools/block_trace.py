@@ -18,7 +18,10 @@ from helpers import make_env  # noqa: E402
 
 E = 4096
 N_AGENTS = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-env = make_env(dict(bench.C2_CFG, n_agents=N_AGENTS), n_envs=E, device="cuda:0")
+cfg = dict(bench.C2_CFG, n_agents=N_AGENTS)
+if os.environ.get("TRACE_LAYOUT_FILE"):  # e.g. uniform_25x25_25each_65clump.txt
+    cfg["env_layout_file"] = os.environ["TRACE_LAYOUT_FILE"]
+env = make_env(cfg, n_envs=E, device="cuda:0")
 env.seed(1)
 env.reset()
 be = env.backend
