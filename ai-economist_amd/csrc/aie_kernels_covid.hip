@@ -21,6 +21,14 @@
 // weighting them by w[s,f] at the end -- a float64 reordering, ~1e-16 relative.
 #pragma clang fp contract(off)
 
+// ablations (tools/covid_ablate.py, -DAIE_DEV build): bits of aie_dev_set_skip_mask -- 1 today's history byte store,
+// 2 history byte loads (constants instead), 4 observation stores, 8 the per-state episode sums, 16 state row stores
+#ifdef AIE_DEV
+#define CV_SKIP(P, bit) (((P).dev_skip_mask & (bit)) != 0)
+#else
+#define CV_SKIP(P, bit) false
+#endif
+
 namespace aie {
 
 __device__ __forceinline__ float np_sum_f32_lds(const float* a, int n) {
@@ -72,7 +80,7 @@ __device__ __forceinline__ float cv_minmax(float x, float lo, float hi) { return
 // generate_observations + the three components' obs and masks, for timestep t.
 __device__ __forceinline__ void cv_write_observations(const aie_params& P, uint8_t* __restrict__ arena, int e, int s,
                                                       int t, const CvLane& a, int subsidy_level,
-                                                      const uint8_t* hist) {
+                                                      int lag_level /* level on day t - beta_delay + 1 */) {
   const aie_covid_config& V = P.c.covid;
   const int n = P.n, NL = P.cv_NL, NS = P.cv_NS, T = P.c.episode_length;
   const bool on = s < n;
@@ -97,15 +105,9 @@ __device__ __forceinline__ void cv_write_observations(const aie_params& P, uint8
     tv = (double)(di - nt % di);
   }
   const float t_vac = (float)(tv / (double)di);
-  // lagged stringency level (:957-970)
+  // lagged stringency level (:957-970): days before the episode divide in float64, the episode's own in float32
   const int tb = t - V.beta_delay + 1;
-  float lag;
-  if (tb < 0) {
-    const uint8_t* tab = arena + P.a_cv_lag_obs;
-    lag = (float)((double)tab[(tb + V.beta_delay) * n + sl] / (double)NL);
-  } else {
-    lag = (float)*(hist + (int64_t)((P.cv_L + tb) >> 4) * P.cv_row + sl * 16 + ((P.cv_L + tb) & 15)) / (float)NL;
-  }
+  const float lag = tb < 0 ? (float)((double)lag_level / (double)NL) : (float)lag_level / (float)NL;
   if (on) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) oa[(AIE_CV_OB_STATE + k) * n + s] = (float)((double)f6[k] / pop);
@@ -237,8 +239,11 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
     }
   }
   if (on && !keep_rewards) reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + s] = 0.f;
-  __syncthreads();  // the history bytes written above are read back for the lagged observation
-  cv_write_observations(P, arena, e, s, 0, a, 0, hist);
+  {  // the lagged observation at t = 0 (:957-970)
+    const int tb = 1 - P.c.covid.beta_delay;
+    const int lag_level = tb < 0 ? (arena + P.a_cv_lag_obs)[(tb + P.c.covid.beta_delay) * n + sl] : a.level;
+    cv_write_observations(P, arena, e, s, 0, a, 0, lag_level);
+  }
 }
 
 // ---- one env.step() (base_env.py:929-1032) ----
@@ -263,15 +268,36 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   const int T = P.c.episode_length;
   const int t = uni(*reinterpret_cast<const int32_t*>(rec + P.o_timestep)) + 1;
   if (t > T) return;  // episode over: the caller has to reset (the reference would index past its arrays)
+  // Every load of the replica's record is issued here, before anything waits: a replica is one wavefront whose whole
+  // step is a dependent chain (timestep -> history bytes -> state -> stores), and all 8192 of BASELINE configs[3] are
+  // resident at once, so a launch lasts as long as that chain.  What does not depend on the timestep travels beside
+  // it; the read-modify-write accumulators (episode sums, index sums) are read now and only written at the end.
+  double* sums = reinterpret_cast<double*>(rec + P.o_cv_sums);
+  const double sum_u0 = sums[AIE_CV_SUM_UNEMPLOYED * 64 + s], sum_s0 = sums[AIE_CV_SUM_STRINGENCY * 64 + s];
+  const double sum_p0 = sums[AIE_CV_SUM_PRODUCTIVITY * 64 + s], sum_b0 = sums[AIE_CV_SUM_SUBSIDY * 64 + s];
+  const float hidx0 = st[AIE_CV_ST_HEALTH_INDEX * 64 + s], eidx0 = st[AIE_CV_ST_ECONOMIC_INDEX * 64 + s];
+  float* pidx = reinterpret_cast<float*>(rec + P.o_cv_p_index);  // planner.state[...] += ... :1160-1161
+  const float pidx0 = pidx[0], pidx1 = pidx[1];
+  const float S1 = st[AIE_CV_ST_S * 64 + sl], I1 = st[AIE_CV_ST_I * 64 + sl], R1 = st[AIE_CV_ST_R * 64 + sl];
+  const float V1 = st[AIE_CV_ST_V * 64 + sl], D1 = st[AIE_CV_ST_D * 64 + sl];
+  const int cool0 = cool[sl];
+  // the lagged stringency level of the new observation (:957-970), fetched with the other history bytes: a load issued
+  // behind today's stores would wait for them (memory operations of a wave complete in order)
+  const int tb = t - V.beta_delay + 1;
+  int lag_level;
+  if (tb < 0) lag_level = (arena + P.a_cv_lag_obs)[(tb + V.beta_delay) * n + sl];
+  else if (V.beta_delay == 1) lag_level = -1;  // today's level, known further down
+  else lag_level = *cv_hist_at(P, hist, sl, L + tb);
 
   // ---- ControlUSStateOpenCloseStatus.component_step :180-221 ----
   int act = act_a ? act_a[(int64_t)e * n + sl] : 0;
   if (V.replay_policies) act = (arena + P.a_cv_replay_a)[(int64_t)(t - 1) * 64 + sl];  // :181-186: yesterday's recorded level
   if (act < 0 || act > NL) act = 0;
-  const int prev_level = *cv_hist_at(P, hist, sl, L + t - 1);
+  const int prev_level = CV_SKIP(P, 2) ? 1 : *cv_hist_at(P, hist, sl, L + t - 1);
   CvLane a;
   a.level = act == 0 ? prev_level : act;
-  a.cooldown = cool[sl];
+  if (lag_level < 0) lag_level = a.level;
+  a.cooldown = cool0;
   if (t == a.cooldown + 1) a.cooldown += act == 0 ? 1 : V.action_cooldown_period;
 
   // ---- FederalGovernmentSubsidy.component_step :393-443 ----
@@ -291,11 +317,9 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
                       : 0;
 
   // ---- sir_step :1477-1515 ----
-  const float S1 = st[AIE_CV_ST_S * 64 + sl], I1 = st[AIE_CV_ST_I * 64 + sl], R1 = st[AIE_CV_ST_R * 64 + sl];
-  const float V1 = st[AIE_CV_ST_V * 64 + sl], D1 = st[AIE_CV_ST_D * 64 + sl];
   const double pop = K[AIE_CV_K_POP * 64 + sl];
   {
-    const int beta_level = *cv_hist_at(P, hist, sl, L + t - V.beta_delay);  // days before the data: level 1
+    const int beta_level = CV_SKIP(P, 2) ? 1 : *cv_hist_at(P, hist, sl, L + t - V.beta_delay);  // days before the data: level 1
     const float beta = (float)(K[AIE_CV_K_BETA_INTERCEPT * 64 + sl] + K[AIE_CV_K_BETA_SLOPE * 64 + sl] * (double)beta_level);
     const float s_eps = S1 + 1e-10f;
     const double q = (double)vac / (double)s_eps;
@@ -346,13 +370,24 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
       // had tap 0 at step t-1 and now leaves the window.  O(1) per step and state instead of L * F multiply-adds
       // and a 601-byte history read; A_0 comes from the reset kernel (Horner over the pre-episode days).
       double* accs = reinterpret_cast<double*>(rec + P.o_cv_acc);
-      const int lev_t = *cv_hist_at(P, hist, sl, t), lev_tm1 = *cv_hist_at(P, hist, sl, t - 1);
+      // (history days <= L are the pre-episode days every replica shares: read from the shared table -- one
+      // cache-resident 51-byte row per day -- instead of this replica's own copy while t <= L)
+      int lev_t, lev_tm1;
+      if (CV_SKIP(P, 2)) lev_t = lev_tm1 = 1;
+      else if (t <= L) {
+        const uint8_t* h0 = arena + P.a_cv_hist0;
+        lev_t = h0[t * n + sl];
+        lev_tm1 = h0[(t - 1) * n + sl];
+      } else {
+        lev_t = *cv_hist_at(P, hist, sl, t);
+        lev_tm1 = *cv_hist_at(P, hist, sl, t - 1);
+      }
       const double d_old = (double)(lev_t - lev_tm1), d_new = (double)(a.level - prev_level);
 #pragma unroll
       for (int f = 0; f < F; ++f) {
         const double r = V.filter_decay[f];
         acc[f] = r * (accs[f * 64 + sl] - V.filter_tail[f] * d_old) + d_new;
-        if (on) accs[f * 64 + s] = acc[f];
+        accs[f * 64 + s] = on ? acc[f] : 0.0;  // (all 64 lanes: whole 128-byte lines, no partial-line writes)
       }
     } else {
     const double* __restrict__ G = reinterpret_cast<const double*>(arena + P.a_cv_filters);  // [row][F]
@@ -425,24 +460,25 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     a.prod = (float)((diff > 0.0 ? diff : 0.0) * (double)(float)V.daily_production_per_worker) + a.subsidy;
   }
 
-  // ---- state write-back ----
-  if (on) {
-    *cv_hist_at(P, hist, s, L + t) = (uint8_t)a.level;
-    cool[s] = a.cooldown;
-    st[AIE_CV_ST_S * 64 + s] = a.S;
-    st[AIE_CV_ST_I * 64 + s] = a.I;
-    st[AIE_CV_ST_R * 64 + s] = a.R;
-    st[AIE_CV_ST_D * 64 + s] = a.D;
-    st[AIE_CV_ST_V * 64 + s] = a.V;
-    st[AIE_CV_ST_U * 64 + s] = a.U;
-    st[AIE_CV_ST_PROD * 64 + s] = a.prod;
-    st[AIE_CV_ST_SUBSIDY * 64 + s] = a.subsidy;
-    // per-state sums over the days of the episode, for scenario_metrics :1613-1687
-    double* sums = reinterpret_cast<double*>(rec + P.o_cv_sums);
-    sums[AIE_CV_SUM_UNEMPLOYED * 64 + s] += (double)a.U;
-    sums[AIE_CV_SUM_STRINGENCY * 64 + s] += (double)a.level;
-    sums[AIE_CV_SUM_PRODUCTIVITY * 64 + s] += (double)a.prod;
-    sums[AIE_CV_SUM_SUBSIDY * 64 + s] += (double)a.subsidy;
+  // ---- state write-back: every row by all 64 lanes (whole lines; the 13 idle lanes write zeros) ----
+  if (on && !CV_SKIP(P, 1)) *cv_hist_at(P, hist, s, L + t) = (uint8_t)a.level;
+  cool[s] = on ? a.cooldown : 0;
+  if (!CV_SKIP(P, 16)) {
+    st[AIE_CV_ST_S * 64 + s] = on ? a.S : 0.f;
+    st[AIE_CV_ST_I * 64 + s] = on ? a.I : 0.f;
+    st[AIE_CV_ST_R * 64 + s] = on ? a.R : 0.f;
+    st[AIE_CV_ST_D * 64 + s] = on ? a.D : 0.f;
+    st[AIE_CV_ST_V * 64 + s] = on ? a.V : 0.f;
+    st[AIE_CV_ST_U * 64 + s] = on ? a.U : 0.f;
+    st[AIE_CV_ST_PROD * 64 + s] = on ? a.prod : 0.f;
+    st[AIE_CV_ST_SUBSIDY * 64 + s] = on ? a.subsidy : 0.f;
+  }
+  // per-state sums over the days of the episode, for scenario_metrics :1613-1687
+  if (!CV_SKIP(P, 8)) {
+    sums[AIE_CV_SUM_UNEMPLOYED * 64 + s] = on ? sum_u0 + (double)a.U : 0.0;
+    sums[AIE_CV_SUM_STRINGENCY * 64 + s] = on ? sum_s0 + (double)a.level : 0.0;
+    sums[AIE_CV_SUM_PRODUCTIVITY * 64 + s] = on ? sum_p0 + (double)a.prod : 0.0;
+    sums[AIE_CV_SUM_SUBSIDY * 64 + s] = on ? sum_b0 + (double)a.subsidy : 0.0;
   }
   if (s == 0) {
     *reinterpret_cast<int32_t*>(rec + P.o_timestep) = t;
@@ -467,8 +503,8 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     const float ra = ((wh * h + we * ec) / (wh + we)) / rnf;
     reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + s] = ra;
     if (rew_log) rew_log[(int64_t)e * (n + 2) + s] = ra;
-    st[AIE_CV_ST_HEALTH_INDEX * 64 + s] += h;  // agent.state["Health Index"] += ... :1123-1125 (float32)
-    st[AIE_CV_ST_ECONOMIC_INDEX * 64 + s] += ec;
+    st[AIE_CV_ST_HEALTH_INDEX * 64 + s] = hidx0 + h;  // agent.state["Health Index"] += ... :1123-1125 (float32)
+    st[AIE_CV_ST_ECONOMIC_INDEX * 64 + s] = eidx0 + ec;
   }
   if (s == 0) {
     const float sum_md = np_sum_f32_lds(red[0], n);
@@ -488,16 +524,15 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
       rew_log[(int64_t)e * (n + 2) + n] = (float)rp;
       rew_log[(int64_t)e * (n + 2) + n + 1] = t >= T ? 1.0f : 0.0f;
     }
-    float* pidx = reinterpret_cast<float*>(rec + P.o_cv_p_index);  // planner.state[...] += ... :1160-1161
-    pidx[0] = (float)((double)pidx[0] + ph);
-    pidx[1] = pidx[1] + pe;
+    pidx[0] = (float)((double)pidx0 + ph);
+    pidx[1] = pidx1 + pe;
     arena[P.a_done + e] = t >= T ? 1 : 0;
     if (t >= T) *reinterpret_cast<int32_t*>(rec + P.o_completions) += 1;
   }
 
   // ---- observations + masks for the new timestep ----
   __syncthreads();  // today's level byte (written above) may be the lagged observation when beta_delay == 1
-  cv_write_observations(P, arena, e, s, t, a, sub_level, hist);
+  if (!CV_SKIP(P, 4)) cv_write_observations(P, arena, e, s, t, a, sub_level, lag_level);
   if (next.a || next.p) {  // aie_step_sample_next: the uniform random policy's draw for the next step, one lane per slot
     const int per_env = P.n * P.act_a_width + P.act_p_width;
     for (int j = s; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, e, j, next.a, next.p);
