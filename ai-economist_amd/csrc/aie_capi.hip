@@ -407,6 +407,13 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
       default: return AIE_E_UNSUPPORTED;
     }
 #undef AIE_CV_LAUNCH
+  } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY && env->spec == AIE_KERNEL_INSTANCE_JIT && env->P.ev_replicas == 0) {
+    const aie_params* dp = env->d_params;
+    uint8_t* ar = env->arena;
+    NextActions nx = next;
+    void* args[] = {&dp, &ar, &d_actions_a, &d_actions_p, &nx};
+    AIE_HIP_CHECK(env, hipModuleLaunchKernel(env->jit_step, (unsigned)env->P.E, 1, 1, OSE_NT, 1, 1, (unsigned)env->lds,
+                                             static_cast<hipStream_t>(stream), args, nullptr));
   } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY && env->spec >= 0 && env->P.ev_replicas == 0) {
     const dim3 g((unsigned)env->P.E), b(OSE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -561,9 +568,11 @@ int aie_specialize(aie_env* env) {
     return AIE_OK;
   }
   const aie_params& P = env->P;
-  if (P.c.scenario != AIE_SCN_GTB || P.ev_replicas > 0 || P.saez_stride || P.M > AIE_NT || P.regen_general) {
+  const bool ose = P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY;
+  if (P.c.scenario == AIE_SCN_COVID || P.ev_replicas > 0 || P.saez_stride ||
+      (!ose && (P.M > AIE_NT || P.regen_general))) {
     snprintf(env->err, sizeof(env->err), "aie_specialize: this configuration runs the full-featured step kernel (dense-log "
-             "replicas, tax_model \"saez\", order books beyond a wavefront, general regeneration) or is not gather-trade-build");
+             "replicas, tax_model \"saez\", order books beyond a wavefront, general regeneration) or is the COVID scenario");
     return AIE_E_UNSUPPORTED;
   }
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
@@ -575,17 +584,19 @@ int aie_specialize(aie_env* env) {
   norm = env->P;
   aie_spec_normalize(&norm);
   const int wg = aie_workgroups_per_cu(env->lds);
-  const int waves = (2 * wg + 3) / 4 < 8 ? (2 * wg + 3) / 4 : 8;  // two waves per workgroup on four SIMDs
+  // gather-trade-build: two waves per workgroup on four SIMDs; one-step-economy: one wave per workgroup
+  const int waves = ose ? (wg >= 16 ? 4 : wg >= 12 ? 3 : 2) : ((2 * wg + 3) / 4 < 8 ? (2 * wg + 3) / 4 : 8);
   std::string code, err;
   bool cached = false;
-  if (!aie_jit::code_object(&norm, sizeof(norm), waves, arch.c_str(), code, err, &cached)) {
+  if (!aie_jit::code_object(&norm, sizeof(norm), waves, arch.c_str(), ose, code, err, &cached)) {
     snprintf(env->err, sizeof(env->err), "aie_specialize: %s", err.c_str());
     return AIE_E_UNSUPPORTED;
   }
   hipModule_t mod = nullptr;
   hipFunction_t fs = nullptr, fr = nullptr;
-  if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fs, mod, "aie_jit_step") != hipSuccess ||
-      hipModuleGetFunction(&fr, mod, "aie_jit_reset") != hipSuccess) {
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess ||
+      hipModuleGetFunction(&fs, mod, ose ? "aie_jit_ose_step" : "aie_jit_step") != hipSuccess ||
+      (!ose && hipModuleGetFunction(&fr, mod, "aie_jit_reset") != hipSuccess)) {
     if (mod) (void)hipModuleUnload(mod);
     snprintf(env->err, sizeof(env->err), "aie_specialize: the compiled code object could not be loaded");
     return AIE_E_UNSUPPORTED;

@@ -74,12 +74,13 @@ static inline void mkdirs(const std::string& p) {
     if (k == p.size() || p[k] == '/') mkdir(p.substr(0, k).c_str(), 0755);
 }
 
-static const char* const kSources[] = {"aie_kernels.hip", "aie_layout.h", "aie_glibc_math.h", "aie_glibc_tables.h"};
+static const char* const kSources[] = {"aie_kernels.hip", "aie_kernels_ose.hip", "aie_layout.h", "aie_glibc_math.h",
+                                       "aie_glibc_tables.h"};
 
 // Compiles (or fetches from the cache) the code object for `image` (sizeof(aie_params) normalised bytes); `waves` =
 // waves per SIMD the kernel is compiled for.  On failure returns false with a message in `err`.
-static inline bool code_object(const void* image, size_t image_bytes, int waves, const char* arch, std::string& code,
-                               std::string& err, bool* from_cache) {
+static inline bool code_object(const void* image, size_t image_bytes, int waves, const char* arch, bool ose,
+                               std::string& code, std::string& err, bool* from_cache) {
   // where the sources live: beside this library (in-tree build), or AIE_JIT_SOURCE_DIR
   std::string csrc;
   if (const char* e = getenv("AIE_JIT_SOURCE_DIR")) csrc = e;
@@ -90,6 +91,7 @@ static inline bool code_object(const void* image, size_t image_bytes, int waves,
   std::string inc = csrc + "/../../include", text;
   uint64_t h = fnv1a(1469598103934665603ull, image, image_bytes);
   h = fnv1a(h, &waves, sizeof(waves));
+  h = fnv1a(h, &ose, sizeof(ose));
   h = fnv1a(h, arch, strlen(arch));
   for (const char* s : kSources) {
     if (!read_file(csrc + "/" + s, text)) { err = "kernel source " + csrc + "/" + s + " not found"; return false; }
@@ -122,7 +124,8 @@ static inline bool code_object(const void* image, size_t image_bytes, int waves,
   }
   hdr += "};\ntemplate <> struct aie_spec_image<0> { static constexpr const unsigned char* bytes = aie_jit_bytes; "
          "static constexpr int waves = " + std::to_string(waves) + "; };\n";
-  const std::string src = "#define AIE_JIT 1\n#include \"aie_kernels.hip\"\n";
+  const std::string src = ose ? "#define AIE_JIT 1\n#define AIE_JIT_OSE 1\n#include \"aie_kernels_ose.hip\"\n"
+                              : "#define AIE_JIT 1\n#include \"aie_kernels.hip\"\n";
   const char* headers[1] = {hdr.c_str()};
   const char* header_names[1] = {"aie_jit_image.h"};
   hiprtcProgram prog = nullptr;

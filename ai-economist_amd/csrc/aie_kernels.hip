@@ -3246,7 +3246,7 @@ extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, 
 }
 #endif  // !AIE_JIT
 
-#ifdef AIE_JIT
+#if defined(AIE_JIT) && !defined(AIE_JIT_OSE)
 // Run-time specialisation (aie_specialize): the step and reset kernels with THIS environment's parameter block as the
 // constant image (aie_jit_image.h is generated per configuration), exactly what the build's compile-time instances
 // are for the BASELINE configurations.

@@ -807,6 +807,7 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
   OSE_STAMP(c, 11);
 }
 
+#ifndef AIE_JIT
 extern "C" __global__ void __launch_bounds__(OSE_NT)
 aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                     const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
@@ -839,3 +840,16 @@ aie_ose_reset_kernel(const aie_params* __restrict__ params, uint8_t* __restrict_
   ose_reset_body(c, s, arena, L, false);
   ose_store_record(c, arena);
 }
+#endif  // !AIE_JIT
+
+#ifdef AIE_JIT_OSE
+// run-time specialisation (aie_specialize) of the one-step-economy step kernel: this environment's parameter block
+// as the constant image (SimpleLabor's skills stay run-time data, as in the build's instance)
+extern "C" __global__ void __launch_bounds__(OSE_NT)
+__attribute__((amdgpu_waves_per_eu(aie_spec_image<0>::waves, aie_spec_image<0>::waves)))
+aie_jit_ose_step(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                 const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  ose_step_body<0>(params, arena, act_a, act_p, next, lds);
+}
+#endif  // AIE_JIT_OSE

@@ -423,7 +423,7 @@ int aie_select_step_kernel(aie_env* env, int which);
  * csrc/aie_kernels.hip with the block as a constant image, ~5 s once; the code object is cached under
  * $AIE_JIT_CACHE / ~/.cache/ai_economist_amd, keyed by the block and the sources).  Afterwards AIE_KERNEL_AUTO runs
  * the specialised kernels (aie_step_kernel_instance() == AIE_KERNEL_INSTANCE_JIT); results are bit-identical to the
- * generic kernel's.  Gather-trade-build environments only.  AIE_E_UNSUPPORTED -- and the environment simply keeps the
+ * generic kernel's.  Gather-trade-build and one-step-economy environments.  AIE_E_UNSUPPORTED -- and the environment simply keeps the
  * generic kernel -- when hiprtc, the kernel sources beside the library ($AIE_JIT_SOURCE_DIR) or the toolchain headers
  * are not there, or when the configuration needs the full-featured kernel (dense-log replicas, tax_model "saez"). */
 #define AIE_KERNEL_INSTANCE_JIT 1000

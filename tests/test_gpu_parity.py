@@ -885,6 +885,11 @@ JIT_CASES = {
     "build_gather_halfwidth": dict(scenario_name="uniform/simple_wood_and_stone", n_agents=5, world_size=[15, 15],
                                    episode_length=90, components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10,
                                    starting_stone_coverage=0.10, starting_wood_coverage=0.10),
+    # a one-step-economy of another size than BASELINE configs[4]'s (which has the build's instance)
+    "one_step_economy_37_agents": dict(scenario_name="one-step-economy", n_agents=37, world_size=[1, 1], episode_length=3,
+                                       components=[["SimpleLabor", {"skills": [1.0 + 0.05 * i for i in range(37)]}],
+                                                   ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+                                                                           "tax_model": "model_wrapper"}]]),
 }
 
 
