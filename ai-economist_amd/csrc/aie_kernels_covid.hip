@@ -67,6 +67,11 @@ __device__ __forceinline__ uint8_t* cv_hist_at(const aie_params& P, uint8_t* his
   return hist + (int64_t)(tau >> 4) * P.cv_row + s * 16 + (tau & 15);
 }
 
+// the recent-days ring (aie_layout.h: o_cv_ring): level of state s on history day tau (any of the last 32)
+__device__ __forceinline__ uint8_t* cv_ring_at(const aie_params& P, uint8_t* rec, int s, int tau) {
+  return rec + P.o_cv_ring + (tau & 31) * 64 + s;
+}
+
 // crra_nonlinearity (covid19_env.py:1056-1078), float32 like the reference's arrays
 __device__ __forceinline__ float cv_crra(float x, float eta) {
   float ax = 365.0f * x;
@@ -201,6 +206,8 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
           *reinterpret_cast<const uint4*>(img + (int64_t)c * P.cv_row + s * 16);
   CvLane a;
   const int sl = on ? s : n - 1;
+  for (int tau = L - 31; tau <= L; ++tau)  // the ring: the 32 days up to day 0 (days before the table begins: level 1)
+    *cv_ring_at(P, rec, s, tau) = on ? (tau >= 0 ? h0[tau * n + s] : (uint8_t)1) : (uint8_t)0;
   if (P.c.covid.filter_recurrence) {  // A_0 of every filter (aie_covid_prepare_kernel)
     double* accs = reinterpret_cast<double*>(rec + P.o_cv_acc);
     const double* acc0 = reinterpret_cast<const double*>(arena + P.a_cv_acc0);
@@ -287,13 +294,13 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   int lag_level;
   if (tb < 0) lag_level = (arena + P.a_cv_lag_obs)[(tb + V.beta_delay) * n + sl];
   else if (V.beta_delay == 1) lag_level = -1;  // today's level, known further down
-  else lag_level = *cv_hist_at(P, hist, sl, L + tb);
+  else lag_level = V.beta_delay <= 32 ? *cv_ring_at(P, rec, sl, L + tb) : *cv_hist_at(P, hist, sl, L + tb);
 
   // ---- ControlUSStateOpenCloseStatus.component_step :180-221 ----
   int act = act_a ? act_a[(int64_t)e * n + sl] : 0;
   if (V.replay_policies) act = (arena + P.a_cv_replay_a)[(int64_t)(t - 1) * 64 + sl];  // :181-186: yesterday's recorded level
   if (act < 0 || act > NL) act = 0;
-  const int prev_level = CV_SKIP(P, 2) ? 1 : *cv_hist_at(P, hist, sl, L + t - 1);
+  const int prev_level = CV_SKIP(P, 2) ? 1 : *cv_ring_at(P, rec, sl, L + t - 1);
   CvLane a;
   a.level = act == 0 ? prev_level : act;
   if (lag_level < 0) lag_level = a.level;
@@ -319,7 +326,8 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   // ---- sir_step :1477-1515 ----
   const double pop = K[AIE_CV_K_POP * 64 + sl];
   {
-    const int beta_level = CV_SKIP(P, 2) ? 1 : *cv_hist_at(P, hist, sl, L + t - V.beta_delay);  // days before the data: level 1
+    const int beta_level = CV_SKIP(P, 2) ? 1 : (V.beta_delay <= 31 ? *cv_ring_at(P, rec, sl, L + t - V.beta_delay)
+                                                                    : *cv_hist_at(P, hist, sl, L + t - V.beta_delay));  // days before the data: level 1
     const float beta = (float)(K[AIE_CV_K_BETA_INTERCEPT * 64 + sl] + K[AIE_CV_K_BETA_SLOPE * 64 + sl] * (double)beta_level);
     const float s_eps = S1 + 1e-10f;
     const double q = (double)vac / (double)s_eps;
@@ -461,7 +469,22 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   }
 
   // ---- state write-back: every row by all 64 lanes (whole lines; the 13 idle lanes write zeros) ----
-  if (on && !CV_SKIP(P, 1)) *cv_hist_at(P, hist, s, L + t) = (uint8_t)a.level;
+  // today's level: one whole 64-byte row of the ring; the long history -- [chunk][state][16 days], the layout the window
+  // sums stream -- gets today's byte every step only when those sums run (51 one-byte stores spread over 816 bytes:
+  // seven partly written lines a step); the recurrence writes a state's 16 bytes once their chunk is complete
+  *cv_ring_at(P, rec, s, L + t) = on ? (uint8_t)a.level : (uint8_t)0;
+  if (!CV_SKIP(P, 1)) {
+    if constexpr (!RECUR) {
+      if (on) *cv_hist_at(P, hist, s, L + t) = (uint8_t)a.level;
+    } else if (((L + t) & 15) == 15) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 15; ++j) w[j >> 2] |= (uint32_t)*cv_ring_at(P, rec, sl, L + t - 15 + j) << (8 * (j & 3));
+      w[3] |= (uint32_t)a.level << 24;
+      if (s * 16 < P.cv_row)
+        *reinterpret_cast<uint4*>(hist + (int64_t)((L + t) >> 4) * P.cv_row + s * 16) = on ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
   cool[s] = on ? a.cooldown : 0;
   if (!CV_SKIP(P, 16)) {
     st[AIE_CV_ST_S * 64 + s] = on ? a.S : 0.f;

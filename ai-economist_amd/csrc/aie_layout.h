@@ -171,6 +171,9 @@ typedef struct aie_params {
   int32_t o_cv_subsidy_level;
   int32_t o_cv_sums;     /* record: AIE_CV_SUM_* float64 rows of 64 lanes                 */
   int32_t o_cv_p_index;  /* record: planner Health Index, Economic Index (float32 x 2)    */
+  int32_t o_cv_ring;     /* record: uint8 [32][64]: the stringency levels of the 32 most recent days, row = (filter_len + day) & 31,
+                          * one 64-byte row per day (what a step reads of the recent past -- yesterday, beta_delay days
+                          * ago, the lagged observation -- and writes for today are single rows, not 51 scattered bytes) */
   int32_t o_cv_acc;      /* record: float64 [F] rows of 64 lanes: each filter's discounted sum of stringency deltas
                           * over the current window (filter_recurrence), else unused       */
   int64_t a_cv_consts;   /* AIE_CV_K_* float64 rows of 64 (shared by all replicas)         */
@@ -367,6 +370,7 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   p->o_cv_cooldown = aie__rec(&cur, 4 * 64, 256);
   p->o_cv_sums = aie__rec(&cur, 8 * 64 * AIE_CV_SUM_COUNT, 256);
   p->o_cv_acc = aie__rec(&cur, 8 * 64 * (v->filter_recurrence ? v->num_filters : 0), 256);
+  p->o_cv_ring = aie__rec(&cur, 32 * 64, 256);
   p->o_cv_subsidy_level = aie__rec(&cur, 4, 4);
   p->o_cv_p_index = aie__rec(&cur, 8, 4);
   p->o_timestep = aie__rec(&cur, 4, 4);
@@ -420,7 +424,11 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
     aie__add(tt, "subsidy_level", AIE_I32, r0 + p->o_cv_subsidy_level, rs, 0, 0, 0, 0, 0, E);
     aie__add(tt, "timestep", AIE_I32, r0 + p->o_timestep, rs, 0, 0, 0, 0, 0, E);
     aie__add(tt, "completions", AIE_I32, r0 + p->o_completions, rs, 0, 0, 0, 0, 0, E);
-    /* stringency level on day (16*chunk + j - filter_len) of the episode, per state */
+    /* stringency level of the 32 most recent days: row (filter_len + day) & 31 (always current) */
+    aie__add(tt, "stringency_ring", AIE_U8, r0 + p->o_cv_ring, rs, 2, 32, n, 0, 0, E);
+    tt->t[tt->n - 1].stride[1] = 64;
+    /* stringency level on day (16*chunk + j - filter_len) of the episode, per state.  With filter_recurrence a chunk
+     * is written when its 16th day is over (from the ring); without, every day (the window sums stream it) */
     aie__add(tt, "stringency_history_chunks", AIE_U8, p->a_cv_hist, (int64_t)p->cv_nch * p->cv_row, 3,
              p->cv_nch, n, 16, 0, E);
     tt->t[tt->n - 1].stride[1] = p->cv_row;

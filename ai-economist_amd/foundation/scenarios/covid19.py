@@ -107,10 +107,17 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
 
     def stringency_level(self, e, day):
         """Stringency level of every state on day `day` of replica e's episode (day < 0: before the start date;
-        covid19_env.py:1210-1217 pads the time before the data begins with level 1)."""
+        covid19_env.py:1210-1217 pads the time before the data begins with level 1).  The 32 most recent days come
+        from the replica's ring (always current); older ones from the chunked history (with filter_recurrence a chunk
+        is written once its 16 days are over)."""
         tau = int(day) + int(self.model["filter_len"])
         assert tau >= 0
-        return self.backend.tensors["stringency_history_chunks"][e, tau // 16, :, tau % 16].cpu().numpy()
+        t = self.backend.tensors
+        now = int(t["timestep"][e].item()) + int(self.model["filter_len"])
+        assert tau <= now, "day %d of replica %d has not happened yet" % (day, e)
+        if now - tau < 32:
+            return t["stringency_ring"][e, tau % 32].cpu().numpy()
+        return t["stringency_history_chunks"][e, tau // 16, :, tau % 16].cpu().numpy()
 
     def scenario_metrics(self, tensors):
         from .. import metrics

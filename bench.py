@@ -136,7 +136,7 @@ def layout_bytes_per_env_step(be, wl):
     if wl.startswith("C4"):
         L, F = int(be.cfg.covid.filter_len), int(be.cfg.covid.num_filters)
         state_rw = 2 * (8 + 1) * n * 4 + n
-        if be.cfg.covid.filter_recurrence:  # O(1) filter update: F float64 sums per state r+w, 5 history bytes per state
+        if be.cfg.covid.filter_recurrence:  # O(1) filter update: F float64 sums per state r+w, 5 recent levels + today's per state
             b = dict(filter_sums_rw=2 * F * n * 8, history_bytes=6 * n, state_rw=state_rw, obs=obs, act=(n + 1) * 4,
                      rew_done=(n + 1) * 4 + 1)
         else:

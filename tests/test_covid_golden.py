@@ -114,7 +114,8 @@ def hip_state(env, e):
     L = env.model["filter_len"]
     tau = L + ts
     st = {k: t[k][e].cpu().numpy() for k in STATE_TOL}
-    st["stringency_level"] = t["stringency_history_chunks"][e, tau // 16, :, tau % 16].cpu().numpy()
+    st["stringency_level"] = t["stringency_ring"][e, tau % 32].cpu().numpy()  # (the ring holds the 32 most recent days)
+    assert np.array_equal(st["stringency_level"], env.stringency_level(e, ts))
     return st
 
 
@@ -403,8 +404,13 @@ def test_covid_filter_recurrence_vs_exact_window_sums():
             env.step({"a": torch.as_tensor(a, device="cuda"), "p": torch.as_tensor(p, device="cuda")})
         if k % 20 == 0 or k == T:
             tr, tx = env_r.tensors, env_x.tensors
-            for name in ("cooldown_until", "subsidy_level", "timestep", "stringency_history_chunks"):
+            for name in ("cooldown_until", "subsidy_level", "timestep", "stringency_ring"):
                 assert torch.equal(tr[name], tx[name]), name
+            # the long history: every day without the recurrence, whole 16-day chunks with it
+            done_chunks = (int(env_r.model["filter_len"]) + k + 1) // 16
+            assert torch.equal(tr["stringency_history_chunks"][:, :done_chunks], tx["stringency_history_chunks"][:, :done_chunks])
+            for day in (k, k - 17, k - 40, 0, -5):
+                assert np.array_equal(env_r.stringency_level(3, day), env_x.stringency_level(3, day)), day
             u_r, u_x = tr["unemployed"].double(), tx["unemployed"].double()
             worst = max(worst, float(((u_r - u_x).abs() / u_x.abs().clamp_min(1.0)).max()))
             for name, tol in STATE_TOL.items():
