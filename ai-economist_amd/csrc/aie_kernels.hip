@@ -2038,9 +2038,12 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
       // last_incomes sorted ascending (redistribution.py:908-911): rank by counting
       const double per = (double)P.c.tax_period;
       const double x = R_F64(c, o_tax_last_income)[i] / per;
+      double* xs = scr_cmr(c);  // (free until the rewards: one division per agent, not one per pair)
+      xs[i] = x;
+      AIE_WSYNC();
       int rank = 0;
       for (int j = 0; j < n; ++j) {
-        const double y = R_F64(c, o_tax_last_income)[j] / per;
+        const double y = xs[j];
         rank += (y < x || (y == x && j < i)) ? 1 : 0;
       }
       scr_sorted_inc(c)[rank] = x;
