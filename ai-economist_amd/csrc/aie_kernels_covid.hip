@@ -190,7 +190,7 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
   const aie_params& P = *params;
   const int e = replica_of_block((int)blockIdx.x, P.E);
   if (env_mask && !env_mask[e]) return;
-  const int s = (int)threadIdx.x, n = P.n, L = P.cv_L;
+  const int s = (int)threadIdx.x, n = P.n, L = P.cv_L, PT = P.cv_pitch;
   const bool on = s < n;
   uint8_t* rec = arena + P.a_records + (int64_t)e * P.rec_bytes;
   float* st = reinterpret_cast<float*>(rec + P.o_cv_state);
@@ -211,7 +211,7 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
   if (P.c.covid.filter_recurrence) {  // A_0 of every filter (aie_covid_prepare_kernel)
     double* accs = reinterpret_cast<double*>(rec + P.o_cv_acc);
     const double* acc0 = reinterpret_cast<const double*>(arena + P.a_cv_acc0);
-    for (int f = 0; f < P.cv_F; ++f) accs[f * 64 + s] = acc0[f * 64 + s];
+    for (int f = 0; f < P.cv_F; ++f) accs[f * PT + s] = acc0[f * 64 + s];
   }
   a.S = (float)K[AIE_CV_K_S0 * 64 + sl];
   a.I = (float)K[AIE_CV_K_I0 * 64 + sl];
@@ -223,18 +223,20 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
   a.subsidy = 0.f;
   a.level = h0[L * n + sl];
   a.cooldown = 0;
-  st[AIE_CV_ST_S * 64 + s] = on ? a.S : 0.f;
-  st[AIE_CV_ST_I * 64 + s] = on ? a.I : 0.f;
-  st[AIE_CV_ST_R * 64 + s] = on ? a.R : 0.f;
-  st[AIE_CV_ST_D * 64 + s] = on ? a.D : 0.f;
-  st[AIE_CV_ST_V * 64 + s] = on ? a.V : 0.f;
-  st[AIE_CV_ST_U * 64 + s] = on ? a.U : 0.f;
-  st[AIE_CV_ST_PROD * 64 + s] = 0.f;
-  st[AIE_CV_ST_SUBSIDY * 64 + s] = 0.f;
-  st[AIE_CV_ST_HEALTH_INDEX * 64 + s] = 0.f;
-  st[AIE_CV_ST_ECONOMIC_INDEX * 64 + s] = 0.f;
-  for (int k = 0; k < AIE_CV_SUM_COUNT; ++k) reinterpret_cast<double*>(rec + P.o_cv_sums)[k * 64 + s] = 0.0;
-  reinterpret_cast<int32_t*>(rec + P.o_cv_cooldown)[s] = 0;
+  if (on) {  // the record's rows are packed: n lanes each (aie_layout.h: cv_pitch)
+    st[AIE_CV_ST_S * PT + s] = a.S;
+    st[AIE_CV_ST_I * PT + s] = a.I;
+    st[AIE_CV_ST_R * PT + s] = a.R;
+    st[AIE_CV_ST_D * PT + s] = a.D;
+    st[AIE_CV_ST_V * PT + s] = a.V;
+    st[AIE_CV_ST_U * PT + s] = a.U;
+    st[AIE_CV_ST_PROD * PT + s] = 0.f;
+    st[AIE_CV_ST_SUBSIDY * PT + s] = 0.f;
+    st[AIE_CV_ST_HEALTH_INDEX * PT + s] = 0.f;
+    st[AIE_CV_ST_ECONOMIC_INDEX * PT + s] = 0.f;
+    for (int k = 0; k < AIE_CV_SUM_COUNT; ++k) reinterpret_cast<double*>(rec + P.o_cv_sums)[k * PT + s] = 0.0;
+    reinterpret_cast<int32_t*>(rec + P.o_cv_cooldown)[s] = 0;
+  }
   if (s == 0) {
     *reinterpret_cast<int32_t*>(rec + P.o_cv_subsidy_level) = 0;
     *reinterpret_cast<int32_t*>(rec + P.o_timestep) = 0;
@@ -264,7 +266,7 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   const aie_params& P = *params;
   const aie_covid_config& V = P.c.covid;
   const int e = replica_of_block((int)blockIdx.x, P.E);
-  const int s = (int)threadIdx.x, n = P.n, L = P.cv_L, NL = P.cv_NL, NS = P.cv_NS;
+  const int s = (int)threadIdx.x, n = P.n, L = P.cv_L, NL = P.cv_NL, NS = P.cv_NS, PT = P.cv_pitch;
   const bool on = s < n;
   const int sl = on ? s : n - 1;  // idle lanes shadow the last state (loads stay in bounds)
   uint8_t* rec = arena + P.a_records + (int64_t)e * P.rec_bytes;
@@ -280,13 +282,13 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   // resident at once, so a launch lasts as long as that chain.  What does not depend on the timestep travels beside
   // it; the read-modify-write accumulators (episode sums, index sums) are read now and only written at the end.
   double* sums = reinterpret_cast<double*>(rec + P.o_cv_sums);
-  const double sum_u0 = sums[AIE_CV_SUM_UNEMPLOYED * 64 + s], sum_s0 = sums[AIE_CV_SUM_STRINGENCY * 64 + s];
-  const double sum_p0 = sums[AIE_CV_SUM_PRODUCTIVITY * 64 + s], sum_b0 = sums[AIE_CV_SUM_SUBSIDY * 64 + s];
-  const float hidx0 = st[AIE_CV_ST_HEALTH_INDEX * 64 + s], eidx0 = st[AIE_CV_ST_ECONOMIC_INDEX * 64 + s];
+  const double sum_u0 = sums[AIE_CV_SUM_UNEMPLOYED * PT + sl], sum_s0 = sums[AIE_CV_SUM_STRINGENCY * PT + sl];
+  const double sum_p0 = sums[AIE_CV_SUM_PRODUCTIVITY * PT + sl], sum_b0 = sums[AIE_CV_SUM_SUBSIDY * PT + sl];
+  const float hidx0 = st[AIE_CV_ST_HEALTH_INDEX * PT + sl], eidx0 = st[AIE_CV_ST_ECONOMIC_INDEX * PT + sl];
   float* pidx = reinterpret_cast<float*>(rec + P.o_cv_p_index);  // planner.state[...] += ... :1160-1161
   const float pidx0 = pidx[0], pidx1 = pidx[1];
-  const float S1 = st[AIE_CV_ST_S * 64 + sl], I1 = st[AIE_CV_ST_I * 64 + sl], R1 = st[AIE_CV_ST_R * 64 + sl];
-  const float V1 = st[AIE_CV_ST_V * 64 + sl], D1 = st[AIE_CV_ST_D * 64 + sl];
+  const float S1 = st[AIE_CV_ST_S * PT + sl], I1 = st[AIE_CV_ST_I * PT + sl], R1 = st[AIE_CV_ST_R * PT + sl];
+  const float V1 = st[AIE_CV_ST_V * PT + sl], D1 = st[AIE_CV_ST_D * PT + sl];
   const int cool0 = cool[sl];
   // the lagged stringency level of the new observation (:957-970), fetched with the other history bytes: a load issued
   // behind today's stores would wait for them (memory operations of a wave complete in order)
@@ -394,8 +396,8 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
 #pragma unroll
       for (int f = 0; f < F; ++f) {
         const double r = V.filter_decay[f];
-        acc[f] = r * (accs[f * 64 + sl] - V.filter_tail[f] * d_old) + d_new;
-        accs[f * 64 + s] = on ? acc[f] : 0.0;  // (all 64 lanes: whole 128-byte lines, no partial-line writes)
+        acc[f] = r * (accs[f * PT + sl] - V.filter_tail[f] * d_old) + d_new;
+        if (on) accs[f * PT + s] = acc[f];
       }
     } else {
     const double* __restrict__ G = reinterpret_cast<const double*>(arena + P.a_cv_filters);  // [row][F]
@@ -468,7 +470,7 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     a.prod = (float)((diff > 0.0 ? diff : 0.0) * (double)(float)V.daily_production_per_worker) + a.subsidy;
   }
 
-  // ---- state write-back: every row by all 64 lanes (whole lines; the 13 idle lanes write zeros) ----
+  // ---- state write-back (rows of n lanes, packed: a replica's rows are one contiguous block) ----
   // today's level: one whole 64-byte row of the ring; the long history -- [chunk][state][16 days], the layout the window
   // sums stream -- gets today's byte every step only when those sums run (51 one-byte stores spread over 816 bytes:
   // seven partly written lines a step); the recurrence writes a state's 16 bytes once their chunk is complete
@@ -485,23 +487,25 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
         *reinterpret_cast<uint4*>(hist + (int64_t)((L + t) >> 4) * P.cv_row + s * 16) = on ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
     }
   }
-  cool[s] = on ? a.cooldown : 0;
-  if (!CV_SKIP(P, 16)) {
-    st[AIE_CV_ST_S * 64 + s] = on ? a.S : 0.f;
-    st[AIE_CV_ST_I * 64 + s] = on ? a.I : 0.f;
-    st[AIE_CV_ST_R * 64 + s] = on ? a.R : 0.f;
-    st[AIE_CV_ST_D * 64 + s] = on ? a.D : 0.f;
-    st[AIE_CV_ST_V * 64 + s] = on ? a.V : 0.f;
-    st[AIE_CV_ST_U * 64 + s] = on ? a.U : 0.f;
-    st[AIE_CV_ST_PROD * 64 + s] = on ? a.prod : 0.f;
-    st[AIE_CV_ST_SUBSIDY * 64 + s] = on ? a.subsidy : 0.f;
-  }
-  // per-state sums over the days of the episode, for scenario_metrics :1613-1687
-  if (!CV_SKIP(P, 8)) {
-    sums[AIE_CV_SUM_UNEMPLOYED * 64 + s] = on ? sum_u0 + (double)a.U : 0.0;
-    sums[AIE_CV_SUM_STRINGENCY * 64 + s] = on ? sum_s0 + (double)a.level : 0.0;
-    sums[AIE_CV_SUM_PRODUCTIVITY * 64 + s] = on ? sum_p0 + (double)a.prod : 0.0;
-    sums[AIE_CV_SUM_SUBSIDY * 64 + s] = on ? sum_b0 + (double)a.subsidy : 0.0;
+  if (on) {
+    cool[s] = a.cooldown;
+    if (!CV_SKIP(P, 16)) {
+      st[AIE_CV_ST_S * PT + s] = a.S;
+      st[AIE_CV_ST_I * PT + s] = a.I;
+      st[AIE_CV_ST_R * PT + s] = a.R;
+      st[AIE_CV_ST_D * PT + s] = a.D;
+      st[AIE_CV_ST_V * PT + s] = a.V;
+      st[AIE_CV_ST_U * PT + s] = a.U;
+      st[AIE_CV_ST_PROD * PT + s] = a.prod;
+      st[AIE_CV_ST_SUBSIDY * PT + s] = a.subsidy;
+    }
+    // per-state sums over the days of the episode, for scenario_metrics :1613-1687
+    if (!CV_SKIP(P, 8)) {
+      sums[AIE_CV_SUM_UNEMPLOYED * PT + s] = sum_u0 + (double)a.U;
+      sums[AIE_CV_SUM_STRINGENCY * PT + s] = sum_s0 + (double)a.level;
+      sums[AIE_CV_SUM_PRODUCTIVITY * PT + s] = sum_p0 + (double)a.prod;
+      sums[AIE_CV_SUM_SUBSIDY * PT + s] = sum_b0 + (double)a.subsidy;
+    }
   }
   if (s == 0) {
     *reinterpret_cast<int32_t*>(rec + P.o_timestep) = t;
@@ -526,8 +530,8 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
     const float ra = ((wh * h + we * ec) / (wh + we)) / rnf;
     reinterpret_cast<float*>(arena + P.a_rew_a)[(int64_t)e * n + s] = ra;
     if (rew_log) rew_log[(int64_t)e * (n + 2) + s] = ra;
-    st[AIE_CV_ST_HEALTH_INDEX * 64 + s] = hidx0 + h;  // agent.state["Health Index"] += ... :1123-1125 (float32)
-    st[AIE_CV_ST_ECONOMIC_INDEX * 64 + s] = eidx0 + ec;
+    st[AIE_CV_ST_HEALTH_INDEX * PT + s] = hidx0 + h;  // agent.state["Health Index"] += ... :1123-1125 (float32)
+    st[AIE_CV_ST_ECONOMIC_INDEX * PT + s] = eidx0 + ec;
   }
   if (s == 0) {
     const float sum_md = np_sum_f32_lds(red[0], n);

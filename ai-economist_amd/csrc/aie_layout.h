@@ -165,6 +165,8 @@ typedef struct aie_params {
   int32_t cv_nch;        /* 16-day chunks in the per-replica stringency history           */
   int32_t cv_row;        /* bytes per history chunk = 16 * n rounded up to 64              */
   int32_t cv_nrow_obs;   /* rows of the per-replica agent observation block               */
+  int32_t cv_pitch;      /* lanes per row of the record's per-state rows (= n: packed; the kernel is HBM-bound and a
+                          * 64-lane pitch would move 20 % idle bytes)                       */
   int32_t cv_t_first_delivery;
   int32_t o_cv_state;    /* record: AIE_CV_ST_* float32 rows of 64 lanes                  */
   int32_t o_cv_cooldown; /* record: int32 row                                              */
@@ -366,10 +368,11 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   p->planner_acts = 1;
 
   int32_t cur = 0;
-  p->o_cv_state = aie__rec(&cur, 4 * 64 * AIE_CV_ST_COUNT, 256);
-  p->o_cv_cooldown = aie__rec(&cur, 4 * 64, 256);
-  p->o_cv_sums = aie__rec(&cur, 8 * 64 * AIE_CV_SUM_COUNT, 256);
-  p->o_cv_acc = aie__rec(&cur, 8 * 64 * (v->filter_recurrence ? v->num_filters : 0), 256);
+  p->cv_pitch = n;
+  p->o_cv_state = aie__rec(&cur, 4 * n * AIE_CV_ST_COUNT, 256);
+  p->o_cv_cooldown = aie__rec(&cur, 4 * n, 4);
+  p->o_cv_sums = aie__rec(&cur, 8 * n * AIE_CV_SUM_COUNT, 8);
+  p->o_cv_acc = aie__rec(&cur, 8 * n * (v->filter_recurrence ? v->num_filters : 0), 8);
   p->o_cv_ring = aie__rec(&cur, 32 * 64, 256);
   p->o_cv_subsidy_level = aie__rec(&cur, 4, 4);
   p->o_cv_p_index = aie__rec(&cur, 8, 4);
@@ -412,14 +415,14 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
     static const char* sum_name[AIE_CV_SUM_COUNT] = {"sum_unemployed", "sum_stringency_level",
                                                      "sum_postsubsidy_productivity", "sum_subsidy"};
     for (int k = 0; k < AIE_CV_SUM_COUNT; ++k)
-      aie__add(tt, sum_name[k], AIE_F64, r0 + p->o_cv_sums + 512 * k, rs, 1, n, 0, 0, 0, E);
+      aie__add(tt, sum_name[k], AIE_F64, r0 + p->o_cv_sums + 8 * n * k, rs, 1, n, 0, 0, 0, E);
     aie__add(tt, "planner_health_economic_index", AIE_F32, r0 + p->o_cv_p_index, rs, 1, 2, 0, 0, 0, E);
     if (v->filter_recurrence) {
       aie__add(tt, "filter_discounted_delta_sums", AIE_F64, r0 + p->o_cv_acc, rs, 2, p->cv_F, n, 0, 0, E);
-      tt->t[tt->n - 1].stride[1] = 512;
+      tt->t[tt->n - 1].stride[1] = 8 * n;
     }
     for (int k = 0; k < AIE_CV_ST_COUNT; ++k)
-      aie__add(tt, st_name[k], AIE_F32, r0 + p->o_cv_state + 256 * k, rs, 1, n, 0, 0, 0, E);
+      aie__add(tt, st_name[k], AIE_F32, r0 + p->o_cv_state + 4 * n * k, rs, 1, n, 0, 0, 0, E);
     aie__add(tt, "cooldown_until", AIE_I32, r0 + p->o_cv_cooldown, rs, 1, n, 0, 0, 0, E);
     aie__add(tt, "subsidy_level", AIE_I32, r0 + p->o_cv_subsidy_level, rs, 0, 0, 0, 0, 0, E);
     aie__add(tt, "timestep", AIE_I32, r0 + p->o_timestep, rs, 0, 0, 0, 0, 0, E);
