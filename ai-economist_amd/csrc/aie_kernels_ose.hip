@@ -88,56 +88,6 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, const aie_param
   return Ctx{P, R, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e};
 }
 
-// Record HBM -> LDS (the image before the generator key), key -> registers, cold per-agent fields -> registers.
-// Every load of a lane is issued before the first one is waited for: a replica starts while the other ~2800 resident
-// waves are streaming their observation rows out, and under that store traffic a load round trip takes several
-// microseconds -- the copy loop with one round trip per 16 bytes per lane cost 22 of a wave's 93 us (tools/ose_trace.py).
-__device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m, OseLane& L) {
-  const uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
-  const uint4* src = reinterpret_cast<const uint4*>(g);
-  uint4* dst = reinterpret_cast<uint4*>(c.rec);
-  const int nq = rec_lds_bytes(c.P) >> 4;
-  const int lane = c.tid & 63;
-  const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
-  const double* gs = reinterpret_cast<const double*>(g + c.P.o_skill);
-  const double* ge = reinterpret_cast<const double*>(g + c.P.o_esc_coin);
-#pragma unroll
-  for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + lane];
-  m.r[9] = lane < 48 ? key[576 + lane] : 0u;
-  m.twists = 0;
-  L.skill0 = c.tid < c.P.n ? gs[c.tid] : 0.0;
-  L.esc0 = c.tid < c.P.n ? ge[c.tid] : 0.0;
-  L.skill1 = c.tid + OSE_NT < c.P.n ? gs[c.tid + OSE_NT] : 0.0;
-  L.esc1 = c.tid + OSE_NT < c.P.n ? ge[c.tid + OSE_NT] : 0.0;
-  L.skobs0 = (float)(L.skill0 / c.P.c.labor_pmsm);
-  L.skobs1 = (float)(L.skill1 / c.P.c.labor_pmsm);
-  L.met_inc0 = L.met_inc1 = L.met_paid0 = L.met_paid1 = 0.0;
-  if (c.P.has_tax && c.met) {
-    const double* mi = reinterpret_cast<const double*>(c.met + c.P.mo_tax_income);
-    const double* mp = reinterpret_cast<const double*>(c.met + c.P.mo_tax_paid);
-    if (c.tid < c.P.n) { L.met_inc0 = mi[c.tid]; L.met_paid0 = mp[c.tid]; }
-    if (c.tid + OSE_NT < c.P.n) { L.met_inc1 = mi[c.tid + OSE_NT]; L.met_paid1 = mp[c.tid + OSE_NT]; }
-  }
-  // eight 16-byte loads in flight per lane and batch (one batch covers records up to 8 KiB); scalars rather than an
-  // array: the array stayed in scratch memory
-  // Fields every step overwrites before it reads them are not fetched: with tax_period == 1 every step is a tax day,
-  // which rewrites last_income / last_marginal_rate (adjacent in the record) before the observations look at them.
-  // HBM reads mixed into the launch's store stream cost about twice their byte share (tools/phase_overlap.hip).
-  const bool dead = c.P.has_tax && c.P.c.tax_period == 1;
-  const int dead_lo = (c.P.o_tax_last_income + 15) >> 4, dead_hi = (c.P.o_tax_last_marginal_rate + 8 * c.P.n) >> 4;
-  for (int q0 = c.tid; q0 < (OSE_SKIP(c, 32) ? 0 : nq); q0 += 8 * OSE_NT) {
-    uint4 v0, v1, v2, v3, v4, v5, v6, v7;
-#define OSE_LIVE(k) (q0 + (k) * OSE_NT < nq && !(dead && q0 + (k) * OSE_NT >= dead_lo && q0 + (k) * OSE_NT < dead_hi))
-#define OSE_LD(k) if (OSE_LIVE(k)) v##k = src[q0 + (k) * OSE_NT];
-#define OSE_ST(k) if (OSE_LIVE(k)) dst[q0 + (k) * OSE_NT] = v##k;
-    OSE_LD(0) OSE_LD(1) OSE_LD(2) OSE_LD(3) OSE_LD(4) OSE_LD(5) OSE_LD(6) OSE_LD(7)
-    OSE_ST(0) OSE_ST(1) OSE_ST(2) OSE_ST(3) OSE_ST(4) OSE_ST(5) OSE_ST(6) OSE_ST(7)
-#undef OSE_LD
-#undef OSE_ST
-#undef OSE_LIVE
-  }
-}
-
 // The draws of np.random.permutation(n) (World.get_random_order_agents, world.py:418-422) for a caller that never
 // looks at the order: only the position of the stream afterwards matters.  Fisher-Yates index i = n-1 .. 1 consumes
 // 32-bit words until one satisfies (word & mask(i)) <= i.  A block of up to 64 consecutive words of the generator
@@ -194,12 +144,77 @@ __device__ __forceinline__ void rng_skip_permutation(MT& m, int lane, int n) {
   }
 }
 
+// Record HBM -> LDS (the image before the generator key), key -> registers, cold per-agent fields -> registers.
+// Every load of a lane is issued before the first one is waited for: a replica starts while the other ~2800 resident
+// waves are streaming their observation rows out, and under that store traffic a load round trip takes several
+// microseconds -- the copy loop with one round trip per 16 bytes per lane cost 22 of a wave's 93 us (tools/ose_trace.py).
+// `early_perm`: SimpleLabor is the first component, so the first thing the step does with the generator is skipping its
+// agent-order permutation -- which needs the key rows and the position, not the record: it runs between issuing the
+// record's loads and waiting for them (~8 us of work under a ~12 us load round trip); m.pos is then the position
+// behind the permutation.
+__device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m, OseLane& L,
+                                                bool early_perm = false) {
+  const uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
+  const uint4* src = reinterpret_cast<const uint4*>(g);
+  uint4* dst = reinterpret_cast<uint4*>(c.rec);
+  const int nq = rec_lds_bytes(c.P) >> 4;
+  const int lane = c.tid & 63;
+  const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
+  const double* gs = reinterpret_cast<const double*>(g + c.P.o_skill);
+  const double* ge = reinterpret_cast<const double*>(g + c.P.o_esc_coin);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + lane];
+  m.r[9] = lane < 48 ? key[576 + lane] : 0u;
+  m.twists = 0;
+  m.pos = early_perm ? uni(*reinterpret_cast<const int32_t*>(g + c.P.o_mt_pos)) : 0;
+  L.skill0 = c.tid < c.P.n ? gs[c.tid] : 0.0;
+  L.esc0 = c.tid < c.P.n ? ge[c.tid] : 0.0;
+  L.skill1 = c.tid + OSE_NT < c.P.n ? gs[c.tid + OSE_NT] : 0.0;
+  L.esc1 = c.tid + OSE_NT < c.P.n ? ge[c.tid + OSE_NT] : 0.0;
+  L.skobs0 = (float)(L.skill0 / c.P.c.labor_pmsm);
+  L.skobs1 = (float)(L.skill1 / c.P.c.labor_pmsm);
+  L.met_inc0 = L.met_inc1 = L.met_paid0 = L.met_paid1 = 0.0;
+  if (c.P.has_tax && c.met) {
+    const double* mi = reinterpret_cast<const double*>(c.met + c.P.mo_tax_income);
+    const double* mp = reinterpret_cast<const double*>(c.met + c.P.mo_tax_paid);
+    if (c.tid < c.P.n) { L.met_inc0 = mi[c.tid]; L.met_paid0 = mp[c.tid]; }
+    if (c.tid + OSE_NT < c.P.n) { L.met_inc1 = mi[c.tid + OSE_NT]; L.met_paid1 = mp[c.tid + OSE_NT]; }
+  }
+  // eight 16-byte loads in flight per lane and batch (one batch covers records up to 8 KiB); scalars rather than an
+  // array: the array stayed in scratch memory
+  // Fields every step overwrites before it reads them are not fetched: with tax_period == 1 every step is a tax day,
+  // which rewrites last_income / last_marginal_rate (adjacent in the record) before the observations look at them.
+  // HBM reads mixed into the launch's store stream cost about twice their byte share (tools/phase_overlap.hip).
+  const bool dead = c.P.has_tax && c.P.c.tax_period == 1;
+  const int dead_lo = (c.P.o_tax_last_income + 15) >> 4, dead_hi = (c.P.o_tax_last_marginal_rate + 8 * c.P.n) >> 4;
+  const int nq_eff = OSE_SKIP(c, 32) ? 0 : nq;
+#define OSE_LIVE(k) (q0 + (k) * OSE_NT < nq_eff && !(dead && q0 + (k) * OSE_NT >= dead_lo && q0 + (k) * OSE_NT < dead_hi))
+#define OSE_LD(k) if (OSE_LIVE(k)) v##k = src[q0 + (k) * OSE_NT];
+#define OSE_ST(k) if (OSE_LIVE(k)) dst[q0 + (k) * OSE_NT] = v##k;
+  {  // the first batch, with the permutation skip between its loads and its LDS writes (wave-uniform control flow)
+    const int q0 = c.tid;
+    uint4 v0, v1, v2, v3, v4, v5, v6, v7;
+    OSE_LD(0) OSE_LD(1) OSE_LD(2) OSE_LD(3) OSE_LD(4) OSE_LD(5) OSE_LD(6) OSE_LD(7)
+    if (early_perm) rng_skip_permutation(m, lane, c.P.n);
+    OSE_ST(0) OSE_ST(1) OSE_ST(2) OSE_ST(3) OSE_ST(4) OSE_ST(5) OSE_ST(6) OSE_ST(7)
+  }
+  for (int q0 = c.tid + 8 * OSE_NT; q0 < nq_eff; q0 += 8 * OSE_NT) {
+    uint4 v0, v1, v2, v3, v4, v5, v6, v7;
+    OSE_LD(0) OSE_LD(1) OSE_LD(2) OSE_LD(3) OSE_LD(4) OSE_LD(5) OSE_LD(6) OSE_LD(7)
+    OSE_ST(0) OSE_ST(1) OSE_ST(2) OSE_ST(3) OSE_ST(4) OSE_ST(5) OSE_ST(6) OSE_ST(7)
+  }
+#undef OSE_LD
+#undef OSE_ST
+#undef OSE_LIVE
+}
+
 // SimpleLabor.component_step simple_labor.py:105-126.  The random agent order
 // (world.py:418-422) is drawn -- it advances the stream -- but the result does not depend
 // on it, so the update itself runs one lane per agent.
-__device__ __forceinline__ void labor_component_step(const Ctx& c, const OseScratch& s, MT& m, const OseLane& L) {
+__device__ __forceinline__ void labor_component_step(const Ctx& c, const OseScratch& s, MT& m, const OseLane& L,
+                                                     bool perm_done = false) {
   const int n = c.P.n;
-  rng_skip_permutation(m, c.tid & 63, n);
+  if (!perm_done) rng_skip_permutation(m, c.tid & 63, n);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int i = c.tid + OSE_NT * k, a = L.act(k);
@@ -717,7 +732,8 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
   MT m;
   OseLane L;
   OSE_STAMP(c, 0);
-  ose_load_record(c, arena, m, L);
+  const bool early_perm = P.c.n_components > 0 && P.c.components[0] == AIE_COMP_SIMPLE_LABOR;
+  ose_load_record(c, arena, m, L, early_perm);
   // parse_actions (base_agent.py:407-438)
   bool bad_a = false, bad_p = false;  // out-of-range indices: NO-OP here, an exception in the reference (AIE_ERR_*)
 #pragma unroll
@@ -757,11 +773,11 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
   // the observations this launch leaves behind: the step's, or -- auto-reset, episode over -- the next episode's first
   const bool will_restart = R.auto_reset && uni(*R_I32(c, o_timestep)) + 1 >= P.c.episode_length;
   ose_store_agent_masks(c, s, arena, will_restart || (P.has_labor && uni(*R_I32(c, o_first_step)) != 0));
-  m.pos = uni(*R_I32(c, o_mt_pos));
+  if (!early_perm) m.pos = uni(*R_I32(c, o_mt_pos));
   if (tid == 0) *R_I32(c, o_timestep) += 1;
   if (c.ev && tid == 0) c.ev[0] = 0;
   for (int k = 0; k < P.c.n_components; ++k) {
-    if (P.c.components[k] == AIE_COMP_SIMPLE_LABOR) labor_component_step(c, s, m, L);
+    if (P.c.components[k] == AIE_COMP_SIMPLE_LABOR) labor_component_step(c, s, m, L, early_perm && k == 0);
     else if (P.c.components[k] == AIE_COMP_TAX) ose_tax_component_step(c, s, m, L);
     else if (P.c.components[k] == AIE_COMP_WEALTH_REDISTRIBUTION) ose_wealth_component_step(c, s, L);
     OSE_STAMP(c, 2 + (k < 2 ? k : 1));
