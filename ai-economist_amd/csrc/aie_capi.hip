@@ -428,7 +428,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
     hipLaunchKernelGGL(aie_ose_step_kernel, dim3((unsigned)env->P.E), dim3(OSE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
 #ifdef AIE_DEV
-  else if (env->spec >= 0 && env->P.dev_trace != nullptr && env->P.dev_skip_mask == 0) {
+  else if (env->spec >= 0 && !(env->P.dev_skip_mask & (1 << 20)) && (env->P.dev_trace != nullptr || env->P.dev_skip_mask != 0)) {
     const dim3 g((unsigned)env->P.E), b(2 * AIE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define AIE_SPEC_LAUNCH_TR(K) \

@@ -78,6 +78,8 @@ struct Ctx {
                      // instruction cache, and rarely taken paths pay for every line they add)
   int tid;
   int e;
+  uint32_t* mtwin;   // LDS [640]: the generator's current window for the regeneration's sparse reads, or nullptr (mt_window_in_lds)
+  int skipm;         // development (-DAIE_DEV builds: aie_dev_set_skip_mask): phases switched off; constant 0 otherwise
 };
 
 #define R_F64(c, off) (reinterpret_cast<double*>((c).rec + (c).P.off))
@@ -117,7 +119,7 @@ __host__ __device__ inline size_t stage_bytes(const aie_params& P) {
   return (b + 15) / 16 * 16;
 }
 
-__host__ __device__ inline size_t lds_bytes(const aie_params& P) {
+__host__ __device__ inline size_t lds_bytes_base(const aie_params& P) {
   size_t b = (size_t)rec_lds_bytes(P);
   b += AIE_MAX_BRACKETS * 4;
   b = (b + 15) / 16 * 16;
@@ -127,12 +129,30 @@ __host__ __device__ inline size_t lds_bytes(const aie_params& P) {
   b += AIE_SRC_CAP * 2 + 16 + (size_t)pad4(P.n) * 4;
   b += 16 + AIE_DIRTY_CAP * 2;
   b = (b + 15) / 16 * 16;
+  return b;
+}
+// The regeneration reads ~80 of a step's 2 500 generator words, scattered over five consecutive windows.  Where a
+// workgroup's LDS footprint leaves room for it WITHOUT costing residency (16 workgroups per CU need <= 10 240 B each),
+// the second wave publishes each window's ten rows to LDS (ten stores) and every lane fetches its two adjacent words
+// with one ds_read2 -- instead of selecting them out of the row registers with ten lane permutes and ten selects per
+// word (scenario_step_regen).  Larger records (ten agents and more) keep the register gather.
+#define AIE_MT_WINDOW_LDS_BYTES 2560  // 10 rows x 64 lanes x 4 B (row 9's upper 16 lanes are padding)
+__host__ __device__ inline bool mt_window_in_lds(const aie_params& P) {
+#ifdef AIE_NO_MT_WINDOW_LDS  // (A/B builds)
+  return false;
+#else
+  return !P.regen_general && lds_bytes_base(P) + AIE_MT_WINDOW_LDS_BYTES <= 10240;
+#endif
+}
+__host__ __device__ inline size_t lds_bytes(const aie_params& P) {
+  size_t b = lds_bytes_base(P);
+  if (mt_window_in_lds(P)) b += AIE_MT_WINDOW_LDS_BYTES;
   if (P.regen_general) b += 2 * (((size_t)P.HW + 15) / 16 * 16);
   return (b + 15) / 16 * 16;
 }
 
 __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R, uint8_t* lds, int e, int tid,
-                                        uint8_t* arena = nullptr, bool with_events = true) {
+                                        uint8_t* arena = nullptr, bool with_events = true, int skipm = 0) {
   uint8_t* q = lds + rec_lds_bytes(P);
   int32_t* act_p = reinterpret_cast<int32_t*>(q);
   q += AIE_MAX_BRACKETS * 4;
@@ -152,6 +172,8 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R
   int32_t* dirty = reinterpret_cast<int32_t*>(q);
   q += 16 + AIE_DIRTY_CAP * 2;
   q = lds + ((q - lds) + 15) / 16 * 16;
+  uint32_t* mtwin = mt_window_in_lds(P) ? reinterpret_cast<uint32_t*>(q) : nullptr;
+  if (mt_window_in_lds(P)) q += AIE_MT_WINDOW_LDS_BYTES;
   uint8_t* snap = P.regen_general ? q : nullptr;
   uint8_t* met = arena ? arena + R.a_metrics + (int64_t)e * P.met_bytes : nullptr;
   // with_events == false is a compile-time constant in the common step kernel: every `if (c.ev)` / `if (c.saez)`
@@ -159,7 +181,7 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R
   int32_t* ev = (with_events && arena && e < P.ev_replicas)
                     ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * P.ev_stride) : nullptr;
   const bool saez = with_events && P.c.tax_model == AIE_TAX_SAEZ;
-  return Ctx{P, R, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, snap, met, ev, saez, with_events, tid, e};
+  return Ctx{P, R, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, snap, met, ev, saez, with_events, tid, e, mtwin, skipm};
 }
 
 // ------------------------------------------------------------------------------------
@@ -326,9 +348,14 @@ __device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__
 // The reference draws from the process-global np.random (F/base/base_env.py:493,
 // F/base/world.py:420, F/components/move.py:138, layout_from_file.py:361-366,400).
 // ------------------------------------------------------------------------------------
+// one word of the twist: y = (a & UPPER) | (b & LOWER); m ^ (y >> 1) ^ (y & 1 ? MATRIX_A : 0) -- five VALU operations
+// (bit-field insert, shift, sign-extended bit 0, one three-input bit operation, xor); the compiler's own selection of
+// the plain C expression takes seven, and the twist is a third of the step kernel's vector instructions
 __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t m) {
-  uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-  return m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  uint32_t y;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(0x7fffffffu), "v"(b), "v"(a));  // (b & mask) | (a & ~mask)
+  const uint32_t low = (uint32_t)__builtin_amdgcn_sbfe((int)b, 0, 1);           // y & 1 ? 0xffffffff : 0
+  return __builtin_amdgcn_bitop3_b32(low, 0x9908b0dfu, y >> 1, 0x6a) ^ m;        // ((low & MATRIX_A) ^ (y >> 1)) ^ m
 }
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   y ^= (y >> 11);
@@ -347,13 +374,21 @@ __device__ __forceinline__ uint32_t lane_get(uint32_t v, int src_lane) { return 
 // lanes [0, ROT) of ROW_HI), so they are merged per source lane first and fetched with one permute; the
 // neighbour word k+1 is a one-lane wave rotation (DPP), with the last lane patched from the next row.
 __device__ __forceinline__ uint32_t lane_rol1(uint32_t v) {  // lane l <- lane (l + 1) & 63
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+}
+// lane l <- lane l + 1 of `v`, lane LAST <- the (wave-uniform) first word of the next row.  LAST == 63: ONE DPP move --
+// a wavefront shift leaves the last lane, which has no source, at the destination's previous value (bound_ctrl off);
+// a select on `lane == 63` compiles to a branch around a move
+template <int LAST>
+__device__ __forceinline__ uint32_t lane_next_word(uint32_t v, uint32_t next0, int lane) {
+  if (LAST == 63) return (uint32_t)__builtin_amdgcn_update_dpp((int)next0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  const uint32_t b = lane_rol1(v);
+  return (lane == LAST) ? next0 : b;
 }
 #define AIE_MT_ROW(J, ROT, SPLIT, ROW_LO, ROW_HI, NEXT0)                                      \
   {                                                                                          \
     const uint32_t a = m.r[J];                                                               \
-    uint32_t b = lane_rol1(a);                                                               \
-    b = (lane == ((J) == 9 ? 47 : 63)) ? (NEXT0) : b;                                        \
+    const uint32_t b = lane_next_word<(J) == 9 ? 47 : 63>(a, (NEXT0), lane);                 \
     const uint32_t src = lane >= (ROT) ? (ROW_LO) : (ROW_HI);                                \
     const uint32_t x = lane_get(src, (lane + (ROT)) & 63);                                   \
     m.r[J] = mt_mix(a, b, x);                                                                \
@@ -365,8 +400,7 @@ __device__ __forceinline__ void mt_twist_body(MT& m, int lane) {
   AIE_MT_ROW(2, 13, 51, m.r[8], m.r[9], bcast(m.r[3], 0))
   {  // row 3: l < 35 old row 9 (rotation 13), l >= 35 NEW row 0 (rotation 29)
     const uint32_t a = m.r[3];
-    uint32_t b = lane_rol1(a);
-    b = (lane == 63) ? bcast(m.r[4], 0) : b;
+    const uint32_t b = lane_next_word<63>(a, bcast(m.r[4], 0), lane);
     const uint32_t x_lo = lane_get(m.r[9], (lane + 13) & 63);
     const uint32_t x_hi = lane_get(m.r[0], (lane + 29) & 63);
     m.r[3] = mt_mix(a, b, lane < 35 ? x_lo : x_hi);
@@ -840,38 +874,85 @@ __device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agen
   const int perm = rng_permutation(m, lane, n);
   uint32_t* cells = R_CELLS(c);
   const double my_bonus = R_F64(c, o_bonus_gather_prob)[lane < n ? lane : 0];
+  // The reference resolves the agents one after the other, and what agent i sees -- the target tile's cell word and
+  // occupancy, then the landing tile's resources -- are two dependent LDS round trips per agent.  Every lane looks
+  // its OWN agent's tiles up first (one round trip for all agents), and the serial loop works on broadcasts of those
+  // as long as no earlier agent of this step's order moved out of or into the agent's target tile (`stale`: then the
+  // agent goes the slow way, through LDS).  Nothing else an earlier agent does is visible to a later one: resources
+  // are only taken from the tile an agent stands on, and nobody else can enter that tile.
+  int my_tcell = -1;     // target tile of my move, -1: none (NO-OP or out of the world)
+  uint32_t my_tw = 0;    // its cell word
+  int my_occ = 1;        // its occupant (0: free)
+  uint32_t my_ow = 0;    // the cell word of the tile I stand on
+  int my_land = 0;
+  if (lane < n) {
+    const int a = (int)AIE_ACT_GATHER(A.act);
+    my_land = A.lr * W + A.lc;
+    my_ow = cells[my_land];
+    // 1 Left, 2 Right, 3 Up, 4 Down (move.py:116-123)
+    const int nr = A.lr + (a == 3 ? -1 : a == 4 ? 1 : 0);
+    const int nc = A.lc + (a == 1 ? -1 : a == 2 ? 1 : 0);
+    if (a != 0 && nr >= 0 && nr < H && nc >= 0 && nc < W) {
+      my_tcell = nr * W + nc;
+      my_tw = cells[my_tcell];
+      my_occ = c.locmap[my_tcell];
+    }
+  }
+  // World.can_agent_occupy, world.py:424-440, on the looked-up values
+  const int my_own = AIE_CELL_OWNER(my_tw);
+  const bool my_can = my_tcell >= 0 && !(AIE_CELL_FLAGS(my_tw) & AIE_CELL_WATER) && (my_own < 0 || my_own == lane) && my_occ == 0;
+  const uint32_t my_pk = (uint32_t)my_land | (my_can ? (uint32_t)my_tcell << 16 : 0xffff0000u);  // (cells fit 16 bits: uint16 lists)
+  const uint32_t my_lw = my_can ? my_tw : my_ow;  // the landing tile's cell word
+  uint64_t stale = 0;
   for (int k = 0; k < n; ++k) {
     const int i = bcast(perm, k);
-    const int a = (int)AIE_ACT_GATHER(bcast(A.act, i));
-    const int r = bcast(A.lr, i), col = bcast(A.lc, i);
-    int land = r * W + col;
-    if (a != 0) {
-      // 1 Left, 2 Right, 3 Up, 4 Down (move.py:116-123)
-      const int nr = r + (a == 3 ? -1 : a == 4 ? 1 : 0);
-      const int nc = col + (a == 1 ? -1 : a == 2 ? 1 : 0);
-      if (nr >= 0 && nr < H && nc >= 0 && nc < W) {
-        // World.can_agent_occupy, world.py:424-440
-        const int tcell = nr * W + nc;
-        const uint32_t tw = cells[tcell];
-        const int occ = c.locmap[tcell];
-        const int own = AIE_CELL_OWNER(tw);
-        if (!(AIE_CELL_FLAGS(tw) & AIE_CELL_WATER) && (own < 0 || own == i) && occ == 0) {
-          c.locmap[land] = 0;
-          c.locmap[tcell] = (uint8_t)(i + 1);
-          dirty_add_uniform(c, m, land);
-          dirty_add_uniform(c, m, tcell);
-          dirty_agent_moved(m, i);
-          if (lane == i) {
-            A.lr = nr;
-            A.lc = nc;
-            A.labor += c.P.c.move_labor;
+    int land, tcell;
+    uint32_t w;
+    bool moves;
+    if (!((stale >> i) & 1ull)) {
+      const uint32_t pk = bcast(my_pk, i);
+      land = (int)(pk & 0xffffu);
+      tcell = (int)(pk >> 16);
+      moves = tcell != 0xffff;
+      w = bcast(my_lw, i);
+    } else {
+      const int a = (int)AIE_ACT_GATHER(bcast(A.act, i));
+      const int r = bcast(A.lr, i), col = bcast(A.lc, i);
+      land = r * W + col;
+      tcell = 0xffff;
+      moves = false;
+      if (a != 0) {
+        const int nr = r + (a == 3 ? -1 : a == 4 ? 1 : 0);
+        const int nc = col + (a == 1 ? -1 : a == 2 ? 1 : 0);
+        if (nr >= 0 && nr < H && nc >= 0 && nc < W) {
+          const int t = nr * W + nc;
+          const uint32_t tw = cells[t];
+          const int occ = c.locmap[t];
+          const int own = AIE_CELL_OWNER(tw);
+          if (!(AIE_CELL_FLAGS(tw) & AIE_CELL_WATER) && (own < 0 || own == i) && occ == 0) {
+            tcell = t;
+            moves = true;
           }
-          land = tcell;
         }
       }
+      w = cells[moves ? tcell : land];
+    }
+    if (moves) {
+      c.locmap[land] = 0;
+      c.locmap[tcell] = (uint8_t)(i + 1);
+      dirty_add_uniform(c, m, land);
+      dirty_add_uniform(c, m, tcell);
+      dirty_agent_moved(m, i);
+      if (lane == i) {
+        A.lr = udiv(tcell, W, c.P.mg_W);
+        A.lc = tcell - A.lr * W;
+        A.labor += c.P.c.move_labor;
+      }
+      // whoever targets the tile this agent left or the one it entered no longer knows that tile's occupancy
+      stale |= __ballot(my_tcell == land || my_tcell == tcell);
+      land = tcell;
     }
     // collect on the landing tile, also on a NO-OP (move.py:112-113,136)
-    uint32_t w = cells[land];
     if ((w & 0xffffu) != 0) {
       const int health[2] = {(int)AIE_CELL_STONE(w), (int)AIE_CELL_WOOD(w)};
       const double bonus = bcast(my_bonus, i);
@@ -1605,6 +1686,24 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
   for (int w = 0; w <= last_win; ++w) {
     if (w > 0) mt_twist_body(m, lane);  // the hot site: inlined (4 twists per step)
     const int lo = w * AIE_MT_N;
+    if (c.mtwin) {
+      // the window through LDS (mt_window_in_lds): ten row stores, then one two-word read per lane and chunk.  LDS
+      // operations of a wave execute in order, so the reads see the stores, and the next window's stores the reads.
+#pragma unroll
+      for (int j = 0; j < 10; ++j) c.mtwin[64 * j + lane] = m.r[j];
+#pragma unroll
+      for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
+        if (k >= nchunk) continue;
+        const int ia = off_a[k] - lo;  // word A's index in this window (-1: A was the previous window's last word)
+        const bool ha = (unsigned)ia < (unsigned)AIE_MT_N, hb = (unsigned)(ia + 1) < (unsigned)AIE_MT_N;
+        if (__ballot(ha || hb) == 0) continue;
+        const int at = ia < 0 ? 0 : (ia > AIE_MT_N - 1 ? AIE_MT_N - 1 : ia);
+        const uint32_t x0 = c.mtwin[at], x1 = c.mtwin[at + 1];  // (word 624 is padding: read, never used)
+        if (ha) wa[k] = x0;
+        if (hb) wb[k] = ia < 0 ? x0 : x1;
+      }
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
       if (k >= nchunk) continue;  // (uniform: the usual map lists < 64 draws)
@@ -1987,7 +2086,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
   const int t = *R_I32(c, o_timestep);
   const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)P.c.episode_length : 1.0));
 
-  const int skip = c.full ? P.dev_skip_mask : 0;
+  const int skip = c.skipm;
   // ================= stage A: per-(commodity, price) sums, per-agent scalars ===========
   if (P.has_cda && !(skip & 64)) {
     // lanes over (commodity r, price k): net price history and full bid / ask histograms
@@ -2133,7 +2232,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
 __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __restrict__ arena) {
   const aie_params& P = c.P;
   const int n = P.n, tid = c.tid, Pp = P.P;
-  const int skip = c.full ? P.dev_skip_mask : 0;
+  const int skip = c.skipm;
   if (skip & 512) return;
   if (tid < n) {
     const int i = tid;
@@ -2257,10 +2356,14 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   const aie_params& R = *params;
   const aie_params& P = aie_spec_params<SPEC>(params);
   const int wid = NW == 1 ? 0 : uni((int)(threadIdx.x >> 6));
-  const Ctx c = make_ctx(P, R, lds, replica_of_block((int)blockIdx.x, R.E), (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG);
+#ifdef AIE_DEV  // phases switched off by aie_dev_set_skip_mask (the generic kernel with hooks and the traced instances)
+  const int skip = (LOG || TRACE) ? R.dev_skip_mask : 0;
+#else
+  const int skip = 0;
+#endif
+  const Ctx c = make_ctx(P, R, lds, replica_of_block((int)blockIdx.x, R.E), (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG, skip);
   MT m;
   Agents A;
-  const int skip = c.full ? P.dev_skip_mask : 0;
   if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x] = wall_clock64();
   if (threadIdx.x == 0) {
     *c.srcn = 0;
