@@ -78,6 +78,9 @@ struct Ctx {
                      // instruction cache, and rarely taken paths pay for every line they add)
   int tid;
   int e;
+  const double* rtab;    // the discretised tax rates (aie_config.tax_disc_rates) and ...
+  const uint32_t* mtab;  // ... the action-mask element tests (aie_params.mask_test): LDS copies in the step kernel where
+                         // the LDS budget allows (const_tables_in_lds), else the parameter block's own arrays
   uint32_t* mtwin;   // LDS [640]: the generator's current window for the regeneration's sparse reads, or nullptr (mt_window_in_lds)
   int skipm;         // development (-DAIE_DEV builds: aie_dev_set_skip_mask): phases switched off; constant 0 otherwise
 };
@@ -137,22 +140,42 @@ __host__ __device__ inline size_t lds_bytes_base(const aie_params& P) {
 // with one ds_read2 -- instead of selecting them out of the row registers with ten lane permutes and ten selects per
 // word (scenario_step_regen).  Larger records (ten agents and more) keep the register gather.
 #define AIE_MT_WINDOW_LDS_BYTES 2560  // 10 rows x 64 lanes x 4 B (row 9's upper 16 lanes are padding)
+// Two small tables of the parameter block are indexed with run-time values on the replica's critical path: the
+// discretised tax rates (by the planner's latched rate indices: every marginal-rate / tax-due evaluation and the
+// curr_rates observation) and the per-element tests of the flattened action mask.  In a compile-time instance the
+// block is a constant image in device memory, so each such lookup is a global (or scalar) memory round trip behind the
+// LDS read of its index.  The step kernel's second wave copies both tables to LDS while the record streams in --
+// where that does not cost residency, like the generator's window below (which takes what room is left).
+__host__ __device__ inline size_t const_table_bytes(const aie_params& P) {
+  const size_t r = (P.has_tax && P.c.tax_model == AIE_TAX_MODEL_WRAPPER) ? (size_t)P.c.tax_n_disc_rates * 8 : 0;
+  return (r + (size_t)P.MA * 4 + 15) / 16 * 16;
+}
+__host__ __device__ inline bool const_tables_in_lds(const aie_params& P) {
+#ifdef AIE_NO_CONST_TABLES_LDS  // (A/B builds)
+  return false;
+#else
+  return lds_bytes_base(P) + const_table_bytes(P) <= 10240;
+#endif
+}
 __host__ __device__ inline bool mt_window_in_lds(const aie_params& P) {
 #ifdef AIE_NO_MT_WINDOW_LDS  // (A/B builds)
   return false;
 #else
-  return !P.regen_general && lds_bytes_base(P) + AIE_MT_WINDOW_LDS_BYTES <= 10240;
+  return !P.regen_general &&
+         lds_bytes_base(P) + (const_tables_in_lds(P) ? const_table_bytes(P) : 0) + AIE_MT_WINDOW_LDS_BYTES <= 10240;
 #endif
 }
 __host__ __device__ inline size_t lds_bytes(const aie_params& P) {
   size_t b = lds_bytes_base(P);
+  if (const_tables_in_lds(P)) b += const_table_bytes(P);
   if (mt_window_in_lds(P)) b += AIE_MT_WINDOW_LDS_BYTES;
   if (P.regen_general) b += 2 * (((size_t)P.HW + 15) / 16 * 16);
   return (b + 15) / 16 * 16;
 }
 
 __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R, uint8_t* lds, int e, int tid,
-                                        uint8_t* arena = nullptr, bool with_events = true, int skipm = 0) {
+                                        uint8_t* arena = nullptr, bool with_events = true, int skipm = 0,
+                                        bool lds_tables = false) {
   uint8_t* q = lds + rec_lds_bytes(P);
   int32_t* act_p = reinterpret_cast<int32_t*>(q);
   q += AIE_MAX_BRACKETS * 4;
@@ -172,6 +195,17 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R
   int32_t* dirty = reinterpret_cast<int32_t*>(q);
   q += 16 + AIE_DIRTY_CAP * 2;
   q = lds + ((q - lds) + 15) / 16 * 16;
+  // (the kernel that asks for the LDS tables fills them: step_body; everyone else reads the parameter block)
+  const double* rtab = P.c.tax_disc_rates;
+  const uint32_t* mtab = P.mask_test;
+  if (const_tables_in_lds(P)) {
+    if (lds_tables) {
+      const bool rates = P.has_tax && P.c.tax_model == AIE_TAX_MODEL_WRAPPER;
+      rtab = reinterpret_cast<const double*>(q);
+      mtab = reinterpret_cast<const uint32_t*>(q + (rates ? P.c.tax_n_disc_rates * 8 : 0));
+    }
+    q += const_table_bytes(P);
+  }
   uint32_t* mtwin = mt_window_in_lds(P) ? reinterpret_cast<uint32_t*>(q) : nullptr;
   if (mt_window_in_lds(P)) q += AIE_MT_WINDOW_LDS_BYTES;
   uint8_t* snap = P.regen_general ? q : nullptr;
@@ -181,7 +215,7 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R
   int32_t* ev = (with_events && arena && e < P.ev_replicas)
                     ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * P.ev_stride) : nullptr;
   const bool saez = with_events && P.c.tax_model == AIE_TAX_SAEZ;
-  return Ctx{P, R, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, snap, met, ev, saez, with_events, tid, e, mtwin, skipm};
+  return Ctx{P, R, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, snap, met, ev, saez, with_events, tid, e, rtab, mtab, mtwin, skipm};
 }
 
 // ------------------------------------------------------------------------------------
@@ -637,10 +671,33 @@ __device__ __forceinline__ double rng_double(MTL& l, int lane) {
   const uint32_t b = rng_u32(l, lane);
   return u53(a, b);
 }
+// legacy rk_interval: 32-bit words are drawn until (word & mask) <= max.  The words ahead are already in the lanes of
+// the register cache, so one ballot finds the first acceptable one (and every word before it counts as drawn) instead
+// of a readlane / compare / branch per attempt; only when the cached block runs out does the word-by-word loop take
+// over (it refills the cache or the draw window).
 __device__ __forceinline__ uint32_t rng_interval(MTL& l, int lane, uint32_t max) {
   if (max == 0) return 0;
   uint32_t mask = max, v;
   mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  int k = l.pos - l.cbase;                       // the next word's lane in the cache
+  if ((unsigned)k >= (unsigned)AIE_NT && l.pos < l.base + l.avail) {  // (as rng_u32: the next 64 words of the window)
+    const int idx = l.pos - l.base + lane;
+    l.cache = l.w[idx < l.avail ? idx : l.avail - 1];
+    l.cbase = l.pos;
+    k = 0;
+  }
+  const int lim = l.base + l.avail - l.cbase;    // lanes below `lim` hold words of the draw window (the rest repeat the last)
+  if ((unsigned)k < (unsigned)AIE_NT && k < lim) {
+    const uint32_t cv = l.cache & mask;
+    uint64_t ok = __ballot(cv <= max) & ~lanemask_lt(k);
+    if (lim < AIE_NT) ok &= lanemask_lt(lim);
+    if (ok != 0) {
+      const int a = __builtin_ctzll(ok);
+      l.pos = l.cbase + a + 1;
+      return bcast(cv, a);
+    }
+    l.pos = l.cbase + (lim < AIE_NT ? lim : AIE_NT);  // every cached word ahead was drawn and rejected
+  }
   while ((v = (rng_u32(l, lane) & mask)) > max) {}
   return v;
 }
@@ -869,7 +926,66 @@ __device__ __forceinline__ void build_component_step(const Ctx& c, MTL& m, Agent
 // ------------------------------------------------------------------------------------
 // Gather.component_step, F/components/move.py:93-153 (wave-uniform control flow)
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agents& A) {
+__device__ __forceinline__ void gather_component_step_serial(const Ctx& c, MTL& m, Agents& A) {
+  const int n = c.P.n, W = c.P.W, H = c.P.H, lane = c.tid;
+  const int perm = rng_permutation(m, lane, n);
+  uint32_t* cells = R_CELLS(c);
+  const double my_bonus = R_F64(c, o_bonus_gather_prob)[lane < n ? lane : 0];
+  for (int k = 0; k < n; ++k) {
+    const int i = bcast(perm, k);
+    const int a = (int)AIE_ACT_GATHER(bcast(A.act, i));
+    const int r = bcast(A.lr, i), col = bcast(A.lc, i);
+    int land = r * W + col;
+    if (a != 0) {
+      // 1 Left, 2 Right, 3 Up, 4 Down (move.py:116-123)
+      const int nr = r + (a == 3 ? -1 : a == 4 ? 1 : 0);
+      const int nc = col + (a == 1 ? -1 : a == 2 ? 1 : 0);
+      if (nr >= 0 && nr < H && nc >= 0 && nc < W) {
+        // World.can_agent_occupy, world.py:424-440
+        const int tcell = nr * W + nc;
+        const uint32_t tw = cells[tcell];
+        const int occ = c.locmap[tcell];
+        const int own = AIE_CELL_OWNER(tw);
+        if (!(AIE_CELL_FLAGS(tw) & AIE_CELL_WATER) && (own < 0 || own == i) && occ == 0) {
+          c.locmap[land] = 0;
+          c.locmap[tcell] = (uint8_t)(i + 1);
+          dirty_add_uniform(c, m, land);
+          dirty_add_uniform(c, m, tcell);
+          dirty_agent_moved(m, i);
+          if (lane == i) {
+            A.lr = nr;
+            A.lc = nc;
+            A.labor += c.P.c.move_labor;
+          }
+          land = tcell;
+        }
+      }
+    }
+    // collect on the landing tile, also on a NO-OP (move.py:112-113,136)
+    uint32_t w = cells[land];
+    if ((w & 0xffffu) != 0) {
+      const int health[2] = {(int)AIE_CELL_STONE(w), (int)AIE_CELL_WOOD(w)};
+      const double bonus = bcast(my_bonus, i);
+#pragma unroll
+      for (int rs = 0; rs < 2; ++rs) {
+        if (health[rs] >= 1) {
+          // rand() is consumed even when bonus_gather_prob == 0 (move.py:138)
+          const int got = 1 + (rng_double(m, lane) < bonus ? 1 : 0);
+          if (lane == i) {
+            if (rs == 0) A.inv0 += got; else A.inv1 += got;
+            A.labor += c.P.c.collect_labor;
+          }
+          w -= (1u << (8 * rs));  // consume_resource, world.py:481-483
+          if (c.ev) log_event(c, AIE_EV_GATHER, i, rs, got, land / W, land % W, 0, 0, 0, 0.0);
+        }
+      }
+      cells[land] = w;
+      dirty_add_uniform(c, m, land);
+    }
+  }
+}
+
+__device__ __forceinline__ void gather_component_step_lookahead(const Ctx& c, MTL& m, Agents& A) {
   const int n = c.P.n, W = c.P.W, H = c.P.H, lane = c.tid;
   const int perm = rng_permutation(m, lane, n);
   uint32_t* cells = R_CELLS(c);
@@ -973,6 +1089,13 @@ __device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agen
       dirty_add_uniform(c, m, land);
     }
   }
+}
+
+// Few agents: the plain serial loop (two dependent LDS round trips per agent).  Eight and more: every lane looks its
+// own agent's tiles up first (measured: 10 agents 43.3 -> 42.3 us per launch, 4 agents 25.2 -> 26.9).
+__device__ __forceinline__ void gather_component_step(const Ctx& c, MTL& m, Agents& A) {
+  if (c.P.n >= 8) gather_component_step_lookahead(c, m, A);
+  else gather_component_step_serial(c, m, A);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1355,7 +1478,7 @@ __device__ __forceinline__ uint8_t* saez_block(const Ctx& c) {
   return c.met - c.R.a_metrics - (int64_t)c.e * c.P.met_bytes + c.R.a_saez + (int64_t)c.e * c.P.saez_stride;
 }
 __device__ __forceinline__ double tax_rate(const Ctx& c, int b) {  // curr_marginal_rates :396-417
-  if (c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER) return c.P.c.tax_disc_rates[R_I32(c, o_tax_rate_idx)[b]];
+  if (c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER) return c.rtab[R_I32(c, o_tax_rate_idx)[b]];
   if (c.saez) {  // np.minimum(curr_bracket_tax_rates, curr_rate_max) :406-409
     const double r = R_F64(c, o_tax_saez_rates)[b];
     const double cap = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.P.c.tax_rate_max;
@@ -1376,10 +1499,10 @@ __device__ __forceinline__ double tax_rate_obs(const Ctx& c, int b) {
 __device__ __forceinline__ bool tax_rate_action_visible(const Ctx& c, int j) {
   if (!c.P.c.tax_annealing) return true;
   double full = 0;
-  for (int k = 0; k < c.P.c.tax_n_disc_rates; ++k) full = fmax(full, fabs(c.P.c.tax_disc_rates[k]));
+  for (int k = 0; k < c.P.c.tax_n_disc_rates; ++k) full = fmax(full, fabs(c.rtab[k]));
   const double vis = aie_annealed_tax_limit(*R_I32(c, o_tax_last_completions), c.P.c.tax_annealing_warmup,
                                             c.P.c.tax_annealing_slope, full);
-  return fabs(c.P.c.tax_disc_rates[j]) <= vis;
+  return fabs(c.rtab[j]) <= vis;
 }
 __device__ __forceinline__ double tax_marginal_rate(const Ctx& c, double income) {  // marginal_rate :837-844
   if (income < 0) return 0.0;
@@ -2270,7 +2393,7 @@ __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __rest
     const int count = n * P.MA;
     auto elem = [&](int idx) -> float {
       const int i = udiv(idx, P.MA, P.mg_MA), m = idx - i * P.MA;
-      const uint32_t t = P.mask_test[m];  // host-built test for element m (aie_layout.h)
+      const uint32_t t = c.mtab[m];  // host-built test for element m (aie_layout.h)
       const uint32_t sh = t & 31u, msk = (t >> 8) & 0xffu, thr = t >> 16;
       return (((uint32_t)c.mflags[i] >> sh) & msk) >= thr ? 1.0f : 0.0f;
     };
@@ -2361,7 +2484,9 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
 #else
   const int skip = 0;
 #endif
-  const Ctx c = make_ctx(P, R, lds, replica_of_block((int)blockIdx.x, R.E), (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG, skip);
+  const Ctx c = make_ctx(P, R, lds, replica_of_block((int)blockIdx.x, R.E), (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG, skip,
+                         /*lds_tables=*/SPEC >= 0);  // (the generic kernel keeps the parameter block's arrays: a pointer
+                                                     // that may be LDS or global at run time costs it flat accesses and spills)
   MT m;
   Agents A;
   if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x] = wall_clock64();
@@ -2384,6 +2509,12 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (wid == NW - 1) gpos = *reinterpret_cast<const int32_t*>(grec + P.o_mt_pos);
   load_record(c, arena, m, wid, NW, /*key_wave=*/-1);  // the generator state stays in HBM for now
   if (wid == NW - 1) draw_window_publish_from_hbm(ml.w, ml.cap, gkey, uni(gpos), c.tid);
+  if (SPEC >= 0 && wid == NW - 1 && const_tables_in_lds(P)) {
+    // the small constant tables (Ctx.rtab / mtab) -> LDS, published by the barrier below
+    if (P.has_tax && P.c.tax_model == AIE_TAX_MODEL_WRAPPER)
+      for (int q = c.tid; q < P.c.tax_n_disc_rates; q += AIE_NT) const_cast<double*>(c.rtab)[q] = P.c.tax_disc_rates[q];
+    for (int q = c.tid; q < P.MA; q += AIE_NT) const_cast<uint32_t*>(c.mtab)[q] = P.mask_test[q];
+  }
   if (wid == 0) decode_actions(c, A, act_a, act_p);
   __syncthreads();  // the record is in LDS
   if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
@@ -2438,8 +2569,13 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     }
   }
   __syncthreads();  // components done; the generator's position (and, after a refill that twisted, its state in HBM) is final
+  // With many agents the first wave's tail (flat vectors of every agent, utilities) is the longer one: it then keeps a
+  // priority above the waves that are still loading (measured at 10 agents: 42.3 -> 41.9 us; at 4 agents any
+  // priority above 0 costs 0.8-1.4 us)
+  const int w0_tail_prio = P.n >= 8 ? 2 : 0;
   if (wid == 0) {
     // first wave: flat observation vectors (they do not look at the map)
+    if (w0_tail_prio) __builtin_amdgcn_s_setprio(2);
     if (!(skip & 8)) write_flat_observations(c, arena);
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
     if (!(skip & 16)) compute_rewards(c, arena, next.rew_log);  // utilities do not look at the map either
@@ -2450,6 +2586,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       if (next.rew_log) next.rew_log[(int64_t)c.e * (P.n + 2) + P.n + 1] = done ? 1.0f : 0.0f;
       if (done) *R_I32(c, o_completions) += 1;
     }
+    if (w0_tail_prio) __builtin_amdgcn_s_setprio(0);
   }
   if (NW == 1 || wid == 1) {
     // second wave: resource regeneration (the generator's rows are in its registers), then what

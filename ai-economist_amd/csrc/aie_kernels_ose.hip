@@ -85,7 +85,8 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, const aie_param
   s.tmpl_p = s.tmpl_a + pad4(P.FA > P.MA ? P.FA : P.MA);
   uint8_t* met = arena + R.a_metrics + (int64_t)e * P.met_bytes;
   int32_t* ev = e < P.ev_replicas ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * P.ev_stride) : nullptr;
-  return Ctx{P, R, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e};
+  return Ctx{P, R, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e,
+             /*rtab=*/P.c.tax_disc_rates, /*mtab=*/P.mask_test, /*mtwin=*/nullptr, /*skipm=*/0};
 }
 
 // The draws of np.random.permutation(n) (World.get_random_order_agents, world.py:418-422) for a caller that never
