@@ -671,33 +671,13 @@ __device__ __forceinline__ double rng_double(MTL& l, int lane) {
   const uint32_t b = rng_u32(l, lane);
   return u53(a, b);
 }
-// legacy rk_interval: 32-bit words are drawn until (word & mask) <= max.  The words ahead are already in the lanes of
-// the register cache, so one ballot finds the first acceptable one (and every word before it counts as drawn) instead
-// of a readlane / compare / branch per attempt; only when the cached block runs out does the word-by-word loop take
-// over (it refills the cache or the draw window).
+// (Tried: finding the first acceptable word of the cached block with one ballot instead of a readlane / compare / branch
+// per attempt -- bit-identical, but the unrolled permutation loops grow and the launch gets slower: C2 24.9 -> 25.7 us,
+// C3 41.6 -> 43.7 us.)
 __device__ __forceinline__ uint32_t rng_interval(MTL& l, int lane, uint32_t max) {
   if (max == 0) return 0;
   uint32_t mask = max, v;
   mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-  int k = l.pos - l.cbase;                       // the next word's lane in the cache
-  if ((unsigned)k >= (unsigned)AIE_NT && l.pos < l.base + l.avail) {  // (as rng_u32: the next 64 words of the window)
-    const int idx = l.pos - l.base + lane;
-    l.cache = l.w[idx < l.avail ? idx : l.avail - 1];
-    l.cbase = l.pos;
-    k = 0;
-  }
-  const int lim = l.base + l.avail - l.cbase;    // lanes below `lim` hold words of the draw window (the rest repeat the last)
-  if ((unsigned)k < (unsigned)AIE_NT && k < lim) {
-    const uint32_t cv = l.cache & mask;
-    uint64_t ok = __ballot(cv <= max) & ~lanemask_lt(k);
-    if (lim < AIE_NT) ok &= lanemask_lt(lim);
-    if (ok != 0) {
-      const int a = __builtin_ctzll(ok);
-      l.pos = l.cbase + a + 1;
-      return bcast(cv, a);
-    }
-    l.pos = l.cbase + (lim < AIE_NT ? lim : AIE_NT);  // every cached word ahead was drawn and rejected
-  }
   while ((v = (rng_u32(l, lane) & mask)) > max) {}
   return v;
 }

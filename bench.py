@@ -419,6 +419,8 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
     be = env.backend
     n = env.n_agents
     specialised = bool(W.get("specialize")) and env.specialize()  # (False: hiprtc / sources missing -> generic kernel)
+    if args.generic_kernel:  # development: what a configuration without an instance runs
+        be.lib.aie_select_step_kernel(be.handle, 1)
     roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger, auto_reset=not args.no_auto_reset)
     gc.collect()
     gc.disable()  # no collector pause between here and the end of the timed window (it may be as short as 20 launches);
@@ -622,6 +624,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true",
                     help="headline workload only (default: a 1-GPU C2 run also times C1, C3, C4, C4x, C5 in short windows)")
+    ap.add_argument("--generic-kernel", action="store_true",
+                    help="development: time the generic step kernel instead of the configuration's compile-time instance")
     ap.add_argument("--no-stagger", action="store_true", help="keep all replicas in lock-step (round-1 behaviour)")
     ap.add_argument("--no-auto-reset", action="store_true",
                     help="C5: separate reset launches instead of restarting replicas inside the step launch")
