@@ -378,8 +378,8 @@ def issue_counters(wl):
     for name, v in d.items():
         if isinstance(v, dict) and "reset" not in name and v.get("wave_instructions_per_launch"):
             if best is None or v["wave_instructions_per_launch"] > best[1]:
-                best = (name, v["wave_instructions_per_launch"])
-    return (best[1] if best else None), os.path.relpath(files[-1], ROOT)
+                best = (name, v["wave_instructions_per_launch"], (v.get("counters") or {}).get("SQ_INSTS_VALU"))
+    return (best[1] if best else None), os.path.relpath(files[-1], ROOT), (best[2] if best else None)
 
 
 def store_roof_gbs(device, nbytes=4 << 30):
@@ -524,8 +524,11 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
         elif wl.startswith("C4"):
             kernel_name = "aie_covid_step_kernel<%d, %s>" % (env.model["num_filters"], "false" if env.exact_filter_sums else "true")
         traffic_frac = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None
-        insts, insts_src = issue_counters(wl)
+        insts, insts_src, valu_insts = issue_counters(wl)
         issue_frac = (insts / (N_SIMDS * SM_CLOCK_HZ * avg_ms * 1e-3)) if (insts and E == W["envs"]) else None
+        # a wave64 vector instruction keeps its SIMD's 16-lane pipe for 4 clocks: the share of all VALU pipe time the
+        # kernel's vector instructions fill
+        valu_frac = (4.0 * valu_insts / (N_SIMDS * SM_CLOCK_HZ * avg_ms * 1e-3)) if (valu_insts and E == W["envs"]) else None
         store_roof = store_roof_gbs(device) if wl == "C5" else None
         store_frac = None
         if store_roof and traffic:
@@ -534,6 +537,8 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
         # / the HBM peak), instruction issue, or neither (dependent chains of too few resident waves)
         if (store_frac or 0) >= 0.7 or (traffic_frac or 0) >= 0.7:
             bound = "hbm"
+        elif (valu_frac or 0) >= 0.5:
+            bound = "valu"
         elif (issue_frac or 0) >= 0.6:
             bound = "issue"
         else:
@@ -542,6 +547,8 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
             bound=bound, roof="hbm", kernel=kernel_name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, hbm_traffic_frac=traffic_frac,
             issue_frac=issue_frac, wave_instructions_per_launch=insts, issue_source=insts_src,
+            valu_frac=valu_frac, valu_instructions_per_launch=valu_insts,
+            valu_roof="a wave64 VALU instruction occupies its SIMD for 4 clocks: %d SIMDs x %.1f GHz / 4" % (N_SIMDS, SM_CLOCK_HZ / 1e9),
             issue_roof="1 wave-instruction per SIMD and clock: %d SIMDs x %.1f GHz" % (N_SIMDS, SM_CLOCK_HZ / 1e9),
             algorithmic_bytes_per_launch=survey_per_launch, algorithmic_bytes_per_unit=W["survey_bytes"],
             unit_of_work="agent-step incl. planner" if wl.startswith("C4") else "agent-step",
@@ -553,6 +560,7 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
                  "*_final_layout does the same with the bytes of the layouts actually used; hbm_traffic_frac = measured "
                  "HBM bytes (committed rocprofv3 FETCH_SIZE/WRITE_SIZE summary of this command) / live launch time / "
                  "peak; issue_frac = wave-instructions per launch (committed SQ_INSTS_* summary) / (SIMDs x clock x live "
+                 "launch time); valu_frac = 4 clocks x vector instructions per launch (same summary) / (SIMDs x clock x live "
                  "launch time); `bound` is derived from those fractions, not asserted")
         if store_roof:
             roof["store_roof_GBps_this_box"] = store_roof
