@@ -372,7 +372,7 @@ def issue_counters(wl):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_sq_counters.json" % wl.lower())),
                    key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     if not files:
-        return None, None
+        return None, None, None
     d = json.load(open(files[-1]))
     best = None
     for name, v in d.items():
