@@ -18,14 +18,16 @@ staggered points of a prologue, so that any window of the rollout -- including a
 order expiries, mid-episode order books and episode ends in their long-run proportions.
 
 `--gpus N` with N > 1 started as a plain process re-executes itself under torch.distributed.run (one rank per GPU);
-`--launcher torchrun` takes that path with --gpus 1 too (the N > 1 launch code on a one-GPU box).
+`--launcher torchrun` takes that path with --gpus 1 too (the N > 1 launch code on a one-GPU box).  `--generic-kernel`
+(development) times the generic step kernel instead of the configuration's compile-time instance.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline      dominant kernel: algorithmic bytes per launch (SURVEY.md 8(d) figure, and the figure recomputed from
                 the final layouts) / average launch duration measured live with HIP events on the launch stream;
                 measured HBM traffic and issued wave-instructions from the committed rocprofv3 PMC summaries of the
-                same command (-> hbm_traffic_frac, issue_frac, and `bound` derived from them); C5: the box's own
-                pure-store roof measured live
+                same command (-> hbm_traffic_frac, issue_frac, valu_frac = the share of all VALU pipe time the
+                kernel's vector instructions fill, and `bound` derived from them); C5: the box's own pure-store roof
+                measured live
   cpu_baseline  the UNMODIFIED reference env.step (oracle/_ref, kind "reference") on this host's cores, P pinned
                 processes timed concurrently on a bounded window; `cpu_port` = the C restatement (oracle/) beside it
 """

@@ -443,6 +443,49 @@ def test_maximum_agent_count_matches_oracle():
         make_env(dict(cfg, n_agents=63), n_envs=2, device="cuda:0").reset()
 
 
+@pytest.mark.parametrize("n_agents,size", [(24, 8), (12, 6), (9, 12)])
+def test_crowded_world_move_conflicts_match_oracle(n_agents, size):
+    """Many agents on a small map, four of five actions a move: agents keep targeting tiles that another agent of the
+    same step's random order has just left or entered -- the case in which the look-ahead Gather (from 8 agents on:
+    every lane resolves its own agent's tiles before the serial loop) must fall back to the LDS path for that agent.
+    Every field of every replica against the oracle after every step."""
+    import torch
+    from helpers import oracle_host_pre_reset
+    from oracle_lib import OracleEnv
+
+    cfg = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=n_agents, world_size=[size, size],
+               episode_length=60, components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10,
+               starting_stone_coverage=0.15, starting_wood_coverage=0.15)
+    E = 48
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(21)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(21)
+    oracle_host_pre_reset(env, oracle)
+    oracle.reset()
+    _compare_all(be, oracle, "crowded reset")
+    g = torch.Generator(device="cpu").manual_seed(7)
+    moved = 0
+    for t in range(70):
+        a = torch.randint(0, 6, (E, n_agents), generator=g, dtype=torch.int32)  # 0 NO-OP, 1 Build, 2..5 moves
+        a = torch.where(a == 0, torch.full_like(a, 2 + t % 4), a).to("cuda:0")  # (hardly any NO-OP: more traffic)
+        _, p = be.sample_random_actions(seed=3)
+        before = be.tensors["loc_r"].clone(), be.tensors["loc_c"].clone()
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        moved += int(((be.tensors["loc_r"] != before[0]) | (be.tensors["loc_c"] != before[1])).sum())
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+        _compare_all(be, oracle, "crowded step %d" % (t + 1))
+        if t == 59:
+            env.reset(be.tensors["done"])
+            oracle_host_pre_reset(env, oracle)
+            oracle.reset(oracle.t["done"].copy())
+            _compare_all(be, oracle, "crowded second reset")
+    assert moved > 10 * E, "the policy is supposed to move agents around"
+
+
 def test_large_uniform_world_uses_the_host_layout_procedure():
     """uniform/ on 52 x 52 (more cells than the reset kernel's layout generator handles in LDS): the layouts come from
     the host-side procedure (dynamic_layout.py: generate_layout, each replica's own stream), the 10 816-word
