@@ -1,9 +1,11 @@
 #!/usr/bin/env python
 """Development probe: the one-step-economy kernel runs at two speeds (1.45 vs 1.67 ms per launch) with the same binary
-ON THE SAME BOX IN THE SAME PROCESS, depending on where its 7 GB arena landed: every environment built here gets a
-fresh arena from torch's allocator; the launch time is printed next to the arena's address.  (Measured: ~half of the
-placements are slow; all of them are 2 MiB aligned; hipExtMallocWithFlags(hipDeviceMallocContiguous) gives both
-speeds as well; the box's fill roof is the same for both.)  GPU only.   python tools/arena_probe.py [count]"""
+on the same box in the same process, depending on where its 7 GB arena lies.
+   python tools/arena_probe.py fresh [count]     a fresh arena from torch's allocator per environment
+   python tools/arena_probe.py offsets [bytes..] the arena at chosen offsets inside ONE 8 GB + 1 GiB allocation
+   python tools/arena_probe.py contiguous [count]  arenas from hipExtMallocWithFlags(hipDeviceMallocContiguous)
+GPU only."""
+import ctypes
 import os
 import sys
 
@@ -16,14 +18,47 @@ import bench  # noqa: E402
 from helpers import make_env  # noqa: E402
 
 WL = os.environ.get("PROBE_WL", "C5")
-keep = []  # (holding the previous arenas makes the allocator hand out new addresses)
+SLACK = 1 << 30
+keep = []
+big = None
+real_zeros = torch.zeros
 
 
-def run(launches=40, warm=15):
-    W = bench.WORKLOADS[WL]
-    env = make_env(W["cfg"](), n_envs=W["envs"], device="cuda:0")
-    env.seed(1)
-    env.reset()
+class Blob:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def run(mode, off=0, launches=40, warm=15):
+    def zeros(n, *a, dtype=None, device=None, **kw):
+        global big
+        if dtype == torch.uint8 and isinstance(n, int) and n > (1 << 26):
+            if mode == "offsets":
+                if big is None:
+                    big = real_zeros(n + SLACK, dtype=torch.uint8, device=device)
+                v = big[off: off + n]
+                v.zero_()
+                return v
+            if mode == "contiguous":
+                hip = ctypes.CDLL("libamdhip64.so")
+                hip.hipExtMallocWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+                ptr = ctypes.c_void_p()
+                rc = hip.hipExtMallocWithFlags(ctypes.byref(ptr), n, 0x4)  # hipDeviceMallocContiguous
+                if rc == 0:
+                    t = torch.as_tensor(Blob(ptr.value, n), device=device)
+                    t.zero_()
+                    return t
+                print("   hipExtMallocWithFlags(contiguous) failed: rc", rc, flush=True)
+        return real_zeros(n, *a, dtype=dtype, device=device, **kw)
+
+    torch.zeros = zeros
+    try:
+        W = bench.WORKLOADS[WL]
+        env = make_env(W["cfg"](), n_envs=W["envs"], device="cuda:0")
+        env.seed(1)
+        env.reset()  # (the backend, and with it the arena, is created here)
+    finally:
+        torch.zeros = real_zeros
     be = env.backend
     if WL == "C5":
         be.lib.aie_set_auto_reset(be.handle, 1)
@@ -38,9 +73,16 @@ def run(launches=40, warm=15):
         be.step(a, p)
     e1.record()
     torch.cuda.synchronize()
-    print("%s arena at %#x  %.4f ms per launch" % (WL, be.arena.data_ptr(), e0.elapsed_time(e1) / launches), flush=True)
-    keep.append(env)
+    print("%s %-10s arena at %#x (offset %d)  %.4f ms per launch" % (WL, mode, be.arena.data_ptr(), off,
+                                                                      e0.elapsed_time(e1) / launches), flush=True)
+    if mode == "fresh":
+        keep.append(env)  # (holding the previous arenas makes the allocator hand out new addresses)
 
 
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
-    run()
+mode = sys.argv[1] if len(sys.argv) > 1 else "fresh"
+if mode == "offsets":
+    for off in [int(x, 0) for x in sys.argv[2:]] or [0, 256, 4096, 1 << 16, 1 << 20, 1 << 21, 3 << 21, 1 << 24, 1 << 27, 1 << 29, 0]:
+        run(mode, off)
+else:
+    for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
+        run(mode)
