@@ -104,9 +104,11 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
   const bool covid = cfg->scenario == AIE_SCN_COVID;
   const bool ose = cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY || covid;  // map-less: no cell words to initialise
   env->lds = covid ? 0 : cfg->scenario == AIE_SCN_ONE_STEP_ECONOMY ? aie::ose_lds_bytes(env->P) : aie::lds_bytes(env->P);
-  if (env->lds + (covid ? 0 : aie::layout_gen_lds_bytes(env->P)) > 64 * 1024) {
+  // a gfx950 workgroup may take the CU's whole 160 KB of LDS (hipDeviceProp.sharedMemPerBlock = 163 840; checked on the
+  // device: launches with 65 ... 160 KB of dynamic LDS run without any function attribute)
+  if (env->lds + (covid ? 0 : aie::layout_gen_lds_bytes(env->P)) > 160 * 1024) {
     snprintf(g_create_err, sizeof(g_create_err),
-             "per-replica working set (%zu B of LDS) exceeds 64 KiB: reduce max_num_orders / world size", env->lds);
+             "per-replica working set (%zu B of LDS) exceeds 160 KiB: reduce max_num_orders / world size", env->lds);
     delete env;
     return AIE_E_UNSUPPORTED;
   }

@@ -763,8 +763,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     if (!gtb) AIE__FAIL("layout_gen needs a gather-trade-build scenario");
     if (c->layout_gen < 0 || c->layout_gen > AIE_LAYOUT_MULTI_ZONE) AIE__FAIL("unknown layout_gen %d", c->layout_gen);
     if (c->shared_layout) AIE__FAIL("generated layouts are per replica: shared_layout must be 0");
-    if (c->world_h * c->world_w > 2304) {
-      if (err) snprintf(err, errlen, "layouts are generated on the device for worlds of up to 2304 cells (48 x 48)");
+    if (c->world_h * c->world_w > 4096) {  /* (the generator's planes live in LDS: 18 B per cell beside the record image) */
+      if (err) snprintf(err, errlen, "layouts are generated on the device for worlds of up to 4096 cells (64 x 64)");
       return AIE_E_UNSUPPORTED;
     }
     for (int r = 0; r < AIE_N_RES; ++r) {

@@ -10,7 +10,7 @@ legacy-NumPy stream (csrc/aie_kernels.hip: layout_generate; restated for the che
 oracle/aie_oracle.c and pinned there against the live reference): a reset has no host
 round trip.  This module supplies the static source-probability maps and the kwargs.
 `generate_layout*` below is the same procedure on the host (NumPy / SciPy), kept for worlds
-larger than the device path's 2304 cells and as documentation of the reference's steps.
+larger than the device path's 4096 cells and as documentation of the reference's steps.
 """
 import numpy as np
 
@@ -151,7 +151,7 @@ class Uniform(LayoutFromFile):
         return metrics.gtb_scenario_metrics(self, tensors)
 
     layout_gen = _cabi.LAYOUT_UNIFORM
-    DEVICE_LAYOUT_MAX_CELLS = 2304  # csrc/aie_layout.h: the generator's planes live in LDS
+    DEVICE_LAYOUT_MAX_CELLS = 4096  # csrc/aie_layout.h: the generator's planes live in LDS (<= 160 KB per workgroup)
 
     @property
     def layouts_on_device(self):

@@ -486,20 +486,24 @@ def test_crowded_world_move_conflicts_match_oracle(n_agents, size):
     assert moved > 10 * E, "the policy is supposed to move agents around"
 
 
-def test_large_uniform_world_uses_the_host_layout_procedure():
-    """uniform/ on 52 x 52 (more cells than the reset kernel's layout generator handles in LDS): the layouts come from
-    the host-side procedure (dynamic_layout.py: generate_layout, each replica's own stream), the 10 816-word
-    regeneration sweep crosses 17 generator windows per step; HIP vs oracle over an episode boundary."""
+@pytest.mark.parametrize("side,on_device", [(52, True), (66, False)])
+def test_large_uniform_worlds(side, on_device):
+    """uniform/ on 52 x 52: the reset kernel draws the layouts itself (its planes + the record image take 70 KB of the
+    workgroup's LDS -- gfx950 allows 160 KB; round 2 stopped at 64 KB / 48 x 48), the 10 816-word regeneration sweep
+    crosses 17 generator windows per step.  66 x 66 (more than the 4096 cells the device path takes): the layouts come
+    from the host-side procedure (dynamic_layout.py: generate_layout, each replica's own stream).  HIP vs oracle over
+    an episode boundary."""
     import torch
     from helpers import oracle_host_pre_reset
     from oracle_lib import OracleEnv
 
-    cfg = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=3, world_size=[52, 52], episode_length=8,
+    cfg = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=3, world_size=[side, side], episode_length=8,
                components=[["Build", {}], ["Gather", {}]], starting_agent_coin=3, starting_stone_coverage=0.03,
                starting_wood_coverage=0.03)
     E = 3
     np.random.seed(77)
     env = make_env(cfg, n_envs=E, device="cuda:0")
+    assert bool(env.layouts_on_device) == on_device
     env.seed(6)
     be = env.backend
     oracle = OracleEnv(env.build_config(), env.layout_planes())
@@ -507,18 +511,19 @@ def test_large_uniform_world_uses_the_host_layout_procedure():
     env.reset()
     oracle_host_pre_reset(env, oracle)
     oracle.reset()
-    _compare_all(be, oracle, "52x52 reset")
+    where = "%dx%d" % (side, side)
+    _compare_all(be, oracle, where + " reset")
     for t in range(12):
         a, p = be.sample_random_actions(seed=2)
         env.step({"a": a, "p": p})
         torch.cuda.synchronize()
         oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=3)
-        _compare_all(be, oracle, "52x52 step %d" % (t + 1))
+        _compare_all(be, oracle, where + " step %d" % (t + 1))
         if t == 7:
             env.reset(be.tensors["done"])
             oracle_host_pre_reset(env, oracle)
             oracle.reset(oracle.t["done"].copy())
-            _compare_all(be, oracle, "52x52 second reset")
+            _compare_all(be, oracle, where + " second reset")
 
 
 def test_dense_source_layouts_take_the_row_by_row_regeneration():
