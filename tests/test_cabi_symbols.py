@@ -66,6 +66,18 @@ def test_arena_bytes_and_validation_without_gpu():
     c = env.build_config()
     c.full_observability = 1  # every agent sees the whole map: n x 6 x 25 x 25 floats instead of n x 7 x 11 x 11
     assert lib.aie_arena_bytes(ctypes.byref(c)) > nbytes
+    # layouts drawn on the device: up to 64 x 64 cells; larger worlds are for the host procedure (layout_gen stays FIXED)
+    for side, ok in ((48, True), (64, True), (65, False)):
+        u = make_env(dict(scenario_name="uniform/simple_wood_and_stone", n_agents=4, world_size=[side, side],
+                          episode_length=10, components=[["Build", {}], ["Gather", {}]], starting_agent_coin=3,
+                          starting_stone_coverage=0.05, starting_wood_coverage=0.05), n_envs=2)
+        assert bool(u.layouts_on_device) == ok
+        uc = u.build_config()
+        assert (uc.layout_gen != _cabi.LAYOUT_FIXED) == ok and lib.aie_arena_bytes(ctypes.byref(uc)) > 0
+        uc.layout_gen = _cabi.LAYOUT_UNIFORM
+        assert (lib.aie_arena_bytes(ctypes.byref(uc)) > 0) == ok
+        if not ok:
+            assert b"4096 cells" in lib.aie_last_error(None)
 
 
 def test_host_registry_and_kwargs_validation():
