@@ -21,7 +21,8 @@ order expiries, mid-episode order books and episode ends in their long-run propo
 `--launcher torchrun` takes that path with --gpus 1 too (the N > 1 launch code on a one-GPU box).  `--generic-kernel`
 (development) times the generic step kernel instead of the configuration's compile-time instance.
 
-Prints ONE JSON line (rank 0) with the contract fields plus
+Prints (rank 0) the full result as one JSON line, writes it to bench_detail.json, and then -- LAST line of stdout, the
+line the driver parses, <= 4 KB (compact_line) -- the contract fields plus the numbers of
   roofline      dominant kernel: algorithmic bytes per launch (SURVEY.md 8(d) figure, and the figure recomputed from
                 the final layouts) / average launch duration measured live with HIP events on the launch stream;
                 measured HBM traffic and issued wave-instructions from the committed rocprofv3 PMC summaries of the
@@ -91,29 +92,36 @@ C1_CFG = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=4, world_s
               components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10, starting_stone_coverage=0.10,
               starting_wood_coverage=0.10)
 WORKLOADS = {
-    "C1": dict(desc="BASELINE configs[0]'s scenario batched: uniform/simple_wood_and_stone 15x15, 4 agents + planner, "
+    "C1": dict(short="BASELINE configs[0] scenario batched: uniform/simple_wood_and_stone 15x15, 4 agents, Build+Gather",
+               desc="BASELINE configs[0]'s scenario batched: uniform/simple_wood_and_stone 15x15, 4 agents + planner, "
                     "Build+Gather (no auction, no taxes), episode_length 1000; every reset draws a new source layout on "
                     "the device",
                cfg=lambda: dict(C1_CFG), envs=4096, survey_bytes=5303.0, kernel="aie_step_kernel"),
-    "C2": dict(desc="BASELINE configs[1]: gather-trade-build 25x25 quadrant layout, 4 agents + planner, Build+"
+    "C2": dict(short="BASELINE configs[1]: gather-trade-build 25x25, 4 agents + planner, Build+CDA+Gather+PeriodicBracketTax, 4096 replicas/GPU",
+               desc="BASELINE configs[1]: gather-trade-build 25x25 quadrant layout, 4 agents + planner, Build+"
                     "ContinuousDoubleAuction(max_num_orders=5)+Gather+PeriodicBracketTax, episode_length 1000",
                cfg=lambda: dict(C2_CFG), envs=4096, survey_bytes=10984.0, kernel="aie_step_kernel"),
-    "C2p": dict(desc="SURVEY 8(d) C2'': BASELINE configs[1] with planner_gets_spatial_info=False (the reference's phase-2 "
+    "C2p": dict(short="configs[1] with planner_gets_spatial_info=False (reference phase-2 YAML)",
+               desc="SURVEY 8(d) C2'': BASELINE configs[1] with planner_gets_spatial_info=False (the reference's phase-2 "
                      "training YAML, tutorials/rllib/phase2/config.yaml); no compile-time instance exists for it: the "
                      "kernels are specialised at run time (aie_specialize: hiprtc, cached)",
                 cfg=lambda: dict(C2_CFG, planner_gets_spatial_info=False), envs=4096, survey_bytes=6601.0,
                 kernel="aie_step_kernel", specialize=True),
-    "C3": dict(desc="BASELINE configs[2], one GPU's share (32768 replicas over 8 GPUs = 4096 each): as C2 with 10 agents",
+    "C3": dict(short="BASELINE configs[2], one GPU share: as C2 with 10 agents, 4096 replicas/GPU",
+               desc="BASELINE configs[2], one GPU's share (32768 replicas over 8 GPUs = 4096 each): as C2 with 10 agents",
                cfg=lambda: dict(C2_CFG, n_agents=10), envs=4096, survey_bytes=7666.0, kernel="aie_step_kernel"),
-    "C4": dict(desc="BASELINE configs[3]: CovidAndEconomySimulation, 51 US-state agents + planner, run config "
+    "C4": dict(short="BASELINE configs[3] COVID 51 states + planner, opt-in O(1) filter recurrence",
+               desc="BASELINE configs[3]: CovidAndEconomySimulation, 51 US-state agents + planner, run config "
                     "covid_and_economy_environment.yaml, episode_length 540; filter_recurrence=True (opt-in O(1) update of "
                     "the unemployment filter bank, `unemployed` within 1.5e-6 relative of the default window sums)",
                cfg=_c4_cfg, envs=8192, survey_bytes=1580.0, kernel="aie_covid_step_kernel"),
-    "C4x": dict(desc="BASELINE configs[3] with the default unemployment filter bank (the reference's 600-tap window sums; "
+    "C4x": dict(short="BASELINE configs[3] COVID 51 states + planner, reference-exact window sums",
+               desc="BASELINE configs[3] with the default unemployment filter bank (the reference's 600-tap window sums; "
                      "C4 runs the opt-in O(1) recurrence)",
                 cfg=lambda: dict(_c4_cfg(), filter_recurrence=False), envs=8192, survey_bytes=1580.0,
                 kernel="aie_covid_step_kernel"),
-    "C5": dict(desc="BASELINE configs[4]: one-step-economy, 100 agents + SimpleLabor + PeriodicBracketTax(period 1), "
+    "C5": dict(short="BASELINE configs[4]: one-step-economy 100 agents + SimpleLabor + tax",
+               desc="BASELINE configs[4]: one-step-economy, 100 agents + SimpleLabor + PeriodicBracketTax(period 1), "
                     "episode_length 2",
                cfg=_c5_cfg, envs=65536, survey_bytes=987.0, kernel="aie_ose_step_kernel"),
 }
@@ -199,6 +207,7 @@ def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64):
     cfg = json.loads(json.dumps(cfg))
     for comp in cfg["components"]:  # `skills=` is an extension of the host mirror (the reference estimates them itself)
         comp[1].pop("skills", None)
+    cfg.pop("filter_recurrence", None)  # (host-mirror extension as well)
     ncores = usable_cores()
     P = max(1, min(ncores, max_procs))
     try:
@@ -213,7 +222,7 @@ def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64):
                "--seed", str(1 + k)]
         procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
                                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")))
-    rate, steps, late, n_agents, ok = 0.0, 0, 0, None, 0
+    rate, steps, late, n_agents, ok, resets = 0.0, 0, 0, None, 0, 0
     for pr in procs:
         try:
             out, _ = pr.communicate(timeout=seconds + 120)
@@ -226,14 +235,19 @@ def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64):
         rate += d["steps"] * d["n_agents"] / d["elapsed"]
         steps += d["steps"]
         late += int(d["late"])
+        resets += int(d.get("resets", 0))
     if not ok:
         return None
     return dict(value=rate, unit="agent-steps/s", cores=ok, kind="reference", per_core=rate / ok,
+                steps=steps, resets=resets, seconds=seconds,
+                sample_short="%d pinned procs x 1 env, unmodified reference env.step, free-running %.0f s window: %d steps, "
+                             "%d env.reset() inside it" % (ok, seconds, steps, resets),
                 sample="%d pinned processes x one environment each, the unmodified reference env.step "
                        "(base_env.py:929-1032, %s) stepped concurrently for %.0f s with uniform random actions: "
-                       "%d steps in total (%d agents each); host reports %d usable cores%s"
+                       "%d steps in total (%d agents each), %d episode ends (env.reset()) inside the window -- a "
+                       "free-running wall-clock window, not SURVEY 8(d)'s 3 whole episodes; host reports %d usable cores%s"
                        % (ok, "byte-compiled into oracle/_ref" if not ref_harness.reference_is_live_tree()
-                          else "live tree", seconds, steps, n_agents, ncores,
+                          else "live tree", seconds, steps, n_agents, resets, ncores,
                           ", %d workers started late" % late if late else ""))
 
 
@@ -587,6 +601,9 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
             "data": "synthetic",
             "config": {
                 "workload": "%s: %s; uniform random policy; mobile agents counted (planner excluded)" % (wl, W["desc"]),
+                "workload_short": "%s %s, uniform random policy, planner not counted" % (wl, W["short"]),
+                "parallelism_short": ("replica sharding x%d, RCCL (reward,done) gather to rank 0" % world) if world > 1
+                else "single GPU",
                 "envs_per_gpu": E, "global_envs": world * E, "n_agents": n,
                 "rng": "per-replica NumPy-legacy MT19937 (parity mode)",
                 "policy": "uniform random (counter RNG)" + ("; the draw for step t+1 happens inside the launch of "
@@ -620,9 +637,88 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
     return out
 
 
+# ---- the line the driver parses -----------------------------------------------------------------------------------
+# The driver keeps an 8 KB tail of stdout: the LAST line has to be short.  Everything else (prose notes, per-workload
+# configs, the layout byte breakdown, per-workload CPU baselines) goes to bench_detail.json and to an earlier line.
+LINE_LIMIT = 4096
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm_traffic_frac", "valu_frac",
+             "avg_launch_ms", "algorithmic_bytes_per_launch")
+SIDE_KEYS = ("value", "ms_per_step", "avg_launch_ms", "frac", "hbm_traffic_frac", "valu_frac", "bound", "kernel",
+             "gpu_region_seconds")
+
+
+def _sig(x, digits=5):
+    """Numbers rounded to `digits` significant figures (the detail file keeps full precision)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(out):
+    """The <= 4 KB driver line from the full result: the contract fields, the short config, the roofline numbers,
+    cpu_baseline {value, unit, cores, kind, sample}, one flat object per side workload.  No prose."""
+    cfg = out["config"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg["workload_short"], "envs_per_gpu": cfg["envs_per_gpu"],
+                      "global_envs": cfg["global_envs"], "n_agents": cfg["n_agents"],
+                      "kernel_specialisation": cfg["kernel_specialisation"], "parallelism": cfg["parallelism_short"]}
+    line["roofline"] = {k: out["roofline"].get(k) for k in ROOF_KEYS}
+    line["gpu_region_seconds"] = out["gpu_region_seconds"]
+    if out["n_gpus"] > 1 or out.get("gather"):
+        line["per_rank_seconds"] = out["per_rank_seconds"]
+        line["gather"] = out.get("gather")
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind")}
+        line["cpu_baseline"]["sample"] = cb.get("sample_short") or cb.get("sample", "")[:160]
+    if out.get("cpu_port"):
+        line["cpu_port"] = {k: out["cpu_port"].get(k) for k in ("value", "cores", "kind")}
+    if out.get("workloads"):
+        sides = {}
+        for name, r in out["workloads"].items():
+            if "error" in r:
+                sides[name] = {"error": r["error"][:80]}
+                continue
+            flat = dict(r.get("roofline") or {}, **{k: r.get(k) for k in ("value", "ms_per_step", "gpu_region_seconds")})
+            sides[name] = {k: flat.get(k) for k in SIDE_KEYS}
+            if r.get("cpu_baseline"):
+                sides[name]["cpu_ref"] = r["cpu_baseline"]["value"]
+        line["workloads"] = sides
+    line["detail"] = "bench_detail.json"
+    line = _sig(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:  # cannot happen with the key sets above (tests/test_bench_accounting.py); never truncate JSON
+        for name in list(line.get("workloads", {})):
+            line["workloads"][name] = {k: line["workloads"][name].get(k) for k in ("value", "ms_per_step", "frac")}
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
 # the other BASELINE configurations a default run also times, in short windows: (workload, steps, warm-up)
 # (C5: the first ~10 launches over its 7 GB arena run 15 % slower than the steady state -- 1.68 ms per launch measured
 # with 6 warm-up launches, 1.447 ms with 10, 30 or 60 on the same box)
+SIDE_CPU_BASELINES = ("C1", "C3", "C4x", "C5")  # (C2p / C4 step the same reference code as C2 / C4x)
+SIDE_CPU_SECONDS = 3.0
+
+
+def emit(out, detail_file):
+    """Full result -> bench_detail.json + an earlier stdout line; the compact line LAST."""
+    detail = json.dumps(out)
+    try:
+        with open(detail_file, "w") as f:
+            f.write(detail + "\n")
+    except OSError:
+        pass
+    print(detail, flush=True)
+    print(compact_line(out), flush=True)
+
+
 SIDE_WORKLOADS = [("C1", 200, 20), ("C2p", 200, 20), ("C3", 200, 20), ("C4", 200, 20), ("C4x", 100, 10), ("C5", 60, 20)]
 
 
@@ -643,6 +739,8 @@ def main():
                     help="C5: separate reset launches instead of restarting replicas inside the step launch")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the N > 1 reward-log gather in a 1-rank group (exercises the RCCL path on one GPU)")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full (uncompacted) result goes; the last stdout line is the <= 4 KB driver line")
     ap.add_argument("--launcher", choices=["auto", "torchrun"], default="auto",
                     help="torchrun: re-execute under torch.distributed.run even with --gpus 1 (the N > 1 launch path on one GPU)")
     args = ap.parse_args()
@@ -693,15 +791,16 @@ def main():
     if rank == 0:
         cfg = out.pop("_cfg")
         wl = args.workload
+        side_cfgs = {}
         if world == 1 and wl == "C2" and not args.no_workloads and not args.envs_per_gpu:
             # every BASELINE configuration under the same clock, in the same invocation (short windows)
             sides = {}
             for swl, ssteps, swarm in SIDE_WORKLOADS:
                 try:
                     r = run_workload(swl, args, ssteps, swarm, rank, local_rank, world, device)
-                    r.pop("_cfg", None)
+                    side_cfgs[swl] = r.pop("_cfg", None)
                     sides[swl] = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype",
-                                                    "config", "roofline")}
+                                                    "config", "roofline", "gpu_region_seconds")}
                 except Exception as exc:  # a side line must not take the headline down
                     sides[swl] = {"error": repr(exc)}
             out["workloads"] = sides
@@ -719,13 +818,22 @@ def main():
                     out["cpu_baseline"] = port
             elif ref is not None:
                 out["cpu_baseline"] = ref
+            # the reference's CPU step beside EVERY configuration of the run: a short window each
+            for swl in SIDE_CPU_BASELINES:
+                if swl in side_cfgs and "error" not in out["workloads"][swl]:
+                    try:
+                        r = cpu_reference_baseline(side_cfgs[swl], seconds=SIDE_CPU_SECONDS)
+                        if r is not None:
+                            out["workloads"][swl]["cpu_baseline"] = r
+                    except Exception as exc:
+                        out["workloads"][swl]["cpu_baseline_error"] = repr(exc)
         try:  # whatever native libraries (RCCL's version banner) left in the C stdio buffer goes out first, so that
             import ctypes  # the JSON line is the last line on stdout
 
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail_file)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

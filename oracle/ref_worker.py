@@ -6,7 +6,8 @@ of these concurrently and adds up their rates.
 
     python oracle/ref_worker.py --cfg-json '{...}' --core 3 --start <unix time> --seconds 10
 
-Prints one JSON line: {"steps": K, "elapsed": seconds, "n_agents": n, "late": bool}.
+Prints one JSON line: {"steps": K, "elapsed": seconds, "n_agents": n, "late": bool, "resets": R} (R = env.reset()
+calls inside the timed window: the window is free-running, an episode end costs what the reference's reset costs).
 """
 import argparse
 import json
@@ -50,6 +51,8 @@ def main():
     p_dims = pl.action_spaces if pl.multi_action_mode else None
     rng = np.random.RandomState(1234 + args.seed)
 
+    resets = [0]
+
     def one_step():
         acts = {str(i): int(a) for i, a in enumerate(rng.randint(0, A, size=n))}
         if p_dims is not None and len(np.atleast_1d(p_dims)):
@@ -57,6 +60,7 @@ def main():
         _, _, done, _ = env.step(acts)
         if done["__all__"]:
             env.reset()
+            resets[0] += 1
 
     for _ in range(20):
         one_step()
@@ -64,13 +68,15 @@ def main():
     while time.time() < args.start:
         time.sleep(0.001)
     t0 = time.time()
+    resets[0] = 0
     end = max(t0, args.start) + args.seconds
     steps = 0
     while time.time() < end:
         for _ in range(10):
             one_step()
         steps += 10
-    print(json.dumps({"steps": steps, "elapsed": time.time() - t0, "n_agents": n, "late": bool(late)}))
+    print(json.dumps({"steps": steps, "elapsed": time.time() - t0, "n_agents": n, "late": bool(late),
+                      "resets": resets[0]}))
 
 
 if __name__ == "__main__":

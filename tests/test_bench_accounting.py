@@ -48,3 +48,70 @@ def test_committed_round3_lines_agree_with_their_counter_summaries(path):
     step_rows = [row for row in stats[1:] if "step_kernel" in row and "reset" not in row]
     avg_ns = float(step_rows[0].split('",')[1].split(",")[2])
     assert avg_ns * 1e-6 == pytest.approx(r["avg_launch_ms"], rel=0.06)  # HIP events vs rocprofv3, same run
+
+
+def _synthetic_full_result(n_gpus=1, long_strings=400):
+    """A full bench result with EVERY optional part present and prose strings far longer than the real ones."""
+    prose = "x" * long_strings
+    roof = dict(bound="latency", roof="hbm", kernel="aie_step_kernel_spec<0>" + "k" * 40, achieved=7225.123456789,
+                peak=8000.0, unit="GB/s", frac=0.903140432, traffic=83412345.678, traffic_source=prose,
+                hbm_traffic_frac=0.4187654321, issue_frac=0.2987654321, wave_instructions_per_launch=123456789,
+                issue_source=prose, valu_frac=0.6087654321, valu_instructions_per_launch=98765432, valu_roof=prose,
+                issue_roof=prose, algorithmic_bytes_per_launch=179961856.0, algorithmic_bytes_per_unit=10984.0,
+                unit_of_work=prose, achieved_final_layout=8281.123, frac_final_layout=1.035,
+                final_layout_bytes_per_launch=1.0e8, final_layout_bytes_per_env_step={k: 1234567 for k in "abcdefgh"},
+                avg_launch_ms=0.0249071234, launches_timed=1999, reset_launches_in_region=99, reset_ms_in_region=1.234,
+                note=prose * 3, store_roof_GBps_this_box=6950.1234, traffic_frac_of_store_roof=0.62, store_roof_note=prose)
+    cfg = dict(workload=prose * 2, workload_short="C2 " + "w" * 140, parallelism_short="p" * 70, envs_per_gpu=4096,
+               global_envs=4096 * n_gpus, n_agents=4, rng=prose, policy=prose, phasing=prose, parallelism=prose,
+               dev_switches=[], kernel_specialisation="run time (aie_specialize)")
+    cpu = dict(value=134418.123456, unit="agent-steps/s", cores=256, kind="reference", per_core=525.1, steps=1234567,
+               resets=1234, seconds=10.0, sample_short="s" * 150, sample=prose * 2)
+    out = dict(metric="agent-steps/sec, " + "m" * 60, value=6.22123456e8, unit="agent-steps/s", n_gpus=n_gpus, steps=2000,
+               warmup=200, ms_per_step=0.0263123456, higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="u8/i32 state + f64 coin/utility (f32 observations)", data="synthetic", config=cfg,
+               per_rank_seconds=[0.0526123456] * n_gpus, host_issue_seconds=0.05, gpu_region_seconds=0.0521234,
+               exchange_ok=True, roofline=roof, cpu_baseline=cpu,
+               cpu_port=dict(value=3.8e6, unit="agent-steps/s", cores=256, kind="port", sample=prose),
+               gather=dict(collectives=32, bytes_per_collective=6291456, wait_seconds=0.00123456))
+    out["workloads"] = {name: dict(metric=prose, value=3.9e9, unit="agent-steps/s", steps=200, warmup=20,
+                                   ms_per_step=1.6725123, dtype=prose, config=cfg, roofline=dict(roof),
+                                   gpu_region_seconds=0.3345, cpu_baseline=dict(cpu))
+                        for name, _, _ in bench.SIDE_WORKLOADS}
+    out["workloads"]["C9"] = {"error": "RuntimeError(" + prose + ")"}
+    return out
+
+
+@pytest.mark.parametrize("n_gpus", [1, 8])
+def test_driver_line_stays_under_4_kb_and_keeps_the_contract(n_gpus):
+    """Round 3's driver record was unparsed because the last stdout line had grown past the driver's 8 KB tail.  The
+    line built from a result with every optional part present (and absurdly long prose) stays under 4 KB, is valid
+    JSON, and still carries the contract fields, `roofline` and `cpu_baseline`."""
+    full = _synthetic_full_result(n_gpus)
+    assert len(json.dumps(full)) > 20000  # the synthetic result is at least as large as round 3's real one
+    text = bench.compact_line(full)
+    assert len(text) < 4096 and "\n" not in text
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["config"]["global_envs"] == n_gpus * line["config"]["envs_per_gpu"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"]
+    assert line["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4)
+    assert line["value"] == pytest.approx(full["value"], rel=1e-4)
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+    for name, _, _ in bench.SIDE_WORKLOADS:
+        assert line["workloads"][name]["value"] == pytest.approx(3.9e9, rel=1e-4)
+        assert line["workloads"][name]["cpu_ref"] == pytest.approx(134418.12, rel=1e-4)
+    if n_gpus > 1:
+        assert len(line["per_rank_seconds"]) == n_gpus and line["gather"]["collectives"] == 32
+
+
+def test_emit_prints_the_compact_line_last(tmp_path, capsys):
+    full = _synthetic_full_result()
+    bench.emit(full, str(tmp_path / "detail.json"))
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert len(lines) == 2 and len(lines[-1]) < 4096
+    assert json.loads(lines[0]) == json.loads(open(tmp_path / "detail.json").read())
+    assert json.loads(lines[-1])["detail"] == "bench_detail.json"
