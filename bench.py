@@ -650,6 +650,8 @@ SIDE_KEYS = ("value", "ms_per_step", "avg_launch_ms", "frac", "hbm_traffic_frac"
 def _sig(x, digits=5):
     """Numbers rounded to `digits` significant figures (the detail file keeps full precision)."""
     if isinstance(x, float):
+        if x.is_integer() and abs(x) < 2 ** 53:  # byte counts stay exact
+            return int(x)
         return float("%.*g" % (digits, x))
     if isinstance(x, dict):
         return {k: _sig(v, digits) for k, v in x.items()}
