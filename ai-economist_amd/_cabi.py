@@ -5,7 +5,7 @@ by env.py purely as the owner of device memory / streams.
 """
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_AGENTS = 64
 MAX_AGENTS_WIDE = 128
 MAX_COMPONENTS = 8
@@ -200,6 +200,8 @@ def bind(lib):
     lib.aie_set_global_saez_buffer.argtypes = [vp, vp, C.c_int64]
     lib.aie_set_auto_reset.restype = C.c_int
     lib.aie_set_auto_reset.argtypes = [vp, C.c_int]
+    lib.aie_set_dense_log_active.restype = C.c_int
+    lib.aie_set_dense_log_active.argtypes = [vp, C.c_int]
     lib.aie_step_kernel_instance.restype = C.c_int
     lib.aie_step_kernel_instance.argtypes = [vp]
     lib.aie_sample_masked_actions.restype = C.c_int
@@ -216,7 +218,7 @@ EXPORTED_SYMBOLS = [
     "aie_tensor_at", "aie_get_tensor", "aie_upload", "aie_download", "aie_set_layout",
     "aie_seed", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
     "aie_sample_masked_actions", "aie_step_sample_next", "aie_set_reward_log", "aie_set_auto_reset",
-    "aie_step_kernel_instance", "aie_select_step_kernel", "aie_specialize", "aie_set_global_saez_buffer", "aie_sizeof_config",
+    "aie_set_dense_log_active", "aie_step_kernel_instance", "aie_select_step_kernel", "aie_specialize", "aie_set_global_saez_buffer", "aie_sizeof_config",
 ]
 KERNEL_AUTO, KERNEL_GENERIC = 0, 1
 KERNEL_INSTANCE_JIT = 1000

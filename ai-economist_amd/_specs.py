@@ -3,8 +3,9 @@
 For each entry the host mirror builds the `aie_config`, the build-time tool csrc/aie_specgen.c derives the parameter
 block from it (the same aie_build_params the library runs at aie_create) and normalises away what depends on the
 batch; the image is baked into `aie_step_kernel_spec<K>`.  At aie_create an environment whose normalised block
-equals an image byte for byte runs on that instance -- any replica count, any seed -- everything else runs on the
-generic kernel.  The list is the BASELINE component tuple (Build, ContinuousDoubleAuction, Gather,
+equals an image byte for byte runs on that instance -- any replica count, any seed, and any value of the scalars the
+normalisation blanks (an image stands for a family, csrc/aie_layout.h: aie_spec_normalize) -- everything else runs on
+the generic kernel until its run-time specialisation is ready (aie_specialize).  The list is the BASELINE component tuple (Build, ContinuousDoubleAuction, Gather,
 PeriodicBracketTax on the 25x25 quadrant layout) at the agent counts of BASELINE configs[1] and configs[2], plus the
 phase-2 setting of the reference's tutorials (planner without spatial observations).
 """
@@ -24,6 +25,28 @@ _BASE = dict(world_size=[25, 25], episode_length=1000, components=GTB, starting_
 _OSE = dict(n_agents=100, world_size=[1, 1], episode_length=2,
             components=[("SimpleLabor", {}), ("PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
                                                                      "tax_model": "model_wrapper"})])
+# the env blocks of the reference's two training YAMLs (tutorials/rllib/phase1|phase2/config.yaml): phase 1 = free
+# market (taxes disabled, energy warm-up "auto"), phase 2 = the planner sets the tax rates (no maps for the planner,
+# annealed rate cap); both with the four fixed skills / start locations.  Their scalars are the family's run-time part.
+def _phase(disable_taxes, **extra):
+    tax = dict(bracket_spacing="us-federal", disable_taxes=disable_taxes, period=100, tax_annealing_schedule=[-100, 0.001],
+               usd_scaling=1000)
+    if not disable_taxes:
+        tax.update(rate_disc=0.05, tax_model="model_wrapper")
+    return dict(n_agents=4, world_size=[25, 25], episode_length=1000, env_layout_file="quadrant_25x25_20each_30clump.txt",
+                components=[("Build", dict(build_labor=10, payment=10, payment_max_skill_multiplier=3, skill_dist="pareto")),
+                            ("ContinuousDoubleAuction", dict(max_bid_ask=10, max_num_orders=5, order_duration=50, order_labor=0.25)),
+                            ("Gather", dict(collect_labor=1, move_labor=1, skill_dist="pareto")),
+                            ("PeriodicBracketTax", tax)],
+                energy_cost=0.21, fixed_four_skill_and_loc=True, flatten_masks=True, flatten_observations=True,
+                isoelastic_eta=0.23, multi_action_mode_agents=False, multi_action_mode_planner=True,
+                planner_gets_spatial_info=False, planner_reward_type="coin_eq_times_productivity", starting_agent_coin=0,
+                **extra)
+
+
+PHASE1 = _phase(True, energy_warmup_constant=10000, energy_warmup_method="auto")
+PHASE2 = _phase(False, energy_warmup_constant=0)
+
 # (name, scenario, kwargs, kernel family, waves per SIMD): "gtb" -> aie_step_kernel_spec<K>, "ose" ->
 # aie_ose_step_kernel_spec<K>.  Waves per SIMD = what the instance's LDS footprint lets a CU hold (two waves per
 # workgroup, four SIMDs per CU, 160 KB of LDS in 1280-byte granules, at most 16 workgroups): C2's 6 736 B and C3's
@@ -40,6 +63,10 @@ SPECS = [
     ("C1: uniform 15x15, 4 agents, Build + Gather (BASELINE configs[0]'s scenario)", "uniform/simple_wood_and_stone",
      dict(n_agents=4, world_size=[15, 15], episode_length=1000, components=[("Build", {}), ("Gather", {})],
           starting_agent_coin=10, starting_stone_coverage=0.10, starting_wood_coverage=0.10), "gtb", 8),
+    ("P2: the reference's phase-2 training YAML (tutorials/rllib/phase2/config.yaml)", "layout_from_file/simple_wood_and_stone",
+     PHASE2, "gtb", 8),
+    ("P1: the reference's phase-1 training YAML (tutorials/rllib/phase1/config.yaml)", "layout_from_file/simple_wood_and_stone",
+     PHASE1, "gtb", 8),
 ]
 
 

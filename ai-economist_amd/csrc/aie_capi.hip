@@ -28,6 +28,7 @@ struct aie_env {
   int64_t sample_t;
   float* rew_log;        // aie_set_reward_log: caller's ring of n_slots step slots, or nullptr
   int32_t rew_log_slots, rew_log_next;
+  int log_active;        // aie_set_dense_log_active: the dense-log replicas record events (default) or run with the rest
   char err[512];
 };
 
@@ -93,12 +94,12 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
   if (rc != AIE_OK) { delete env; return rc; }
   env->device = device;
   env->spec = -1;
+  env->log_active = 1;
   if (cfg->scenario != AIE_SCN_COVID) {  // a compile-time instance exists for exactly this parameter block?
-    static aie_params norm;
-    norm = env->P;
-    aie_spec_normalize(&norm);
+    std::vector<aie_params> norm(1, env->P);  // (heap: the block is ~10 KB; not static: aie_create may run on several threads)
+    aie_spec_normalize(&norm[0]);
     for (int k = 0; k < AIE_N_SPECS; ++k)
-      if (memcmp(&norm, aie_spec_table[k], sizeof(aie_params)) == 0) env->spec = k;
+      if (memcmp(&norm[0], aie_spec_table[k], sizeof(aie_params)) == 0) env->spec = k;
   }
   env->spec_match = env->spec;
   const bool covid = cfg->scenario == AIE_SCN_COVID;
@@ -396,6 +397,18 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   if (env->P.saez_stride)  // tax_model "saez": the period-start formula runs ahead of the step (aie_kernels_saez.hip)
     hipLaunchKernelGGL(aie_saez_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0, static_cast<hipStream_t>(stream),
                        env->d_params, env->arena);
+  if (env->P.c.scenario == AIE_SCN_GTB && env->P.ev_replicas > 0 && env->log_active) {
+    // dense-log replicas whose episode is being logged: they -- and only they -- take the full-featured kernel, which
+    // records the AIE_EV_* rows; every other replica runs the environment's fast kernel below, in the same stream
+    NextActions lg = next;
+    lg.e_lo = 0;
+    lg.e_hi = env->P.ev_replicas;
+    hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
+                       static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, lg);
+    if (env->P.ev_replicas >= env->P.E) goto stepped;
+    next.e_lo = env->P.ev_replicas;
+    next.e_hi = env->P.E;
+  }
   if (env->P.c.scenario == AIE_SCN_COVID) {
     const dim3 g((unsigned)env->P.E), b(AIE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -409,14 +422,14 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
       default: return AIE_E_UNSUPPORTED;
     }
 #undef AIE_CV_LAUNCH
-  } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY && env->spec == AIE_KERNEL_INSTANCE_JIT && env->P.ev_replicas == 0) {
+  } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY && env->spec == AIE_KERNEL_INSTANCE_JIT) {
     const aie_params* dp = env->d_params;
     uint8_t* ar = env->arena;
     NextActions nx = next;
     void* args[] = {&dp, &ar, &d_actions_a, &d_actions_p, &nx};
     AIE_HIP_CHECK(env, hipModuleLaunchKernel(env->jit_step, (unsigned)env->P.E, 1, 1, OSE_NT, 1, 1, (unsigned)env->lds,
                                              static_cast<hipStream_t>(stream), args, nullptr));
-  } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY && env->spec >= 0 && env->P.ev_replicas == 0) {
+  } else if (env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY && env->spec >= 0) {
     const dim3 g((unsigned)env->P.E), b(OSE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define AIE_SPEC_LAUNCH_OSE(K) \
@@ -442,8 +455,8 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
 #undef AIE_SPEC_LAUNCH_TR
   }
 #endif
-  else if ((env->P.ev_replicas > 0 || env->P.saez_stride || env->P.M > AIE_NT || env->P.regen_general ||
-                                    env->P.dev_skip_mask != 0 || env->P.dev_trace != nullptr))
+  else if (env->P.saez_stride || env->P.M > AIE_NT || env->P.regen_general || env->P.dev_skip_mask != 0 ||
+           env->P.dev_trace != nullptr)
     hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
   else if (env->spec == AIE_KERNEL_INSTANCE_JIT) {
@@ -469,6 +482,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   else
     hipLaunchKernelGGL(aie_step_kernel, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, next);
+stepped:
   if (env->P.auto_reset && env->P.c.scenario != AIE_SCN_ONE_STEP_ECONOMY) {
     // auto-reset: the replicas this step finished restart right behind it on the same stream (mask = the `done`
     // tensor the step just wrote; the reset keeps the terminal rewards / done).  one-step-economy does it inside the
@@ -502,6 +516,12 @@ int aie_set_global_saez_buffer(aie_env* env, const double* d_pairs, int64_t n_pa
     AIE_HIP_CHECK(env, hipMemcpy(g + 16, d_pairs, (size_t)n_pairs * 16, hipMemcpyDeviceToDevice));
   const int32_t len = (int32_t)n_pairs;
   AIE_HIP_CHECK(env, hipMemcpy(g, &len, 4, hipMemcpyHostToDevice));
+  return AIE_OK;
+}
+
+int aie_set_dense_log_active(aie_env* env, int on) {
+  if (!env) return AIE_E_INVALID;
+  env->log_active = on ? 1 : 0;
   return AIE_OK;
 }
 
@@ -571,10 +591,9 @@ int aie_specialize(aie_env* env) {
   }
   const aie_params& P = env->P;
   const bool ose = P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY;
-  if (P.c.scenario == AIE_SCN_COVID || P.ev_replicas > 0 || P.saez_stride ||
-      (!ose && (P.M > AIE_NT || P.regen_general))) {
-    snprintf(env->err, sizeof(env->err), "aie_specialize: this configuration runs the full-featured step kernel (dense-log "
-             "replicas, tax_model \"saez\", order books beyond a wavefront, general regeneration) or is the COVID scenario");
+  if (P.c.scenario == AIE_SCN_COVID || P.saez_stride || (!ose && (P.M > AIE_NT || P.regen_general))) {
+    snprintf(env->err, sizeof(env->err), "aie_specialize: this configuration runs the full-featured step kernel (tax_model "
+             "\"saez\", order books beyond a wavefront, general regeneration) or is the COVID scenario");
     return AIE_E_UNSUPPORTED;
   }
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
@@ -582,8 +601,8 @@ int aie_specialize(aie_env* env) {
   AIE_HIP_CHECK(env, hipGetDeviceProperties(&prop, env->device));
   std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
   arch = arch.substr(0, arch.find(':'));
-  static aie_params norm;
-  norm = env->P;
+  std::vector<aie_params> norm_v(1, env->P);  // (not static: two environments may specialise from different threads)
+  aie_params& norm = norm_v[0];
   aie_spec_normalize(&norm);
   const int wg = aie_workgroups_per_cu(env->lds);
   // gather-trade-build: two waves per workgroup on four SIMDs; one-step-economy: one wave per workgroup

@@ -196,7 +196,7 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R
   q += 16 + AIE_DIRTY_CAP * 2;
   q = lds + ((q - lds) + 15) / 16 * 16;
   // (the kernel that asks for the LDS tables fills them: step_body; everyone else reads the parameter block)
-  const double* rtab = P.c.tax_disc_rates;
+  const double* rtab = R.c.tax_disc_rates;
   const uint32_t* mtab = P.mask_test;
   if (const_tables_in_lds(P)) {
     if (lds_tables) {
@@ -212,8 +212,8 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R
   uint8_t* met = arena ? arena + R.a_metrics + (int64_t)e * P.met_bytes : nullptr;
   // with_events == false is a compile-time constant in the common step kernel: every `if (c.ev)` / `if (c.saez)`
   // folds away (environments with dense-log replicas or tax_model "saez" run aie_step_kernel_log)
-  int32_t* ev = (with_events && arena && e < P.ev_replicas)
-                    ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * P.ev_stride) : nullptr;
+  int32_t* ev = (with_events && arena && e < R.ev_replicas)  // (the event buffer is a property of the batch, not of an
+                    ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * R.ev_stride) : nullptr;  // instance's family)
   const bool saez = with_events && P.c.tax_model == AIE_TAX_SAEZ;
   return Ctx{P, R, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, snap, met, ev, saez, with_events, tid, e, rtab, mtab, mtwin, skipm};
 }
@@ -735,7 +735,7 @@ __device__ __forceinline__ void log_event(const Ctx& c, int type, int a1, int a2
                                           int a6, int a7, int a8, double f) {
   if (c.tid != 0) return;
   const int k = c.srcn[2];
-  if (k >= c.P.ev_cap) return;
+  if (k >= c.R.ev_cap) return;
   int32_t* row = c.ev + 4 + k * AIE_EV_WORDS;
   row[0] = type; row[1] = a1; row[2] = a2; row[3] = a3; row[4] = a4;
   row[5] = a5; row[6] = a6; row[7] = a7; row[8] = a8; row[9] = 0;
@@ -895,7 +895,7 @@ __device__ __forceinline__ void build_component_step(const Ctx& c, MTL& m, Agent
       A.inv0 -= 1;
       A.inv1 -= 1;
       A.coin += R_F64(c, o_build_payment)[i];
-      A.labor += c.P.c.build_labor;
+      A.labor += c.R.c.build_labor;
     }
     cells[cell] = (w & 0xff00ffffu) | ((uint32_t)i << 16);  // world.py:474-479 (every lane, same value)
     dirty_add_uniform(c, m, cell);
@@ -935,7 +935,7 @@ __device__ __forceinline__ void gather_component_step_serial(const Ctx& c, MTL& 
           if (lane == i) {
             A.lr = nr;
             A.lc = nc;
-            A.labor += c.P.c.move_labor;
+            A.labor += c.R.c.move_labor;
           }
           land = tcell;
         }
@@ -953,7 +953,7 @@ __device__ __forceinline__ void gather_component_step_serial(const Ctx& c, MTL& 
           const int got = 1 + (rng_double(m, lane) < bonus ? 1 : 0);
           if (lane == i) {
             if (rs == 0) A.inv0 += got; else A.inv1 += got;
-            A.labor += c.P.c.collect_labor;
+            A.labor += c.R.c.collect_labor;
           }
           w -= (1u << (8 * rs));  // consume_resource, world.py:481-483
           if (c.ev) log_event(c, AIE_EV_GATHER, i, rs, got, land / W, land % W, 0, 0, 0, 0.0);
@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void gather_component_step_lookahead(const Ctx& c, MT
       if (lane == i) {
         A.lr = udiv(tcell, W, c.P.mg_W);
         A.lc = tcell - A.lr * W;
-        A.labor += c.P.c.move_labor;
+        A.labor += c.R.c.move_labor;
       }
       // whoever targets the tile this agent left or the one it entered no longer knows that tile's occupancy
       stale |= __ballot(my_tcell == land || my_tcell == tcell);
@@ -1059,7 +1059,7 @@ __device__ __forceinline__ void gather_component_step_lookahead(const Ctx& c, MT
           const int got = 1 + (rng_double(m, lane) < bonus ? 1 : 0);
           if (lane == i) {
             if (rs == 0) A.inv0 += got; else A.inv1 += got;
-            A.labor += c.P.c.collect_labor;
+            A.labor += c.R.c.collect_labor;
           }
           w -= (1u << (8 * rs));  // consume_resource, world.py:481-483
           if (c.ev) log_event(c, AIE_EV_GATHER, i, rs, got, land / W, land % W, 0, 0, 0, 0.0);
@@ -1150,7 +1150,7 @@ __device__ __forceinline__ void hist_sub_lane(uint8_t* hist, int idx) {  // one 
 // ContinuousDoubleAuction.component_step :440-489 (decay of :451 already applied)
 __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
   const int n = c.P.n, M = c.P.M, P = c.P.P, lane = c.tid;
-  const int maxo = c.P.c.cda_max_num_orders, dur = c.P.c.cda_order_duration;
+  const int maxo = c.P.c.cda_max_num_orders, dur = c.R.c.cda_order_duration;
   uint8_t* bid_hist = R_U8(c, o_cda_bid_hist);
   uint8_t* ask_hist = R_U8(c, o_cda_ask_hist);
   int nb[2] = {uni(R_I32(c, o_cda_n_bids)[0]), uni(R_I32(c, o_cda_n_bids)[1])};
@@ -1180,7 +1180,7 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
             const double tr = A.coin < (double)price ? A.coin : (double)price;  // base_agent.py:279-299
             A.coin -= tr;
             A.esc_coin += tr;
-            A.labor += c.P.c.cda_order_labor;
+            A.labor += c.R.c.cda_order_labor;
           }
         }
       }
@@ -1194,7 +1194,7 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
           if (lane == i) {
             if (r) { A.no1 += 1; A.inv1 -= 1; A.esc1 += 1; }
             else { A.no0 += 1; A.inv0 -= 1; A.esc0 += 1; }
-            A.labor += c.P.c.cda_order_labor;
+            A.labor += c.R.c.cda_order_labor;
           }
         }
       }
@@ -1450,8 +1450,8 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
 // curr_rate_max :390-394: the annealed limit follows _last_completions, which generate_masks
 // refreshes AFTER the observations of a reset are built (:1036-1046) -- kept as a state field.
 __device__ __forceinline__ double tax_curr_rate_max(const Ctx& c) {
-  return aie_annealed_tax_limit(*R_I32(c, o_tax_last_completions), c.P.c.tax_annealing_warmup,
-                                c.P.c.tax_annealing_slope, c.P.c.tax_rate_max);
+  return aie_annealed_tax_limit(*R_I32(c, o_tax_last_completions), c.R.c.tax_annealing_warmup,
+                                c.R.c.tax_annealing_slope, c.R.c.tax_rate_max);
 }
 // this replica's Saez block (tax_model "saez", aie_layout.h: a_saez); step / reset kernels only (c.met set)
 __device__ __forceinline__ uint8_t* saez_block(const Ctx& c) {
@@ -1461,10 +1461,10 @@ __device__ __forceinline__ double tax_rate(const Ctx& c, int b) {  // curr_margi
   if (c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER) return c.rtab[R_I32(c, o_tax_rate_idx)[b]];
   if (c.saez) {  // np.minimum(curr_bracket_tax_rates, curr_rate_max) :406-409
     const double r = R_F64(c, o_tax_saez_rates)[b];
-    const double cap = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.P.c.tax_rate_max;
+    const double cap = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.R.c.tax_rate_max;
     return r < cap ? r : cap;
   }
-  const double r = c.P.c.tax_fixed_rates[b];
+  const double r = c.R.c.tax_fixed_rates[b];
   if (!c.P.c.tax_annealing) return r;
   const double cap = tax_curr_rate_max(c);
   return r < cap ? r : cap;
@@ -1480,24 +1480,24 @@ __device__ __forceinline__ bool tax_rate_action_visible(const Ctx& c, int j) {
   if (!c.P.c.tax_annealing) return true;
   double full = 0;
   for (int k = 0; k < c.P.c.tax_n_disc_rates; ++k) full = fmax(full, fabs(c.rtab[k]));
-  const double vis = aie_annealed_tax_limit(*R_I32(c, o_tax_last_completions), c.P.c.tax_annealing_warmup,
-                                            c.P.c.tax_annealing_slope, full);
+  const double vis = aie_annealed_tax_limit(*R_I32(c, o_tax_last_completions), c.R.c.tax_annealing_warmup,
+                                            c.R.c.tax_annealing_slope, full);
   return fabs(c.rtab[j]) <= vis;
 }
 __device__ __forceinline__ double tax_marginal_rate(const Ctx& c, double income) {  // marginal_rate :837-844
   if (income < 0) return 0.0;
   const int NB = c.P.NB;
   for (int b = 0; b < NB; ++b) {
-    const double lo = c.P.c.tax_bracket_cutoffs[b];
-    const bool under = (b + 1 < NB) ? (income < c.P.c.tax_bracket_cutoffs[b + 1]) : (income < __builtin_huge_val());
+    const double lo = c.R.c.tax_bracket_cutoffs[b];
+    const bool under = (b + 1 < NB) ? (income < c.R.c.tax_bracket_cutoffs[b + 1]) : (income < __builtin_huge_val());
     if (income >= lo && under) return tax_rate(c, b);
   }
   return tax_rate(c, 0);
 }
 __device__ __forceinline__ double tax_bin(const Ctx& c, double income, int b) {
   const int NB = c.P.NB;
-  const double cut = c.P.c.tax_bracket_cutoffs[b];
-  const double size = (b + 1 < NB) ? c.P.c.tax_bracket_cutoffs[b + 1] - cut : __builtin_huge_val();
+  const double cut = c.R.c.tax_bracket_cutoffs[b];
+  const double size = (b + 1 < NB) ? c.R.c.tax_bracket_cutoffs[b + 1] - cut : __builtin_huge_val();
   double past = income - cut;
   if (past < 0) past = 0;
   return tax_rate(c, b) * (size < past ? size : past);
@@ -1543,7 +1543,7 @@ __device__ __forceinline__ void tax_enact(const Ctx& c, Agents& A) {
       int bin = 0;  // income_bin :828-835
       if (income >= 0)
         for (int b = 0; b < c.P.NB; ++b)
-          if (income >= c.P.c.tax_bracket_cutoffs[b] && (b + 1 == c.P.NB || income < c.P.c.tax_bracket_cutoffs[b + 1])) { bin = b; break; }
+          if (income >= c.R.c.tax_bracket_cutoffs[b] && (b + 1 == c.P.NB || income < c.R.c.tax_bracket_cutoffs[b + 1])) { bin = b; break; }
       atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_occ) + bin, 1);
     }
   }
@@ -1578,7 +1578,7 @@ __device__ __forceinline__ void tax_enact(const Ctx& c, Agents& A) {
       buf[2 * (len + i) + 1] = R_F64(c, o_tax_last_marginal_rate)[i];
     }
     len += n;
-    const int size = c.P.c.saez_buffer_size;
+    const int size = c.R.c.saez_buffer_size;
     if (len > size) {  // drop the oldest: move down chunk by chunk (a chunk's loads precede its stores;
       const int shift = 2 * (len - size);  // later chunks only read above what earlier ones wrote)
       __builtin_amdgcn_s_waitcnt(0);
@@ -1605,8 +1605,8 @@ __device__ __forceinline__ void tax_component_step(const Ctx& c, MTL& ml, Agents
     if (uni(reinterpret_cast<const int32_t*>(blk)[1])) {  // the formula ran in aie_saez_kernel just before this launch
       if (c.tid < c.P.NB) R_F64(c, o_tax_saez_rates)[c.tid] = reinterpret_cast<const double*>(blk + AIE_SAEZ_OFF_NEXT)[c.tid];
     } else {  // np.random.uniform(low=rate_min, high=curr_rate_max, size=n_brackets) :451-457
-      const double lo = c.P.c.tax_rate_min;
-      const double hi = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.P.c.tax_rate_max;
+      const double lo = c.R.c.tax_rate_min;
+      const double hi = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.R.c.tax_rate_max;
       for (int b = 0; b < c.P.NB; ++b) {
         const double r = lo + (hi - lo) * rng_double(ml, c.tid);
         if (c.tid == b) R_F64(c, o_tax_saez_rates)[b] = r;
@@ -1623,7 +1623,7 @@ __device__ __forceinline__ void tax_component_step(const Ctx& c, MTL& ml, Agents
     }
     AIE_WSYNC();
   }
-  if (pos >= c.P.c.tax_period) {
+  if (pos >= c.R.c.tax_period) {
     tax_enact(c, A);
     pos = 0;
   }
@@ -1680,16 +1680,16 @@ __device__ __forceinline__ void regen_cell(const Ctx& c, uint32_t ta, uint32_t t
       // multiply-add per kernel element in scipy's order (input rows r0+hw .. r0-hw, columns c0+hw .. c0-hw, zeros
       // outside the world), over the pre-step snapshot (dynamic_layout.py:446-463)
       const int dd = 1 + 2 * hwid, W = c.P.W, r0 = cell / W, c0 = cell - r0 * W;
-      const double kern = c.P.c.regen_weight[rs] / (double)(dd * dd);
+      const double kern = c.R.c.regen_weight[rs] / (double)(dd * dd);
       const uint8_t* sp = c.snap + rs * ((HW + 15) / 16 * 16);
       p = 0.0;
       for (int r = r0 + hwid; r >= r0 - hwid; --r)
         for (int cc = c0 + hwid; cc >= c0 - hwid; --cc)
           if (r >= 0 && r < c.P.H && cc >= 0 && cc < W) p += kern * (double)sp[r * W + cc];
     } else if (hwid > 0) {
-      p = c.P.regen_p[rs][R_U8(c, o_regen_count)[rs * HW + cell]];
+      p = c.R.regen_p[rs][R_U8(c, o_regen_count)[rs * HW + cell]];
     } else {
-      p = c.P.c.regen_weight[rs] * (double)health;
+      p = c.R.c.regen_weight[rs] * (double)health;
     }
     if (u < p && mval < (uint32_t)c.P.c.max_health[rs]) {
       cb[rs] = (uint8_t)(mval + 1);
@@ -1829,9 +1829,9 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
 // Utilities / rewards
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ double energy_weight(const Ctx& c) {  // layout_from_file.py:249-267
-  if (c.P.c.energy_warmup_constant <= 0.0) return 1.0;
+  if (!c.P.sh_energy_warmup) return 1.0;  // (energy_warmup_constant <= 0: a property of the instance's family)
   const int v = c.P.c.energy_warmup_method == AIE_WARMUP_DECAY ? *R_I32(c, o_completions) : *R_I32(c, o_auto_warmup);
-  return 1.0 - aie_exp_glibc(-(double)v / c.P.c.energy_warmup_constant);  // libm's exp, bit for bit (aie_glibc_math.h)
+  return 1.0 - aie_exp_glibc(-(double)v / c.R.c.energy_warmup_constant);  // libm's exp, bit for bit (aie_glibc_math.h)
 }
 
 // get_current_optimization_metrics layout_from_file.py:269-318 with
@@ -1845,13 +1845,13 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
   double* coin = scr_coin(c);
   double* out = scr_part(c);
   double* tmp = scr_cmr(c);  // free at this point
-  const double lcf = energy_weight(c) * c.P.c.energy_cost;
-  const double eta = c.P.c.isoelastic_eta;
+  const double lcf = energy_weight(c) * c.R.c.energy_cost;
+  const double eta = c.R.c.isoelastic_eta;
   if (i < n) {
     const double ci = R_F64(c, o_inv_coin)[i] + R_F64(c, o_esc_coin)[i];
     coin[i] = ci;
     double util_c;
-    if (eta == 1.0) util_c = aie_log_glibc(ci > 1 ? ci : 1);
+    if (c.P.sh_eta_is_one) util_c = aie_log_glibc(ci > 1 ? ci : 1);
     else util_c = (aie_pow_glibc(ci, 1 - eta) - 1) / (1 - eta);  // libm's pow bit for bit: the sign of a ~1e-16 mean reward
                                                                   // feeds the integer auto_warmup counter (aie_glibc_math.h)
     out[i] = util_c - R_F64(c, o_labor)[i] * lcf;
@@ -1885,7 +1885,7 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
       gini = 1 - (2.0 / (n + 1)) * np_sum_small(s, n);
     }
     if (i == 0) {
-      const double ew = 1 - c.P.c.mixing_weight_gini_vs_coin;
+      const double ew = 1 - c.R.c.mixing_weight_gini_vs_coin;
       out[n] = (ew * (1 - gini) + (1 - ew)) * (tot / n);
     }
   } else {
@@ -2187,7 +2187,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
   const BufRsrc aflat = make_rsrc(arena + c.R.a_obs_a_flat + (int64_t)c.e * n * P.FA * 4, (uint32_t)(n * P.FA * 4));
   auto AF = [&](int idx, float v) { buf_store_f32(aflat, v, 4 * idx, 0); };
   const int t = *R_I32(c, o_timestep);
-  const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)P.c.episode_length : 1.0));
+  const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)c.R.c.episode_length : 1.0));
 
   const int skip = c.skipm;
   // ================= stage A: per-(commodity, price) sums, per-agent scalars ===========
@@ -2218,7 +2218,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
     const int inv0 = R_I32(c, o_inv_res)[i], inv1 = R_I32(c, o_inv_res)[n + i];
     const int lr = R_I32(c, o_loc_r)[i], lc = R_I32(c, o_loc_c)[i];
     if (P.has_build) {  // build.py:163-178
-      AF(f0 + P.fa_build + 0, (float)(R_F64(c, o_build_payment)[i] / (double)P.c.build_payment));
+      AF(f0 + P.fa_build + 0, (float)(R_F64(c, o_build_payment)[i] / (double)c.R.c.build_payment));
       AF(f0 + P.fa_build + 1, (float)R_F64(c, o_build_skill)[i]);
     }
     if (P.has_gather) AF(f0 + P.fa_gather, (float)R_F64(c, o_bonus_gather_prob)[i]);  // move.py:155-165
@@ -2238,7 +2238,7 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
     reinterpret_cast<float*>(arena + c.R.a_obs_a_time)[(int64_t)c.e * n + i] = tval;
     if (P.has_tax) {
       // last_incomes sorted ascending (redistribution.py:908-911): rank by counting
-      const double per = (double)P.c.tax_period;
+      const double per = (double)c.R.c.tax_period;
       const double x = R_F64(c, o_tax_last_income)[i] / per;
       double* xs = scr_cmr(c);  // (free until the rewards: one division per agent, not one per pair)
       xs[i] = x;
@@ -2296,9 +2296,9 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
   if (P.has_tax && !(skip & 256)) {
     // redistribution.py:974-1023; lanes over (agent or planner, element of the fragment)
     const int pos = *R_I32(c, o_tax_cycle_pos);
-    const float is_tax_day = pos >= P.c.tax_period ? 1.0f : 0.0f;
+    const float is_tax_day = pos >= c.R.c.tax_period ? 1.0f : 0.0f;
     const float is_first_day = pos == 1 ? 1.0f : 0.0f;
-    const float tax_phase = (float)((double)pos / (double)P.c.tax_period);
+    const float tax_phase = (float)((double)pos / (double)c.R.c.tax_period);
     const int fragA = NB + n + 4;
     for (int q = tid; q < (n + 1) * fragA; q += AIE_NT) {
       const int i = udiv(q, fragA, P.mg_taxA);
@@ -2444,6 +2444,10 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
   // aie_set_reward_log: this step's slot of the caller's reward log, f32 [E][n + 2] = agents' rewards, the
   // planner's reward, done -- or nullptr
   float* rew_log;
+  // replicas this launch steps: [e_lo, e_hi), or all of them when e_hi == 0.  An environment with dense-log replicas
+  // whose current episode is being logged steps those replicas with aie_step_kernel_log and the rest with its fast
+  // kernel (aie_capi.hip: aie_step_impl)
+  int32_t e_lo, e_hi;
 };
 // SPEC >= 0: a compile-time instance (aie_spec_generated.h): P is a constant image of the parameter block of one
 // configuration -- every dimension, record offset, component list, mask table and magic divisor folds into the
@@ -2464,7 +2468,9 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
 #else
   const int skip = 0;
 #endif
-  const Ctx c = make_ctx(P, R, lds, replica_of_block((int)blockIdx.x, R.E), (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG, skip,
+  const int e_blk = replica_of_block((int)blockIdx.x, R.E);
+  if (next.e_hi > 0 && (e_blk < next.e_lo || e_blk >= next.e_hi)) return;  // (uniform over the workgroup, ahead of every barrier)
+  const Ctx c = make_ctx(P, R, lds, e_blk, (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG, skip,
                          /*lds_tables=*/SPEC >= 0);  // (the generic kernel keeps the parameter block's arrays: a pointer
                                                      // that may be LDS or global at run time costs it flat accesses and spills)
   MT m;
@@ -2492,7 +2498,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (SPEC >= 0 && wid == NW - 1 && const_tables_in_lds(P)) {
     // the small constant tables (Ctx.rtab / mtab) -> LDS, published by the barrier below
     if (P.has_tax && P.c.tax_model == AIE_TAX_MODEL_WRAPPER)
-      for (int q = c.tid; q < P.c.tax_n_disc_rates; q += AIE_NT) const_cast<double*>(c.rtab)[q] = P.c.tax_disc_rates[q];
+      for (int q = c.tid; q < P.c.tax_n_disc_rates; q += AIE_NT) const_cast<double*>(c.rtab)[q] = R.c.tax_disc_rates[q];
     for (int q = c.tid; q < P.MA; q += AIE_NT) const_cast<uint32_t*>(c.mtab)[q] = P.mask_test[q];
   }
   if (wid == 0) decode_actions(c, A, act_a, act_p);
@@ -2561,7 +2567,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     if (!(skip & 16)) compute_rewards(c, arena, next.rew_log);  // utilities do not look at the map either
     AIE_WSYNC();
     if (c.tid == 0) {
-      const int done = *R_I32(c, o_timestep) >= P.c.episode_length;
+      const int done = *R_I32(c, o_timestep) >= R.c.episode_length;
       (arena + c.R.a_done)[c.e] = (uint8_t)done;
       if (next.rew_log) next.rew_log[(int64_t)c.e * (P.n + 2) + P.n + 1] = done ? 1.0f : 0.0f;
       if (done) *R_I32(c, o_completions) += 1;
@@ -2914,7 +2920,7 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
         }
         cnt += lg_block_count(in, sh, par, wave, lane);
       }
-      mz_scale[rs] = (1.0 / ((double)cnt / (double)HW)) * g.layout_coverage[1];
+      mz_scale[rs] = (1.0 / ((double)cnt / (double)HW)) * c.R.c.layout_coverage[1];
     }
   }
   auto source_prob = [&](int rs, int cell, double clump) -> double {
@@ -2942,7 +2948,7 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
     LG_CNT(5);
     for (int q = 0; q < 2; ++q) {
       const int rs = q == 0 ? 1 : 0;  // ["Wood", "Stone"]
-      const double cov = g.layout_coverage[rs], clump = g.layout_clump[rs];
+      const double cov = c.R.c.layout_coverage[rs], clump = c.R.c.layout_clump[rs];
       uint8_t* mb = mbp[rs];
       const uint8_t* other = q == 0 ? nullptr : mbp[1];  // empty = nothing placed on the tile yet
       // tmp = rs.rand(H, W): NT doubles per pass, thread t takes words pos + 2 t, + 1
@@ -3116,7 +3122,7 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
         const int cell = base + gtid;
         count += lg_block_count(cell < HW && mbp[rs][cell], sh, par, wave, lane);
       }
-      const double ratio = ((double)count / (double)HW) / g.layout_coverage[rs];
+      const double ratio = ((double)count / (double)HW) / c.R.c.layout_coverage[rs];
       if (!((1 / 1.4) <= ratio && ratio <= 1.4)) happy = false;
     }
   }
@@ -3183,7 +3189,7 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
     if (tid < n) {
       R_I32(c, o_inv_res)[tid] = 0; R_I32(c, o_inv_res)[n + tid] = 0;
       R_I32(c, o_esc_res)[tid] = 0; R_I32(c, o_esc_res)[n + tid] = 0;
-      R_F64(c, o_inv_coin)[tid] = P.c.starting_agent_coin;
+      R_F64(c, o_inv_coin)[tid] = c.R.c.starting_agent_coin;
       R_F64(c, o_esc_coin)[tid] = 0;
       R_F64(c, o_labor)[tid] = 0;
       R_I32(c, o_loc_r)[tid] = -1;
@@ -3242,7 +3248,7 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
       case AIE_COMP_BUILD:
         for (int i = 0; i < n; ++i) {
           double skill = 1, pay = 1;
-          const double pm = (double)P.c.build_payment_max_skill_multiplier;
+          const double pm = (double)c.R.c.build_payment_max_skill_multiplier;
           if (P.c.build_skill_dist == AIE_SKILL_PARETO) {
             skill = rng_pareto(m, tid, 4.0);
             pay = (pm - 1) * skill + 1; if (pm < pay) pay = pm;
@@ -3250,7 +3256,7 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
             skill = rng_lognormal(c, m, -1.0, 0.5);
             pay = (pm - 1) * skill + 1; if (pm < pay) pay = pm;
           }
-          R_F64(c, o_build_payment)[i] = pay * (double)P.c.build_payment;
+          R_F64(c, o_build_payment)[i] = pay * (double)c.R.c.build_payment;
           R_F64(c, o_build_skill)[i] = skill;
         }
         break;
@@ -3292,13 +3298,13 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
     const int perm = rng_permutation(m, tid, n);
     for (int k = 0; k < n; ++k) {
       const int i = bcast(perm, k);
-      const int r = P.c.ranked_locs[k][0], col = P.c.ranked_locs[k][1];
+      const int r = c.R.c.ranked_locs[k][0], col = c.R.c.ranked_locs[k][1];
       if (can_agent_occupy(c, r, col, i)) {
         R_I32(c, o_loc_r)[i] = r;
         R_I32(c, o_loc_c)[i] = col;
         c.locmap[r * P.W + col] = (uint8_t)(i + 1);
       }
-      R_F64(c, o_build_payment)[i] = P.c.avg_ranked_skill[k];
+      R_F64(c, o_build_payment)[i] = c.R.c.avg_ranked_skill[k];
     }
   }
   if (P.c.split_water_line > 0) {  // SplitLayout.additional_reset_steps layout_from_file.py:759-793
@@ -3311,8 +3317,8 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
     const int wl = P.c.split_water_line;
     for (int k = 0; k < n; ++k) {
       const int i = bcast(perm, k);
-      R_F64(c, o_build_payment)[i] = P.c.avg_ranked_skill[k];
-      const bool top = (P.c.split_top_ranks[k >> 5] >> (k & 31)) & 1u;
+      R_F64(c, o_build_payment)[i] = c.R.c.avg_ranked_skill[k];
+      const bool top = (c.R.c.split_top_ranks[k >> 5] >> (k & 31)) & 1u;
       const int r_min = top ? 0 : wl + 1, r_max = top ? wl : P.H;
       int r = r_min + (int)rng_interval(m, tid, (uint32_t)(r_max - r_min - 1));
       int col = (int)rng_interval(m, tid, (uint32_t)(P.W - 1)), tries = 0;

@@ -84,9 +84,9 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, const aie_param
   s.tmpl_a = reinterpret_cast<float*>(q);
   s.tmpl_p = s.tmpl_a + pad4(P.FA > P.MA ? P.FA : P.MA);
   uint8_t* met = arena + R.a_metrics + (int64_t)e * P.met_bytes;
-  int32_t* ev = e < P.ev_replicas ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * P.ev_stride) : nullptr;
+  int32_t* ev = e < R.ev_replicas ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * R.ev_stride) : nullptr;
   return Ctx{P, R, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e,
-             /*rtab=*/P.c.tax_disc_rates, /*mtab=*/P.mask_test, /*mtwin=*/nullptr, /*skipm=*/0};
+             /*rtab=*/R.c.tax_disc_rates, /*mtab=*/P.mask_test, /*mtwin=*/nullptr, /*skipm=*/0};
 }
 
 // The draws of np.random.permutation(n) (World.get_random_order_agents, world.py:418-422) for a caller that never
@@ -172,8 +172,8 @@ __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __r
   L.esc0 = c.tid < c.P.n ? ge[c.tid] : 0.0;
   L.skill1 = c.tid + OSE_NT < c.P.n ? gs[c.tid + OSE_NT] : 0.0;
   L.esc1 = c.tid + OSE_NT < c.P.n ? ge[c.tid + OSE_NT] : 0.0;
-  L.skobs0 = (float)(L.skill0 / c.P.c.labor_pmsm);
-  L.skobs1 = (float)(L.skill1 / c.P.c.labor_pmsm);
+  L.skobs0 = (float)(L.skill0 / c.R.c.labor_pmsm);
+  L.skobs1 = (float)(L.skill1 / c.R.c.labor_pmsm);
   L.met_inc0 = L.met_inc1 = L.met_paid0 = L.met_paid1 = 0.0;
   if (c.P.has_tax && c.met) {
     const double* mi = reinterpret_cast<const double*>(c.met + c.P.mo_tax_income);
@@ -249,8 +249,8 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
     if (uni(reinterpret_cast<const int32_t*>(blk)[1])) {
       if (c.tid < c.P.NB) R_F64(c, o_tax_saez_rates)[c.tid] = reinterpret_cast<const double*>(blk + AIE_SAEZ_OFF_NEXT)[c.tid];
     } else {
-      const double lo = c.P.c.tax_rate_min;
-      const double hi = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.P.c.tax_rate_max;
+      const double lo = c.R.c.tax_rate_min;
+      const double hi = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.R.c.tax_rate_max;
       for (int b = 0; b < c.P.NB; ++b) {
         const double r = lo + (hi - lo) * rng_double(m, c.tid & 63);
         if (c.tid == b) R_F64(c, o_tax_saez_rates)[b] = r;
@@ -289,7 +289,7 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
       int bin = 0;  // income_bin :828-835
       if (income >= 0)
         for (int b = 0; b < c.P.NB; ++b)
-          if (income >= c.P.c.tax_bracket_cutoffs[b] && (b + 1 == c.P.NB || income < c.P.c.tax_bracket_cutoffs[b + 1])) { bin = b; break; }
+          if (income >= c.R.c.tax_bracket_cutoffs[b] && (b + 1 == c.P.NB || income < c.R.c.tax_bracket_cutoffs[b + 1])) { bin = b; break; }
       if (k) { L.met_inc1 += income > 0 ? income : 0.0; L.met_paid1 += eff; bin1 = bin; }
       else { L.met_inc0 += income > 0 ? income : 0.0; L.met_paid0 += eff; bin0 = bin; }
       if (!OSE_SKIP(c, 4)) {
@@ -348,7 +348,7 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
         buf[2 * (len + i) + 1] = R_F64(c, o_tax_last_marginal_rate)[i];
       }
       len += n;
-      const int size = c.P.c.saez_buffer_size;
+      const int size = c.R.c.saez_buffer_size;
       if (len > size) {  // drop the oldest: chunk by chunk, a chunk's loads precede its stores
         const int shift = 2 * (len - size);
         __builtin_amdgcn_s_waitcnt(0);
@@ -445,11 +445,11 @@ __device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s, c
     s.coin[i] = coin;
     double u;
     if (P.c.ose_agent_reward_type == AIE_AGENT_REW_ISOELASTIC) {
-      const double eta = P.c.isoelastic_eta;
-      const double uc = (eta == 1.0) ? aie_log_glibc(coin > 1 ? coin : 1) : (aie_pow_glibc(coin, 1 - eta) - 1) / (1 - eta);
-      u = uc - labor * P.c.ose_labor_cost;
+      const double eta = c.R.c.isoelastic_eta;
+      const double uc = c.P.sh_eta_is_one ? aie_log_glibc(coin > 1 ? coin : 1) : (aie_pow_glibc(coin, 1 - eta) - 1) / (1 - eta);
+      u = uc - labor * c.R.c.ose_labor_cost;
     } else {
-      u = coin - aie_pow_glibc(labor, P.c.ose_labor_exponent) * P.c.ose_labor_cost;
+      u = coin - aie_pow_glibc(labor, c.R.c.ose_labor_exponent) * c.R.c.ose_labor_cost;
     }
     s.part[i] = u;
   }
@@ -460,7 +460,7 @@ __device__ __forceinline__ void ose_metrics(const Ctx& c, const OseScratch& s, c
     __syncthreads();
     const double gini = ose_gini(s, s.tmp, n, c.tid);
     if (c.tid == 0) {
-      const double ew = 1 - P.c.mixing_weight_gini_vs_coin;
+      const double ew = 1 - c.R.c.mixing_weight_gini_vs_coin;
       const double prod = np_sum_small(s.coin, n) / n;
       s.part[n] = (ew * (1 - gini) + (1 - ew)) * prod;
     }
@@ -549,10 +549,10 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
   const aie_params& P = c.P;
   const int n = P.n, NB = P.NB, tid = c.tid;
   const int t = *R_I32(c, o_timestep);
-  const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)P.c.episode_length : 1.0));
+  const float tval = (float)((double)t / (P.c.allow_observation_scaling ? (double)c.R.c.episode_length : 1.0));
   // ---- shared quantities ----
   if (P.has_tax) {
-    const double per = (double)P.c.tax_period;
+    const double per = (double)c.P.c.tax_period;
     for (int i = tid; i < n; i += OSE_NT) s.tmp[i] = R_F64(c, o_tax_last_income)[i] / per;
     __syncthreads();
     rank_sort(s.tmp, s.sorted, n, tid);
@@ -562,7 +562,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
       float v;
       if (j < NB) v = (float)tax_rate_obs(c, j);
       else if (j == NB) v = pos == 1 ? 1.0f : 0.0f;               // is_first_day
-      else if (j == NB + 1) v = pos >= P.c.tax_period ? 1.0f : 0.0f;  // is_tax_day
+      else if (j == NB + 1) v = pos >= c.P.c.tax_period ? 1.0f : 0.0f;  // is_tax_day
       else if (j < NB + 2 + n) v = (float)s.sorted[j - NB - 2];   // last_incomes (sorted)
       else v = (float)((double)pos / per);                        // tax_phase
       if (j != NB + 2 + n) s.tmpl_a[P.fa_tax + j] = v;            // [NB+2+n] = marginal_rate: per agent
@@ -608,7 +608,7 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
       float* gp = reinterpret_cast<float*>(arena + c.R.a_obs_p_agents) + (int64_t)c.e * n * P.FPA;
       for (int i = tid; i < n; i += OSE_NT) {
         gp[i * 3 + 0] = (float)s.tmp[i];
-        gp[i * 3 + 1] = (float)(R_F64(c, o_tax_last_income)[i] / (double)P.c.tax_period);
+        gp[i * 3 + 1] = (float)(R_F64(c, o_tax_last_income)[i] / (double)c.P.c.tax_period);
         gp[i * 3 + 2] = (float)R_F64(c, o_tax_last_marginal_rate)[i];
       }
     }
@@ -676,7 +676,7 @@ __device__ __forceinline__ void ose_reset_body(const Ctx& c, const OseScratch& s
   OSE_MY_AGENTS(k, i, n) {
     R_F64(c, o_inv_coin)[i] = 0; R_F64(c, o_labor)[i] = 0;
     const double sk = P.has_labor ? c.R.c.labor_skills[i] : 0;
-    const float so = (float)(sk / P.c.labor_pmsm);
+    const float so = (float)(sk / c.R.c.labor_pmsm);
     if (k) { L.esc1 = 0; L.skill1 = sk; L.skobs1 = so; } else { L.esc0 = 0; L.skill0 = sk; L.skobs0 = so; }
     reinterpret_cast<double*>(grec + P.o_esc_coin)[i] = 0;
     reinterpret_cast<double*>(grec + P.o_skill)[i] = sk;
@@ -772,7 +772,7 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
   __syncthreads();
   OSE_STAMP(c, 1);
   // the observations this launch leaves behind: the step's, or -- auto-reset, episode over -- the next episode's first
-  const bool will_restart = R.auto_reset && uni(*R_I32(c, o_timestep)) + 1 >= P.c.episode_length;
+  const bool will_restart = R.auto_reset && uni(*R_I32(c, o_timestep)) + 1 >= R.c.episode_length;
   ose_store_agent_masks(c, s, arena, will_restart || (P.has_labor && uni(*R_I32(c, o_first_step)) != 0));
   if (!early_perm) m.pos = uni(*R_I32(c, o_mt_pos));
   if (tid == 0) *R_I32(c, o_timestep) += 1;
@@ -786,7 +786,7 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
   if (tid == 0) *R_I32(c, o_mt_pos) = m.pos;
   ose_store_key(c, arena, m);
   __syncthreads();
-  const bool done = uni(*R_I32(c, o_timestep)) >= P.c.episode_length;
+  const bool done = uni(*R_I32(c, o_timestep)) >= R.c.episode_length;
   // auto-reset (aie_set_auto_reset): a replica that finishes its episode in this step restarts inside this launch;
   // its terminal observations would be overwritten by the reset's before anything can read them, so they are not
   // written (rewards and `done` are the terminal step's)

@@ -191,15 +191,29 @@ typedef struct aie_params {
   int64_t a_cv_hist;     /* uint8 [E][nch][cv_row]                                         */
   int64_t a_cv_obs_a;    /* float32 [E][cv_nrow_obs][n]                                    */
   int64_t a_cv_obs_p;    /* float32 [E][4 + 1 + NS]                                        */
+  /* properties of run-time scalars that DO shape the code (they stay in the instances' images, the values do not) */
+  int32_t sh_energy_warmup; /* energy_warmup_constant > 0: the labor cost is weighted by 1 - exp(-v / constant)   */
+  int32_t sh_eta_is_one;    /* isoelastic_eta == 1: log utility instead of the power form                        */
   int32_t auto_reset;    /* run-time switch (aie_set_auto_reset): replicas restart inside the launch that ends their episode */
   int32_t dev_draw_window; /* development (tests): capacity of the components' draw window in words, 0 = stage_window_words();
                             * honoured by aie_step_kernel_log only */
 } aie_params;
 
-/* Compile-time instances of the step kernel (aie_spec_generated.h) bake a CONSTANT image of aie_params into the code;
- * what depends on the batch rather than on the configuration is read from the run-time block instead and is zeroed
- * in the image: the replica count, every arena offset, development hooks.  An environment runs on an instance iff its
- * normalised block equals the instance's image byte for byte (aie_capi.hip: aie_create). */
+/* Compile-time instances of the step kernel (aie_spec_generated.h) bake a CONSTANT image of aie_params into the code.
+ * An image stands for a FAMILY of configurations: everything that shapes the code (component tuple, agent count,
+ * world size, observation window, book capacity, bracket / rate counts, every flag, every record offset and table
+ * derived from those) is in it; what does not is read from the run-time block (Ctx::R) and is blanked in the image:
+ *   - what depends on the batch: the replica count, every arena offset, the dense-log event buffer, development hooks;
+ *   - the configuration's SCALARS and value tables: episode_length, starting_agent_coin, isoelastic_eta, energy_cost,
+ *     energy_warmup_constant, mixing weight, every labor cost, Build payment / multiplier, order_duration, tax period
+ *     (gather-trade-build), bracket cutoffs, the discretised / fixed rates, rate_min / rate_max, the annealing schedule,
+ *     regeneration weights (and regen_p derived from them), fixed-four locations and skills, split-layout ranks,
+ *     starting coverages / clumpiness of generated layouts, SimpleLabor's skills and multiplier, labor exponent / cost.
+ * The blanked scalars are POISONED (0x5A bytes), not zeroed: a kernel line that still read one of them from the
+ * image would compute with 1 515 870 810 / 2.6e130 and fail every parity test, instead of passing by accident where
+ * the configuration's value happens to be 0.
+ * An environment runs on an instance iff its normalised block equals the instance's image byte for byte
+ * (aie_capi.hip: aie_create): same family, any scalars, any replica count, any seed. */
 static inline void aie_spec_normalize(aie_params* p) {
   p->E = 0;
   p->c.n_envs = 0;
@@ -217,7 +231,29 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->dev_trace = 0;
   p->dev_draw_window = 0;
   p->auto_reset = 0;
+  p->ev_replicas = p->ev_cap = p->ev_stride = 0;  /* dense-log replicas: the fast kernels never record events */
+  p->c.dense_log_replicas = 0;
   memset(p->c.labor_skills, 0, sizeof(p->c.labor_skills));  /* SimpleLabor's skills are data, read from the run-time block */
+#define AIE__BLANK(field) memset(&(field), 0x5A, sizeof(field))
+  {
+    aie_config* c = &p->c;
+    AIE__BLANK(c->episode_length); AIE__BLANK(c->starting_agent_coin); AIE__BLANK(c->isoelastic_eta);
+    AIE__BLANK(c->energy_cost); AIE__BLANK(c->energy_warmup_constant); AIE__BLANK(c->mixing_weight_gini_vs_coin);
+    AIE__BLANK(c->build_payment); AIE__BLANK(c->build_payment_max_skill_multiplier); AIE__BLANK(c->build_labor);
+    AIE__BLANK(c->move_labor); AIE__BLANK(c->collect_labor); AIE__BLANK(c->cda_order_labor);
+    AIE__BLANK(c->cda_order_duration);
+    /* one-step-economy keeps its tax period in the image: with period 1 two record fields are dead and are neither
+     * loaded nor stored (aie_kernels_ose.hip: ose_load_record) -- there the period shapes the code */
+    if (c->scenario != AIE_SCN_ONE_STEP_ECONOMY) AIE__BLANK(c->tax_period);
+    AIE__BLANK(c->tax_bracket_cutoffs); AIE__BLANK(c->tax_disc_rates); AIE__BLANK(c->tax_fixed_rates);
+    AIE__BLANK(c->tax_rate_max); AIE__BLANK(c->tax_rate_min); AIE__BLANK(c->tax_annealing_warmup);
+    AIE__BLANK(c->tax_annealing_slope); AIE__BLANK(c->regen_weight); AIE__BLANK(c->ranked_locs);
+    AIE__BLANK(c->avg_ranked_skill); AIE__BLANK(c->split_top_ranks); AIE__BLANK(c->layout_coverage);
+    AIE__BLANK(c->layout_clump); AIE__BLANK(c->ose_labor_exponent); AIE__BLANK(c->ose_labor_cost);
+    AIE__BLANK(c->labor_pmsm); AIE__BLANK(c->saez_buffer_size); AIE__BLANK(c->saez_fixed_elas);
+    AIE__BLANK(p->regen_p); AIE__BLANK(p->saez_edges);
+  }
+#undef AIE__BLANK
 }
 
 typedef struct aie_tensor_table {
@@ -786,6 +822,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     AIE__FAIL("mixing_weight_gini_vs_coin not in [0,1]");
 
   p->c = *c;
+  p->sh_energy_warmup = c->energy_warmup_constant > 0.0 ? 1 : 0;
+  p->sh_eta_is_one = c->isoelastic_eta == 1.0 ? 1 : 0;
   p->E = c->n_envs;
   p->n = c->n_agents;
   p->H = c->world_h;

@@ -164,6 +164,11 @@ class DeviceBackend:
         aie_set_auto_reset): `done` and the rewards are the terminal step's, state and observations the new episode's."""
         self._check(self.lib.aie_set_auto_reset(self.handle, 1 if on else 0))
 
+    def set_dense_log_active(self, on=True):
+        """Dense-log replicas record event rows (and run the full-featured kernel) only while an episode is being
+        logged (include/aie.h: aie_set_dense_log_active); otherwise they step with the rest of the batch."""
+        self._check(self.lib.aie_set_dense_log_active(self.handle, 1 if on else 0))
+
     def step_sample_next(self, actions_a, actions_p, seed, env_offset=0, next_slot=1):
         """One launch: step with (actions_a, actions_p) and fill the action buffers of `next_slot`
         with the uniform random policy's next draw (same values as sample_random_actions)."""

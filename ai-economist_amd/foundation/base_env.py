@@ -367,6 +367,9 @@ class BaseEnvironment:
             # completed episodes of the logged replica, before this reset (base_env.py:885-891)
             done_eps = int(self.backend.tensors["completions"][0].item()) if self._backend is not None else 0
             self._dense_log_this_episode = bool(force_dense_logging) or done_eps % self._create_dense_log_every == 0
+            # the logged replica records event rows (full-featured kernel) only in the episodes that are logged; in the
+            # others it steps with the rest of the batch on the fast kernel (include/aie.h: aie_set_dense_log_active)
+            self.backend.set_dense_log_active(self._dense_log_this_episode)
         if log_replica_resets:
             self._replay_log = {"reset": dict(seed_state=self.rng_state(0) if self._dense_log_this_episode else None),
                                 "step": []}

@@ -45,7 +45,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define AIE_ABI_VERSION 8
+#define AIE_ABI_VERSION 9
 
 #define AIE_MAX_AGENTS 64      /* mobile agents per replica, spatial scenarios (one lane each) */
 #define AIE_MAX_AGENTS_WIDE 128 /* mobile agents per replica, map-less one-step-economy        */
@@ -402,6 +402,13 @@ int aie_set_auto_reset(aie_env* env, int on);
  * uses global + its own samples added since the buffers were last reset (`saez_additions` tensor), as the
  * reference's `saez_buffer` property does. */
 int aie_set_global_saez_buffer(aie_env* env, const double* d_pairs, int64_t n_pairs);
+
+/* Dense logs (aie_config.dense_log_replicas > 0; reference: F/base/base_env.py:273-283, 883-891 -- only every
+ * `dense_log_frequency`-th episode is logged): with on == 0 the dense-log replicas stop recording AIE_EV_* rows and
+ * step with the rest of the batch on the environment's fast kernel; with on != 0 (the default) they -- and only they
+ * -- take the full-featured kernel.  State and observations are bit-identical either way; the host mirror switches
+ * it per episode (foundation/base_env.py: reset). */
+int aie_set_dense_log_active(aie_env* env, int on);
 
 /* sizeof(aie_config) as this library was built: a binding checks its mirror of the struct against it. */
 int aie_sizeof_config(void);

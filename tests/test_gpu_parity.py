@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (F64_FIELDS, INT_FIELDS, compare_state, dev_library, golden_names, load_golden, make_env,
+from helpers import (F64_FIELDS, FAMILY_CASES, INT_FIELDS, compare_state, dev_library, golden_names, load_golden, make_env,
                      state_from_golden)
 
 pytestmark = pytest.mark.gpu
@@ -870,22 +870,25 @@ C1_INSTANCE = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=4, wo
                    starting_wood_coverage=0.10)
 
 
-@pytest.mark.parametrize("n_agents", [4, 10, "c1"])
-def test_compile_time_instance_equals_generic_kernel(n_agents):
-    """BASELINE configs[1] / [2] run on a compile-time instance of the step kernel (aie_spec_generated.h: the parameter
-    block folded into the code); the generic kernel on the same replicas must produce the same arena, bit for bit."""
+@pytest.mark.parametrize("case", sorted(FAMILY_CASES))
+def test_compile_time_instance_equals_generic_kernel(case):
+    """BASELINE configs[0] / [1] / [2] AND every configuration that differs from them in scalars only run on a
+    compile-time instance of the step and reset kernels (aie_spec_generated.h: the code-shaping part of the parameter
+    block folded into the code, the scalars read from the run-time block) without any call by the user; the generic
+    kernel on the same replicas must produce the same arena, bit for bit, across episode ends and masked resets."""
     import ctypes
 
     import torch
 
-    base = dict(C1_INSTANCE) if n_agents == "c1" else dict(C2, n_agents=n_agents)
-    cfg = dict(base, episode_length=150)
-    cfg_spec = dict(base)
+    cfg, in_family = FAMILY_CASES[case]
     with dev_library():  # aie_dev_lds_bytes below is a development hook
-        env_s = make_env(cfg_spec, n_envs=8, device="cuda:0")
+        env_s = make_env(cfg, n_envs=8, device="cuda:0")
         env_s.backend
     k_inst = env_s.backend.lib.aie_step_kernel_instance(env_s.backend.handle)
-    assert k_inst >= 0, "no compile-time instance selected"
+    if not in_family:
+        assert k_inst == -1, "%s must not match an instance's family" % case
+        return
+    assert k_inst >= 0, "no compile-time instance selected for %s" % case
     # the occupancy the instance is compiled for (_specs.py) is what its LDS footprint lets a CU hold
     from ai_economist_amd import _specs
 
@@ -893,24 +896,19 @@ def test_compile_time_instance_equals_generic_kernel(n_agents):
     env_s.backend.lib.aie_dev_lds_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     assert env_s.backend.lib.aie_dev_lds_bytes(env_s.backend.handle, lds) == 0
     assert -(-2 * lds[5] // 4) == _specs.SPECS[k_inst][4], "instance %d: %d B of LDS -> %d workgroups per CU" % (k_inst, lds[0], lds[5])
-    envs = [make_env(cfg, n_envs=512, device="cuda:0") for _ in range(2)]
-    for env in envs:
-        env.seed(21)
-        env.reset()
-    b_gen, b_other = envs[0].backend, envs[1].backend
-    # episode_length 150 is not an instance's configuration: both run the generic kernel ...
-    assert b_gen.lib.aie_step_kernel_instance(b_gen.handle) == -1
-    # ... so compare instance vs generic on the instance's own configuration instead
-    pair = [make_env(cfg_spec, n_envs=512, device="cuda:0") for _ in range(2)]
+    pair = [make_env(cfg, n_envs=512, device="cuda:0") for _ in range(2)]
+    b_spec, b_ref = pair[0].backend, pair[1].backend
+    assert b_ref.lib.aie_select_step_kernel(b_ref.handle, 1) == 0  # AIE_KERNEL_GENERIC (step and reset)
+    assert b_spec.lib.aie_step_kernel_instance(b_spec.handle) >= 0 and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == -1
     for env in pair:
         env.seed(21)
         env.reset()
-    b_spec, b_ref = pair[0].backend, pair[1].backend
-    assert b_ref.lib.aie_select_step_kernel(b_ref.handle, 1) == 0  # AIE_KERNEL_GENERIC
-    assert b_spec.lib.aie_step_kernel_instance(b_spec.handle) >= 0 and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == -1
+    T = int(cfg["episode_length"])
     cur_s = b_spec.sample_random_actions(seed=4, slot=0)
     slot = 0
-    for t in range(230):
+    steps = 230 if T > 200 else 2 * T + 25
+    checks = {0, 57, 101, steps - 1, T - 1, T, 2 * T - 1}
+    for t in range(steps):
         a, p = b_ref.sample_random_actions(seed=4)
         b_ref.step(a, p)
         if t % 3 == 0:  # both entry points of the instance
@@ -919,11 +917,82 @@ def test_compile_time_instance_equals_generic_kernel(n_agents):
         else:
             b_spec.step(cur_s[0], cur_s[1])
             cur_s = b_spec.sample_random_actions(seed=4, slot=slot)
-        if t in (0, 57, 101, 229):
+        if t in checks:
             torch.cuda.synchronize()
             for k in b_ref.tensors:
-                assert torch.equal(b_ref.tensors[k], b_spec.tensors[k]), "step %d: %s differs" % (t + 1, k)
-    del b_gen, b_other
+                assert torch.equal(b_ref.tensors[k], b_spec.tensors[k]), "%s step %d: %s differs" % (case, t + 1, k)
+        if (t + 1) % T == 0:  # episode end: the instance's reset kernel against the generic one
+            for b in (b_ref, b_spec):
+                b.reset(b.tensors["done"])
+        elif t % 40 == 39:  # and a masked reset mid-episode
+            mask = (torch.arange(512, device="cuda") % 5 == (t // 40) % 5).to(torch.uint8)
+            for b in (b_ref, b_spec):
+                b.reset(mask)
+
+
+def test_dense_log_switch_keeps_state_identical():
+    """aie_set_dense_log_active: while no episode is being logged the dense-log replica steps with the rest of the batch
+    on the fast kernel; state, observations and rewards are the same as with the switch on -- only the event rows stop."""
+    import torch
+
+    cfg, _ = FAMILY_CASES["phase2_yaml"]
+    cfg = dict(cfg, episode_length=50)
+    on, off = [make_env(cfg, n_envs=96, device="cuda:0") for _ in range(2)]
+    for env in (on, off):
+        env.seed(3)
+        env.backend.reset(None)
+    off.backend.set_dense_log_active(False)
+    assert "log_events" in on.backend.tensors and on.backend.lib.aie_step_kernel_instance(on.backend.handle) >= 0
+    for t in range(120):
+        a, p = on.backend.sample_random_actions(seed=2)
+        for env in (on, off):
+            env.backend.step(a, p)
+        if (t + 1) % 50 == 0:
+            for env in (on, off):
+                env.backend.reset(env.backend.tensors["done"])
+        if t in (0, 1, 49, 50, 119):
+            torch.cuda.synchronize()
+            for k in on.backend.tensors:
+                if not k.startswith("log_event"):
+                    assert torch.equal(on.backend.tensors[k], off.backend.tensors[k]), "step %d: %s differs" % (t + 1, k)
+    assert int(on.backend.tensors["log_event_count"].sum()) >= 0
+    # back on: the very next step records rows again, identical to an environment that never switched
+    off.backend.set_dense_log_active(True)
+    a, p = on.backend.sample_random_actions(seed=2)
+    for env in (on, off):
+        env.backend.step(a, p)
+    torch.cuda.synchronize()
+    for k in on.backend.tensors:
+        assert torch.equal(on.backend.tensors[k], off.backend.tensors[k]), "after switching back on: %s differs" % k
+
+
+def test_instance_family_member_matches_oracle():
+    """One member of C2's family that is not BASELINE's configuration, on the instance, against the CPU oracle (the
+    other family tests compare with the generic kernel, which the variant tests compare with the oracle)."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    cfg, _ = FAMILY_CASES["c2_every_scalar"]
+    E = 48
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(5)
+    env.reset()
+    be = env.backend
+    assert be.lib.aie_step_kernel_instance(be.handle) >= 0
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(5)
+    oracle.reset()
+    for t in range(150):
+        a, p = be.sample_random_actions(seed=12)
+        be.step(a, p)
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy())
+        if (t + 1) % 70 == 0:
+            be.reset(be.tensors["done"])
+            torch.cuda.synchronize()
+            oracle.reset(np.ones(E, dtype=np.uint8))
+        if t in (0, 19, 20, 69, 70, 149):
+            _compare_all(be, oracle, "family member step %d" % (t + 1))
 
 
 JIT_CASES = {
