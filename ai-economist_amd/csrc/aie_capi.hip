@@ -28,6 +28,8 @@ struct aie_env {
   int64_t sample_t;
   float* rew_log;        // aie_set_reward_log: caller's ring of n_slots step slots, or nullptr
   int32_t rew_log_slots, rew_log_next;
+  int cv_taps_f32;       // COVID: every uploaded filter tap is a float32 value (aie_upload checks): the window-sum kernel
+                         // then keeps its LDS tap table in float32
   int log_active;        // aie_set_dense_log_active: the dense-log replicas record events (default) or run with the rest
   char err[512];
 };
@@ -95,6 +97,7 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
   env->device = device;
   env->spec = -1;
   env->log_active = 1;
+  env->cv_taps_f32 = 1;  // (the arena starts zeroed)
   if (cfg->scenario != AIE_SCN_COVID) {  // a compile-time instance exists for exactly this parameter block?
     std::vector<aie_params> norm(1, env->P);  // (heap: the block is ~10 KB; not static: aie_create may run on several threads)
     aie_spec_normalize(&norm[0]);
@@ -248,6 +251,13 @@ static int copy_tensor(aie_env* env, const char* name, void* host, int64_t bytes
 
 int aie_upload(aie_env* env, const char* name, const void* host, int64_t bytes) {
   const int rc = copy_tensor(env, name, const_cast<void*>(host), bytes, true);
+  if (rc == AIE_OK && env->P.c.scenario == AIE_SCN_COVID && strcmp(name, "model_unemp_conv_filters") == 0) {
+    // float32-valued taps (the reference's) let the window-sum kernel keep its LDS tap table in float32
+    const double* taps = static_cast<const double*>(host);
+    env->cv_taps_f32 = 1;
+    for (int64_t q = 0; q < bytes / 8; ++q)
+      if ((double)(float)taps[q] != taps[q]) env->cv_taps_f32 = 0;
+  }
   if (rc == AIE_OK && env->P.c.scenario == AIE_SCN_COVID && strcmp(name, "model_stringency_level_history_0") == 0) {
     // what every reset derives from this table is derived once, here (history-format image, filter sums at t = 0)
     hipLaunchKernelGGL(aie_covid_prepare_kernel, dim3(1), dim3(AIE_NT), 0, 0, env->d_params, env->arena);
@@ -385,6 +395,23 @@ int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t
   return aie_step_impl(env, d_actions_a, d_actions_p, stream, next);
 }
 
+int aie_step_sample_next_masked(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, uint64_t seed,
+                                int64_t global_env_offset, int32_t* d_next_a, int32_t* d_next_p, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  if (env->P.c.scenario != AIE_SCN_COVID) {
+    snprintf(env->err, sizeof(env->err), "aie_step_sample_next_masked: COVID scenario only (elsewhere: aie_step + aie_sample_masked_actions)");
+    return AIE_E_UNSUPPORTED;
+  }
+  if ((d_next_a && d_next_a == d_actions_a) || (d_next_p && d_next_p == d_actions_p)) {
+    snprintf(env->err, sizeof(env->err), "aie_step_sample_next_masked: the next-action buffers must differ from the current ones");
+    return AIE_E_INVALID;
+  }
+  NextActions next{d_next_a, d_next_p, seed, global_env_offset, env->sample_t, nullptr};
+  next.masked = 1;
+  env->sample_t += 1;
+  return aie_step_impl(env, d_actions_a, d_actions_p, stream, next);
+}
+
 static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream,
                          const NextActions& next_in) {
   if (!env) return AIE_E_INVALID;
@@ -412,9 +439,12 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   if (env->P.c.scenario == AIE_SCN_COVID) {
     const dim3 g((unsigned)env->P.E), b(AIE_NT);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 gw((unsigned)((env->P.E + AIE_CV_WIN_WAVES - 1) / AIE_CV_WIN_WAVES)), bw(AIE_CV_WIN_WAVES * AIE_NT);
+    const size_t lw = aie_covid_win_lds_bytes(env->P, env->cv_taps_f32 ? 4 : 8);
 #define AIE_CV_LAUNCH(FN) \
   case FN: if (env->P.c.covid.filter_recurrence) hipLaunchKernelGGL((aie_covid_step_kernel<FN, true>), g, b, 0, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); \
-           else hipLaunchKernelGGL((aie_covid_step_kernel<FN, false>), g, b, 0, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); \
+           else if (env->cv_taps_f32) hipLaunchKernelGGL((aie_covid_step_kernel<FN, false, float>), gw, bw, lw, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); \
+           else hipLaunchKernelGGL((aie_covid_step_kernel<FN, false, double>), gw, bw, lw, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); \
            break
     switch (env->P.cv_F) {
       AIE_CV_LAUNCH(1); AIE_CV_LAUNCH(2); AIE_CV_LAUNCH(3); AIE_CV_LAUNCH(4);

@@ -2448,6 +2448,7 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
   // whose current episode is being logged steps those replicas with aie_step_kernel_log and the rest with its fast
   // kernel (aie_capi.hip: aie_step_impl)
   int32_t e_lo, e_hi;
+  int32_t masked;  // aie_step_sample_next_masked (COVID): the next actions are drawn among what the new masks allow
 };
 // SPEC >= 0: a compile-time instance (aie_spec_generated.h): P is a constant image of the parameter block of one
 // configuration -- every dimension, record offset, component list, mask table and magic divisor folds into the

@@ -54,6 +54,13 @@ __device__ __forceinline__ float np_sum_f32_lds(const float* a, int n) {
 
 typedef const double __attribute__((address_space(4))) * cv_tap_ptr;
 
+__device__ __forceinline__ int wave_max_i32(int v) {  // wave-uniform maximum over the 64 lanes
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_min_i32(int v) { return -wave_max_i32(-v); }
+
 struct CvLane {
   float S, I, R, D, V, U, prod, subsidy;
   int level;     // stringency level in force at the current timestep
@@ -165,6 +172,28 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
       *reinterpret_cast<uint4*>(img + (int64_t)c * P.cv_row + s * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
   }
+  if (P.cv_ev_groups) {
+    // the pre-episode days' level changes as every state's initial event list (what reset copies); a list that does not
+    // fit makes every replica start "dense" (the window sums then stream the history as they always did)
+    uint32_t* ev0 = reinterpret_cast<uint32_t*>(arena + P.a_cv_ev0);
+    int32_t* ht0 = reinterpret_cast<int32_t*>(arena + P.a_cv_ev0 + (int64_t)P.cv_ev_groups * 1024);
+    const int cap = 4 * P.cv_ev_groups;
+    int cnt = 0;
+    bool over = false;
+    int prev = h0[sl];
+    for (int tau = 1; tau <= L; ++tau) {
+      const int lev = h0[tau * n + sl];
+      if (lev != prev) {
+        if (cnt < cap) ev0[((cnt >> 2) * 64 + s) * 4 + (cnt & 3)] = (uint32_t)tau | ((uint32_t)((lev - prev) & 0xff) << 16);
+        else over = true;
+        cnt += cnt < cap ? 1 : 0;
+      }
+      prev = lev;
+    }
+    ht0[s] = on ? (cnt << 16) : 0;
+    const bool any_over = __ballot(on && over) != 0ull;
+    if (s == 0) ht0[64] = any_over ? 1 : 0;
+  }
   if (P.c.covid.filter_recurrence) {
     double* acc0 = reinterpret_cast<double*>(arena + P.a_cv_acc0);
     for (int f = 0; f < P.cv_F; ++f) {
@@ -208,6 +237,18 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
   const int sl = on ? s : n - 1;
   for (int tau = L - 31; tau <= L; ++tau)  // the ring: the 32 days up to day 0 (days before the table begins: level 1)
     *cv_ring_at(P, rec, s, tau) = on ? (tau >= 0 ? h0[tau * n + s] : (uint8_t)1) : (uint8_t)0;
+  if (P.cv_ev_groups) {  // the pre-episode level changes (aie_covid_prepare_kernel): every state's list, head/tail, dense flag
+    const uint4* ev0 = reinterpret_cast<const uint4*>(arena + P.a_cv_ev0);
+    const int32_t* ht0 = reinterpret_cast<const int32_t*>(arena + P.a_cv_ev0 + (int64_t)P.cv_ev_groups * 1024);
+    uint4* evb = reinterpret_cast<uint4*>(arena + P.a_cv_events + (int64_t)e * P.cv_ev_groups * 1024);
+    const int ht = ht0[s];
+    const int groups = wave_max_i32(((ht >> 16) + 3) >> 2);
+    for (int g = 0; g < groups; ++g) evb[g * 64 + s] = ev0[g * 64 + s];
+    if (on) reinterpret_cast<int32_t*>(rec + P.o_cv_ev_ht)[s] = ht;
+    if (s == 0) *reinterpret_cast<int32_t*>(rec + P.o_cv_dense) = ht0[64];
+  } else if (s == 0) {
+    *reinterpret_cast<int32_t*>(rec + P.o_cv_dense) = 0;
+  }
   if (P.c.covid.filter_recurrence) {  // A_0 of every filter (aie_covid_prepare_kernel)
     double* accs = reinterpret_cast<double*>(rec + P.o_cv_acc);
     const double* acc0 = reinterpret_cast<const double*>(arena + P.a_cv_acc0);
@@ -256,17 +297,21 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
 }
 
 // ---- one env.step() (base_env.py:929-1032) ----
-template <int F, bool RECUR>
-__global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
-    aie_covid_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
-                          const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+// `red`: this replica's three reduction rows in LDS; `taps` (window sums only): the workgroup's LDS copy of the filter
+// taps, row 0 zero, row 1 + l = tap l ([filter_len + 1][F] doubles).
+// TapT: double, or float when every uploaded tap is a float32 value (the reference's are: covid19_env.py:242-247 builds
+// them in float32) -- the same numbers in half the LDS bytes and with odd-dword rows, i.e. per-lane reads of different
+// rows that spread over all 64 banks instead of colliding on 32 bank pairs.
+template <int F, bool RECUR, typename TapT>
+__device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                                             const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
+                                             const NextActions& next, const int e, const int s, float (*red)[64],
+                                             const TapT* taps) {
   float* __restrict__ rew_log = next.rew_log;  // this step's slot of aie_set_reward_log, or nullptr
   using namespace aie;
-  __shared__ float red[3][64];
   const aie_params& P = *params;
   const aie_covid_config& V = P.c.covid;
-  const int e = replica_of_block((int)blockIdx.x, P.E);
-  const int s = (int)threadIdx.x, n = P.n, L = P.cv_L, NL = P.cv_NL, NS = P.cv_NS, PT = P.cv_pitch;
+  const int n = P.n, L = P.cv_L, NL = P.cv_NL, NS = P.cv_NS, PT = P.cv_pitch;
   const bool on = s < n;
   const int sl = on ? s : n - 1;  // idle lanes shadow the last state (loads stay in bounds)
   uint8_t* rec = arena + P.a_records + (int64_t)e * P.rec_bytes;
@@ -282,14 +327,28 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   // resident at once, so a launch lasts as long as that chain.  What does not depend on the timestep travels beside
   // it; the read-modify-write accumulators (episode sums, index sums) are read now and only written at the end.
   double* sums = reinterpret_cast<double*>(rec + P.o_cv_sums);
-  const double sum_u0 = sums[AIE_CV_SUM_UNEMPLOYED * PT + sl], sum_s0 = sums[AIE_CV_SUM_STRINGENCY * PT + sl];
-  const double sum_p0 = sums[AIE_CV_SUM_PRODUCTIVITY * PT + sl], sum_b0 = sums[AIE_CV_SUM_SUBSIDY * PT + sl];
-  const float hidx0 = st[AIE_CV_ST_HEALTH_INDEX * PT + sl], eidx0 = st[AIE_CV_ST_ECONOMIC_INDEX * PT + sl];
   float* pidx = reinterpret_cast<float*>(rec + P.o_cv_p_index);  // planner.state[...] += ... :1160-1161
-  const float pidx0 = pidx[0], pidx1 = pidx[1];
-  const float S1 = st[AIE_CV_ST_S * PT + sl], I1 = st[AIE_CV_ST_I * PT + sl], R1 = st[AIE_CV_ST_R * PT + sl];
-  const float V1 = st[AIE_CV_ST_V * PT + sl], D1 = st[AIE_CV_ST_D * PT + sl];
-  const int cool0 = cool[sl];
+  double sum_u0, sum_s0, sum_p0, sum_b0;
+  float hidx0, eidx0, pidx0, pidx1, S1, I1, R1, V1, D1;
+  int cool0;
+#define CV_LOAD_STATE()                                                                                      \
+  do {                                                                                                       \
+    sum_u0 = sums[AIE_CV_SUM_UNEMPLOYED * PT + sl]; sum_s0 = sums[AIE_CV_SUM_STRINGENCY * PT + sl];           \
+    sum_p0 = sums[AIE_CV_SUM_PRODUCTIVITY * PT + sl]; sum_b0 = sums[AIE_CV_SUM_SUBSIDY * PT + sl];            \
+    hidx0 = st[AIE_CV_ST_HEALTH_INDEX * PT + sl]; eidx0 = st[AIE_CV_ST_ECONOMIC_INDEX * PT + sl];             \
+    pidx0 = pidx[0]; pidx1 = pidx[1];                                                                        \
+    S1 = st[AIE_CV_ST_S * PT + sl]; I1 = st[AIE_CV_ST_I * PT + sl]; R1 = st[AIE_CV_ST_R * PT + sl];            \
+    V1 = st[AIE_CV_ST_V * PT + sl]; D1 = st[AIE_CV_ST_D * PT + sl];                                           \
+    cool0 = cool[sl];                                                                                        \
+  } while (0)
+  // recurrence: every load of the replica's record goes out here.  Window sums: the sums over the change events come
+  // FIRST, with nothing else live in registers (the streamed fallback needs them all), the record follows behind them
+  if constexpr (RECUR) CV_LOAD_STATE();
+  int dense = 0, ev_ht = 0;  // window sums: does the replica stream its whole window; this state's event list head | tail << 16
+  if constexpr (!RECUR) {
+    dense = uni(*reinterpret_cast<const int32_t*>(rec + P.o_cv_dense));
+    ev_ht = reinterpret_cast<const int32_t*>(rec + P.o_cv_ev_ht)[sl];
+  }
   // the lagged stringency level of the new observation (:957-970), fetched with the other history bytes: a load issued
   // behind today's stores would wait for them (memory operations of a wave complete in order)
   const int tb = t - V.beta_delay + 1;
@@ -301,11 +360,140 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   // ---- ControlUSStateOpenCloseStatus.component_step :180-221 ----
   int act = act_a ? act_a[(int64_t)e * n + sl] : 0;
   if (V.replay_policies) act = (arena + P.a_cv_replay_a)[(int64_t)(t - 1) * 64 + sl];  // :181-186: yesterday's recorded level
-  if (act < 0 || act > NL) act = 0;
   const int prev_level = CV_SKIP(P, 2) ? 1 : *cv_ring_at(P, rec, sl, L + t - 1);
+  if (act < 0 || act > NL) act = 0;
   CvLane a;
   a.level = act == 0 ? prev_level : act;
   if (lag_level < 0) lag_level = a.level;
+  double acc[F];  // every filter's sum over the window (window sums: formed right here; recurrence: further down)
+  bool flush_now = false;
+  uint32_t flushw[4] = {0u, 0u, 0u, 0u};
+  if constexpr (!RECUR) {
+    double acc_ev[F];  // window sums: every filter's sum over the window's change events before today
+    int ev_expired = 0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc_ev[f] = 0.0;
+    {
+      if (!dense) {
+        // the sum over the non-zero deltas of the window, in the order the reference adds the days; it needs nothing but
+        // the timestep and the list, so its loads travel beside the record's
+        const uint32_t* evb = reinterpret_cast<const uint32_t*>(arena + P.a_cv_events + (int64_t)e * P.cv_ev_groups * 1024);
+        const int head = ev_ht & 0xffff, tail = ev_ht >> 16;
+        const int g_lo = wave_min_i32(on ? head >> 2 : 0x7fff), g_hi = wave_max_i32(on ? (tail + 3) >> 2 : 0);
+        const uint4* evq = reinterpret_cast<const uint4*>(evb) + s;
+        // a replica's step is one dependent chain: the groups are fetched CV_BURST at a time, one memory round trip
+        // for the 32 events that cover a cool-down of two weeks or more over the whole window
+        constexpr int CV_BURST = 8;
+        for (int g0 = g_lo; g0 < g_hi; g0 += CV_BURST) {
+          uint4 qb[CV_BURST];
+#pragma unroll
+          for (int k = 0; k < CV_BURST; ++k)
+            qb[k] = (on && 4 * (g0 + k) < tail) ? evq[(g0 + k) * 64] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+          for (int k = 0; k < CV_BURST; ++k) {
+            if (g0 + k >= g_hi) break;  // (wave-uniform)
+            const uint32_t w4[4] = {qb[k].x, qb[k].y, qb[k].z, qb[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int idx = 4 * (g0 + k) + j, tau = (int)(w4[j] & 0xffffu);
+              const bool live = on && idx >= head && idx < tail;
+              if (live && tau <= t) ev_expired += 1;  // left the window (at most one per step: the days are distinct)
+              if (live && tau > t) {
+                const double d = (double)((int)(w4[j] << 8) >> 24);
+                const TapT* tp = taps + (tau - t) * F;  // tap l = tau - t - 1 lives in row l + 1
+#pragma unroll
+                for (int f = 0; f < F; ++f) acc_ev[f] = __builtin_fma(d, (double)tp[f], acc_ev[f]);
+              }
+            }
+          }
+        }
+      }
+    }
+    // (1) the change events: acc_ev = the sum over the window's earlier non-zero deltas; today's change is the window's last day
+    const int d_new_i = a.level - prev_level;
+    if (!dense) {
+      int32_t* htrow = reinterpret_cast<int32_t*>(rec + P.o_cv_ev_ht);
+      uint32_t* evb = reinterpret_cast<uint32_t*>(arena + P.a_cv_events + (int64_t)e * P.cv_ev_groups * 1024);
+      const int head = ev_ht & 0xffff, tail = ev_ht >> 16, cap = 4 * P.cv_ev_groups;
+      const bool grow = on && d_new_i != 0;
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[f] = acc_ev[f];
+      if (__ballot(grow && tail >= cap) != 0ull) {
+        // a state's list is full: from this step to the next reset the replica streams its whole window
+        dense = 1;
+        flush_now = true;
+        if (s == 0) *reinterpret_cast<int32_t*>(rec + P.o_cv_dense) = 1;
+      } else {
+        if (grow) evb[((tail >> 2) * 64 + s) * 4 + (tail & 3)] = (uint32_t)(L + t) | ((uint32_t)(d_new_i & 0xff) << 16);
+        if (on) htrow[s] = (head + ev_expired) | ((tail + (grow ? 1 : 0)) << 16);
+        // today's change (history day L + t, tap L - 1) is the window's last day
+        if (on) {
+          const double d = (double)d_new_i;
+          const TapT* tp = taps + L * F;
+#pragma unroll
+          for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, (double)tp[f], acc[f]);
+        }
+      }
+    }
+    if (flush_now) {  // the current chunk's days so far, from the ring (the dense sums below and every later step read them)
+#pragma unroll
+      for (int j = 0; j < 15; ++j)
+        if (j < ((L + t) & 15)) flushw[j >> 2] |= (uint32_t)*cv_ring_at(P, rec, sl, ((L + t) & ~15) + j) << (8 * (j & 3));
+    }
+    if (dense) {  // (2) the whole window, day by day
+    const double* __restrict__ G = reinterpret_cast<const double*>(arena + P.a_cv_filters);  // [row][F]
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.0;
+    const int c0 = t >> 4;
+    const int c_today = (t + L) >> 4, sh_today = 8 * ((t + L) & 3), q_today = ((t + L) & 15) >> 2;
+    const int ngroups = ((L >> 4) + 2 + AIE_CV_GROUP - 1) / AIE_CV_GROUP;
+    const uint8_t* row = hist + sl * 16 + (int64_t)c0 * P.cv_row;
+    int carry = 0;
+    uint4 cur[AIE_CV_GROUP], nxt[AIE_CV_GROUP];
+#pragma unroll
+    for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = *reinterpret_cast<const uint4*>(row + (int64_t)k * P.cv_row);
+    for (int g = 0; g < ngroups; ++g) {
+      if (g + 1 < ngroups) {
+#pragma unroll
+        for (int k = 0; k < AIE_CV_GROUP; ++k)
+          nxt[k] = *reinterpret_cast<const uint4*>(row + (int64_t)((g + 1) * AIE_CV_GROUP + k) * P.cv_row);
+      }
+#pragma unroll
+      for (int k = 0; k < AIE_CV_GROUP; ++k) {
+        const int c = c0 + g * AIE_CV_GROUP + k;
+        uint32_t ww[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+        if (c == c_today) {  // today's level is still in registers: patch it into the stream
+          if (flush_now) {   // ... and so are the chunk's earlier days in the step that turns the replica dense
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ww[q] = flushw[q];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q == q_today) ww[q] = (ww[q] & ~(0xffu << sh_today)) | ((uint32_t)a.level << sh_today);
+        }
+        // wave-uniform pointer into the read-only tap table -> s_load through the scalar cache
+        cv_tap_ptr g0 = (cv_tap_ptr)(uintptr_t)(G + (int64_t)(16 * c - t - 1 + AIE_CV_TAP_PAD_FRONT) * F);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int lev = (int)((ww[j >> 2] >> (8 * (j & 3))) & 0xffu);
+          const double d = (double)(lev - carry);
+          carry = lev;
+#pragma unroll
+          for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, g0[j * F + f], acc[f]);
+          // 16*F doubles of taps per chunk do not fit the SGPR file: tie the pointer to the
+          // accumulator every 4 days so that only 4*F taps are fetched ahead of their use
+          if ((j & 3) == 3) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) asm volatile("" : "+s"(g0), "+v"(acc[f]));
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = nxt[k];
+    }
+    }
+  }
+  if constexpr (!RECUR) CV_LOAD_STATE();
   a.cooldown = cool0;
   if (t == a.cooldown + 1) a.cooldown += act == 0 ? 1 : V.action_cooldown_period;
 
@@ -372,7 +560,6 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   // lane in flight (HBM latency >> the ~300 cycles of FMA work in one chunk).
   double unemployed;
   {
-    double acc[F];
     if constexpr (RECUR) {
       // The taps are exp(-age / lambda_f): each filter's discounted delta sum over the window obeys
       //   A_t = r_f * (A_{t-1} - r_f^(L-1) * d_old) + d_new,
@@ -399,54 +586,7 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
         acc[f] = r * (accs[f * PT + sl] - V.filter_tail[f] * d_old) + d_new;
         if (on) accs[f * PT + s] = acc[f];
       }
-    } else {
-    const double* __restrict__ G = reinterpret_cast<const double*>(arena + P.a_cv_filters);  // [row][F]
-#pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = 0.0;
-    const int c0 = t >> 4;
-    const int c_today = (t + L) >> 4, sh_today = 8 * ((t + L) & 3), q_today = ((t + L) & 15) >> 2;
-    const int ngroups = ((L >> 4) + 2 + AIE_CV_GROUP - 1) / AIE_CV_GROUP;
-    const uint8_t* row = hist + sl * 16 + (int64_t)c0 * P.cv_row;
-    int carry = 0;
-    uint4 cur[AIE_CV_GROUP], nxt[AIE_CV_GROUP];
-#pragma unroll
-    for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = *reinterpret_cast<const uint4*>(row + (int64_t)k * P.cv_row);
-    for (int g = 0; g < ngroups; ++g) {
-      if (g + 1 < ngroups) {
-#pragma unroll
-        for (int k = 0; k < AIE_CV_GROUP; ++k)
-          nxt[k] = *reinterpret_cast<const uint4*>(row + (int64_t)((g + 1) * AIE_CV_GROUP + k) * P.cv_row);
-      }
-#pragma unroll
-      for (int k = 0; k < AIE_CV_GROUP; ++k) {
-        const int c = c0 + g * AIE_CV_GROUP + k;
-        uint32_t ww[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
-        if (c == c_today) {  // today's level is still in registers: patch it into the stream
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q == q_today) ww[q] = (ww[q] & ~(0xffu << sh_today)) | ((uint32_t)a.level << sh_today);
-        }
-        // wave-uniform pointer into the read-only tap table -> s_load through the scalar cache
-        cv_tap_ptr g0 = (cv_tap_ptr)(uintptr_t)(G + (int64_t)(16 * c - t - 1 + AIE_CV_TAP_PAD_FRONT) * F);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int lev = (int)((ww[j >> 2] >> (8 * (j & 3))) & 0xffu);
-          const double d = (double)(lev - carry);
-          carry = lev;
-#pragma unroll
-          for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, g0[j * F + f], acc[f]);
-          // 16*F doubles of taps per chunk do not fit the SGPR file: tie the pointer to the
-          // accumulator every 4 days so that only 4*F taps are fetched ahead of their use
-          if ((j & 3) == 3) {
-#pragma unroll
-            for (int f = 0; f < F; ++f) asm volatile("" : "+s"(g0), "+v"(acc[f]));
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = nxt[k];
     }
-    }  // direct sum over the uploaded taps
     double x = 0.0;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
@@ -476,8 +616,13 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   // seven partly written lines a step); the recurrence writes a state's 16 bytes once their chunk is complete
   *cv_ring_at(P, rec, s, L + t) = on ? (uint8_t)a.level : (uint8_t)0;
   if (!CV_SKIP(P, 1)) {
-    if constexpr (!RECUR) {
+    if (!RECUR && dense && !flush_now) {
       if (on) *cv_hist_at(P, hist, s, L + t) = (uint8_t)a.level;
+    } else if (flush_now) {  // the replica turned dense in this step: the open chunk's days so far and today's, in one piece
+      uint32_t w[4] = {flushw[0], flushw[1], flushw[2], flushw[3]};
+      w[((L + t) & 15) >> 2] |= (uint32_t)a.level << (8 * ((L + t) & 3));
+      if (s * 16 < P.cv_row)
+        *reinterpret_cast<uint4*>(hist + (int64_t)((L + t) >> 4) * P.cv_row + s * 16) = on ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
     } else if (((L + t) & 15) == 15) {
       uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -517,7 +662,7 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   red[0][s] = on ? marginal_deaths : 0.f;
   red[1][s] = on ? a.subsidy : 0.f;
   red[2][s] = on ? a.prod : 0.f;
-  __syncthreads();
+  AIE_WSYNC();  // (a replica is one wavefront: its LDS writes are ordered, no workgroup barrier needed)
   const float eta = (float)V.economic_reward_crra_eta;
   const float rnf = (float)V.reward_normalization_factor;
   if (on) {
@@ -558,10 +703,56 @@ __global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 
   }
 
   // ---- observations + masks for the new timestep ----
-  __syncthreads();  // today's level byte (written above) may be the lagged observation when beta_delay == 1
   if (!CV_SKIP(P, 4)) cv_write_observations(P, arena, e, s, t, a, sub_level, lag_level);
   if (next.a || next.p) {  // aie_step_sample_next: the uniform random policy's draw for the next step, one lane per slot
     const int per_env = P.n * P.act_a_width + P.act_p_width;
-    for (int j = s; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, e, j, next.a, next.p);
+    if (next.masked) {
+      // aie_step_sample_next_masked: uniform over what the masks just written allow -- a state's levels only outside its
+      // cooldown, the planner's subsidy levels only on the first day of an interval; NO-OP always (the allowed set is
+      // {0} or {0 .. N}, so the pick-th allowed entry of aie_sample_masked_actions is the pick itself)
+      if (s <= n) {
+        const uint32_t u = aie_counter_rng(next.seed, (uint64_t)(next.env_offset + e), (uint64_t)next.t, (uint64_t)s);
+        const bool open = s < n ? (t >= a.cooldown || V.replay_policies) : (t % V.subsidy_interval == 0 || V.replay_policies);
+        const int count = open ? 1 + (s < n ? NL : NS) : 1;
+        const int32_t pick = (int32_t)(((uint64_t)u * (uint64_t)count) >> 32);
+        if (s < n) { if (next.a) next.a[(int64_t)e * n + s] = pick; }
+        else if (next.p) next.p[e] = pick;
+      }
+    } else {
+      for (int j = s; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, e, j, next.a, next.p);
+    }
   }
+}
+
+#undef CV_LOAD_STATE
+
+// recurrence (filter_recurrence): one replica per workgroup; window sums: AIE_CV_WIN_WAVES replicas per workgroup
+template <int F, bool RECUR, typename TapT = double>
+__global__ void __launch_bounds__(RECUR ? AIE_NT : AIE_CV_WIN_WAVES * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+    aie_covid_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
+                          const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
+  if constexpr (RECUR) {
+    __shared__ float red[3][64];
+    cv_step_body<F, true, double>(params, arena, act_a, act_p, next, aie::replica_of_block((int)blockIdx.x, params->E),
+                                  (int)threadIdx.x, red, nullptr);
+  } else {
+    // window sums: AIE_CV_WIN_WAVES replicas (one wavefront each) per workgroup share an LDS copy of the filter taps --
+    // [1 + filter_len][F], row 0 zero -- which the sums over the change events index per lane
+    extern __shared__ __attribute__((aligned(16))) uint8_t cv_lds[];
+    const aie_params& P = *params;
+    TapT* taps = reinterpret_cast<TapT*>(cv_lds);
+    const int rows = P.cv_L + 1;
+    float (*red)[64] = reinterpret_cast<float (*)[64]>(cv_lds + (((size_t)rows * F * sizeof(TapT) + 255) & ~(size_t)255)) + 3 * (threadIdx.x >> 6);
+    const double* G = reinterpret_cast<const double*>(arena + P.a_cv_filters) + (int64_t)(AIE_CV_TAP_PAD_FRONT - 1) * F;
+    for (int q = (int)threadIdx.x; q < rows * F; q += AIE_CV_WIN_WAVES * AIE_NT) taps[q] = (TapT)G[q];  // (row PAD_FRONT - 1 is a zero row)
+    __syncthreads();
+    const int b = (int)blockIdx.x * AIE_CV_WIN_WAVES + (int)(threadIdx.x >> 6);
+    if (b >= P.E) return;
+    cv_step_body<F, false, TapT>(params, arena, act_a, act_p, next, aie::replica_of_block(b, P.E), (int)(threadIdx.x & 63),
+                                 red, taps);
+  }
+}
+// dynamic LDS of the window-sum kernel
+__host__ __device__ inline size_t aie_covid_win_lds_bytes(const aie_params& P, size_t tap_bytes) {
+  return (((size_t)(P.cv_L + 1) * P.cv_F * tap_bytes + 255) & ~(size_t)255) + (size_t)AIE_CV_WIN_WAVES * 3 * 64 * 4;
 }

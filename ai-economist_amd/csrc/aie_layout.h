@@ -178,6 +178,18 @@ typedef struct aie_params {
                           * ago, the lagged observation -- and writes for today are single rows, not 51 scattered bytes) */
   int32_t o_cv_acc;      /* record: float64 [F] rows of 64 lanes: each filter's discounted sum of stringency deltas
                           * over the current window (filter_recurrence), else unused       */
+  /* window sums (filter_recurrence == 0) over the NON-ZERO level changes only: per replica and state the change events
+   * (history day tau, delta) of the episode so far + the pre-episode days, oldest first.  A day without a change adds
+   * fma(0, tap, acc) == acc to the reference's sum, so the sum over the events in the same order is the SAME float64,
+   * bit for bit.  A state that would exceed the list's capacity makes its replica "dense" until the next reset: the
+   * kernel then streams the 600-day history as before.                                                          */
+  int32_t cv_ev_groups;  /* capacity of a state's event list in groups of 4 (0: filter_recurrence)                */
+  int32_t o_cv_ev_ht;    /* record: int32 row: head | tail << 16 of every state's list                           */
+  int32_t o_cv_dense;    /* record: int32: 1 = this replica streams the whole window (list overflow)              */
+  int32_t cv_pad2_;
+  int64_t a_cv_events;   /* uint32 [E][cv_ev_groups][64 lanes][4]: tau | (delta & 0xff) << 16                     */
+  int64_t a_cv_ev0;      /* shared: the pre-episode days' lists in the same format, then int32 [64] head/tail row,
+                          * then int32 dense flag (a pre-episode list overflowed); aie_covid_prepare_kernel       */
   int64_t a_cv_consts;   /* AIE_CV_K_* float64 rows of 64 (shared by all replicas)         */
   int64_t a_cv_filters;  /* float64 [pad+L+pad][F]                                              */
   int64_t a_cv_hist0;    /* uint8 [L+1][n]   stringency levels of the L days before t=0 + t=0 */
@@ -225,6 +237,7 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->a_saez = p->a_events = p->a_metrics = p->a_saez_global = 0;
   p->a_cv_consts = p->a_cv_filters = p->a_cv_hist0 = p->a_cv_lag_obs = p->a_cv_hist = p->a_cv_obs_a = p->a_cv_obs_p = 0;
   p->a_cv_hist0c = p->a_cv_acc0 = 0;
+  p->a_cv_events = p->a_cv_ev0 = 0;
   p->a_cv_replay_a = p->a_cv_replay_p = p->a_cv_replay_state = 0;
   p->a_layout_prob = 0;
   p->dev_skip_mask = 0;
@@ -342,6 +355,10 @@ enum { AIE_CV_OB_STATE = 0, AIE_CV_OB_PROD = 6, AIE_CV_OB_LAG = 7, AIE_CV_OB_TIM
        AIE_CV_OB_T_SUBSIDY = 10, AIE_CV_OB_SUBSIDY_LEVEL = 11, AIE_CV_OB_T_VACCINE = 12, AIE_CV_OB_MASK = 13 };
 
 #define AIE_CV_GROUP 2            /* history chunks fetched per prefetch group                 */
+#define AIE_CV_EVENT_CAP 64       /* level changes per state a replica's event list holds (multiple of 4)      */
+#ifndef AIE_CV_WIN_WAVES
+#define AIE_CV_WIN_WAVES 8        /* replicas per workgroup of the window-sum kernel (they share the LDS tap table) */
+#endif
 #define AIE_CV_TAP_PAD_FRONT 16   /* zero rows before tap 0 in the filter-tap table            */
 #define AIE_CV_TAP_PAD_BACK (16 * (AIE_CV_GROUP + 3))
 
@@ -410,6 +427,9 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   p->o_cv_sums = aie__rec(&cur, 8 * n * AIE_CV_SUM_COUNT, 8);
   p->o_cv_acc = aie__rec(&cur, 8 * n * (v->filter_recurrence ? v->num_filters : 0), 8);
   p->o_cv_ring = aie__rec(&cur, 32 * 64, 256);
+  p->cv_ev_groups = v->filter_recurrence ? 0 : AIE_CV_EVENT_CAP / 4;
+  p->o_cv_ev_ht = aie__rec(&cur, p->cv_ev_groups ? 4 * n : 0, 4);
+  p->o_cv_dense = aie__rec(&cur, 4, 4);
   p->o_cv_subsidy_level = aie__rec(&cur, 4, 4);
   p->o_cv_p_index = aie__rec(&cur, 8, 4);
   p->o_timestep = aie__rec(&cur, 4, 4);
@@ -436,6 +456,8 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
     p->a_cv_replay_state = a; a = aie__align(a + (int64_t)6 * (c->episode_length + 1) * 64 * 8, 256);
   }
   p->a_cv_hist = a;    a = aie__align(a + E * (int64_t)p->cv_nch * p->cv_row, 256);
+  p->a_cv_ev0 = a;     a = aie__align(a + (int64_t)p->cv_ev_groups * 1024 + 256 + 16, 256);
+  p->a_cv_events = a;  a = aie__align(a + E * (int64_t)p->cv_ev_groups * 1024, 256);
   p->a_cv_obs_a = a;   a = aie__align(a + E * no, 256);
   p->a_cv_obs_p = a;   a = aie__align(a + E * po, 256);
   p->a_rew_a = a; a = aie__align(a + E * n * 4, 256);
@@ -468,6 +490,15 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
     tt->t[tt->n - 1].stride[1] = 64;
     /* stringency level on day (16*chunk + j - filter_len) of the episode, per state.  With filter_recurrence a chunk
      * is written when its 16th day is over (from the ring); without, every day (the window sums stream it) */
+    if (p->cv_ev_groups) {
+      /* level-change events per state: list positions [head, tail) are inside the current filter window */
+      aie__add(tt, "stringency_change_head_tail", AIE_I32, r0 + p->o_cv_ev_ht, rs, 1, n, 0, 0, 0, E);
+      aie__add(tt, "stringency_change_events", AIE_U32, p->a_cv_events, (int64_t)p->cv_ev_groups * 1024, 3, p->cv_ev_groups,
+               n, 4, 0, E);
+      tt->t[tt->n - 1].stride[1] = 1024;
+      tt->t[tt->n - 1].stride[2] = 16;
+    }
+    aie__add(tt, "window_streams_whole_history", AIE_I32, r0 + p->o_cv_dense, rs, 0, 0, 0, 0, 0, E);
     aie__add(tt, "stringency_history_chunks", AIE_U8, p->a_cv_hist, (int64_t)p->cv_nch * p->cv_row, 3,
              p->cv_nch, n, 16, 0, E);
     tt->t[tt->n - 1].stride[1] = p->cv_row;

@@ -169,14 +169,16 @@ class DeviceBackend:
         logged (include/aie.h: aie_set_dense_log_active); otherwise they step with the rest of the batch."""
         self._check(self.lib.aie_set_dense_log_active(self.handle, 1 if on else 0))
 
-    def step_sample_next(self, actions_a, actions_p, seed, env_offset=0, next_slot=1):
+    def step_sample_next(self, actions_a, actions_p, seed, env_offset=0, next_slot=1, masked=False):
         """One launch: step with (actions_a, actions_p) and fill the action buffers of `next_slot`
-        with the uniform random policy's next draw (same values as sample_random_actions)."""
+        with the uniform random policy's next draw (same values as sample_random_actions; masked=True, COVID only:
+        as sample_masked_actions, from the masks this step writes)."""
         torch = _torch()
         a = self._ptr(actions_a, torch.int32, "actions_a", self.act_a_numel)
         p = self._ptr(actions_p, torch.int32, "actions_p", self.act_p_numel)
         na, np_ = self._action_buffers(next_slot)
-        self._check(self.lib.aie_step_sample_next(
+        fn = self.lib.aie_step_sample_next_masked if masked else self.lib.aie_step_sample_next
+        self._check(fn(
             self.handle, a, p, C.c_uint64(seed), C.c_int64(env_offset),
             C.c_void_p(na.data_ptr()), C.c_void_p(np_.data_ptr()), self._stream()))
         return na, np_

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- random-policy rollout throughput of the batched Foundation env.step().
 
-    python bench.py --gpus N --steps K --warmup W [--workload C1|C2|C2p|C3|C4|C4x|C5] [--no-workloads]
+    python bench.py --gpus N --steps K --warmup W [--workload C1|C2|C2v|P2|C3|C4|C4x|C5] [--no-workloads]
 
 Workloads = BASELINE.json configs[0..4].  The default run (1 GPU, C2) is the headline line and
 ALSO times every other BASELINE configuration in a short window of the same invocation (`"workloads": {C1, C3, C4, C4x,
@@ -66,6 +66,14 @@ def _c5_cfg():
                                                     "tax_model": "model_wrapper"}]])
 
 
+def _phase2_cfg():
+    from ai_economist_amd import _specs
+
+    kw = dict(_specs.PHASE2, scenario_name="layout_from_file/simple_wood_and_stone", dense_log_frequency=20)
+    kw["components"] = [[name, dict(c)] for name, c in kw["components"]]
+    return kw
+
+
 def _c4_cfg():
     # the env block of the reference's training/run_configs/covid_and_economy_environment.yaml:10-39
     return dict(scenario_name="CovidAndEconomySimulation", collate_agent_step_and_reset_data=True,
@@ -101,12 +109,17 @@ WORKLOADS = {
                desc="BASELINE configs[1]: gather-trade-build 25x25 quadrant layout, 4 agents + planner, Build+"
                     "ContinuousDoubleAuction(max_num_orders=5)+Gather+PeriodicBracketTax, episode_length 1000",
                cfg=lambda: dict(C2_CFG), envs=4096, survey_bytes=10984.0, kernel="aie_step_kernel"),
-    "C2p": dict(short="configs[1] with planner_gets_spatial_info=False (reference phase-2 YAML)",
-               desc="SURVEY 8(d) C2'': BASELINE configs[1] with planner_gets_spatial_info=False (the reference's phase-2 "
-                     "training YAML, tutorials/rllib/phase2/config.yaml); no compile-time instance exists for it: the "
-                     "kernels are specialised at run time (aie_specialize: hiprtc, cached)",
-                cfg=lambda: dict(C2_CFG, planner_gets_spatial_info=False), envs=4096, survey_bytes=6601.0,
-                kernel="aie_step_kernel", specialize=True),
+    "C2v": dict(short="configs[1] with starting_agent_coin=15, isoelastic_eta=0.5, episode_length=500 (same instance family)",
+                desc="BASELINE configs[1] with other scalars (starting_agent_coin 15, isoelastic_eta 0.5, episode_length 500): "
+                     "the compile-time instance of C2's family runs it, no call by the user",
+                cfg=lambda: dict(C2_CFG, starting_agent_coin=15, isoelastic_eta=0.5, episode_length=500), envs=4096,
+                survey_bytes=10984.0, kernel="aie_step_kernel"),
+    "P2": dict(short="the reference's phase-2 training YAML env block (incl. dense_log_frequency 20; no episode being logged)",
+               desc="SURVEY 8(d) C2'': the env block of the reference's tutorials/rllib/phase2/config.yaml as it stands "
+                    "(planner without maps, fixed four skills, annealed tax cap, dense_log_frequency 20): runs on the "
+                    "build's P2 instance; the dense-log replica records events in every 20th episode only "
+                    "(aie_set_dense_log_active), the window times one of the other 19",
+               cfg=lambda: _phase2_cfg(), envs=4096, survey_bytes=6601.0, kernel="aie_step_kernel", dense_log_off=True),
     "C3": dict(short="BASELINE configs[2], one GPU share: as C2 with 10 agents, 4096 replicas/GPU",
                desc="BASELINE configs[2], one GPU's share (32768 replicas over 8 GPUs = 4096 each): as C2 with 10 agents",
                cfg=lambda: dict(C2_CFG, n_agents=10), envs=4096, survey_bytes=7666.0, kernel="aie_step_kernel"),
@@ -319,7 +332,12 @@ class Rollout:
         e = torch.arange(self.E, device=self.be.device)
         self.group_masks = [((e % self.G) == g).to(torch.uint8) for g in range(self.G)] if self.G > 1 else None
         self.reset_events = []
-        self.cur = self.be.sample_random_actions(ACTION_SEED, self.off, slot=0)
+        # COVID: the random policy respects the action masks (a state's stringency levels only outside its cool-down,
+        # subsidy levels only on interval starts) -- the policy a trainer that applies `action_mask` to its logits
+        # starts from, and the one under which the reference's cool-down component means anything; drawn inside the
+        # step launch like the uniform one (aie_step_sample_next_masked)
+        self.masked = wl.startswith("C4")
+        self.cur = (self.be.sample_masked_actions if self.masked else self.be.sample_random_actions)(ACTION_SEED, self.off, slot=0)
         self.slot = 0
 
     def prologue(self):
@@ -339,7 +357,8 @@ class Rollout:
     def _launch(self):
         be = self.be
         if self.fused:
-            self.cur = be.step_sample_next(self.cur[0], self.cur[1], ACTION_SEED, self.off, next_slot=self.slot ^ 1)
+            self.cur = be.step_sample_next(self.cur[0], self.cur[1], ACTION_SEED, self.off, next_slot=self.slot ^ 1,
+                                           masked=self.masked)
             self.slot ^= 1
         else:
             a, p = be.sample_random_actions(ACTION_SEED, self.off)
@@ -434,7 +453,8 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
     env.reset()
     be = env.backend
     n = env.n_agents
-    specialised = bool(W.get("specialize")) and env.specialize()  # (False: hiprtc / sources missing -> generic kernel)
+    if W.get("dense_log_off"):
+        be.set_dense_log_active(False)
     if args.generic_kernel:  # development: what a configuration without an instance runs
         be.lib.aie_select_step_kernel(be.handle, 1)
     roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger, auto_reset=not args.no_auto_reset)
@@ -538,7 +558,12 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
         elif inst >= 0 and not wl.startswith("C4"):
             kernel_name = "%s_spec<%d>" % (W["kernel"], inst)
         elif wl.startswith("C4"):
-            kernel_name = "aie_covid_step_kernel<%d, %s>" % (env.model["num_filters"], "false" if env.exact_filter_sums else "true")
+            import numpy as np
+
+            taps = np.asarray(env.model["unemp_conv_filters"], np.float64)
+            tap_t = "float" if np.array_equal(taps.astype(np.float32).astype(np.float64), taps) else "double"
+            kernel_name = ("aie_covid_step_kernel<%d, false, %s>" % (env.model["num_filters"], tap_t) if env.exact_filter_sums
+                           else "aie_covid_step_kernel<%d, true, double>" % env.model["num_filters"])
         traffic_frac = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None
         insts, insts_src, valu_insts = issue_counters(wl)
         issue_frac = (insts / (N_SIMDS * SM_CLOCK_HZ * avg_ms * 1e-3)) if (insts and E == W["envs"]) else None
@@ -587,7 +612,8 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
         out = {
             "metric": "agent-steps/sec, %s" % {"C1": "simple_wood_and_stone 15x15 4-agent Gather+Build batched envs",
                                                 "C2": "gather-trade-build 25x25 4-agent batched envs",
-                                                "C2p": "gather-trade-build 25x25 4-agent batched envs, planner without maps",
+                                                "C2v": "gather-trade-build 25x25 4-agent batched envs, other scalars",
+                                                "P2": "gather-trade-build 25x25 4-agent batched envs, phase-2 YAML",
                                                 "C3": "gather-trade-build 25x25 10-agent batched envs",
                                                 "C4": "covid19_env 51 US-state agents + planner",
                                                 "C4x": "covid19_env 51 US-state agents + planner",
@@ -601,12 +627,13 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
             "data": "synthetic",
             "config": {
                 "workload": "%s: %s; uniform random policy; mobile agents counted (planner excluded)" % (wl, W["desc"]),
-                "workload_short": "%s %s, uniform random policy, planner not counted" % (wl, W["short"]),
+                "workload_short": "%s %s, %s random policy, planner not counted" % (wl, W["short"], "mask-respecting" if roll.masked else "uniform"),
                 "parallelism_short": ("replica sharding x%d, RCCL (reward,done) gather to rank 0" % world) if world > 1
                 else "single GPU",
                 "envs_per_gpu": E, "global_envs": world * E, "n_agents": n,
                 "rng": "per-replica NumPy-legacy MT19937 (parity mode)",
-                "policy": "uniform random (counter RNG)" + ("; the draw for step t+1 happens inside the launch of "
+                "policy": ("uniform random over the actions the masks allow (counter RNG)" if roll.masked else
+                           "uniform random (counter RNG)") + ("; the draw for step t+1 happens inside the launch of "
                                                              "step t (aie_step_sample_next), one launch per step"
                                                              if roll.fused else ""),
                 "phasing": ("replicas de-phased in %d blocks, episode ends %d steps apart (prologue of %d untimed "
@@ -705,7 +732,7 @@ def compact_line(out):
 # the other BASELINE configurations a default run also times, in short windows: (workload, steps, warm-up)
 # (C5: the first ~10 launches over its 7 GB arena run 15 % slower than the steady state -- 1.68 ms per launch measured
 # with 6 warm-up launches, 1.447 ms with 10, 30 or 60 on the same box)
-SIDE_CPU_BASELINES = ("C1", "C3", "C4x", "C5")  # (C2p / C4 step the same reference code as C2 / C4x)
+SIDE_CPU_BASELINES = ("C1", "C3", "C4x", "C5")  # (C2v, P2 and C4 step the same reference code as C2 and C4x)
 SIDE_CPU_SECONDS = 3.0
 
 
@@ -721,7 +748,7 @@ def emit(out, detail_file):
     print(compact_line(out), flush=True)
 
 
-SIDE_WORKLOADS = [("C1", 200, 20), ("C2p", 200, 20), ("C3", 200, 20), ("C4", 200, 20), ("C4x", 100, 10), ("C5", 60, 20)]
+SIDE_WORKLOADS = [("C1", 200, 20), ("C2v", 200, 20), ("P2", 200, 20), ("C3", 200, 20), ("C4", 200, 20), ("C4x", 100, 10), ("C5", 60, 20)]
 
 
 def main():

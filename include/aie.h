@@ -337,7 +337,10 @@ int aie_tensor_at(const aie_env* env, int index, aie_tensor_desc* out);
 int aie_get_tensor(const aie_env* env, const char* name, aie_tensor_desc* out);
 
 /* Host <-> device copies of one named tensor (dense, C-order, leading dim = E).
- * Synchronous; meant for initial state injection and parity dumps. */
+ * Synchronous; meant for initial state injection and parity dumps.  The COVID tables "model_stringency_level_history_0"
+ * and "model_unemp_conv_filters" have to be written through aie_upload (not through a view of the arena): the library
+ * derives data from them at that point (the history-format image and the pre-episode change events every reset copies;
+ * whether the taps are float32 values, which selects the tap-table format of the window-sum kernel). */
 int aie_upload(aie_env* env, const char* name, const void* host, int64_t bytes);
 int aie_download(aie_env* env, const char* name, void* host, int64_t bytes);
 
@@ -375,6 +378,13 @@ int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_of
  * of the uniform random policy then needs one launch per step instead of two. */
 int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, uint64_t seed,
                          int64_t global_env_offset, int32_t* d_next_a, int32_t* d_next_p, void* stream);
+
+/* The same with the NEXT actions drawn as aie_sample_masked_actions would draw them from the masks this step writes
+ * (a state's stringency levels only outside its cooldown, the planner's subsidy levels only on the first day of an
+ * interval, NO-OP always): the random policy of a trainer that applies `action_mask` to its logits, one launch per
+ * step.  COVID scenario; AIE_E_UNSUPPORTED elsewhere (there: aie_step, then aie_sample_masked_actions). */
+int aie_step_sample_next_masked(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, uint64_t seed,
+                                int64_t global_env_offset, int32_t* d_next_a, int32_t* d_next_p, void* stream);
 
 /* Reward log for learners on another device: every following aie_step / aie_step_sample_next ALSO
  * writes replica e's (agent rewards [n_agents], planner reward, done as 0/1) as n_agents + 2 floats to

@@ -15,7 +15,7 @@ import bench  # noqa: E402
 
 @pytest.mark.parametrize("wl", sorted(bench.WORKLOADS))
 def test_counter_lookups_return_their_triples_for_every_workload(wl):
-    insts, src, valu = bench.issue_counters(wl)  # (None, None, None) for a workload without a summary, e.g. C2p
+    insts, src, valu = bench.issue_counters(wl)  # (None, None, None) for a workload without a summary, e.g. P2
     assert (insts is None) == (src is None)
     if insts is not None:
         assert insts > 0 and os.path.exists(os.path.join(ROOT, src))

@@ -418,3 +418,97 @@ def test_covid_filter_recurrence_vs_exact_window_sums():
             np.testing.assert_allclose(tr["rewards_a"].cpu().numpy(), tx["rewards_a"].cpu().numpy(), rtol=0, atol=1e-5)
     assert worst < 4e-6, "unemployed: recurrence vs exact window sums differ by %.3g relative" % worst
     print("covid filter recurrence: max relative deviation of `unemployed` from the exact window sums: %.3g" % worst)
+
+
+def _covid_state_tensors(env):
+    skip = ("stringency_change_", "window_streams_whole_history", "stringency_history_chunks")
+    return {k: v for k, v in env.tensors.items() if not k.startswith(skip)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["masked", "unmasked"])
+def test_covid_window_sums_over_change_events_equal_the_streamed_window(policy):
+    """The default (reference-exact) filter sums add only the NON-ZERO level changes of the 600-day window, kept per
+    state as an event list; a day without a change contributes fma(0, tap, acc) == acc to the streamed sum, so both
+    must give the SAME float64 -- every tensor bit for bit.  Environment `ev` keeps the lists, `st` is made to stream
+    its whole window from the first step (the exported flag).  "masked": the policy respects the cool-down masks, the
+    lists never overflow over a whole episode; "unmasked": levels change on most days, a list overflows mid-episode
+    and the replica carries on streaming (the step that switches builds the open history chunk from the recent-days
+    ring).  Masked resets in between."""
+    import torch
+
+    g = load_covid_golden("c4_covid_51ag")
+    cfg = g["cfg"]
+    E = 40
+    ev, st = hip_env(cfg, n_envs=E), hip_env(cfg, n_envs=E)
+    for env in (ev, st):
+        env.reset()
+    st.tensors["window_streams_whole_history"].fill_(1)
+    T = int(cfg["episode_length"])
+    steps = T + 30 if policy == "masked" else 220
+    went_dense_at = None
+    for k in range(1, steps + 1):
+        if policy == "masked":
+            a, p = ev.backend.sample_masked_actions(seed=5)
+        else:
+            a, p = ev.backend.sample_random_actions(seed=5)
+        for env in (ev, st):
+            env.backend.step(a, p)
+        if k % 90 == 0 or k == T:
+            mask = ev.tensors["done"].clone() if k == T else (torch.arange(E, device="cuda") % 3 == 0).to(torch.uint8)
+            for env in (ev, st):
+                env.backend.reset(mask)
+            st.tensors["window_streams_whole_history"].fill_(1)
+        if k % 15 == 0 or k in (1, 2, T - 1, T, T + 1, steps):
+            torch.cuda.synchronize()
+            a_t, b_t = _covid_state_tensors(ev), _covid_state_tensors(st)
+            for name in a_t:
+                assert torch.equal(a_t[name], b_t[name]), "day %d: %s differs (event lists vs streamed window)" % (k, name)
+            dense = ev.tensors["window_streams_whole_history"]
+            if policy == "masked":
+                assert int(dense.sum()) == 0, "day %d: a list overflowed under the masked policy" % k
+                ht = ev.tensors["stringency_change_head_tail"]
+                assert int((ht >> 16).max()) <= 64 and bool(((ht & 0xffff) <= (ht >> 16)).all())
+            elif went_dense_at is None and int(dense.sum()) > 0:
+                went_dense_at = k
+    if policy == "unmasked":
+        assert went_dense_at is not None and went_dense_at > 15, "the unmasked rollout was meant to overflow a list mid-episode"
+        # whole 16-day chunks of the long history agree as well once a replica streams
+        e = int(torch.nonzero(ev.tensors["window_streams_whole_history"])[0])
+        L, ts = int(ev.model["filter_len"]), int(ev.tensors["timestep"][e])
+        done_chunks = (L + ts + 1) // 16
+        assert torch.equal(ev.tensors["stringency_history_chunks"][e, :done_chunks], st.tensors["stringency_history_chunks"][e, :done_chunks])
+
+
+@pytest.mark.gpu
+@FILTER_MODES
+def test_covid_step_sample_next_masked_equals_two_launches(recurrence):
+    """aie_step_sample_next_masked: the next actions drawn inside the step launch are what aie_sample_masked_actions
+    draws from the masks that step wrote."""
+    import torch
+
+    g = load_covid_golden("c4_covid_variant")
+    E = 64
+    one, two = [hip_env(g["cfg"], n_envs=E, filter_recurrence=recurrence) for _ in range(2)]
+    for env in (one, two):
+        env.reset()
+    cur = one.backend.sample_masked_actions(seed=9, slot=0)
+    slot = 0
+    for k in range(1, int(g["cfg"]["episode_length"]) + 1):  # (a step past the episode's end does nothing, draws included)
+        a, p = two.backend.sample_masked_actions(seed=9)
+        torch.cuda.synchronize()
+        assert torch.equal(a, cur[0]) and torch.equal(p, cur[1]), "day %d: fused masked draw differs" % k
+        two.backend.step(a, p)
+        cur = one.backend.step_sample_next(cur[0], cur[1], seed=9, next_slot=slot ^ 1, masked=True)
+        slot ^= 1
+        if k % 40 == 0:
+            torch.cuda.synchronize()
+            for name in _covid_state_tensors(one):
+                assert torch.equal(one.tensors[name], two.tensors[name]), "day %d: %s" % (k, name)
+    with pytest.raises(Exception):  # COVID only
+        from helpers import C2, make_env
+
+        gtb = make_env(C2, n_envs=4, device="cuda:0")
+        gtb.reset()
+        a, p = gtb.backend.sample_random_actions(seed=1)
+        gtb.backend.step_sample_next(a, p, seed=1, masked=True)

@@ -45,6 +45,9 @@ class OracleBackend:
         self.tensors = {k: torch.from_numpy(v) for k, v in oracle.t.items()
                         if v.dtype != np.uint32 and v.dtype != np.uint16}
 
+    def set_dense_log_active(self, on=True):
+        pass  # (the oracle records the logged replicas' events on every step)
+
     def reset(self, mask=None):
         self.o.reset(None if mask is None else np.asarray(mask, np.uint8))
 
@@ -241,6 +244,7 @@ def test_hip_dense_log_matches_oracle(case):
     twin._backend = OracleBackend(o)
     twin.host_pre_reset = lambda mask: oracle_host_pre_reset(twin, o)
     be = None
+    logged_steps = 0
     for ep in range(2):
         env.reset()
         twin.reset()
@@ -249,6 +253,11 @@ def test_hip_dense_log_matches_oracle(case):
             a, p = be.sample_random_actions(seed=5)
             env.step({"a": a, "p": p})
             twin.step({"a": a.cpu(), "p": p.cpu()})
+            if not env._dense_log_this_episode:
+                # not one of the every-`dense_log_frequency`-th episodes: the logged replica steps with the rest of the
+                # batch on the fast kernel and records no rows (aie_set_dense_log_active); the oracle always records
+                continue
+            logged_steps += 1
             cnt = be.tensors["log_event_count"].cpu().numpy()
             assert np.array_equal(cnt, o.t["log_event_count"]), (case, ep, t)
             got = be.tensors["log_events"].cpu().numpy()[0, : cnt[0]]
@@ -259,6 +268,7 @@ def test_hip_dense_log_matches_oracle(case):
                                            np.ascontiguousarray(want[:, 10:]).view(np.float64), rtol=1e-9, atol=1e-9)
         assert bool(be.tensors["done"][0])
         assert_logs_equal(env.previous_episode_dense_log, twin.previous_episode_dense_log, tol=1e-6)
+    assert logged_steps >= cfg["episode_length"]
 
 
 @pytest.mark.gpu

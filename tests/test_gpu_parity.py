@@ -955,7 +955,6 @@ def test_dense_log_switch_keeps_state_identical():
             for k in on.backend.tensors:
                 if not k.startswith("log_event"):
                     assert torch.equal(on.backend.tensors[k], off.backend.tensors[k]), "step %d: %s differs" % (t + 1, k)
-    assert int(on.backend.tensors["log_event_count"].sum()) >= 0
     # back on: the very next step records rows again, identical to an environment that never switched
     off.backend.set_dense_log_active(True)
     a, p = on.backend.sample_random_actions(seed=2)
@@ -963,7 +962,11 @@ def test_dense_log_switch_keeps_state_identical():
         env.backend.step(a, p)
     torch.cuda.synchronize()
     for k in on.backend.tensors:
-        assert torch.equal(on.backend.tensors[k], off.backend.tensors[k]), "after switching back on: %s differs" % k
+        if k != "log_events":
+            assert torch.equal(on.backend.tensors[k], off.backend.tensors[k]), "after switching back on: %s differs" % k
+    for e in range(on.backend.tensors["log_events"].shape[0]):  # (rows behind the count are leftovers of earlier steps)
+        cnt = int(on.backend.tensors["log_event_count"][e])
+        assert torch.equal(on.backend.tensors["log_events"][e, :cnt], off.backend.tensors["log_events"][e, :cnt])
 
 
 def test_instance_family_member_matches_oracle():

@@ -42,5 +42,5 @@ for k, d in acc.items():
     print(k)
     for name, v in c.items():
         print("   %-26s mean %.4g" % (name, v))
-json.dump(out, open("$R/gpurun_out/r03_${WL}_sq_counters.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/r04_${WL}_sq_counters.json", "w"), indent=1)
 PY
