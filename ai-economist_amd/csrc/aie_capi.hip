@@ -441,10 +441,14 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 gw((unsigned)((env->P.E + AIE_CV_WIN_WAVES - 1) / AIE_CV_WIN_WAVES)), bw(AIE_CV_WIN_WAVES * AIE_NT);
     const size_t lw = aie_covid_win_lds_bytes(env->P, env->cv_taps_f32 ? 4 : 8);
+    // window sums: the step, then -- a launch of its own -- the upkeep of the change-event lists and the next step's sums
 #define AIE_CV_LAUNCH(FN) \
   case FN: if (env->P.c.covid.filter_recurrence) hipLaunchKernelGGL((aie_covid_step_kernel<FN, true>), g, b, 0, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); \
-           else if (env->cv_taps_f32) hipLaunchKernelGGL((aie_covid_step_kernel<FN, false, float>), gw, bw, lw, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); \
-           else hipLaunchKernelGGL((aie_covid_step_kernel<FN, false, double>), gw, bw, lw, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); \
+           else { \
+             hipLaunchKernelGGL((aie_covid_step_kernel<FN, false>), g, b, 0, st, env->d_params, env->arena, d_actions_a, d_actions_p, next); \
+             if (env->cv_taps_f32) hipLaunchKernelGGL((aie_covid_window_kernel<FN, float>), gw, bw, lw, st, env->d_params, env->arena); \
+             else hipLaunchKernelGGL((aie_covid_window_kernel<FN, double>), gw, bw, lw, st, env->d_params, env->arena); \
+           } \
            break
     switch (env->P.cv_F) {
       AIE_CV_LAUNCH(1); AIE_CV_LAUNCH(2); AIE_CV_LAUNCH(3); AIE_CV_LAUNCH(4);

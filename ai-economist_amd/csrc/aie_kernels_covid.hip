@@ -194,6 +194,22 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
     const bool any_over = __ballot(on && over) != 0ull;
     if (s == 0) ht0[64] = any_over ? 1 : 0;
   }
+  if (!P.c.covid.filter_recurrence) {
+    // window sums: step 1's sums over its window WITHOUT its own day -- history days 2 .. L meet taps 0 .. L - 2 -- in
+    // the order the reference adds the days (what the tail of every step leaves for the next one, here for the first)
+    double* acc0 = reinterpret_cast<double*>(arena + P.a_cv_acc0);
+    const double* G = reinterpret_cast<const double*>(arena + P.a_cv_filters) + (int64_t)AIE_CV_TAP_PAD_FRONT * P.cv_F;
+    double A[AIE_COVID_MAX_FILTERS];
+    for (int f = 0; f < AIE_COVID_MAX_FILTERS; ++f) A[f] = 0.0;
+    int prev = h0[1 * n + sl];
+    for (int tau = 2; tau <= L; ++tau) {
+      const int lev = h0[tau * n + sl];
+      const double d = (double)(lev - prev);
+      prev = lev;
+      for (int f = 0; f < P.cv_F; ++f) A[f] = __builtin_fma(d, G[(int64_t)(tau - 2) * P.cv_F + f], A[f]);
+    }
+    for (int f = 0; f < P.cv_F; ++f) acc0[f * 64 + s] = on ? A[f] : 0.0;
+  }
   if (P.c.covid.filter_recurrence) {
     double* acc0 = reinterpret_cast<double*>(arena + P.a_cv_acc0);
     for (int f = 0; f < P.cv_F; ++f) {
@@ -249,10 +265,11 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
   } else if (s == 0) {
     *reinterpret_cast<int32_t*>(rec + P.o_cv_dense) = 0;
   }
-  if (P.c.covid.filter_recurrence) {  // A_0 of every filter (aie_covid_prepare_kernel)
+  {  // recurrence: A_0 of every filter; window sums: step 1's sums before its own day (aie_covid_prepare_kernel)
     double* accs = reinterpret_cast<double*>(rec + P.o_cv_acc);
     const double* acc0 = reinterpret_cast<const double*>(arena + P.a_cv_acc0);
-    for (int f = 0; f < P.cv_F; ++f) accs[f * PT + s] = acc0[f * 64 + s];
+    if (on)
+      for (int f = 0; f < P.cv_F; ++f) accs[f * PT + s] = acc0[f * 64 + s];
   }
   a.S = (float)K[AIE_CV_K_S0 * 64 + sl];
   a.I = (float)K[AIE_CV_K_I0 * 64 + sl];
@@ -297,16 +314,178 @@ extern "C" __global__ void __launch_bounds__(AIE_NT)
 }
 
 // ---- one env.step() (base_env.py:929-1032) ----
+// What follows a window-sum step (filter_recurrence off), as a launch of its own (aie_covid_window_kernel).  Every filter's sum over the 600-day window is a sum over the
+// window's NON-ZERO level changes -- a day without a change adds fma(0, tap, acc) == acc to the reference's sum, so the
+// sum over the change events in the same order is the same float64, bit for bit -- and all of those but the step's own
+// day are known one step ahead.  So a step ends by (1) recording its own change in the state's event list, (2) forming
+// the NEXT step's sums over everything but that step's own day -- over the list (one burst of list loads, per-lane
+// reads of the LDS tap table), or, once a list has overflowed, over the streamed history as the kernel always did --
+// and leaving them in the record, where the next step finds them with its other loads and adds its own day's term.
+// A launch of its own because the step kernel sits at the register file's limit (64 registers for 8 waves per SIMD,
+// i.e. the whole batch resident): inlined ahead of the step this work cost ~20 spilled values and 15 us, inlined behind
+// it still 8.  Also writes the long history ([chunk][state][16 days]).
+template <int F, typename TapT>
+__device__ __forceinline__ void cv_window_tail(const aie_params& P, uint8_t* __restrict__ arena, uint8_t* __restrict__ rec,
+                                               uint8_t* __restrict__ hist, const int e, const int s, const int t,
+                                               const int level, const int prev_level, int dense, const int ev_ht,
+                                               const TapT* taps) {
+  using namespace aie;
+  const int n = P.n, L = P.cv_L, PT = P.cv_pitch;
+  const bool on = s < n;
+  const int sl = on ? s : n - 1;
+  const int d_new_i = level - prev_level;
+  const bool grow = on && d_new_i != 0;
+  const int head = ev_ht & 0xffff, tail = ev_ht >> 16, cap = 4 * P.cv_ev_groups;
+  bool flush_now = false;
+  uint32_t flushw[4] = {0u, 0u, 0u, 0u};
+  if (!dense && __ballot(grow && tail >= cap) != 0ull) {
+    // a state's list is full: from here to the next reset the replica streams its whole window; the open chunk's
+    // days so far come from the recent-days ring
+    dense = 1;
+    flush_now = true;
+    if (s == 0) *reinterpret_cast<int32_t*>(rec + P.o_cv_dense) = 1;
+#pragma unroll
+    for (int j = 0; j < 15; ++j)
+      if (j < ((L + t) & 15)) flushw[j >> 2] |= (uint32_t)*cv_ring_at(P, rec, sl, ((L + t) & ~15) + j) << (8 * (j & 3));
+  }
+  // the long history: a replica on event lists gets a state's 16 bytes when their chunk is complete (from the ring); a
+  // streaming one every day (51 one-byte stores spread over 816 bytes); the step that switches writes the open chunk's
+  // days so far in one piece
+  if (!CV_SKIP(P, 1)) {
+    if (dense && !flush_now) {
+      if (on) *cv_hist_at(P, hist, s, L + t) = (uint8_t)level;
+    } else if (flush_now) {
+      uint32_t w[4] = {flushw[0], flushw[1], flushw[2], flushw[3]};
+      w[((L + t) & 15) >> 2] |= (uint32_t)level << (8 * ((L + t) & 3));
+      if (s * 16 < P.cv_row)
+        *reinterpret_cast<uint4*>(hist + (int64_t)((L + t) >> 4) * P.cv_row + s * 16) = on ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
+    } else if (((L + t) & 15) == 15) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 15; ++j) w[j >> 2] |= (uint32_t)*cv_ring_at(P, rec, sl, L + t - 15 + j) << (8 * (j & 3));
+      w[3] |= (uint32_t)level << 24;
+      if (s * 16 < P.cv_row)
+        *reinterpret_cast<uint4*>(hist + (int64_t)((L + t) >> 4) * P.cv_row + s * 16) = on ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  if (t >= P.c.episode_length) return;  // the episode is over: reset supplies the first step's sums
+  const int t1 = t + 1;                 // the step the sums are for: window = history days t1 + 1 .. t1 + L, its own day = L + t1
+  double acc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = 0.0;
+  if (!dense) {
+    int32_t* htrow = reinterpret_cast<int32_t*>(rec + P.o_cv_ev_ht);
+    uint32_t* evb = reinterpret_cast<uint32_t*>(arena + P.a_cv_events + (int64_t)e * P.cv_ev_groups * 1024);
+    const int g_lo = wave_min_i32(on ? head >> 2 : 0x7fff), g_hi = wave_max_i32(on ? (tail + 3) >> 2 : 0);
+    const uint4* evq = reinterpret_cast<const uint4*>(evb) + s;
+    int expired = 0;
+    // the list in memory holds the events before today's, oldest first; the groups are fetched CV_BURST at a time
+    // (one memory round trip covers the 32 events of a two-week cool-down over the whole window)
+    constexpr int CV_BURST = 8;
+    for (int g0 = g_lo; g0 < g_hi; g0 += CV_BURST) {
+      uint4 qb[CV_BURST];
+#pragma unroll
+      for (int k = 0; k < CV_BURST; ++k)
+        qb[k] = (on && 4 * (g0 + k) < tail) ? evq[(g0 + k) * 64] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int k = 0; k < CV_BURST; ++k) {
+        if (g0 + k >= g_hi) break;  // (wave-uniform)
+        const uint32_t w4[4] = {qb[k].x, qb[k].y, qb[k].z, qb[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = 4 * (g0 + k) + j, tau = (int)(w4[j] & 0xffffu);
+          const bool live = on && idx >= head && idx < tail;
+          if (live && tau <= t1) expired += 1;  // leaves the window (at most one per step: the days are distinct)
+          if (live && tau > t1) {
+            const double d = (double)((int)(w4[j] << 8) >> 24);
+            const TapT* tp = taps + (tau - t1) * F;  // tap l = tau - t1 - 1 lives in row l + 1
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, (double)tp[f], acc[f]);
+          }
+        }
+      }
+    }
+    if (grow) {  // today's change: still in registers (its tap tomorrow: L - 2), and onto the list
+      const double d = (double)d_new_i;
+      const TapT* tp = taps + (L - 1) * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, (double)tp[f], acc[f]);
+      evb[((tail >> 2) * 64 + s) * 4 + (tail & 3)] = (uint32_t)(L + t) | ((uint32_t)(d_new_i & 0xff) << 16);
+    }
+    if (on) htrow[s] = (head + expired) | ((tail + (grow ? 1 : 0)) << 16);
+  } else {
+    // the whole window, day by day: deltas of the daily levels of history days t1 .. t1 + L; the delta between days
+    // tau' - 1 and tau' meets tap l = tau' - t1 - 1.  The tap table is zero-padded (AIE_CV_TAP_PAD_FRONT rows before tap
+    // 0, zeros after tap L - 1), so whole 16-day chunks are processed without any window test.  Chunks are fetched in
+    // groups of AIE_CV_GROUP, one group ahead.  Today's level is still in registers and the next step's own day counts
+    // as "no change" here (the step adds its term itself): both bytes are patched into the stream.
+    const double* __restrict__ G = reinterpret_cast<const double*>(arena + P.a_cv_filters);  // [row][F]
+    const int c0 = t1 >> 4;
+    const int d_today = L + t, d_next = L + t1;
+    const int ngroups = ((L >> 4) + 2 + AIE_CV_GROUP - 1) / AIE_CV_GROUP;
+    const uint8_t* row = hist + sl * 16 + (int64_t)c0 * P.cv_row;
+    int carry = 0;
+    uint4 cur[AIE_CV_GROUP], nxt[AIE_CV_GROUP];
+#pragma unroll
+    for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = *reinterpret_cast<const uint4*>(row + (int64_t)k * P.cv_row);
+    for (int g = 0; g < ngroups; ++g) {
+      if (g + 1 < ngroups) {
+#pragma unroll
+        for (int k = 0; k < AIE_CV_GROUP; ++k)
+          nxt[k] = *reinterpret_cast<const uint4*>(row + (int64_t)((g + 1) * AIE_CV_GROUP + k) * P.cv_row);
+      }
+#pragma unroll
+      for (int k = 0; k < AIE_CV_GROUP; ++k) {
+        const int c = c0 + g * AIE_CV_GROUP + k;
+        uint32_t ww[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+        if (c == (d_today >> 4)) {
+          if (flush_now) {  // the chunk's earlier days are not in the long history yet in the step that switches
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ww[q] = flushw[q];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q == ((d_today & 15) >> 2)) ww[q] = (ww[q] & ~(0xffu << (8 * (d_today & 3)))) | ((uint32_t)level << (8 * (d_today & 3)));
+        }
+        if (c == (d_next >> 4)) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q == ((d_next & 15) >> 2)) ww[q] = (ww[q] & ~(0xffu << (8 * (d_next & 3)))) | ((uint32_t)level << (8 * (d_next & 3)));
+        }
+        // wave-uniform pointer into the read-only tap table -> s_load through the scalar cache
+        cv_tap_ptr g0 = (cv_tap_ptr)(uintptr_t)(G + (int64_t)(16 * c - t1 - 1 + AIE_CV_TAP_PAD_FRONT) * F);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int lev = (int)((ww[j >> 2] >> (8 * (j & 3))) & 0xffu);
+          const double d = (double)(lev - carry);
+          carry = lev;
+#pragma unroll
+          for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, g0[j * F + f], acc[f]);
+          // 16*F doubles of taps per chunk do not fit the SGPR file: tie the pointer to the
+          // accumulator every 4 days so that only 4*F taps are fetched ahead of their use
+          if ((j & 3) == 3) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) asm volatile("" : "+s"(g0), "+v"(acc[f]));
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = nxt[k];
+    }
+  }
+  if (on) {
+    double* accs = reinterpret_cast<double*>(rec + P.o_cv_acc);
+#pragma unroll
+    for (int f = 0; f < F; ++f) accs[f * PT + s] = acc[f];
+  }
+}
+
 // `red`: this replica's three reduction rows in LDS; `taps` (window sums only): the workgroup's LDS copy of the filter
 // taps, row 0 zero, row 1 + l = tap l ([filter_len + 1][F] doubles).
-// TapT: double, or float when every uploaded tap is a float32 value (the reference's are: covid19_env.py:242-247 builds
-// them in float32) -- the same numbers in half the LDS bytes and with odd-dword rows, i.e. per-lane reads of different
-// rows that spread over all 64 banks instead of colliding on 32 bank pairs.
-template <int F, bool RECUR, typename TapT>
+template <int F, bool RECUR>
 __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                                              const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
-                                             const NextActions& next, const int e, const int s, float (*red)[64],
-                                             const TapT* taps) {
+                                             const NextActions& next, const int e, const int s, float (*red)[64]) {
   float* __restrict__ rew_log = next.rew_log;  // this step's slot of aie_set_reward_log, or nullptr
   using namespace aie;
   const aie_params& P = *params;
@@ -333,22 +512,21 @@ __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ para
   int cool0;
 #define CV_LOAD_STATE()                                                                                      \
   do {                                                                                                       \
-    sum_u0 = sums[AIE_CV_SUM_UNEMPLOYED * PT + sl]; sum_s0 = sums[AIE_CV_SUM_STRINGENCY * PT + sl];           \
-    sum_p0 = sums[AIE_CV_SUM_PRODUCTIVITY * PT + sl]; sum_b0 = sums[AIE_CV_SUM_SUBSIDY * PT + sl];            \
-    hidx0 = st[AIE_CV_ST_HEALTH_INDEX * PT + sl]; eidx0 = st[AIE_CV_ST_ECONOMIC_INDEX * PT + sl];             \
-    pidx0 = pidx[0]; pidx1 = pidx[1];                                                                        \
     S1 = st[AIE_CV_ST_S * PT + sl]; I1 = st[AIE_CV_ST_I * PT + sl]; R1 = st[AIE_CV_ST_R * PT + sl];            \
     V1 = st[AIE_CV_ST_V * PT + sl]; D1 = st[AIE_CV_ST_D * PT + sl];                                           \
     cool0 = cool[sl];                                                                                        \
   } while (0)
-  // recurrence: every load of the replica's record goes out here.  Window sums: the sums over the change events come
-  // FIRST, with nothing else live in registers (the streamed fallback needs them all), the record follows behind them
-  if constexpr (RECUR) CV_LOAD_STATE();
-  int dense = 0, ev_ht = 0;  // window sums: does the replica stream its whole window; this state's event list head | tail << 16
-  if constexpr (!RECUR) {
-    dense = uni(*reinterpret_cast<const int32_t*>(rec + P.o_cv_dense));
-    ev_ht = reinterpret_cast<const int32_t*>(rec + P.o_cv_ev_ht)[sl];
-  }
+#define CV_LOAD_ACCUMULATORS()                                                                                \
+  do {                                                                                                       \
+    sum_u0 = sums[AIE_CV_SUM_UNEMPLOYED * PT + sl]; sum_s0 = sums[AIE_CV_SUM_STRINGENCY * PT + sl];           \
+    sum_p0 = sums[AIE_CV_SUM_PRODUCTIVITY * PT + sl]; sum_b0 = sums[AIE_CV_SUM_SUBSIDY * PT + sl];            \
+    hidx0 = st[AIE_CV_ST_HEALTH_INDEX * PT + sl]; eidx0 = st[AIE_CV_ST_ECONOMIC_INDEX * PT + sl];             \
+    pidx0 = pidx[0]; pidx1 = pidx[1];                                                                        \
+  } while (0)
+  CV_LOAD_STATE();
+  // (the read-modify-write accumulators -- episode sums, index sums -- are read now and only written at the end)
+  CV_LOAD_ACCUMULATORS();
+  double acc[F];
   // the lagged stringency level of the new observation (:957-970), fetched with the other history bytes: a load issued
   // behind today's stores would wait for them (memory operations of a wave complete in order)
   const int tb = t - V.beta_delay + 1;
@@ -365,135 +543,6 @@ __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ para
   CvLane a;
   a.level = act == 0 ? prev_level : act;
   if (lag_level < 0) lag_level = a.level;
-  double acc[F];  // every filter's sum over the window (window sums: formed right here; recurrence: further down)
-  bool flush_now = false;
-  uint32_t flushw[4] = {0u, 0u, 0u, 0u};
-  if constexpr (!RECUR) {
-    double acc_ev[F];  // window sums: every filter's sum over the window's change events before today
-    int ev_expired = 0;
-#pragma unroll
-    for (int f = 0; f < F; ++f) acc_ev[f] = 0.0;
-    {
-      if (!dense) {
-        // the sum over the non-zero deltas of the window, in the order the reference adds the days; it needs nothing but
-        // the timestep and the list, so its loads travel beside the record's
-        const uint32_t* evb = reinterpret_cast<const uint32_t*>(arena + P.a_cv_events + (int64_t)e * P.cv_ev_groups * 1024);
-        const int head = ev_ht & 0xffff, tail = ev_ht >> 16;
-        const int g_lo = wave_min_i32(on ? head >> 2 : 0x7fff), g_hi = wave_max_i32(on ? (tail + 3) >> 2 : 0);
-        const uint4* evq = reinterpret_cast<const uint4*>(evb) + s;
-        // a replica's step is one dependent chain: the groups are fetched CV_BURST at a time, one memory round trip
-        // for the 32 events that cover a cool-down of two weeks or more over the whole window
-        constexpr int CV_BURST = 8;
-        for (int g0 = g_lo; g0 < g_hi; g0 += CV_BURST) {
-          uint4 qb[CV_BURST];
-#pragma unroll
-          for (int k = 0; k < CV_BURST; ++k)
-            qb[k] = (on && 4 * (g0 + k) < tail) ? evq[(g0 + k) * 64] : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-          for (int k = 0; k < CV_BURST; ++k) {
-            if (g0 + k >= g_hi) break;  // (wave-uniform)
-            const uint32_t w4[4] = {qb[k].x, qb[k].y, qb[k].z, qb[k].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int idx = 4 * (g0 + k) + j, tau = (int)(w4[j] & 0xffffu);
-              const bool live = on && idx >= head && idx < tail;
-              if (live && tau <= t) ev_expired += 1;  // left the window (at most one per step: the days are distinct)
-              if (live && tau > t) {
-                const double d = (double)((int)(w4[j] << 8) >> 24);
-                const TapT* tp = taps + (tau - t) * F;  // tap l = tau - t - 1 lives in row l + 1
-#pragma unroll
-                for (int f = 0; f < F; ++f) acc_ev[f] = __builtin_fma(d, (double)tp[f], acc_ev[f]);
-              }
-            }
-          }
-        }
-      }
-    }
-    // (1) the change events: acc_ev = the sum over the window's earlier non-zero deltas; today's change is the window's last day
-    const int d_new_i = a.level - prev_level;
-    if (!dense) {
-      int32_t* htrow = reinterpret_cast<int32_t*>(rec + P.o_cv_ev_ht);
-      uint32_t* evb = reinterpret_cast<uint32_t*>(arena + P.a_cv_events + (int64_t)e * P.cv_ev_groups * 1024);
-      const int head = ev_ht & 0xffff, tail = ev_ht >> 16, cap = 4 * P.cv_ev_groups;
-      const bool grow = on && d_new_i != 0;
-#pragma unroll
-      for (int f = 0; f < F; ++f) acc[f] = acc_ev[f];
-      if (__ballot(grow && tail >= cap) != 0ull) {
-        // a state's list is full: from this step to the next reset the replica streams its whole window
-        dense = 1;
-        flush_now = true;
-        if (s == 0) *reinterpret_cast<int32_t*>(rec + P.o_cv_dense) = 1;
-      } else {
-        if (grow) evb[((tail >> 2) * 64 + s) * 4 + (tail & 3)] = (uint32_t)(L + t) | ((uint32_t)(d_new_i & 0xff) << 16);
-        if (on) htrow[s] = (head + ev_expired) | ((tail + (grow ? 1 : 0)) << 16);
-        // today's change (history day L + t, tap L - 1) is the window's last day
-        if (on) {
-          const double d = (double)d_new_i;
-          const TapT* tp = taps + L * F;
-#pragma unroll
-          for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, (double)tp[f], acc[f]);
-        }
-      }
-    }
-    if (flush_now) {  // the current chunk's days so far, from the ring (the dense sums below and every later step read them)
-#pragma unroll
-      for (int j = 0; j < 15; ++j)
-        if (j < ((L + t) & 15)) flushw[j >> 2] |= (uint32_t)*cv_ring_at(P, rec, sl, ((L + t) & ~15) + j) << (8 * (j & 3));
-    }
-    if (dense) {  // (2) the whole window, day by day
-    const double* __restrict__ G = reinterpret_cast<const double*>(arena + P.a_cv_filters);  // [row][F]
-#pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = 0.0;
-    const int c0 = t >> 4;
-    const int c_today = (t + L) >> 4, sh_today = 8 * ((t + L) & 3), q_today = ((t + L) & 15) >> 2;
-    const int ngroups = ((L >> 4) + 2 + AIE_CV_GROUP - 1) / AIE_CV_GROUP;
-    const uint8_t* row = hist + sl * 16 + (int64_t)c0 * P.cv_row;
-    int carry = 0;
-    uint4 cur[AIE_CV_GROUP], nxt[AIE_CV_GROUP];
-#pragma unroll
-    for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = *reinterpret_cast<const uint4*>(row + (int64_t)k * P.cv_row);
-    for (int g = 0; g < ngroups; ++g) {
-      if (g + 1 < ngroups) {
-#pragma unroll
-        for (int k = 0; k < AIE_CV_GROUP; ++k)
-          nxt[k] = *reinterpret_cast<const uint4*>(row + (int64_t)((g + 1) * AIE_CV_GROUP + k) * P.cv_row);
-      }
-#pragma unroll
-      for (int k = 0; k < AIE_CV_GROUP; ++k) {
-        const int c = c0 + g * AIE_CV_GROUP + k;
-        uint32_t ww[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
-        if (c == c_today) {  // today's level is still in registers: patch it into the stream
-          if (flush_now) {   // ... and so are the chunk's earlier days in the step that turns the replica dense
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ww[q] = flushw[q];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q == q_today) ww[q] = (ww[q] & ~(0xffu << sh_today)) | ((uint32_t)a.level << sh_today);
-        }
-        // wave-uniform pointer into the read-only tap table -> s_load through the scalar cache
-        cv_tap_ptr g0 = (cv_tap_ptr)(uintptr_t)(G + (int64_t)(16 * c - t - 1 + AIE_CV_TAP_PAD_FRONT) * F);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int lev = (int)((ww[j >> 2] >> (8 * (j & 3))) & 0xffu);
-          const double d = (double)(lev - carry);
-          carry = lev;
-#pragma unroll
-          for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, g0[j * F + f], acc[f]);
-          // 16*F doubles of taps per chunk do not fit the SGPR file: tie the pointer to the
-          // accumulator every 4 days so that only 4*F taps are fetched ahead of their use
-          if ((j & 3) == 3) {
-#pragma unroll
-            for (int f = 0; f < F; ++f) asm volatile("" : "+s"(g0), "+v"(acc[f]));
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < AIE_CV_GROUP; ++k) cur[k] = nxt[k];
-    }
-    }
-  }
-  if constexpr (!RECUR) CV_LOAD_STATE();
   a.cooldown = cool0;
   if (t == a.cooldown + 1) a.cooldown += act == 0 ? 1 : V.action_cooldown_period;
 
@@ -586,6 +635,16 @@ __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ para
         acc[f] = r * (accs[f * PT + sl] - V.filter_tail[f] * d_old) + d_new;
         if (on) accs[f * PT + s] = acc[f];
       }
+    } else {
+      // window sums: the sums over the window's earlier days are in the record (aie_covid_window_kernel left them there
+      // behind the previous step; reset for the first); today's change (history day L + t, tap L - 1) is the window's
+      // last day
+      const double* accs = reinterpret_cast<const double*>(rec + P.o_cv_acc);
+      const double d = (double)(a.level - prev_level);
+      cv_tap_ptr tp = (cv_tap_ptr)(uintptr_t)(reinterpret_cast<const double*>(arena + P.a_cv_filters) +
+                                              (int64_t)(AIE_CV_TAP_PAD_FRONT + L - 1) * F);  // (one row, the same for every lane)
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[f] = __builtin_fma(d, tp[f], accs[f * PT + sl]);
     }
     double x = 0.0;
 #pragma unroll
@@ -597,6 +656,7 @@ __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ para
     if (V.replay_data) unemployed = rws[5 * rw_plane + (int64_t)t * 64 + sl];  // :815-818 (not clamped)
     a.U = (float)unemployed;
   }
+
 
   // ---- economy_step :1444-1475 ----
   {
@@ -615,22 +675,13 @@ __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ para
   // sums stream -- gets today's byte every step only when those sums run (51 one-byte stores spread over 816 bytes:
   // seven partly written lines a step); the recurrence writes a state's 16 bytes once their chunk is complete
   *cv_ring_at(P, rec, s, L + t) = on ? (uint8_t)a.level : (uint8_t)0;
-  if (!CV_SKIP(P, 1)) {
-    if (!RECUR && dense && !flush_now) {
-      if (on) *cv_hist_at(P, hist, s, L + t) = (uint8_t)a.level;
-    } else if (flush_now) {  // the replica turned dense in this step: the open chunk's days so far and today's, in one piece
-      uint32_t w[4] = {flushw[0], flushw[1], flushw[2], flushw[3]};
-      w[((L + t) & 15) >> 2] |= (uint32_t)a.level << (8 * ((L + t) & 3));
-      if (s * 16 < P.cv_row)
-        *reinterpret_cast<uint4*>(hist + (int64_t)((L + t) >> 4) * P.cv_row + s * 16) = on ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
-    } else if (((L + t) & 15) == 15) {
-      uint32_t w[4] = {0u, 0u, 0u, 0u};
+  if (RECUR && !CV_SKIP(P, 1) && ((L + t) & 15) == 15) {  // (window sums: the tail writes the long history)
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int j = 0; j < 15; ++j) w[j >> 2] |= (uint32_t)*cv_ring_at(P, rec, sl, L + t - 15 + j) << (8 * (j & 3));
-      w[3] |= (uint32_t)a.level << 24;
-      if (s * 16 < P.cv_row)
-        *reinterpret_cast<uint4*>(hist + (int64_t)((L + t) >> 4) * P.cv_row + s * 16) = on ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
-    }
+    for (int j = 0; j < 15; ++j) w[j >> 2] |= (uint32_t)*cv_ring_at(P, rec, sl, L + t - 15 + j) << (8 * (j & 3));
+    w[3] |= (uint32_t)a.level << 24;
+    if (s * 16 < P.cv_row)
+      *reinterpret_cast<uint4*>(hist + (int64_t)((L + t) >> 4) * P.cv_row + s * 16) = on ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
   }
   if (on) {
     cool[s] = a.cooldown;
@@ -722,37 +773,57 @@ __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ para
       for (int j = s; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, e, j, next.a, next.p);
     }
   }
+  // window sums: aie_covid_window_kernel, launched behind this one, records today's change and forms the next step's sums
+  if constexpr (!RECUR)
+    if (s == 0) *reinterpret_cast<int32_t*>(rec + P.o_cv_tail_pending) = 1;
 }
 
 #undef CV_LOAD_STATE
+#undef CV_LOAD_ACCUMULATORS
 
-// recurrence (filter_recurrence): one replica per workgroup; window sums: AIE_CV_WIN_WAVES replicas per workgroup
-template <int F, bool RECUR, typename TapT = double>
-__global__ void __launch_bounds__(RECUR ? AIE_NT : AIE_CV_WIN_WAVES * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+// One replica per workgroup (one wavefront).
+template <int F, bool RECUR>
+__global__ void __launch_bounds__(AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     aie_covid_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                           const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
-  if constexpr (RECUR) {
-    __shared__ float red[3][64];
-    cv_step_body<F, true, double>(params, arena, act_a, act_p, next, aie::replica_of_block((int)blockIdx.x, params->E),
-                                  (int)threadIdx.x, red, nullptr);
-  } else {
-    // window sums: AIE_CV_WIN_WAVES replicas (one wavefront each) per workgroup share an LDS copy of the filter taps --
-    // [1 + filter_len][F], row 0 zero -- which the sums over the change events index per lane
-    extern __shared__ __attribute__((aligned(16))) uint8_t cv_lds[];
-    const aie_params& P = *params;
-    TapT* taps = reinterpret_cast<TapT*>(cv_lds);
-    const int rows = P.cv_L + 1;
-    float (*red)[64] = reinterpret_cast<float (*)[64]>(cv_lds + (((size_t)rows * F * sizeof(TapT) + 255) & ~(size_t)255)) + 3 * (threadIdx.x >> 6);
-    const double* G = reinterpret_cast<const double*>(arena + P.a_cv_filters) + (int64_t)(AIE_CV_TAP_PAD_FRONT - 1) * F;
-    for (int q = (int)threadIdx.x; q < rows * F; q += AIE_CV_WIN_WAVES * AIE_NT) taps[q] = (TapT)G[q];  // (row PAD_FRONT - 1 is a zero row)
-    __syncthreads();
-    const int b = (int)blockIdx.x * AIE_CV_WIN_WAVES + (int)(threadIdx.x >> 6);
-    if (b >= P.E) return;
-    cv_step_body<F, false, TapT>(params, arena, act_a, act_p, next, aie::replica_of_block(b, P.E), (int)(threadIdx.x & 63),
-                                 red, taps);
-  }
+  __shared__ float red[3][64];
+  cv_step_body<F, RECUR>(params, arena, act_a, act_p, next, aie::replica_of_block((int)blockIdx.x, params->E),
+                         (int)threadIdx.x, red);
+}
+
+// Window sums (filter_recurrence off): the second launch of a step.  AIE_CV_WIN_WAVES replicas (one wavefront each) per
+// workgroup share an LDS copy of the filter taps -- [1 + filter_len][F], row 0 zero -- which the sums over the change
+// events index per lane.  TapT: double, or float when every uploaded tap is a float32 value (the reference's are:
+// covid19_env.py:242-247 builds them in float32) -- the same numbers in half the LDS bytes and with odd-dword rows, i.e.
+// per-lane reads of different rows spread over all 64 banks instead of colliding on 32 bank pairs.
+template <int F, typename TapT>
+__global__ void __launch_bounds__(AIE_CV_WIN_WAVES * AIE_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+    aie_covid_window_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena) {
+  using namespace aie;
+  extern __shared__ __attribute__((aligned(16))) uint8_t cv_lds[];
+  const aie_params& P = *params;
+  const int b = (int)blockIdx.x * AIE_CV_WIN_WAVES + (int)(threadIdx.x >> 6);
+  const int e = replica_of_block(b < P.E ? b : 0, P.E), s = (int)(threadIdx.x & 63);
+  uint8_t* rec = arena + P.a_records + (int64_t)e * P.rec_bytes;
+  // this wave's loads go out ahead of the table copy: the step just taken (pending flag), the streaming flag, the
+  // state's list head / tail, today's and yesterday's level (the recent-days ring)
+  const int n = P.n, L = P.cv_L;
+  const int sl = s < n ? s : n - 1;
+  const int pending = b < P.E ? uni(*reinterpret_cast<const int32_t*>(rec + P.o_cv_tail_pending)) : 0;
+  const int t = uni(*reinterpret_cast<const int32_t*>(rec + P.o_timestep));
+  const int dense = uni(*reinterpret_cast<const int32_t*>(rec + P.o_cv_dense));
+  const int ev_ht = reinterpret_cast<const int32_t*>(rec + P.o_cv_ev_ht)[sl];
+  const int level = *cv_ring_at(P, rec, sl, L + t), prev_level = *cv_ring_at(P, rec, sl, L + t - 1);
+  TapT* taps = reinterpret_cast<TapT*>(cv_lds);
+  const int rows = L + 1;
+  const double* G = reinterpret_cast<const double*>(arena + P.a_cv_filters) + (int64_t)(AIE_CV_TAP_PAD_FRONT - 1) * F;
+  for (int q = (int)threadIdx.x; q < rows * F; q += AIE_CV_WIN_WAVES * AIE_NT) taps[q] = (TapT)G[q];  // (row PAD_FRONT - 1 is a zero row)
+  __syncthreads();
+  if (!pending) return;  // the step launch did nothing for this replica (episode over, or past the batch)
+  if (s == 0) *reinterpret_cast<int32_t*>(rec + P.o_cv_tail_pending) = 0;
+  cv_window_tail<F, TapT>(P, arena, rec, cv_hist_base(P, arena, e), e, s, t, level, prev_level, dense, ev_ht, taps);
 }
 // dynamic LDS of the window-sum kernel
 __host__ __device__ inline size_t aie_covid_win_lds_bytes(const aie_params& P, size_t tap_bytes) {
-  return (((size_t)(P.cv_L + 1) * P.cv_F * tap_bytes + 255) & ~(size_t)255) + (size_t)AIE_CV_WIN_WAVES * 3 * 64 * 4;
+  return ((size_t)(P.cv_L + 1) * P.cv_F * tap_bytes + 255) & ~(size_t)255;
 }

@@ -176,8 +176,9 @@ typedef struct aie_params {
   int32_t o_cv_ring;     /* record: uint8 [32][64]: the stringency levels of the 32 most recent days, row = (filter_len + day) & 31,
                           * one 64-byte row per day (what a step reads of the recent past -- yesterday, beta_delay days
                           * ago, the lagged observation -- and writes for today are single rows, not 51 scattered bytes) */
-  int32_t o_cv_acc;      /* record: float64 [F] rows of 64 lanes: each filter's discounted sum of stringency deltas
-                          * over the current window (filter_recurrence), else unused       */
+  int32_t o_cv_acc;      /* record: float64 [F] rows of n lanes: filter_recurrence: each filter's discounted sum of stringency
+                          * deltas over the current window; else: each filter's sum over the NEXT step's window without that
+                          * step's own day, formed by the tail of the previous step (or by reset) */
   /* window sums (filter_recurrence == 0) over the NON-ZERO level changes only: per replica and state the change events
    * (history day tau, delta) of the episode so far + the pre-episode days, oldest first.  A day without a change adds
    * fma(0, tap, acc) == acc to the reference's sum, so the sum over the events in the same order is the SAME float64,
@@ -186,7 +187,7 @@ typedef struct aie_params {
   int32_t cv_ev_groups;  /* capacity of a state's event list in groups of 4 (0: filter_recurrence)                */
   int32_t o_cv_ev_ht;    /* record: int32 row: head | tail << 16 of every state's list                           */
   int32_t o_cv_dense;    /* record: int32: 1 = this replica streams the whole window (list overflow)              */
-  int32_t cv_pad2_;
+  int32_t o_cv_tail_pending; /* record: int32: the step kernel took a step that aie_covid_window_kernel has to follow up  */
   int64_t a_cv_events;   /* uint32 [E][cv_ev_groups][64 lanes][4]: tau | (delta & 0xff) << 16                     */
   int64_t a_cv_ev0;      /* shared: the pre-episode days' lists in the same format, then int32 [64] head/tail row,
                           * then int32 dense flag (a pre-episode list overflowed); aie_covid_prepare_kernel       */
@@ -195,7 +196,8 @@ typedef struct aie_params {
   int64_t a_cv_hist0;    /* uint8 [L+1][n]   stringency levels of the L days before t=0 + t=0 */
   int64_t a_cv_hist0c;   /* uint8 [nch][cv_row]: the same days in the per-replica history format (what reset copies);
                           * derived from a_cv_hist0 by aie_covid_prepare_kernel whenever that table is uploaded  */
-  int64_t a_cv_acc0;     /* float64 [F][64]: every filter's discounted delta sum at t = 0 (filter_recurrence), ditto */
+  int64_t a_cv_acc0;     /* float64 [F][64]: what reset puts into o_cv_acc (recurrence: A_0; window sums: step 1's sums over
+                          * the pre-episode days), ditto */
   int64_t a_cv_lag_obs;  /* uint8 [beta_delay][n]                                          */
   int64_t a_cv_replay_a; /* uint8 [T][64]: replay_policies: the states' stringency action of step t in row t - 1 */
   int64_t a_cv_replay_p; /* int32 [T]: replay_policies: the planner's subsidy level of step t at t - 1            */
@@ -425,11 +427,12 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   p->o_cv_state = aie__rec(&cur, 4 * n * AIE_CV_ST_COUNT, 256);
   p->o_cv_cooldown = aie__rec(&cur, 4 * n, 4);
   p->o_cv_sums = aie__rec(&cur, 8 * n * AIE_CV_SUM_COUNT, 8);
-  p->o_cv_acc = aie__rec(&cur, 8 * n * (v->filter_recurrence ? v->num_filters : 0), 8);
+  p->o_cv_acc = aie__rec(&cur, 8 * n * v->num_filters, 8);  /* recurrence: A_t; window sums: the coming step's sums over the days before its own */
   p->o_cv_ring = aie__rec(&cur, 32 * 64, 256);
   p->cv_ev_groups = v->filter_recurrence ? 0 : AIE_CV_EVENT_CAP / 4;
   p->o_cv_ev_ht = aie__rec(&cur, p->cv_ev_groups ? 4 * n : 0, 4);
   p->o_cv_dense = aie__rec(&cur, 4, 4);
+  p->o_cv_tail_pending = aie__rec(&cur, 4, 4);
   p->o_cv_subsidy_level = aie__rec(&cur, 4, 4);
   p->o_cv_p_index = aie__rec(&cur, 8, 4);
   p->o_timestep = aie__rec(&cur, 4, 4);
@@ -475,10 +478,11 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
     for (int k = 0; k < AIE_CV_SUM_COUNT; ++k)
       aie__add(tt, sum_name[k], AIE_F64, r0 + p->o_cv_sums + 8 * n * k, rs, 1, n, 0, 0, 0, E);
     aie__add(tt, "planner_health_economic_index", AIE_F32, r0 + p->o_cv_p_index, rs, 1, 2, 0, 0, 0, E);
-    if (v->filter_recurrence) {
-      aie__add(tt, "filter_discounted_delta_sums", AIE_F64, r0 + p->o_cv_acc, rs, 2, p->cv_F, n, 0, 0, E);
-      tt->t[tt->n - 1].stride[1] = 8 * n;
-    }
+    /* recurrence: each filter's discounted delta sum A_t; window sums: each filter's sum over the NEXT step's window
+     * without that step's own day (formed at the end of a step, when the registers are free; the step adds its day) */
+    aie__add(tt, v->filter_recurrence ? "filter_discounted_delta_sums" : "filter_window_sums_before_today", AIE_F64,
+             r0 + p->o_cv_acc, rs, 2, p->cv_F, n, 0, 0, E);
+    tt->t[tt->n - 1].stride[1] = 8 * n;
     for (int k = 0; k < AIE_CV_ST_COUNT; ++k)
       aie__add(tt, st_name[k], AIE_F32, r0 + p->o_cv_state + 4 * n * k, rs, 1, n, 0, 0, 0, E);
     aie__add(tt, "cooldown_until", AIE_I32, r0 + p->o_cv_cooldown, rs, 1, n, 0, 0, 0, E);

@@ -560,10 +560,12 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
         elif wl.startswith("C4"):
             import numpy as np
 
+            # window sums: two launches per step (the step, then the change-event lists' upkeep and the next step's sums)
             taps = np.asarray(env.model["unemp_conv_filters"], np.float64)
             tap_t = "float" if np.array_equal(taps.astype(np.float32).astype(np.float64), taps) else "double"
-            kernel_name = ("aie_covid_step_kernel<%d, false, %s>" % (env.model["num_filters"], tap_t) if env.exact_filter_sums
-                           else "aie_covid_step_kernel<%d, true, double>" % env.model["num_filters"])
+            nf = env.model["num_filters"]
+            kernel_name = ("aie_covid_step_kernel<%d, false> + aie_covid_window_kernel<%d, %s>" % (nf, nf, tap_t)
+                           if env.exact_filter_sums else "aie_covid_step_kernel<%d, true>" % nf)
         traffic_frac = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None
         insts, insts_src, valu_insts = issue_counters(wl)
         issue_frac = (insts / (N_SIMDS * SM_CLOCK_HZ * avg_ms * 1e-3)) if (insts and E == W["envs"]) else None
