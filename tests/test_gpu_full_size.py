@@ -224,3 +224,121 @@ def test_c1_uniform_layouts_drawn_on_device_full_batch():
         if (t + 1) % 6 == 0:
             _compare_all(be, oracle, "C1 step %d" % (t + 1))
     assert int(be.tensors["completions"].min()) == 2
+
+
+def _drive_rollout_against_oracle(wl, E, timed_steps, compare_every):
+    """bench.Rollout -- the very object bench.py times -- with its backend calls mirrored on the CPU oracle: every action
+    pair a step launch consumed (the fused draws of aie_step_sample_next included), every masked block reset, in order."""
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    from oracle_lib import OracleEnv
+    from test_gpu_parity import _compare_all
+
+    W = bench.WORKLOADS[wl]
+    env = bench.make_env(W["cfg"](), n_envs=E, device="cuda:0")
+    env.seed(bench.ENV_SEED)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(bench.ENV_SEED)
+    oracle.reset()
+    roll = bench.Rollout(wl, env, 0)
+    calls = []
+    real_step, real_reset = be.step_sample_next, be.reset
+
+    def spy_step(a, p, *args, **kw):
+        torch.cuda.synchronize()
+        calls.append(("step", a.cpu().numpy().copy(), p.cpu().numpy().copy()))
+        return real_step(a, p, *args, **kw)
+
+    def spy_reset(mask=None):
+        calls.append(("reset", None if mask is None else mask.cpu().numpy().astype(np.uint8).copy()))
+        return real_reset(mask)
+
+    be.step_sample_next, be.reset = spy_step, spy_reset
+    auto = roll.auto_reset
+
+    def replay():
+        for kind, x, *rest in calls:
+            if kind == "step":
+                oracle.step(x, rest[0], nthreads=8)
+                if auto:  # aie_set_auto_reset: the replicas a step finishes restart behind it
+                    d = oracle.t["done"].astype(np.uint8).copy()
+                    if d.any():
+                        rew_a, rew_p = oracle.t["rewards_a"].copy(), oracle.t["rewards_p"].copy()
+                        oracle.reset(d)
+                        oracle.t["done"][:] = d  # (the terminal step's rewards and done stay)
+                        oracle.t["rewards_a"][:] = rew_a
+                        oracle.t["rewards_p"][:] = rew_p
+            else:
+                oracle.reset(x)
+        calls.clear()
+
+    n_prologue = roll.prologue()
+    replay()
+    torch.cuda.synchronize()
+    _compare_all(be, oracle, "%s after the de-phasing prologue (%d steps)" % (wl, n_prologue))
+    if not auto:
+        roll.warm_reset_path()
+    resets_seen = 0
+    for k in range(1, timed_steps + 1):
+        roll.step(timed=True)
+        resets_seen += sum(1 for c in calls if c[0] == "reset" and c[1] is not None and c[1].any())
+        if k % compare_every == 0 or k == timed_steps:
+            replay()
+            torch.cuda.synchronize()
+            _compare_all(be, oracle, "%s timed path, step %d" % (wl, k))
+    return roll, resets_seen
+
+
+def test_bench_rollout_path_matches_oracle_c2():
+    """the timed path of bench.py as a whole -- staggered prologue, masked block resets on the host-known
+    schedule, one aie_step_sample_next launch per step -- against the oracle: BASELINE configs[1], 512 replicas, the
+    1000-step prologue plus 60 steps of the timed loop (three block resets), every tensor every 10 steps."""
+    roll, resets = _drive_rollout_against_oracle("C2", 512, 60, 10)
+    assert roll.G == 50 and roll.fused and resets >= 3
+
+
+def test_bench_rollout_path_matches_oracle_c5():
+    """The same for BASELINE configs[4] (one-step-economy, auto-reset: a replica restarts inside the step launch that
+    ends its 2-step episode)."""
+    roll, _ = _drive_rollout_against_oracle("C5", 256, 12, 2)
+    assert roll.auto_reset and roll.G == 1
+
+
+def test_c2_full_batch_crosses_an_episode_end_on_the_compile_time_instance():
+    """4096 replicas of BASELINE configs[1] with a shortened episode (60 steps: the instance's family
+    covers it, episode_length is read from the run-time block) across two episode ends, reset by the `done` mask --
+    step and reset kernels of the compile-time instance against the oracle, every field of every replica."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    E, T, EP = 4096, 130, 60
+    cfg = dict(C2, episode_length=EP)
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(2)
+    env.reset()
+    be = env.backend
+    assert be.lib.aie_step_kernel_instance(be.handle) >= 0, "the shortened episode must stay in C2's instance family"
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(2)
+    oracle.reset()
+    for t in range(T):
+        a, p = be.sample_random_actions(seed=99)
+        be.step(a, p)
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=NTHREADS)
+        if (t + 1) % EP == 0:
+            _compare_all(be, oracle, "terminal step %d" % (t + 1))
+            assert bool(be.tensors["done"].all())
+            be.reset(be.tensors["done"])
+            oracle.reset(np.ones(E, np.uint8))
+            torch.cuda.synchronize()
+            _compare_all(be, oracle, "reset after step %d" % (t + 1))
+        elif (t + 1) % 10 == 0 or (t + 1) % EP == 1:
+            _compare_all(be, oracle, "step %d" % (t + 1))
+    assert int(be.tensors["completions"].min()) == 2
