@@ -14,7 +14,7 @@
 #include "aie_jit.h"
 
 struct aie_env {
-  aie_params P;
+  aie_params P{};
   aie_params* d_params;  // device copy of P (kernel parameter block)
   aie_tensor_table tt;
   uint8_t* arena;
@@ -25,6 +25,8 @@ struct aie_env {
   int spec_match;  // the instance that matches the configuration (what AIE_KERNEL_AUTO selects), or -1
   hipModule_t jit_mod;              // aie_specialize: the code object compiled for this configuration, or nullptr
   hipFunction_t jit_step, jit_reset;  // its entry points; the environment then runs as instance AIE_KERNEL_INSTANCE_JIT
+  std::shared_ptr<aie_jit::Job> jit_job;  // the background specialisation aie_create started, until its code is loaded
+  int pinned_generic;    // aie_select_step_kernel(AIE_KERNEL_GENERIC): stay on the generic kernel, whatever becomes ready
   int64_t sample_t;
   float* rew_log;        // aie_set_reward_log: caller's ring of n_slots step slots, or nullptr
   int32_t rew_log_slots, rew_log_next;
@@ -35,6 +37,9 @@ struct aie_env {
 };
 
 static thread_local char g_create_err[512] = "";
+static inline void aie_jit_poll(aie_env* env);  // adopts the background specialisation once it is ready (below)
+static bool aie_jit_eligible(const aie_env* env);
+static int aie_jit_request(aie_env* env);
 
 #define AIE_DEV_API __attribute__((visibility("default")))
 
@@ -90,8 +95,7 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
     snprintf(g_create_err, sizeof(g_create_err), "null argument");
     return AIE_E_INVALID;
   }
-  aie_env* env = new aie_env();
-  memset(env, 0, sizeof(*env));
+  aie_env* env = new aie_env();  // (value-initialised: every plain member zero)
   int rc = aie_build_params(cfg, &env->P, &env->tt, g_create_err, sizeof(g_create_err));
   if (rc != AIE_OK) { delete env; return rc; }
   env->device = device;
@@ -167,6 +171,11 @@ int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_byt
     return AIE_E_HIP;
   }
   for (int i = 0; i < env->tt.n; ++i) env->tt.t[i].data = env->arena + env->tt.t[i].arena_offset;
+  // no compile-time instance for this configuration's family: kernels specialised on it are compiled (or fetched from
+  // the cache) in the background, the generic kernel runs until they are ready.  AIE_JIT_AUTO=0 switches this off
+  // (aie_specialize still does it on request).
+  const char* auto_jit = getenv("AIE_JIT_AUTO");
+  if (env->spec < 0 && aie_jit_eligible(env) && !(auto_jit && auto_jit[0] == '0')) (void)aie_jit_request(env);
   *out = env;
   return AIE_OK;
 }
@@ -351,6 +360,7 @@ static void aie_launch_gtb_reset(aie_env* env, const uint8_t* d_mask, int keep_r
 
 int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
   if (!env) return AIE_E_INVALID;
+  aie_jit_poll(env);
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   if (env->P.c.scenario == AIE_SCN_COVID)
     hipLaunchKernelGGL(aie_covid_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0,
@@ -415,6 +425,7 @@ int aie_step_sample_next_masked(aie_env* env, const int32_t* d_actions_a, const 
 static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream,
                          const NextActions& next_in) {
   if (!env) return AIE_E_INVALID;
+  aie_jit_poll(env);
   NextActions next = next_in;
   if (env->rew_log) {  // this step's slot of the reward log (aie_set_reward_log)
     next.rew_log = env->rew_log + (int64_t)env->rew_log_next * env->P.E * (env->P.n + 2);
@@ -605,12 +616,88 @@ int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_of
 // Which step kernel runs this environment: >= 0 = compile-time instance (index into aie_spec_generated.h), -1 = generic.
 int aie_step_kernel_instance(aie_env* env) { return env ? env->spec : -2; }
 
+// ---- run-time specialisation (aie_jit.h): requested in the background by aie_create, adopted at a step boundary ----
+static bool aie_jit_eligible(const aie_env* env) {
+  const aie_params& P = env->P;
+  const bool ose = P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY;
+  return !(P.c.scenario == AIE_SCN_COVID || P.saez_stride || (!ose && (P.M > AIE_NT || P.regen_general)));
+}
+// starts (or joins) the background job that compiles / fetches the code object of this environment's family
+static int aie_jit_request(aie_env* env) {
+  if (env->jit_job) return AIE_OK;
+  hipDeviceProp_t prop;
+  AIE_HIP_CHECK(env, hipGetDeviceProperties(&prop, env->device));
+  std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
+  arch = arch.substr(0, arch.find(':'));
+  std::vector<aie_params> norm(1, env->P);  // (not static: environments specialise from different threads)
+  aie_spec_normalize(&norm[0]);
+  const bool ose = env->P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY;
+  const int wg = aie_workgroups_per_cu(env->lds);
+  // gather-trade-build: two waves per workgroup on four SIMDs; one-step-economy: one wave per workgroup
+  const int waves = ose ? (wg >= 16 ? 4 : wg >= 12 ? 3 : 2) : ((2 * wg + 3) / 4 < 8 ? (2 * wg + 3) / 4 : 8);
+  env->jit_job = aie_jit::start_job(&norm[0], sizeof(aie_params), waves, arch.c_str(), ose);
+  return AIE_OK;
+}
+static bool aie_jit_load(aie_env* env, const std::string& code, bool ose) {
+  hipModule_t mod = nullptr;
+  hipFunction_t fs = nullptr, fr = nullptr;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess ||
+      hipModuleGetFunction(&fs, mod, ose ? "aie_jit_ose_step" : "aie_jit_step") != hipSuccess ||
+      (!ose && hipModuleGetFunction(&fr, mod, "aie_jit_reset") != hipSuccess)) {
+    if (mod) (void)hipModuleUnload(mod);
+    (void)hipGetLastError();
+    return false;
+  }
+  env->jit_mod = mod;
+  env->jit_step = fs;
+  env->jit_reset = fr;
+  return true;
+}
+// If the job has finished: load its code object and, unless the caller pinned the generic kernel, switch to it.  Called
+// at the top of aie_step / aie_reset (a launch boundary: the kernels are bit-identical, so the switch is invisible) and
+// by aie_specialize (wait = true).  Returns AIE_OK when the environment now has its specialised kernels.
+static int aie_jit_adopt(aie_env* env, bool wait) {
+  if (!env->jit_job) return env->spec_match == AIE_KERNEL_INSTANCE_JIT ? AIE_OK : AIE_E_UNSUPPORTED;
+  std::shared_ptr<aie_jit::Job> job = env->jit_job;
+  int st = job->state.load(std::memory_order_acquire);
+  while (wait && st == 0) {
+    usleep(2000);
+    st = job->state.load(std::memory_order_acquire);
+  }
+  if (st == 0) return AIE_E_UNSUPPORTED;  // still compiling: the generic kernel carries on
+  env->jit_job.reset();
+  if (st < 0) {
+    snprintf(env->err, sizeof(env->err), "aie_specialize: %s", job->err.c_str());
+    return AIE_E_UNSUPPORTED;
+  }
+  (void)hipSetDevice(env->device);
+  bool ok = aie_jit_load(env, job->code, job->ose);
+  if (!ok) {
+    // a cached code object that does not load (another toolchain, a damaged file): drop it and compile once more
+    std::string code, err;
+    if (aie_jit::code_object(job->image.data(), job->image.size(), job->waves, job->arch.c_str(), job->ose, code, err, nullptr,
+                             /*ignore_cache=*/true))
+      ok = aie_jit_load(env, code, job->ose);
+  }
+  if (!ok) {
+    snprintf(env->err, sizeof(env->err), "aie_specialize: the compiled code object could not be loaded");
+    return AIE_E_UNSUPPORTED;
+  }
+  env->spec_match = AIE_KERNEL_INSTANCE_JIT;
+  if (!env->pinned_generic) env->spec = AIE_KERNEL_INSTANCE_JIT;
+  return AIE_OK;
+}
+static inline void aie_jit_poll(aie_env* env) {
+  if (env->jit_job && env->jit_job->state.load(std::memory_order_acquire) != 0) (void)aie_jit_adopt(env, false);
+}
+
 int aie_select_step_kernel(aie_env* env, int which) {
   if (!env) return AIE_E_INVALID;
   if (which != AIE_KERNEL_AUTO && which != AIE_KERNEL_GENERIC) {
     snprintf(env->err, sizeof(env->err), "aie_select_step_kernel: unknown kernel %d", which);
     return AIE_E_INVALID;
   }
+  env->pinned_generic = which == AIE_KERNEL_GENERIC;
   env->spec = which == AIE_KERNEL_GENERIC ? -1 : env->spec_match;
   return AIE_OK;
 }
@@ -620,47 +707,18 @@ int aie_specialize(aie_env* env) {
   // already on a specialised kernel (a compile-time instance, or an earlier call); AIE_JIT_FORCE=1 compiles anyway
   // (A/B of a run-time against a compile-time instance, tools/jit_timing.py)
   if (env->spec_match >= 0 && !(getenv("AIE_JIT_FORCE") && env->spec_match != AIE_KERNEL_INSTANCE_JIT)) {
-    env->spec = env->spec_match;
+    if (!env->pinned_generic) env->spec = env->spec_match;
     return AIE_OK;
   }
-  const aie_params& P = env->P;
-  const bool ose = P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY;
-  if (P.c.scenario == AIE_SCN_COVID || P.saez_stride || (!ose && (P.M > AIE_NT || P.regen_general))) {
+  if (!aie_jit_eligible(env)) {
     snprintf(env->err, sizeof(env->err), "aie_specialize: this configuration runs the full-featured step kernel (tax_model "
              "\"saez\", order books beyond a wavefront, general regeneration) or is the COVID scenario");
     return AIE_E_UNSUPPORTED;
   }
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
-  hipDeviceProp_t prop;
-  AIE_HIP_CHECK(env, hipGetDeviceProperties(&prop, env->device));
-  std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
-  arch = arch.substr(0, arch.find(':'));
-  std::vector<aie_params> norm_v(1, env->P);  // (not static: two environments may specialise from different threads)
-  aie_params& norm = norm_v[0];
-  aie_spec_normalize(&norm);
-  const int wg = aie_workgroups_per_cu(env->lds);
-  // gather-trade-build: two waves per workgroup on four SIMDs; one-step-economy: one wave per workgroup
-  const int waves = ose ? (wg >= 16 ? 4 : wg >= 12 ? 3 : 2) : ((2 * wg + 3) / 4 < 8 ? (2 * wg + 3) / 4 : 8);
-  std::string code, err;
-  bool cached = false;
-  if (!aie_jit::code_object(&norm, sizeof(norm), waves, arch.c_str(), ose, code, err, &cached)) {
-    snprintf(env->err, sizeof(env->err), "aie_specialize: %s", err.c_str());
-    return AIE_E_UNSUPPORTED;
-  }
-  hipModule_t mod = nullptr;
-  hipFunction_t fs = nullptr, fr = nullptr;
-  if (hipModuleLoadData(&mod, code.data()) != hipSuccess ||
-      hipModuleGetFunction(&fs, mod, ose ? "aie_jit_ose_step" : "aie_jit_step") != hipSuccess ||
-      (!ose && hipModuleGetFunction(&fr, mod, "aie_jit_reset") != hipSuccess)) {
-    if (mod) (void)hipModuleUnload(mod);
-    snprintf(env->err, sizeof(env->err), "aie_specialize: the compiled code object could not be loaded");
-    return AIE_E_UNSUPPORTED;
-  }
-  env->jit_mod = mod;
-  env->jit_step = fs;
-  env->jit_reset = fr;
-  env->spec = env->spec_match = AIE_KERNEL_INSTANCE_JIT;
-  return AIE_OK;
+  const int rc = aie_jit_request(env);
+  if (rc != AIE_OK) return rc;
+  return aie_jit_adopt(env, /*wait=*/true);
 }
 
 #ifdef AIE_DEV

@@ -13,7 +13,14 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace aie_jit {
@@ -28,6 +35,7 @@ struct Rtc {
   int (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
   int (*GetCode)(hiprtcProgram, char*) = nullptr;
   int (*DestroyProgram)(hiprtcProgram*) = nullptr;
+  int (*Version)(int*, int*) = nullptr;
   std::string path;  // where libhiprtc.so was found (its ROCm root holds the HIP and clang headers)
 };
 
@@ -39,7 +47,7 @@ static inline bool load_rtc(Rtc& r) {
   if (!r.lib) return false;
 #define AIE_RTC_SYM(f) *reinterpret_cast<void**>(&r.f) = dlsym(r.lib, "hiprtc" #f)
   AIE_RTC_SYM(CreateProgram); AIE_RTC_SYM(CompileProgram); AIE_RTC_SYM(GetProgramLogSize); AIE_RTC_SYM(GetProgramLog);
-  AIE_RTC_SYM(GetCodeSize); AIE_RTC_SYM(GetCode); AIE_RTC_SYM(DestroyProgram);
+  AIE_RTC_SYM(GetCodeSize); AIE_RTC_SYM(GetCode); AIE_RTC_SYM(DestroyProgram); AIE_RTC_SYM(Version);
 #undef AIE_RTC_SYM
   Dl_info info;
   if (r.CreateProgram && dladdr(reinterpret_cast<void*>(r.CreateProgram), &info) && info.dli_fname) r.path = info.dli_fname;
@@ -69,18 +77,25 @@ static inline bool is_dir(const std::string& p) {
   struct stat st;
   return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
 }
-static inline void mkdirs(const std::string& p) {
+static inline void mkdirs(const std::string& p) {  // (private to the user: the files in it are code that gets loaded and run)
   for (size_t k = 1; k <= p.size(); ++k)
-    if (k == p.size() || p[k] == '/') mkdir(p.substr(0, k).c_str(), 0755);
+    if (k == p.size() || p[k] == '/') mkdir(p.substr(0, k).c_str(), 0700);
 }
+// a cache directory is only used if it belongs to this user and nobody else can write to it
+static inline bool private_dir(const std::string& p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+static const char* const kRecipe = "recipe 2: -O3 -std=c++17 -Wno-comment";  // compile options: part of the cache key
 
 static const char* const kSources[] = {"aie_kernels.hip", "aie_kernels_ose.hip", "aie_layout.h", "aie_glibc_math.h",
                                        "aie_glibc_tables.h"};
 
 // Compiles (or fetches from the cache) the code object for `image` (sizeof(aie_params) normalised bytes); `waves` =
 // waves per SIMD the kernel is compiled for.  On failure returns false with a message in `err`.
+// `ignore_cache`: compile even if a cached object exists (it failed to load) and replace it.
 static inline bool code_object(const void* image, size_t image_bytes, int waves, const char* arch, bool ose,
-                               std::string& code, std::string& err, bool* from_cache) {
+                               std::string& code, std::string& err, bool* from_cache, bool ignore_cache = false) {
   // where the sources live: beside this library (in-tree build), or AIE_JIT_SOURCE_DIR
   std::string csrc;
   if (const char* e = getenv("AIE_JIT_SOURCE_DIR")) csrc = e;
@@ -89,7 +104,13 @@ static inline bool code_object(const void* image, size_t image_bytes, int waves,
     if (dladdr(reinterpret_cast<void*>(&fnv1a), &info) && info.dli_fname) csrc = dirname_of(info.dli_fname);
   }
   std::string inc = csrc + "/../../include", text;
+  Rtc rtc;  // (loaded up front: its version is part of the key -- a code object of another toolchain is not reused)
+  const bool have_rtc = load_rtc(rtc);
+  int rtc_version[2] = {0, 0};
+  if (have_rtc && rtc.Version) (void)rtc.Version(&rtc_version[0], &rtc_version[1]);
   uint64_t h = fnv1a(1469598103934665603ull, image, image_bytes);
+  h = fnv1a(h, kRecipe, strlen(kRecipe));
+  h = fnv1a(h, rtc_version, sizeof(rtc_version));
   h = fnv1a(h, &waves, sizeof(waves));
   h = fnv1a(h, &ose, sizeof(ose));
   h = fnv1a(h, arch, strlen(arch));
@@ -103,17 +124,19 @@ static inline bool code_object(const void* image, size_t image_bytes, int waves,
   if (const char* e = getenv("AIE_JIT_CACHE")) cache = e;
   else if (const char* x = getenv("XDG_CACHE_HOME")) cache = std::string(x) + "/ai_economist_amd";
   else if (const char* home = getenv("HOME")) cache = std::string(home) + "/.cache/ai_economist_amd";
-  else cache = "/tmp/ai_economist_amd_cache";
+  else cache = "/tmp/ai_economist_amd_cache_" + std::to_string((long)geteuid());
+  mkdirs(cache);
+  const bool use_cache = private_dir(cache);  // (somebody else's or a world-writable directory: compile every time instead)
   char name[64];
   snprintf(name, sizeof(name), "/jit_%016llx.hsaco", (unsigned long long)h);
   const std::string file = cache + name;
-  if (read_file(file, code) && code.size() > 1024) {
+  if (use_cache && ignore_cache) unlink(file.c_str());
+  if (use_cache && !ignore_cache && read_file(file, code) && code.size() > 1024) {
     if (from_cache) *from_cache = true;
     return true;
   }
   if (from_cache) *from_cache = false;
-  Rtc rtc;
-  if (!load_rtc(rtc)) { err = "libhiprtc.so could not be loaded"; return false; }
+  if (!have_rtc) { err = "libhiprtc.so could not be loaded"; return false; }
   // the image as a header: exactly the shape of aie_spec_generated.h, one instance
   std::string hdr = "#pragma once\n#define AIE_N_SPECS 1\ntemplate <int K> struct aie_spec_image;\n"
                     "alignas(16) static constexpr unsigned char aie_jit_bytes[" + std::to_string(image_bytes) + "] = {";
@@ -166,14 +189,88 @@ static inline bool code_object(const void* image, size_t image_bytes, int waves,
   rtc.GetCode(prog, &code[0]);
   rtc.DestroyProgram(&prog);
   // cache it (temporary name + rename: concurrent ranks compile the same thing and race harmlessly)
-  mkdirs(cache);
+  if (!use_cache) return true;
   const std::string tmp = file + ".tmp" + std::to_string((long)getpid());
   if (FILE* f = fopen(tmp.c_str(), "wb")) {
+    (void)chmod(tmp.c_str(), 0600);
     const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
     fclose(f);
     if (!ok || rename(tmp.c_str(), file.c_str()) != 0) unlink(tmp.c_str());
   }
   return true;
+}
+
+
+// ---- background specialisation (aie_create starts one for every configuration without a compile-time instance) ----
+// A job outlives its environment if need be (the thread holds a reference): destroying an environment never waits for
+// a compiler.  At most two compile at a time; environments of the same configuration share one job.
+struct Job {
+  std::vector<unsigned char> image;
+  int waves = 0;
+  bool ose = false;
+  std::string arch, code, err;
+  std::atomic<int> state{0};  // 0 running, 1 code ready, -1 failed
+};
+struct JobTable {
+  std::mutex mu;
+  std::condition_variable cv;
+  int running = 0;
+  bool shutting_down = false;  // process exit: queued jobs give up, the exit waits for the (at most two) running ones
+  std::map<uint64_t, std::weak_ptr<Job>> jobs;
+};
+static inline JobTable& job_table() {
+  static JobTable* t = [] {
+    JobTable* tt = new JobTable();  // (never destroyed: detached threads may outlive static destructors)
+    // a compiler thread must not be running when the process tears its libraries down
+    atexit([] {
+      JobTable& T = job_table();
+      std::unique_lock<std::mutex> lock(T.mu);
+      T.shutting_down = true;
+      T.cv.notify_all();
+      T.cv.wait_for(lock, std::chrono::seconds(60), [&T] { return T.running == 0; });
+    });
+    return tt;
+  }();
+  return *t;
+}
+static inline std::shared_ptr<Job> start_job(const void* image, size_t image_bytes, int waves, const char* arch, bool ose) {
+  JobTable& T = job_table();
+  uint64_t key = fnv1a(1469598103934665603ull, image, image_bytes);
+  key = fnv1a(key, &waves, sizeof(waves));
+  key = fnv1a(key, arch, strlen(arch));
+  std::lock_guard<std::mutex> lock(T.mu);
+  auto it = T.jobs.find(key);
+  if (it != T.jobs.end())
+    if (std::shared_ptr<Job> j = it->second.lock()) return j;
+  std::shared_ptr<Job> job = std::make_shared<Job>();
+  job->image.assign(static_cast<const unsigned char*>(image), static_cast<const unsigned char*>(image) + image_bytes);
+  job->waves = waves;
+  job->ose = ose;
+  job->arch = arch;
+  T.jobs[key] = job;
+  std::thread([job]() {
+    JobTable& T = job_table();
+    {
+      std::unique_lock<std::mutex> lock(T.mu);
+      T.cv.wait(lock, [&T] { return T.running < 2 || T.shutting_down; });
+      if (T.shutting_down) {
+        job->err = "process exit";
+        job->state.store(-1, std::memory_order_release);
+        return;
+      }
+      T.running += 1;
+    }
+    bool cached = false;
+    const bool ok = code_object(job->image.data(), job->image.size(), job->waves, job->arch.c_str(), job->ose, job->code,
+                                job->err, &cached);
+    {
+      std::lock_guard<std::mutex> lock(T.mu);
+      T.running -= 1;
+    }
+    T.cv.notify_all();
+    job->state.store(ok ? 1 : -1, std::memory_order_release);
+  }).detach();
+  return job;
 }
 
 }  // namespace aie_jit

@@ -1024,6 +1024,7 @@ def test_runtime_specialisation_equals_generic_kernel(case):
     pair = [make_env(cfg, n_envs=384, device="cuda:0") for _ in range(2)]
     b_jit, b_ref = pair[0].backend, pair[1].backend
     assert b_jit.lib.aie_step_kernel_instance(b_jit.handle) == -1, "the case must not have a compile-time instance"
+    assert b_ref.lib.aie_select_step_kernel(b_ref.handle, 1) == 0  # pinned: the background specialisation must not swap in
     assert pair[0].specialize(required=True)
     assert b_jit.lib.aie_step_kernel_instance(b_jit.handle) == 1000 and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == -1
     for env in pair:
@@ -1045,7 +1046,46 @@ def test_runtime_specialisation_equals_generic_kernel(case):
     # the switch works both ways, and a second environment of the same configuration finds the cached code object
     assert b_jit.lib.aie_select_step_kernel(b_jit.handle, 1) == 0 and b_jit.lib.aie_step_kernel_instance(b_jit.handle) == -1
     assert b_jit.lib.aie_select_step_kernel(b_jit.handle, 0) == 0 and b_jit.lib.aie_step_kernel_instance(b_jit.handle) == 1000
-    assert pair[1].specialize(required=True)
+    assert b_ref.lib.aie_select_step_kernel(b_ref.handle, 0) == 0
+    assert pair[1].specialize(required=True) and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == 1000
+
+
+def test_background_specialisation_swaps_in_without_a_call():
+    """A configuration outside every compile-time instance's family starts on the generic kernel; aie_create has its
+    kernels compiled in the background (hiprtc, cached) and a later aie_step / aie_reset adopts them at its launch
+    boundary -- no call by the user.  Before, across and after the switch every tensor equals a twin that is pinned to
+    the generic kernel, bit for bit."""
+    import time
+
+    import torch
+
+    cfg = dict(C2, n_agents=7, episode_length=40, starting_agent_coin=2)
+    env, twin = [make_env(cfg, n_envs=256, device="cuda:0") for _ in range(2)]
+    be, bt = env.backend, twin.backend
+    assert bt.lib.aie_select_step_kernel(bt.handle, 1) == 0
+    assert be.lib.aie_step_kernel_instance(be.handle) == -1 and bt.lib.aie_step_kernel_instance(bt.handle) == -1
+    for e in (env, twin):
+        e.seed(3)
+        e.reset()
+    t0, steps, swapped_at = time.time(), 0, None
+    while steps < 60 or (swapped_at is None and time.time() - t0 < 120) or (swapped_at is not None and steps < swapped_at + 90):
+        a, p = bt.sample_random_actions(seed=6)
+        for b in (be, bt):
+            b.step(a, p)
+        steps += 1
+        if steps % 40 == 0:
+            for b in (be, bt):
+                b.reset(b.tensors["done"])
+        if swapped_at is None and be.lib.aie_step_kernel_instance(be.handle) == 1000:
+            swapped_at = steps
+        if steps % 20 == 0 or steps == swapped_at:
+            torch.cuda.synchronize()
+            for k in bt.tensors:
+                assert torch.equal(bt.tensors[k], be.tensors[k]), "step %d (switch at %s): %s differs" % (steps, swapped_at, k)
+            if swapped_at is None:
+                time.sleep(0.05)  # (the compiler needs a second or two the first time; nothing to do with the device)
+    assert swapped_at is not None, "the background specialisation never arrived (hiprtc missing?)"
+    assert bt.lib.aie_step_kernel_instance(bt.handle) == -1
 
 
 def test_reset_is_deterministic_across_environments():
