@@ -51,6 +51,9 @@ class CovidOracleBackend:
         self.L = int(filter_len)
         self.completions = 0
 
+    def set_dense_log_active(self, on=True):
+        pass
+
     @property
     def tensors(self):
         import torch

@@ -251,9 +251,10 @@ def test_hip_dense_log_matches_oracle(case):
         be = env.backend
         for t in range(cfg["episode_length"]):
             a, p = be.sample_random_actions(seed=5)
+            logging = env._dense_log_this_episode  # (the step that ends the episode closes its log)
             env.step({"a": a, "p": p})
             twin.step({"a": a.cpu(), "p": p.cpu()})
-            if not env._dense_log_this_episode:
+            if not logging:
                 # not one of the every-`dense_log_frequency`-th episodes: the logged replica steps with the rest of the
                 # batch on the fast kernel and records no rows (aie_set_dense_log_active); the oracle always records
                 continue
