@@ -532,7 +532,27 @@ class BaseEnvironment:
     def as_reference_dicts(self, e):
         """Rebuilds the reference's per-replica observation dict
         ({"0": {...}, ..., "p": {..., "p0": ...}}) for replica e as NumPy arrays -- with
-        `flatten_observations=False` in the reference's unflattened form (scalars as floats)."""
+        `flatten_observations=False` in the reference's unflattened form (scalars as floats), with
+        `flatten_masks=False` every actor's "action_mask" as the reference's dictionary {"<Component>" or
+        "<Component>.<sub-action>": list of uint8} without the NO-OP entries (base_env.py:749-756)."""
+        out = self._reference_dicts_flat_masks(e)
+        if not self._flatten_masks:
+            from .obs_keys import mask_keys
+
+            if self._mask_key_views is None:
+                self._mask_key_views = mask_keys(self)
+            tab = self._mask_key_views
+            t = self.backend.tensors
+            ma = t["obs_a_action_mask"][e].cpu().numpy()  # [n, entries]; the collated COVID masks are [entries, n]
+            if self.mask_axis_agents != -1:
+                ma = ma.T
+            mp = t["obs_p_action_mask"][e].cpu().numpy()
+            for i in range(self.n_agents):
+                out[str(i)]["action_mask"] = {key: ma[i, off:off + size].astype(np.uint8).tolist() for key, off, size in tab["a"]}
+            out["p"]["action_mask"] = {key: mp[off:off + size].astype(np.uint8).tolist() for key, off, size in tab["p"]}
+        return out
+
+    def _reference_dicts_flat_masks(self, e):
         t = self.backend.tensors
         out = {}
         unflat = not self._flatten_observations and not self.supports_unflattened_observations

@@ -291,3 +291,49 @@ def test_reference_action_dictionaries_in_multi_action_mode_without_a_gpu():
     st = host.rng_state(0)
     host.step(acts, seed_state=st)  # a valid state passes through
     assert host.rng_state(0)[0] == "MT19937"
+
+
+def test_reference_format_view_unflattened_masks_match_the_live_reference():
+    """make_env_instance(reference_format=True, flatten_masks=False) has to return the reference's mask
+    DICTIONARIES ({"<Component>[.<sub-action>]": list of uint8}, NO-OP entries left out, base_env.py:749-756) for every
+    actor, not the flattened float vectors.  Same stream as the live reference (np.random.seed(3) -> replica 0), reset
+    plus three steps, multi-action planner with taxes: keys and values equal."""
+    import numpy as np
+    from ai_economist_amd import foundation
+    from ai_economist_amd.foundation.reference_view import ReferenceFormatEnv
+    from helpers import oracle_host_pre_reset
+    from oracle_lib import OracleEnv
+    from ref_harness import load_reference_foundation, reference_available
+    from test_dense_log import ReplayOracleBackend
+
+    if not reference_available():
+        pytest.skip("reference tree not present")
+    cfg = dict(ENV_CONFIG, scenario_name="layout_from_file/simple_wood_and_stone", world_size=[25, 25],
+               env_layout_file="quadrant_25x25_20each_30clump.txt", flatten_observations=True, flatten_masks=False,
+               components=[{"Build": {}}, {"ContinuousDoubleAuction": {"max_num_orders": 5}}, {"Gather": {}},
+                           {"PeriodicBracketTax": {}}])
+    for k in ("starting_stone_coverage", "starting_wood_coverage"):
+        cfg.pop(k)
+    scen = cfg.pop("scenario_name")
+    kw_ref = dict(cfg, components=[tuple(c.items())[0] for c in cfg["components"]])
+    np.random.seed(3)
+    ref = load_reference_foundation().make_env_instance(scen, **kw_ref)
+    ref.seed(3)
+    host = foundation.make_env_instance(scen, n_envs=1, **cfg)
+    o = OracleEnv(host.build_config(), host.layout_planes())
+    host._backend = ReplayOracleBackend(o, host)
+    host.host_pre_reset = lambda mask: oracle_host_pre_reset(host, o)
+    st = np.random.get_state()
+    o.t["mt"][0] = st[1]
+    o.t["mt_pos"][0] = st[2]
+    env = ReferenceFormatEnv(host)
+    obs, want = env.reset(), ref.reset()
+    acts = {"0": 3, "1": 47, "2": 0, "3": 48, "p": [1, 0, 2, 0, 0, 0, 0]}
+    for t in range(4):
+        for actor in [str(i) for i in range(cfg["n_agents"])] + ["p"]:
+            got_m, want_m = obs[actor]["action_mask"], want[actor]["action_mask"]
+            assert isinstance(got_m, dict) and sorted(got_m) == sorted(want_m), (t, actor)
+            for key in want_m:
+                assert isinstance(got_m[key], list) and got_m[key] == want_m[key], (t, actor, key)
+        obs, _, _, _ = env.step(acts)
+        want, _, _, _ = ref.step(acts)
