@@ -685,6 +685,9 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
     p->o_tax_last_coin = aie__rec(&cur, 8 * n, 8);
     p->o_tax_last_income = aie__rec(&cur, 8 * n, 8);
     p->o_tax_last_marginal_rate = aie__rec(&cur, 8 * n, 8);
+    /* aie_kernels_ose.hip (ose_load_record) skips [o_tax_last_income, o_tax_last_marginal_rate + 8 n) as one dead range
+     * when every step is a tax day: the two fields have to stay adjacent */
+    if (p->o_tax_last_marginal_rate != p->o_tax_last_income + 8 * n) return AIE_E_INVALID;
     p->o_tax_total_collected = aie__rec(&cur, 8, 8);
     p->o_tax_cycle_pos = aie__rec(&cur, 4, 4);
     p->o_tax_last_completions = aie__rec(&cur, 4, 4);

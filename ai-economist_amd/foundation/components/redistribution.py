@@ -212,8 +212,11 @@ class PeriodicBracketTax(BaseComponent):
         if self.tax_model == "saez":
             # every replica of every rank may pool a full local buffer (sharding.accumulate_and_broadcast_saez_buffers)
             cap = self._global_buffer_capacity
-            cfg.saez_global_capacity = int(cap if cap is not None
-                                           else _default_world_size() * cfg.n_envs * int(self._buffer_size))
+            cap = int(cap if cap is not None else _default_world_size() * cfg.n_envs * int(self._buffer_size))
+            if not 0 <= cap < 2 ** 31:  # (an int32 field of the C ABI; 16 bytes per pair on the device)
+                raise ValueError("saez global buffer capacity %d (ranks x replicas x buffer_size) does not fit: pass "
+                                 "saez_global_capacity= explicitly (0 switches the cross-replica buffer off)" % cap)
+            cfg.saez_global_capacity = cap
         cfg.saez_pareto_weight_uniform = int(self.pareto_weight_type == "uniform")
         cfg.saez_fixed_elas_given = int(self._saez_fixed_elas is not None)
         cfg.saez_fixed_elas = float(self._saez_fixed_elas or 0.0)

@@ -409,6 +409,11 @@ def issue_counters(wl):
     if not files:
         return None, None, None
     d = json.load(open(files[-1]))
+    if wl == "C4x" and any("window_kernel" in k for k in d):
+        # window sums: a step is two launches (the step kernel, then the change-event lists' upkeep): their sum
+        rows = [v for k, v in d.items() if isinstance(v, dict) and ("covid_step_kernel" in k or "window_kernel" in k)]
+        return (sum(v["wave_instructions_per_launch"] for v in rows), os.path.relpath(files[-1], ROOT),
+                sum((v.get("counters") or {}).get("SQ_INSTS_VALU", 0.0) for v in rows))
     best = None
     for name, v in d.items():
         if isinstance(v, dict) and "reset" not in name and v.get("wave_instructions_per_launch"):

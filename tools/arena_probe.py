@@ -4,6 +4,11 @@ on the same box in the same process, depending on where its 7 GB arena lies.
    python tools/arena_probe.py fresh [count]     a fresh arena from torch's allocator per environment
    python tools/arena_probe.py offsets [bytes..] the arena at chosen offsets inside ONE 8 GB + 1 GiB allocation
    python tools/arena_probe.py contiguous [count]  arenas from hipExtMallocWithFlags(hipDeviceMallocContiguous)
+   python tools/arena_probe.py hipmalloc|vmm|vmm2m [count]  arenas from tools/arena_alloc.hip (hipMalloc; hipMemCreate +
+                                                 hipMemMap in one piece / in 128 MiB pieces of 2 MiB granules)
+   python tools/arena_probe.py procs [N] [out.json]  VERDICT r3 #7: every allocator in N FRESH processes each (what
+                                                 matters is the placement a process gets at its first allocation), the
+                                                 launch times per allocator -> JSON
 GPU only."""
 import ctypes
 import os
@@ -39,6 +44,17 @@ def run(mode, off=0, launches=40, warm=15):
                 v = big[off: off + n]
                 v.zero_()
                 return v
+            if mode in ("hipmalloc", "vmm", "vmm2m"):
+                lib = ctypes.CDLL(os.path.join(ROOT, "tools", "bin", "libarena_alloc.so"))
+                lib.arena_alloc.restype = ctypes.c_void_p
+                lib.arena_alloc.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
+                gran = ctypes.c_size_t(0)
+                ptr = lib.arena_alloc({"hipmalloc": 0, "vmm": 2, "vmm2m": 3}[mode], n, 0, ctypes.byref(gran))
+                if ptr:
+                    t = torch.as_tensor(Blob(ptr, n), device=device)
+                    t.zero_()
+                    return t
+                print("   arena_alloc(%s) failed" % mode, flush=True)
             if mode == "contiguous":
                 hip = ctypes.CDLL("libamdhip64.so")
                 hip.hipExtMallocWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
@@ -80,6 +96,29 @@ def run(mode, off=0, launches=40, warm=15):
 
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "fresh"
+if mode == "procs":
+    import json
+    import re
+    import subprocess
+
+    n_procs = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "r04_c5_alloc.json")
+    res = {}
+    for alloc in ("fresh", "hipmalloc", "contiguous", "vmm", "vmm2m"):
+        times = []
+        for k in range(n_procs):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), alloc, "1"], capture_output=True, text=True, timeout=600)
+            m = re.search(r"([0-9.]+) ms per launch", r.stdout)
+            times.append(float(m.group(1)) if m else None)
+            print(alloc, k, times[-1], (r.stderr.strip().splitlines() or [""])[-1][:120] if not m else "", flush=True)
+        ok = [t for t in times if t is not None]
+        res[{"fresh": "torch caching allocator"}.get(alloc, alloc)] = dict(
+            ms_per_launch=times, best=min(ok) if ok else None, worst=max(ok) if ok else None,
+            at_or_below_1p50=sum(1 for t in ok if t <= 1.50), processes=n_procs)
+    res["workload"] = "%s: one fresh process per sample, 15 warm-up + 40 timed launches each (tools/arena_probe.py procs)" % WL
+    json.dump(res, open(out_path, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+    sys.exit(0)
 if mode == "offsets":
     for off in [int(x, 0) for x in sys.argv[2:]] or [0, 256, 4096, 1 << 16, 1 << 20, 1 << 21, 3 << 21, 1 << 24, 1 << 27, 1 << 29, 0]:
         run(mode, off)

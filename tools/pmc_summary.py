@@ -23,11 +23,14 @@ def col(path, name, kernel=None):
             and (kernel != "aie_step_kernel" or "_log" not in r["Kernel_Name"])]
 
 
-f = col(fetch_csv, "FETCH_SIZE")
-w = col(write_csv, "WRITE_SIZE")
+parts = KERNEL.split("+")  # "k1+k2": a step made of two launches; per-step bytes = the sum of the kernels' means
+per = {k: (col(fetch_csv, "FETCH_SIZE", k), col(write_csv, "WRITE_SIZE", k)) for k in parts}
+f = [sum(st.mean(per[k][0]) for k in parts)] * len(per[parts[0]][0]) if len(parts) > 1 else per[parts[0]][0]
+w = [sum(st.mean(per[k][1]) for k in parts)] * len(per[parts[0]][1]) if len(parts) > 1 else per[parts[0]][1]
 fill = [float(r["Counter_Value"]) for r in csv.DictReader(open(write_csv)) if "FillFunctor<unsigned char>" in r["Kernel_Name"]]
 res = {
     "kernel": KERNEL,
+    "per_kernel_hbm_bytes": {k: (2 * st.mean(per[k][0]) + st.mean(per[k][1])) * 1024 for k in parts},
     "launches": len(f),
     "FETCH_SIZE_KiB_mean": st.mean(f),
     "WRITE_SIZE_KiB_mean": st.mean(w),

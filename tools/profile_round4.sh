@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-4 rocprofv3 evidence for bench.py's numbers (run on the GPU box via gpurun), per workload:
+#   --kernel-trace --stats of `bench.py --workload <wl> --no-workloads`, separate FETCH_SIZE / WRITE_SIZE --pmc passes
+#   (HBM traffic; never combined with other traces), SQ instruction / cycle counters incl. the lane-utilisation pass
+#   (tools/sq_passes.sh) -> summaries in gpurun_out/summ/r04_<wl>_{bench.json,kernel_stats.csv,pmc.json,sq_counters.json}
+#   (copied to profiles/ by hand).
+# usage: tools/profile_round4.sh C2 [C3 C4x C5 ...]
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/summ
+cd /tmp && export TMPDIR=/tmp
+for WL in "$@"; do
+  case $WL in C5) STEPS=100; WARM=20;; C4*) STEPS=300; WARM=30;; *) STEPS=600; WARM=50;; esac
+  case $WL in C5) KN=aie_ose_step_kernel;; C4x) KN=aie_covid_step_kernel+aie_covid_window_kernel;; C4) KN=aie_covid_step_kernel;; *) KN=aie_step_kernel;; esac
+  w=$(echo $WL | tr 'A-Z' 'a-z')
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r04_$WL -o s -- \
+    python $R/bench.py --workload $WL --no-workloads --no-cpu-baseline --steps $STEPS --warmup $WARM > $R/gpurun_out/prof_r04_$WL.json 2> $R/gpurun_out/prof_r04_$WL.err
+  tail -1 $R/gpurun_out/prof_r04_$WL.json > $R/gpurun_out/summ/r04_${w}_bench.json
+  find $R/gpurun_out/prof_r04_$WL -name "*kernel_stats.csv" | head -1 | xargs -r head -12 > $R/gpurun_out/summ/r04_${w}_kernel_stats.csv
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_r04_${WL}_$C -o s -- \
+      python $R/bench.py --workload $WL --no-workloads --no-cpu-baseline --steps $((STEPS / 3)) --warmup $WARM > /dev/null 2> $R/gpurun_out/pmc_r04_${WL}_$C.err
+  done
+  python3 $R/tools/pmc_summary.py $(find $R/gpurun_out/pmc_r04_${WL}_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
+    $(find $R/gpurun_out/pmc_r04_${WL}_WRITE_SIZE -name "*counter_collection.csv" | head -1) $R/gpurun_out/summ/r04_${w}_pmc.json $KN > /dev/null 2> $R/gpurun_out/summ/pmc_$w.err
+  $R/tools/sq_passes.sh $WL --no-workloads > $R/gpurun_out/r04_sq_$WL.txt 2>&1
+  cp $R/gpurun_out/r04_${WL}_sq_counters.json $R/gpurun_out/summ/r04_${w}_sq_counters.json 2>/dev/null
+  head -4 $R/gpurun_out/summ/r04_${w}_kernel_stats.csv | cut -c1-160
+  rm -rf $R/gpurun_out/prof_r04_$WL $R/gpurun_out/pmc_r04_${WL}_* $R/gpurun_out/sq_${WL}_*
+done

@@ -32,7 +32,10 @@ E = 4096
 
 
 def main():
+    import json
+
     agents = [int(x) for x in sys.argv[1:]] or [4, 10]
+    times = {}
     for n in agents:
         env = make_env(dict(bench.C2_CFG, n_agents=n), n_envs=E, device="cuda:0")
         env.seed(1)
@@ -64,8 +67,11 @@ def main():
             if base is None:
                 base = us
             print("  mask %6d %-40s %7.2f us per launch (%+6.2f)" % (m, NAMES.get(m, "?"), us, us - base), flush=True)
+            times.setdefault(str(n), []).append({"mask": m, "phase_off": NAMES.get(m, "?"), "us_per_launch": us})
         be.lib.aie_dev_set_skip_mask(be.handle, 0)
         del env, be
+    if os.environ.get("ABLATE_JSON"):  # launch times per switched-off phase (tools/spec_ablate_report.py adds the counters)
+        json.dump(times, open(os.environ["ABLATE_JSON"], "w"), indent=1)
 
 
 if __name__ == "__main__":
