@@ -372,7 +372,8 @@ static inline void aie__add_shared(aie_tensor_table* tt, const char* name, int d
 static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tensor_table* tt,
                                    char* err, size_t errlen) {
   const aie_covid_config* v = &c->covid;
-  if (c->n_agents > AIE_MAX_AGENTS) AIE__FAIL("n_agents > %d unsupported for the COVID scenario", AIE_MAX_AGENTS);
+  if (c->n_agents > AIE_MAX_AGENTS)
+    AIE__FAIL("n_agents = %d: the COVID scenario holds at most %d states per replica here (one lane each)", c->n_agents, AIE_MAX_AGENTS);
   if (c->multi_action_mode_agents || c->multi_action_mode_planner)
     AIE__FAIL("the COVID scenario uses single-action mode for agents and planner");
   static const int want[3] = {AIE_COMP_COVID_CONTROL, AIE_COMP_COVID_SUBSIDY, AIE_COMP_COVID_VACCINE};
@@ -804,9 +805,11 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     return aie__build_covid(c, p, tt, err, errlen);
   }
   if (c->scenario == AIE_SCN_GTB && c->n_agents > AIE_MAX_AGENTS - 2)
-    AIE__FAIL("n_agents > %d unsupported for spatial scenarios", AIE_MAX_AGENTS - 2);
+    AIE__FAIL("n_agents = %d: the spatial scenarios hold at most %d mobile agents per replica here (one lane of a 64-lane "
+              "wavefront each; the reference has no upper bound, base_env.py:221-224)", c->n_agents, AIE_MAX_AGENTS - 2);
   if (c->scenario == AIE_SCN_ONE_STEP_ECONOMY && c->n_agents > AIE_MAX_AGENTS_WIDE)
-    AIE__FAIL("n_agents > %d unsupported for one-step-economy", AIE_MAX_AGENTS_WIDE);
+    AIE__FAIL("n_agents = %d: one-step-economy holds at most %d agents per replica here (the reference has no upper "
+              "bound, base_env.py:221-224)", c->n_agents, AIE_MAX_AGENTS_WIDE);
   if (c->world_h < 1 || c->world_w < 1 || c->world_h > 255 || c->world_w > 255)
     AIE__FAIL("world_size out of range");
   if (c->episode_length < 1) AIE__FAIL("episode_length must be >= 1 (base_env.py:254)");

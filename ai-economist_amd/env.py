@@ -43,13 +43,43 @@ class DeviceBackend:
         nbytes = self.lib.aie_arena_bytes(C.byref(cfg))
         if nbytes < 0:
             raise self._err(None, nbytes)
-        self.arena = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
+        # Small arenas are torch allocations (the caching allocator hands them out without a device call).  Large ones
+        # (AIE_ARENA_VMM_MIN_MB, default 1 GiB, and up) are allocated by the library as a virtual range backed by 64 MiB
+        # physical pieces: the store-bound one-step-economy launch over its 7 GB arena runs 14 % faster that way than on
+        # one allocation of torch's or hipMalloc's (csrc/aie_capi.hip: aie_arena_alloc, profiles/r04_c5_alloc.json);
+        # the library owns that memory until aie_destroy, `self.arena` is a view of it.
+        lib_owned = int(nbytes) >= (int(os.environ.get("AIE_ARENA_VMM_MIN_MB", "1024")) << 20) and \
+            os.environ.get("AIE_ARENA_PIECE_MB", "64") != "0"
+        self.arena = None if lib_owned else torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
         h = C.c_void_p()
-        rc = self.lib.aie_create(C.byref(cfg), self.device.index, self.arena.data_ptr(),
-                                 int(nbytes), C.byref(h))
+        with torch.cuda.device(self.device):
+            rc = self.lib.aie_create(C.byref(cfg), self.device.index, self.arena.data_ptr() if self.arena is not None else None,
+                                     int(nbytes), C.byref(h))
         if rc != 0:
             raise self._err(None, rc)
         self.handle = h
+        if lib_owned:
+            d0 = _cabi.AieTensorDesc()
+            self.lib.aie_tensor_at(self.handle, 0, C.byref(d0))
+            base = int(d0.data) - int(d0.arena_offset)
+
+            class _Arena:
+                """The library's allocation as a CUDA array (torch wraps it without copying and keeps this object alive
+                for as long as any view of the arena lives): it owns the environment handle, so the memory is released
+                -- aie_destroy -- when the last tensor that points into it is gone, not when the backend is closed."""
+                __cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (base, False), "version": 2}
+
+                def __init__(self, lib, handle):
+                    self.lib, self.handle = lib, handle
+
+                def __del__(self):
+                    try:
+                        self.lib.aie_destroy(self.handle)
+                    except Exception:
+                        pass
+
+            self._arena_owner = _Arena(self.lib, self.handle)
+            self.arena = torch.as_tensor(self._arena_owner, device=self.device)
         self.E = cfg.n_envs
         self.n = cfg.n_agents
         self.descs = {}
@@ -308,7 +338,13 @@ class DeviceBackend:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.aie_destroy(self.handle)
+            if getattr(self, "_arena_owner", None) is not None:
+                # the library owns the arena: the handle is destroyed when the last view of the arena is gone
+                self._arena_owner = None
+                self.arena = None
+                self.tensors = {}
+            else:
+                self.lib.aie_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 extern "C" __attribute__((visibility("default"))) void* arena_alloc(int kind, size_t n, int device, size_t* granularity_out) {
   void* p = nullptr;
@@ -29,7 +30,9 @@ extern "C" __attribute__((visibility("default"))) void* arena_alloc(int kind, si
   const size_t total = (n + gran - 1) / gran * gran;
   hipDeviceptr_t va = nullptr;
   if (hipMemAddressReserve(&va, total, gran, nullptr, 0) != hipSuccess) { fprintf(stderr, "arena_alloc: reserve failed\n"); return nullptr; }
-  const size_t piece = kind == 2 ? total : (size_t)64 * gran;  // kind 3: 128 MiB pieces, each its own physical handle
+  size_t piece = kind == 2 ? total : (size_t)64 * gran;  // kind 3: 128 MiB pieces (ARENA_PIECE_MB overrides), each its own physical handle
+  if (kind == 3 && getenv("ARENA_PIECE_MB")) piece = ((size_t)atol(getenv("ARENA_PIECE_MB")) << 20) / gran * gran;
+  if (piece < gran) piece = gran;
   for (size_t off = 0; off < total; off += piece) {
     const size_t len = off + piece <= total ? piece : total - off;
     hipMemGenericAllocationHandle_t h;

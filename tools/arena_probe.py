@@ -96,6 +96,24 @@ def run(mode, off=0, launches=40, warm=15):
 
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "fresh"
+if mode == "pieces":  # the VMM arena in pieces of several sizes, N fresh processes each
+    import json
+    import re
+    import subprocess
+
+    n_procs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    res = {}
+    for mb in (2, 16, 64, 128, 256, 1024):
+        times = []
+        for k in range(n_procs):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "vmm2m", "1"], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, ARENA_PIECE_MB=str(mb)))
+            m = re.search(r"([0-9.]+) ms per launch", r.stdout)
+            times.append(float(m.group(1)) if m else None)
+        res["%d MiB pieces" % mb] = times
+        print(mb, times, flush=True)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r04_c5_alloc_pieces.json"), "w"), indent=1)
+    sys.exit(0)
 if mode == "procs":
     import json
     import re
