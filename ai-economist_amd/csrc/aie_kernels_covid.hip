@@ -381,7 +381,10 @@ __device__ __forceinline__ void cv_window_tail(const aie_params& P, uint8_t* __r
     int expired = 0;
     // the list in memory holds the events before today's, oldest first; the groups are fetched CV_BURST at a time
     // (one memory round trip covers the 32 events of a two-week cool-down over the whole window)
-    constexpr int CV_BURST = 8;
+#ifndef AIE_CV_BURST
+#define AIE_CV_BURST 8
+#endif
+    constexpr int CV_BURST = AIE_CV_BURST;
     for (int g0 = g_lo; g0 < g_hi; g0 += CV_BURST) {
       uint4 qb[CV_BURST];
 #pragma unroll
