@@ -163,12 +163,20 @@ def layout_bytes_per_env_step(be, wl):
             b = dict(filter_sums_rw=2 * F * n * 8, history_bytes=6 * n, state_rw=state_rw, obs=obs, act=(n + 1) * 4,
                      rew_done=(n + 1) * 4 + 1)
         else:
-            b = dict(history_window=(L + 1) * n, state_rw=state_rw, obs=obs, act=(n + 1) * 4, rew_done=(n + 1) * 4 + 1)
+            # window sums over the change events (round 4): F float64 sums per state r + w (formed one step ahead), the
+            # states' event lists (4 B per live event, the batch's mean list length at the end of the window, read once
+            # per step; + head / tail r + w), today's and yesterday's level rows -- the 601-day window is streamed only by
+            # replicas whose list overflowed
+            ht = be.tensors["stringency_change_head_tail"]
+            live = float(((ht >> 16) - (ht & 0xffff)).float().mean().item())
+            b = dict(window_sums_rw=2 * F * n * 8, event_lists=live * 4 * n + 2 * 4 * n, history_bytes=6 * n, state_rw=state_rw,
+                     obs=obs, act=(n + 1) * 4, rew_done=(n + 1) * 4 + 1, mean_live_events_per_state=live)
+            b = {k: v for k, v in b.items()}
     else:
         key = "cells" if "cells" in be.descs else "inv_coin"
         rec = be.descs[key][2][0]  # per-replica record bytes = stride of any record field along the replica axis
         b = dict(obs=obs, state_rw=2 * rec, act=n * 4 + be._act_p_width() * 4, rew_done=(n + 1) * 4 + 1)
-    b["total"] = sum(b.values())
+    b["total"] = sum(v for k, v in b.items() if k != "mean_live_events_per_state")
     return b
 
 

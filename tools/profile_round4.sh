@@ -14,7 +14,7 @@ for WL in "$@"; do
   w=$(echo $WL | tr 'A-Z' 'a-z')
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r04_$WL -o s -- \
     python $R/bench.py --workload $WL --no-workloads --no-cpu-baseline --steps $STEPS --warmup $WARM > $R/gpurun_out/prof_r04_$WL.json 2> $R/gpurun_out/prof_r04_$WL.err
-  tail -1 $R/gpurun_out/prof_r04_$WL.json > $R/gpurun_out/summ/r04_${w}_bench.json
+  tail -1 $R/gpurun_out/prof_r04_$WL.json > $R/gpurun_out/summ/r04_${w}_bench.json  # (the compact driver line; the full one is the line before it)
   find $R/gpurun_out/prof_r04_$WL -name "*kernel_stats.csv" | head -1 | xargs -r head -12 > $R/gpurun_out/summ/r04_${w}_kernel_stats.csv
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_r04_${WL}_$C -o s -- \
