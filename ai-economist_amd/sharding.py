@@ -79,22 +79,41 @@ class ObservationGather:
         missing = [k for k in keys if k not in backend.tensors]
         if missing:
             raise KeyError("ObservationGather: the environment has no tensor(s) %s" % missing)
-        self.recv = None
-        if self.rank == dst and self.world > 1:
-            self.recv = {k: [torch.empty_like(backend.tensors[k].contiguous()) for _ in range(self.world)] for k in self.keys}
+        # two sets of snapshot / receive buffers: a gather started with start() runs while the steps go on (they
+        # overwrite the live observation tensors, so what travels is a device-side snapshot taken in stream order)
+        self.snap = [None, None]
+        self.recv = [None, None]
+        if self.world > 1:
+            self.snap = [{k: torch.empty_like(backend.tensors[k].contiguous()) for k in self.keys} for _ in range(2)]
+            if self.rank == dst:
+                self.recv = [{k: [torch.empty_like(backend.tensors[k].contiguous()) for _ in range(self.world)]
+                              for k in self.keys} for _ in range(2)]
         self.bytes_per_call = sum(int(backend.tensors[k].numel() * backend.tensors[k].element_size()) for k in self.keys)
 
+    def start(self, slot=0):
+        """Snapshots the current observations and starts their gather (asynchronous collectives, one per key); the
+        steps that follow overlap it.  finish(slot) waits and returns what __call__ returns."""
+        works = []
+        if self.world > 1:
+            for k in self.keys:
+                self.snap[slot][k].copy_(self.backend.tensors[k])
+                works.append(self.dist.gather(self.snap[slot][k], self.recv[slot][k] if self.rank == self.dst else None,
+                                              dst=self.dst, async_op=True))
+            return works
+        # one rank: a copy, not a view of the live arena (the multi-rank path returns copies too)
+        return {k: self.backend.tensors[k].clone() for k in self.keys}
+
+    def finish(self, started, slot=0):
+        if self.world > 1:
+            for w in started:
+                w.wait()
+            if self.rank != self.dst:
+                return None
+            return {k: self.torch.cat(self.recv[slot][k], dim=0) for k in self.keys}
+        return started if self.rank == self.dst else None
+
     def __call__(self):
-        out = {}
-        for k in self.keys:
-            t = self.backend.tensors[k].contiguous()
-            if self.world > 1:
-                self.dist.gather(t, self.recv[k] if self.rank == self.dst else None, dst=self.dst)
-                if self.rank == self.dst:
-                    out[k] = self.torch.cat(self.recv[k], dim=0)
-            else:
-                out[k] = t
-        return out if self.rank == self.dst else None
+        return self.finish(self.start(0), 0)
 
 
 class RewardLogGather:
@@ -138,6 +157,7 @@ class RewardLogGather:
             self.recv = [[torch.empty_like(self.log[: self.K]) for _ in range(self.world)] for _ in range(2)]
         self.received = []
         self.obs_gather = ObservationGather(backend, gather_obs, dst) if gather_obs else None
+        self.obs_pending = [None, None]  # observation gathers started with a block, waited for with it
         self.received_obs = []
         self.n_collectives = 0
         self.bytes_per_collective = int(self.log[: self.K].numel() * self.log.element_size())
@@ -165,26 +185,32 @@ class RewardLogGather:
         elif self.keep:
             self.received.append(view.clone()[None])
         if self.obs_gather is not None:
-            obs = self.obs_gather()
-            if obs is not None:
-                self.received_obs.append({k: v.clone() for k, v in obs.items()})
+            # asynchronous like the reward block: the collectives travel while the next block's steps run, and are
+            # waited for where the block's own collective is
+            self.obs_pending[b] = self.obs_gather.start(b)
         self.filled = 0
         self.block ^= 1
         self._wait(self.block)  # the block about to be overwritten must have left
         return True
 
     def _wait(self, b):
-        w = self.pending[b]
-        if w is None:
-            return
         import time
 
-        t0 = time.perf_counter()
-        w.wait()
-        self.wait_seconds += time.perf_counter() - t0
-        self.pending[b] = None
-        if self.keep and self.rank == self.dst:
-            self.received.append(self.torch.stack(self.recv[b]).clone())
+        w = self.pending[b]
+        if w is not None:
+            t0 = time.perf_counter()
+            w.wait()
+            self.wait_seconds += time.perf_counter() - t0
+            self.pending[b] = None
+            if self.keep and self.rank == self.dst:
+                self.received.append(self.torch.stack(self.recv[b]).clone())
+        if self.obs_pending[b] is not None:
+            t0 = time.perf_counter()
+            obs = self.obs_gather.finish(self.obs_pending[b], b)
+            self.wait_seconds += time.perf_counter() - t0
+            self.obs_pending[b] = None
+            if obs is not None:
+                self.received_obs.append({k: v.clone() for k, v in obs.items()} if self.world > 1 else obs)
 
     def finish(self):
         """Ships what the current block holds (a rollout need not end on a block boundary) and waits for everything
@@ -193,6 +219,8 @@ class RewardLogGather:
         self._wait(self.block)
         if self.filled:
             b, f = self.block, self.filled
+            if self.obs_gather is not None:  # the partial block's observations travel too: received_obs stays in step with received
+                self.obs_pending[b] = self.obs_gather.start(b)
             view = self.log[b * self.K: b * self.K + f]
             if self.collective:
                 w = self.dist.gather(view, [r[:f] for r in self.recv[b]] if self.rank == self.dst else None,
@@ -207,6 +235,7 @@ class RewardLogGather:
                     self.received.append(self.torch.stack([r[:f] for r in self.recv[b]]).clone())
             elif self.keep:
                 self.received.append(view.clone()[None])
+            self._wait(b)  # (the partial block's observations)
             self.filled = 0
             # the next step writes slot 0 again (the writer's slot counter lives in the library)
             self.backend.rewind_reward_log()

@@ -299,9 +299,10 @@ def _obs_worker(rank, world, port, out):
         return gid[:, None, None] * 100 + torch.arange(n)[None, :, None] * 10 + torch.arange(5)[None, None, :] + 0.5 * t
 
     if rank == 0:
-        ok &= len(g.received_obs) == T // K  # one observation set per completed block: steps 2 and 5
+        # one observation set per block, the partial one finish() ships included: steps 2, 5 and 6 -- in step with g.received
+        ok &= len(g.received_obs) == T // K + 1 == len(g.received)
         for blk, obs in enumerate(g.received_obs):
-            t = (blk + 1) * K - 1
+            t = min((blk + 1) * K, T) - 1
             ok &= torch.equal(obs["obs_a_flat"], want_flat(t))
             ok &= torch.equal(obs["obs_a_action_mask"],
                               ((gid[:, None, None] + torch.arange(3)[None, None, :] + t) % 2).expand(E_total, n, 3))
