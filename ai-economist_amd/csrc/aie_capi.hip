@@ -326,8 +326,10 @@ int aie_upload(aie_env* env, const char* name, const void* host, int64_t bytes) 
     for (int64_t q = 0; q < bytes / 8; ++q)
       if ((double)(float)taps[q] != taps[q]) env->cv_taps_f32 = 0;
   }
-  if (rc == AIE_OK && env->P.c.scenario == AIE_SCN_COVID && strcmp(name, "model_stringency_level_history_0") == 0) {
-    // what every reset derives from this table is derived once, here (history-format image, filter sums at t = 0)
+  if (rc == AIE_OK && env->P.c.scenario == AIE_SCN_COVID &&
+      (strcmp(name, "model_stringency_level_history_0") == 0 || strcmp(name, "model_unemp_conv_filters") == 0)) {
+    // what every reset derives from these tables is derived once, here (history-format image, the pre-episode change
+    // events, the first step's filter sums -- which need the taps as well: either upload refreshes them)
     hipLaunchKernelGGL(aie_covid_prepare_kernel, dim3(1), dim3(AIE_NT), 0, 0, env->d_params, env->arena);
     AIE_HIP_CHECK(env, hipGetLastError());
     AIE_HIP_CHECK(env, hipDeviceSynchronize());

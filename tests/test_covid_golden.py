@@ -512,3 +512,48 @@ def test_covid_step_sample_next_masked_equals_two_launches(recurrence):
         gtb.reset()
         a, p = gtb.backend.sample_random_actions(seed=1)
         gtb.backend.step_sample_next(a, p, seed=1, masked=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["filters_last", "history_last"])
+def test_covid_window_sums_with_taps_that_are_not_float32_values(order):
+    """The window kernel keeps its LDS tap table in float32 only when every uploaded tap is a float32 value (the
+    reference's are); any other table takes the float64 one.  Taps perturbed in their low mantissa bits, uploaded through
+    aie_upload in either order relative to the pre-episode history (both uploads refresh what reset copies: the first
+    step's sums need the taps): the sums over the event lists (LDS table, float64 this time) against the streamed window
+    (which reads the uploaded float64 taps from memory), every tensor bit for bit."""
+    import torch
+
+    g = load_covid_golden("c4_covid_51ag")
+    cfg = g["cfg"]
+    E = 16
+    envs = [hip_env(cfg, n_envs=E), hip_env(cfg, n_envs=E)]
+    for env in envs:
+        be = env.backend
+        taps = np.asarray(env.model["unemp_conv_filters"], np.float64) * (1.0 + 3e-9)  # [F, L]: no longer float32 values
+        assert not np.array_equal(taps.astype(np.float32).astype(np.float64), taps)
+        hist = np.asarray(env.model["stringency_level_history_0"])
+        first, second = ("model_stringency_level_history_0", hist), ("model_unemp_conv_filters", taps)
+        if order == "history_last":
+            first, second = second, first
+        be.upload(first[0], first[1][None])
+        be.upload(second[0], second[1][None])
+        env.reset()
+    ev, st = envs
+    st.tensors["window_streams_whole_history"].fill_(1)
+    for k in range(1, 41):
+        a, p = ev.backend.sample_masked_actions(seed=21)
+        for env in envs:
+            env.backend.step(a, p)
+        torch.cuda.synchronize()
+        for name in _covid_state_tensors(ev):
+            assert torch.equal(ev.tensors[name], st.tensors[name]), "day %d: %s differs (float64 tap table)" % (k, name)
+    assert int(ev.tensors["window_streams_whole_history"].sum()) == 0
+    # and the perturbation is visible: the same rollout on the reference's own taps gives another `unemployed`
+    ref = hip_env(cfg, n_envs=E)
+    ref.reset()
+    for k in range(1, 41):
+        a, p = ref.backend.sample_masked_actions(seed=21)
+        ref.backend.step(a, p)
+    torch.cuda.synchronize()
+    assert not torch.equal(ref.tensors["unemployed"], ev.tensors["unemployed"])
