@@ -342,3 +342,35 @@ def test_c2_full_batch_crosses_an_episode_end_on_the_compile_time_instance():
         elif (t + 1) % 10 == 0 or (t + 1) % EP == 1:
             _compare_all(be, oracle, "step %d" % (t + 1))
     assert int(be.tensors["completions"].min()) == 2
+
+
+def test_c2_full_batch_whole_episode_and_its_end():
+    """BASELINE configs[1] exactly as benchmarked -- 4096 replicas, 1000-step episodes -- through a WHOLE episode, its
+    end and the reset behind it: ten tax days, twenty order-expiry horizons, every field of every replica every 100
+    steps, at the terminal step, after the reset and five steps into the second episode."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    E, EP = 4096, 1000
+    env = make_env(dict(C2), n_envs=E, device="cuda:0")
+    env.seed(4)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(4)
+    oracle.reset()
+    for t in range(EP + 5):
+        a, p = be.sample_random_actions(seed=31)
+        be.step(a, p)
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=NTHREADS)
+        if t + 1 == EP:
+            _compare_all(be, oracle, "terminal step")
+            assert bool(be.tensors["done"].all())
+            be.reset(be.tensors["done"])
+            oracle.reset(np.ones(E, np.uint8))
+            torch.cuda.synchronize()
+            _compare_all(be, oracle, "reset behind the first episode")
+        elif (t + 1) % 100 == 0 or t + 1 > EP:
+            _compare_all(be, oracle, "step %d" % (t + 1))
+    assert int(oracle.t["metrics_tax_days"].min()) == 0 and int(be.tensors["completions"].min()) == 1
