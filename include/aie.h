@@ -311,7 +311,11 @@ int64_t aie_arena_bytes(const aie_config* cfg);
 
 /* Creates E replicas on HIP device `device`.  If `arena` is non-NULL it must be a
  * device allocation of at least aie_arena_bytes(cfg) bytes, 256-byte aligned, that
- * outlives the env (e.g. a torch uint8 tensor); otherwise the library hipMallocs it. */
+ * outlives the env (e.g. a torch uint8 tensor); otherwise the library allocates it: hipMalloc, or -- from
+ * $AIE_ARENA_VMM_MIN_MB (default 1024) MiB on -- a virtual range backed by physical pieces of $AIE_ARENA_PIECE_MB
+ * (default 64) MiB each (hipMemCreate / hipMemMap), on which the store-bound one-step-economy launch runs 14 % faster
+ * than on one big allocation.  For a configuration outside every compile-time instance's family aie_create also starts
+ * the run-time specialisation in the background (see aie_specialize; $AIE_JIT_AUTO=0 switches that off). */
 int aie_create(const aie_config* cfg, int device, void* arena, int64_t arena_bytes,
                aie_env** out);
 int aie_destroy(aie_env* env);
@@ -423,26 +427,34 @@ int aie_set_dense_log_active(aie_env* env, int on);
 /* sizeof(aie_config) as this library was built: a binding checks its mirror of the struct against it. */
 int aie_sizeof_config(void);
 
-/* Which step kernel runs this environment: >= 0 = a compile-time instance (the configuration's parameter block folded
- * into the code, csrc/aie_spec_generated.h), -1 = the generic kernel. */
+/* Which step kernel runs this environment: 0 .. 999 = a compile-time instance (the code-shaping part of the
+ * configuration's parameter block folded into the code, csrc/aie_spec_generated.h; an instance stands for the family of
+ * configurations that differ in scalars only), AIE_KERNEL_INSTANCE_JIT = the run-time specialisation, -1 = the generic
+ * kernel. */
 int aie_step_kernel_instance(aie_env* env);
 
 /* Chooses between the step kernels that can run this environment: AIE_KERNEL_AUTO (default) = the specialised
- * instance when one matches the configuration, AIE_KERNEL_GENERIC = the generic kernel that reads the parameter block
- * at run time.  Both produce the same arena bit for bit (tests/test_gpu_parity.py steps them side by side); the
+ * instance when one matches the configuration's family (compile-time) or once its run-time specialisation is ready,
+ * AIE_KERNEL_GENERIC = pinned to the generic kernel that reads the parameter block at run time.  Both produce the same arena bit for bit (tests/test_gpu_parity.py steps them side by side); the
  * switch exists so that a user can check exactly that on their own configuration. */
 #define AIE_KERNEL_AUTO 0
 #define AIE_KERNEL_GENERIC 1
 int aie_select_step_kernel(aie_env* env, int which);
 
-/* Specialises the step and reset kernels on THIS environment's configuration at run time, the way the build does for
- * the BASELINE configurations: the parameter block becomes a compile-time constant of the kernels (hiprtc compiles
- * csrc/aie_kernels.hip with the block as a constant image, ~5 s once; the code object is cached under
- * $AIE_JIT_CACHE / ~/.cache/ai_economist_amd, keyed by the block and the sources).  Afterwards AIE_KERNEL_AUTO runs
+/* Specialises the step and reset kernels on THIS environment's configuration family at run time, the way the build does
+ * for the BASELINE configurations: the code-shaping part of the parameter block (component tuple, agent count, world
+ * size, capacities, flags; NOT scalars such as starting coin, eta, episode length, labor costs, tax period / cutoffs,
+ * which every specialised kernel reads at run time) becomes a compile-time constant of the kernels (hiprtc compiles
+ * csrc/aie_kernels.hip with it as a constant image, a few seconds once; the code object is cached under
+ * $AIE_JIT_CACHE / ~/.cache/ai_economist_amd -- private directories only -- keyed by the image, the sources, the
+ * architecture, the compiler version and options).  aie_create already starts this in the background and a later
+ * aie_step / aie_reset adopts the result at its launch boundary; this call WAITS for it.  Afterwards AIE_KERNEL_AUTO runs
  * the specialised kernels (aie_step_kernel_instance() == AIE_KERNEL_INSTANCE_JIT); results are bit-identical to the
  * generic kernel's.  Gather-trade-build and one-step-economy environments.  AIE_E_UNSUPPORTED -- and the environment simply keeps the
  * generic kernel -- when hiprtc, the kernel sources beside the library ($AIE_JIT_SOURCE_DIR) or the toolchain headers
- * are not there, or when the configuration needs the full-featured kernel (dense-log replicas, tax_model "saez"). */
+ * are not there, or when the configuration needs the full-featured kernel (tax_model "saez", order books beyond a
+ * wavefront, general regeneration; dense-log replicas do NOT: they take the full-featured kernel alone and only while an
+ * episode is being logged, aie_set_dense_log_active). */
 #define AIE_KERNEL_INSTANCE_JIT 1000
 int aie_specialize(aie_env* env);
 
