@@ -720,6 +720,7 @@ static bool aie_jit_load(aie_env* env, const std::string& code, bool ose) {
 static int aie_jit_adopt(aie_env* env, bool wait) {
   if (!env->jit_job) return env->spec_match == AIE_KERNEL_INSTANCE_JIT ? AIE_OK : AIE_E_UNSUPPORTED;
   std::shared_ptr<aie_jit::Job> job = env->jit_job;
+  if (wait) aie_jit::run_job_now_if_queued(job);  // (still in the queue behind other environments' jobs: compile it here)
   int st = job->state.load(std::memory_order_acquire);
   while (wait && st == 0) {
     usleep(2000);

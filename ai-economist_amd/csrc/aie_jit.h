@@ -210,6 +210,8 @@ struct Job {
   bool ose = false;
   std::string arch, code, err;
   std::atomic<int> state{0};  // 0 running, 1 code ready, -1 failed
+  std::atomic<int> claim{0};  // who compiles: 0 nobody yet (queued), 1 the background thread, 2 a caller that waits for
+                              // the result anyway (aie_specialize: no point queueing behind other environments' jobs)
 };
 struct JobTable {
   std::mutex mu;
@@ -258,6 +260,8 @@ static inline std::shared_ptr<Job> start_job(const void* image, size_t image_byt
         job->state.store(-1, std::memory_order_release);
         return;
       }
+      int nobody = 0;
+      if (!job->claim.compare_exchange_strong(nobody, 1)) return;  // a waiting caller took the job over
       T.running += 1;
     }
     bool cached = false;
@@ -271,6 +275,16 @@ static inline std::shared_ptr<Job> start_job(const void* image, size_t image_byt
     job->state.store(ok ? 1 : -1, std::memory_order_release);
   }).detach();
   return job;
+}
+
+// A caller that waits for `job` anyway compiles it itself if the background thread has not started on it.
+static inline void run_job_now_if_queued(const std::shared_ptr<Job>& job) {
+  int nobody = 0;
+  if (!job->claim.compare_exchange_strong(nobody, 2)) return;
+  bool cached = false;
+  const bool ok = code_object(job->image.data(), job->image.size(), job->waves, job->arch.c_str(), job->ose, job->code, job->err,
+                              &cached);
+  job->state.store(ok ? 1 : -1, std::memory_order_release);
 }
 
 }  // namespace aie_jit

@@ -1056,7 +1056,7 @@ def test_runtime_specialisation_equals_generic_kernel(case):
     assert pair[1].specialize(required=True) and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == 1000
 
 
-def test_background_specialisation_swaps_in_without_a_call():
+def test_background_specialisation_swaps_in_without_a_call(monkeypatch):
     """A configuration outside every compile-time instance's family starts on the generic kernel; aie_create has its
     kernels compiled in the background (hiprtc, cached) and a later aie_step / aie_reset adopts them at its launch
     boundary -- no call by the user.  Before, across and after the switch every tensor equals a twin that is pinned to
@@ -1065,6 +1065,7 @@ def test_background_specialisation_swaps_in_without_a_call():
 
     import torch
 
+    monkeypatch.setenv("AIE_JIT_AUTO", "1")  # the product's default (tests/conftest.py switches it off for the suite)
     cfg = dict(C2, n_agents=7, episode_length=40, starting_agent_coin=2)
     env, twin = [make_env(cfg, n_envs=256, device="cuda:0") for _ in range(2)]
     be, bt = env.backend, twin.backend
