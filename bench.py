@@ -319,7 +319,7 @@ class Rollout:
     """The timed loop of one rank: one launch per step, de-phased replicas, masked resets on a host-known
     schedule (block g of the replicas, g = e mod G, ends its episode at steps = offset_g mod episode_length)."""
 
-    def __init__(self, wl, env, rank_offset, stagger=True, auto_reset=True):
+    def __init__(self, wl, env, rank_offset, stagger=True, auto_reset=True, unmasked_covid=False):
         import torch
 
         self.torch = torch
@@ -344,7 +344,7 @@ class Rollout:
         # subsidy levels only on interval starts) -- the policy a trainer that applies `action_mask` to its logits
         # starts from, and the one under which the reference's cool-down component means anything; drawn inside the
         # step launch like the uniform one (aie_step_sample_next_masked)
-        self.masked = wl.startswith("C4")
+        self.masked = wl.startswith("C4") and not unmasked_covid
         self.cur = (self.be.sample_masked_actions if self.masked else self.be.sample_random_actions)(ACTION_SEED, self.off, slot=0)
         self.slot = 0
 
@@ -470,7 +470,8 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
         be.set_dense_log_active(False)
     if args.generic_kernel:  # development: what a configuration without an instance runs
         be.lib.aie_select_step_kernel(be.handle, 1)
-    roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger, auto_reset=not args.no_auto_reset)
+    roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger, auto_reset=not args.no_auto_reset,
+                   unmasked_covid=args.covid_unmasked_policy)
     gc.collect()
     gc.disable()  # no collector pause between here and the end of the timed window (it may be as short as 20 launches);
     #               collected now, while the GPU has nothing queued: a pause later would let it run dry before the window
@@ -784,6 +785,9 @@ def main():
     ap.add_argument("--no-stagger", action="store_true", help="keep all replicas in lock-step (round-1 behaviour)")
     ap.add_argument("--no-auto-reset", action="store_true",
                     help="C5: separate reset launches instead of restarting replicas inside the step launch")
+    ap.add_argument("--covid-unmasked-policy", action="store_true",
+                    help="C4 / C4x: the uniform policy that ignores the action masks (round 3's; stringency levels then change "
+                         "on most days, the change-event lists overflow and the replicas stream their whole window)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the N > 1 reward-log gather in a 1-rank group (exercises the RCCL path on one GPU)")
     ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"),
