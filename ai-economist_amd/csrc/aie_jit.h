@@ -111,6 +111,8 @@ static inline bool code_object(const void* image, size_t image_bytes, int waves,
   uint64_t h = fnv1a(1469598103934665603ull, image, image_bytes);
   h = fnv1a(h, kRecipe, strlen(kRecipe));
   h = fnv1a(h, rtc_version, sizeof(rtc_version));
+  const char* pad_nops = getenv("AIE_JIT_PAD_NOPS");  // development: code placement experiment (aie_kernels.hip)
+  if (pad_nops) h = fnv1a(h, pad_nops, strlen(pad_nops));
   h = fnv1a(h, &waves, sizeof(waves));
   h = fnv1a(h, &ose, sizeof(ose));
   h = fnv1a(h, arch, strlen(arch));
@@ -156,6 +158,7 @@ static inline bool code_object(const void* image, size_t image_bytes, int waves,
   // include paths: our sources, the HIP headers and clang's own headers of the ROCm tree hiprtc came from, libc's
   std::vector<std::string> opts = {std::string("--offload-arch=") + arch, "-O3", "-std=c++17", "-Wno-comment",
                                    "-I" + csrc, "-I" + inc};
+  if (pad_nops) opts.push_back(std::string("-DAIE_JIT_PAD_NOPS=") + pad_nops);
   std::string rocm = getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "";
   if (rocm.empty() && !rtc.path.empty()) rocm = dirname_of(dirname_of(rtc.path));
   if (rocm.empty() || !is_dir(rocm + "/include/hip")) rocm = "/opt/rocm";

@@ -3477,6 +3477,14 @@ extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, 
 #endif  // !AIE_JIT
 
 #if defined(AIE_JIT) && !defined(AIE_JIT_OSE)
+#ifdef AIE_JIT_PAD_NOPS  // development (AIE_JIT_PAD_NOPS=N in the environment): N no-ops ahead of the kernels shift their
+                         // placement in the code object -- does a launch's duration follow where its code lies?
+extern "C" __global__ void aie_jit_pad() {
+#define AIE_STR2(x) #x
+#define AIE_STR(x) AIE_STR2(x)
+  asm volatile(".rept " AIE_STR(AIE_JIT_PAD_NOPS) "\n s_nop 0\n .endr");
+}
+#endif
 // Run-time specialisation (aie_specialize): the step and reset kernels with THIS environment's parameter block as the
 // constant image (aie_jit_image.h is generated per configuration), exactly what the build's compile-time instances
 // are for the BASELINE configurations.

@@ -70,6 +70,8 @@ for name, cfg in CASES.items():
         line += " | generic kernel: %6.2f us" % per_launch(be)
         os.environ["AIE_JIT_FORCE"] = "1"  # the same configuration compiled at run time: A/B against the build's instance
         if env.specialize():
+            be.lib.aie_select_step_kernel(be.handle, 0)  # (release the pin on the generic kernel)
+            assert be.lib.aie_step_kernel_instance(be.handle) == 1000
             line += " | run-time instance: %6.2f us (host issue %.1f us)" % (per_launch(be), HOST_US)
         del os.environ["AIE_JIT_FORCE"]
     print(line, flush=True)
