@@ -22,7 +22,7 @@ CELL_WATER, CELL_STONE_SRC, CELL_WOOD_SRC = 1, 2, 4
 SCN_GTB, SCN_ONE_STEP_ECONOMY, SCN_COVID = 0, 1, 2
 LAYOUT_FIXED, LAYOUT_UNIFORM, LAYOUT_QUADRANT, LAYOUT_MULTI_ZONE = 0, 1, 2, 3
 COVID_MAX_FILTERS = 8
-MAX_TENSORS = 128  # AIE_MAX_TENSORS (csrc/aie_layout.h)
+MAX_TENSORS = 160  # AIE_MAX_TENSORS (csrc/aie_layout.h)
 AGENT_REWARD = {"coin_minus_labor_cost": 0, "isoelastic_coin_minus_labor": 1}
 SKILL = {"none": 0, "pareto": 1, "lognormal": 2}
 TAX_MODEL = {
@@ -212,6 +212,8 @@ def bind(lib):
     lib.aie_select_step_kernel.argtypes = [vp, C.c_int]
     lib.aie_specialize.restype = C.c_int
     lib.aie_specialize.argtypes = [vp]
+    lib.aie_arena_info.restype = C.c_int
+    lib.aie_arena_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     return lib
 
 
@@ -221,6 +223,8 @@ EXPORTED_SYMBOLS = [
     "aie_seed", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
     "aie_sample_masked_actions", "aie_step_sample_next", "aie_step_sample_next_masked", "aie_set_reward_log", "aie_set_auto_reset",
     "aie_set_dense_log_active", "aie_step_kernel_instance", "aie_select_step_kernel", "aie_specialize", "aie_set_global_saez_buffer", "aie_sizeof_config",
+    "aie_arena_info",
 ]
+ARENA_ALLOCATORS = ["caller", "hipMalloc", "vmm"]  # AIE_ARENA_*
 KERNEL_AUTO, KERNEL_GENERIC = 0, 1
 KERNEL_INSTANCE_JIT = 1000

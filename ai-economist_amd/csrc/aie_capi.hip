@@ -28,9 +28,9 @@ struct aie_env {
   hipFunction_t jit_step, jit_reset;  // its entry points; the environment then runs as instance AIE_KERNEL_INSTANCE_JIT
   std::shared_ptr<aie_jit::Job> jit_job;  // the background specialisation aie_create started, until its code is loaded
   int pinned_generic;    // aie_select_step_kernel(AIE_KERNEL_GENERIC): stay on the generic kernel, whatever becomes ready
-  int64_t sample_t;
   float* rew_log;        // aie_set_reward_log: caller's ring of n_slots step slots, or nullptr
-  int32_t rew_log_slots, rew_log_next;
+  int32_t rew_log_slots, rew_log_epoch;  // epoch: bumped by every aie_set_reward_log call (the replicas' slot counters --
+                                         // record field o_rew_slot -- restart at 0 when they see a new one)
   int cv_taps_f32;       // COVID: every uploaded filter tap is a float32 value (aie_upload checks): the window-sum kernel
                          // then keeps its LDS tap table in float32
   int log_active;        // aie_set_dense_log_active: the dense-log replicas record events (default) or run with the rest
@@ -142,6 +142,14 @@ static inline int aie_workgroups_per_cu(size_t lds) {
 extern "C" {
 
 int aie_sizeof_config(void) { return (int)sizeof(aie_config); }
+
+int aie_arena_info(const aie_env* env, int64_t* bytes, int32_t* allocator, int64_t* piece_bytes) {
+  if (!env) return AIE_E_INVALID;
+  if (bytes) *bytes = env->P.arena_bytes;
+  if (allocator) *allocator = !env->owns_arena ? AIE_ARENA_CALLER : env->vmm_total ? AIE_ARENA_VMM : AIE_ARENA_HIPMALLOC;
+  if (piece_bytes) *piece_bytes = (int64_t)env->vmm_piece;
+  return AIE_OK;
+}
 
 int64_t aie_arena_bytes(const aie_config* cfg) {
   aie_params P;
@@ -421,8 +429,16 @@ static void aie_launch_gtb_reset(aie_env* env, const uint8_t* d_mask, int keep_r
 
 int aie_reset(aie_env* env, const uint8_t* d_env_mask, void* stream) {
   if (!env) return AIE_E_INVALID;
-  aie_jit_poll(env);
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  // the one place where a finished background specialisation is adopted without being asked for (an episode boundary;
+  // hipModuleLoadData synchronises, so never from aie_step and never on a stream that is being captured)
+  if (env->jit_job) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)
+      aie_jit_poll(env);
+    else
+      (void)hipGetLastError();
+  }
   if (env->P.c.scenario == AIE_SCN_COVID)
     hipLaunchKernelGGL(aie_covid_reset_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_env_mask, 0);
@@ -446,12 +462,12 @@ int aie_set_reward_log(aie_env* env, float* d_log, int32_t n_slots) {
   }
   env->rew_log = d_log;
   env->rew_log_slots = d_log ? n_slots : 0;
-  env->rew_log_next = 0;
+  env->rew_log_epoch += 1;  // (the arena starts zeroed and this starts at 1: never equal to a fresh record's epoch)
   return AIE_OK;
 }
 
 int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream) {
-  return aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{nullptr, nullptr, 0, 0, 0, nullptr});
+  return aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{});
 }
 
 int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, uint64_t seed,
@@ -461,8 +477,11 @@ int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t
     snprintf(env->err, sizeof(env->err), "aie_step_sample_next: the next-action buffers must differ from the current ones");
     return AIE_E_INVALID;
   }
-  const NextActions next{d_next_a, d_next_p, seed, global_env_offset, env->sample_t, nullptr};
-  env->sample_t += 1;
+  NextActions next{};
+  next.a = d_next_a;
+  next.p = d_next_p;
+  next.seed = seed;
+  next.env_offset = global_env_offset;
   return aie_step_impl(env, d_actions_a, d_actions_p, stream, next);
 }
 
@@ -477,20 +496,23 @@ int aie_step_sample_next_masked(aie_env* env, const int32_t* d_actions_a, const 
     snprintf(env->err, sizeof(env->err), "aie_step_sample_next_masked: the next-action buffers must differ from the current ones");
     return AIE_E_INVALID;
   }
-  NextActions next{d_next_a, d_next_p, seed, global_env_offset, env->sample_t, nullptr};
+  NextActions next{};
+  next.a = d_next_a;
+  next.p = d_next_p;
+  next.seed = seed;
+  next.env_offset = global_env_offset;
   next.masked = 1;
-  env->sample_t += 1;
   return aie_step_impl(env, d_actions_a, d_actions_p, stream, next);
 }
 
 static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, void* stream,
                          const NextActions& next_in) {
   if (!env) return AIE_E_INVALID;
-  aie_jit_poll(env);
   NextActions next = next_in;
-  if (env->rew_log) {  // this step's slot of the reward log (aie_set_reward_log)
-    next.rew_log = env->rew_log + (int64_t)env->rew_log_next * env->P.E * (env->P.n + 2);
-    env->rew_log_next = (env->rew_log_next + 1) % env->rew_log_slots;
+  if (env->rew_log) {  // reward log (aie_set_reward_log): the replicas pick and advance their slot themselves
+    next.rew_log = env->rew_log;
+    next.rew_slots = env->rew_log_slots;
+    next.rew_epoch = env->rew_log_epoch;
   }
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   if (env->P.saez_stride)  // tax_model "saez": the period-start formula runs ahead of the step (aie_kernels_saez.hip)
@@ -653,9 +675,9 @@ int aie_sample_random_actions(aie_env* env, uint64_t seed, int64_t global_env_of
   const aie_params& P = env->P;
   const int64_t tot = (int64_t)P.E * (P.n * P.act_a_width + P.act_p_width);
   hipLaunchKernelGGL(aie_sample_actions_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), P, seed, global_env_offset, env->sample_t, d_actions_a,
-                     d_actions_p);
-  env->sample_t += 1;
+                     static_cast<hipStream_t>(stream), P, env->arena, seed, global_env_offset, d_actions_a, d_actions_p);
+  hipLaunchKernelGGL(aie_sample_advance_kernel, dim3((unsigned)((P.E + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), env->arena, P.a_records, P.rec_bytes, P.o_sample_t, P.E);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
 }
@@ -667,9 +689,9 @@ int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_of
   const aie_params& P = env->P;
   const int64_t tot = (int64_t)P.E * (P.n * P.act_a_width + P.act_p_width);
   hipLaunchKernelGGL(aie_sample_masked_actions_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), P, env->arena, seed, global_env_offset, env->sample_t,
-                     d_actions_a, d_actions_p);
-  env->sample_t += 1;
+                     static_cast<hipStream_t>(stream), P, env->arena, seed, global_env_offset, d_actions_a, d_actions_p);
+  hipLaunchKernelGGL(aie_sample_advance_kernel, dim3((unsigned)((P.E + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), env->arena, P.a_records, P.rec_bytes, P.o_sample_t, P.E);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
 }
@@ -685,7 +707,8 @@ static bool aie_jit_eligible(const aie_env* env) {
 }
 // starts (or joins) the background job that compiles / fetches the code object of this environment's family
 static int aie_jit_request(aie_env* env) {
-  if (env->jit_job) return AIE_OK;
+  if (env->jit_job && env->jit_job->pid == (long)getpid()) return AIE_OK;
+  env->jit_job.reset();  // (inherited across fork(): the parent's compiler thread does not exist here)
   hipDeviceProp_t prop;
   AIE_HIP_CHECK(env, hipGetDeviceProperties(&prop, env->device));
   std::string arch = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
@@ -715,8 +738,8 @@ static bool aie_jit_load(aie_env* env, const std::string& code, bool ose) {
   return true;
 }
 // If the job has finished: load its code object and, unless the caller pinned the generic kernel, switch to it.  Called
-// at the top of aie_step / aie_reset (a launch boundary: the kernels are bit-identical, so the switch is invisible) and
-// by aie_specialize (wait = true).  Returns AIE_OK when the environment now has its specialised kernels.
+// at the top of aie_reset (an episode boundary; the kernels are bit-identical, so the switch is invisible; not while the
+// stream is being captured: loading a module synchronises) and by aie_specialize (wait = true).  aie_step never does.  Returns AIE_OK when the environment now has its specialised kernels.
 static int aie_jit_adopt(aie_env* env, bool wait) {
   if (!env->jit_job) return env->spec_match == AIE_KERNEL_INSTANCE_JIT ? AIE_OK : AIE_E_UNSUPPORTED;
   std::shared_ptr<aie_jit::Job> job = env->jit_job;
@@ -750,6 +773,7 @@ static int aie_jit_adopt(aie_env* env, bool wait) {
   return AIE_OK;
 }
 static inline void aie_jit_poll(aie_env* env) {
+  if (env->jit_job && env->jit_job->pid != (long)getpid()) env->jit_job.reset();
   if (env->jit_job && env->jit_job->state.load(std::memory_order_acquire) != 0) (void)aie_jit_adopt(env, false);
 }
 

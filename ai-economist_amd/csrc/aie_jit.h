@@ -10,6 +10,9 @@
 #pragma once
 #include <dirent.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/file.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -139,6 +142,19 @@ static inline bool code_object(const void* image, size_t image_bytes, int waves,
   }
   if (from_cache) *from_cache = false;
   if (!have_rtc) { err = "libhiprtc.so could not be loaded"; return false; }
+  // one compiler per code object and cache directory: the ranks of a multi-process launch all miss the cache at the same
+  // moment; the others wait on the lock file and then find the object the first one wrote
+  struct FileLock {
+    int fd = -1;
+    ~FileLock() { if (fd >= 0) { (void)flock(fd, LOCK_UN); close(fd); } }
+  } lock;
+  if (use_cache) {
+    lock.fd = open((file + ".lock").c_str(), O_CREAT | O_RDWR, 0600);
+    if (lock.fd >= 0 && flock(lock.fd, LOCK_EX) == 0 && !ignore_cache && read_file(file, code) && code.size() > 1024) {
+      if (from_cache) *from_cache = true;
+      return true;
+    }
+  }
   // the image as a header: exactly the shape of aie_spec_generated.h, one instance
   std::string hdr = "#pragma once\n#define AIE_N_SPECS 1\ntemplate <int K> struct aie_spec_image;\n"
                     "alignas(16) static constexpr unsigned char aie_jit_bytes[" + std::to_string(image_bytes) + "] = {";
@@ -213,6 +229,7 @@ struct Job {
   bool ose = false;
   std::string arch, code, err;
   std::atomic<int> state{0};  // 0 running, 1 code ready, -1 failed
+  long pid = (long)getpid();  // the process whose thread compiles it (a forked child does not wait for the parent's jobs)
   std::atomic<int> claim{0};  // who compiles: 0 nobody yet (queued), 1 the background thread, 2 a caller that waits for
                               // the result anyway (aie_specialize: no point queueing behind other environments' jobs)
 };
@@ -223,20 +240,32 @@ struct JobTable {
   bool shutting_down = false;  // process exit: queued jobs give up, the exit waits for the (at most two) running ones
   std::map<uint64_t, std::weak_ptr<Job>> jobs;
 };
+static inline JobTable*& job_table_slot() {
+  static JobTable* t = nullptr;
+  return t;
+}
 static inline JobTable& job_table() {
-  static JobTable* t = [] {
-    JobTable* tt = new JobTable();  // (never destroyed: detached threads may outlive static destructors)
-    // a compiler thread must not be running when the process tears its libraries down
+  static const bool once = [] {
+    job_table_slot() = new JobTable();  // (never destroyed: detached threads may outlive static destructors)
+    // A compiler thread should not be inside hiprtc when the process tears its libraries down: queued jobs give up at
+    // once, a running compile gets $AIE_JIT_EXIT_WAIT_S seconds (default 10; a compile takes about 5) to finish.
     atexit([] {
       JobTable& T = job_table();
+      const char* w = getenv("AIE_JIT_EXIT_WAIT_S");
+      const int secs = w ? atoi(w) : 10;
       std::unique_lock<std::mutex> lock(T.mu);
       T.shutting_down = true;
       T.cv.notify_all();
-      T.cv.wait_for(lock, std::chrono::seconds(60), [&T] { return T.running == 0; });
+      T.cv.wait_for(lock, std::chrono::seconds(secs > 0 ? secs : 0), [&T] { return T.running == 0; });
     });
-    return tt;
+    // fork(): the child has none of the parent's compiler threads, and the table's mutex may have been locked by one of
+    // them at that moment -- the child starts with a fresh table (jobs of inherited environments are simply never
+    // adopted there: they stay on the generic kernel unless the child calls aie_specialize)
+    pthread_atfork(nullptr, nullptr, [] { job_table_slot() = new JobTable(); });
+    return true;
   }();
-  return *t;
+  (void)once;
+  return *job_table_slot();
 }
 static inline std::shared_ptr<Job> start_job(const void* image, size_t image_bytes, int waves, const char* arch, bool ose) {
   JobTable& T = job_table();

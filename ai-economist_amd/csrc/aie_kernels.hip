@@ -2440,16 +2440,32 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
   int32_t* a;
   int32_t* p;
   uint64_t seed;
-  int64_t env_offset, t;
-  // aie_set_reward_log: this step's slot of the caller's reward log, f32 [E][n + 2] = agents' rewards, the
-  // planner's reward, done -- or nullptr
+  int64_t env_offset;  // (the draw index `t` of the counter RNG is the replica's own record field o_sample_t)
+  // aie_set_reward_log: the caller's reward log, f32 [rew_slots][E][n + 2] = agents' rewards, the planner's reward, done
+  // -- or nullptr.  The slot a step fills is the replica's record field o_rew_slot (advanced by the step itself,
+  // restarted at 0 when rew_epoch differs from the record's o_rew_epoch, i.e. after a new aie_set_reward_log call):
+  // nothing here changes from step to step, so a captured launch can be replayed.
   float* rew_log;
+  int32_t rew_slots, rew_epoch;
   // replicas this launch steps: [e_lo, e_hi), or all of them when e_hi == 0.  An environment with dense-log replicas
   // whose current episode is being logged steps those replicas with aie_step_kernel_log and the rest with its fast
   // kernel (aie_capi.hip: aie_step_impl)
   int32_t e_lo, e_hi;
   int32_t masked;  // aie_step_sample_next_masked (COVID): the next actions are drawn among what the new masks allow
 };
+// This step's slot of the reward log: the replica's slot counter selects it and moves on (`writer`: the one lane that
+// stores the counter back; every lane of the wave calls this with the same fields).
+__device__ __forceinline__ float* rew_log_claim(const NextActions& next, int32_t* slot_field, int32_t* epoch_field, int E,
+                                                int n, bool writer) {
+  if (!next.rew_log) return nullptr;
+  int slot = __builtin_amdgcn_readfirstlane(*slot_field);
+  if (__builtin_amdgcn_readfirstlane(*epoch_field) != next.rew_epoch) slot = 0;
+  if (writer) {
+    *epoch_field = next.rew_epoch;
+    *slot_field = slot + 1 >= next.rew_slots ? 0 : slot + 1;
+  }
+  return next.rew_log + (int64_t)slot * E * (n + 2);
+}
 // SPEC >= 0: a compile-time instance (aie_spec_generated.h): P is a constant image of the parameter block of one
 // configuration -- every dimension, record offset, component list, mask table and magic divisor folds into the
 // instruction stream (no scalar loads of parameters, fully unrolled per-agent loops) -- and only what depends on
@@ -2552,7 +2568,9 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     // ... and the next step's random actions
     if (next.a || next.p) {
       const int per_env = P.n * P.act_a_width + P.act_p_width;
-      for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, c.e, j, next.a, next.p);
+      const int st = uni(*R_I32(c, o_sample_t));  // (the first wave does not touch this field)
+      for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, (int64_t)st, c.e, j, next.a, next.p);
+      if (c.tid == 0) *R_I32(c, o_sample_t) = st + 1;
     }
   }
   __syncthreads();  // components done; the generator's position (and, after a refill that twisted, its state in HBM) is final
@@ -2565,12 +2583,13 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     if (w0_tail_prio) __builtin_amdgcn_s_setprio(2);
     if (!(skip & 8)) write_flat_observations(c, arena);
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
-    if (!(skip & 16)) compute_rewards(c, arena, next.rew_log);  // utilities do not look at the map either
+    float* const rew_log = rew_log_claim(next, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), R.E, P.n, c.tid == 0);
+    if (!(skip & 16)) compute_rewards(c, arena, rew_log);  // utilities do not look at the map either
     AIE_WSYNC();
     if (c.tid == 0) {
       const int done = *R_I32(c, o_timestep) >= R.c.episode_length;
       (arena + c.R.a_done)[c.e] = (uint8_t)done;
-      if (next.rew_log) next.rew_log[(int64_t)c.e * (P.n + 2) + P.n + 1] = done ? 1.0f : 0.0f;
+      if (rew_log) rew_log[(int64_t)c.e * (P.n + 2) + P.n + 1] = done ? 1.0f : 0.0f;
       if (done) *R_I32(c, o_completions) += 1;
     }
     if (w0_tail_prio) __builtin_amdgcn_s_setprio(0);
@@ -3404,26 +3423,36 @@ extern "C" __global__ void aie_seed_kernel(const aie_params P, uint8_t* __restri
 
 // Synthetic uniform random policy of the benchmark: a counter RNG
 // keyed (seed, global replica id, t, agent); one thread per (replica, agent slot).
-extern "C" __global__ void aie_sample_actions_kernel(const aie_params P, uint64_t seed, int64_t env_offset, int64_t t,
-                                                     int32_t* __restrict__ act_a, int32_t* __restrict__ act_p) {
+// The draw index t is the replica's own record field o_sample_t (read here, advanced by aie_sample_advance_kernel behind
+// this launch: no host-side counter travels by value, the pair can be captured in a hipGraph and replayed).
+extern "C" __global__ void aie_sample_actions_kernel(const aie_params P, const uint8_t* __restrict__ arena, uint64_t seed,
+                                                     int64_t env_offset, int32_t* __restrict__ act_a,
+                                                     int32_t* __restrict__ act_p) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int per_env = P.n * P.act_a_width + P.act_p_width;
   if (q >= (int64_t)P.E * per_env) return;
   const int e = (int)(q / per_env);
+  const int64_t t = *reinterpret_cast<const int32_t*>(arena + P.a_records + (int64_t)e * P.rec_bytes + P.o_sample_t);
   aie::sample_action_slot(P, seed, env_offset, t, e, (int)(q - (int64_t)e * per_env), act_a, act_p);
+}
+extern "C" __global__ void aie_sample_advance_kernel(uint8_t* __restrict__ arena, int64_t a_records, int rec_bytes,
+                                                     int o_sample_t, int E) {
+  const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (e < E) *reinterpret_cast<int32_t*>(arena + a_records + (int64_t)e * rec_bytes + o_sample_t) += 1;
 }
 
 // Masked uniform random policy (see include/aie.h: aie_sample_masked_actions).  One thread
 // per (replica, agent) and one per (replica, planner subspace): count the allowed entries
 // of the relevant slice of the flattened mask, pick the floor(u * count)-th one.
 extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, const uint8_t* __restrict__ arena,
-                                                            uint64_t seed, int64_t env_offset, int64_t t,
+                                                            uint64_t seed, int64_t env_offset,
                                                             int32_t* __restrict__ act_a, int32_t* __restrict__ act_p) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int per_env = P.n * P.act_a_width + P.act_p_width;
   if (q >= (int64_t)P.E * per_env) return;
   const int e = (int)(q / per_env);
   const int j = (int)(q - (int64_t)e * per_env);
+  const int64_t t = *reinterpret_cast<const int32_t*>(arena + P.a_records + (int64_t)e * P.rec_bytes + P.o_sample_t);
   const uint32_t u = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)j);
   const float* mask;
   int lo, len, stride = 1;  // mask entry k of the slot's subspace: mask[(lo + k) * stride]

@@ -489,7 +489,6 @@ template <int F, bool RECUR>
 __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                                              const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
                                              const NextActions& next, const int e, const int s, float (*red)[64]) {
-  float* __restrict__ rew_log = next.rew_log;  // this step's slot of aie_set_reward_log, or nullptr
   using namespace aie;
   const aie_params& P = *params;
   const aie_covid_config& V = P.c.covid;
@@ -504,6 +503,11 @@ __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ para
   const int T = P.c.episode_length;
   const int t = uni(*reinterpret_cast<const int32_t*>(rec + P.o_timestep)) + 1;
   if (t > T) return;  // episode over: the caller has to reset (the reference would index past its arrays)
+  // the replica's call counters (beside the timestep in the record): the draw index of the synthetic random policy and
+  // this step's slot of the reward log (aie_set_reward_log; nullptr = off).  Lane 0 stores them back at the end.
+  const int sample_t = uni(*reinterpret_cast<const int32_t*>(rec + P.o_sample_t));
+  float* __restrict__ rew_log = rew_log_claim(next, reinterpret_cast<int32_t*>(rec + P.o_rew_slot),
+                                              reinterpret_cast<int32_t*>(rec + P.o_rew_epoch), P.E, n, s == 0);
   // Every load of the replica's record is issued here, before anything waits: a replica is one wavefront whose whole
   // step is a dependent chain (timestep -> history bytes -> state -> stores), and all 8192 of BASELINE configs[3] are
   // resident at once, so a launch lasts as long as that chain.  What does not depend on the timestep travels beside
@@ -765,7 +769,7 @@ __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ para
       // cooldown, the planner's subsidy levels only on the first day of an interval; NO-OP always (the allowed set is
       // {0} or {0 .. N}, so the pick-th allowed entry of aie_sample_masked_actions is the pick itself)
       if (s <= n) {
-        const uint32_t u = aie_counter_rng(next.seed, (uint64_t)(next.env_offset + e), (uint64_t)next.t, (uint64_t)s);
+        const uint32_t u = aie_counter_rng(next.seed, (uint64_t)(next.env_offset + e), (uint64_t)sample_t, (uint64_t)s);
         const bool open = s < n ? (t >= a.cooldown || V.replay_policies) : (t % V.subsidy_interval == 0 || V.replay_policies);
         const int count = open ? 1 + (s < n ? NL : NS) : 1;
         const int32_t pick = (int32_t)(((uint64_t)u * (uint64_t)count) >> 32);
@@ -773,8 +777,9 @@ __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ para
         else if (next.p) next.p[e] = pick;
       }
     } else {
-      for (int j = s; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, e, j, next.a, next.p);
+      for (int j = s; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, (int64_t)sample_t, e, j, next.a, next.p);
     }
+    if (s == 0) *reinterpret_cast<int32_t*>(rec + P.o_sample_t) = sample_t + 1;
   }
   // window sums: aie_covid_window_kernel, launched behind this one, records today's change and forms the next step's sums
   if constexpr (!RECUR)

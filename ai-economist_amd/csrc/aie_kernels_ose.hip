@@ -724,7 +724,6 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
                                               const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p,
                                               const NextActions& next, uint8_t* lds) {
   using namespace aie;
-  float* __restrict__ rew_log = next.rew_log;  // this step's slot of aie_set_reward_log, or nullptr
   const aie_params& R = *params;
   const aie_params& P = aie_spec_params<SPEC>(params);
   OseScratch s;
@@ -797,6 +796,9 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
   // compute_reward one_step_economy.py:195-222
   ose_metrics(c, s, L);
   OSE_STAMP(c, 9);
+  // this step's slot of aie_set_reward_log (or nullptr): every thread reads the replica's slot counter, thread 0 advances
+  // it behind the barrier below
+  float* __restrict__ rew_log = rew_log_claim(next, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), R.E, n, false);
   {
     double* util = R_F64(c, o_util);
     for (int i = tid; i <= n; i += OSE_NT) {
@@ -810,7 +812,10 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
   __syncthreads();
   if (tid == 0) {
     (arena + c.R.a_done)[c.e] = (uint8_t)done;
-    if (rew_log) rew_log[(int64_t)c.e * (n + 2) + n + 1] = done ? 1.0f : 0.0f;
+    if (rew_log) {
+      rew_log[(int64_t)c.e * (n + 2) + n + 1] = done ? 1.0f : 0.0f;
+      (void)rew_log_claim(next, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), R.E, n, true);
+    }
     if (done) *R_I32(c, o_completions) += 1;
   }
   __syncthreads();
@@ -818,7 +823,9 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
   if (restart) ose_reset_body(c, s, arena, L, true, true);
   if (next.a || next.p) {  // aie_step_sample_next: the uniform random policy's draw for the next step
     const int per_env = P.n * P.act_a_width + P.act_p_width;
-    for (int j = tid; j < per_env; j += OSE_NT) sample_action_slot(P, next.seed, next.env_offset, next.t, c.e, j, next.a, next.p);
+    const int st = *R_I32(c, o_sample_t);
+    for (int j = tid; j < per_env; j += OSE_NT) sample_action_slot(P, next.seed, next.env_offset, (int64_t)st, c.e, j, next.a, next.p);
+    if (tid == 0) *R_I32(c, o_sample_t) = st + 1;  // (one wavefront per replica: every lane has read it)
   }
   ose_store_record(c, arena);
   OSE_STAMP(c, 11);

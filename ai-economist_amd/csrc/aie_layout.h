@@ -28,7 +28,7 @@
 
 #include "aie.h"
 
-#define AIE_MAX_TENSORS 128
+#define AIE_MAX_TENSORS 160
 #define AIE_MAX_MASK 544   /* entries of one agent's flattened action mask (4 x 127 prices + ...) */
 
 /* internal action-subspace slots of a mobile agent */
@@ -209,6 +209,11 @@ typedef struct aie_params {
   int32_t sh_energy_warmup; /* energy_warmup_constant > 0: the labor cost is weighted by 1 - exp(-v / constant)   */
   int32_t sh_eta_is_one;    /* isoelastic_eta == 1: log utility instead of the power form                        */
   int32_t auto_reset;    /* run-time switch (aie_set_auto_reset): replicas restart inside the launch that ends their episode */
+  /* per-replica call counters (record fields, so that nothing a step needs travels by value from a host-side counter: a
+   * captured hipGraph of aie_step / aie_step_sample_next replays correctly): o_sample_t = draws of the synthetic random
+   * policy so far (the `t` of its counter RNG), o_rew_slot = the reward-log slot the next step fills, o_rew_epoch = the
+   * aie_set_reward_log call that slot counter belongs to (a new call restarts the slots at 0 without touching memory) */
+  int32_t o_sample_t, o_rew_slot, o_rew_epoch;
   int32_t dev_draw_window; /* development (tests): capacity of the components' draw window in words, 0 = stage_window_words();
                             * honoured by aie_step_kernel_log only */
 } aie_params;
@@ -438,6 +443,9 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   p->o_cv_p_index = aie__rec(&cur, 8, 4);
   p->o_timestep = aie__rec(&cur, 4, 4);
   p->o_completions = aie__rec(&cur, 4, 4);
+  p->o_sample_t = aie__rec(&cur, 4, 4);
+  p->o_rew_slot = aie__rec(&cur, 4, 4);
+  p->o_rew_epoch = aie__rec(&cur, 4, 4);
   p->rec_bytes = (int32_t)aie__align(cur, 256);
 
   const int64_t E = p->E;
@@ -490,6 +498,8 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
     aie__add(tt, "subsidy_level", AIE_I32, r0 + p->o_cv_subsidy_level, rs, 0, 0, 0, 0, 0, E);
     aie__add(tt, "timestep", AIE_I32, r0 + p->o_timestep, rs, 0, 0, 0, 0, 0, E);
     aie__add(tt, "completions", AIE_I32, r0 + p->o_completions, rs, 0, 0, 0, 0, 0, E);
+    aie__add(tt, "sample_t", AIE_I32, r0 + p->o_sample_t, rs, 0, 0, 0, 0, 0, E);
+    aie__add(tt, "rew_log_slot", AIE_I32, r0 + p->o_rew_slot, rs, 0, 0, 0, 0, 0, E);
     /* stringency level of the 32 most recent days: row (filter_len + day) & 31 (always current) */
     aie__add(tt, "stringency_ring", AIE_U8, r0 + p->o_cv_ring, rs, 2, 32, n, 0, 0, E);
     tt->t[tt->n - 1].stride[1] = 64;
@@ -703,6 +713,9 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
   p->o_auto_warmup = aie__rec(&cur, 4, 4);
   p->o_first_step = aie__rec(&cur, 4, 4);
   p->o_error_flags = aie__rec(&cur, 4, 4);
+  p->o_sample_t = aie__rec(&cur, 4, 4);
+  p->o_rew_slot = aie__rec(&cur, 4, 4);
+  p->o_rew_epoch = aie__rec(&cur, 4, 4);
   p->o_mt_gauss = aie__rec(&cur, 8, 8);
   p->o_mt_pos = aie__rec(&cur, 4, 4);
   p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
@@ -759,6 +772,8 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
     }
     REC("timestep", AIE_I32, p->o_timestep, 0, 0);
     REC("completions", AIE_I32, p->o_completions, 0, 0);
+    REC("sample_t", AIE_I32, p->o_sample_t, 0, 0);
+    REC("rew_log_slot", AIE_I32, p->o_rew_slot, 0, 0);
     REC("labor_first_step", AIE_I32, p->o_first_step, 0, 0);
     REC("error_flags", AIE_I32, p->o_error_flags, 0, 0);
     REC("mt", AIE_U32, p->o_mt, 1, AIE_MT_N);
@@ -1095,6 +1110,9 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->o_auto_warmup = aie__rec(&cur, 4, 4);
   p->o_obs_valid = aie__rec(&cur, 4, 4);
   p->o_error_flags = aie__rec(&cur, 4, 4);
+  p->o_sample_t = aie__rec(&cur, 4, 4);
+  p->o_rew_slot = aie__rec(&cur, 4, 4);
+  p->o_rew_epoch = aie__rec(&cur, 4, 4);
   p->o_mt_gauss = aie__rec(&cur, 8, 8);
   p->o_mt_pos = aie__rec(&cur, 4, 4);
   p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
@@ -1184,6 +1202,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     }
     REC("timestep", AIE_I32, p->o_timestep, 0, 0, 0, 0);
     REC("completions", AIE_I32, p->o_completions, 0, 0, 0, 0);
+    REC("sample_t", AIE_I32, p->o_sample_t, 0, 0, 0, 0);
+    REC("rew_log_slot", AIE_I32, p->o_rew_slot, 0, 0, 0, 0);
     REC("auto_warmup", AIE_I32, p->o_auto_warmup, 0, 0, 0, 0);
     REC("obs_valid", AIE_I32, p->o_obs_valid, 0, 0, 0, 0);
     REC("error_flags", AIE_I32, p->o_error_flags, 0, 0, 0, 0);

@@ -213,6 +213,13 @@ class DeviceBackend:
             C.c_void_p(na.data_ptr()), C.c_void_p(np_.data_ptr()), self._stream()))
         return na, np_
 
+    def arena_info(self):
+        """{"bytes", "allocator": "caller" (a torch tensor) | "hipMalloc" | "vmm", "piece_mib"} -- aie_arena_info."""
+        b, a, pc = C.c_int64(), C.c_int32(), C.c_int64()
+        self._check(self.lib.aie_arena_info(self.handle, C.byref(b), C.byref(a), C.byref(pc)))
+        name = _cabi.ARENA_ALLOCATORS[a.value]
+        return {"bytes": int(b.value), "allocator": "torch" if name == "caller" else name, "piece_mib": int(pc.value) >> 20}
+
     def specialize(self, required=False):
         """aie_specialize: kernels compiled for this configuration at run time (hiprtc, cached).  Returns True when the
         environment now runs on specialised kernels; False (or, with required=True, an exception) when that is not

@@ -102,6 +102,15 @@ class BaseEnvironment:
             else:
                 cname, ckw = list(spec.keys())[0], list(spec.values())[0]
             ccls = component_registry.get(cname)
+            if not int(getattr(ccls, "comp_id", 0)):
+                # The registry is open like the reference's (base_component.py:378, registrar.py:48-66), but a component's
+                # dynamics are a device kernel here: Python component_step / generate_observations code cannot run
+                # inside a batched launch.  Said at construction, not as "unknown component id 0" at the first reset.
+                raise NotImplementedError(
+                    "component {!r} ({}) has no device kernel: this backend runs the reference's built-in components only "
+                    "(Build, ContinuousDoubleAuction, Gather, PeriodicBracketTax, WealthRedistribution, SimpleLabor, "
+                    "ControlUSStateOpenCloseStatus, FederalGovernmentSubsidy, VaccinationCampaign); a registered class "
+                    "needs a `comp_id` the kernels know (include/aie.h: AIE_COMP_*)".format(cname, ccls.__name__))
             self._register_entities(ccls.required_entities)
             obj = ccls(self.n_agents, self._episode_length, inventory_scale=self.inv_scale, **ckw)
             if obj.name in self._components_dict:

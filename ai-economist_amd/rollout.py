@@ -1,0 +1,141 @@
+"""Trainer-facing rollout loop: policy -> env.step with NOTHING on the host between the steps.
+
+The reference's GPU trainer calls, per step, `sample actions from the policy` then `env_wrapper.step_all_envs()`
+(ai_economist/training/training_script.py:88-133 builds that trainer; F/env_wrapper.py:355-377 is the step it drives),
+each a handful of kernel launches issued from Python.  At 25 us per environment step the host is the bottleneck long
+before the GPU is.  `GraphedStep` captures one iteration -- the caller's policy (any torch code that reads the
+observation tensors and writes the action buffers), `aie_step`, and the masked reset of the replicas that finished --
+into a hipGraph once and replays it: one host call per environment step, or per `unroll` steps.
+
+Replay-safety is a property of the C ABI, not of this wrapper: aie_step takes nothing by value that changes from step
+to step (the random-policy draw index and the reward-log slot are per-replica record fields the kernels advance
+themselves, include/aie.h), and never loads code or synchronises.  tests/test_gpu_parity.py:
+test_step_is_hipgraph_replayable replays a captured loop against its eager twin and the oracle.
+
+torch is plumbing here (streams, graph capture, the policy network); the environment step is the HIP kernel.
+"""
+
+
+class GraphedStep:
+    def __init__(self, env, policy, auto_reset=True, unroll=1, warmup=3):
+        """env: a batched environment (foundation.make_env_instance(..., n_envs=E)), already reset.
+        policy(tensors, actions_a, actions_p): reads observation tensors (env.backend.tensors: "obs_a_flat",
+        "obs_a_action_mask", "obs_p_flat", ... zero-copy views of the arena) and writes int32 actions IN PLACE into
+        actions_a [E, n, width] / actions_p [E, width_p].  It is captured: no host synchronisation, no data-dependent
+        Python control flow, fixed shapes.
+        auto_reset: replicas restart right behind the step that ends their episode (aie_set_auto_reset).
+        unroll: environment steps per replay."""
+        import torch
+
+        self.torch = torch
+        self.env, self.be = env, env.backend
+        self.policy = policy
+        self.unroll = int(unroll)
+        be = self.be
+        if auto_reset:
+            be.set_auto_reset(True)
+        self.actions_a, self.actions_p = be._action_buffers(0)
+        self.graph = None
+        self._capture(warmup)
+
+    def _iteration(self):
+        self.policy(self.be.tensors, self.actions_a, self.actions_p)
+        self.be.step(self.actions_a, self.actions_p)
+
+    def eager(self, iterations=1):
+        """The same iteration issued call by call (what the capture recorded): `iterations` x unroll steps."""
+        for _ in range(iterations * self.unroll):
+            self._iteration()
+
+    def _capture(self, warmup):
+        torch = self.torch
+        # torch's capture protocol: run the work a few times on a side stream first (lazy initialisations -- cuBLAS/
+        # hipBLASLt handles, allocator pools -- must not happen inside the capture); the warm-up iterations ARE
+        # environment steps (the caller resets afterwards if it wants a clean start)
+        side = torch.cuda.Stream(device=self.be.device)
+        side.wait_stream(torch.cuda.current_stream(self.be.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(0, warmup)):
+                self._iteration()
+        torch.cuda.current_stream(self.be.device).wait_stream(side)
+        torch.cuda.synchronize(self.be.device)
+        self.warmup_steps = max(0, warmup)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            for _ in range(self.unroll):
+                self._iteration()
+
+    def replay(self, n=1):
+        """n replays = n * unroll environment steps; asynchronous like every other call."""
+        for _ in range(n):
+            self.graph.replay()
+
+
+class MaskedMLPPolicy:
+    """A small policy network of the shape the reference's trainers use on the flat observations (fully connected
+    trunk, one categorical head per action subspace, `action_mask` applied to the logits: base_env.py:141-145,
+    tutorials/rllib/env_wrapper.py:50-211) with random-init weights: enough to put a real policy's launches --
+    GEMMs, masking, sampling -- between the environment steps.  Sampling is Gumbel-max with noise from a device-side
+    counter hash (deterministic, capture-safe, identical eager and replayed)."""
+
+    def __init__(self, be, hidden=128, seed=0, dtype=None):
+        import torch
+
+        self.torch = torch
+        self.be = be
+        t = be.tensors
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        dev = be.device
+        dtype = dtype or torch.float32
+        self.dtype = dtype
+        FA = t["obs_a_flat"].shape[-1]
+        MA = t["obs_a_action_mask"].shape[-1]
+        FP = t["obs_p_flat"].shape[-1]
+        MP = t["obs_p_action_mask"].shape[-1]
+
+        def lin(i, o):
+            return (torch.randn(i, o, generator=g) / i ** 0.5).to(dev, dtype), torch.zeros(o, device=dev, dtype=dtype)
+
+        self.wa1, self.ba1 = lin(FA, hidden)
+        self.wa2, self.ba2 = lin(hidden, hidden)
+        self.wa3, self.ba3 = lin(hidden, MA)
+        self.wp1, self.bp1 = lin(FP, hidden)
+        self.wp2, self.bp2 = lin(hidden, hidden)
+        self.wp3, self.bp3 = lin(hidden, MP)
+        self.MA, self.MP = MA, MP
+        cfg = be.cfg
+        self.multi_a = bool(cfg.multi_action_mode_agents)
+        self.multi_p = bool(cfg.multi_action_mode_planner)
+        self.p_width = be._act_p_width()
+        if self.multi_a:
+            raise NotImplementedError("MaskedMLPPolicy: single-action agents (the BASELINE configurations)")
+        self.counter = torch.zeros((), dtype=torch.float32, device=dev)
+        self.idx_a = torch.arange(be.E * be.n * MA, device=dev, dtype=torch.float32).view(be.E, be.n, MA)
+        self.idx_p = torch.arange(be.E * MP, device=dev, dtype=torch.float32).view(be.E, MP)
+
+    def _gumbel(self, idx, salt):
+        torch = self.torch
+        u = torch.frac(torch.sin(idx * 12.9898 + (self.counter + salt) * 78.233) * 43758.5453).abs_()
+        u = u.clamp_(1e-6, 1.0 - 1e-6)
+        return -torch.log(-torch.log(u))
+
+    def __call__(self, tensors, actions_a, actions_p):
+        torch = self.torch
+        xa = tensors["obs_a_flat"].to(self.dtype)
+        h = torch.relu(xa @ self.wa1 + self.ba1)
+        h = torch.relu(h @ self.wa2 + self.ba2)
+        la = (h @ self.wa3 + self.ba3).float()
+        la = la + self._gumbel(self.idx_a, 0.0)
+        la = la.masked_fill(tensors["obs_a_action_mask"] < 0.5, -1e30)
+        actions_a.view(self.be.E, self.be.n).copy_(la.argmax(-1))
+        xp = tensors["obs_p_flat"].to(self.dtype)
+        h = torch.relu(xp @ self.wp1 + self.bp1)
+        h = torch.relu(h @ self.wp2 + self.bp2)
+        lp = (h @ self.wp3 + self.bp3).float()
+        lp = lp + self._gumbel(self.idx_p, 0.5)
+        lp = lp.masked_fill(tensors["obs_p_action_mask"] < 0.5, -1e30)
+        if self.multi_p and self.p_width > 1:  # one categorical head per bracket: [E, width, 1 + rates]
+            actions_p.copy_(lp.view(self.be.E, self.p_width, -1).argmax(-1))
+        else:
+            actions_p.view(self.be.E).copy_(lp.argmax(-1))
+        self.counter += 1.0

@@ -46,6 +46,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable copy rate
+INFINITY_CACHE_BYTES = 256 << 20  # MI355X memory-side cache (MI355X_MICROARCH.md): an arena that fits is re-read from it,
+#                                   and FETCH_SIZE / WRITE_SIZE (L2 <-> fabric) then are not DRAM traffic
 ACTION_SEED = 1234
 ENV_SEED = 1
 STAGGER_STRIDE = 20  # steps between the prologue's block resets = steps between reset launches in the rollout
@@ -133,6 +135,19 @@ WORKLOADS = {
                      "C4 runs the opt-in O(1) recurrence)",
                 cfg=lambda: dict(_c4_cfg(), filter_recurrence=False), envs=8192, survey_bytes=1580.0,
                 kernel="aie_covid_step_kernel"),
+    "C4xu": dict(short="BASELINE configs[3] COVID, window sums, SURVEY 8(d)'s UNMASKED uniform policy",
+                 desc="BASELINE configs[3] with the reference's window sums under the policy SURVEY.md 8(d) prescribes: "
+                      "agents U{0..10}, planner U{0..20} regardless of the masks (the reference's components do not re-check "
+                      "them, covid19_components.py:180-199): stringency levels change on most days",
+                 cfg=lambda: dict(_c4_cfg(), filter_recurrence=False), envs=8192, survey_bytes=1580.0,
+                 kernel="aie_covid_step_kernel", policy="unmasked"),
+    "C2@16384": dict(short="configs[1] at 16384 replicas/GPU (arena 0.72 GB: past the 256 MiB Infinity Cache)",
+                     desc="BASELINE configs[1] with 16384 replicas on the GPU: the arena (0.72 GB) no longer fits the 256 MiB "
+                          "Infinity Cache", cfg=lambda: dict(C2_CFG), envs=16384, survey_bytes=10984.0,
+                     kernel="aie_step_kernel", profile_tag="c2_e16384"),
+    "C2@65536": dict(short="configs[1] at 65536 replicas/GPU (arena 2.9 GB)",
+                     desc="BASELINE configs[1] with 65536 replicas on the GPU (arena 2.9 GB)", cfg=lambda: dict(C2_CFG),
+                     envs=65536, survey_bytes=10984.0, kernel="aie_step_kernel", profile_tag="c2_e65536"),
     "C5": dict(short="BASELINE configs[4]: one-step-economy 100 agents + SimpleLabor + tax",
                desc="BASELINE configs[4]: one-step-economy, 100 agents + SimpleLabor + PeriodicBracketTax(period 1), "
                     "episode_length 2",
@@ -180,6 +195,11 @@ def layout_bytes_per_env_step(be, wl):
     return b
 
 
+def profile_tag(wl):
+    """profiles/rNN_<tag>_{pmc,sq_counters,kernel_stats}.*: the committed rocprofv3 summaries of a workload."""
+    return WORKLOADS[wl].get("profile_tag", wl.lower())
+
+
 def measured_traffic(wl, envs_per_gpu):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary for this workload
     (profiles/*<wl>*pmc.json, made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same
@@ -190,10 +210,11 @@ def measured_traffic(wl, envs_per_gpu):
     def version(path):
         return [int(x) for x in re.findall(r"\d+", os.path.basename(path))]
 
-    tag = wl.lower()
     if wl not in WORKLOADS:
         return None, None
-    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")) if ("_%s_" % tag) in os.path.basename(f)]
+    tag = profile_tag(wl)
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))
+             if re.match(r"^r\d+_%s_pmc\.json$" % re.escape(tag), os.path.basename(f))]
     if wl == "C2":
         files += [f for f in glob.glob(os.path.join(ROOT, "profiles", "r01_v*_pmc.json"))]
     files = sorted(files, key=version)
@@ -217,7 +238,7 @@ def usable_cores():
     return n
 
 
-def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64):
+def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64, policy="unmasked"):
     """The reference's own env.step (oracle/_ref or the live tree, through oracle/ref_harness.py): P = usable cores
     processes, one environment each, pinned, stepped concurrently with uniform random actions."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -240,7 +261,7 @@ def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64):
     for k in range(P):
         cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_worker.py"), "--cfg-json", json.dumps(cfg),
                "--core", str(cores[k % len(cores)]), "--start", repr(start), "--seconds", repr(seconds),
-               "--seed", str(1 + k)]
+               "--seed", str(1 + k), "--policy", policy]
         procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
                                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")))
     rate, steps, late, n_agents, ok, resets = 0.0, 0, 0, None, 0, 0
@@ -260,15 +281,15 @@ def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64):
     if not ok:
         return None
     return dict(value=rate, unit="agent-steps/s", cores=ok, kind="reference", per_core=rate / ok,
-                steps=steps, resets=resets, seconds=seconds,
-                sample_short="%d pinned procs x 1 env, unmodified reference env.step, free-running %.0f s window: %d steps, "
-                             "%d env.reset() inside it" % (ok, seconds, steps, resets),
+                steps=steps, resets=resets, seconds=seconds, policy=policy,
+                sample_short="%d pinned procs x 1 env, unmodified reference env.step, %s uniform policy, free-running %.0f s "
+                             "window: %d steps, %d env.reset() inside it" % (ok, policy, seconds, steps, resets),
                 sample="%d pinned processes x one environment each, the unmodified reference env.step "
-                       "(base_env.py:929-1032, %s) stepped concurrently for %.0f s with uniform random actions: "
+                       "(base_env.py:929-1032, %s) stepped concurrently for %.0f s with uniform random actions (%s): "
                        "%d steps in total (%d agents each), %d episode ends (env.reset()) inside the window -- a "
                        "free-running wall-clock window, not SURVEY 8(d)'s 3 whole episodes; host reports %d usable cores%s"
                        % (ok, "byte-compiled into oracle/_ref" if not ref_harness.reference_is_live_tree()
-                          else "live tree", seconds, steps, n_agents, resets, ncores,
+                          else "live tree", seconds, policy, steps, n_agents, resets, ncores,
                           ", %d workers started late" % late if late else ""))
 
 
@@ -412,12 +433,13 @@ def issue_counters(wl):
     import glob
     import re
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_sq_counters.json" % wl.lower())),
+    files = sorted([f for f in glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json"))
+                    if re.match(r"^r\d+_%s_sq_counters\.json$" % re.escape(profile_tag(wl)), os.path.basename(f))],
                    key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     if not files:
         return None, None, None
     d = json.load(open(files[-1]))
-    if wl == "C4x" and any("window_kernel" in k for k in d):
+    if wl in ("C4x", "C4xu") and any("window_kernel" in k for k in d):
         # window sums: a step is two launches (the step kernel, then the change-event lists' upkeep): their sum
         rows = [v for k, v in d.items() if isinstance(v, dict) and ("covid_step_kernel" in k or "window_kernel" in k)]
         return (sum(v["wave_instructions_per_launch"] for v in rows), os.path.relpath(files[-1], ROOT),
@@ -471,7 +493,7 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
     if args.generic_kernel:  # development: what a configuration without an instance runs
         be.lib.aie_select_step_kernel(be.handle, 1)
     roll = Rollout(wl, env, env_offset, stagger=not args.no_stagger, auto_reset=not args.no_auto_reset,
-                   unmasked_covid=args.covid_unmasked_policy)
+                   unmasked_covid=args.covid_unmasked_policy or W.get("policy") == "unmasked")
     gc.collect()
     gc.disable()  # no collector pause between here and the end of the timed window (it may be as short as 20 launches);
     #               collected now, while the GPU has nothing queued: a pause later would let it run dry before the window
@@ -552,12 +574,18 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
         elapsed = max(per_rank)
 
     out = None
+    region_ms = ev0.elapsed_time(ev1)
+    timed_resets = roll.reset_events[n_warm_resets:]
+    reset_ms = sum(a.elapsed_time(b) for a, b in timed_resets)
+    launches_in_region = steps - (1 if first_outside else 0)
+    avg_ms = (region_ms - reset_ms) / launches_in_region
+    per_rank_launch_ms = [avg_ms]
+    if world > 1:  # every rank's own kernel time (HIP events on its launch stream): separates it from the gather's wait
+        tt = torch.tensor([avg_ms], dtype=torch.float64, device=device)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        torch.distributed.all_gather(allt, tt)
+        per_rank_launch_ms = [float(x.item()) for x in allt]
     if rank == 0:
-        region_ms = ev0.elapsed_time(ev1)
-        timed_resets = roll.reset_events[n_warm_resets:]
-        reset_ms = sum(a.elapsed_time(b) for a, b in timed_resets)
-        launches_in_region = steps - (1 if first_outside else 0)
-        avg_ms = (region_ms - reset_ms) / launches_in_region
         lay = layout_bytes_per_env_step(be, wl)
         units = (n + 1) if wl.startswith("C4") else n  # C4's per-unit figure counts the planner
         survey_per_launch = W["survey_bytes"] * units * E
@@ -600,7 +628,10 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
             bound = "issue"
         else:
             bound = "latency"
+        arena = be.arena_info()
         roof = dict(
+            arena_bytes=arena["bytes"], fits_infinity_cache=arena["bytes"] <= INFINITY_CACHE_BYTES,
+            arena_allocator=arena["allocator"], arena_piece_mib=arena["piece_mib"],
             bound=bound, roof="hbm", kernel=kernel_name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, hbm_traffic_frac=traffic_frac,
             issue_frac=issue_frac, wave_instructions_per_launch=insts, issue_source=insts_src,
@@ -633,13 +664,15 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
                                                 "C3": "gather-trade-build 25x25 10-agent batched envs",
                                                 "C4": "covid19_env 51 US-state agents + planner",
                                                 "C4x": "covid19_env 51 US-state agents + planner",
+                                                "C4xu": "covid19_env 51 US-state agents + planner, unmasked policy",
+                                                "C2@16384": "gather-trade-build 25x25 4-agent batched envs, 16384 replicas",
+                                                "C2@65536": "gather-trade-build 25x25 4-agent batched envs, 65536 replicas",
                                                 "C5": "one_step_economy 100 agents + SimpleLabor + planner tax"}[wl],
             "value": agent_steps / elapsed, "unit": "agent-steps/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"C4": "f32 state, f64 filter bank (f32 observations)",
-                      "C4x": "f32 state, f64 filter bank (f32 observations)"}.get(
-                wl, "u8/i32 state + f64 coin/utility (f32 observations)"),
+            "dtype": ("f32 state, f64 filter bank (f32 observations)" if wl.startswith("C4") else
+                      "u8/i32 state + f64 coin/utility (f32 observations)"),
             "data": "synthetic",
             "config": {
                 "workload": "%s: %s; uniform random policy; mobile agents counted (planner excluded)" % (wl, W["desc"]),
@@ -647,6 +680,7 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
                 "parallelism_short": ("replica sharding x%d, RCCL (reward,done) gather to rank 0" % world) if world > 1
                 else "single GPU",
                 "envs_per_gpu": E, "global_envs": world * E, "n_agents": n,
+                "policy_short": "masked" if roll.masked else "unmasked",
                 "rng": "per-replica NumPy-legacy MT19937 (parity mode)",
                 "policy": ("uniform random over the actions the masks allow (counter RNG)" if roll.masked else
                            "uniform random (counter RNG)") + ("; the draw for step t+1 happens inside the launch of "
@@ -665,7 +699,7 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
                 "kernel_specialisation": ("run time (aie_specialize)" if inst == 1000 else
                                           "compile time" if inst >= 0 else "none (generic kernel)"),
             },
-            "per_rank_seconds": per_rank,
+            "per_rank_seconds": per_rank, "per_rank_avg_launch_ms": per_rank_launch_ms,
             "host_issue_seconds": t_issue, "gpu_region_seconds": region_ms * 1e-3,
             "exchange_ok": (gather is not None) if (world > 1 or args.force_gather) else None,
             "roofline": roof,
@@ -688,9 +722,9 @@ LINE_LIMIT = 4096
 # actually used (COVID: SURVEY's figure assumes the 601-day window is streamed every step, which neither kernel does any
 # more -- the sums over the window are the same float64, the bytes are not)
 ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_final_layout", "traffic", "hbm_traffic_frac",
-             "valu_frac", "avg_launch_ms", "algorithmic_bytes_per_launch")
-SIDE_KEYS = ("value", "ms_per_step", "avg_launch_ms", "frac", "frac_final_layout", "hbm_traffic_frac", "valu_frac", "bound",
-             "kernel", "gpu_region_seconds")
+             "valu_frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "arena_bytes", "fits_infinity_cache")
+# (side entries: no kernel names -- the detail file has them -- so that thirteen of them fit the 4 KB line)
+SIDE_KEYS = ("value", "ms_per_step", "avg_launch_ms", "frac", "frac_final_layout", "hbm_traffic_frac", "valu_frac", "bound")
 
 
 def _sig(x, digits=5):
@@ -732,10 +766,23 @@ def compact_line(out):
             if "error" in r:
                 sides[name] = {"error": r["error"][:80]}
                 continue
+            if r.get("compact"):  # workloads with their own shape (C2pi: a policy in the loop)
+                sides[name] = dict(r["compact"])
+                continue
             flat = dict(r.get("roofline") or {}, **{k: r.get(k) for k in ("value", "ms_per_step", "gpu_region_seconds")})
-            sides[name] = {k: flat.get(k) for k in SIDE_KEYS}
+            sides[name] = {k: flat.get(k) for k in SIDE_KEYS if flat.get(k) is not None}
+            if name.startswith("C4"):
+                sides[name]["policy"] = (r.get("config") or {}).get("policy_short")
+            if not flat.get("fits_infinity_cache", True):
+                sides[name]["arena_bytes"] = flat.get("arena_bytes")
+            if name == "C5":
+                sides[name].update({k: flat.get(k) for k in ("arena_allocator", "arena_piece_mib")})
+                if r.get("fresh_process"):
+                    sides[name]["fresh_ms"] = r["fresh_process"].get("avg_launch_ms")
             if r.get("cpu_baseline"):
                 sides[name]["cpu_ref"] = r["cpu_baseline"]["value"]
+                if name.startswith("C4"):
+                    sides[name]["cpu_policy"] = r["cpu_baseline"].get("policy")
         line["workloads"] = sides
     line["detail"] = "bench_detail.json"
     line = _sig(line)
@@ -751,7 +798,7 @@ def compact_line(out):
 # the other BASELINE configurations a default run also times, in short windows: (workload, steps, warm-up)
 # (C5: the first ~10 launches over its 7 GB arena run 15 % slower than the steady state -- 1.68 ms per launch measured
 # with 6 warm-up launches, 1.447 ms with 10, 30 or 60 on the same box)
-SIDE_CPU_BASELINES = ("C1", "C3", "C4x", "C5")  # (C2v, P2 and C4 step the same reference code as C2 and C4x)
+SIDE_CPU_BASELINES = ("C1", "C3", "C4x", "C4xu", "C5")  # (C2v, P2 and C4 step the same reference code as C2 and C4x)
 SIDE_CPU_SECONDS = 3.0
 
 
@@ -767,7 +814,102 @@ def emit(out, detail_file):
     print(compact_line(out), flush=True)
 
 
-SIDE_WORKLOADS = [("C1", 200, 20), ("C2v", 200, 20), ("P2", 200, 20), ("C3", 200, 20), ("C4", 200, 20), ("C4x", 100, 10), ("C5", 60, 20)]
+SIDE_WORKLOADS = [("C1", 200, 20), ("C2v", 200, 20), ("P2", 200, 20), ("C3", 200, 20), ("C4", 200, 20), ("C4x", 100, 10),
+                  ("C4xu", 100, 10), ("C2@16384", 100, 20), ("C2@65536", 60, 10), ("C5", 60, 20)]
+
+
+def run_policy_workload(args, steps, warmup, device):
+    """C2pi: BASELINE configs[1] with a POLICY in the loop: a small torch MLP on `obs_a_flat` /
+    `obs_p_flat`, `action_mask` applied to its logits, Gumbel-max sampling, actions written on the device, aie_step --
+    issued call by call from Python (eager) and as one captured hipGraph replay per step
+    (ai_economist_amd/rollout.py).  Everything else in this file fuses the random draw into the step kernel; this is
+    what a trainer's rollout worker sees."""
+    import gc
+
+    import torch
+
+    from ai_economist_amd.rollout import GraphedStep, MaskedMLPPolicy
+
+    E = 4096
+    env = make_env(dict(C2_CFG), n_envs=E, device=device)
+    env.seed(ENV_SEED)
+    env.reset()
+    be = env.backend
+    n = env.n_agents
+    pol = MaskedMLPPolicy(be, hidden=128)
+    gs = GraphedStep(env, pol, auto_reset=True, warmup=3)
+    # the policy alone, captured the same way: what share of a replayed step is the policy's
+    g_pol = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_pol):
+        pol(be.tensors, gs.actions_a, gs.actions_p)
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            fn()
+        ev1.record()
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        return dt, t_issue, ev0.elapsed_time(ev1) * 1e-3
+
+    dt_e, iss_e, gpu_e = timed(lambda: gs.eager(1))
+    dt_g, iss_g, gpu_g = timed(lambda: gs.replay(1))
+    dt_p, _, gpu_p = timed(g_pol.replay)
+    assert int(be.tensors["error_flags"].abs().sum()) == 0  # the policy honoured the masks
+    out = {
+        "metric": "agent-steps/sec, gather-trade-build 25x25 4-agent batched envs, torch MLP policy in the loop",
+        "value": E * n * steps / dt_g, "unit": "agent-steps/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": dt_g / steps * 1e3, "host_issue_seconds": iss_g, "gpu_region_seconds": gpu_g,
+        "eager": {"value": E * n * steps / dt_e, "ms_per_step": dt_e / steps * 1e3, "host_issue_seconds": iss_e,
+                  "gpu_region_seconds": gpu_e},
+        "policy_only_ms_per_step": gpu_p / steps * 1e3,
+        "config": {"workload": "C2pi: BASELINE configs[1], 4096 replicas, lock-step with auto-reset; policy = 3-layer MLP "
+                               "(hidden 128, fp32, random init) on obs_a_flat [E,4,%d] and obs_p_flat [E,%d], action_mask "
+                               "applied to the logits, Gumbel-max sampling on the device; one hipGraph replay per step "
+                               "(policy + aie_step + auto-reset launch) vs the same calls issued from Python"
+                               % (be.tensors["obs_a_flat"].shape[-1], be.tensors["obs_p_flat"].shape[-1]),
+                   "envs_per_gpu": E, "n_agents": n},
+    }
+    out["compact"] = _sig({"value": out["value"], "ms_per_step": out["ms_per_step"], "host_issue_s": iss_g,
+                           "eager_value": out["eager"]["value"], "eager_ms_per_step": out["eager"]["ms_per_step"],
+                           "eager_host_issue_s": iss_e, "policy_ms": out["policy_only_ms_per_step"], "steps": steps})
+    del gs, g_pol, pol, be, env
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def c5_fresh_process(trials=3, piece_mb=None):
+    """C5's launch time in FRESH processes (its 7 GB arena lands on the memory channels differently from process to
+    process and box to box: the figure of the long-lived bench process alone says little): `trials` sub-processes of 60
+    timed launches each; min / median of their avg_launch_ms."""
+    res = []
+    env = dict(os.environ)
+    if piece_mb is not None:
+        env["AIE_ARENA_PIECE_MB"] = str(piece_mb)
+    for _ in range(trials):
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "C5", "--steps", "60", "--warmup",
+                                  "20", "--no-cpu-baseline", "--no-workloads", "--detail-file", os.devnull],
+                                 capture_output=True, text=True, timeout=300, env=env).stdout
+            d = json.loads(out.strip().splitlines()[-1])
+            res.append(d["roofline"]["avg_launch_ms"])
+        except Exception:
+            pass
+    if not res:
+        return None
+    res.sort()
+    return {"avg_launch_ms": res[len(res) // 2], "min": res[0], "max": res[-1], "trials": len(res),
+            "piece_mib": piece_mb if piece_mb is not None else int(os.environ.get("AIE_ARENA_PIECE_MB", "64"))}
 
 
 def main():
@@ -854,6 +996,18 @@ def main():
                                                     "config", "roofline", "gpu_region_seconds")}
                 except Exception as exc:  # a side line must not take the headline down
                     sides[swl] = {"error": repr(exc)}
+            try:
+                sides["C2pi"] = run_policy_workload(args, 200, 20, device)
+            except Exception as exc:
+                sides["C2pi"] = {"error": repr(exc)}
+            if "error" not in sides.get("C5", {"error": 1}):
+                # the same C5 window in fresh processes; if they stay slow, other physical piece sizes of the arena
+                fresh = c5_fresh_process(3)
+                if fresh:
+                    sides["C5"]["fresh_process"] = fresh
+                    if fresh["avg_launch_ms"] >= 1.55:
+                        alts = {mb: c5_fresh_process(1, piece_mb=mb) for mb in (16, 128)}
+                        sides["C5"]["fresh_process_other_piece_sizes"] = alts
             out["workloads"] = sides
         if not args.no_cpu_baseline and world == 1:
             ref = None
@@ -873,7 +1027,9 @@ def main():
             for swl in SIDE_CPU_BASELINES:
                 if swl in side_cfgs and "error" not in out["workloads"][swl]:
                     try:
-                        r = cpu_reference_baseline(side_cfgs[swl], seconds=SIDE_CPU_SECONDS)
+                        r = cpu_reference_baseline(side_cfgs[swl], seconds=SIDE_CPU_SECONDS,
+                                                   policy=out["workloads"][swl]["config"].get("policy_short", "unmasked")
+                                                   if swl.startswith("C4") else "unmasked")
                         if r is not None:
                             out["workloads"][swl]["cpu_baseline"] = r
                     except Exception as exc:

@@ -424,6 +424,14 @@ int aie_set_global_saez_buffer(aie_env* env, const double* d_pairs, int64_t n_pa
  * it per episode (foundation/base_env.py: reset). */
 int aie_set_dense_log_active(aie_env* env, int on);
 
+/* Where the arena lives: *bytes = its size, *allocator = AIE_ARENA_CALLER (passed to aie_create), AIE_ARENA_HIPMALLOC
+ * (one hipMalloc) or AIE_ARENA_VMM (a virtual range backed by physical pieces of *piece_bytes each; see aie_create).
+ * Any out pointer may be NULL.  (Launch times of the store-bound kernels depend on it: a measurement names it.) */
+#define AIE_ARENA_CALLER 0
+#define AIE_ARENA_HIPMALLOC 1
+#define AIE_ARENA_VMM 2
+int aie_arena_info(const aie_env* env, int64_t* bytes, int32_t* allocator, int64_t* piece_bytes);
+
 /* sizeof(aie_config) as this library was built: a binding checks its mirror of the struct against it. */
 int aie_sizeof_config(void);
 

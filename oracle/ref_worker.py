@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--start", type=float, default=0.0)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--policy", choices=["unmasked", "masked"], default="unmasked",
+                    help="unmasked: i.i.d. uniform over the full action range (SURVEY 8(d)); masked: uniform over the entries "
+                         "the current `action_mask` observation allows (what bench.py's mask-respecting GPU legs draw)")
     args = ap.parse_args()
     if args.core >= 0:
         try:
@@ -44,22 +47,49 @@ def main():
     kw["components"] = [tuple(c) for c in kw["components"]]
     env = foundation.make_env_instance(scenario, **kw)
     env.seed(args.seed)
-    env.reset()
+    obs = [env.reset()]
     n = env.n_agents
     A = env.world.agents[0].action_spaces
     pl = env.world.planner
-    p_dims = pl.action_spaces if pl.multi_action_mode else None
+    # the planner always acts: one index per subspace in multi-action mode, one flat index otherwise (round 4 left the
+    # single-action planner -- COVID's -- without an action)
+    p_dims = np.atleast_1d(pl.action_spaces) if pl.multi_action_mode else None
+    p_flat = None if pl.multi_action_mode else int(pl.action_spaces)
     rng = np.random.RandomState(1234 + args.seed)
+    masked = args.policy == "masked"
 
     resets = [0]
 
+    def pick(mask):
+        ok = np.flatnonzero(np.asarray(mask).ravel() > 0.5)
+        return int(ok[rng.randint(len(ok))]) if len(ok) else 0
+
+    def agent_mask(ob, i):
+        if "a" in ob:  # collated observations (COVID run config): [entries, n]
+            return np.asarray(ob["a"]["action_mask"])[:, i]
+        return ob[str(i)]["action_mask"]
+
     def one_step():
-        acts = {str(i): int(a) for i, a in enumerate(rng.randint(0, A, size=n))}
-        if p_dims is not None and len(np.atleast_1d(p_dims)):
-            acts["p"] = [int(rng.randint(0, d)) for d in np.atleast_1d(p_dims)]
-        _, _, done, _ = env.step(acts)
+        ob = obs[0]
+        if masked:
+            acts = {str(i): pick(agent_mask(ob, i)) for i in range(n)}
+        else:
+            acts = {str(i): int(a) for i, a in enumerate(rng.randint(0, A, size=n))}
+        if p_dims is not None and len(p_dims):
+            if masked:
+                m = np.asarray(ob["p"]["action_mask"]).ravel()
+                acts["p"], lo = [], 0
+                for d in p_dims:
+                    acts["p"].append(pick(m[lo: lo + 1 + int(d)]))
+                    lo += 1 + int(d)
+            else:
+                acts["p"] = [int(rng.randint(0, d)) for d in p_dims]
+        elif p_flat:
+            acts["p"] = pick(ob["p"]["action_mask"]) if masked else int(rng.randint(0, p_flat))
+        ob2, _, done, _ = env.step(acts)
+        obs[0] = ob2
         if done["__all__"]:
-            env.reset()
+            obs[0] = env.reset()
             resets[0] += 1
 
     for _ in range(20):
@@ -76,7 +106,7 @@ def main():
             one_step()
         steps += 10
     print(json.dumps({"steps": steps, "elapsed": time.time() - t0, "n_agents": n, "late": bool(late),
-                      "resets": resets[0]}))
+                      "resets": resets[0], "policy": args.policy}))
 
 
 if __name__ == "__main__":

@@ -337,3 +337,32 @@ def test_reference_format_view_unflattened_masks_match_the_live_reference():
                 assert isinstance(got_m[key], list) and got_m[key] == want_m[key], (t, actor, key)
         obs, _, _, _ = env.step(acts)
         want, _, _, _ = ref.step(acts)
+
+
+def test_registered_component_without_a_device_kernel_is_refused_at_construction():
+    """The component registry is open like the reference's (base_component.py:378, registrar.py:48-66); a registered
+    class whose dynamics are Python cannot run inside a batched launch, and make_env_instance says so -- by name --
+    instead of failing at backend creation with "unknown component id 0"."""
+    from ai_economist_amd import foundation
+    from ai_economist_amd.foundation.components import component_registry
+    from ai_economist_amd.foundation.components.base import BaseComponent
+
+    @component_registry.add
+    class GiftEveryone(BaseComponent):
+        name = "GiftEveryoneForTheTest"
+        required_entities = ["Coin"]
+        agent_subclasses = ["BasicMobileAgent"]
+
+        def __init__(self, *args, amount=1, **kwargs):
+            super().__init__(*args, **kwargs)
+            self.amount = amount
+
+        def get_n_actions(self, agent_cls_name):
+            return None
+
+    assert component_registry.has("GiftEveryoneForTheTest")
+    kw = dict(ENV_CONFIG)
+    scenario = kw.pop("scenario_name")
+    kw["components"] = list(kw["components"]) + [{"GiftEveryoneForTheTest": {"amount": 2}}]
+    with pytest.raises(NotImplementedError, match="GiftEveryoneForTheTest.*no device kernel"):
+        foundation.make_env_instance(scenario, **kw)

@@ -1229,3 +1229,109 @@ def test_auto_reset_equals_step_then_masked_reset(case):
                 continue
             assert torch.equal(v, b_auto.tensors[k]), "step %d: %s differs" % (t + 1, k)
     assert int(b_auto.tensors["completions"].min()) >= 2
+
+
+# ---- hipGraph replay (a policy in the loop without the host between the steps) -----------------------
+def _graph_env(cfg, E, seed, reward_log):
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.seed(seed)
+    env.reset()
+    log = env.backend.set_reward_log(5) if reward_log else None
+    return env, log
+
+
+@pytest.mark.parametrize("reward_log", [False, True])
+def test_step_is_hipgraph_replayable(reward_log):
+    """policy -> aie_step (+ the auto-reset launch) captured ONCE on the caller's stream and replayed 64 times equals
+    the same loop issued call by call -- the whole arena, bit for bit, and the reward log with its slot counters --
+    and the eager twin equals the oracle stepped with the actions the policy chose.  Nothing aie_step needs travels by
+    value from a host-side counter (include/aie.h), so a replay is a step, not a repetition of the captured one."""
+    import torch
+
+    from ai_economist_amd.rollout import GraphedStep, MaskedMLPPolicy
+    from oracle_lib import OracleEnv
+
+    cfg = dict(C2, episode_length=40, starting_agent_coin=12)  # 64 replays cross an episode end (auto-reset inside the graph)
+    E, WARM, N = 48, 3, 64
+    env_g, log_g = _graph_env(cfg, E, 5, reward_log)
+    env_e, log_e = _graph_env(cfg, E, 5, reward_log)
+    oracle = OracleEnv(env_e.build_config(), env_e.layout_planes())
+    oracle.seed(5)
+    oracle.reset()
+    pol_g, pol_e = MaskedMLPPolicy(env_g.backend, seed=3), MaskedMLPPolicy(env_e.backend, seed=3)
+    gs = GraphedStep(env_g, pol_g, auto_reset=True, warmup=WARM)  # (runs WARM eager steps, then captures one more: not executed)
+    be_e = env_e.backend
+    be_e.set_auto_reset(True)
+    a_e, p_e = be_e._action_buffers(0)
+    T = int(cfg["episode_length"])
+    for t in range(WARM + N):
+        pol_e(be_e.tensors, a_e, p_e)
+        a_h, p_h = a_e.cpu().numpy().copy(), p_e.cpu().numpy().copy()
+        be_e.step(a_e, p_e)
+        oracle.step(a_h.reshape(E, -1), p_h, nthreads=4)
+        if (t + 1) % T == 0:  # auto-reset: rewards / done of the terminal step stay, state and observations restart
+            rew_a, rew_p, done = (oracle.t[k].copy() for k in ("rewards_a", "rewards_p", "done"))
+            assert done.all()
+            oracle.reset(done)
+            oracle.t["rewards_a"][...], oracle.t["rewards_p"][...], oracle.t["done"][...] = rew_a, rew_p, done
+    gs.replay(N)
+    torch.cuda.synchronize()
+    assert float(pol_g.counter) == float(pol_e.counter) == WARM + N
+    assert torch.equal(env_g.backend.arena, be_e.arena), "replayed loop != eager loop"
+    if reward_log:
+        assert torch.equal(log_g, log_e)
+        assert int(be_e.tensors["rew_log_slot"][0]) == (WARM + N) % 5
+    assert int(be_e.tensors["timestep"][0]) == (WARM + N) % T
+    _compare_all(be_e, oracle, "eager twin of the replayed loop")
+    assert np.array_equal(be_e.tensors["obs_a_action_mask"].cpu().numpy(), oracle.t["obs_a_action_mask"])
+    # the policy's choices respected the masks it was shown: no replica raised an action error
+    assert int(be_e.tensors["error_flags"].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("case", ["gather_trade_build", "one_step_economy", "covid"])
+def test_fused_random_policy_is_hipgraph_replayable(case):
+    """aie_step_sample_next (the bench's one-launch-per-step rollout) captured as a pair of launches -- the two action
+    buffers swap roles every step -- and replayed equals the same calls issued one by one: the draw index is the
+    replicas' own record field, not a host counter.  All three scenario families (three kernels)."""
+    import torch
+
+    cfg = dict(C2, episode_length=50) if case == "gather_trade_build" else _reward_log_cases()[case]
+    T = int(cfg["episode_length"])
+    envs = [make_env(cfg, n_envs=64, device="cuda:0", env_offset=128) for _ in range(2)]
+    for env in envs:
+        if case != "covid":
+            env.seed(9)
+        env.reset()
+        env.backend.set_auto_reset(True)
+    b0, b1 = envs[0].backend, envs[1].backend
+    logs = [b.set_reward_log(4) for b in (b0, b1)]
+    for b in (b0, b1):
+        b.sample_random_actions(seed=77, env_offset=128, slot=0)
+
+    def pair(b):
+        a0, p0 = b._action_buffers(0)
+        a1, p1 = b._action_buffers(1)
+        b.step_sample_next(a0, p0, 77, 128, next_slot=1)
+        b.step_sample_next(a1, p1, 77, 128, next_slot=0)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pair(b1)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        pair(b1)
+    n_pairs = min(30, T + 3)
+    for _ in range(n_pairs):
+        g.replay()
+    for _ in range(1 + n_pairs):
+        pair(b0)
+    torch.cuda.synchronize()
+    assert int(b0.tensors["sample_t"][0]) == 1 + 2 * (1 + n_pairs)
+    assert torch.equal(b0.arena, b1.arena)
+    assert torch.equal(logs[0], logs[1])
+    for s in (0, 1):
+        assert torch.equal(b0._action_buffers(s)[0], b1._action_buffers(s)[0])
+        assert torch.equal(b0._action_buffers(s)[1], b1._action_buffers(s)[1])
