@@ -5,7 +5,7 @@ by env.py purely as the owner of device memory / streams.
 """
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_AGENTS = 64
 MAX_AGENTS_WIDE = 128
 MAX_COMPONENTS = 8
@@ -13,6 +13,8 @@ MAX_BRACKETS = 16
 MAX_RATES = 64
 N_RES = 2
 MT_N = 624
+RNG_NUMPY, RNG_FAST = 0, 1  # aie_config.rng_mode (AIE_RNG_*)
+RNG_FAST_STATE_WORDS = 4     # tensor "mt" in fast mode: key32, block number, salt, 0
 
 COMP_BUILD, COMP_CDA, COMP_GATHER, COMP_TAX, COMP_SIMPLE_LABOR = 1, 2, 3, 4, 5
 COMP_COVID_CONTROL, COMP_COVID_SUBSIDY, COMP_COVID_VACCINE = 6, 7, 8
@@ -120,7 +122,7 @@ class AieConfig(C.Structure):
         ("covid", AieCovidConfig),
         ("split_water_line", C.c_int32),
         ("split_top_ranks", C.c_uint32 * 2),
-        ("reserved2_", C.c_int32),
+        ("rng_mode", C.c_int32),
         ("tax_annealing", C.c_int32),
         ("dense_log_replicas", C.c_int32),
         ("tax_annealing_warmup", C.c_double),
@@ -184,6 +186,8 @@ def bind(lib):
     lib.aie_set_layout.argtypes = [vp, vp, vp, vp]
     lib.aie_seed.restype = C.c_int
     lib.aie_seed.argtypes = [vp, C.c_uint32, vp]
+    lib.aie_seed_fast.restype = C.c_int
+    lib.aie_seed_fast.argtypes = [vp, C.c_uint64, C.c_int64, vp]
     lib.aie_set_rng_state.restype = C.c_int
     lib.aie_set_rng_state.argtypes = [vp, vp, vp]
     lib.aie_reset.restype = C.c_int
@@ -220,7 +224,7 @@ def bind(lib):
 EXPORTED_SYMBOLS = [
     "aie_arena_bytes", "aie_create", "aie_destroy", "aie_last_error", "aie_num_tensors",
     "aie_tensor_at", "aie_get_tensor", "aie_upload", "aie_download", "aie_set_layout",
-    "aie_seed", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
+    "aie_seed", "aie_seed_fast", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
     "aie_sample_masked_actions", "aie_step_sample_next", "aie_step_sample_next_masked", "aie_set_reward_log", "aie_set_auto_reset",
     "aie_set_dense_log_active", "aie_step_kernel_instance", "aie_select_step_kernel", "aie_specialize", "aie_set_global_saez_buffer", "aie_sizeof_config",
     "aie_arena_info",

@@ -67,6 +67,10 @@ SPECS = [
      PHASE2, "gtb", 8),
     ("P1: the reference's phase-1 training YAML (tutorials/rllib/phase1/config.yaml)", "layout_from_file/simple_wood_and_stone",
      PHASE1, "gtb", 8),
+    # the throughput mode (rng_mode="fast": a counter-based stream per replica instead of NumPy's MT19937, include/aie.h
+    # AIE_RNG_FAST) of the two headline configurations -- never the headline itself
+    ("C2f: C2 with rng_mode='fast'", "layout_from_file/simple_wood_and_stone", dict(_BASE, n_agents=4, rng_mode="fast"), "gtb", 8),
+    ("C3f: C3 with rng_mode='fast'", "layout_from_file/simple_wood_and_stone", dict(_BASE, n_agents=10, rng_mode="fast"), "gtb", 8),
 ]
 
 

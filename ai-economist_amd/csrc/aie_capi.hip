@@ -371,14 +371,26 @@ int aie_set_layout(aie_env* env, const uint8_t* stone_src, const uint8_t* wood_s
   return AIE_OK;
 }
 
-int aie_seed(aie_env* env, uint32_t base_seed, void* stream) {
-  if (!env) return AIE_E_INVALID;
+static int aie_seed_impl(aie_env* env, uint64_t base_seed, void* stream) {
   if (env->P.c.scenario == AIE_SCN_COVID) return AIE_OK;  // the COVID simulation draws no random numbers
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   hipLaunchKernelGGL(aie_seed_kernel, dim3((unsigned)((env->P.E + 63) / 64)), dim3(64), 0,
                      static_cast<hipStream_t>(stream), env->P, env->arena, base_seed);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
+}
+int aie_seed(aie_env* env, uint32_t base_seed, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  return aie_seed_impl(env, (uint64_t)base_seed, stream);
+}
+int aie_seed_fast(aie_env* env, uint64_t seed, int64_t global_env_offset, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  if (env->P.c.scenario != AIE_SCN_COVID && env->P.c.rng_mode != AIE_RNG_FAST) {
+    snprintf(env->err, sizeof(env->err), "aie_seed_fast: this environment was created with rng_mode = AIE_RNG_NUMPY (the "
+             "generator is part of the record layout; create it with rng_mode = AIE_RNG_FAST)");
+    return AIE_E_UNSUPPORTED;
+  }
+  return aie_seed_impl(env, seed + (uint64_t)global_env_offset, stream);
 }
 
 int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos) {
@@ -388,7 +400,7 @@ int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos) {
     return AIE_E_UNSUPPORTED;
   }
   const int64_t E = env->P.E;
-  int rc = aie_upload(env, "mt", key, E * AIE_MT_N * 4);
+  int rc = aie_upload(env, "mt", key, E * aie__rng_state_words(&env->P.c) * 4);
   if (rc != AIE_OK) return rc;
   rc = aie_upload(env, "mt_pos", pos, E * 4);
   if (rc != AIE_OK) return rc;

@@ -101,8 +101,10 @@ __device__ __forceinline__ double* scr_part(const Ctx& c) { return c.fscr + 2 * 
 __device__ __forceinline__ double* scr_gini_sort(const Ctx& c) { return c.fscr + 2 * c.P.P + 4 * c.P.n + 2; }
 __host__ __device__ inline int fscr_doubles(const aie_params& P) { return 2 * P.P + 5 * P.n + 2; }
 
-// The LDS image of the record stops where the MT19937 key starts (it lives in VGPRs).
-__host__ __device__ inline int rec_lds_bytes(const aie_params& P) { return P.o_mt; }
+// The LDS image of the record stops where the MT19937 key starts (it lives in VGPRs).  The counter stream's state
+// (AIE_RNG_FAST: key32, block number, salt, 0 -- 16 bytes) is part of the image.
+__host__ __device__ inline bool rng_fast(const aie_params& P) { return P.c.rng_mode == AIE_RNG_FAST; }
+__host__ __device__ inline int rec_lds_bytes(const aie_params& P) { return P.o_mt + (rng_fast(P) ? 16 : 0); }
 
 // staging area: the components' draw window (the next tempered MT19937 words, see MTL) and the small
 // observation vectors the flat-vector writer stages
@@ -161,7 +163,7 @@ __host__ __device__ inline bool mt_window_in_lds(const aie_params& P) {
 #ifdef AIE_NO_MT_WINDOW_LDS  // (A/B builds)
   return false;
 #else
-  return !P.regen_general &&
+  return !P.regen_general && !rng_fast(P) &&  // (the counter stream addresses its words directly)
          lds_bytes_base(P) + (const_tables_in_lds(P) ? const_table_bytes(P) : 0) + AIE_MT_WINDOW_LDS_BYTES <= 10240;
 #endif
 }
@@ -321,7 +323,34 @@ struct MT {
   uint32_t r[10];  // word 64*j + lane (row 9: lanes 0..47)
   int pos;         // wave-uniform index of the next unused word (624 = twist first)
   int twists;      // mt_twist calls since the owner zeroed it (one-step-economy: the rows go back to HBM only then)
+  // AIE_RNG_FAST (include/aie.h): the stream is Philox2x32-10 keyed per replica, consumed in blocks of 624 words with
+  // the same position bookkeeping; `r` then holds the FINAL words of block `fblk` (no tempering), "twist" = next block
+  bool fast;       // (a compile-time constant in the instances: P.c.rng_mode folds)
+  uint32_t fkey, fblk, fsalt;  // wave-uniform
 };
+#define R_U32(c, off) (reinterpret_cast<uint32_t*>((c).rec + (c).P.off))
+
+// ---- AIE_RNG_FAST: Philox2x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11;
+// multiplier and Weyl key increment of Random123).  Word g of a replica's stream = element g & 1 of
+// philox(counter = (lo32(g >> 1), hi32(g >> 1) | salt), key32).  One 32 x 32 -> 64 multiply and one three-input xor
+// per round.
+__device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t key, uint32_t& o0, uint32_t& o1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p = (uint64_t)0xD256D193u * (uint64_t)c0;
+    c0 = (uint32_t)(p >> 32) ^ key ^ c1;
+    c1 = (uint32_t)p;
+    key += 0x9E3779B9u;
+  }
+  o0 = c0;
+  o1 = c1;
+}
+// words 2 h and 2 h + 1 of block `blk` (h may run past the block's 312 pairs: the stream is linear, block b starts at
+// pair 312 b)
+__device__ __forceinline__ void fast_pair(uint32_t key, uint32_t blk, uint32_t salt, int h, uint32_t& o0, uint32_t& o1) {
+  const uint64_t pair = (uint64_t)blk * 312ull + (uint64_t)(uint32_t)h;
+  philox2x32_10((uint32_t)pair, (uint32_t)(pair >> 32) | salt, key, o0, o1);
+}
 
 // Also collects, with LDS atomics, the list of regeneration draws that matter: double d of
 // the step's 2*H*W np.random.rand values targets Wood cell d (d < HW) or Stone cell d-HW,
@@ -357,7 +386,7 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
       }
     }
   }
-  if (wave != key_wave) return;
+  if (wave != key_wave || rng_fast(c.P)) return;  // (the counter stream's state came with the image: mt_fast_attach)
   const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
 #pragma unroll
   for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
@@ -370,7 +399,7 @@ __device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
   for (int q = wave * AIE_NT + c.tid; q < nq; q += nwaves * AIE_NT) dst[q] = src[q];
-  if (wave != key_wave) return;  // the generator's rows are in that wave's registers
+  if (wave != key_wave || rng_fast(c.P)) return;  // the generator's rows are in that wave's registers
   uint32_t* key = reinterpret_cast<uint32_t*>(g + c.P.o_mt);
 #pragma unroll
   for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
@@ -453,6 +482,7 @@ __device__ __forceinline__ void mt_twist_body(MT& m, int lane) {
 struct MTRows { uint32_t r[10]; };
 __device__ __attribute__((noinline)) MTRows mt_twist_rows(MTRows in, int lane) {
   MT m;
+  m.fast = false;
 #pragma unroll
   for (int j = 0; j < 10; ++j) m.r[j] = in.r[j];
   m.pos = 0;
@@ -462,7 +492,36 @@ __device__ __attribute__((noinline)) MTRows mt_twist_rows(MTRows in, int lane) {
   for (int j = 0; j < 10; ++j) out.r[j] = m.r[j];
   return out;
 }
+// AIE_RNG_FAST: the 624 words of block m.fblk in the row layout (word 64 J + l in r[J], lane l).  Lane l computes the
+// pairs 64 j + l (j = 0..4: words 128 j + 2 l, + 1); row 2 j takes its words from lanes l >> 1, row 2 j + 1 from lanes
+// 32 + (l >> 1).  Five Philox blocks and twenty lane permutes per 624 words: costlier than an MT19937 twist (the
+// sequential consumers -- resets, layout generation -- pay that; the step kernel never comes here, it addresses the
+// words it needs directly).
+__device__ __attribute__((noinline)) MTRows mt_fast_rows_of(uint32_t key, uint32_t blk, uint32_t salt, int lane) {
+  MTRows out;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    uint32_t x0, x1;
+    fast_pair(key, blk, salt, 64 * j + lane, x0, x1);
+    const uint32_t lo0 = lane_get(x0, lane >> 1), lo1 = lane_get(x1, lane >> 1);
+    const uint32_t hi0 = lane_get(x0, 32 + (lane >> 1)), hi1 = lane_get(x1, 32 + (lane >> 1));
+    out.r[2 * j] = (lane & 1) ? lo1 : lo0;
+    out.r[2 * j + 1] = (lane & 1) ? hi1 : hi0;
+  }
+  return out;
+}
+__device__ __forceinline__ void mt_fast_rows(MT& m, int lane) {
+  const MTRows t = mt_fast_rows_of(m.fkey, m.fblk, m.fsalt, lane);
+#pragma unroll
+  for (int j = 0; j < 10; ++j) m.r[j] = t.r[j];
+}
 __device__ __forceinline__ void mt_twist(MT& m, int lane) {
+  if (m.fast) {
+    m.fblk += 1;
+    mt_fast_rows(m, lane);
+    m.twists += 1;
+    return;
+  }
   MTRows t;
 #pragma unroll
   for (int j = 0; j < 10; ++j) t.r[j] = m.r[j];
@@ -472,6 +531,39 @@ __device__ __forceinline__ void mt_twist(MT& m, int lane) {
   m.twists += 1;
 }
 
+// a row register's value as the stream's word: MT19937 tempers its state words, the counter stream's rows are final
+__device__ __forceinline__ uint32_t mt_word(const MT& m, uint32_t raw) { return m.fast ? raw : mt_temper(raw); }
+// A generator for a kernel section: MT19937 (rows arrive with load_record) or the counter stream (mt_fast_attach once the
+// record is in LDS).
+__device__ __forceinline__ void mt_init(MT& m, const aie_params& P) {
+  m.fast = rng_fast(P);
+  m.pos = AIE_MT_N;
+  m.twists = 0;
+  m.fkey = m.fblk = m.fsalt = 0u;
+}
+__device__ __forceinline__ void mt_copy(MT& d, const MT& s) {  // (rows and, for the counter stream, which block they are)
+#pragma unroll
+  for (int j = 0; j < 10; ++j) d.r[j] = s.r[j];
+  d.fast = s.fast;
+  d.fkey = s.fkey;
+  d.fblk = s.fblk;
+  d.fsalt = s.fsalt;
+  d.twists = s.twists;
+}
+// AIE_RNG_FAST, once the record is in LDS and m.pos is set: the stream's identity from the image, and the current
+// block's rows if words of it are still to come (pos == 624: the next draw starts a block anyway).  detach: the block
+// number goes back into the image (every lane stores the same value).
+__device__ __forceinline__ void mt_fast_attach(const Ctx& c, MT& m) {
+  if (!m.fast) return;
+  const uint32_t* st = R_U32(c, o_mt);
+  m.fkey = (uint32_t)uni((int)st[0]);
+  m.fblk = (uint32_t)uni((int)st[1]);
+  m.fsalt = (uint32_t)uni((int)st[2]);
+  if (m.pos < AIE_MT_N) mt_fast_rows(m, c.tid & (AIE_NT - 1));
+}
+__device__ __forceinline__ void mt_fast_detach(const Ctx& c, const MT& m) {
+  if (m.fast) R_U32(c, o_mt)[1] = m.fblk;
+}
 // sequential draws (wave-uniform: every lane gets the same value)
 __device__ __forceinline__ uint32_t rng_u32(MT& m, int lane) {
   if (m.pos >= AIE_MT_N) {
@@ -484,7 +576,7 @@ __device__ __forceinline__ uint32_t rng_u32(MT& m, int lane) {
   for (int j = 1; j < 10; ++j) v = (row == j) ? m.r[j] : v;
   const uint32_t w = bcast(v, m.pos & 63);
   m.pos += 1;
-  return mt_temper(w);
+  return mt_word(m, w);
 }
 __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
@@ -590,8 +682,9 @@ struct MTL {
   uint32_t mv0, mv1;  // agents that moved
   int base, avail;    // what the draw window holds
   int tw;             // twists rng_refill performed this step (-> c.dirty[3])
-  uint32_t* gkey;     // the replica's generator state in HBM (record + o_mt)
+  uint32_t* gkey;     // the replica's generator state in HBM (record + o_mt); AIE_RNG_FAST: in the record's LDS image
   int cap;            // capacity of the draw window in words
+  bool fast;          // AIE_RNG_FAST (compile-time in the instances)
 };
 // Tempered words [pos, pos + avail) of the state in m -> w[0, avail); returns avail = min(cap, 624 - pos).
 __device__ __forceinline__ int draw_window_publish(uint32_t* w, int cap, const MT& m, int pos, int lane) {
@@ -604,7 +697,7 @@ __device__ __forceinline__ int draw_window_publish(uint32_t* w, int cap, const M
 #pragma unroll
     for (int j = 1; j < 10; ++j) v = (r == j) ? m.r[j] : v;
     const int slot = 64 * r + lane - pos;
-    if (slot >= 0 && slot < avail) w[slot] = mt_temper(v);
+    if (slot >= 0 && slot < avail) w[slot] = mt_word(m, v);
   }
   AIE_WSYNC();
   return avail;
@@ -634,6 +727,7 @@ struct Refill { int pos, avail, twisted; };
 // state comes from HBM -- the record's copy, or what an earlier refill of this step wrote back.
 __device__ __attribute__((noinline, cold)) Refill rng_refill(uint32_t* gkey, uint32_t* w, int cap, int pos, int lane) {
   MT m;
+  m.fast = false;  // (MT19937 only: the counter stream refills through rng_refill_fast)
   mt_rows_from_hbm(m, gkey, lane);
   int twisted = 0;
   if (pos >= AIE_MT_N) {
@@ -647,9 +741,41 @@ __device__ __attribute__((noinline, cold)) Refill rng_refill(uint32_t* gkey, uin
   const int avail = draw_window_publish(w, cap, m, pos, lane);
   return Refill{pos, avail, twisted};
 }
+// ---- AIE_RNG_FAST: the draw window straight from the counter stream.  Words [pos, pos + avail) of block `blk` -> w[0,
+// avail): lane l of pass d computes pair (pos >> 1) + 64 d + l, i.e. window slots 2 (64 d + l) - (pos & 1) and the next.
+__device__ __forceinline__ int draw_window_publish_fast(uint32_t* w, int cap, uint32_t key, uint32_t blk, uint32_t salt, int pos,
+                                                        int lane) {
+  const int npass = (cap + 127) >> 7;
+  int avail = cap < AIE_MT_N - pos ? cap : AIE_MT_N - pos;
+  if (avail > 128 * npass - (pos & 1)) avail = 128 * npass - (pos & 1);
+  for (int d = 0; d < npass; ++d) {
+    if (128 * d - (pos & 1) >= avail) break;
+    uint32_t x0, x1;
+    fast_pair(key, blk, salt, (pos >> 1) + 64 * d + lane, x0, x1);
+    const int slot = 2 * (64 * d + lane) - (pos & 1);
+    if (slot >= 0 && slot < avail) w[slot] = x0;
+    if (slot + 1 < avail) w[slot + 1] = x1;
+  }
+  return avail;
+}
+// `st`: the stream's state in the record's LDS image (key32, block number, salt).  The wave that runs the components
+// moves to the next block here; the other wave of the replica picks the block number up behind the workgroup barrier.
+__device__ __attribute__((noinline, cold)) Refill rng_refill_fast(uint32_t* st, uint32_t* w, int cap, int pos, int lane) {
+  uint32_t blk = (uint32_t)uni((int)st[1]);
+  int twisted = 0;
+  if (pos >= AIE_MT_N) {
+    blk += 1u;
+    pos = 0;
+    twisted = 1;
+    if (lane == 0) st[1] = blk;
+  }
+  const int avail = draw_window_publish_fast(w, cap, (uint32_t)uni((int)st[0]), blk, (uint32_t)uni((int)st[2]), pos, lane);
+  AIE_WSYNC();
+  return Refill{pos, avail, twisted};
+}
 __device__ __forceinline__ uint32_t rng_u32(MTL& l, int lane) {
   if (__builtin_expect(l.pos >= l.base + l.avail, 0)) {
-    const Refill r = rng_refill(l.gkey, l.w, l.cap, l.pos, lane);
+    const Refill r = l.fast ? rng_refill_fast(l.gkey, l.w, l.cap, l.pos, lane) : rng_refill(l.gkey, l.w, l.cap, l.pos, lane);
     l.pos = uni(r.pos);  // (a function's results come back in vector registers: keep the bookkeeping scalar)
     l.base = l.pos;
     l.avail = uni(r.avail);
@@ -1711,7 +1837,7 @@ __device__ __forceinline__ void scenario_step_regen_rows(const Ctx& c, MT& m) {
     }
     const int pos = m.pos;
     if (carry) {  // second half of a double whose first word was word 623 of the old state
-      if (lane == 0) regen_cell(c, carry_t, mt_temper(m.r[0]), carry_d);
+      if (lane == 0) regen_cell(c, carry_t, mt_word(m, m.r[0]), carry_d);
       carry = false;
     }
 #pragma unroll
@@ -1720,9 +1846,9 @@ __device__ __forceinline__ void scenario_step_regen_rows(const Ctx& c, MT& m) {
       if (done + (64 * J - pos) >= total) continue;  // row entirely beyond this step's needs
       const int a_idx = 64 * J + lane;
       const int q = done + (a_idx - pos);           // regen-relative word number
-      const uint32_t t = mt_temper(m.r[J]);
+      const uint32_t t = mt_word(m, m.r[J]);
       uint32_t tn = lane_get(t, (lane + 1) & 63);
-      if (J < 9) tn = (lane == 63) ? mt_temper(bcast(m.r[J + 1], 0)) : tn;
+      if (J < 9) tn = (lane == 63) ? mt_word(m, bcast(m.r[J + 1], 0)) : tn;
       const bool first = a_idx >= pos && a_idx < AIE_MT_N - 1 && (q & 1) == 0 && q < total;
       if (first) regen_cell(c, t, tn, q >> 1);
     }
@@ -1732,7 +1858,7 @@ __device__ __forceinline__ void scenario_step_regen_rows(const Ctx& c, MT& m) {
       const int q623 = done + (AIE_MT_N - 1 - pos);
       if ((q623 & 1) == 0 && q623 < total) {
         carry = true;
-        carry_t = mt_temper(bcast(m.r[9], 47));
+        carry_t = mt_word(m, bcast(m.r[9], 47));
         carry_d = q623 >> 1;
       }
     }
@@ -1770,6 +1896,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
   }
   const int S = uni(*c.srcn);
   if (S > AIE_SRC_CAP) {
+    if (m.fast && m.pos < AIE_MT_N) mt_fast_rows(m, c.tid);  // (the counter stream keeps no rows between steps)
     scenario_step_regen_rows(c, m);
     return;
   }
@@ -1777,6 +1904,27 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
   const int total = 4 * c.P.HW;
   const int pos0 = m.pos;  // <= 624
   const int nchunk = (S + AIE_NT - 1) / AIE_NT;
+  if (m.fast) {
+    // AIE_RNG_FAST: source double d is words pos0 + 2 d, + 1 of the linear stream -- computed where they are needed.  One
+    // Philox block per lane when pos0 is even (both words in one pair), two when it is odd (wave-uniform).
+    const int odd = pos0 & 1;
+#pragma unroll
+    for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
+      if (k >= nchunk) continue;
+      const int j = k * AIE_NT + lane;
+      const int d = j < S ? (int)c.srcl[j] : 0;
+      const int h = (pos0 >> 1) + d;  // pair that holds word pos0 + 2 d
+      uint32_t a0, a1, b0 = 0, b1 = 0;
+      fast_pair(m.fkey, m.fblk, m.fsalt, h, a0, a1);
+      if (odd) fast_pair(m.fkey, m.fblk, m.fsalt, h + 1, b0, b1);
+      if (j < S) regen_cell(c, odd ? a1 : a0, odd ? b0 : a1, d);
+    }
+    const int last_win = (pos0 + total - 1) / AIE_MT_N;
+    m.pos = pos0 + total - last_win * AIE_MT_N;
+    m.fblk += (uint32_t)last_win;
+    AIE_WSYNC();
+    return;
+  }
   int off_a[AIE_SRC_CAP / AIE_NT];
   uint32_t wa[AIE_SRC_CAP / AIE_NT], wb[AIE_SRC_CAP / AIE_NT];
 #pragma unroll
@@ -2491,6 +2639,8 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
                          /*lds_tables=*/SPEC >= 0);  // (the generic kernel keeps the parameter block's arrays: a pointer
                                                      // that may be LDS or global at run time costs it flat accesses and spills)
   MT m;
+  mt_init(m, P);
+  const bool FAST = rng_fast(P);  // the counter stream (include/aie.h: AIE_RNG_FAST); compile-time in the instances
   Agents A;
   if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x] = wall_clock64();
   if (threadIdx.x == 0) {
@@ -2504,14 +2654,18 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
   uint8_t* grec = arena + R.a_records + (int64_t)c.e * P.rec_bytes;
   uint32_t* gkey = reinterpret_cast<uint32_t*>(grec + P.o_mt);
-  MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0, 0u, -AIE_MT_N, 0, 0u, 0u, 0, 0, 0, gkey, stage_window_words(P)};
+  MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0, 0u, -AIE_MT_N, 0, 0u, 0u, 0, 0, 0,
+         FAST ? reinterpret_cast<uint32_t*>(c.rec + P.o_mt) : gkey, stage_window_words(P), FAST};
   if (LOG && R.dev_draw_window > 0 && R.dev_draw_window < ml.cap) ml.cap = R.dev_draw_window;  // tests: force refills
   // the generator's position, ahead of the record: the last wave turns the words the components will draw into the
   // LDS draw window while the record copy is in flight
   int gpos = 0;
   if (wid == NW - 1) gpos = *reinterpret_cast<const int32_t*>(grec + P.o_mt_pos);
   load_record(c, arena, m, wid, NW, /*key_wave=*/-1);  // the generator state stays in HBM for now
-  if (wid == NW - 1) draw_window_publish_from_hbm(ml.w, ml.cap, gkey, uni(gpos), c.tid);
+  if (wid == NW - 1) {
+    if (FAST) draw_window_publish_fast(ml.w, ml.cap, (uint32_t)uni((int)gkey[0]), (uint32_t)uni((int)gkey[1]), (uint32_t)uni((int)gkey[2]), uni(gpos), c.tid);
+    else draw_window_publish_from_hbm(ml.w, ml.cap, gkey, uni(gpos), c.tid);
+  }
   if (SPEC >= 0 && wid == NW - 1 && const_tables_in_lds(P)) {
     // the small constant tables (Ctx.rtab / mtab) -> LDS, published by the barrier below
     if (P.has_tax && P.c.tax_model == AIE_TAX_MODEL_WRAPPER)
@@ -2525,6 +2679,10 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (wid == 0) {
     ml.pos = ml.base = uni(*R_I32(c, o_mt_pos));
     ml.avail = ml.cap < AIE_MT_N - ml.pos ? ml.cap : AIE_MT_N - ml.pos;  // what draw_window_publish_from_hbm left
+    if (FAST) {  // (draw_window_publish_fast: whole pairs, one word less when the position is odd)
+      const int covered = 128 * ((ml.cap + 127) >> 7) - (ml.pos & 1);
+      if (ml.avail > covered) ml.avail = covered;
+    }
     agents_load(c, A);
     if (P.has_cda && !(skip & 1)) cda_decay_price_history(c);
   }
@@ -2561,10 +2719,12 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   } else {
     // the second wave has nothing to do until the components are done: the generator state for the regeneration
     // (rows -> registers, the loads go out first; re-read below if the components twisted it) ...
-    const uint32_t* key = gkey;
+    if (!FAST) {
+      const uint32_t* key = gkey;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
-    m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
+      for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
+      m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
+    }
     // ... and the next step's random actions
     if (next.a || next.p) {
       const int per_env = P.n * P.act_a_width + P.act_p_width;
@@ -2599,10 +2759,20 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     // depends on the map: incremental map observations, action masks
     if (NW == 2) __builtin_amdgcn_s_setprio(2);  // from here on this wave is the critical one (the first has slack)
     // a refill that twisted (components drew past word 623) left the new state in HBM
-    if (NW == 1 || uni(c.dirty[3]) != 0) mt_rows_from_hbm(m, gkey, c.tid);
+    if (FAST) {  // the stream's state is in the LDS image (the components may have moved it to the next block)
+      const uint32_t* st = R_U32(c, o_mt);
+      m.fkey = (uint32_t)uni((int)st[0]);
+      m.fblk = (uint32_t)uni((int)st[1]);
+      m.fsalt = (uint32_t)uni((int)st[2]);
+    } else if (NW == 1 || uni(c.dirty[3]) != 0) {
+      mt_rows_from_hbm(m, gkey, c.tid);
+    }
     m.pos = uni(*R_I32(c, o_mt_pos));
     if (!(skip & 2)) scenario_step_regen(c, m);
-    if (c.tid == 0) *R_I32(c, o_mt_pos) = m.pos;
+    if (c.tid == 0) {
+      *R_I32(c, o_mt_pos) = m.pos;
+      if (FAST) R_U32(c, o_mt)[1] = m.fblk;
+    }
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
     AIE_WSYNC();
     if (!(skip & 4)) {
@@ -2708,14 +2878,12 @@ struct MT3 {
 };
 __device__ __forceinline__ void mt3_need(MT3& s, int k, int lane) {  // make windows 0..k valid (k <= 2)
   if (s.have <= 1 && k >= 1) {
-#pragma unroll
-    for (int j = 0; j < 10; ++j) s.w[1].r[j] = s.w[0].r[j];
+    mt_copy(s.w[1], s.w[0]);
     mt_twist(s.w[1], lane);
     s.have = 2;
   }
   if (s.have <= 2 && k >= 2) {
-#pragma unroll
-    for (int j = 0; j < 10; ++j) s.w[2].r[j] = s.w[1].r[j];
+    mt_copy(s.w[2], s.w[1]);
     mt_twist(s.w[2], lane);
     s.have = 3;
   }
@@ -2746,7 +2914,7 @@ __device__ __forceinline__ uint32_t mt3_word(const MT3& s, int o) {
       v = mt3_window_word(s.w[k], i, v, win == k, rlo, rhi);
     }
   }
-  return mt_temper(v);
+  return mt_word(s.w[0], v);
 }
 // the four tempered words o .. o + 3 (one polar attempt): the window / row bookkeeping once for all four
 __device__ __forceinline__ void mt3_words4(const MT3& s, int o, uint32_t out[4]) {
@@ -2779,17 +2947,14 @@ __device__ __forceinline__ void mt3_words4(const MT3& s, int o, uint32_t out[4])
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) out[j] = mt_temper(v[j]);
+  for (int j = 0; j < 4; ++j) out[j] = mt_word(s.w[0], v[j]);
 }
 __device__ __forceinline__ void mt3_consume(MT3& s, int nwords, int lane) {  // nwords <= 2 * 624
   s.pos += nwords;
   while (s.pos >= AIE_MT_N) {
     mt3_need(s, 1, lane);
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-      s.w[0].r[j] = s.w[1].r[j];
-      s.w[1].r[j] = s.w[2].r[j];
-    }
+    mt_copy(s.w[0], s.w[1]);
+    mt_copy(s.w[1], s.w[2]);
     s.have -= 1;
     s.pos -= AIE_MT_N;
   }
@@ -2959,8 +3124,7 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
   const uint64_t lg_start = wall_clock64();
 #endif
   MT3 s3;
-#pragma unroll
-  for (int j = 0; j < 10; ++j) s3.w[0].r[j] = m.r[j];
+  mt_copy(s3.w[0], m);
   s3.pos = m.pos;
   s3.have = 1;  // (pos == 624, a freshly seeded generator: every word then comes from window 1, the first twist)
   bool happy = false;
@@ -3146,8 +3310,7 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
       if (!((1 / 1.4) <= ratio && ratio <= 1.4)) happy = false;
     }
   }
-#pragma unroll
-  for (int j = 0; j < 10; ++j) m.r[j] = s3.w[0].r[j];
+  mt_copy(m, s3.w[0]);
   m.pos = s3.pos;
   uint8_t* cb = reinterpret_cast<uint8_t*>(R_CELLS(c));
   for (int cell = gtid; cell < HW; cell += NT) {
@@ -3191,11 +3354,13 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
     if (c.ev && tid == 0) c.ev[0] = 0;
   }
   MT m;
+  mt_init(m, P);
   if (gtid == 0) *c.srcn = 0;
   __syncthreads();
   load_record(c, arena, m, wave, nwaves, wave);  // every wave takes its own copy of the generator's rows
   __syncthreads();
   m.pos = uni(*R_I32(c, o_mt_pos));
+  mt_fast_attach(c, m);
   if (LAYOUT && P.c.layout_gen != AIE_LAYOUT_FIXED) {  // a fresh source layout, drawn before anything else of the reset
     layout_generate(c, m, arena, lds + lds_bytes(P), gtid);
     if (wave != 0) return;
@@ -3356,6 +3521,7 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
     }
   }
   *R_I32(c, o_mt_pos) = m.pos;
+  mt_fast_detach(c, m);
   __syncthreads();
   current_metrics(c);
   __syncthreads();
@@ -3405,16 +3571,26 @@ aie_reset_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict
 
 // np.random.seed(base_seed + e): init_genrand (Knuth LCG), pos = 624.
 // BaseEnvironment.seed, F/base/base_env.py:481-494.  One thread per replica.
-extern "C" __global__ void aie_seed_kernel(const aie_params P, uint8_t* __restrict__ arena, uint32_t base_seed) {
+// AIE_RNG_FAST (aie_seed_fast; aie_seed with base_seed < 2^32): the counter stream keyed by base_seed + e (48 bits): key32,
+// block number 0 with pos = 624 (the first draw opens block 1), salt.
+extern "C" __global__ void aie_seed_kernel(const aie_params P, uint8_t* __restrict__ arena, uint64_t base_seed) {
   const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (e >= P.E) return;
   uint8_t* rec = arena + P.a_records + (int64_t)e * P.rec_bytes;
   uint32_t* mt = reinterpret_cast<uint32_t*>(rec + P.o_mt);
-  uint32_t x = base_seed + (uint32_t)e;
-  mt[0] = x;
-  for (int i = 1; i < AIE_MT_N; ++i) {
-    x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
-    mt[i] = x;
+  if (aie::rng_fast(P)) {
+    const uint64_t s = base_seed + (uint64_t)e;
+    mt[0] = (uint32_t)s;
+    mt[1] = 0u;
+    mt[2] = ((uint32_t)(s >> 32) & 0xffffu) << 16;
+    mt[3] = 0u;
+  } else {
+    uint32_t x = (uint32_t)base_seed + (uint32_t)e;
+    mt[0] = x;
+    for (int i = 1; i < AIE_MT_N; ++i) {
+      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+      mt[i] = x;
+    }
   }
   *reinterpret_cast<int32_t*>(rec + P.o_mt_pos) = AIE_MT_N;
   *reinterpret_cast<int32_t*>(rec + P.o_mt_has_gauss) = 0;

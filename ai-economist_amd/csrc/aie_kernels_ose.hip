@@ -101,20 +101,32 @@ __device__ __forceinline__ void rng_skip_permutation(MT& m, int lane, int n) {
   int i = n - 1;
   while (i >= 1) {
     if (m.pos >= AIE_MT_N) {
-      mt_twist(m, lane);
+      if (m.fast) {  // the counter stream: the next block (its words are computed where they are read, no rows)
+        m.fblk += 1u;
+        m.twists += 1;
+      } else {
+        mt_twist(m, lane);
+      }
       m.pos = 0;
     }
     const int pos = m.pos, cnt = min(64, AIE_MT_N - pos);
-    // word pos + lane lives in row (pos + lane) >> 6, lane (pos + lane) & 63: at most two adjacent rows
-    const int row_a = pos >> 6, src = (pos + lane) & 63;
-    uint32_t ra = m.r[0], rb = m.r[1];
+    uint32_t w;
+    if (m.fast) {  // word pos + lane: element (pos + lane) & 1 of pair (pos + lane) >> 1
+      uint32_t x0, x1;
+      fast_pair(m.fkey, m.fblk, m.fsalt, (pos + lane) >> 1, x0, x1);
+      w = ((pos + lane) & 1) ? x1 : x0;
+    } else {
+      // word pos + lane lives in row (pos + lane) >> 6, lane (pos + lane) & 63: at most two adjacent rows
+      const int row_a = pos >> 6, src = (pos + lane) & 63;
+      uint32_t ra = m.r[0], rb = m.r[1];
 #pragma unroll
-    for (int j = 1; j < 10; ++j) {
-      ra = (row_a == j) ? m.r[j] : ra;
-      rb = (row_a + 1 == j) ? m.r[j] : rb;
+      for (int j = 1; j < 10; ++j) {
+        ra = (row_a == j) ? m.r[j] : ra;
+        rb = (row_a + 1 == j) ? m.r[j] : rb;
+      }
+      const uint32_t wa = lane_get(ra, src), wb = lane_get(rb, src);
+      w = mt_temper((pos & 63) + lane < 64 ? wa : wb);
     }
-    const uint32_t wa = lane_get(ra, src), wb = lane_get(rb, src);
-    const uint32_t w = mt_temper((pos & 63) + lane < 64 ? wa : wb);
     int start = 0;  // first word of the block not consumed yet
     while (i >= 1 && start < cnt) {
       uint32_t mask = (uint32_t)i;
@@ -163,9 +175,17 @@ __device__ __forceinline__ void ose_load_record(const Ctx& c, const uint8_t* __r
   const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
   const double* gs = reinterpret_cast<const double*>(g + c.P.o_skill);
   const double* ge = reinterpret_cast<const double*>(g + c.P.o_esc_coin);
+  mt_init(m, c.P);
+  if (m.fast) {  // the counter stream: 16 bytes of state (they also travel with the image); rows only where a component
+                 // draws sequentially (ose_tax_component_step)
+    m.fkey = (uint32_t)uni((int)key[0]);
+    m.fblk = (uint32_t)uni((int)key[1]);
+    m.fsalt = (uint32_t)uni((int)key[2]);
+  } else {
 #pragma unroll
-  for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + lane];
-  m.r[9] = lane < 48 ? key[576 + lane] : 0u;
+    for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + lane];
+    m.r[9] = lane < 48 ? key[576 + lane] : 0u;
+  }
   m.twists = 0;
   m.pos = early_perm ? uni(*reinterpret_cast<const int32_t*>(g + c.P.o_mt_pos)) : 0;
   L.skill0 = c.tid < c.P.n ? gs[c.tid] : 0.0;
@@ -251,6 +271,7 @@ __device__ __forceinline__ void ose_tax_component_step(const Ctx& c, const OseSc
     } else {
       const double lo = c.R.c.tax_rate_min;
       const double hi = c.P.c.tax_annealing ? tax_curr_rate_max(c) : c.R.c.tax_rate_max;
+      if (m.fast && m.pos < AIE_MT_N) mt_fast_rows(m, c.tid & 63);  // (sequential draws read the block's rows)
       for (int b = 0; b < c.P.NB; ++b) {
         const double r = lo + (hi - lo) * rng_double(m, c.tid & 63);
         if (c.tid == b) R_F64(c, o_tax_saez_rates)[b] = r;
@@ -646,6 +667,10 @@ __device__ __forceinline__ void ose_write_observations(const Ctx& c, const OseSc
 // the position is a record field), and as soon as the components are done: ten registers less for the rest of the step.
 __device__ __forceinline__ void ose_store_key(const Ctx& c, uint8_t* __restrict__ arena, const MT& m) {
   if (m.twists == 0 || c.tid >= 64) return;  // (wave-uniform; every wave holds the same rows)
+  if (m.fast) {  // the block number, in the record's LDS image (ose_store_record follows behind a barrier)
+    if (c.tid == 0) R_U32(c, o_mt)[1] = m.fblk;
+    return;
+  }
   uint32_t* key = reinterpret_cast<uint32_t*>(arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes + c.P.o_mt);
 #pragma unroll
   for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
@@ -833,6 +858,7 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
 
 #ifndef AIE_JIT
 extern "C" __global__ void __launch_bounds__(OSE_NT)
+__attribute__((amdgpu_waves_per_eu(4, 4)))  // (128 VGPRs, as the instances: the run-time generator switch cost three more)
 aie_ose_step_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                     const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];

@@ -308,6 +308,10 @@ static inline int aie__has(const aie_config* c, int comp) {
     return AIE_E_INVALID;                                \
   } while (0)
 
+/* words of generator state in a replica's record ("mt"): MT19937's key, or (key32, block number, salt, 0) of the
+ * counter stream (include/aie.h: AIE_RNG_FAST) */
+static inline int32_t aie__rng_state_words(const aie_config* c) { return c->rng_mode == AIE_RNG_FAST ? 4 : AIE_MT_N; }
+
 /* record field allocator */
 static inline int32_t aie__rec(int32_t* cur, int32_t bytes, int32_t align) {
   int32_t o = (int32_t)aie__align(*cur, align);
@@ -719,7 +723,7 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
   p->o_mt_gauss = aie__rec(&cur, 8, 8);
   p->o_mt_pos = aie__rec(&cur, 4, 4);
   p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
-  p->o_mt = aie__rec(&cur, 4 * AIE_MT_N, 16);
+  p->o_mt = aie__rec(&cur, 4 * aie__rng_state_words(c), 16);
   /* behind the generator: per-agent fields a step only reads (SimpleLabor's skills; the escrow account, which no
    * component of this scenario moves) -- the kernels keep them in registers, they are not part of the LDS image
    * (everything before o_mt), which is what decides how many replicas a CU holds at once */
@@ -776,7 +780,7 @@ static inline int aie__build_one_step_economy(const aie_config* c, aie_params* p
     REC("rew_log_slot", AIE_I32, p->o_rew_slot, 0, 0);
     REC("labor_first_step", AIE_I32, p->o_first_step, 0, 0);
     REC("error_flags", AIE_I32, p->o_error_flags, 0, 0);
-    REC("mt", AIE_U32, p->o_mt, 1, AIE_MT_N);
+    REC("mt", AIE_U32, p->o_mt, 1, aie__rng_state_words(&p->c));
     REC("mt_pos", AIE_I32, p->o_mt_pos, 0, 0);
     REC("mt_has_gauss", AIE_I32, p->o_mt_has_gauss, 0, 0);
     REC("mt_gauss", AIE_F64, p->o_mt_gauss, 0, 0);
@@ -815,6 +819,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   if (c->n_agents < 2) AIE__FAIL("n_agents must be >= 2 (base_env.py:223)");
   if (c->scenario != AIE_SCN_GTB && c->scenario != AIE_SCN_ONE_STEP_ECONOMY && c->scenario != AIE_SCN_COVID)
     AIE__FAIL("unknown scenario %d", c->scenario);
+  if (c->rng_mode != AIE_RNG_NUMPY && c->rng_mode != AIE_RNG_FAST) AIE__FAIL("unknown rng_mode %d", c->rng_mode);
   if (c->scenario == AIE_SCN_COVID) {
     if (c->episode_length < 1) AIE__FAIL("episode_length must be >= 1 (base_env.py:254)");
     return aie__build_covid(c, p, tt, err, errlen);
@@ -1116,7 +1121,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->o_mt_gauss = aie__rec(&cur, 8, 8);
   p->o_mt_pos = aie__rec(&cur, 4, 4);
   p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
-  p->o_mt = aie__rec(&cur, 4 * AIE_MT_N, 16);
+  p->o_mt = aie__rec(&cur, 4 * aie__rng_state_words(c), 16);
   p->rec_bytes = (int32_t)aie__align(cur, 16);
 
   /* ---- arena ------------------------------------------------------------------- */
@@ -1207,7 +1212,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     REC("auto_warmup", AIE_I32, p->o_auto_warmup, 0, 0, 0, 0);
     REC("obs_valid", AIE_I32, p->o_obs_valid, 0, 0, 0, 0);
     REC("error_flags", AIE_I32, p->o_error_flags, 0, 0, 0, 0);
-    REC("mt", AIE_U32, p->o_mt, 1, AIE_MT_N, 0, 0);
+    REC("mt", AIE_U32, p->o_mt, 1, aie__rng_state_words(&p->c), 0, 0);
     REC("mt_pos", AIE_I32, p->o_mt_pos, 0, 0, 0, 0);
     REC("mt_has_gauss", AIE_I32, p->o_mt_has_gauss, 0, 0, 0, 0);
     REC("mt_gauss", AIE_F64, p->o_mt_gauss, 0, 0, 0, 0);

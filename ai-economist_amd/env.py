@@ -152,10 +152,16 @@ class DeviceBackend:
 
     # ---- API ----
     def seed(self, base_seed):
-        self._check(self.lib.aie_seed(self.handle, C.c_uint32(base_seed & 0xFFFFFFFF), self._stream()))
+        """Replica e gets the stream of seed base_seed + e: np.random.seed(base_seed + e) (rng_mode "numpy"), or the
+        counter stream keyed by base_seed + e (rng_mode "fast": aie_seed_fast, 48 bits of the seed are used)."""
+        if self.cfg.rng_mode == _cabi.RNG_FAST:
+            self._check(self.lib.aie_seed_fast(self.handle, C.c_uint64(base_seed & 0xFFFFFFFFFFFFFFFF), C.c_int64(0), self._stream()))
+        else:
+            self._check(self.lib.aie_seed(self.handle, C.c_uint32(base_seed & 0xFFFFFFFF), self._stream()))
 
     def set_rng_state(self, keys, pos):
-        keys = np.ascontiguousarray(keys, np.uint32).reshape(self.E, _cabi.MT_N)
+        words = _cabi.RNG_FAST_STATE_WORDS if self.cfg.rng_mode == _cabi.RNG_FAST else _cabi.MT_N
+        keys = np.ascontiguousarray(keys, np.uint32).reshape(self.E, words)
         pos = np.ascontiguousarray(pos, np.int32).reshape(self.E)
         self._check(self.lib.aie_set_rng_state(self.handle, keys.ctypes.data, pos.ctypes.data))
 

@@ -36,7 +36,7 @@ class BaseEnvironment:
                  flatten_observations=True, flatten_masks=True,
                  allow_observation_scaling=True, dense_log_frequency=None,
                  world_dense_log_frequency=50, collate_agent_step_and_reset_data=False,
-                 seed=None, n_envs=1, device=None, env_offset=0, track_episode_metrics=False):
+                 seed=None, n_envs=1, device=None, env_offset=0, track_episode_metrics=False, rng_mode="numpy"):
         assert self.name
         assert isinstance(self.agent_subclasses, (tuple, list)) and len(self.agent_subclasses) > 0
         assert isinstance(self.required_entities, (tuple, list))
@@ -90,6 +90,12 @@ class BaseEnvironment:
         assert self.n_envs >= 1
         self.env_offset = int(env_offset)  # global index of replica 0 (multi-GPU sharding)
         self._device = device
+        # which generator stands behind the replicas' np.random.* draws (include/aie.h: AIE_RNG_*): "numpy" = NumPy's legacy
+        # MT19937 stream per replica, bit for bit with the reference (the default); "fast" = a counter-based stream
+        # (Philox2x32-10) -- a throughput mode the reference does not have, NOT stream-compatible with NumPy
+        if rng_mode not in ("numpy", "fast"):
+            raise ValueError("rng_mode must be 'numpy' (parity with the reference) or 'fast' (counter-based stream), got %r" % (rng_mode,))
+        self.rng_mode = rng_mode
 
         self._entities = {"resources": ["Coin"], "landmarks": [], "endogenous": ["Labor"]}
         self._register_entities(self.required_entities)
@@ -204,6 +210,7 @@ class BaseEnvironment:
         cfg.multi_action_mode_planner = int(self.multi_action_mode_planner)
         cfg.allow_observation_scaling = int(self._allow_observation_scaling)
         cfg.dense_log_replicas = 1 if self._create_dense_log_every is not None else 0
+        cfg.rng_mode = _cabi.RNG_FAST if self.rng_mode == "fast" else _cabi.RNG_NUMPY
         if len(self._components) > _cabi.MAX_COMPONENTS:
             raise ValueError("too many components")
         cfg.n_components = len(self._components)
@@ -320,7 +327,8 @@ class BaseEnvironment:
         t = self.backend.tensors
         if "mt" not in t:  # a scenario without random draws
             return None
-        return ("MT19937", t["mt"][e].cpu().numpy().view(np.uint32).copy(), int(t["mt_pos"][e].item()),
+        # (rng_mode "fast": the same 5-tuple with the counter stream's four state words under the name "PHILOX2X32")
+        return ("MT19937" if self.rng_mode == "numpy" else "PHILOX2X32", t["mt"][e].cpu().numpy().view(np.uint32).copy(), int(t["mt_pos"][e].item()),
                 int(t["mt_has_gauss"][e].item()), float(t["mt_gauss"][e].item()))
 
     def set_replica_rng_state(self, seed_state, e=0):
@@ -333,7 +341,10 @@ class BaseEnvironment:
         if "mt" not in t:
             return
         key = np.array(seed_state[1], dtype=np.uint32)
-        assert key.shape == (624,) and str(seed_state[0]) == "MT19937"
+        if self.rng_mode == "numpy":
+            assert key.shape == (624,) and str(seed_state[0]) == "MT19937"
+        else:
+            assert key.shape == (_cabi.RNG_FAST_STATE_WORDS,) and str(seed_state[0]) == "PHILOX2X32"
         t["mt"][e].copy_(torch.from_numpy(key.view(np.int32).copy()))
         t["mt_pos"][e] = int(seed_state[2])
         t["mt_has_gauss"][e] = int(seed_state[3])

@@ -169,6 +169,10 @@ class Uniform(LayoutFromFile):
             cfg.layout_coverage[i] = float(self.layout_specs[r]["starting_coverage"])
             cfg.layout_clump[i] = float(1 - np.clip(self.clumpiness[r], 0.0, 0.99))
         cfg.layout_gen = self.layout_gen if self.layouts_on_device else _cabi.LAYOUT_FIXED
+        if not self.layouts_on_device and self.rng_mode != "numpy":
+            raise NotImplementedError("rng_mode='fast': worlds above %d cells draw their source layouts on the host from "
+                                      "the replica's NumPy stream, which the counter-based generator does not have; use "
+                                      "rng_mode='numpy' or a smaller world" % self.DEVICE_LAYOUT_MAX_CELLS)
         cfg.layout_checker = int(self._checker_source_blocks)
         if cfg.layout_gen != _cabi.LAYOUT_FIXED:
             # constant tensors that go with this configuration (the device backend uploads them once; the CPU checker

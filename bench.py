@@ -125,6 +125,18 @@ WORKLOADS = {
     "C3": dict(short="BASELINE configs[2], one GPU share: as C2 with 10 agents, 4096 replicas/GPU",
                desc="BASELINE configs[2], one GPU's share (32768 replicas over 8 GPUs = 4096 each): as C2 with 10 agents",
                cfg=lambda: dict(C2_CFG, n_agents=10), envs=4096, survey_bytes=7666.0, kernel="aie_step_kernel"),
+    "C2f": dict(short="configs[1] with rng_mode='fast' (counter-based Philox2x32-10 stream per replica; NOT NumPy's stream)",
+                desc="BASELINE configs[1] in the throughput mode rng_mode='fast' (include/aie.h AIE_RNG_FAST): every "
+                     "np.random.* draw of the replicas comes from a counter-based stream (Philox2x32-10 keyed by seed + "
+                     "global replica) instead of NumPy's MT19937 -- 16 B of generator state per replica instead of 2 496, "
+                     "the regeneration computes only the words of its source cells; checked bit for bit against the "
+                     "oracle's restatement of the same generator (tests/test_rng_fast.py); never the headline",
+                cfg=lambda: dict(C2_CFG, rng_mode="fast"), envs=4096, survey_bytes=10984.0, kernel="aie_step_kernel",
+                rng="fast"),
+    "C3f": dict(short="configs[2] one GPU share with rng_mode='fast' (counter-based stream; NOT NumPy's stream)",
+                desc="BASELINE configs[2], one GPU's share, in the throughput mode rng_mode='fast' (see C2f)",
+                cfg=lambda: dict(C2_CFG, n_agents=10, rng_mode="fast"), envs=4096, survey_bytes=7666.0,
+                kernel="aie_step_kernel", rng="fast"),
     "C4": dict(short="BASELINE configs[3] COVID 51 states + planner, opt-in O(1) filter recurrence",
                desc="BASELINE configs[3]: CovidAndEconomySimulation, 51 US-state agents + planner, run config "
                     "covid_and_economy_environment.yaml, episode_length 540; filter_recurrence=True (opt-in O(1) update of "
@@ -200,7 +212,20 @@ def profile_tag(wl):
     return WORKLOADS[wl].get("profile_tag", wl.lower())
 
 
-def measured_traffic(wl, envs_per_gpu):
+def workload_of_profile(path):
+    """(workload, round) of a committed profiles/rNN_<tag>_<kind>.{json,csv} file."""
+    import re
+
+    m = re.match(r"^r(\d+)_(.+)_(bench\.json|pmc\.json|sq_counters\.json|kernel_stats\.csv)$", os.path.basename(path))
+    if not m:
+        return None, None
+    for wl in WORKLOADS:
+        if profile_tag(wl) == m.group(2):
+            return wl, int(m.group(1))
+    return None, int(m.group(1))
+
+
+def measured_traffic(wl, envs_per_gpu, max_round=None):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary for this workload
     (profiles/*<wl>*pmc.json, made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same
     command).  Counters cannot be collected from inside the run; only valid for the default batch size."""
@@ -218,6 +243,8 @@ def measured_traffic(wl, envs_per_gpu):
     if wl == "C2":
         files += [f for f in glob.glob(os.path.join(ROOT, "profiles", "r01_v*_pmc.json"))]
     files = sorted(files, key=version)
+    if max_round is not None:  # (tests: the summaries a committed line of that round was derived from)
+        files = [f for f in files if version(f)[0] <= max_round]
     if not files or envs_per_gpu != WORKLOADS[wl]["envs"]:
         return None, None
     d = json.load(open(files[-1]))
@@ -427,7 +454,7 @@ SM_CLOCK_HZ = 2.4e9   # MI355X peak engine clock (MI355X_MICROARCH.md): the issu
 N_SIMDS = 256 * 4
 
 
-def issue_counters(wl):
+def issue_counters(wl, max_round=None):
     """Wave-instructions the dominant kernel issues per launch, from the newest committed SQ-counter summary of this
     workload (profiles/*_<wl>_sq_counters.json: rocprofv3 --pmc SQ_INSTS_* passes of this same command, tools/sq_passes.sh)."""
     import glob
@@ -436,6 +463,8 @@ def issue_counters(wl):
     files = sorted([f for f in glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json"))
                     if re.match(r"^r\d+_%s_sq_counters\.json$" % re.escape(profile_tag(wl)), os.path.basename(f))],
                    key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    if max_round is not None:
+        files = [f for f in files if int(re.findall(r"\d+", os.path.basename(f))[0]) <= max_round]
     if not files:
         return None, None, None
     d = json.load(open(files[-1]))
@@ -660,6 +689,8 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
             "metric": "agent-steps/sec, %s" % {"C1": "simple_wood_and_stone 15x15 4-agent Gather+Build batched envs",
                                                 "C2": "gather-trade-build 25x25 4-agent batched envs",
                                                 "C2v": "gather-trade-build 25x25 4-agent batched envs, other scalars",
+                                                "C2f": "gather-trade-build 25x25 4-agent batched envs, counter-based RNG (not NumPy's stream)",
+                                                "C3f": "gather-trade-build 25x25 10-agent batched envs, counter-based RNG (not NumPy's stream)",
                                                 "P2": "gather-trade-build 25x25 4-agent batched envs, phase-2 YAML",
                                                 "C3": "gather-trade-build 25x25 10-agent batched envs",
                                                 "C4": "covid19_env 51 US-state agents + planner",
@@ -681,7 +712,9 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
                 else "single GPU",
                 "envs_per_gpu": E, "global_envs": world * E, "n_agents": n,
                 "policy_short": "masked" if roll.masked else "unmasked",
-                "rng": "per-replica NumPy-legacy MT19937 (parity mode)",
+                "rng": ("per-replica counter-based stream, Philox2x32-10 (rng_mode='fast': NOT NumPy's stream; bit-exact "
+                        "against the oracle's restatement of the same generator)" if W.get("rng") == "fast" else
+                        "per-replica NumPy-legacy MT19937 (parity mode)"),
                 "policy": ("uniform random over the actions the masks allow (counter RNG)" if roll.masked else
                            "uniform random (counter RNG)") + ("; the draw for step t+1 happens inside the launch of "
                                                              "step t (aie_step_sample_next), one launch per step"
@@ -724,7 +757,7 @@ LINE_LIMIT = 4096
 ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_final_layout", "traffic", "hbm_traffic_frac",
              "valu_frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "arena_bytes", "fits_infinity_cache")
 # (side entries: no kernel names -- the detail file has them -- so that thirteen of them fit the 4 KB line)
-SIDE_KEYS = ("value", "ms_per_step", "avg_launch_ms", "frac", "frac_final_layout", "hbm_traffic_frac", "valu_frac", "bound")
+SIDE_KEYS = ("value", "ms_per_step", "avg_launch_ms", "frac", "hbm_traffic_frac", "valu_frac", "bound")  # (frac_final_layout: detail file)
 
 
 def _sig(x, digits=5):
@@ -814,7 +847,8 @@ def emit(out, detail_file):
     print(compact_line(out), flush=True)
 
 
-SIDE_WORKLOADS = [("C1", 200, 20), ("C2v", 200, 20), ("P2", 200, 20), ("C3", 200, 20), ("C4", 200, 20), ("C4x", 100, 10),
+SIDE_WORKLOADS = [("C1", 200, 20), ("C2v", 200, 20), ("C2f", 200, 20), ("P2", 200, 20), ("C3", 200, 20), ("C3f", 200, 20),
+                  ("C4", 200, 20), ("C4x", 100, 10),
                   ("C4xu", 100, 10), ("C2@16384", 100, 20), ("C2@65536", 60, 10), ("C5", 60, 20)]
 
 

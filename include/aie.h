@@ -12,6 +12,10 @@
  *                         F/env_wrapper.py:96-265 (FoundationEnvWrapper.__init__)
  *   aie_seed              F/base/base_env.py:481-494 (BaseEnvironment.seed ->
  *                         np.random.seed), one legacy MT19937 stream PER replica
+ *   aie_seed_fast         the same seam for environments created with rng_mode = AIE_RNG_FAST: a counter-based
+ *                         stream (Philox2x32-10) per replica instead of NumPy's MT19937 -- a throughput mode the
+ *                         reference does not have (its trainers only ever call np.random.seed, base_env.py:481-494);
+ *                         NOT stream-compatible with NumPy
  *   aie_set_rng_state     F/base/base_env.py:871-881 / 968-978 (seed_state injection)
  *   aie_reset             F/base/base_env.py:852-927 (reset) +
  *                         F/env_wrapper.py:267-353 (reset_all_envs/reset_only_done_envs)
@@ -45,7 +49,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define AIE_ABI_VERSION 9
+#define AIE_ABI_VERSION 10
 
 #define AIE_MAX_AGENTS 64      /* mobile agents per replica, spatial scenarios (one lane each) */
 #define AIE_MAX_AGENTS_WIDE 128 /* mobile agents per replica, map-less one-step-economy        */
@@ -55,6 +59,23 @@ extern "C" {
 #define AIE_MAX_SUBSPACES 16   /* action subspaces per agent class                      */
 #define AIE_N_RES 2            /* collectible resources, sorted: 0 = Stone, 1 = Wood    */
 #define AIE_MT_N 624
+/* aie_config.rng_mode: which generator feeds the replicas' np.random.* draws (agent orders, pick-up bonus, resource
+ * regeneration, reset placement / skills / layouts).
+ *   AIE_RNG_NUMPY  NumPy's legacy MT19937 stream per replica, bit for bit (the parity mode; the default).
+ *   AIE_RNG_FAST   a counter-based stream per replica: 32-bit word number g of replica e is element g & 1 of
+ *                  Philox2x32-10(counter = (lo32(g >> 1), hi32(g >> 1) | salt), key = key32) with
+ *                  key32 = lo32(seed + e_global) and salt = (bits 32..47 of seed + e_global) << 16 (Salmon et al.,
+ *                  "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123 constants).  Every consumer of
+ *                  the stream (53-bit doubles from two words, masked-rejection integers, Fisher-Yates permutations,
+ *                  polar Gauss) is unchanged, so a run differs from the parity mode ONLY in the words drawn.  The
+ *                  record carries 16 bytes of generator state instead of 2 496, and a step computes only the words it
+ *                  uses (the resource regeneration addresses the words of its source cells directly instead of
+ *                  advancing MT19937 through all 4 H W of them).  Checked bit for bit against oracle/'s restatement of
+ *                  the same generator; not stream-compatible with NumPy.  COVID draws no random numbers: ignored there.
+ * The position bookkeeping is shared: the stream is consumed in blocks of AIE_MT_N words ("mt_pos" counts inside the
+ * block, 624 = block exhausted); in fast mode tensor "mt" is uint32 [E, 4] = key32, block number, salt, 0. */
+#define AIE_RNG_NUMPY 0
+#define AIE_RNG_FAST 1
 #define AIE_COVID_MAX_FILTERS 8 /* unemployment filter bank size (covid19_env.py:242)    */
 
 /* ---- error codes ---------------------------------------------------------------- */
@@ -243,7 +264,7 @@ typedef struct aie_config {
    * are placed above the water row if their skill rank is listed, else below it. */
   int32_t split_water_line;          /* 0: not a split layout; else 0 < row < world_h - 1 */
   uint32_t split_top_ranks[2];       /* bit k: skill rank k starts in the top part        */
-  int32_t reserved2_;
+  int32_t rng_mode;                  /* AIE_RNG_NUMPY (0, parity with the reference) or AIE_RNG_FAST              */
 
   /* PeriodicBracketTax tax_annealing_schedule=[warmup, slope] (redistribution.py:311-330,
    * utils.py:10-118): the highest allowed rate grows with the number of completed episodes */
@@ -356,7 +377,11 @@ int aie_set_layout(aie_env* env, const uint8_t* stone_src, const uint8_t* wood_s
 
 /* Replica e gets the stream np.random.seed(base_seed + e) would give. */
 int aie_seed(aie_env* env, uint32_t base_seed, void* stream);
-/* Raw legacy-MT19937 state per replica: key[E][624], pos[E] (np.random.get_state()). */
+/* rng_mode == AIE_RNG_FAST only (AIE_E_UNSUPPORTED otherwise): replica e gets the counter stream keyed by
+ * seed + global_env_offset + e (48 bits are used); aie_seed(env, s, ...) is aie_seed_fast(env, s, 0, ...) there. */
+int aie_seed_fast(aie_env* env, uint64_t seed, int64_t global_env_offset, void* stream);
+/* Raw legacy-MT19937 state per replica: key[E][624], pos[E] (np.random.get_state()); rng_mode == AIE_RNG_FAST:
+ * key[E][4] (key32, block number, salt, 0), pos[E]. */
 int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos);
 
 /* Resets the replicas whose env_mask byte is non-zero (NULL = all); env_mask is a

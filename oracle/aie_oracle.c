@@ -72,9 +72,50 @@ static void mt_twist(uint32_t* mt) {
   mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
 }
 
+/* ------------------------------------------------------------------------------- */
+/* rng_mode == AIE_RNG_FAST (include/aie.h): NOT the reference's generator -- the   */
+/* product's throughput mode, restated here so that the device can be checked bit   */
+/* for bit in that mode too.  Philox2x32-10 of Salmon, Moraes, Dror, Shaw, "Parallel */
+/* random numbers: as easy as 1, 2, 3" (SC'11), constants of the authors' Random123  */
+/* library (philox.h: PHILOX_M2x32_0, PHILOX_W32_0); tests/test_rng_fast.py holds    */
+/* that library's known-answer vectors.  Stream word g = element g & 1 of            */
+/* philox(counter = (lo32(g >> 1), hi32(g >> 1) | salt), key32); the stream is       */
+/* consumed in blocks of 624 words under the position bookkeeping of the MT19937     */
+/* path below (pos == 624: the next draw opens block + 1), so that every consumer -- */
+/* doubles, masked-rejection integers, permutations, polar Gauss -- is shared.       */
+/* ------------------------------------------------------------------------------- */
+void aie_oracle_philox2x32_10(const uint32_t ctr[2], uint32_t key, uint32_t out[2]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1];
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t prod = (uint64_t)0xD256D193u * (uint64_t)c0;
+    const uint32_t hi = (uint32_t)(prod >> 32), lo = (uint32_t)prod;
+    c0 = hi ^ key ^ c1;
+    c1 = lo;
+    key += 0x9E3779B9u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+}
+/* word `pos` of block `st[1]` of the stream with state st = (key32, block, salt, 0) */
+static uint32_t fast_word(const uint32_t* st, int pos) {
+  const uint64_t g = (uint64_t)st[1] * 624u + (uint64_t)pos;
+  const uint64_t pair = g >> 1;
+  const uint32_t ctr[2] = {(uint32_t)pair, (uint32_t)(pair >> 32) | st[2]};
+  uint32_t out[2];
+  aie_oracle_philox2x32_10(ctr, st[0], out);
+  return out[g & 1];
+}
+
 static uint32_t rng_u32(ctx_t* c) {
   uint32_t* mt = (uint32_t*)(c->rec + c->p->o_mt);
   int32_t* pos = I32(c, o_mt_pos);
+  if (c->p->c.rng_mode == AIE_RNG_FAST) {
+    if (*pos >= 624) {
+      mt[1] += 1u;
+      *pos = 0;
+    }
+    return fast_word(mt, (*pos)++);
+  }
   if (*pos >= 624) {
     mt_twist(mt);
     *pos = 0;
@@ -1788,15 +1829,22 @@ void aie_oracle_reset(const aie_params* p, uint8_t* arena, const uint8_t* mask, 
       else reset_one(p, arena, e);
     }
 }
-void aie_oracle_seed(const aie_params* p, uint8_t* arena, uint32_t base_seed) {
+void aie_oracle_seed64(const aie_params* p, uint8_t* arena, uint64_t base_seed) {
   for (int e = 0; e < p->E; ++e) {
     uint8_t* rec = arena + p->a_records + (int64_t)e * p->rec_bytes;
-    aie_oracle_seed_one((uint32_t*)(rec + p->o_mt), base_seed + (uint32_t)e);
+    if (p->c.rng_mode == AIE_RNG_FAST) { /* aie_seed_fast(base_seed, 0); aie_seed: base_seed < 2^32 */
+      uint32_t* st = (uint32_t*)(rec + p->o_mt);
+      const uint64_t s = base_seed + (uint64_t)e;
+      st[0] = (uint32_t)s; st[1] = 0u; st[2] = ((uint32_t)(s >> 32) & 0xffffu) << 16; st[3] = 0u;
+    } else {
+      aie_oracle_seed_one((uint32_t*)(rec + p->o_mt), (uint32_t)base_seed + (uint32_t)e);
+    }
     *(int32_t*)(rec + p->o_mt_pos) = 624;
     *(int32_t*)(rec + p->o_mt_has_gauss) = 0;
     *(double*)(rec + p->o_mt_gauss) = 0.0;
   }
 }
+void aie_oracle_seed(const aie_params* p, uint8_t* arena, uint32_t base_seed) { aie_oracle_seed64(p, arena, (uint64_t)base_seed); }
 /* multi-threaded step for the cpu_baseline leg of bench.py */
 void aie_oracle_step_mt(const aie_params* p, uint8_t* arena, const int32_t* aa, const int32_t* ap, int nthreads) {
   int E = p->E;

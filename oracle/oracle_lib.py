@@ -50,6 +50,10 @@ def lib():
         L.aie_oracle_reset.restype = None
         L.aie_oracle_seed.argtypes = [vp, vp, C.c_uint32]
         L.aie_oracle_seed.restype = None
+        L.aie_oracle_seed64.argtypes = [vp, vp, C.c_uint64]
+        L.aie_oracle_seed64.restype = None
+        L.aie_oracle_philox2x32_10.argtypes = [vp, C.c_uint32, vp]
+        L.aie_oracle_philox2x32_10.restype = None
         _LIB = L
     return _LIB
 
@@ -135,7 +139,7 @@ class OracleEnv:
                 self.t["cell_flags"][e] = fl
 
     def seed(self, base_seed):
-        lib().aie_oracle_seed(self._params, self.arena.ctypes.data, base_seed)
+        lib().aie_oracle_seed64(self._params, self.arena.ctypes.data, base_seed)  # (rng_mode "numpy": the low 32 bits)
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8).ctypes.data

@@ -421,7 +421,8 @@ def test_covid_filter_recurrence_vs_exact_window_sums():
 
 
 def _covid_state_tensors(env):
-    skip = ("stringency_change_", "window_streams_whole_history", "stringency_history_chunks")
+    # (sample_t: the policy's draw index, a record field since round 5 -- only the environment the test draws from advances it)
+    skip = ("stringency_change_", "window_streams_whole_history", "stringency_history_chunks", "sample_t")
     return {k: v for k, v in env.tensors.items() if not k.startswith(skip)}
 
 

@@ -110,6 +110,13 @@ def test_hip_reset_matches_reference_golden(name):
         _obs_check(be, g, list(g["obs_steps"]).index(0), name + " reset obs", e=1)
 
 
+def _state_keys(tensors):
+    """Every named tensor but the sampler's draw index: `sample_t` (a record field since round 5, so that a captured
+    launch can be replayed) counts the action draws an environment has made -- tests that draw from one environment and
+    step two with the same actions differ there and nowhere else."""
+    return [k for k in tensors if k != "sample_t"]
+
+
 def _compare_all(be, oracle, where, sl=None):
     """Every state field, observation, reward and accumulator of the replicas in `sl` (default: all): integers,
     books and the MT19937 key bit-exact -- including `auto_warmup`, the integer the sign of a ~1e-16 mean
@@ -245,7 +252,9 @@ def test_step_sample_next_equals_two_launches(case):
         if (t + 1) % T == 0:
             b0.reset(b0.tensors["done"])
             b1.reset(b1.tensors["done"])
-    torch.cuda.synchronize()
+    b0.sample_random_actions(seed=4242, env_offset=640)  # (b1 has drawn the next step's actions already: the draw index
+    torch.cuda.synchronize()                             # is a record field)
+    assert torch.equal(b0.tensors["sample_t"], b1.tensors["sample_t"])
     assert torch.equal(b0.arena, b1.arena)
     with pytest.raises(ValueError):
         b1._check(b1.lib.aie_step_sample_next(b1.handle, cur[0].data_ptr(), cur[1].data_ptr(), 1, 0,
@@ -925,7 +934,7 @@ def test_compile_time_instance_equals_generic_kernel(case):
             cur_s = b_spec.sample_random_actions(seed=4, slot=slot)
         if t in checks:
             torch.cuda.synchronize()
-            for k in b_ref.tensors:
+            for k in _state_keys(b_ref.tensors):
                 assert torch.equal(b_ref.tensors[k], b_spec.tensors[k]), "%s step %d: %s differs" % (case, t + 1, k)
         if (t + 1) % T == 0:  # episode end: the instance's reset kernel against the generic one
             for b in (b_ref, b_spec):
@@ -958,7 +967,7 @@ def test_dense_log_switch_keeps_state_identical():
                 env.backend.reset(env.backend.tensors["done"])
         if t in (0, 1, 49, 50, 119):
             torch.cuda.synchronize()
-            for k in on.backend.tensors:
+            for k in _state_keys(on.backend.tensors):
                 if not k.startswith("log_event"):
                     assert torch.equal(on.backend.tensors[k], off.backend.tensors[k]), "step %d: %s differs" % (t + 1, k)
     # back on: the very next step records rows again, identical to an environment that never switched
@@ -967,7 +976,7 @@ def test_dense_log_switch_keeps_state_identical():
     for env in (on, off):
         env.backend.step(a, p)
     torch.cuda.synchronize()
-    for k in on.backend.tensors:
+    for k in _state_keys(on.backend.tensors):
         if k != "log_events":
             assert torch.equal(on.backend.tensors[k], off.backend.tensors[k]), "after switching back on: %s differs" % k
     for e in range(on.backend.tensors["log_events"].shape[0]):  # (rows behind the count are leftovers of earlier steps)
@@ -1047,7 +1056,7 @@ def test_runtime_specialisation_equals_generic_kernel(case):
             b_jit.reset(mask)
         if t in (0, 1, 39, 40, T - 1) or bool(b_ref.tensors["done"][0]):
             torch.cuda.synchronize()
-            for k in b_ref.tensors:
+            for k in _state_keys(b_ref.tensors):
                 assert torch.equal(b_ref.tensors[k], b_jit.tensors[k]), "%s step %d: %s differs" % (case, t + 1, k)
     # the switch works both ways, and a second environment of the same configuration finds the cached code object
     assert b_jit.lib.aie_select_step_kernel(b_jit.handle, 1) == 0 and b_jit.lib.aie_step_kernel_instance(b_jit.handle) == -1
@@ -1087,7 +1096,7 @@ def test_background_specialisation_swaps_in_without_a_call(monkeypatch):
             swapped_at = steps
         if steps % 20 == 0 or steps == swapped_at:
             torch.cuda.synchronize()
-            for k in bt.tensors:
+            for k in _state_keys(bt.tensors):
                 assert torch.equal(bt.tensors[k], be.tensors[k]), "step %d (switch at %s): %s differs" % (steps, swapped_at, k)
             if swapped_at is None:
                 time.sleep(0.05)  # (the compiler needs a second or two the first time; nothing to do with the device)
@@ -1114,7 +1123,7 @@ def test_reset_is_deterministic_across_environments():
         torch.cuda.synchronize()
         a = envs[0].backend
         for other in envs[1:]:
-            for k in a.tensors:
+            for k in _state_keys(a.tensors):
                 assert torch.equal(a.tensors[k], other.backend.tensors[k]), "round %d: %s differs between identical environments" % (rep, k)
 
 
@@ -1145,7 +1154,7 @@ def test_draw_window_refills_do_not_change_the_stream(words):
             small.reset(small.backend.tensors["done"])
         if t in (0, 1, 2, 29, 59, 60, 129):
             torch.cuda.synchronize()
-            for k in ref.backend.tensors:
+            for k in _state_keys(ref.backend.tensors):
                 assert torch.equal(ref.backend.tensors[k], small.backend.tensors[k]), "step %d: %s differs" % (t + 1, k)
 
 
@@ -1179,7 +1188,7 @@ def test_compile_time_instance_equals_generic_kernel_one_step_economy():
             b_ref.reset(b_ref.tensors["done"])
             b_spec.reset(b_spec.tensors["done"])
         torch.cuda.synchronize()
-        for k in b_ref.tensors:
+        for k in _state_keys(b_ref.tensors):
             assert torch.equal(b_ref.tensors[k], b_spec.tensors[k]), "step %d: %s differs" % (t + 1, k)
 
 
@@ -1225,7 +1234,7 @@ def test_auto_reset_equals_step_then_masked_reset(case):
         assert torch.equal(b_auto.tensors["done"], done), "step %d: done" % (t + 1)
         assert torch.equal(b_auto.tensors["rewards_a"], rew_a) and torch.equal(b_auto.tensors["rewards_p"], rew_p)
         for k, v in b_ref.tensors.items():
-            if k in ("done", "rewards_a", "rewards_p") or k.startswith("metrics_"):
+            if k in ("done", "rewards_a", "rewards_p", "sample_t") or k.startswith("metrics_"):
                 continue
             assert torch.equal(v, b_auto.tensors[k]), "step %d: %s differs" % (t + 1, k)
     assert int(b_auto.tensors["completions"].min()) >= 2

@@ -1,0 +1,338 @@
+"""rng_mode="fast" (include/aie.h: AIE_RNG_FAST): a counter-based stream per replica (Philox2x32-10) in place of NumPy's
+MT19937 -- a throughput mode the reference does not have (its trainers only ever call np.random.seed,
+base_env.py:481-494).  The parity chain, so that nothing here is "statistical only":
+
+    reference == oracle(MT19937) bit for bit         tests/test_oracle_vs_reference.py, tests/golden/ (unchanged)
+    oracle(fast) differs from oracle(MT19937) in ONE function, rng_u32 (oracle/aie_oracle.c): the words drawn
+    Philox2x32-10 itself                             Random123's known-answer vectors (below)
+    HIP(fast) == oracle(fast) bit for bit            the -m gpu tests below: every state field, every observation
+    oracle(fast) ~ oracle(MT19937) in distribution   chi-square / binomial checks below (regeneration rate, placement)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import make_env
+
+GTB = [["Build", {}], ["ContinuousDoubleAuction", {"max_num_orders": 5}], ["Gather", {}], ["PeriodicBracketTax", {}]]
+C2 = dict(scenario_name="layout_from_file/simple_wood_and_stone", n_agents=4, world_size=[25, 25],
+          episode_length=1000, components=GTB, starting_agent_coin=10,
+          env_layout_file="quadrant_25x25_20each_30clump.txt")
+C1 = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=4, world_size=[15, 15], episode_length=1000,
+          components=[["Build", {}], ["Gather", {}]], starting_agent_coin=10, starting_stone_coverage=0.10,
+          starting_wood_coverage=0.10)
+
+
+def _ose_cfg(n=12, T=3):
+    rs = np.random.RandomState(4)
+    return dict(scenario_name="one-step-economy", n_agents=n, world_size=[1, 1], episode_length=T,
+                components=[["SimpleLabor", {"skills": [float(x) for x in np.sort(1 + rs.rand(n) * 2)]}],
+                            ["PeriodicBracketTax", {"bracket_spacing": "us-federal", "period": 1,
+                                                    "tax_model": "model_wrapper"}]])
+
+
+def _philox(c0, c1, key):
+    from oracle_lib import lib
+
+    ctr = (C.c_uint32 * 2)(c0, c1)
+    out = (C.c_uint32 * 2)()
+    lib().aie_oracle_philox2x32_10(ctr, key, out)
+    return int(out[0]), int(out[1])
+
+
+def _oracle(cfg, E, seed, **extra):
+    from oracle_lib import OracleEnv
+
+    env = make_env(cfg, n_envs=E, **extra)
+    o = OracleEnv(env.build_config(), env.layout_planes())
+    o.seed(seed)
+    o.reset()
+    return env, o
+
+
+# ---- the generator ---------------------------------------------------------------------------------------------------
+def test_philox2x32_10_known_answers():
+    """Random123 (Salmon et al., SC'11) kat_vectors, philox2x32 with 10 rounds: counter, key -> output."""
+    assert _philox(0x00000000, 0x00000000, 0x00000000) == (0xff1dae59, 0x6cd10df2)
+    assert _philox(0xffffffff, 0xffffffff, 0xffffffff) == (0x2c3f628b, 0xab4fd7ad)
+    assert _philox(0x243f6a88, 0x85a308d3, 0x13198a2e) == (0xdd7ce038, 0xf62a4c12)
+
+
+def test_fast_stream_is_the_documented_function_of_seed_replica_and_word_number():
+    """include/aie.h: word g of replica e = element g & 1 of philox(counter = (lo32(g >> 1), hi32(g >> 1) | salt),
+    key32), key32 = lo32(seed + e), salt = bits 32..47 of (seed + e) << 16; the first draw after seeding is word 624
+    (block 1).  Checked through the oracle's own consumer: the agents' reset placement draws (randint via masked
+    rejection on successive words, layout_from_file.py:360-370)."""
+    seed = (0x1234 << 32) | 0xfffffffe  # replica 2's key wraps into the salt bits
+    env, o = _oracle(C2, 4, seed, rng_mode="fast")
+    st = o.t["mt"]
+    assert st.shape == (4, 4) and o.t["mt_pos"].shape == (4,)
+    for e in range(4):
+        s = seed + e
+        assert int(st[e, 0]) == s & 0xffffffff and int(st[e, 2]) == ((s >> 32) & 0xffff) << 16 and int(st[e, 3]) == 0
+        assert int(st[e, 1]) == 1  # the reset drew from block 1
+        # replay the placement of agent 0: row = first word & 31 that is <= 24, then the column likewise
+        g, vals = 624, []
+        while len(vals) < 2:
+            pair = g >> 1
+            w = _philox(pair & 0xffffffff, (pair >> 32) | int(st[e, 2]), int(st[e, 0]))[g & 1]
+            g += 1
+            if (w & 31) <= 24:
+                vals.append(w & 31)
+        # (the first candidate cell may be occupied / water in which case the reference redraws: accept either the
+        # replayed cell or a cell reached after more draws, but the FIRST pair must have been looked at)
+        r, c = int(o.t["loc_r"][e, 0]), int(o.t["loc_c"][e, 0])
+        water = env.layout_planes()[2].reshape(25, 25)
+        if not water[vals[0], vals[1]]:
+            assert (r, c) == (vals[0], vals[1]), (e, r, c, vals)
+
+
+def test_fast_mode_is_deterministic_and_keyed_by_global_replica():
+    """Replica e of a batch seeded s == replica 0 of a batch seeded s + e (the sharding rule: env_offset adds to the
+    seed), and two runs agree bit for bit."""
+    rs = np.random.RandomState(0)
+    _, big = _oracle(C2, 6, 11, rng_mode="fast")
+    _, again = _oracle(C2, 6, 11, rng_mode="fast")
+    _, shard = _oracle(C2, 2, 15, rng_mode="fast")
+    for t in range(40):
+        a = rs.randint(0, 50, size=(6, 4)).astype(np.int32)
+        p = rs.randint(0, 22, size=(6, 7)).astype(np.int32)
+        big.step(a, p)
+        again.step(a, p)
+        shard.step(a[4:], p[4:])
+    for k in big.t:
+        if big.t[k].shape[0] != 6:
+            continue
+        assert np.array_equal(big.t[k], again.t[k]), k
+        assert np.array_equal(big.t[k][4:], shard.t[k]), k
+
+
+def test_fast_and_numpy_modes_differ_only_in_the_stream():
+    """Same configuration: the two modes share every tensor's shape except the generator state, and where no draw
+    decides anything (NO-OP actions, nothing to regenerate) their trajectories coincide."""
+    _, of = _oracle(C2, 3, 5, rng_mode="fast")
+    _, om = _oracle(C2, 3, 5)
+    assert of.t["mt"].shape == (3, 4) and om.t["mt"].shape == (3, 624)
+    for k in om.t:
+        if k != "mt":
+            assert of.t[k].shape == om.t[k].shape, k
+    z_a, z_p = np.zeros((3, 4), np.int32), np.zeros((3, 7), np.int32)
+    pos0 = of.t["mt_pos"].copy(), om.t["mt_pos"].copy()
+    blk0 = of.t["mt"][:, 1].copy()
+    for t in range(5):
+        of.step(z_a, z_p)
+        om.step(z_a, z_p)
+    for k in ("stone", "wood", "inv_coin", "inv_res", "timestep", "labor", "rewards_a", "done"):
+        assert np.array_equal(of.t[k], om.t[k]), k
+    # both consumed the same number of words: per step two agent-order permutations' worth of rejection draws differ,
+    # the 4 H W regeneration words do not -- the fast stream moved on by about 5 x 2500 words = 20 blocks
+    adv = (of.t["mt"][:, 1].astype(np.int64) - blk0) * 624 + of.t["mt_pos"] - pos0[0]
+    assert ((adv >= 5 * 2500) & (adv < 5 * 2600)).all(), adv
+
+
+# ---- distribution: oracle(fast) against oracle(MT19937) and against theory -------------------------------------------------
+def _respawn_counts(mode, E, steps, seed):
+    extra = dict(rng_mode="fast") if mode == "fast" else {}
+    _, o = _oracle(dict(C2, resource_regen_prob=0.05), E, seed, **extra)
+    src = (o.t["cell_flags"] & 2).astype(bool), (o.t["cell_flags"] & 4).astype(bool)  # stone / wood source blocks
+    o.t["stone"][...] = 0
+    o.t["wood"][...] = 0
+    z_a, z_p = np.zeros((E, 4), np.int32), np.zeros((E, 7), np.int32)
+    # park the agents on cells that are not source blocks?  NO-OP agents do not gather (move.py:126: only a MOVE
+    # collects), so respawned resources stay where they are
+    n_src = int(src[0].sum() + src[1].sum())
+    filled = []
+    for t in range(steps):
+        o.step(z_a, z_p)
+        filled.append(int((o.t["stone"][src[0]] > 0).sum() + (o.t["wood"][src[1]] > 0).sum()))
+    return n_src, np.array(filled)
+
+
+def test_regeneration_rate_matches_theory_in_both_modes():
+    """Empty source blocks respawn with probability regen_weight per step (layout_from_file.py:394-403): after k steps
+    a fraction 1 - (1 - p)^k is back.  ~10 000 Bernoulli chains per mode: both modes within 4 sigma of theory and of
+    each other."""
+    E, steps, p = 128, 20, 0.05
+    res = {}
+    for mode in ("numpy", "fast"):
+        n_src, filled = _respawn_counts(mode, E, steps, seed=17)
+        assert n_src > 5000
+        for k in (1, 5, 20):
+            q = 1 - (1 - p) ** k
+            sigma = np.sqrt(n_src * q * (1 - q))
+            assert abs(filled[k - 1] - n_src * q) < 4 * sigma, (mode, k, filled[k - 1], n_src * q, sigma)
+        res[mode] = (n_src, filled)
+    n_src = res["numpy"][0]
+    for k in (1, 5, 20):
+        q = 1 - (1 - p) ** k
+        assert abs(res["numpy"][1][k - 1] - res["fast"][1][k - 1]) < 4 * np.sqrt(2 * n_src * q * (1 - q))
+
+
+def test_reset_placement_has_the_same_distribution_in_both_modes():
+    """Agent start cells are np.random.randint draws with rejection of occupied / water cells
+    (layout_from_file.py:360-370).  Two-sample chi-square over the 25 rows and the 25 columns of agent 0's start cell,
+    4096 replicas per mode (24 degrees of freedom: 99.9 % quantile 51.2)."""
+    E = 4096
+    _, of = _oracle(C2, E, 1, rng_mode="fast")
+    _, om = _oracle(C2, E, 1)
+    for key in ("loc_r", "loc_c"):
+        hf = np.bincount(of.t[key][:, 0], minlength=25).astype(np.float64)
+        hm = np.bincount(om.t[key][:, 0], minlength=25).astype(np.float64)
+        ok = (hf + hm) > 0
+        chi2 = float((((hf - hm) ** 2) / (hf + hm))[ok].sum())
+        assert chi2 < 51.2, (key, chi2)
+    # and the agent-order permutations behind Gather / Build resolve conflicts without a bias between the modes: the
+    # four agents' total collected resources after 60 random steps agree within 4 sigma of the replica spread
+    tot = {}
+    for name, o in (("fast", of), ("numpy", om)):
+        rs = np.random.RandomState(3)
+        p = np.zeros((E, 7), np.int32)
+        for t in range(60):
+            o.step(rs.randint(0, 50, size=(E, 4)).astype(np.int32), p, nthreads=8)
+        tot[name] = o.t["inv_res"].reshape(E, -1).sum(axis=1).astype(np.float64)
+    d = tot["fast"].mean() - tot["numpy"].mean()
+    se = np.sqrt(tot["fast"].var() / E + tot["numpy"].var() / E)
+    assert abs(d) < 4 * se, (d, se)
+
+
+def test_word_stream_bytes_are_uniform():
+    """Chi-square of the byte values of 2^17 stream words of one replica (255 degrees of freedom: 99.9 % quantile
+    330.5) and of the top bit between consecutive words (serial pairs)."""
+    from oracle_lib import lib
+
+    L = lib()
+    n = 1 << 16
+    ctr = (C.c_uint32 * 2)()
+    out = (C.c_uint32 * 2)()
+    words = np.empty(2 * n, np.uint32)
+    for i in range(n):
+        ctr[0], ctr[1] = i, 0
+        L.aie_oracle_philox2x32_10(ctr, 12345, out)
+        words[2 * i], words[2 * i + 1] = out[0], out[1]
+    h = np.bincount(words.view(np.uint8), minlength=256).astype(np.float64)
+    exp = words.size * 4 / 256.0
+    assert float(((h - exp) ** 2 / exp).sum()) < 330.5
+    top = (words >> 31).astype(np.int64)
+    pairs = np.bincount(2 * top[:-1] + top[1:], minlength=4).astype(np.float64)
+    exp = (words.size - 1) / 4.0
+    assert float(((pairs - exp) ** 2 / exp).sum()) < 16.3  # 3 dof, 99.9 %
+
+
+# ---- host API ------------------------------------------------------------------------------------------------------------
+def test_rng_mode_is_validated_and_part_of_the_config():
+    from ai_economist_amd import _cabi
+
+    with pytest.raises(ValueError):
+        make_env(C2, n_envs=1, rng_mode="philox")
+    assert make_env(C2, n_envs=1).build_config().rng_mode == _cabi.RNG_NUMPY
+    assert make_env(C2, n_envs=1, rng_mode="fast").build_config().rng_mode == _cabi.RNG_FAST
+    with pytest.raises(NotImplementedError):  # host-drawn layouts continue the replica's NumPy stream
+        make_env(dict(C1, world_size=[70, 70]), n_envs=1, rng_mode="fast").build_config()
+
+
+def test_fast_instances_are_families_of_their_own():
+    """The compile-time images of C2f / C3f differ from C2 / C3 (the generator is part of the record layout)."""
+    from ai_economist_amd import _specs
+
+    names = [s[0] for s in _specs.SPECS]
+    assert any(n.startswith("C2f") for n in names) and any(n.startswith("C3f") for n in names)
+
+
+# ---- the device against the oracle, bit for bit --------------------------------------------------------------------------
+def _gpu_case(cfg, E, T, seed, generic=False, check_every=10, reset_at=(), nthreads=4):
+    import torch
+    from oracle_lib import OracleEnv
+    from test_gpu_parity import _compare_all
+
+    env = make_env(cfg, n_envs=E, device="cuda:0", rng_mode="fast")
+    be = env.backend
+    if generic:
+        assert be.lib.aie_select_step_kernel(be.handle, 1) == 0
+    env.seed(seed)
+    env.reset()
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(seed)
+    oracle.reset()
+    assert be.tensors["mt"].shape == (E, 4)
+    _compare_all(be, oracle, "after reset")
+    for t in range(T):
+        a, p = be.sample_random_actions(seed=99)
+        env.step({"a": a, "p": p})
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=nthreads)
+        if (t + 1) % check_every == 0 or t + 1 == T or (t + 1) in reset_at or t < 3:
+            _compare_all(be, oracle, "step %d" % (t + 1))
+        if (t + 1) in reset_at:
+            done = be.tensors["done"].clone()
+            assert bool(done.any())
+            env.reset(done)
+            oracle.reset(done.cpu().numpy())
+            _compare_all(be, oracle, "reset after step %d" % (t + 1))
+    return env, be, oracle
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["c2_instance", "c3_instance", "c2_generic", "c3_generic"])
+def test_hip_fast_mode_equals_the_oracle_bit_for_bit(case):
+    """C2f / C3f (compile-time instances) and the generic kernel: seeded uniform-random rollouts, every replica, every
+    field incl. the generator state, across tax days, an episode end and the masked reset behind it."""
+    n = 4 if case.startswith("c2") else 10
+    cfg = dict(C2, n_agents=n, episode_length=120)
+    env, be, _ = _gpu_case(cfg, 192 if n == 4 else 96, 150, seed=5, generic=case.endswith("generic"), reset_at=(120,))
+    inst = be.lib.aie_step_kernel_instance(be.handle)
+    assert (inst == -1) if case.endswith("generic") else (inst >= 0), inst
+
+
+@pytest.mark.gpu
+def test_hip_fast_mode_other_layouts_and_scalars():
+    """Another layout file (more source blocks: the second chunk of the regeneration's source list), other scalars, a
+    short episode; runs on the C2f instance's family or the generic kernel, whichever applies."""
+    cfg = dict(C2, episode_length=60, starting_agent_coin=15, resource_regen_prob=0.05,
+               env_layout_file="uniform_25x25_25each_65clump.txt")
+    _gpu_case(cfg, 128, 130, seed=8, reset_at=(60, 120))
+
+
+@pytest.mark.gpu
+def test_hip_fast_mode_dynamic_layouts():
+    """uniform/ (BASELINE configs[0]'s scenario): the reset draws the source layout from the replica's stream -- thousands
+    of sequential words, through the block rows (mt_fast_rows) -- four wavefronts per replica."""
+    _gpu_case(dict(C1, episode_length=40), 96, 85, seed=21, reset_at=(40, 80))
+
+
+@pytest.mark.gpu
+def test_hip_fast_mode_one_step_economy():
+    """one-step-economy: the agent-order permutation SimpleLabor draws and discards (the stream's position is state)."""
+    _gpu_case(_ose_cfg(12, 3), 64, 20, seed=6, check_every=1, reset_at=(3, 6, 9, 12, 15, 18))
+    _gpu_case(_ose_cfg(100, 2), 256, 12, seed=7, check_every=1, reset_at=(2, 4, 6, 8, 10, 12))
+
+
+@pytest.mark.gpu
+def test_hip_fast_mode_many_source_blocks_take_the_row_path():
+    """More source doubles than the sparse list holds (AIE_SRC_CAP = 128; uniform layouts with 22 % coverage per resource
+    on 20 x 20) regenerate through the block rows (scenario_step_regen_rows)."""
+    cfg = dict(scenario_name="uniform/simple_wood_and_stone", n_agents=5, world_size=[20, 20], episode_length=25,
+               components=[["Build", {}], ["Gather", {}]], starting_agent_coin=3, starting_stone_coverage=0.22,
+               starting_wood_coverage=0.22, wood_regen_weight=0.3, stone_regen_weight=0.2)
+    env, be, _ = _gpu_case(cfg, 16, 40, seed=4, check_every=6, reset_at=(25,))
+    flags = be.tensors["cell_flags"].reshape(16, -1).cpu().numpy()
+    assert ((((flags & 2) != 0).sum(axis=1) + ((flags & 4) != 0).sum(axis=1)) > 128).all()
+
+
+@pytest.mark.gpu
+def test_aie_seed_fast_entry_point():
+    import torch
+
+    env = make_env(C2, n_envs=8, device="cuda:0", rng_mode="fast", env_offset=3)
+    be = env.backend
+    seed = (7 << 32) + 5
+    be._check(be.lib.aie_seed_fast(be.handle, C.c_uint64(seed), C.c_int64(3), None))
+    torch.cuda.synchronize()
+    st = be.tensors["mt"].cpu().numpy().view(np.uint32)
+    for e in range(8):
+        s = seed + 3 + e
+        assert list(st[e]) == [s & 0xffffffff, 0, ((s >> 32) & 0xffff) << 16, 0]
+    assert (be.tensors["mt_pos"].cpu().numpy() == 624).all()
+    plain = make_env(C2, n_envs=8, device="cuda:0").backend
+    assert plain.lib.aie_seed_fast(plain.handle, C.c_uint64(1), C.c_int64(0), None) != 0
+    assert b"rng_mode" in plain.lib.aie_last_error(plain.handle)

@@ -16,11 +16,11 @@ import bench  # noqa: E402
 
 for path in sys.argv[1:]:
     line = json.loads(open(path).read().strip().splitlines()[-1])
-    wl = os.path.basename(path).split("_")[1].upper().replace("C4X", "C4x")
+    wl, rnd = bench.workload_of_profile(path)
     r = line["roofline"]
     t = r["avg_launch_ms"] * 1e-3
-    traffic, tsrc = bench.measured_traffic(wl, line["config"]["envs_per_gpu"])
-    insts, isrc, valu = bench.issue_counters(wl)
+    traffic, tsrc = bench.measured_traffic(wl, line["config"]["envs_per_gpu"], max_round=rnd)
+    insts, isrc, valu = bench.issue_counters(wl, max_round=rnd)
     r["traffic"] = traffic
     r["hbm_traffic_frac"] = traffic / t / 1e9 / bench.HBM_PEAK_GBS if traffic else None
     r["issue_frac"] = insts / (bench.N_SIMDS * bench.SM_CLOCK_HZ * t) if insts else None
