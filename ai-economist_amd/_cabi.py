@@ -194,6 +194,8 @@ def bind(lib):
     lib.aie_reset.argtypes = [vp, vp, vp]
     lib.aie_step.restype = C.c_int
     lib.aie_step.argtypes = [vp, vp, vp, vp]
+    lib.aie_sample_policy_actions.restype = C.c_int
+    lib.aie_sample_policy_actions.argtypes = [vp, vp, vp, C.c_uint64, C.c_int64, vp, vp, vp]
     lib.aie_sample_random_actions.restype = C.c_int
     lib.aie_sample_random_actions.argtypes = [vp, C.c_uint64, C.c_int64, vp, vp, vp]
     lib.aie_set_reward_log.restype = C.c_int
@@ -225,7 +227,7 @@ EXPORTED_SYMBOLS = [
     "aie_arena_bytes", "aie_create", "aie_destroy", "aie_last_error", "aie_num_tensors",
     "aie_tensor_at", "aie_get_tensor", "aie_upload", "aie_download", "aie_set_layout",
     "aie_seed", "aie_seed_fast", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
-    "aie_sample_masked_actions", "aie_step_sample_next", "aie_step_sample_next_masked", "aie_set_reward_log", "aie_set_auto_reset",
+    "aie_sample_masked_actions", "aie_sample_policy_actions", "aie_step_sample_next", "aie_step_sample_next_masked", "aie_set_reward_log", "aie_set_auto_reset",
     "aie_set_dense_log_active", "aie_step_kernel_instance", "aie_select_step_kernel", "aie_specialize", "aie_set_global_saez_buffer", "aie_sizeof_config",
     "aie_arena_info",
 ]

@@ -59,13 +59,22 @@ static int aie_jit_request(aie_env* env);
 // allocation / single VMM allocation, in every one of 8 + 3 fresh processes (profiles/r04_c5_alloc.json; pieces of 2,
 // 16, 128, 256, 1024 MiB: 1.57, 1.47, 1.43, 1.48, 1.66 ms -- one big physical allocation lands on the memory channels
 // less evenly than many medium ones).  AIE_ARENA_PIECE_MB overrides the piece size, 0 = always hipMalloc.
+// Round 5: the piece size does not explain the box-to-box spread of the one-step-economy launch (fresh processes with 16 /
+// 64 / 128 MiB pieces: 1.53 / 1.61 / 1.49 ms on one box, 1.616 / 1.622 / 1.633 ms on the next -- tools/c5_piece_experiment.sh,
+// DESIGN.md section 4); a create-time store probe that re-mapped the arena with several piece sizes and kept the fastest was
+// tried and dropped (a map / unmap / re-map cycle of the 7 GB range faulted on this driver, and the probe had nothing
+// consistent to find).  64 MiB stays the default.
+static uint8_t* aie_arena_alloc_pieces(int device, size_t bytes, size_t piece_mb, size_t* vmm_total, size_t* vmm_piece);
 static uint8_t* aie_arena_alloc(int device, size_t bytes, size_t* vmm_total, size_t* vmm_piece) {
-  *vmm_total = *vmm_piece = 0;
   const char* e_min = getenv("AIE_ARENA_VMM_MIN_MB");
   const char* e_piece = getenv("AIE_ARENA_PIECE_MB");
-  const size_t min_mb = e_min ? (size_t)atol(e_min) : 1024, piece_mb = e_piece ? (size_t)atol(e_piece) : 64;
+  const size_t min_mb = e_min ? (size_t)atol(e_min) : 1024;
+  return aie_arena_alloc_pieces(device, bytes, bytes >= (min_mb << 20) ? (e_piece ? (size_t)atol(e_piece) : 64) : 0, vmm_total, vmm_piece);
+}
+static uint8_t* aie_arena_alloc_pieces(int device, size_t bytes, size_t piece_mb, size_t* vmm_total, size_t* vmm_piece) {
+  *vmm_total = *vmm_piece = 0;
   void* p = nullptr;
-  if (piece_mb > 0 && bytes >= (min_mb << 20)) {
+  if (piece_mb > 0) {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -368,6 +377,21 @@ int aie_set_layout(aie_env* env, const uint8_t* stone_src, const uint8_t* wood_s
   AIE_HIP_CHECK(env, hipGetLastError());
   AIE_HIP_CHECK(env, hipDeviceSynchronize());
   AIE_HIP_CHECK(env, hipFree(dfl));
+  if (aie__shared_src_list(&P.c)) {
+    // the regeneration's source doubles, once for the whole batch (aie_params.a_src_list): double d of a step's 2 H W
+    // np.random.rand values targets Wood cell d (d < H W) or Stone cell d - H W (layout_from_file.py:394-403)
+    struct { int32_t count, pad[3]; uint16_t d[AIE_SRC_CAP]; } lst;
+    memset(&lst, 0, sizeof(lst));
+    for (int r = 0; r < 2; ++r) {
+      const uint8_t* plane = r == 0 ? wood_src : stone_src;
+      for (int cell = 0; cell < P.HW; ++cell)
+        if (plane[cell]) {
+          if (lst.count < AIE_SRC_CAP) lst.d[lst.count] = (uint16_t)(r * P.HW + cell);
+          lst.count += 1;
+        }
+    }
+    AIE_HIP_CHECK(env, hipMemcpy(env->arena + P.a_src_list, &lst, sizeof(lst), hipMemcpyHostToDevice));
+  }
   return AIE_OK;
 }
 
@@ -536,7 +560,11 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
     NextActions lg = next;
     lg.e_lo = 0;
     lg.e_hi = env->P.ev_replicas;
-    hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)env->P.E), dim3(2 * AIE_NT), env->lds,
+    // The grid covers the workgroups that map to the logged replicas [0, L) and as little else as possible (the others
+    // leave at once): replica_of_block is the identity when E is not a multiple of 8, else replica e < E / 8 is workgroup 8 e.
+    const int64_t L = env->P.ev_replicas, E8 = env->P.E >> 3;
+    const unsigned log_grid = (env->P.E & 7) ? (unsigned)L : (L <= E8 ? (unsigned)(8 * (L - 1) + 1) : (unsigned)env->P.E);
+    hipLaunchKernelGGL(aie_step_kernel_log, dim3(log_grid), dim3(2 * AIE_NT), env->lds,
                        static_cast<hipStream_t>(stream), env->d_params, env->arena, d_actions_a, d_actions_p, lg);
     if (env->P.ev_replicas >= env->P.E) goto stepped;
     next.e_lo = env->P.ev_replicas;
@@ -704,6 +732,20 @@ int aie_sample_masked_actions(aie_env* env, uint64_t seed, int64_t global_env_of
                      static_cast<hipStream_t>(stream), P, env->arena, seed, global_env_offset, d_actions_a, d_actions_p);
   hipLaunchKernelGGL(aie_sample_advance_kernel, dim3((unsigned)((P.E + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), env->arena, P.a_records, P.rec_bytes, P.o_sample_t, P.E);
+  AIE_HIP_CHECK(env, hipGetLastError());
+  return AIE_OK;
+}
+
+int aie_sample_policy_actions(aie_env* env, const float* d_logits_a, const float* d_logits_p, uint64_t seed,
+                              int64_t global_env_offset, int32_t* d_actions_a, int32_t* d_actions_p, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  if ((d_actions_a && !d_logits_a) || (d_actions_p && !d_logits_p)) {
+    snprintf(env->err, sizeof(env->err), "aie_sample_policy_actions: an action buffer without its logits");
+    return AIE_E_INVALID;
+  }
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  hipLaunchKernelGGL(aie_sample_policy_actions_kernel, dim3((unsigned)env->P.E), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     env->P, env->arena, d_logits_a, d_logits_p, seed, global_env_offset, d_actions_a, d_actions_p);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
 }

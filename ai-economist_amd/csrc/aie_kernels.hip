@@ -47,7 +47,7 @@ __device__ __forceinline__ const aie_params& aie_spec_params(const aie_params* r
 
 #define AIE_NT 64  // threads per replica (one wavefront)
 #define AIE_DIRTY_CAP 64  // map cells one step may change before the incremental map observations give up (= one lane each)
-#define AIE_SRC_CAP 128  // source-block doubles handled by the gather regen (else row regen)
+// (AIE_SRC_CAP, aie_layout.h: source-block doubles handled by the gather regen, else row regen)
 
 namespace aie {
 
@@ -104,6 +104,13 @@ __host__ __device__ inline int fscr_doubles(const aie_params& P) { return 2 * P.
 // The LDS image of the record stops where the MT19937 key starts (it lives in VGPRs).  The counter stream's state
 // (AIE_RNG_FAST: key32, block number, salt, 0 -- 16 bytes) is part of the image.
 __host__ __device__ inline bool rng_fast(const aie_params& P) { return P.c.rng_mode == AIE_RNG_FAST; }
+// one list of the regeneration's source doubles for the whole batch (aie_layout.h: aie__shared_src_list, a_src_list)
+__host__ __device__ inline bool shared_src_list(const aie_params& P) {
+#ifdef AIE_NO_SHARED_SRC_LIST  // (A/B builds)
+  return false;
+#endif
+  return P.c.scenario == AIE_SCN_GTB && P.c.shared_layout && P.c.layout_gen == AIE_LAYOUT_FIXED;
+}
 __host__ __device__ inline int rec_lds_bytes(const aie_params& P) { return P.o_mt + (rng_fast(P) ? 16 : 0); }
 
 // staging area: the components' draw window (the next tempered MT19937 words, see MTL) and the small
@@ -368,7 +375,7 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
     const uint4 v = src[q];
     dst[q] = v;
     const int cell0 = 4 * q - (c.P.o_cells >> 2);
-    if (cell0 >= 0 && cell0 < HW) {
+    if (!shared_src_list(c.P) && cell0 >= 0 && cell0 < HW) {  // (shared fixed layouts: the batch's one list, a_src_list)
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1882,7 +1889,32 @@ __device__ __forceinline__ uint32_t mt_window_word(const MT& m, int idx) {
   }
   return v;
 }
-__device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
+// The source doubles of this replica: the LDS list load_record collected, or -- fixed layouts shared by the batch -- the
+// caller's registers (entry k * 64 + lane of aie_params.a_src_list, fetched while the components ran) and their count.
+struct SrcList {
+  int S;                            // number of source doubles (may exceed AIE_SRC_CAP: row-by-row regeneration)
+  int d[AIE_SRC_CAP / AIE_NT];      // this lane's entries
+};
+__device__ __forceinline__ SrcList src_list_from_lds(const Ctx& c) {
+  SrcList L;
+  L.S = uni(*c.srcn);
+#pragma unroll
+  for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
+    const int j = k * AIE_NT + c.tid;
+    L.d[k] = (j < L.S && j < AIE_SRC_CAP) ? (int)c.srcl[j] : 0;
+  }
+  return L;
+}
+__device__ __forceinline__ SrcList src_list_from_arena(const Ctx& c, const uint8_t* __restrict__ arena) {
+  SrcList L;
+  const uint8_t* g = arena + c.R.a_src_list;
+  L.S = uni(*reinterpret_cast<const int32_t*>(g));
+  const uint16_t* lst = reinterpret_cast<const uint16_t*>(g + 16);
+#pragma unroll
+  for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) L.d[k] = (int)lst[k * AIE_NT + c.tid];  // (entries past the count are zero)
+  return L;
+}
+__device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, const SrcList& src) {
   if (c.full && c.snap) {  // P.regen_general: the planes the reference convolves, before any of this step's respawns
     const int HW = c.P.HW, stride = (HW + 15) / 16 * 16;
     const uint8_t* cb = reinterpret_cast<const uint8_t*>(R_CELLS(c));
@@ -1894,7 +1926,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
     }
     AIE_WSYNC();
   }
-  const int S = uni(*c.srcn);
+  const int S = src.S;
   if (S > AIE_SRC_CAP) {
     if (m.fast && m.pos < AIE_MT_N) mt_fast_rows(m, c.tid);  // (the counter stream keeps no rows between steps)
     scenario_step_regen_rows(c, m);
@@ -1912,7 +1944,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
       if (k >= nchunk) continue;
       const int j = k * AIE_NT + lane;
-      const int d = j < S ? (int)c.srcl[j] : 0;
+      const int d = j < S ? src.d[k] : 0;
       const int h = (pos0 >> 1) + d;  // pair that holds word pos0 + 2 d
       uint32_t a0, a1, b0 = 0, b1 = 0;
       fast_pair(m.fkey, m.fblk, m.fsalt, h, a0, a1);
@@ -1930,7 +1962,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m) {
 #pragma unroll
   for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
     const int j = k * AIE_NT + lane;
-    off_a[k] = (k < nchunk && j < S) ? pos0 + 2 * (int)c.srcl[j] : -16;  // stream offset of word A
+    off_a[k] = (k < nchunk && j < S) ? pos0 + 2 * src.d[k] : -16;  // stream offset of word A
     wa[k] = wb[k] = 0;
   }
   const int last_win = (pos0 + total - 1) / AIE_MT_N;
@@ -2643,6 +2675,11 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   const bool FAST = rng_fast(P);  // the counter stream (include/aie.h: AIE_RNG_FAST); compile-time in the instances
   Agents A;
   if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x] = wall_clock64();
+  const bool SHL = shared_src_list(P);  // one list of source doubles for the whole batch (a_src_list)
+  SrcList src;
+  src.S = 0;
+#pragma unroll
+  for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) src.d[k] = 0;
   if (threadIdx.x == 0) {
     *c.srcn = 0;
     c.dirty[0] = 0;
@@ -2719,6 +2756,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   } else {
     // the second wave has nothing to do until the components are done: the generator state for the regeneration
     // (rows -> registers, the loads go out first; re-read below if the components twisted it) ...
+    if (SHL) src = src_list_from_arena(c, arena);  // (the loads ride under the first wave's dynamics)
     if (!FAST) {
       const uint32_t* key = gkey;
 #pragma unroll
@@ -2768,7 +2806,8 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       mt_rows_from_hbm(m, gkey, c.tid);
     }
     m.pos = uni(*R_I32(c, o_mt_pos));
-    if (!(skip & 2)) scenario_step_regen(c, m);
+    if (!SHL) src = src_list_from_lds(c);
+    if (!(skip & 2)) scenario_step_regen(c, m, src);
     if (c.tid == 0) {
       *R_I32(c, o_mt_pos) = m.pos;
       if (FAST) R_U32(c, o_mt)[1] = m.fblk;
@@ -3678,6 +3717,90 @@ extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, 
     }
   }
   *dst = chosen;
+}
+
+// Categorical sampling from the caller's policy logits under the current action masks (include/aie.h:
+// aie_sample_policy_actions): Gumbel-max, entry k of a slot scores logit_k - log(-log(u_k)) with u_k from the counter
+// RNG keyed (seed, global replica, the replica's draw index t, slot, k); the allowed entry with the highest score wins
+// (lowest index on ties; NaN logits count as masked; nothing allowed: NO-OP).  Scores are float64 and the logarithm is
+// libm's bit for bit (aie_glibc_math.h), so the CPU restatement picks the same entries.  One workgroup of four waves per
+// replica: a wave takes every fourth slot, a lane every 64th entry of it; thread 0 advances the draw index behind a
+// barrier -- one launch, nothing by value from a host counter (replayable from a hipGraph).
+extern "C" __global__ void __launch_bounds__(256)
+aie_sample_policy_actions_kernel(const aie_params P, uint8_t* __restrict__ arena, const float* __restrict__ logits_a,
+                                 const float* __restrict__ logits_p, uint64_t seed, int64_t env_offset,
+                                 int32_t* __restrict__ act_a, int32_t* __restrict__ act_p) {
+  const int e = (int)blockIdx.x;
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  const int na = P.n * P.act_a_width, per_env = na + P.act_p_width;
+  int32_t* tfield = reinterpret_cast<int32_t*>(arena + P.a_records + (int64_t)e * P.rec_bytes + P.o_sample_t);
+  const int64_t t = aie::uni(*tfield);
+  const bool covid = P.c.scenario == AIE_SCN_COVID;
+  const int wa = covid ? 1 + P.cv_NL : P.MA;  // logits per agent, in the mask's own (flattened) layout
+  for (int j = wave; j < per_env; j += 4) {
+    const float* mask;
+    const float* lg;
+    int lo, len, stride = 1;
+    int32_t* dst;
+    if (j < na) {
+      if (!act_a || !logits_a) continue;
+      const int i = j / P.act_a_width, s = j - i * P.act_a_width;
+      if (covid) {
+        mask = reinterpret_cast<const float*>(arena + P.a_cv_obs_a) + ((int64_t)e * P.cv_nrow_obs + AIE_CV_OB_MASK) * P.n + i;
+        stride = P.n;
+      } else {
+        mask = reinterpret_cast<const float*>(arena + P.a_obs_a_mask) + ((int64_t)e * P.n + i) * P.MA;
+      }
+      lg = logits_a + ((int64_t)e * P.n + i) * wa;
+      if (P.c.multi_action_mode_agents) {
+        lo = 0;
+        for (int k = 0; k < s; ++k) lo += 1 + P.sub_a_dim[k];
+        len = P.n_sub_a ? 1 + P.sub_a_dim[s] : 1;
+      } else {
+        lo = 0;
+        len = wa;
+      }
+      dst = act_a + (int64_t)e * na + j;
+    } else {
+      if (!act_p || !logits_p) continue;
+      const int s = j - na;
+      if (covid) mask = reinterpret_cast<const float*>(arena + P.a_cv_obs_p) + (int64_t)e * (4 + P.MP) + 4;
+      else mask = reinterpret_cast<const float*>(arena + P.a_obs_p_mask) + (int64_t)e * P.MP;
+      lg = logits_p + (int64_t)e * P.MP;
+      if (P.c.multi_action_mode_planner) {
+        lo = s * (1 + P.sub_p_dim);
+        len = P.n_sub_p ? 1 + P.sub_p_dim : 1;
+      } else {
+        lo = 0;
+        len = P.MP;
+      }
+      dst = act_p + (int64_t)e * P.act_p_width + s;
+    }
+    double best = 0.0;
+    int best_k = -1;  // (-1: nothing allowed so far)
+    for (int k = lane; k < len; k += 64) {
+      const float x = lg[lo + k];
+      if (!(mask[(lo + k) * stride] > 0.5f) || x != x) continue;
+      const uint32_t r = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)per_env + (uint64_t)j * 2048ull + (uint64_t)k);
+      const double u = ((double)r + 0.5) * (1.0 / 4294967296.0);
+      const double sc = (double)x - aie_log_glibc(-aie_log_glibc(u));
+      if (best_k < 0 || sc > best) {  // (k ascends within a lane: a tie keeps the lower index)
+        best = sc;
+        best_k = k;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ob = __shfl_xor(best, off, 64);
+      const int ok = __shfl_xor(best_k, off, 64);
+      const bool take = ok >= 0 && (best_k < 0 || ob > best || (ob == best && ok < best_k));
+      best = take ? ob : best;
+      best_k = take ? ok : best_k;
+    }
+    if (lane == 0) *dst = best_k < 0 ? 0 : best_k;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *tfield = (int32_t)t + 1;
 }
 #endif  // !AIE_JIT
 

@@ -135,6 +135,11 @@ typedef struct aie_params {
   int32_t saez_global_cap, saez_pad_;
   int64_t a_layout_prob; /* shared f64 [AIE_N_RES][H*W]: source probability maps of the generated layouts (layout_gen
                           * UNIFORM / QUADRANT: uploaded once by the host, tensor "layout_source_prob") */
+  int64_t a_src_list;    /* shared, fixed layouts with shared_layout only (aie__shared_src_list): int32 count (16 B), then
+                          * uint16 [AIE_SRC_CAP]: the regeneration draws that target a source block (double d of a step's
+                          * 2 H W np.random.rand values: Wood cell d, or Stone cell d - H W), derived once by
+                          * aie_set_layout instead of by every step from the cells' flag bytes; count > AIE_SRC_CAP: no
+                          * list (row-by-row regeneration) */
   int32_t o_tax_saez_rates; /* record: f64 [NB] curr_bracket_tax_rates */
   int32_t o_tax_saez_obs_rates; /* record: f64 [NB] _curr_rates_obs: the rates the "curr_rates" observation shows,
                                    refreshed at period starts and -- BEFORE the running average replaces the
@@ -247,6 +252,7 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->a_cv_events = p->a_cv_ev0 = 0;
   p->a_cv_replay_a = p->a_cv_replay_p = p->a_cv_replay_state = 0;
   p->a_layout_prob = 0;
+  p->a_src_list = 0;
   p->dev_skip_mask = 0;
   p->dev_trace = 0;
   p->dev_draw_window = 0;
@@ -308,6 +314,13 @@ static inline int aie__has(const aie_config* c, int comp) {
     return AIE_E_INVALID;                                \
   } while (0)
 
+/* source-block doubles the sparse regeneration handles (else: row-by-row) */
+#define AIE_SRC_CAP 128
+/* One list of the regeneration's source doubles for the whole batch (aie_params.a_src_list): every replica has the same,
+ * never-changing source blocks */
+static inline int aie__shared_src_list(const aie_config* c) {
+  return c->scenario == AIE_SCN_GTB && c->shared_layout && c->layout_gen == AIE_LAYOUT_FIXED;
+}
 /* words of generator state in a replica's record ("mt"): MT19937's key, or (key32, block number, salt, 0) of the
  * counter stream (include/aie.h: AIE_RNG_FAST) */
 static inline int32_t aie__rng_state_words(const aie_config* c) { return c->rng_mode == AIE_RNG_FAST ? 4 : AIE_MT_N; }
@@ -396,6 +409,11 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   if (v->filter_len < 1 || v->filter_len > 65536) AIE__FAIL("filter_len out of range");
   if (v->num_filters < 1 || v->num_filters > AIE_COVID_MAX_FILTERS) AIE__FAIL("num_filters out of range");
   if (v->filter_len < v->beta_delay) AIE__FAIL("filter_len < beta_delay is not supported");
+  /* the window sums keep a state's level changes as events `history day | delta << 16` (aie_kernels_covid.hip): the day
+   * index runs to filter_len + episode_length and must fit 16 bits (the reference has no such bound) */
+  if (!v->filter_recurrence && (int64_t)v->filter_len + (int64_t)c->episode_length > 65535)
+    AIE__FAIL("filter_len + episode_length = %lld: the reference-exact window sums index history days with 16 bits "
+              "(<= 65535); use filter_recurrence or a shorter episode", (long long)v->filter_len + c->episode_length);
   if (v->action_cooldown_period < 1) AIE__FAIL("action_cooldown_period must be >= 1 (covid19_components.py:57)");
   if (v->subsidy_interval < 1) AIE__FAIL("subsidy_interval must be >= 1 (covid19_components.py:278)");
   if (v->num_subsidy_levels < 1 || v->num_subsidy_levels > 255) AIE__FAIL("num_subsidy_levels out of range");
@@ -1153,6 +1171,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   aie__alloc_saez(c, p, &a);
   p->a_layout_prob = a;
   if (c->layout_gen != AIE_LAYOUT_FIXED) a = aie__align(a + (int64_t)AIE_N_RES * HW * 8, 256);
+  p->a_src_list = a;
+  if (aie__shared_src_list(c)) a = aie__align(a + 16 + 2 * AIE_SRC_CAP, 256);
   p->arena_bytes = a;
 
   /* ---- tensor table ------------------------------------------------------------ */

@@ -245,6 +245,25 @@ class DeviceBackend:
             C.c_void_p(a.data_ptr()), C.c_void_p(p.data_ptr()), self._stream()))
         return a, p
 
+    def sample_policy_actions(self, logits_a, logits_p, seed, env_offset=0, slot=0, out=None):
+        """Categorical sampling from the caller's policy logits under the current action masks (aie_sample_policy_actions:
+        Gumbel-max in one launch, replayable from a captured graph).  logits_a: float32 [E, n, MA] in the layout of the
+        agents' flattened action mask (COVID: [E, n, 1 + levels]), logits_p: float32 [E, MP]; either may be None.
+        Returns the action buffers (int32 [E, n, width], [E, width_p]) -- `out=(a, p)` to fill the caller's own."""
+        torch = _torch()
+        a, p = out if out is not None else self._action_buffers(slot)
+        la = lp = None
+        if logits_a is not None:
+            per_agent = self.tensors["obs_a_action_mask"].numel() // (self.E * self.n)
+            la = self._ptr(logits_a, torch.float32, "logits_a", self.E * self.n * per_agent)
+        if logits_p is not None:
+            lp = self._ptr(logits_p, torch.float32, "logits_p", self.tensors["obs_p_action_mask"].numel())
+        self._check(self.lib.aie_sample_policy_actions(
+            self.handle, la, lp, C.c_uint64(seed), C.c_int64(env_offset),
+            C.c_void_p(a.data_ptr()) if logits_a is not None else None,
+            C.c_void_p(p.data_ptr()) if logits_p is not None else None, self._stream()))
+        return a, p
+
     def _action_buffers(self, slot):
         torch = _torch()
         if self._rand_a is None:
@@ -323,6 +342,12 @@ class DeviceBackend:
             fl = (np.asarray(state["water"], np.uint8) + 2 * np.asarray(state["stone_src"], np.uint8)
                   + 4 * np.asarray(state["wood_src"], np.uint8)).astype(np.uint8)
             src = torch.as_tensor(fl, device=self.device)
+            if self.cfg.shared_layout and self.cfg.layout_gen == _cabi.LAYOUT_FIXED:
+                # one source layout for the whole batch (the regeneration's source list is derived from it once,
+                # aie_set_layout): a state that carries another layout cannot be injected into some replicas only
+                if not bool((self.tensors["cell_flags"][0 if e is None else e] == src).all()):
+                    raise ValueError("load_state: the state's source / water planes differ from the environment's shared "
+                                     "layout (shared_layout=1): create the environment with that layout")
             if e is None:
                 self.tensors["cell_flags"][...] = src
             else:

@@ -74,11 +74,14 @@ class GraphedStep:
 class MaskedMLPPolicy:
     """A small policy network of the shape the reference's trainers use on the flat observations (fully connected
     trunk, one categorical head per action subspace, `action_mask` applied to the logits: base_env.py:141-145,
-    tutorials/rllib/env_wrapper.py:50-211) with random-init weights: enough to put a real policy's launches --
-    GEMMs, masking, sampling -- between the environment steps.  Sampling is Gumbel-max with noise from a device-side
-    counter hash (deterministic, capture-safe, identical eager and replayed)."""
+    tutorials/rllib/env_wrapper.py:50-211) with random-init weights: enough to put a real policy's launches between the
+    environment steps.  The network is torch (three GEMMs with fused bias per actor class, two ReLUs); masking and
+    sampling -- what every trainer does with its logits -- is ONE launch of the library (aie_sample_policy_actions:
+    Gumbel-max under the action masks, float64 scores, the draw index a record field, so the loop can be captured).
+    `sampler="torch"` keeps the round-4 formulation (Gumbel noise, masked_fill and argmax as ~15 elementwise launches per
+    actor class) for comparison."""
 
-    def __init__(self, be, hidden=128, seed=0, dtype=None):
+    def __init__(self, be, hidden=128, seed=0, dtype=None, sampler="library", sample_seed=1234):
         import torch
 
         self.torch = torch
@@ -107,11 +110,15 @@ class MaskedMLPPolicy:
         self.multi_a = bool(cfg.multi_action_mode_agents)
         self.multi_p = bool(cfg.multi_action_mode_planner)
         self.p_width = be._act_p_width()
-        if self.multi_a:
-            raise NotImplementedError("MaskedMLPPolicy: single-action agents (the BASELINE configurations)")
+        assert sampler in ("library", "torch")
+        self.sampler = sampler
+        self.sample_seed = int(sample_seed)
+        if self.multi_a and sampler == "torch":
+            raise NotImplementedError("MaskedMLPPolicy(sampler='torch'): single-action agents (the BASELINE configurations)")
         self.counter = torch.zeros((), dtype=torch.float32, device=dev)
-        self.idx_a = torch.arange(be.E * be.n * MA, device=dev, dtype=torch.float32).view(be.E, be.n, MA)
-        self.idx_p = torch.arange(be.E * MP, device=dev, dtype=torch.float32).view(be.E, MP)
+        if sampler == "torch":
+            self.idx_a = torch.arange(be.E * be.n * MA, device=dev, dtype=torch.float32).view(be.E, be.n, MA)
+            self.idx_p = torch.arange(be.E * MP, device=dev, dtype=torch.float32).view(be.E, MP)
 
     def _gumbel(self, idx, salt):
         torch = self.torch
@@ -119,19 +126,28 @@ class MaskedMLPPolicy:
         u = u.clamp_(1e-6, 1.0 - 1e-6)
         return -torch.log(-torch.log(u))
 
+    def logits(self, tensors):
+        """(agents' logits [E * n, MA], planner's logits [E, MP]) in the layout of the flattened action masks."""
+        torch = self.torch
+        xa = tensors["obs_a_flat"].to(self.dtype).reshape(-1, self.wa1.shape[0])
+        h = torch.addmm(self.ba1, xa, self.wa1).relu_()
+        h = torch.addmm(self.ba2, h, self.wa2).relu_()
+        la = torch.addmm(self.ba3, h, self.wa3).float()
+        xp = tensors["obs_p_flat"].to(self.dtype)
+        h = torch.addmm(self.bp1, xp, self.wp1).relu_()
+        h = torch.addmm(self.bp2, h, self.wp2).relu_()
+        lp = torch.addmm(self.bp3, h, self.wp3).float()
+        return la, lp
+
     def __call__(self, tensors, actions_a, actions_p):
         torch = self.torch
-        xa = tensors["obs_a_flat"].to(self.dtype)
-        h = torch.relu(xa @ self.wa1 + self.ba1)
-        h = torch.relu(h @ self.wa2 + self.ba2)
-        la = (h @ self.wa3 + self.ba3).float()
-        la = la + self._gumbel(self.idx_a, 0.0)
+        la, lp = self.logits(tensors)
+        if self.sampler == "library":
+            self.be.sample_policy_actions(la, lp, self.sample_seed, out=(actions_a, actions_p))
+            return
+        la = la.view(self.be.E, self.be.n, self.MA) + self._gumbel(self.idx_a, 0.0)
         la = la.masked_fill(tensors["obs_a_action_mask"] < 0.5, -1e30)
         actions_a.view(self.be.E, self.be.n).copy_(la.argmax(-1))
-        xp = tensors["obs_p_flat"].to(self.dtype)
-        h = torch.relu(xp @ self.wp1 + self.bp1)
-        h = torch.relu(h @ self.wp2 + self.bp2)
-        lp = (h @ self.wp3 + self.bp3).float()
         lp = lp + self._gumbel(self.idx_p, 0.5)
         lp = lp.masked_fill(tensors["obs_p_action_mask"] < 0.5, -1e30)
         if self.multi_p and self.p_width > 1:  # one categorical head per bracket: [E, width, 1 + rates]

@@ -786,6 +786,8 @@ def compact_line(out):
     line["gpu_region_seconds"] = out["gpu_region_seconds"]
     if out["n_gpus"] > 1 or out.get("gather"):
         line["per_rank_seconds"] = out["per_rank_seconds"]
+        # kernel time per rank beside the wall time per rank: what separates the step launches from the gather's wait
+        line["per_rank_avg_launch_ms"] = out.get("per_rank_avg_launch_ms")
         line["gather"] = out.get("gather")
     cb = out.get("cpu_baseline")
     if cb:
@@ -935,15 +937,18 @@ def c5_fresh_process(trials=3, piece_mb=None):
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "C5", "--steps", "60", "--warmup",
                                   "20", "--no-cpu-baseline", "--no-workloads", "--detail-file", os.devnull],
                                  capture_output=True, text=True, timeout=300, env=env).stdout
-            d = json.loads(out.strip().splitlines()[-1])
-            res.append(d["roofline"]["avg_launch_ms"])
+            lines = out.strip().splitlines()
+            d = json.loads(lines[-2])  # (the full result; the compact driver line follows it)
+            res.append((d["roofline"]["avg_launch_ms"], d["roofline"].get("arena_piece_mib")))
         except Exception:
             pass
     if not res:
         return None
     res.sort()
-    return {"avg_launch_ms": res[len(res) // 2], "min": res[0], "max": res[-1], "trials": len(res),
-            "piece_mib": piece_mb if piece_mb is not None else int(os.environ.get("AIE_ARENA_PIECE_MB", "64"))}
+    # piece_mib: what each process's arena was mapped with -- forced (piece_mb) or what the library's store probe chose
+    # at aie_create (csrc/aie_capi.hip: aie_arena_alloc)
+    return {"avg_launch_ms": res[len(res) // 2][0], "min": res[0][0], "max": res[-1][0], "trials": len(res),
+            "piece_mib": [r[1] for r in res], "piece_forced": piece_mb is not None}
 
 
 def main():
@@ -1040,7 +1045,7 @@ def main():
                 if fresh:
                     sides["C5"]["fresh_process"] = fresh
                     if fresh["avg_launch_ms"] >= 1.55:
-                        alts = {mb: c5_fresh_process(1, piece_mb=mb) for mb in (16, 128)}
+                        alts = {mb: c5_fresh_process(1, piece_mb=mb) for mb in (16, 64, 128)}
                         sides["C5"]["fresh_process_other_piece_sizes"] = alts
             out["workloads"] = sides
         if not args.no_cpu_baseline and world == 1:

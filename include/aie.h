@@ -371,7 +371,10 @@ int aie_download(aie_env* env, const char* name, void* host, int64_t bytes);
 
 /* Source-block / water planes (HOST pointers, u8 [H*W] each; with shared_layout=1 one
  * replica's planes which are broadcast, else E of them).  They are packed into the
- * static flag byte of every map cell (layout_from_file.py:103-112, 323-334). */
+ * static flag byte of every map cell (layout_from_file.py:103-112, 323-334).  With shared_layout=1 (fixed layouts) the
+ * call also derives the batch's one list of regeneration draws that target a source block (the step kernels read it
+ * instead of scanning the flag bytes every step): change such a layout through this call, not by writing the
+ * `cell_flags` tensor. */
 int aie_set_layout(aie_env* env, const uint8_t* stone_src, const uint8_t* wood_src,
                    const uint8_t* water);
 
@@ -446,7 +449,9 @@ int aie_set_global_saez_buffer(aie_env* env, const double* d_pairs, int64_t n_pa
  * `dense_log_frequency`-th episode is logged): with on == 0 the dense-log replicas stop recording AIE_EV_* rows and
  * step with the rest of the batch on the environment's fast kernel; with on != 0 (the default) they -- and only they
  * -- take the full-featured kernel.  State and observations are bit-identical either way; the host mirror switches
- * it per episode (foundation/base_env.py: reset). */
+ * it per episode (foundation/base_env.py: reset).  Gather-trade-build only: the one-step-economy kernel records its
+ * (few) events for the dense-log replicas regardless of this switch -- there is no separate full-featured kernel to
+ * leave -- and COVID has no event rows. */
 int aie_set_dense_log_active(aie_env* env, int on);
 
 /* Where the arena lives: *bytes = its size, *allocator = AIE_ARENA_CALLER (passed to aie_create), AIE_ARENA_HIPMALLOC
@@ -490,6 +495,21 @@ int aie_select_step_kernel(aie_env* env, int which);
  * episode is being logged, aie_set_dense_log_active). */
 #define AIE_KERNEL_INSTANCE_JIT 1000
 int aie_specialize(aie_env* env);
+
+/* Categorical sampling from the CALLER's policy logits under the current action masks (the step a trainer
+ * performs between two env steps -- the reference's trainers apply `action_mask` to the logits and sample,
+ * base_env.py:141-145, tutorials/rllib/env_wrapper.py:50-211, training_script.py:88-133).
+ *   d_logits_a  float32 [E, n, MA]  in the layout of obs_a_action_mask (single-action agents: one row of MA entries,
+ *               entry 0 = NO-OP; multi-action: the subspaces' (1 + dim) entries back to back; COVID: [E, n, 1 + levels])
+ *   d_logits_p  float32 [E, MP]     in the layout of obs_p_action_mask
+ * Sub-action = argmax over the allowed entries k of logit_k - log(-log(u_k)) (Gumbel-max: a draw from softmax(logits)
+ * restricted to the mask), u_k from the counter RNG keyed (seed, global env id, the replica's draw index, slot, k); ties
+ * take the lower index, NaN logits count as masked, NO-OP if nothing is allowed.  Scores are float64 with libm's log bit
+ * for bit, so the CPU restatement (oracle/: aie_oracle_sample_policy_actions) picks the same entries.  One launch; the
+ * draw index is the replica's record field `sample_t`, advanced by the kernel (replayable from a hipGraph).  Either pair
+ * (logits, actions) may be NULL. */
+int aie_sample_policy_actions(aie_env* env, const float* d_logits_a, const float* d_logits_p, uint64_t seed,
+                              int64_t global_env_offset, int32_t* d_actions_a, int32_t* d_actions_p, void* stream);
 
 /* Same counter RNG, but each sub-action is drawn uniformly among the entries that the
  * CURRENT action masks allow (obs_a_action_mask / obs_p_action_mask; NO-OP is always

@@ -1845,6 +1845,62 @@ void aie_oracle_seed64(const aie_params* p, uint8_t* arena, uint64_t base_seed) 
   }
 }
 void aie_oracle_seed(const aie_params* p, uint8_t* arena, uint32_t base_seed) { aie_oracle_seed64(p, arena, (uint64_t)base_seed); }
+/* aie_sample_policy_actions (include/aie.h) restated: Gumbel-max over the allowed entries of every action slot, float64
+ * scores logit - log(-log(u)) with libm's log, u from the counter RNG keyed (seed, global replica, draw index, slot, k);
+ * ties take the lower index, NaN logits count as masked, NO-OP if nothing is allowed; advances `sample_t`.  Not part of
+ * the reference (its trainers sample in their own framework, training_script.py:88-133): this pins the PRODUCT's
+ * sampler.  Gather-trade-build and one-step-economy layouts (COVID's collated masks: covid_oracle.py). */
+void aie_oracle_sample_policy_actions(const aie_params* p, uint8_t* arena, const float* logits_a, const float* logits_p,
+                                      uint64_t seed, int64_t env_offset, int32_t* act_a, int32_t* act_p) {
+  const int na = p->n * p->act_a_width, per_env = na + p->act_p_width;
+  for (int e = 0; e < p->E; ++e) {
+    int32_t* tf = (int32_t*)(arena + p->a_records + (int64_t)e * p->rec_bytes + p->o_sample_t);
+    const int64_t t = *tf;
+    for (int j = 0; j < per_env; ++j) {
+      const float *mask, *lg;
+      int lo = 0, len;
+      int32_t* dst;
+      if (j < na) {
+        if (!act_a || !logits_a) continue;
+        const int i = j / p->act_a_width, s = j - i * p->act_a_width;
+        mask = (const float*)(arena + p->a_obs_a_mask) + ((int64_t)e * p->n + i) * p->MA;
+        lg = logits_a + ((int64_t)e * p->n + i) * p->MA;
+        if (p->c.multi_action_mode_agents) {
+          for (int k = 0; k < s; ++k) lo += 1 + p->sub_a_dim[k];
+          len = p->n_sub_a ? 1 + p->sub_a_dim[s] : 1;
+        } else {
+          len = p->MA;
+        }
+        dst = act_a + (int64_t)e * na + j;
+      } else {
+        if (!act_p || !logits_p) continue;
+        const int s = j - na;
+        mask = (const float*)(arena + p->a_obs_p_mask) + (int64_t)e * p->MP;
+        lg = logits_p + (int64_t)e * p->MP;
+        if (p->c.multi_action_mode_planner) {
+          lo = s * (1 + p->sub_p_dim);
+          len = p->n_sub_p ? 1 + p->sub_p_dim : 1;
+        } else {
+          len = p->MP;
+        }
+        dst = act_p + (int64_t)e * p->act_p_width + s;
+      }
+      double best = 0.0;
+      int best_k = -1;
+      for (int k = 0; k < len; ++k) {
+        const float x = lg[lo + k];
+        if (!(mask[lo + k] > 0.5f) || x != x) continue;
+        const uint32_t r = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t,
+                                           (uint64_t)per_env + (uint64_t)j * 2048ull + (uint64_t)k);
+        const double u = ((double)r + 0.5) * (1.0 / 4294967296.0);
+        const double sc = (double)x - log(-log(u));
+        if (best_k < 0 || sc > best) { best = sc; best_k = k; }
+      }
+      *dst = best_k < 0 ? 0 : best_k;
+    }
+    *tf = (int32_t)t + 1;
+  }
+}
 /* multi-threaded step for the cpu_baseline leg of bench.py */
 void aie_oracle_step_mt(const aie_params* p, uint8_t* arena, const int32_t* aa, const int32_t* ap, int nthreads) {
   int E = p->E;

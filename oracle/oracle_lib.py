@@ -54,6 +54,8 @@ def lib():
         L.aie_oracle_seed64.restype = None
         L.aie_oracle_philox2x32_10.argtypes = [vp, C.c_uint32, vp]
         L.aie_oracle_philox2x32_10.restype = None
+        L.aie_oracle_sample_policy_actions.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int64, vp, vp]
+        L.aie_oracle_sample_policy_actions.restype = None
         _LIB = L
     return _LIB
 
@@ -140,6 +142,17 @@ class OracleEnv:
 
     def seed(self, base_seed):
         lib().aie_oracle_seed64(self._params, self.arena.ctypes.data, base_seed)  # (rng_mode "numpy": the low 32 bits)
+
+    def sample_policy_actions(self, logits_a, logits_p, seed, env_offset=0, width_a=1, width_p=1):
+        """aie_sample_policy_actions on this arena's masks: (actions_a int32 [E, n, width_a], actions_p int32 [E, width_p];
+        the widths are the action buffers' -- sub-actions per agent / planner)."""
+        la = np.ascontiguousarray(logits_a, np.float32)
+        lp = np.ascontiguousarray(logits_p, np.float32)
+        a = np.zeros((self.E, self.n, int(width_a)), np.int32)
+        p = np.zeros((self.E, int(width_p)), np.int32)
+        lib().aie_oracle_sample_policy_actions(self._params, self.arena.ctypes.data, la.ctypes.data, lp.ctypes.data, seed,
+                                               env_offset, a.ctypes.data, p.ctypes.data)
+        return a, p
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8).ctypes.data

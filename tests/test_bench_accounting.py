@@ -77,7 +77,7 @@ def _synthetic_full_result(n_gpus=1, long_strings=400):
     out = dict(metric="agent-steps/sec, " + "m" * 60, value=6.22123456e8, unit="agent-steps/s", n_gpus=n_gpus, steps=2000,
                warmup=200, ms_per_step=0.0263123456, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="u8/i32 state + f64 coin/utility (f32 observations)", data="synthetic", config=cfg,
-               per_rank_seconds=[0.0526123456] * n_gpus, host_issue_seconds=0.05, gpu_region_seconds=0.0521234,
+               per_rank_seconds=[0.0526123456] * n_gpus, per_rank_avg_launch_ms=[0.0248123456] * n_gpus, host_issue_seconds=0.05, gpu_region_seconds=0.0521234,
                exchange_ok=True, roofline=roof, cpu_baseline=cpu,
                cpu_port=dict(value=3.8e6, unit="agent-steps/s", cores=256, kind="port", sample=prose),
                gather=dict(collectives=32, bytes_per_collective=6291456, wait_seconds=0.00123456))
@@ -113,6 +113,7 @@ def test_driver_line_stays_under_4_kb_and_keeps_the_contract(n_gpus):
         assert line["workloads"][name]["cpu_ref"] == pytest.approx(134418.12, rel=1e-4)
     if n_gpus > 1:
         assert len(line["per_rank_seconds"]) == n_gpus and line["gather"]["collectives"] == 32
+        assert len(line["per_rank_avg_launch_ms"]) == n_gpus
 
 
 def test_emit_prints_the_compact_line_last(tmp_path, capsys):

@@ -1249,6 +1249,63 @@ def _graph_env(cfg, E, seed, reward_log):
     return env, log
 
 
+@pytest.mark.parametrize("case", ["gtb_c2", "gtb_multi_action", "one_step_economy"])
+def test_policy_sampler_equals_its_cpu_restatement(case):
+    """aie_sample_policy_actions (Gumbel-max over the caller's logits under the action masks, one launch) against
+    oracle/'s restatement: the same sub-action in every slot of every replica, over steps whose masks change (inventory-
+    dependent trades, the planner's tax days), with NaN logits, ties and fully masked rows thrown in; the draw index
+    advances once per call."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    if case == "one_step_economy":
+        cfg = _auto_reset_cases()["one_step_economy"]
+    else:
+        cfg = dict(C2, episode_length=30, multi_action_mode_agents=(case == "gtb_multi_action"),
+                   multi_action_mode_planner=(case != "gtb_multi_action"))
+    E = 64
+    env = make_env(cfg, n_envs=E, device="cuda:0", env_offset=1000)
+    env.seed(3)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(3 + 1000)
+    oracle.reset()
+    a_buf, p_buf = be._action_buffers(0)
+    MA, MP = be.tensors["obs_a_action_mask"].shape[-1], be.tensors["obs_p_action_mask"].shape[-1]
+    g = torch.Generator(device="cpu").manual_seed(11)
+    seen = set()
+    for t in range(36):
+        la = (torch.randn(E, be.n, MA, generator=g) * 3).float()
+        lp = (torch.randn(E, MP, generator=g) * 3).float()
+        la[t % E, 0, 1:4] = float("nan")           # NaN logits are masked entries
+        la[(t + 1) % E, 1, :] = 0.25                # all-equal logits: the noise alone decides
+        lp[(t + 2) % E, :] = -1e30                  # hopeless logits still yield an allowed entry
+        la[(t + 3) % E, 2, :] = float("nan")        # a fully NaN row: NO-OP
+        a, p = be.sample_policy_actions(la.to("cuda:0"), lp.to("cuda:0"), seed=77, env_offset=1000)
+        torch.cuda.synchronize()
+        assert np.array_equal(be.tensors["obs_a_action_mask"].cpu().numpy(), oracle.t["obs_a_action_mask"])
+        wa, wp = oracle.sample_policy_actions(la.numpy(), lp.numpy(), 77, 1000, width_a=a.shape[-1], width_p=p.shape[-1])
+        assert np.array_equal(a.cpu().numpy(), wa), "step %d: agents' sub-actions differ" % t
+        assert np.array_equal(p.cpu().numpy(), wp), "step %d: planner's sub-actions differ" % t
+        assert np.array_equal(be.tensors["sample_t"].cpu().numpy(), oracle.t["sample_t"]) and int(oracle.t["sample_t"][0]) == t + 1
+        assert (wa[(t + 3) % E, 2] == 0).all()
+        seen.update(np.unique(wa).tolist())
+        env.step({"a": a, "p": p})
+        oracle.step(wa.reshape(E, -1), wp, nthreads=4)
+        if (t + 1) % int(cfg["episode_length"]) == 0:
+            env.reset(be.tensors["done"])
+            oracle.reset(oracle.t["done"].copy())
+    assert int(be.tensors["error_flags"].abs().sum()) == 0  # every choice was an allowed one
+    assert len(seen) > 5
+    # NULL pairs: only the planner / only the agents
+    before = a.clone()
+    be._check(be.lib.aie_sample_policy_actions(be.handle, None, lp.to("cuda:0").data_ptr(), 77, 1000, None, p.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(a, before)
+    assert be.lib.aie_sample_policy_actions(be.handle, None, None, 77, 1000, a.data_ptr(), None, None) != 0
+
+
 @pytest.mark.parametrize("reward_log", [False, True])
 def test_step_is_hipgraph_replayable(reward_log):
     """policy -> aie_step (+ the auto-reset launch) captured ONCE on the caller's stream and replayed 64 times equals
@@ -1285,7 +1342,7 @@ def test_step_is_hipgraph_replayable(reward_log):
             oracle.t["rewards_a"][...], oracle.t["rewards_p"][...], oracle.t["done"][...] = rew_a, rew_p, done
     gs.replay(N)
     torch.cuda.synchronize()
-    assert float(pol_g.counter) == float(pol_e.counter) == WARM + N
+    assert int(be_e.tensors["sample_t"][0]) == WARM + N  # (the policy's sampler advanced the draw index once per step)
     assert torch.equal(env_g.backend.arena, be_e.arena), "replayed loop != eager loop"
     if reward_log:
         assert torch.equal(log_g, log_e)

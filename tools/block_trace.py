@@ -21,6 +21,8 @@ N_AGENTS = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 cfg = dict(bench.C2_CFG, n_agents=N_AGENTS)
 if os.environ.get("TRACE_LAYOUT_FILE"):  # e.g. uniform_25x25_25each_65clump.txt
     cfg["env_layout_file"] = os.environ["TRACE_LAYOUT_FILE"]
+if os.environ.get("TRACE_RNG_MODE"):  # "fast": the counter-based stream (C2f / C3f)
+    cfg["rng_mode"] = os.environ["TRACE_RNG_MODE"]
 env = make_env(cfg, n_envs=E, device="cuda:0")
 env.seed(1)
 env.reset()
