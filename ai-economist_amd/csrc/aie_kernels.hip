@@ -104,12 +104,15 @@ __host__ __device__ inline int fscr_doubles(const aie_params& P) { return 2 * P.
 // The LDS image of the record stops where the MT19937 key starts (it lives in VGPRs).  The counter stream's state
 // (AIE_RNG_FAST: key32, block number, salt, 0 -- 16 bytes) is part of the image.
 __host__ __device__ inline bool rng_fast(const aie_params& P) { return P.c.rng_mode == AIE_RNG_FAST; }
-// one list of the regeneration's source doubles for the whole batch (aie_layout.h: aie__shared_src_list, a_src_list)
+// One list of the regeneration's source doubles for the whole batch (aie_layout.h: aie__shared_src_list, a_src_list)
+// instead of a scan of the cells' flag bytes in every step -- used in the counter-stream mode only: A/B on one box
+// (tools/ab_variants.sh, round 5) C2f 22.35 -> 22.0 us, but C2 24.7 -> 25.4 us and C3 40.5 -> 40.7 us with MT19937, whose
+// second wave already holds the generator's ten rows while the list's registers wait for the regeneration.
 __host__ __device__ inline bool shared_src_list(const aie_params& P) {
 #ifdef AIE_NO_SHARED_SRC_LIST  // (A/B builds)
   return false;
 #endif
-  return P.c.scenario == AIE_SCN_GTB && P.c.shared_layout && P.c.layout_gen == AIE_LAYOUT_FIXED;
+  return rng_fast(P) && P.c.scenario == AIE_SCN_GTB && P.c.shared_layout && P.c.layout_gen == AIE_LAYOUT_FIXED;
 }
 __host__ __device__ inline int rec_lds_bytes(const aie_params& P) { return P.o_mt + (rng_fast(P) ? 16 : 0); }
 
@@ -2024,7 +2027,8 @@ __device__ __forceinline__ void current_metrics(const Ctx& c) {
   const int n = c.P.n, i = c.tid;
   double* coin = scr_coin(c);
   double* out = scr_part(c);
-  double* tmp = scr_cmr(c);  // free at this point
+  double* tmp = scr_gini_sort(c);  // (its own slot: only the other planner reward type sorts there, and the flat-vector
+                                   // writer -- which may run on the other wave meanwhile -- ranks incomes in scr_cmr)
   const double lcf = energy_weight(c) * c.R.c.energy_cost;
   const double eta = c.R.c.isoelastic_eta;
   if (i < n) {
@@ -2646,6 +2650,20 @@ __device__ __forceinline__ float* rew_log_claim(const NextActions& next, int32_t
   }
   return next.rew_log + (int64_t)slot * E * (n + 2);
 }
+// rewards of the step (compute_reward, layout_from_file.py:519-559), the reward log's slot, `done` and the completed-episode
+// count: one wave
+__device__ __forceinline__ void step_rewards_and_done(const aie::Ctx& c, uint8_t* __restrict__ arena, const NextActions& next, int skip) {
+  using namespace aie;
+  float* const rew_log = rew_log_claim(next, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), c.R.E, c.P.n, c.tid == 0);
+  if (!(skip & 16)) compute_rewards(c, arena, rew_log);
+  AIE_WSYNC();
+  if (c.tid == 0) {
+    const int done = *R_I32(c, o_timestep) >= c.R.c.episode_length;
+    (arena + c.R.a_done)[c.e] = (uint8_t)done;
+    if (rew_log) rew_log[(int64_t)c.e * (c.P.n + 2) + c.P.n + 1] = done ? 1.0f : 0.0f;
+    if (done) *R_I32(c, o_completions) += 1;
+  }
+}
 // SPEC >= 0: a compile-time instance (aie_spec_generated.h): P is a constant image of the parameter block of one
 // configuration -- every dimension, record offset, component list, mask table and magic divisor folds into the
 // instruction stream (no scalar loads of parameters, fully unrolled per-agent loops) -- and only what depends on
@@ -2776,20 +2794,19 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   // priority above the waves that are still loading (measured at 10 agents: 42.3 -> 41.9 us; at 4 agents any
   // priority above 0 costs 0.8-1.4 us)
   const int w0_tail_prio = P.n >= 8 ? 2 : 0;
+  // Where the rewards run.  With MT19937 the second wave's tail (four twists of regeneration, map observations, masks) is
+  // as long as the first wave's (flat vectors, rewards); with the counter stream the regeneration shrinks to a few Philox
+  // blocks and the first wave's tail is the long pole (tools/block_trace.py: 7.1 us against 3.7 us), so the rewards move
+  // behind the masks on the second wave -- up to 7 agents (A/B on one box, tools/ab_variants.sh: C2f 22.1 -> 21.7 us; with
+  // ten agents the utilities' n^2 gini terms make them the longer piece: C3f 35.3 -> 37.4 us, so they stay where they
+  // were).  They share no scratch slot with the flat-vector writer (current_metrics).
+  const bool REW_ON_W1 = FAST && NW == 2 && P.n < 8;
   if (wid == 0) {
     // first wave: flat observation vectors (they do not look at the map)
     if (w0_tail_prio) __builtin_amdgcn_s_setprio(2);
     if (!(skip & 8)) write_flat_observations(c, arena);
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
-    float* const rew_log = rew_log_claim(next, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), R.E, P.n, c.tid == 0);
-    if (!(skip & 16)) compute_rewards(c, arena, rew_log);  // utilities do not look at the map either
-    AIE_WSYNC();
-    if (c.tid == 0) {
-      const int done = *R_I32(c, o_timestep) >= R.c.episode_length;
-      (arena + c.R.a_done)[c.e] = (uint8_t)done;
-      if (rew_log) rew_log[(int64_t)c.e * (P.n + 2) + P.n + 1] = done ? 1.0f : 0.0f;
-      if (done) *R_I32(c, o_completions) += 1;
-    }
+    if (!REW_ON_W1) step_rewards_and_done(c, arena, next, skip);  // utilities do not look at the map either
     if (w0_tail_prio) __builtin_amdgcn_s_setprio(0);
   }
   if (NW == 1 || wid == 1) {
@@ -2823,6 +2840,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     }
     if (!(skip & 8)) write_action_masks(c, arena);
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
+    if (REW_ON_W1) step_rewards_and_done(c, arena, next, skip);
     if (NW == 2) __builtin_amdgcn_s_setprio(0);
   }
   __syncthreads();
@@ -3813,6 +3831,27 @@ extern "C" __global__ void aie_jit_pad() {
   asm volatile(".rept " AIE_STR(AIE_JIT_PAD_NOPS) "\n s_nop 0\n .endr");
 }
 #endif
+// A second caller, never launched, for the out-of-line helpers.  Round 5 found what rounds 2 - 4 could not: a run-time
+// instance was 3 - 6 % slower than the build's instance of the same family because in THIS translation unit the helpers
+// have one caller each with compile-time arguments (n, the draw window's capacity ...), interprocedural constant
+// propagation specialises them, and the kernels' register allocation around the call sites changes with them (16
+// instead of 29 spilled VGPRs, 100 more instructions; same compiler, same flags -- hipcc --genco of this file gave
+// hiprtc's code byte for byte).  In the build the helpers are shared by every instance and stay generic.  With this
+// caller (run-time arguments; np_sum_leaf's mode is 1 at every call site of the build, too) the step and reset kernels
+// come out instruction for instruction as the build's (llvm-objdump, tools/jit_gap_experiment.py).
+extern "C" __global__ void aie_jit_keep_helpers_generic(const double* a, int n, uint32_t M, int o, int m, uint32_t* gkey,
+                                                        uint32_t* w, int cap, int pos, double* out) {
+  const int lane = (int)threadIdx.x & 63;
+  out[0] = aie::np_sum_leaf(a, n, 1, M, o, m, lane);
+  const aie::Refill r = aie::rng_refill(gkey, w, cap, pos, lane);
+  const aie::Refill rf = aie::rng_refill_fast(gkey, w, cap, pos, lane);
+  out[1] = (double)(r.pos + r.avail + r.twisted + rf.pos + rf.avail + rf.twisted);
+  aie::MTRows t;
+  for (int j = 0; j < 10; ++j) t.r[j] = gkey[64 * j + lane];
+  t = aie::mt_twist_rows(t, lane);
+  const aie::MTRows f = aie::mt_fast_rows_of(gkey[0], gkey[1], gkey[2], lane);
+  for (int j = 0; j < 10; ++j) gkey[64 * j + lane] = t.r[j] ^ f.r[j];
+}
 // Run-time specialisation (aie_specialize): the step and reset kernels with THIS environment's parameter block as the
 // constant image (aie_jit_image.h is generated per configuration), exactly what the build's compile-time instances
 // are for the BASELINE configurations.

@@ -342,7 +342,7 @@ class DeviceBackend:
             fl = (np.asarray(state["water"], np.uint8) + 2 * np.asarray(state["stone_src"], np.uint8)
                   + 4 * np.asarray(state["wood_src"], np.uint8)).astype(np.uint8)
             src = torch.as_tensor(fl, device=self.device)
-            if self.cfg.shared_layout and self.cfg.layout_gen == _cabi.LAYOUT_FIXED:
+            if self.cfg.shared_layout and self.cfg.layout_gen == _cabi.LAYOUT_FIXED and self.cfg.rng_mode == _cabi.RNG_FAST:
                 # one source layout for the whole batch (the regeneration's source list is derived from it once,
                 # aie_set_layout): a state that carries another layout cannot be injected into some replicas only
                 if not bool((self.tensors["cell_flags"][0 if e is None else e] == src).all()):

@@ -372,9 +372,9 @@ int aie_download(aie_env* env, const char* name, void* host, int64_t bytes);
 /* Source-block / water planes (HOST pointers, u8 [H*W] each; with shared_layout=1 one
  * replica's planes which are broadcast, else E of them).  They are packed into the
  * static flag byte of every map cell (layout_from_file.py:103-112, 323-334).  With shared_layout=1 (fixed layouts) the
- * call also derives the batch's one list of regeneration draws that target a source block (the step kernels read it
- * instead of scanning the flag bytes every step): change such a layout through this call, not by writing the
- * `cell_flags` tensor. */
+ * call also derives the batch's one list of regeneration draws that target a source block (rng_mode AIE_RNG_FAST: the
+ * step kernels read it instead of scanning the flag bytes every step): change such a layout through this call, not by
+ * writing the `cell_flags` tensor. */
 int aie_set_layout(aie_env* env, const uint8_t* stone_src, const uint8_t* wood_src,
                    const uint8_t* water);
 
