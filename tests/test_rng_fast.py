@@ -320,6 +320,95 @@ def test_hip_fast_mode_many_source_blocks_take_the_row_path():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("words", [8, 64])
+def test_hip_fast_mode_draw_window_refills(words):
+    """The components' draw window cut down to `words` (development hook; the environment then runs the full-featured
+    kernel): every step of a 10-agent environment refills it several times from the counter stream -- block changes
+    included -- and still equals the oracle, which knows no window."""
+    import ctypes
+
+    import torch
+    from helpers import dev_library
+    from oracle_lib import OracleEnv
+    from test_gpu_parity import _compare_all
+
+    cfg = dict(C2, n_agents=10, episode_length=40)
+    with dev_library():
+        env = make_env(cfg, n_envs=96, device="cuda:0", rng_mode="fast")
+        env.seed(8)
+        env.reset()
+    be = env.backend
+    be.lib.aie_dev_set_draw_window.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert be.lib.aie_dev_set_draw_window(be.handle, words) == 0
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(8)
+    oracle.reset()
+    for t in range(50):
+        a, p = be.sample_random_actions(seed=9)
+        be.step(a, p)
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+        if t % 7 == 0 or t in (39, 49):
+            _compare_all(be, oracle, "window %d, step %d" % (words, t + 1))
+        if t == 39:
+            env.reset(be.tensors["done"])
+            oracle.reset(oracle.t["done"].copy())
+
+
+@pytest.mark.gpu
+def test_hip_fast_mode_many_agents_multi_zone_and_dense_log_replica():
+    """30 agents (a draw window of 256 words, order books beyond a wavefront -> the full-featured kernel), multi_zone/ (the
+    reset shuffles the zone grid with masked-rejection draws before it generates the layout) and an environment with a
+    dense-log replica (the logged replica steps on aie_step_kernel_log): all in fast mode against the oracle."""
+    _gpu_case(dict(C2, n_agents=30, episode_length=25, env_layout_file="uniform_25x25_25each_65clump.txt"), 24, 30, seed=3,
+              check_every=5, reset_at=(25,))
+    mz = dict(scenario_name="multi_zone/simple_wood_and_stone", n_agents=4, world_size=[16, 16], episode_length=20,
+              components=[["Build", {}], ["Gather", {}]], starting_agent_coin=5)
+    _gpu_case(mz, 48, 45, seed=12, check_every=5, reset_at=(20, 40))
+    _gpu_case(dict(C2, episode_length=30, dense_log_frequency=1), 16, 35, seed=4, check_every=5, reset_at=(30,))
+
+
+@pytest.mark.gpu
+def test_hip_fast_mode_saez_random_rates_and_rng_state_injection():
+    """tax_model "saez" draws its first periods' rates from the stream (np.random.uniform: sequential doubles inside the
+    tax component); and aie_set_rng_state takes the counter stream's four words per replica."""
+    import torch
+    from oracle_lib import OracleEnv
+    from test_gpu_parity import _compare_all
+
+    comps = [["Build", {}], ["ContinuousDoubleAuction", {"max_num_orders": 5}], ["Gather", {}],
+             ["PeriodicBracketTax", {"tax_model": "saez", "period": 5, "rate_min": 0.1, "rate_max": 0.9}]]
+    _gpu_case(dict(C2, components=comps, episode_length=30), 32, 40, seed=9, check_every=5, reset_at=(30,))
+    E = 8
+    env = make_env(dict(C2, episode_length=20), n_envs=E, device="cuda:0", rng_mode="fast")
+    env.seed(1)
+    env.reset()
+    be = env.backend
+    keys = np.zeros((E, 4), np.uint32)
+    keys[:, 0] = np.arange(E) + 4000
+    keys[:, 1] = 17
+    keys[:, 2] = 5 << 16
+    pos = np.full(E, 123, np.int32)
+    be.set_rng_state(keys, pos)
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(1)
+    oracle.reset()
+    oracle.t["mt"][...] = keys
+    oracle.t["mt_pos"][...] = pos
+    oracle.t["mt_has_gauss"][...] = 0
+    oracle.t["mt_gauss"][...] = 0
+    env.reset()
+    oracle.reset()
+    for t in range(6):
+        a, p = be.sample_random_actions(seed=2)
+        be.step(a, p)
+        torch.cuda.synchronize()
+        oracle.step(a.cpu().numpy(), p.cpu().numpy())
+    _compare_all(be, oracle, "after state injection")
+    assert (be.tensors["mt"].cpu().numpy().view(np.uint32)[:, 1] > 17).all()
+
+
+@pytest.mark.gpu
 def test_aie_seed_fast_entry_point():
     import torch
 
