@@ -1306,6 +1306,66 @@ def test_policy_sampler_equals_its_cpu_restatement(case):
     assert be.lib.aie_sample_policy_actions(be.handle, None, None, 77, 1000, a.data_ptr(), None, None) != 0
 
 
+def test_policy_sampler_covid_collated_masks():
+    """aie_sample_policy_actions on the COVID scenario's collated masks ([1 + levels][states] rows per replica, stride n):
+    against a NumPy restatement of the sampler written out here (counter hash, Gumbel-max with libm's log, lowest index on
+    ties) -- every state's and the planner's sub-action, over steps whose masks change with the cool-downs."""
+    import math
+
+    import torch
+    from helpers import load_covid_golden
+
+    cfg = dict(load_covid_golden("c4_covid_variant")["cfg"], scenario_name="CovidAndEconomySimulation")
+    E = 6
+    env = make_env(cfg, n_envs=E, device="cuda:0", env_offset=50)
+    env.reset()
+    be = env.backend
+    n = be.n
+    ma = be.tensors["obs_a_action_mask"]   # [E, 1 + levels, n]
+    mp = be.tensors["obs_p_action_mask"]   # [E, MP]
+    NL1, MP = ma.shape[1], mp.shape[-1]
+    per_env = n + 1
+    M64 = (1 << 64) - 1
+
+    def counter_rng(seed, env_id, t, slot):
+        z = (seed + 0x9E3779B97F4A7C15 * (env_id + 1)) & M64
+        z ^= ((t + 1) * 0xBF58476D1CE4E5B9) & M64
+        z ^= ((slot + 1) * 0x94D049BB133111EB) & M64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        z ^= z >> 31
+        return z >> 32
+
+    def pick(logits, mask, e, t, j):
+        best, best_k = 0.0, -1
+        for k in range(len(logits)):
+            x = float(logits[k])
+            if not (mask[k] > 0.5) or x != x:
+                continue
+            u = (counter_rng(31, 50 + e, t, per_env + j * 2048 + k) + 0.5) / 4294967296.0
+            sc = x - math.log(-math.log(u))
+            if best_k < 0 or sc > best:
+                best, best_k = sc, k
+        return max(best_k, 0)
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    changed = 0
+    for t in range(12):
+        la = (torch.randn(E, n, NL1, generator=g) * 2).float()
+        lp = (torch.randn(E, MP, generator=g) * 2).float()
+        a, p = be.sample_policy_actions(la.to("cuda:0"), lp.to("cuda:0"), seed=31, env_offset=50)
+        torch.cuda.synchronize()
+        mah, mph = ma.cpu().numpy(), mp.cpu().numpy()
+        assert int(be.tensors["sample_t"][0]) == t + 1
+        for e in range(E):
+            for i in range(n):
+                assert int(a[e, i, 0]) == pick(la[e, i].numpy(), mah[e, :, i], e, t, i), (t, e, i)
+            assert int(p[e, 0]) == pick(lp[e].numpy(), mph[e], e, t, n), (t, e)
+        changed += int((a != 0).sum())
+        env.step({"a": a, "p": p})
+    assert changed > 0
+
+
 @pytest.mark.parametrize("reward_log", [False, True])
 def test_step_is_hipgraph_replayable(reward_log):
     """policy -> aie_step (+ the auto-reset launch) captured ONCE on the caller's stream and replayed 64 times equals
