@@ -58,6 +58,23 @@ class DeviceBackend:
         if rc != 0:
             raise self._err(None, rc)
         self.handle = h
+        try:
+            self._finish_init(cfg, layout_planes, lib_owned, nbytes)
+        except BaseException:
+            # nothing else knows the handle yet: destroy it (and a library-owned arena with it) instead of leaking it
+            self._arena_owner = None
+            self.tensors = {}
+            try:
+                if lib_owned and getattr(self, "arena", None) is not None:
+                    self.arena = None  # (drops the owner object, whose __del__ destroys the handle)
+                else:
+                    self.lib.aie_destroy(self.handle)
+            finally:
+                self.handle = None
+            raise
+
+    def _finish_init(self, cfg, layout_planes, lib_owned, nbytes):
+        torch = _torch()
         if lib_owned:
             d0 = _cabi.AieTensorDesc()
             self.lib.aie_tensor_at(self.handle, 0, C.byref(d0))
@@ -74,7 +91,8 @@ class DeviceBackend:
 
                 def __del__(self):
                     try:
-                        self.lib.aie_destroy(self.handle)
+                        if self.handle:
+                            self.lib.aie_destroy(self.handle)
                     except Exception:
                         pass
 
@@ -375,15 +393,36 @@ class DeviceBackend:
         return np.stack(out).astype(np.uint8)
 
     def close(self):
+        """Releases the environment.  A library-owned arena (1 GiB and up) is freed when the LAST tensor view of it is
+        gone -- action buffers and tensors the caller still holds keep it alive; `free_now()` does not wait for them."""
         if getattr(self, "handle", None):
             if getattr(self, "_arena_owner", None) is not None:
                 # the library owns the arena: the handle is destroyed when the last view of the arena is gone
                 self._arena_owner = None
                 self.arena = None
                 self.tensors = {}
+                self._rand_a = self._rand_p = None
             else:
                 self.lib.aie_destroy(self.handle)
             self.handle = None
+
+    def free_now(self):
+        """close() + the memory back NOW (large environments created back to back: a stale view of a library-owned
+        7 GB arena would otherwise keep it until the garbage collector finds it).  Views the caller still holds dangle
+        afterwards -- use only when none are."""
+        import gc
+
+        owner = getattr(self, "_arena_owner", None)
+        self.close()
+        if owner is not None:
+            try:
+                _torch().cuda.synchronize(self.device)
+            except Exception:
+                pass
+            h, owner.handle = owner.handle, None  # (the owner's __del__ then has nothing left to destroy)
+            if h:
+                self.lib.aie_destroy(h)
+        gc.collect()
 
     def __del__(self):
         try:

@@ -81,13 +81,15 @@ class ObservationGather:
             raise KeyError("ObservationGather: the environment has no tensor(s) %s" % missing)
         # two sets of snapshot / receive buffers: a gather started with start() runs while the steps go on (they
         # overwrite the live observation tensors, so what travels is a device-side snapshot taken in stream order)
-        self.snap = [None, None]
-        self.recv = [None, None]
+        # (slot 2 belongs to the synchronous __call__: it must not reuse a slot a start()ed gather -- RewardLogGather's
+        # block gathers use 0 and 1 -- may still have in flight)
+        self.snap = [None, None, None]
+        self.recv = [None, None, None]
         if self.world > 1:
-            self.snap = [{k: torch.empty_like(backend.tensors[k].contiguous()) for k in self.keys} for _ in range(2)]
+            self.snap = [{k: torch.empty_like(backend.tensors[k].contiguous()) for k in self.keys} for _ in range(3)]
             if self.rank == dst:
                 self.recv = [{k: [torch.empty_like(backend.tensors[k].contiguous()) for _ in range(self.world)]
-                              for k in self.keys} for _ in range(2)]
+                              for k in self.keys} for _ in range(3)]
         self.bytes_per_call = sum(int(backend.tensors[k].numel() * backend.tensors[k].element_size()) for k in self.keys)
 
     def start(self, slot=0):
@@ -113,7 +115,7 @@ class ObservationGather:
         return started if self.rank == self.dst else None
 
     def __call__(self):
-        return self.finish(self.start(0), 0)
+        return self.finish(self.start(2), 2)
 
 
 class RewardLogGather:

@@ -969,6 +969,8 @@ def main():
     ap.add_argument("--covid-unmasked-policy", action="store_true",
                     help="C4 / C4x: the uniform policy that ignores the action masks (round 3's; stringency levels then change "
                          "on most days, the change-event lists overflow and the replicas stream their whole window)")
+    ap.add_argument("--c5-piece-probe", action="store_true",
+                    help="C5: also time fresh processes with forced 16 / 64 / 128 MiB arena pieces (development)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the N > 1 reward-log gather in a 1-rank group (exercises the RCCL path on one GPU)")
     ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"),
@@ -1040,11 +1042,13 @@ def main():
             except Exception as exc:
                 sides["C2pi"] = {"error": repr(exc)}
             if "error" not in sides.get("C5", {"error": 1}):
-                # the same C5 window in fresh processes; if they stay slow, other physical piece sizes of the arena
-                fresh = c5_fresh_process(3)
+                # the same C5 window in two fresh processes (where a process's 7 GB arena lands differs from process to
+                # process and box to box; the arena's piece size is NOT what separates fast from slow boxes: round 5,
+                # tools/c5_piece_experiment.sh -- `--c5-piece-probe` repeats that experiment here)
+                fresh = c5_fresh_process(2)
                 if fresh:
                     sides["C5"]["fresh_process"] = fresh
-                    if fresh["avg_launch_ms"] >= 1.55:
+                    if args.c5_piece_probe:
                         alts = {mb: c5_fresh_process(1, piece_mb=mb) for mb in (16, 64, 128)}
                         sides["C5"]["fresh_process_other_piece_sizes"] = alts
             out["workloads"] = sides
