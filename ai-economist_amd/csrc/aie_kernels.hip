@@ -3741,10 +3741,13 @@ extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, 
 // aie_sample_policy_actions): Gumbel-max, entry k of a slot scores logit_k - log(-log(u_k)) with u_k from the counter
 // RNG keyed (seed, global replica, the replica's draw index t, slot, k); the allowed entry with the highest score wins
 // (lowest index on ties; NaN logits count as masked; nothing allowed: NO-OP).  Scores are float64 and the logarithm is
-// libm's bit for bit (aie_glibc_math.h), so the CPU restatement picks the same entries.  One workgroup of four waves per
-// replica: a wave takes every fourth slot, a lane every 64th entry of it; thread 0 advances the draw index behind a
-// barrier -- one launch, nothing by value from a host counter (replayable from a hipGraph).
-extern "C" __global__ void __launch_bounds__(256)
+// a fixed sequence of IEEE operations (aie_layout.h: aie_sampler_log), so the CPU restatement picks the same entries.  One
+// workgroup of four waves per replica: a wave takes every fourth slot, a lane every 64th entry of it; thread 0 advances
+// the draw index behind a barrier -- one launch, nothing by value from a host counter (replayable from a hipGraph).
+// The kernel is bound by its vector arithmetic (rocprofv3: a wave per slot instead of four waves per replica made it
+// slower, 25 -> 40 us on BASELINE configs[1]), which is why the per-entry work is what it is: a 32-bit hash, two short
+// logarithms, one LDS atomic.
+extern "C" __global__ void __launch_bounds__(1024)
 aie_sample_policy_actions_kernel(const aie_params P, uint8_t* __restrict__ arena, const float* __restrict__ logits_a,
                                  const float* __restrict__ logits_p, uint64_t seed, int64_t env_offset,
                                  int32_t* __restrict__ act_a, int32_t* __restrict__ act_p) {
@@ -3755,7 +3758,9 @@ aie_sample_policy_actions_kernel(const aie_params P, uint8_t* __restrict__ arena
   const int64_t t = aie::uni(*tfield);
   const bool covid = P.c.scenario == AIE_SCN_COVID;
   const int wa = covid ? 1 + P.cv_NL : P.MA;  // logits per agent, in the mask's own (flattened) layout
-  for (int j = wave; j < per_env; j += 4) {
+  const int nwaves = (int)blockDim.x >> 6;  // (four: aie_capi.hip)
+  __shared__ unsigned long long cell[16];
+  for (int j = wave; j < per_env; j += nwaves) {
     const float* mask;
     const float* lg;
     int lo, len, stride = 1;
@@ -3794,28 +3799,25 @@ aie_sample_policy_actions_kernel(const aie_params P, uint8_t* __restrict__ arena
       }
       dst = act_p + (int64_t)e * P.act_p_width + s;
     }
-    double best = 0.0;
-    int best_k = -1;  // (-1: nothing allowed so far)
+    // one 64-bit hash per slot, a 32-bit finaliser per entry; (score, entry) as one ordered key (aie_layout.h), the slot's
+    // arg-max as one LDS atomic max per lane (LDS operations of a wave execute in order: reset, maxima, read-back)
+    const uint32_t slot_word = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)per_env + (uint64_t)j);
+    if (lane == 0) cell[wave] = 0ull;
+    AIE_WSYNC();
     for (int k = lane; k < len; k += 64) {
       const float x = lg[lo + k];
       if (!(mask[(lo + k) * stride] > 0.5f) || x != x) continue;
-      const uint32_t r = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)per_env + (uint64_t)j * 2048ull + (uint64_t)k);
+      const uint32_t r = aie_sampler_entry_rng(slot_word, (uint32_t)k);
       const double u = ((double)r + 0.5) * (1.0 / 4294967296.0);
-      const double sc = (double)x - aie_log_glibc(-aie_log_glibc(u));
-      if (best_k < 0 || sc > best) {  // (k ascends within a lane: a tie keeps the lower index)
-        best = sc;
-        best_k = k;
-      }
+      const double sc = (double)x - aie_sampler_log(-aie_sampler_log(u));
+      atomicMax(&cell[wave], (unsigned long long)aie_sampler_key(sc, k));
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double ob = __shfl_xor(best, off, 64);
-      const int ok = __shfl_xor(best_k, off, 64);
-      const bool take = ok >= 0 && (best_k < 0 || ob > best || (ob == best && ok < best_k));
-      best = take ? ob : best;
-      best_k = take ? ok : best_k;
+    AIE_WSYNC();
+    if (lane == 0) {
+      const unsigned long long best = cell[wave];
+      *dst = best ? 2047 - (int)(best & 0x7ffull) : 0;
     }
-    if (lane == 0) *dst = best_k < 0 ? 0 : best_k;
+    AIE_WSYNC();
   }
   __syncthreads();
   if (threadIdx.x == 0) *tfield = (int32_t)t + 1;

@@ -1285,6 +1285,60 @@ AIE_HD static inline double aie_annealed_tax_limit(int completions, double warmu
   return pv * final_max;
 }
 
+/* The logarithm of the policy sampler's Gumbel scores (aie_sample_policy_actions): log(v) for a normal double v > 0 as a
+ * FIXED sequence of IEEE double operations -- no fma, no libm, no table -- so that the kernel, the CPU restatement
+ * (oracle/) and a NumPy / Python transcription produce the same bits: v = m 2^e with m in [sqrt(1/2), sqrt(2)),
+ * log v = e ln 2 + 2 atanh(s), s = (m - 1) / (m + 1), atanh by its odd series through s^13 (|s| <= 0.1716: the first
+ * dropped term is below 3e-13 of the leading one) -- far more than a sampler needs; what it needs is that everybody
+ * computes the SAME score.  (libm's log restated operation by operation, aie_glibc_math.h, cost
+ * the sampler 26 us per launch on BASELINE configs[1]: two table-driven logarithms per entry.) */
+/* The policy sampler's per-entry random word: one 64-bit counter hash per action slot (aie_counter_rng, keyed seed /
+ * global replica / draw index / slot), then a 32-bit finaliser per entry (two multiplies; "lowbias32" of C. Wellons'
+ * hash prospector) -- the 64-bit hash per ENTRY was a third of the sampler's vector work. */
+AIE_HD static inline uint32_t aie_sampler_entry_rng(uint32_t slot_word, uint32_t k) {
+  uint32_t h = slot_word + k * 0x9E3779B1u;
+  h ^= h >> 16;
+  h *= 0x7feb352du;
+  h ^= h >> 15;
+  h *= 0x846ca68bu;
+  h ^= h >> 16;
+  return h;
+}
+/* (score, entry) as ONE unsigned 64-bit key whose order is "higher score first, lower entry index on ties": the double's
+ * bits made monotone (sign flip), its lowest 11 mantissa bits replaced by 2047 - k (k < 2048; scores that agree in all
+ * but those bits -- 2.4e-13 relative -- count as tied).  0 = nothing allowed.  The arg-max of a slot is then one LDS
+ * atomic max per lane instead of a six-step shuffle tree of (double, int) pairs. */
+AIE_HD static inline uint64_t aie_sampler_key(double score, int k) {
+  union { double d; uint64_t u; } c;
+  c.d = score;
+  uint64_t b = c.u;
+  b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+  return (b & ~0x7ffull) | (uint64_t)(2047 - k);
+}
+AIE_HD static inline double aie_sampler_log(double v) {
+#if defined(__HIPCC__)
+  _Pragma("clang fp contract(off)")
+#endif
+  union { double d; uint64_t u; } c;
+  c.d = v;
+  int e = (int)((c.u >> 52) & 0x7ffu) - 1023;
+  c.u = (c.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+  double m = c.d; /* [1, 2) */
+  if (m > 1.4142135623730951) {
+    m = m * 0.5;
+    e += 1;
+  }
+  const double s = (m - 1.0) / (m + 1.0);
+  const double z = s * s;
+  double p = 0.076923076923076927;   /* 1/13 */
+  p = p * z + 0.090909090909090912;  /* 1/11 */
+  p = p * z + 0.1111111111111111;    /* 1/9 */
+  p = p * z + 0.14285714285714285;   /* 1/7 */
+  p = p * z + 0.2;                   /* 1/5 */
+  p = p * z + 0.33333333333333331;   /* 1/3 */
+  p = p * z + 1.0;
+  return (double)e * 0.69314718055994529 + (2.0 * s) * p;
+}
 AIE_HD static inline uint32_t aie_counter_rng(uint64_t seed, uint64_t env, uint64_t t, uint64_t slot) {
   uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env + 1ull);
   z ^= (t + 1ull) * 0xBF58476D1CE4E5B9ull;

@@ -956,7 +956,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="C2")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["C2pi"], default="C2",
+                    help="C2pi: configs[1] with a torch MLP policy in the loop, alone (one JSON line; no CPU legs)")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true",
@@ -1009,6 +1010,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
+    if args.workload == "C2pi":  # the policy-in-the-loop side workload on its own (profiling)
+        r = run_policy_workload(args, min(args.steps, 400), min(args.warmup, 40), device)
+        r.pop("compact", None)
+        print(json.dumps(r), flush=True)
+        return
     out = run_workload(args.workload, args, args.steps, args.warmup, rank, local_rank, world, device)
     if world > 1:
         # every rank empties its native stdio buffers (RCCL's version banner) before rank 0 prints the JSON line, so

@@ -1846,7 +1846,8 @@ void aie_oracle_seed64(const aie_params* p, uint8_t* arena, uint64_t base_seed) 
 }
 void aie_oracle_seed(const aie_params* p, uint8_t* arena, uint32_t base_seed) { aie_oracle_seed64(p, arena, (uint64_t)base_seed); }
 /* aie_sample_policy_actions (include/aie.h) restated: Gumbel-max over the allowed entries of every action slot, float64
- * scores logit - log(-log(u)) with libm's log, u from the counter RNG keyed (seed, global replica, draw index, slot, k);
+ * scores logit - log(-log(u)) with the sampler's fixed-operation log (aie_layout.h: aie_sampler_log; tests compare it with
+ * libm's), u from the counter RNG keyed (seed, global replica, draw index, slot, k);
  * ties take the lower index, NaN logits count as masked, NO-OP if nothing is allowed; advances `sample_t`.  Not part of
  * the reference (its trainers sample in their own framework, training_script.py:88-133): this pins the PRODUCT's
  * sampler.  Gather-trade-build and one-step-economy layouts (COVID's collated masks: covid_oracle.py). */
@@ -1885,17 +1886,18 @@ void aie_oracle_sample_policy_actions(const aie_params* p, uint8_t* arena, const
         }
         dst = act_p + (int64_t)e * p->act_p_width + s;
       }
-      double best = 0.0;
-      int best_k = -1;
+      const uint32_t slot_word = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)per_env + (uint64_t)j);
+      uint64_t best = 0; /* (score, entry) as one ordered key: aie_layout.h */
       for (int k = 0; k < len; ++k) {
         const float x = lg[lo + k];
         if (!(mask[lo + k] > 0.5f) || x != x) continue;
-        const uint32_t r = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t,
-                                           (uint64_t)per_env + (uint64_t)j * 2048ull + (uint64_t)k);
+        const uint32_t r = aie_sampler_entry_rng(slot_word, (uint32_t)k);
         const double u = ((double)r + 0.5) * (1.0 / 4294967296.0);
-        const double sc = (double)x - log(-log(u));
-        if (best_k < 0 || sc > best) { best = sc; best_k = k; }
+        const double sc = (double)x - aie_sampler_log(-aie_sampler_log(u)); /* (the product's own log: aie_layout.h) */
+        const uint64_t key = aie_sampler_key(sc, k);
+        if (key > best) best = key;
       }
+      const int best_k = best ? 2047 - (int)(best & 0x7ffu) : -1;
       *dst = best_k < 0 ? 0 : best_k;
     }
     *tf = (int32_t)t + 1;

@@ -1369,17 +1369,46 @@ def test_policy_sampler_covid_collated_masks():
         z ^= z >> 31
         return z >> 32
 
+    def slog(v):  # csrc/aie_layout.h: aie_sampler_log, transcribed (plain IEEE multiplies, adds and one division)
+        m, ex = math.frexp(v)
+        m, ex = m * 2.0, ex - 1
+        if m > 1.4142135623730951:
+            m, ex = m * 0.5, ex + 1
+        sv = (m - 1.0) / (m + 1.0)
+        z = sv * sv
+        pl = 0.076923076923076927
+        for cst in (0.090909090909090912, 0.1111111111111111, 0.14285714285714285, 0.2, 0.33333333333333331, 1.0):
+            pl = pl * z + cst
+        return float(ex) * 0.69314718055994529 + (2.0 * sv) * pl
+
+    for v in (1e-10, 0.3, 0.9999999, 1.0, 2.5, 22.0):
+        assert abs(slog(v) - math.log(v)) <= 1e-12 * max(1.0, abs(math.log(v)))
+
+    def entry_rng(slot_word, k):  # aie_sampler_entry_rng
+        h = (slot_word + k * 0x9E3779B1) & 0xffffffff
+        h ^= h >> 16
+        h = (h * 0x7feb352d) & 0xffffffff
+        h ^= h >> 15
+        h = (h * 0x846ca68b) & 0xffffffff
+        return h ^ (h >> 16)
+
+    def key(score, k):  # aie_sampler_key
+        import struct
+
+        b = struct.unpack("<Q", struct.pack("<d", score))[0]
+        b = (~b & M64) if b >> 63 else (b | (1 << 63))
+        return (b & ~0x7ff) | (2047 - k)
+
     def pick(logits, mask, e, t, j):
-        best, best_k = 0.0, -1
+        slot_word = counter_rng(31, 50 + e, t, per_env + j)
+        best = 0
         for k in range(len(logits)):
             x = float(logits[k])
             if not (mask[k] > 0.5) or x != x:
                 continue
-            u = (counter_rng(31, 50 + e, t, per_env + j * 2048 + k) + 0.5) / 4294967296.0
-            sc = x - math.log(-math.log(u))
-            if best_k < 0 or sc > best:
-                best, best_k = sc, k
-        return max(best_k, 0)
+            u = (entry_rng(slot_word, k) + 0.5) / 4294967296.0
+            best = max(best, key(x - slog(-slog(u)), k))
+        return 2047 - (best & 0x7ff) if best else 0
 
     g = torch.Generator(device="cpu").manual_seed(5)
     changed = 0

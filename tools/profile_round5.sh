@@ -29,3 +29,11 @@ for WL in "$@"; do
   head -4 $R/gpurun_out/summ/r05_${w}_kernel_stats.csv | cut -c1-160
   rm -rf $R/gpurun_out/prof_r05_$w $R/gpurun_out/pmc_r05_${w}_* $R/gpurun_out/sq_${WL}_*
 done
+# the policy-in-the-loop workload: kernel stats only (which launches a replayed iteration consists of)
+if [ -n "$C2PI" ]; then
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r05_c2pi -o s -- \
+    python $R/bench.py --workload C2pi --steps 300 --warmup 30 > $R/gpurun_out/summ/r05_c2pi_bench.json 2> $R/gpurun_out/prof_r05_c2pi.err
+  find $R/gpurun_out/prof_r05_c2pi -name "*kernel_stats.csv" | head -1 | xargs -r head -24 > $R/gpurun_out/summ/r05_c2pi_kernel_stats.csv
+  head -12 $R/gpurun_out/summ/r05_c2pi_kernel_stats.csv | cut -c1-150
+  rm -rf $R/gpurun_out/prof_r05_c2pi
+fi
