@@ -115,6 +115,7 @@ class MaskedMLPPolicy:
         self.sample_seed = int(sample_seed)
         if self.multi_a and sampler == "torch":
             raise NotImplementedError("MaskedMLPPolicy(sampler='torch'): single-action agents (the BASELINE configurations)")
+        self._fused_relu = None  # decided at the first call (outside any capture: GraphedStep warms the policy up first)
         self.counter = torch.zeros((), dtype=torch.float32, device=dev)
         if sampler == "torch":
             self.idx_a = torch.arange(be.E * be.n * MA, device=dev, dtype=torch.float32).view(be.E, be.n, MA)
@@ -126,16 +127,33 @@ class MaskedMLPPolicy:
         u = u.clamp_(1e-6, 1.0 - 1e-6)
         return -torch.log(-torch.log(u))
 
+    def _layer(self, b, x, w):
+        """relu(x @ w + b): one launch where the BLAS library fuses the activation into the GEMM's epilogue
+        (torch._addmm_activation), else the GEMM and an in-place ReLU."""
+        torch = self.torch
+        if self._fused_relu is None:
+            self._fused_relu = False
+            fn = getattr(torch, "_addmm_activation", None)
+            if fn is not None:
+                try:
+                    got = fn(b, x, w, use_gelu=False)
+                    self._fused_relu = bool(torch.allclose(got, torch.addmm(b, x, w).relu_(), rtol=1e-4, atol=1e-4))
+                except Exception:
+                    self._fused_relu = False
+        if self._fused_relu:
+            return torch._addmm_activation(b, x, w, use_gelu=False)
+        return torch.addmm(b, x, w).relu_()
+
     def logits(self, tensors):
         """(agents' logits [E * n, MA], planner's logits [E, MP]) in the layout of the flattened action masks."""
         torch = self.torch
         xa = tensors["obs_a_flat"].to(self.dtype).reshape(-1, self.wa1.shape[0])
-        h = torch.addmm(self.ba1, xa, self.wa1).relu_()
-        h = torch.addmm(self.ba2, h, self.wa2).relu_()
+        h = self._layer(self.ba1, xa, self.wa1)
+        h = self._layer(self.ba2, h, self.wa2)
         la = torch.addmm(self.ba3, h, self.wa3).float()
         xp = tensors["obs_p_flat"].to(self.dtype)
-        h = torch.addmm(self.bp1, xp, self.wp1).relu_()
-        h = torch.addmm(self.bp2, h, self.wp2).relu_()
+        h = self._layer(self.bp1, xp, self.wp1)
+        h = self._layer(self.bp2, h, self.wp2)
         lp = torch.addmm(self.bp3, h, self.wp3).float()
         return la, lp
 
