@@ -3738,16 +3738,56 @@ extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, 
 }
 
 // Categorical sampling from the caller's policy logits under the current action masks (include/aie.h:
-// aie_sample_policy_actions): Gumbel-max, entry k of a slot scores logit_k - log(-log(u_k)) with u_k from the counter
-// RNG keyed (seed, global replica, the replica's draw index t, slot, k); the allowed entry with the highest score wins
-// (lowest index on ties; NaN logits count as masked; nothing allowed: NO-OP).  Scores are float64 and the logarithm is
-// a fixed sequence of IEEE operations (aie_layout.h: aie_sampler_log), so the CPU restatement picks the same entries.  One
-// workgroup of four waves per replica: a wave takes every fourth slot, a lane every 64th entry of it; thread 0 advances
-// the draw index behind a barrier -- one launch, nothing by value from a host counter (replayable from a hipGraph).
-// The kernel is bound by its vector arithmetic (rocprofv3: a wave per slot instead of four waves per replica made it
-// slower, 25 -> 40 us on BASELINE configs[1]), which is why the per-entry work is what it is: a 32-bit hash, two short
-// logarithms, one LDS atomic.
-extern "C" __global__ void __launch_bounds__(1024)
+// aie_sample_policy_actions): Gumbel-max, entry k of a slot scores logit_k - log(-log(u_k)) with u_k from a counter hash
+// keyed (seed, global replica, the replica's draw index t, slot, k); the allowed entry with the highest score wins (lowest
+// index on ties; NaN logits count as masked; nothing allowed: NO-OP).  Scores are float64 and the logarithm is a fixed
+// sequence of IEEE operations (aie_layout.h: aie_sampler_log), so the CPU restatement picks the same entries.
+// One workgroup of four waves per replica; a wave takes every fourth WORK ITEM: one action slot, or -- where the rows of
+// a group are equally long and at most 32 entries (the planner's tax brackets: 22, COVID's states: 11) -- as many whole
+// rows as fit its 64 lanes; a lane takes one entry (every 64th of a longer row).  The kernel is bound by its vector
+// arithmetic (a wave per slot instead of four waves per replica made it slower: 25 -> 40 us on BASELINE configs[1]), hence
+// one 64-bit hash per replica and a 32-bit finaliser per slot and per entry, two short logarithms, (score, entry) as one
+// ordered 64-bit key and ONE LDS atomic max per lane for the row's arg-max.  Thread 0 advances the draw index behind a
+// barrier: one launch, nothing by value from a host counter (replayable from a hipGraph).
+struct SamplerRow {
+  const float* mask;
+  const float* lg;
+  int lo, len, stride;
+};
+__device__ __forceinline__ SamplerRow sampler_row(const aie_params& P, const uint8_t* __restrict__ arena, const float* __restrict__ logits_a,
+                                                  const float* __restrict__ logits_p, int e, int j, int na, int wa, bool covid) {
+  SamplerRow r;
+  r.stride = 1;
+  if (j < na) {
+    const int i = j / P.act_a_width, s = j - i * P.act_a_width;
+    if (covid) {
+      r.mask = reinterpret_cast<const float*>(arena + P.a_cv_obs_a) + ((int64_t)e * P.cv_nrow_obs + AIE_CV_OB_MASK) * P.n + i;
+      r.stride = P.n;
+    } else {
+      r.mask = reinterpret_cast<const float*>(arena + P.a_obs_a_mask) + ((int64_t)e * P.n + i) * P.MA;
+    }
+    r.lg = logits_a + ((int64_t)e * P.n + i) * wa;
+    r.lo = 0;
+    r.len = wa;
+    if (P.c.multi_action_mode_agents) {
+      for (int k = 0; k < s; ++k) r.lo += 1 + P.sub_a_dim[k];
+      r.len = P.n_sub_a ? 1 + P.sub_a_dim[s] : 1;
+    }
+  } else {
+    const int s = j - na;
+    if (covid) r.mask = reinterpret_cast<const float*>(arena + P.a_cv_obs_p) + (int64_t)e * (4 + P.MP) + 4;
+    else r.mask = reinterpret_cast<const float*>(arena + P.a_obs_p_mask) + (int64_t)e * P.MP;
+    r.lg = logits_p + (int64_t)e * P.MP;
+    r.lo = 0;
+    r.len = P.MP;
+    if (P.c.multi_action_mode_planner) {
+      r.lo = s * (1 + P.sub_p_dim);
+      r.len = P.n_sub_p ? 1 + P.sub_p_dim : 1;
+    }
+  }
+  return r;
+}
+extern "C" __global__ void __launch_bounds__(256)
 aie_sample_policy_actions_kernel(const aie_params P, uint8_t* __restrict__ arena, const float* __restrict__ logits_a,
                                  const float* __restrict__ logits_p, uint64_t seed, int64_t env_offset,
                                  int32_t* __restrict__ act_a, int32_t* __restrict__ act_p) {
@@ -3758,64 +3798,48 @@ aie_sample_policy_actions_kernel(const aie_params P, uint8_t* __restrict__ arena
   const int64_t t = aie::uni(*tfield);
   const bool covid = P.c.scenario == AIE_SCN_COVID;
   const int wa = covid ? 1 + P.cv_NL : P.MA;  // logits per agent, in the mask's own (flattened) layout
-  const int nwaves = (int)blockDim.x >> 6;  // (four: aie_capi.hip)
-  __shared__ unsigned long long cell[16];
-  for (int j = wave; j < per_env; j += nwaves) {
-    const float* mask;
-    const float* lg;
-    int lo, len, stride = 1;
-    int32_t* dst;
-    if (j < na) {
-      if (!act_a || !logits_a) continue;
-      const int i = j / P.act_a_width, s = j - i * P.act_a_width;
-      if (covid) {
-        mask = reinterpret_cast<const float*>(arena + P.a_cv_obs_a) + ((int64_t)e * P.cv_nrow_obs + AIE_CV_OB_MASK) * P.n + i;
-        stride = P.n;
-      } else {
-        mask = reinterpret_cast<const float*>(arena + P.a_obs_a_mask) + ((int64_t)e * P.n + i) * P.MA;
-      }
-      lg = logits_a + ((int64_t)e * P.n + i) * wa;
-      if (P.c.multi_action_mode_agents) {
-        lo = 0;
-        for (int k = 0; k < s; ++k) lo += 1 + P.sub_a_dim[k];
-        len = P.n_sub_a ? 1 + P.sub_a_dim[s] : 1;
-      } else {
-        lo = 0;
-        len = wa;
-      }
-      dst = act_a + (int64_t)e * na + j;
-    } else {
-      if (!act_p || !logits_p) continue;
-      const int s = j - na;
-      if (covid) mask = reinterpret_cast<const float*>(arena + P.a_cv_obs_p) + (int64_t)e * (4 + P.MP) + 4;
-      else mask = reinterpret_cast<const float*>(arena + P.a_obs_p_mask) + (int64_t)e * P.MP;
-      lg = logits_p + (int64_t)e * P.MP;
-      if (P.c.multi_action_mode_planner) {
-        lo = s * (1 + P.sub_p_dim);
-        len = P.n_sub_p ? 1 + P.sub_p_dim : 1;
-      } else {
-        lo = 0;
-        len = P.MP;
-      }
-      dst = act_p + (int64_t)e * P.act_p_width + s;
+  __shared__ unsigned long long cell[4][64];
+  // work items: groups of equally long rows are packed several to a wave
+  const bool have_a = act_a && logits_a, have_p = act_p && logits_p;
+  const int len_a = P.c.multi_action_mode_agents ? 0 : wa;  // (0: rows differ in length)
+  const int rpw_a = (len_a > 0 && len_a <= 32) ? 64 / len_a : 1;
+  const int items_a = have_a ? (na + rpw_a - 1) / rpw_a : 0;
+  const int len_p = P.c.multi_action_mode_planner ? (P.n_sub_p ? 1 + P.sub_p_dim : 1) : P.MP;
+  const int rpw_p = len_p <= 32 ? 64 / len_p : 1;
+  const int items_p = have_p ? (P.act_p_width + rpw_p - 1) / rpw_p : 0;
+  const uint32_t base_lo = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)per_env);
+  for (int it = wave; it < items_a + items_p; it += 4) {
+    const bool ag = it < items_a;
+    const int rpw = ag ? rpw_a : rpw_p;
+    const int j0 = ag ? it * rpw : na + (it - items_a) * rpw, jend = ag ? na : per_env;
+    const int len_u = ag ? len_a : len_p;
+    int sub = 0, kk = lane;
+    if (rpw > 1) {
+      sub = lane / len_u;
+      kk = lane - sub * len_u;
     }
-    // one 64-bit hash per slot, a 32-bit finaliser per entry; (score, entry) as one ordered key (aie_layout.h), the slot's
-    // arg-max as one LDS atomic max per lane (LDS operations of a wave execute in order: reset, maxima, read-back)
-    const uint32_t slot_word = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)per_env + (uint64_t)j);
-    if (lane == 0) cell[wave] = 0ull;
+    const int j = j0 + sub;
+    cell[wave][lane] = 0ull;
     AIE_WSYNC();
-    for (int k = lane; k < len; k += 64) {
-      const float x = lg[lo + k];
-      if (!(mask[(lo + k) * stride] > 0.5f) || x != x) continue;
-      const uint32_t r = aie_sampler_entry_rng(slot_word, (uint32_t)k);
-      const double u = ((double)r + 0.5) * (1.0 / 4294967296.0);
-      const double sc = (double)x - aie_sampler_log(-aie_sampler_log(u));
-      atomicMax(&cell[wave], (unsigned long long)aie_sampler_key(sc, k));
+    if (sub < rpw && j < jend) {
+      const SamplerRow r = sampler_row(P, arena, logits_a, logits_p, e, j, na, wa, covid);
+      const uint32_t slot_word = aie_sampler_entry_rng(base_lo, 0x40000000u + (uint32_t)j);
+      for (int k = kk; k < r.len; k += 64) {  // (packed rows: one pass)
+        const float x = r.lg[r.lo + k];
+        if (!(r.mask[(r.lo + k) * r.stride] > 0.5f) || x != x) continue;
+        const uint32_t rnd = aie_sampler_entry_rng(slot_word, (uint32_t)k);
+        const double u = ((double)rnd + 0.5) * (1.0 / 4294967296.0);
+        const double sc = (double)x - aie_sampler_log(-aie_sampler_log(u));
+        atomicMax(&cell[wave][sub], (unsigned long long)aie_sampler_key(sc, k));
+      }
     }
     AIE_WSYNC();
-    if (lane == 0) {
-      const unsigned long long best = cell[wave];
-      *dst = best ? 2047 - (int)(best & 0x7ffull) : 0;
+    if (lane < rpw && j0 + lane < jend) {  // lane s reports row j0 + s
+      const unsigned long long best = cell[wave][lane];
+      const int choice = best ? 2047 - (int)(best & 0x7ffull) : 0;
+      const int jr = j0 + lane;
+      if (jr < na) act_a[(int64_t)e * na + jr] = choice;
+      else act_p[(int64_t)e * P.act_p_width + (jr - na)] = choice;
     }
     AIE_WSYNC();
   }

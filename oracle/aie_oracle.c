@@ -1886,7 +1886,8 @@ void aie_oracle_sample_policy_actions(const aie_params* p, uint8_t* arena, const
         }
         dst = act_p + (int64_t)e * p->act_p_width + s;
       }
-      const uint32_t slot_word = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)per_env + (uint64_t)j);
+      const uint32_t base = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)per_env); /* per replica and call */
+      const uint32_t slot_word = aie_sampler_entry_rng(base, 0x40000000u + (uint32_t)j);
       uint64_t best = 0; /* (score, entry) as one ordered key: aie_layout.h */
       for (int k = 0; k < len; ++k) {
         const float x = lg[lo + k];

@@ -1400,7 +1400,7 @@ def test_policy_sampler_covid_collated_masks():
         return (b & ~0x7ff) | (2047 - k)
 
     def pick(logits, mask, e, t, j):
-        slot_word = counter_rng(31, 50 + e, t, per_env + j)
+        slot_word = entry_rng(counter_rng(31, 50 + e, t, per_env), 0x40000000 + j)
         best = 0
         for k in range(len(logits)):
             x = float(logits[k])
