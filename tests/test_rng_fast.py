@@ -409,6 +409,34 @@ def test_hip_fast_mode_saez_random_rates_and_rng_state_injection():
 
 
 @pytest.mark.gpu
+def test_hip_fast_mode_is_shard_invariant():
+    """Replica sharding: the counter stream is keyed by the GLOBAL replica id, so the second half of a
+    64-replica batch equals a 32-replica batch created with env_offset=32 -- every tensor, after steps and a reset."""
+    import torch
+
+    cfg = dict(C2, episode_length=25)
+    whole = make_env(cfg, n_envs=64, device="cuda:0", rng_mode="fast")
+    half = make_env(cfg, n_envs=32, device="cuda:0", rng_mode="fast", env_offset=32)
+    for env in (whole, half):
+        env.seed(77)
+        env.reset()
+    bw, bh = whole.backend, half.backend
+    for t in range(30):
+        aw, pw = bw.sample_random_actions(seed=5)
+        ah, ph = bh.sample_random_actions(seed=5, env_offset=32)
+        assert torch.equal(aw[32:], ah) and torch.equal(pw[32:], ph)
+        bw.step(aw, pw)
+        bh.step(ah, ph)
+        if t == 24:
+            bw.reset(bw.tensors["done"])
+            bh.reset(bh.tensors["done"])
+    torch.cuda.synchronize()
+    for k, v in bh.tensors.items():
+        if v.shape[0] == 32:
+            assert torch.equal(bw.tensors[k][32:], v), k
+
+
+@pytest.mark.gpu
 def test_aie_seed_fast_entry_point():
     import torch
 
