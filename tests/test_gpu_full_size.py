@@ -344,16 +344,17 @@ def test_c2_full_batch_crosses_an_episode_end_on_the_compile_time_instance():
     assert int(be.tensors["completions"].min()) == 2
 
 
-@pytest.mark.parametrize("n_agents", [4, 10])
-def test_c2_c3_full_batch_whole_episode_and_its_end(n_agents):
+@pytest.mark.parametrize("n_agents,rng_mode", [(4, "numpy"), (10, "numpy"), (4, "fast"), (10, "fast")])
+def test_c2_c3_full_batch_whole_episode_and_its_end(n_agents, rng_mode):
     """BASELINE configs[1] / one GPU's share of configs[2] exactly as benchmarked -- 4096 replicas, 1000-step episodes -- through a WHOLE episode, its
     end and the reset behind it: ten tax days, twenty order-expiry horizons, every field of every replica every 100
-    steps, at the terminal step, after the reset and five steps into the second episode."""
+    steps, at the terminal step, after the reset and five steps into the second episode.  "fast": the C2f / C3f
+    workloads (counter-based stream) against the oracle's restatement of the same generator."""
     import torch
     from oracle_lib import OracleEnv
 
     E, EP = 4096, 1000
-    env = make_env(dict(C2, n_agents=n_agents), n_envs=E, device="cuda:0")
+    env = make_env(dict(C2, n_agents=n_agents), n_envs=E, device="cuda:0", rng_mode=rng_mode)
     env.seed(4)
     env.reset()
     be = env.backend
