@@ -743,6 +743,15 @@ int aie_sample_policy_actions(aie_env* env, const float* d_logits_a, const float
     snprintf(env->err, sizeof(env->err), "aie_sample_policy_actions: an action buffer without its logits");
     return AIE_E_INVALID;
   }
+  {  // (score, entry) travel as one 64-bit key with 11 bits of entry index (aie_layout.h: aie_sampler_key)
+    const aie_params& P = env->P;
+    const int wa = P.c.scenario == AIE_SCN_COVID ? 1 + P.cv_NL : P.MA;
+    const int wp = P.c.multi_action_mode_planner ? 1 + P.sub_p_dim : P.MP;
+    if (wa > 2048 || wp > 2048) {
+      snprintf(env->err, sizeof(env->err), "aie_sample_policy_actions: action rows of more than 2048 entries (%d / %d)", wa, wp);
+      return AIE_E_UNSUPPORTED;
+    }
+  }
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   hipLaunchKernelGGL(aie_sample_policy_actions_kernel, dim3((unsigned)env->P.E), dim3(256), 0, static_cast<hipStream_t>(stream),
                      env->P, env->arena, d_logits_a, d_logits_p, seed, global_env_offset, d_actions_a, d_actions_p);
