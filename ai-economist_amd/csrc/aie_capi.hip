@@ -762,7 +762,7 @@ int aie_sample_policy_actions(aie_env* env, const float* d_logits_a, const float
 // Which step kernel runs this environment: >= 0 = compile-time instance (index into aie_spec_generated.h), -1 = generic.
 int aie_step_kernel_instance(aie_env* env) { return env ? env->spec : -2; }
 
-// ---- run-time specialisation (aie_jit.h): requested in the background by aie_create, adopted at a step boundary ----
+// ---- run-time specialisation (aie_jit.h): requested in the background by aie_create, adopted at the next aie_reset ----
 static bool aie_jit_eligible(const aie_env* env) {
   const aie_params& P = env->P;
   const bool ose = P.c.scenario == AIE_SCN_ONE_STEP_ECONOMY;

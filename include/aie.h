@@ -486,7 +486,7 @@ int aie_select_step_kernel(aie_env* env, int which);
  * csrc/aie_kernels.hip with it as a constant image, a few seconds once; the code object is cached under
  * $AIE_JIT_CACHE / ~/.cache/ai_economist_amd -- private directories only -- keyed by the image, the sources, the
  * architecture, the compiler version and options).  aie_create already starts this in the background and a later
- * aie_step / aie_reset adopts the result at its launch boundary; this call WAITS for it.  Afterwards AIE_KERNEL_AUTO runs
+ * aie_reset (an episode boundary, outside stream capture; never aie_step) adopts the result; this call WAITS for it.  Afterwards AIE_KERNEL_AUTO runs
  * the specialised kernels (aie_step_kernel_instance() == AIE_KERNEL_INSTANCE_JIT); results are bit-identical to the
  * generic kernel's.  Gather-trade-build and one-step-economy environments.  AIE_E_UNSUPPORTED -- and the environment simply keeps the
  * generic kernel -- when hiprtc, the kernel sources beside the library ($AIE_JIT_SOURCE_DIR) or the toolchain headers
