@@ -1065,18 +1065,29 @@ def test_runtime_specialisation_equals_generic_kernel(case):
     assert pair[1].specialize(required=True) and b_ref.lib.aie_step_kernel_instance(b_ref.handle) == 1000
 
 
-def test_background_specialisation_swaps_in_without_a_call(monkeypatch):
+@pytest.mark.parametrize("case", ["gtb_7_agents", "gtb_7_agents_fast_rng", "one_step_economy_37_agents", "uniform_layout_5_agents"])
+def test_background_specialisation_swaps_in_without_a_call(monkeypatch, case):
     """A configuration outside every compile-time instance's family starts on the generic kernel; aie_create has its
-    kernels compiled in the background (hiprtc, cached) and a later aie_step / aie_reset adopts them at its launch
-    boundary -- no call by the user.  Before, across and after the switch every tensor equals a twin that is pinned to
-    the generic kernel, bit for bit."""
+    kernels compiled in the background (hiprtc, cached) and a later aie_reset adopts them -- no call by the user.
+    Before, across and after the switch every tensor equals a twin that is pinned to the generic kernel, bit for bit.
+    The product's default path (tests/conftest.py switches it off for the rest of the suite) in every kernel family: the
+    gather-trade-build step / reset pair with either generator, the one-step-economy kernel, a scenario whose reset
+    draws layouts."""
     import time
 
     import torch
 
     monkeypatch.setenv("AIE_JIT_AUTO", "1")  # the product's default (tests/conftest.py switches it off for the suite)
-    cfg = dict(C2, n_agents=7, episode_length=40, starting_agent_coin=2)
-    env, twin = [make_env(cfg, n_envs=256, device="cuda:0") for _ in range(2)]
+    extra = {}
+    if case.startswith("gtb_7_agents"):
+        cfg = dict(C2, n_agents=7, episode_length=40, starting_agent_coin=2)
+        if case.endswith("fast_rng"):
+            extra = dict(rng_mode="fast")
+    elif case == "one_step_economy_37_agents":
+        cfg = dict(JIT_CASES["one_step_economy_37_agents"], episode_length=40)
+    else:
+        cfg = dict(JIT_CASES["build_gather_halfwidth"], episode_length=40)
+    env, twin = [make_env(cfg, n_envs=256, device="cuda:0", **extra) for _ in range(2)]
     be, bt = env.backend, twin.backend
     assert bt.lib.aie_select_step_kernel(bt.handle, 1) == 0
     assert be.lib.aie_step_kernel_instance(be.handle) == -1 and bt.lib.aie_step_kernel_instance(bt.handle) == -1
