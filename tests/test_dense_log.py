@@ -273,12 +273,14 @@ def test_hip_dense_log_matches_oracle(case):
 
 
 @pytest.mark.gpu
-def test_hip_replay_log_reproduces_the_logged_replica():
+@pytest.mark.parametrize("rng_mode", ["numpy", "fast"])
+def test_hip_replay_log_reproduces_the_logged_replica(rng_mode):
     """Replica 0 of a 6-replica batch is dense-logged; its replay log, fed to a fresh ONE-replica environment (the
-    reference's per-actor action dictionaries, seed states injected), reproduces its dense log and metrics."""
+    reference's per-actor action dictionaries, seed states injected), reproduces its dense log and metrics -- with
+    either generator behind the stream (rng_mode "fast": the seed states are the counter stream's four words)."""
     import torch
 
-    cfg = dict(CASES["gtb_5ag"])
+    cfg = dict(CASES["gtb_5ag"], rng_mode=rng_mode)
     env = make_env(cfg, n_envs=6, device="cuda:0", track_episode_metrics=True)
     env.seed(19)
     env.reset(force_dense_logging=True)
@@ -290,6 +292,7 @@ def test_hip_replay_log_reproduces_the_logged_replica():
         env.step({"a": a, "p": p})
     want, replay = env.previous_episode_dense_log, env.previous_episode_replay_log
     assert len(replay["step"]) == cfg["episode_length"] and replay["reset"]["seed_state"] is not None
+    assert replay["reset"]["seed_state"][0] == ("MT19937" if rng_mode == "numpy" else "PHILOX2X32")
 
     one = make_env(cfg, n_envs=1, device="cuda:0")
     one.seed(1234)  # irrelevant: every draw of the episode comes from the injected states
