@@ -139,8 +139,7 @@ def _respawn_counts(mode, E, steps, seed):
     o.t["stone"][...] = 0
     o.t["wood"][...] = 0
     z_a, z_p = np.zeros((E, 4), np.int32), np.zeros((E, 7), np.int32)
-    # park the agents on cells that are not source blocks?  NO-OP agents do not gather (move.py:126: only a MOVE
-    # collects), so respawned resources stay where they are
+    # (NO-OP agents do not gather -- move.py:126: only a move collects -- so respawned resources stay where they are)
     n_src = int(src[0].sum() + src[1].sum())
     filled = []
     for t in range(steps):
