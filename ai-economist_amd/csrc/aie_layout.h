@@ -401,9 +401,15 @@ static inline int aie__build_covid(const aie_config* c, aie_params* p, aie_tenso
   static const int want[3] = {AIE_COMP_COVID_CONTROL, AIE_COMP_COVID_SUBSIDY, AIE_COMP_COVID_VACCINE};
   if (c->n_components != 3) AIE__FAIL("the COVID scenario needs exactly its three components");
   if (c->dense_log_replicas != 0) AIE__FAIL("dense logs are not available for the COVID scenario");
-  for (int i = 0; i < 3; ++i)
-    if (c->components[i] != want[i])
-      AIE__FAIL("COVID components must be ControlUSStateOpenCloseStatus, FederalGovernmentSubsidy, VaccinationCampaign (in this order)");
+  /* each of the three exactly once, in any order: their steps touch disjoint state and the reference's rewards and
+   * observations do not depend on the order (live reference, tests/test_covid_component_order.py); the fused kernel runs
+   * them in the canonical one */
+  for (int k = 0; k < 3; ++k) {
+    int seen = 0;
+    for (int i = 0; i < 3; ++i) seen += c->components[i] == want[k];
+    if (seen != 1)
+      AIE__FAIL("COVID components must be ControlUSStateOpenCloseStatus, FederalGovernmentSubsidy and VaccinationCampaign, each once");
+  }
   if (v->num_stringency_levels < 1 || v->num_stringency_levels > 100) AIE__FAIL("num_stringency_levels out of range");
   if (v->beta_delay < 1 || v->beta_delay > 4096) AIE__FAIL("beta_delay out of range");
   if (v->filter_len < 1 || v->filter_len > 65536) AIE__FAIL("filter_len out of range");

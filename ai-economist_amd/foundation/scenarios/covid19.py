@@ -70,12 +70,18 @@ class CovidAndEconomyEnvironment(BaseEnvironment):
         assert ((m["weightage_on_marginal_agent_health_index"] >= 0)
                 & (m["weightage_on_marginal_agent_health_index"] <= 1)).all()
         assert 0 <= m["weightage_on_marginal_planner_health_index"] <= 1
+        # The three components in ANY order (round 5): each one's step touches state the other two neither read nor write
+        # in theirs (stringency levels / subsidies / vaccinations; the scenario step combines them afterwards) and the
+        # observation keys are sorted by name, so the reference itself produces the same rewards and observations for all
+        # six orders (checked on the live reference, tests/test_covid_component_order.py); the fused kernel has one.
         names = [c.name for c in self.components]
-        if names != ["ControlUSStateOpenCloseStatus", "FederalGovernmentSubsidy", "VaccinationCampaign"]:
+        if sorted(names) != ["ControlUSStateOpenCloseStatus", "FederalGovernmentSubsidy", "VaccinationCampaign"]:
             raise NotImplementedError(
-                "CovidAndEconomySimulation runs with ControlUSStateOpenCloseStatus, "
-                "FederalGovernmentSubsidy and VaccinationCampaign, in this order")
-        ctrl, sub, vac = self.components
+                "CovidAndEconomySimulation runs with exactly ControlUSStateOpenCloseStatus, "
+                "FederalGovernmentSubsidy and VaccinationCampaign (in any order)")
+        by_name = {c.name: c for c in self.components}
+        ctrl, sub, vac = (by_name["ControlUSStateOpenCloseStatus"], by_name["FederalGovernmentSubsidy"],
+                          by_name["VaccinationCampaign"])
         if ctrl.n_stringency_levels != m["num_stringency_levels"]:
             # covid19_components.py:169-178
             raise ValueError("The environment was not configured correctly. For the given model fit, you need "
