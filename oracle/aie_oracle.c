@@ -1904,6 +1904,11 @@ void aie_oracle_sample_policy_actions(const aie_params* p, uint8_t* arena, const
     *tf = (int32_t)t + 1;
   }
 }
+/* the sampler's building blocks (aie_layout.h), exported so that a CPU test can hold them to their Python transcription
+ * and to libm */
+double aie_oracle_sampler_log(double v) { return aie_sampler_log(v); }
+uint64_t aie_oracle_sampler_key(double score, int k) { return aie_sampler_key(score, k); }
+uint32_t aie_oracle_sampler_entry_rng(uint32_t slot_word, uint32_t k) { return aie_sampler_entry_rng(slot_word, k); }
 /* multi-threaded step for the cpu_baseline leg of bench.py */
 void aie_oracle_step_mt(const aie_params* p, uint8_t* arena, const int32_t* aa, const int32_t* ap, int nthreads) {
   int E = p->E;
