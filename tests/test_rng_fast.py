@@ -131,6 +131,54 @@ def test_fast_and_numpy_modes_differ_only_in_the_stream():
     assert ((adv >= 5 * 2500) & (adv < 5 * 2600)).all(), adv
 
 
+def test_fast_mode_step_consumes_the_stream_exactly_as_documented():
+    """An independent transcription of ONE step's draws in Python (Philox through the known-answer-checked function,
+    NumPy's consumers written out): Build's and Gather's agent-order permutations (world.py:418-422: Fisher-Yates from
+    the top, masked-rejection integers), then 2 H W doubles for the regeneration -- Wood's plane first, then Stone's,
+    two words per double (layout_from_file.py:394-403) -- predicts which emptied source cells respawn and where the
+    stream stands afterwards.  The device is compared with the oracle; this compares the oracle with the documentation."""
+    E, p_regen = 3, 0.3
+    env, o = _oracle(dict(C2, resource_regen_prob=p_regen), E, 21, rng_mode="fast")
+    flags = o.t["cell_flags"].reshape(E, -1)
+    o.t["stone"][...] = 0
+    o.t["wood"][...] = 0
+    st0, pos0 = o.t["mt"].copy(), o.t["mt_pos"].copy()
+    o.step(np.zeros((E, 4), np.int32), np.zeros((E, 7), np.int32))
+    HW = 625
+    for e in range(E):
+        key, blk, salt = int(st0[e, 0]), int(st0[e, 1]), int(st0[e, 2])
+        g = blk * 624 + int(pos0[e])  # linear word number of the next draw (pos == 624: the first word of block + 1)
+
+        def word(i):
+            pair = i >> 1
+            return _philox(pair & 0xffffffff, (pair >> 32) | salt, key)[i & 1]
+
+        for _ in range(2):  # Build, then Gather: np.random.permutation(4)
+            for i in (3, 2, 1):
+                mask = 3 if i >= 2 else 1
+                while True:
+                    w = word(g) & mask
+                    g += 1
+                    if w <= i:
+                        break
+        wood = np.zeros(HW, np.int64)
+        stone = np.zeros(HW, np.int64)
+        for d in range(2 * HW):
+            a, b = word(g) >> 5, word(g + 1) >> 6
+            g += 2
+            u = (a * 67108864.0 + b) / 9007199254740992.0
+            cell = d % HW
+            src = flags[e, cell] & (4 if d < HW else 2)
+            if src and u < p_regen:
+                (wood if d < HW else stone)[cell] = 1
+        assert np.array_equal(o.t["wood"][e].reshape(-1), wood), e
+        assert np.array_equal(o.t["stone"][e].reshape(-1), stone), e
+        assert wood.sum() + stone.sum() > 5
+        # where the stream stands: the oracle keeps (block, position in the block) with position in 1 .. 624
+        blk1, pos1 = int(o.t["mt"][e, 1]), int(o.t["mt_pos"][e])
+        assert blk1 * 624 + pos1 == g, (blk1, pos1, g)
+
+
 # ---- distribution: oracle(fast) against oracle(MT19937) and against theory -------------------------------------------------
 def _respawn_counts(mode, E, steps, seed):
     extra = dict(rng_mode="fast") if mode == "fast" else {}
