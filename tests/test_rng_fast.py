@@ -5,6 +5,7 @@ base_env.py:481-494).  The parity chain, so that nothing here is "statistical on
     reference == oracle(MT19937) bit for bit         tests/test_oracle_vs_reference.py, tests/golden/ (unchanged)
     oracle(fast) differs from oracle(MT19937) in ONE function, rng_u32 (oracle/aie_oracle.c): the words drawn
     Philox2x32-10 itself                             Random123's known-answer vectors (below)
+    how oracle(fast) consumes the stream             an independent Python transcription of one step's draws (below)
     HIP(fast) == oracle(fast) bit for bit            the -m gpu tests below: every state field, every observation
     oracle(fast) ~ oracle(MT19937) in distribution   chi-square / binomial checks below (regeneration rate, placement)
 """
