@@ -140,6 +140,39 @@ __global__ void aie_set_flags_kernel(const aie_params P, uint8_t* __restrict__ a
   *w = (*w & 0x00ffffffu) | (fl << 24);
 }
 
+// The replicas' source-double lists (record fields o_src_n / o_src_list, aie_layout.h) from the cells' flag bytes in
+// device memory: one wavefront per replica, the order of aie::build_src_list (Wood cells ascending, then Stone cells).
+// Launched wherever the flags change outside a reset (aie_set_layout, aie_upload of the cells).
+__global__ void __launch_bounds__(64) aie_src_list_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena) {
+  const aie_params& P = *params;
+  const int e = (int)blockIdx.x, lane = (int)threadIdx.x, HW = P.HW;
+  if (!P.o_src_list || e >= P.E) return;
+  uint8_t* rec = arena + P.a_records + (int64_t)e * P.rec_bytes;
+  const uint8_t* cb = rec + P.o_cells;
+  uint16_t* lst = reinterpret_cast<uint16_t*>(rec + P.o_src_list);
+  for (int k = lane; k < AIE_SRC_CAP; k += 64) lst[k] = 0;
+  int base = 0;
+  for (int rs = 0; rs < 2; ++rs) {
+    const uint32_t bit = rs == 0 ? AIE_CELL_WOOD_SRC : AIE_CELL_STONE_SRC;
+    for (int q0 = 0; q0 < HW; q0 += 64) {
+      const int q = q0 + lane;
+      const bool on = q < HW && (cb[4 * q + 3] & bit);
+      const uint64_t mask = __ballot(on);
+      const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (on && slot < AIE_SRC_CAP) lst[slot] = (uint16_t)(rs * HW + q);
+      base += __popcll(mask);
+    }
+  }
+  if (lane == 0) *reinterpret_cast<int32_t*>(rec + P.o_src_n) = base;
+}
+static int aie_rebuild_src_lists(aie_env* env) {
+  if (env->P.c.scenario != AIE_SCN_GTB || !env->P.o_src_list) return AIE_OK;
+  hipLaunchKernelGGL(aie_src_list_kernel, dim3((unsigned)env->P.E), dim3(64), 0, 0, env->d_params, env->arena);
+  AIE_HIP_CHECK(env, hipGetLastError());
+  AIE_HIP_CHECK(env, hipDeviceSynchronize());
+  return AIE_OK;
+}
+
 // Workgroups of `lds` dynamic LDS bytes a gfx950 CU holds at once: 160 KB, allocated in 1280-byte granules, at most
 // 16 workgroups of two waves (8 waves per SIMD).
 static inline int aie_workgroups_per_cu(size_t lds) {
@@ -336,6 +369,8 @@ static int copy_tensor(aie_env* env, const char* name, void* host, int64_t bytes
 
 int aie_upload(aie_env* env, const char* name, const void* host, int64_t bytes) {
   const int rc = copy_tensor(env, name, const_cast<void*>(host), bytes, true);
+  if (rc == AIE_OK && (strcmp(name, "cells") == 0 || strcmp(name, "cell_flags") == 0))
+    return aie_rebuild_src_lists(env);  // the regeneration's source doubles follow the flags (o_src_list)
   if (rc == AIE_OK && env->P.c.scenario == AIE_SCN_COVID && strcmp(name, "model_unemp_conv_filters") == 0) {
     // float32-valued taps (the reference's) let the window-sum kernel keep its LDS tap table in float32
     const double* taps = static_cast<const double*>(host);
@@ -377,6 +412,7 @@ int aie_set_layout(aie_env* env, const uint8_t* stone_src, const uint8_t* wood_s
   AIE_HIP_CHECK(env, hipGetLastError());
   AIE_HIP_CHECK(env, hipDeviceSynchronize());
   AIE_HIP_CHECK(env, hipFree(dfl));
+  if (const int rc = aie_rebuild_src_lists(env)) return rc;
   if (aie__shared_src_list(&P.c)) {
     // the regeneration's source doubles, once for the whole batch (aie_params.a_src_list): double d of a step's 2 H W
     // np.random.rand values targets Wood cell d (d < H W) or Stone cell d - H W (layout_from_file.py:394-403)
@@ -545,6 +581,7 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
                          const NextActions& next_in) {
   if (!env) return AIE_E_INVALID;
   NextActions next = next_in;
+  next.E = (int32_t)env->P.E;
   if (env->rew_log) {  // reward log (aie_set_reward_log): the replicas pick and advance their slot themselves
     next.rew_log = env->rew_log;
     next.rew_slots = env->rew_log_slots;

@@ -64,8 +64,9 @@ struct Ctx {
   uint8_t* locmap;   // LDS [HW] 0 = empty, i+1 = agent i
   double* fscr;      // LDS f64 scratch
   float* stage;      // LDS staging of the small observation vectors (also: MT word dump during regen)
-  uint16_t* srcl;    // LDS [AIE_SRC_CAP] regen doubles that target a source block
-  int32_t* srcn;     // LDS [1] number of source doubles found (may exceed AIE_SRC_CAP)
+  uint16_t* srcl;    // LDS [AIE_SRC_CAP] regen doubles that target a source block: the record's own list (o_src_list), nullptr
+                     // where the batch shares one (shared_src_list)
+  int32_t* srcn;     // LDS [4] scratch words ([2]: the dense log's event rows of this step)
   int32_t* mflags;   // LDS [n] per-agent mask bits
   int32_t* dirty;    // LDS [4 + AIE_DIRTY_CAP/2]: count, moved-agent mask (2 words), pad, uint16 cell list
   uint8_t* snap;     // LDS [2][HW]: pre-step max(map, source block) per resource (P.regen_general only), else nullptr
@@ -141,7 +142,7 @@ __host__ __device__ inline size_t lds_bytes_base(const aie_params& P) {
   b += ((size_t)P.HW + 15) / 16 * 16;
   b += (size_t)fscr_doubles(P) * 8;
   b += stage_bytes(P);
-  b += AIE_SRC_CAP * 2 + 16 + (size_t)pad4(P.n) * 4;
+  b += 16 + (size_t)pad4(P.n) * 4;  // (the source list is part of the record image since round 6)
   b += 16 + AIE_DIRTY_CAP * 2;
   b = (b + 15) / 16 * 16;
   return b;
@@ -198,8 +199,7 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R
   q += fscr_doubles(P) * 8;
   float* stage = reinterpret_cast<float*>(q);
   q += stage_bytes(P);
-  uint16_t* srcl = reinterpret_cast<uint16_t*>(q);
-  q += AIE_SRC_CAP * 2;
+  uint16_t* srcl = P.o_src_list ? reinterpret_cast<uint16_t*>(lds + P.o_src_list) : nullptr;
   int32_t* srcn = reinterpret_cast<int32_t*>(q);
   q += 16;
   int32_t* mflags = reinterpret_cast<int32_t*>(q);
@@ -255,8 +255,16 @@ __device__ __forceinline__ double bcast(double v, int lane) {
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// (base and size are wave-uniform at every call site.  They go through v_readfirstlane -- free for a value that already
+// sits in scalar registers -- because a descriptor the instruction selector happened to build in vector registers makes
+// EVERY store through it a "waterfall" loop over its distinct values: round 6 met that when the kernels' first address
+// computations moved, +900 vector instructions in one instance.)
 __device__ __forceinline__ BufRsrc make_rsrc(void* base, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uint64_t)lo | ((uint64_t)hi << 32)), 0,
+                                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 __device__ __forceinline__ void buf_store_f32(BufRsrc r, float v, int voff, int soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
@@ -362,10 +370,9 @@ __device__ __forceinline__ void fast_pair(uint32_t key, uint32_t blk, uint32_t s
   philox2x32_10((uint32_t)pair, (uint32_t)(pair >> 32) | salt, key, o0, o1);
 }
 
-// Also collects, with LDS atomics, the list of regeneration draws that matter: double d of
-// the step's 2*H*W np.random.rand values targets Wood cell d (d < HW) or Stone cell d-HW,
-// and only source-block cells can respawn (layout_from_file.py:394-403).
-// *c.srcn must have been zeroed (and a barrier passed) before the call.
+// (Until round 5 this copy also scanned the cells' flag bytes for the regeneration's source doubles, every step: 250 of a
+// replica-step's 2 150 vector instructions on BASELINE configs[1].  The list is a record field now, o_src_list, kept by
+// the reset kernel.)
 // `wave` of `nwaves` copies every nwaves-th 16-byte unit; wave `key_wave` also takes the MT19937 key (registers).
 __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m, int wave = 0,
                                             int nwaves = 1, int key_wave = 0) {
@@ -373,29 +380,7 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
   const uint4* src = reinterpret_cast<const uint4*>(g);
   uint4* dst = reinterpret_cast<uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
-  const int HW = c.P.HW;
-  for (int q = wave * AIE_NT + c.tid; q < nq; q += nwaves * AIE_NT) {
-    const uint4 v = src[q];
-    dst[q] = v;
-    const int cell0 = 4 * q - (c.P.o_cells >> 2);
-    if (!shared_src_list(c.P) && cell0 >= 0 && cell0 < HW) {  // (shared fixed layouts: the batch's one list, a_src_list)
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t fl = w[k] >> 24;
-        if ((fl & (AIE_CELL_STONE_SRC | AIE_CELL_WOOD_SRC)) && cell0 + k < HW) {
-          if (fl & AIE_CELL_WOOD_SRC) {
-            const int slot = atomicAdd(c.srcn, 1);
-            if (slot < AIE_SRC_CAP) c.srcl[slot] = (uint16_t)(cell0 + k);
-          }
-          if (fl & AIE_CELL_STONE_SRC) {
-            const int slot = atomicAdd(c.srcn, 1);
-            if (slot < AIE_SRC_CAP) c.srcl[slot] = (uint16_t)(HW + cell0 + k);
-          }
-        }
-      }
-    }
-  }
+  for (int q = wave * AIE_NT + c.tid; q < nq; q += nwaves * AIE_NT) dst[q] = src[q];
   if (wave != key_wave || rng_fast(c.P)) return;  // (the counter stream's state came with the image: mt_fast_attach)
   const uint32_t* key = reinterpret_cast<const uint32_t*>(g + c.P.o_mt);
 #pragma unroll
@@ -403,12 +388,15 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
   m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
 }
 __device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m, int wave = 0,
-                                             int nwaves = 1, int key_wave = 0) {
+                                             int nwaves = 1, int key_wave = 0, bool with_src_list = false) {
   uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
   uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
-  const int nq = rec_lds_bytes(c.P) >> 4;
+  // (the source list -- the image's last fields -- only changes where a kernel rebuilds it: `with_src_list`)
+  const int nq = (with_src_list || !c.P.o_src_list ? rec_lds_bytes(c.P) : c.P.o_src_n) >> 4;
   for (int q = wave * AIE_NT + c.tid; q < nq; q += nwaves * AIE_NT) dst[q] = src[q];
+  if (!with_src_list && c.P.o_src_list && rng_fast(c.P) && wave == 0 && c.tid == 0)  // the counter stream's state lies behind the list
+    reinterpret_cast<uint4*>(g + c.P.o_mt)[0] = reinterpret_cast<const uint4*>(c.rec + c.P.o_mt)[0];
   if (wave != key_wave || rng_fast(c.P)) return;  // the generator's rows are in that wave's registers
   uint32_t* key = reinterpret_cast<uint32_t*>(g + c.P.o_mt);
 #pragma unroll
@@ -622,7 +610,12 @@ __device__ __forceinline__ double np_seq_elem(const double* a, int n, int mode, 
   const int r = (int)(((uint32_t)idx * M) >> 16);
   return fabs(a[r] - a[idx - r * n]);
 }
-__device__ __attribute__((noinline)) double np_sum_leaf(const double* a, int n, int mode, uint32_t M, int o, int m,
+#ifdef AIE_EXP_NOSCRATCH
+__device__ __forceinline__ double np_sum_leaf(
+#else
+__device__ __attribute__((noinline)) double np_sum_leaf(
+#endif
+const double* a, int n, int mode, uint32_t M, int o, int m,
                                                         int lane) {
   if (m < 8) {
     double res = -0.0;
@@ -700,12 +693,20 @@ struct MTL {
 __device__ __forceinline__ int draw_window_publish(uint32_t* w, int cap, const MT& m, int pos, int lane) {
   const int avail = cap < AIE_MT_N - pos ? cap : AIE_MT_N - pos;
   const int r0 = pos >> 6;
+  // (the rows as opaque register values: left to itself the optimiser turns the select chain below into ONE load with a
+  // run-time index -- and the ten rows into a stack array in scratch memory for it)
+  uint32_t rr[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    rr[j] = m.r[j];
+    asm("" : "+v"(rr[j]));
+  }
   for (int d = 0; d * 64 < cap + 64; ++d) {  // lane l of row r holds word 64 r + l
     const int r = r0 + d;
     if (r > 9) break;
-    uint32_t v = m.r[0];
+    uint32_t v = rr[0];
 #pragma unroll
-    for (int j = 1; j < 10; ++j) v = (r == j) ? m.r[j] : v;
+    for (int j = 1; j < 10; ++j) v = (r == j) ? rr[j] : v;
     const int slot = 64 * r + lane - pos;
     if (slot >= 0 && slot < avail) w[slot] = mt_word(m, v);
   }
@@ -784,7 +785,12 @@ __device__ __attribute__((noinline, cold)) Refill rng_refill_fast(uint32_t* st, 
   return Refill{pos, avail, twisted};
 }
 __device__ __forceinline__ uint32_t rng_u32(MTL& l, int lane) {
+#ifdef AIE_EXP_NOSCRATCH  // (timing experiment only: no refill, wrong numbers past the window)
+  if (l.pos >= l.base + l.avail) { l.pos += 1; return (uint32_t)l.pos * 2654435761u; }
+  if (false) {
+#else
   if (__builtin_expect(l.pos >= l.base + l.avail, 0)) {
+#endif
     const Refill r = l.fast ? rng_refill_fast(l.gkey, l.w, l.cap, l.pos, lane) : rng_refill(l.gkey, l.w, l.cap, l.pos, lane);
     l.pos = uni(r.pos);  // (a function's results come back in vector registers: keep the bookkeeping scalar)
     l.base = l.pos;
@@ -940,7 +946,9 @@ __device__ __forceinline__ void agents_store(const Ctx& c, const Agents& A) {
 
 // parse_actions base_env.py:552-556 -> base_agent.py:407-438: lane i decodes agent i's
 // action into its packed per-subspace word; lane b decodes planner bracket b.
-__device__ __forceinline__ void decode_actions(const Ctx& c, Agents& A, const int32_t* __restrict__ aa,
+// Returns the AIE_ERR_* bits of out-of-range indices (wave-uniform); the caller ORs them into the record's error_flags
+// once the record is in LDS -- the action loads themselves leave ahead of it (step_body).
+__device__ __forceinline__ int decode_actions(const Ctx& c, Agents& A, const int32_t* __restrict__ aa,
                                const int32_t* __restrict__ ap) {
   const aie_params& P = c.P;
   const int i = c.tid;
@@ -980,8 +988,7 @@ __device__ __forceinline__ void decode_actions(const Ctx& c, Agents& A, const in
     }
     c.act_p[i] = v;
   }
-  const int err = (__ballot(bad_a) ? AIE_ERR_AGENT_ACTION : 0) | (__ballot(bad_p) ? AIE_ERR_PLANNER_ACTION : 0);
-  if (err && i == 0) *R_I32(c, o_error_flags) |= err;
+  return (__ballot(bad_a) ? AIE_ERR_AGENT_ACTION : 0) | (__ballot(bad_p) ? AIE_ERR_PLANNER_ACTION : 0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1900,12 +1907,9 @@ struct SrcList {
 };
 __device__ __forceinline__ SrcList src_list_from_lds(const Ctx& c) {
   SrcList L;
-  L.S = uni(*c.srcn);
+  L.S = uni(*R_I32(c, o_src_n));
 #pragma unroll
-  for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) {
-    const int j = k * AIE_NT + c.tid;
-    L.d[k] = (j < L.S && j < AIE_SRC_CAP) ? (int)c.srcl[j] : 0;
-  }
+  for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) L.d[k] = (int)c.srcl[k * AIE_NT + c.tid];  // (entries past the count are zero)
   return L;
 }
 __device__ __forceinline__ SrcList src_list_from_arena(const Ctx& c, const uint8_t* __restrict__ arena) {
@@ -1930,7 +1934,11 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, const S
     AIE_WSYNC();
   }
   const int S = src.S;
+#ifdef AIE_EXP_NOSCRATCH
+  if (false) {
+#else
   if (S > AIE_SRC_CAP) {
+#endif
     if (m.fast && m.pos < AIE_MT_N) mt_fast_rows(m, c.tid);  // (the counter stream keeps no rows between steps)
     scenario_step_regen_rows(c, m);
     return;
@@ -2595,6 +2603,30 @@ __device__ __forceinline__ void rebuild_locmap(const Ctx& c) {
   AIE_WSYNC();
 }
 
+// The replica's source doubles from the cells' flag bytes (LDS image), ascending: Wood cells, then Stone cells
+// (layout_from_file.py:394-403: np.random.rand(2, H, W) is consumed for Wood first).  One wave; count and list land in
+// the record image (o_src_n, o_src_list; a count above AIE_SRC_CAP selects the row-by-row regeneration).
+__device__ __forceinline__ void build_src_list(const Ctx& c) {
+  if (!c.P.o_src_list) return;
+  const int HW = c.P.HW;
+  const uint8_t* cb = reinterpret_cast<const uint8_t*>(R_CELLS(c));
+  for (int k = c.tid; k < AIE_SRC_CAP; k += AIE_NT) c.srcl[k] = 0;
+  int base = 0;
+  for (int rs = 0; rs < 2; ++rs) {
+    const uint32_t bit = rs == 0 ? AIE_CELL_WOOD_SRC : AIE_CELL_STONE_SRC;
+    for (int q0 = 0; q0 < HW; q0 += AIE_NT) {
+      const int q = q0 + c.tid;
+      const bool on = q < HW && (cb[4 * q + 3] & bit);
+      const uint64_t mask = __ballot(on);
+      const int slot = base + __popcll(mask & lanemask_lt(c.tid));
+      if (on && slot < AIE_SRC_CAP) c.srcl[slot] = (uint16_t)(rs * HW + q);
+      base += __popcll(mask);
+    }
+  }
+  if (c.tid == 0) *R_I32(c, o_src_n) = base;
+  AIE_WSYNC();
+}
+
 }  // namespace aie
 
 // ======================================================================================
@@ -2636,6 +2668,10 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
   // kernel (aie_capi.hip: aie_step_impl)
   int32_t e_lo, e_hi;
   int32_t masked;  // aie_step_sample_next_masked (COVID): the next actions are drawn among what the new masks allow
+  // The replica count, by value: a workgroup needs it for its very first decision (which replica it is), and as a
+  // kernel argument it arrives with the argument segment instead of behind a second, dependent round trip to the
+  // parameter block (round 6: the caches are cold at every launch, a first touch from the far XCDs takes ~1 us).
+  int32_t E;
 };
 // This step's slot of the reward log: the replica's slot counter selects it and moves on (`writer`: the one lane that
 // stores the counter back; every lane of the wave calls this with the same fields).
@@ -2683,66 +2719,56 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
 #else
   const int skip = 0;
 #endif
-  const int e_blk = replica_of_block((int)blockIdx.x, R.E);
+  static_assert(NW == 2, "a replica is a workgroup of two wavefronts");
+  const int e_blk = replica_of_block((int)blockIdx.x, next.E);  // (the replica count travels as a kernel argument)
   if (next.e_hi > 0 && (e_blk < next.e_lo || e_blk >= next.e_hi)) return;  // (uniform over the workgroup, ahead of every barrier)
-  const Ctx c = make_ctx(P, R, lds, e_blk, (int)(threadIdx.x & (AIE_NT - 1)), arena, LOG, skip,
+  const bool FAST = rng_fast(P);  // the counter stream (include/aie.h: AIE_RNG_FAST); compile-time in the instances
+  const int tid0 = (int)(threadIdx.x & (AIE_NT - 1));
+  uint8_t* grec = arena + (int64_t)e_blk * P.rec_bytes;  // (a_records == 0: the records open the arena, aie_layout.h)
+  uint32_t* gkey = reinterpret_cast<uint32_t*>(grec + P.o_mt);
+  const Ctx c = make_ctx(P, R, lds, e_blk, tid0, arena, LOG, skip,
                          /*lds_tables=*/SPEC >= 0);  // (the generic kernel keeps the parameter block's arrays: a pointer
                                                      // that may be LDS or global at run time costs it flat accesses and spills)
-  MT m;
-  mt_init(m, P);
-  const bool FAST = rng_fast(P);  // the counter stream (include/aie.h: AIE_RNG_FAST); compile-time in the instances
-  Agents A;
-  if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x] = wall_clock64();
   const bool SHL = shared_src_list(P);  // one list of source doubles for the whole batch (a_src_list)
-  SrcList src;
-  src.S = 0;
-#pragma unroll
-  for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) src.d[k] = 0;
-  if (threadIdx.x == 0) {
-    *c.srcn = 0;
-    c.dirty[0] = 0;
-    c.dirty[1] = 0;
-    c.dirty[2] = 0;
-    c.dirty[3] = 0;
-  }
-  __syncthreads();
-  if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
-  uint8_t* grec = arena + R.a_records + (int64_t)c.e * P.rec_bytes;
-  uint32_t* gkey = reinterpret_cast<uint32_t*>(grec + P.o_mt);
-  MTL ml{reinterpret_cast<uint32_t*>(c.stage), 0, 0u, -AIE_MT_N, 0, 0u, 0u, 0, 0, 0,
-         FAST ? reinterpret_cast<uint32_t*>(c.rec + P.o_mt) : gkey, stage_window_words(P), FAST};
-  if (LOG && R.dev_draw_window > 0 && R.dev_draw_window < ml.cap) ml.cap = R.dev_draw_window;  // tests: force refills
-  // the generator's position, ahead of the record: the last wave turns the words the components will draw into the
-  // LDS draw window while the record copy is in flight
-  int gpos = 0;
-  if (wid == NW - 1) gpos = *reinterpret_cast<const int32_t*>(grec + P.o_mt_pos);
-  load_record(c, arena, m, wid, NW, /*key_wave=*/-1);  // the generator state stays in HBM for now
-  if (wid == NW - 1) {
-    if (FAST) draw_window_publish_fast(ml.w, ml.cap, (uint32_t)uni((int)gkey[0]), (uint32_t)uni((int)gkey[1]), (uint32_t)uni((int)gkey[2]), uni(gpos), c.tid);
-    else draw_window_publish_from_hbm(ml.w, ml.cap, gkey, uni(gpos), c.tid);
-  }
-  if (SPEC >= 0 && wid == NW - 1 && const_tables_in_lds(P)) {
-    // the small constant tables (Ctx.rtab / mtab) -> LDS, published by the barrier below
-    if (P.has_tax && P.c.tax_model == AIE_TAX_MODEL_WRAPPER)
-      for (int q = c.tid; q < P.c.tax_n_disc_rates; q += AIE_NT) const_cast<double*>(c.rtab)[q] = R.c.tax_disc_rates[q];
-    for (int q = c.tid; q < P.MA; q += AIE_NT) const_cast<uint32_t*>(c.mtab)[q] = P.mask_test[q];
-  }
-  if (wid == 0) decode_actions(c, A, act_a, act_p);
-  __syncthreads();  // the record is in LDS
-  if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
-  if (NW == 1 || wid == 1) rebuild_locmap(c);
+  uint32_t* const draw_w = reinterpret_cast<uint32_t*>(c.stage);  // the components' draw window (LDS)
+  int draw_cap = stage_window_words(P);
+  if (LOG && R.dev_draw_window > 0 && R.dev_draw_window < draw_cap) draw_cap = R.dev_draw_window;  // tests: force refills
+  // With many agents the first wave's tail (flat vectors of every agent, utilities) is the longer one: it then keeps a
+  // priority above the waves that are still loading (measured at 10 agents: 42.3 -> 41.9 us; at 4 agents any
+  // priority above 0 costs 0.8-1.4 us)
+  const int w0_tail_prio = P.n >= 8 ? 2 : 0;
+  // Where the rewards run.  With MT19937 the second wave's tail (four twists of regeneration, map observations, masks) is
+  // as long as the first wave's (flat vectors, rewards); with the counter stream the regeneration shrinks to a few Philox
+  // blocks and the first wave's tail is the long pole (tools/block_trace.py: 7.1 us against 3.7 us), so the rewards move
+  // behind the masks on the second wave -- up to 7 agents (A/B on one box, tools/ab_variants.sh: C2f 22.1 -> 21.7 us; with
+  // ten agents the utilities' n^2 gini terms make them the longer piece: C3f 35.3 -> 37.4 us, so they stay where they
+  // were).  They share no scratch slot with the flat-vector writer (current_metrics).
+  const bool REW_ON_W1 = FAST && P.n < 8;
+  // The two waves run two separate ARMS from here to the end, each with its own copy of the four workgroup barriers
+  // (the branch is wave-uniform, every wave passes the same number of them): a value that only one wave carries --
+  // the agents' registers and the draw cache of the first, the generator's ten rows of the second -- is then live in
+  // its own arm only and does not count against the other wave's code in the 64-register budget.
   if (wid == 0) {
+    // ---------------- first wave: actions, components, flat vectors, rewards ----------------
+    Agents A;
+    const int act_err = decode_actions(c, A, act_a, act_p);  // (the loads ride beside the record's; c.act_p is LDS scratch)
+    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x] = wall_clock64();
+    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
+    MT none;
+    load_record(c, arena, none, 0, NW, /*key_wave=*/-1);
+    __syncthreads();  // (2) the record is in LDS
+    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 8] = wall_clock64();
+    MTL ml{draw_w, 0, 0u, -AIE_MT_N, 0, 0u, 0u, 0, 0, 0, FAST ? reinterpret_cast<uint32_t*>(c.rec + P.o_mt) : gkey, draw_cap, FAST};
     ml.pos = ml.base = uni(*R_I32(c, o_mt_pos));
-    ml.avail = ml.cap < AIE_MT_N - ml.pos ? ml.cap : AIE_MT_N - ml.pos;  // what draw_window_publish_from_hbm left
+    ml.avail = ml.cap < AIE_MT_N - ml.pos ? ml.cap : AIE_MT_N - ml.pos;  // what the second wave's draw_window_publish left
     if (FAST) {  // (draw_window_publish_fast: whole pairs, one word less when the position is odd)
       const int covered = 128 * ((ml.cap + 127) >> 7) - (ml.pos & 1);
       if (ml.avail > covered) ml.avail = covered;
     }
     agents_load(c, A);
+    if (act_err && c.tid == 0) *R_I32(c, o_error_flags) |= act_err;
     if (P.has_cda && !(skip & 1)) cda_decay_price_history(c);
-  }
-  __syncthreads();  // occupancy map rebuilt
-  if (wid == 0) {
+    __syncthreads();  // (3) occupancy map rebuilt
     if (c.tid == 0) *R_I32(c, o_timestep) += 1;
     if (c.ev && c.tid == 0) c.srcn[2] = 0;
     __builtin_amdgcn_s_setprio(3);  // the serial dynamics are the replica's critical path
@@ -2771,55 +2797,62 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       c.dirty[3] = ml.tw;
     }
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 5] = wall_clock64();
+    __syncthreads();  // (4) components done; the generator's position (and, after a refill that twisted, its state in HBM) is final
+    // flat observation vectors and rewards: neither looks at the map
+    if (w0_tail_prio) __builtin_amdgcn_s_setprio(2);
+    if (!(skip & 8)) write_flat_observations(c, arena);
+    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
+    if (!REW_ON_W1) step_rewards_and_done(c, arena, next, skip);
+    if (w0_tail_prio) __builtin_amdgcn_s_setprio(0);
+    __syncthreads();  // (5)
+    if (!(skip & 32)) store_record(c, arena, none, 0, NW, /*key_wave=*/NW - 1);
+    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 7] = wall_clock64();
   } else {
-    // the second wave has nothing to do until the components are done: the generator state for the regeneration
-    // (rows -> registers, the loads go out first; re-read below if the components twisted it) ...
-    if (SHL) src = src_list_from_arena(c, arena);  // (the loads ride under the first wave's dynamics)
-    if (!FAST) {
-      const uint32_t* key = gkey;
-#pragma unroll
-      for (int j = 0; j < 9; ++j) m.r[j] = key[64 * j + c.tid];
-      m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
+    // ---------------- second wave: generator, occupancy map, regeneration, map observations, masks ----------------
+    MT m;
+    mt_init(m, P);
+    const int gpos = *reinterpret_cast<const int32_t*>(grec + P.o_mt_pos);
+    load_record(c, arena, m, 1, NW, /*key_wave=*/-1);
+    // behind its share of the copy: the words the components will draw -> the LDS draw window (two or three rows of the
+    // generator's state, fetched from HBM; the state itself follows while the components run)
+    if (FAST) draw_window_publish_fast(draw_w, draw_cap, (uint32_t)uni((int)gkey[0]), (uint32_t)uni((int)gkey[1]), (uint32_t)uni((int)gkey[2]), uni(gpos), c.tid);
+    else draw_window_publish_from_hbm(draw_w, draw_cap, gkey, uni(gpos), c.tid);
+    if (SPEC >= 0 && const_tables_in_lds(P)) {
+      // the small constant tables (Ctx.rtab / mtab) -> LDS, published by the barrier below
+      if (P.has_tax && P.c.tax_model == AIE_TAX_MODEL_WRAPPER)
+        for (int q = c.tid; q < P.c.tax_n_disc_rates; q += AIE_NT) const_cast<double*>(c.rtab)[q] = R.c.tax_disc_rates[q];
+      for (int q = c.tid; q < P.MA; q += AIE_NT) const_cast<uint32_t*>(c.mtab)[q] = P.mask_test[q];
     }
-    // ... and the next step's random actions
+    __syncthreads();  // (2)
+    rebuild_locmap(c);
+    __syncthreads();  // (3)
+    // nothing to do until the components are done but the next step's random actions
+    SrcList src;
+    src.S = 0;
+#pragma unroll
+    for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) src.d[k] = 0;
+    if (SHL) src = src_list_from_arena(c, arena);  // (the loads ride under the first wave's dynamics)
+    if (!FAST) {  // the generator's rows -> registers (re-read after the barrier if the components twisted the state)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) m.r[j] = gkey[64 * j + c.tid];
+      m.r[9] = c.tid < 48 ? gkey[576 + c.tid] : 0u;
+    }
     if (next.a || next.p) {
       const int per_env = P.n * P.act_a_width + P.act_p_width;
       const int st = uni(*R_I32(c, o_sample_t));  // (the first wave does not touch this field)
       for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, (int64_t)st, c.e, j, next.a, next.p);
       if (c.tid == 0) *R_I32(c, o_sample_t) = st + 1;
     }
-  }
-  __syncthreads();  // components done; the generator's position (and, after a refill that twisted, its state in HBM) is final
-  // With many agents the first wave's tail (flat vectors of every agent, utilities) is the longer one: it then keeps a
-  // priority above the waves that are still loading (measured at 10 agents: 42.3 -> 41.9 us; at 4 agents any
-  // priority above 0 costs 0.8-1.4 us)
-  const int w0_tail_prio = P.n >= 8 ? 2 : 0;
-  // Where the rewards run.  With MT19937 the second wave's tail (four twists of regeneration, map observations, masks) is
-  // as long as the first wave's (flat vectors, rewards); with the counter stream the regeneration shrinks to a few Philox
-  // blocks and the first wave's tail is the long pole (tools/block_trace.py: 7.1 us against 3.7 us), so the rewards move
-  // behind the masks on the second wave -- up to 7 agents (A/B on one box, tools/ab_variants.sh: C2f 22.1 -> 21.7 us; with
-  // ten agents the utilities' n^2 gini terms make them the longer piece: C3f 35.3 -> 37.4 us, so they stay where they
-  // were).  They share no scratch slot with the flat-vector writer (current_metrics).
-  const bool REW_ON_W1 = FAST && NW == 2 && P.n < 8;
-  if (wid == 0) {
-    // first wave: flat observation vectors (they do not look at the map)
-    if (w0_tail_prio) __builtin_amdgcn_s_setprio(2);
-    if (!(skip & 8)) write_flat_observations(c, arena);
-    if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
-    if (!REW_ON_W1) step_rewards_and_done(c, arena, next, skip);  // utilities do not look at the map either
-    if (w0_tail_prio) __builtin_amdgcn_s_setprio(0);
-  }
-  if (NW == 1 || wid == 1) {
-    // second wave: resource regeneration (the generator's rows are in its registers), then what
-    // depends on the map: incremental map observations, action masks
-    if (NW == 2) __builtin_amdgcn_s_setprio(2);  // from here on this wave is the critical one (the first has slack)
-    // a refill that twisted (components drew past word 623) left the new state in HBM
+    __syncthreads();  // (4)
+    // resource regeneration (the generator's rows are in this wave's registers), then what depends on the map:
+    // incremental map observations, action masks
+    __builtin_amdgcn_s_setprio(2);  // from here on this wave is the critical one (the first has slack)
     if (FAST) {  // the stream's state is in the LDS image (the components may have moved it to the next block)
       const uint32_t* st = R_U32(c, o_mt);
       m.fkey = (uint32_t)uni((int)st[0]);
       m.fblk = (uint32_t)uni((int)st[1]);
       m.fsalt = (uint32_t)uni((int)st[2]);
-    } else if (NW == 1 || uni(c.dirty[3]) != 0) {
+    } else if (uni(c.dirty[3]) != 0) {  // a refill that twisted (components drew past word 623) left the new state in HBM
       mt_rows_from_hbm(m, gkey, c.tid);
     }
     m.pos = uni(*R_I32(c, o_mt_pos));
@@ -2834,18 +2867,21 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     if (!(skip & 4)) {
       // the map observations of the previous step are still in the arena: update them in place,
       // unless something outside the kernels touched the state (obs_valid == 0)
+#ifdef AIE_EXP_NOSCRATCH
+      update_spatial_observations(c, arena);
+#else
       if (uni(*R_I32(c, o_obs_valid)) && !(skip & 32768)) update_spatial_observations(c, arena);
       else write_spatial_observations(c, arena);
+#endif
       if (c.tid == 0) *R_I32(c, o_obs_valid) = 1;
     }
     if (!(skip & 8)) write_action_masks(c, arena);
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
     if (REW_ON_W1) step_rewards_and_done(c, arena, next, skip);
-    if (NW == 2) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();  // (5)
+    if (!(skip & 32)) store_record(c, arena, m, 1, NW, /*key_wave=*/1);
   }
-  __syncthreads();
-  if (!(skip & 32)) store_record(c, arena, m, wid, NW, /*key_wave=*/NW - 1);
-  if (TRACE && R.dev_trace && threadIdx.x == 0) R.dev_trace[12 * blockIdx.x + 7] = wall_clock64();
 }
 
 #ifndef AIE_JIT  // (a run-time specialisation compiles the two entry points at the end of this file only)
@@ -2871,9 +2907,14 @@ aie_step_kernel_log(const aie_params* __restrict__ params, uint8_t* __restrict__
   step_body<2, true>(params, arena, act_a, act_p, lds, next);
 }
 // compile-time instances for the configurations listed in ai-economist_amd/_specs.py (BASELINE configs[1], [2], ...)
+#ifdef AIE_EXP_WAVES  // (timing experiment: another register budget for the instances)
+#define AIE_SPEC_WAVES(S) AIE_EXP_WAVES
+#else
+#define AIE_SPEC_WAVES(S) aie_spec_image<S>::waves
+#endif
 template <int SPEC>
 __global__ void __launch_bounds__(2 * AIE_NT)
-__attribute__((amdgpu_waves_per_eu(aie_spec_image<SPEC>::waves, aie_spec_image<SPEC>::waves)))
+__attribute__((amdgpu_waves_per_eu(AIE_SPEC_WAVES(SPEC), AIE_SPEC_WAVES(SPEC))))
 aie_step_kernel_spec(const aie_params* __restrict__ params, uint8_t* __restrict__ arena,
                      const int32_t* __restrict__ act_a, const int32_t* __restrict__ act_p, NextActions next) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -3412,8 +3453,6 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
   }
   MT m;
   mt_init(m, P);
-  if (gtid == 0) *c.srcn = 0;
-  __syncthreads();
   load_record(c, arena, m, wave, nwaves, wave);  // every wave takes its own copy of the generator's rows
   __syncthreads();
   m.pos = uni(*R_I32(c, o_mt_pos));
@@ -3450,6 +3489,7 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
     }
   }
   __syncthreads();
+  build_src_list(c);  // the regeneration's source doubles of this episode's layout
   if (P.regen_conv) {  // source blocks per d x d window, zero-padded ("same"), once per episode
     const uint8_t* cb = reinterpret_cast<const uint8_t*>(R_CELLS(c));
     for (int q = tid; q < AIE_N_RES * HW; q += AIE_NT) {
@@ -3599,7 +3639,7 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
     }
   }
   __syncthreads();
-  store_record(c, arena, m);
+  store_record(c, arena, m, 0, 1, 0, /*with_src_list=*/true);
 }
 }  // namespace aie
 

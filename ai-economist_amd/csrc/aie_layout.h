@@ -94,6 +94,12 @@ typedef struct aie_params {
   int32_t o_mt, o_mt_pos, o_mt_has_gauss, o_mt_gauss;
   int32_t o_tax_last_completions; /* PeriodicBracketTax._last_completions (tax annealing)     */
   int32_t o_error_flags; /* AIE_ERR_* bits (include/aie.h), sticky until reset */
+  int32_t o_src_n, o_src_list; /* the regeneration's source doubles of THIS replica (round 6): int32 count, uint16 [AIE_SRC_CAP]
+                          * ascending -- double d of a step's 2 H W np.random.rand values targets Wood cell d (d < H W) or Stone
+                          * cell d - H W, and only source-block cells can respawn.  Derived from the cells' flag bytes by the
+                          * reset kernel (and by aie_set_layout / aie_upload of the cells; load_state on the host), read by every
+                          * step instead of a scan of the flags.  The LAST fields of the record's LDS image, never stored back by
+                          * the step (aie_rec_store_bytes).  Absent (0) where the batch shares one list (a_src_list). */
   int32_t o_obs_valid;   /* 1: the map observation tensors hold this replica's current state (the step
                           * kernel then only rewrites what a step changes); cleared by anything that
                           * edits state from outside the kernels                                     */
@@ -320,6 +326,11 @@ static inline int aie__has(const aie_config* c, int comp) {
  * never-changing source blocks */
 static inline int aie__shared_src_list(const aie_config* c) {
   return c->scenario == AIE_SCN_GTB && c->shared_layout && c->layout_gen == AIE_LAYOUT_FIXED;
+}
+/* ... which the kernels use with the counter stream only (aie_kernels.hip: shared_src_list); everybody else keeps a list
+ * per replica in the record (o_src_n / o_src_list) */
+static inline int aie__record_src_list(const aie_config* c) {
+  return c->scenario == AIE_SCN_GTB && !(aie__shared_src_list(c) && c->rng_mode == AIE_RNG_FAST);
 }
 /* words of generator state in a replica's record ("mt"): MT19937's key, or (key32, block number, salt, 0) of the
  * counter stream (include/aie.h: AIE_RNG_FAST) */
@@ -1145,6 +1156,11 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->o_mt_gauss = aie__rec(&cur, 8, 8);
   p->o_mt_pos = aie__rec(&cur, 4, 4);
   p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
+  p->o_src_n = p->o_src_list = 0;
+  if (aie__record_src_list(c)) {  /* (16-byte aligned: the step stores the image up to here, aie_rec_store_bytes) */
+    p->o_src_n = aie__rec(&cur, 16, 16);
+    p->o_src_list = aie__rec(&cur, 2 * AIE_SRC_CAP, 16);
+  }
   p->o_mt = aie__rec(&cur, 4 * aie__rng_state_words(c), 16);
   p->rec_bytes = (int32_t)aie__align(cur, 16);
 
@@ -1238,6 +1254,10 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     REC("auto_warmup", AIE_I32, p->o_auto_warmup, 0, 0, 0, 0);
     REC("obs_valid", AIE_I32, p->o_obs_valid, 0, 0, 0, 0);
     REC("error_flags", AIE_I32, p->o_error_flags, 0, 0, 0, 0);
+    if (p->o_src_list) {
+      REC("regen_src_n", AIE_I32, p->o_src_n, 0, 0, 0, 0);
+      REC("regen_src_list", AIE_I16, p->o_src_list, 1, AIE_SRC_CAP, 0, 0);
+    }
     REC("mt", AIE_U32, p->o_mt, 1, aie__rng_state_words(&p->c), 0, 0);
     REC("mt_pos", AIE_I32, p->o_mt_pos, 0, 0, 0, 0);
     REC("mt_has_gauss", AIE_I32, p->o_mt_has_gauss, 0, 0, 0, 0);

@@ -370,6 +370,22 @@ class DeviceBackend:
                 self.tensors["cell_flags"][...] = src
             else:
                 self.tensors["cell_flags"][e] = src
+            if "regen_src_list" in self.tensors:
+                # the regeneration's source doubles (record fields the reset kernel derives from the flags,
+                # csrc/aie_layout.h: o_src_list): Wood cells ascending, then Stone cells
+                hw = int(np.asarray(state["wood_src"]).size)
+                d = np.concatenate([np.flatnonzero(np.asarray(state["wood_src"]).reshape(-1)),
+                                    hw + np.flatnonzero(np.asarray(state["stone_src"]).reshape(-1))])
+                cap = int(self.tensors["regen_src_list"].shape[-1])
+                lst = np.zeros(cap, np.int16)
+                lst[: min(cap, d.size)] = d[:cap].astype(np.uint16).view(np.int16)
+                lst_t = torch.as_tensor(lst, device=self.device)
+                if e is None:
+                    self.tensors["regen_src_list"][...] = lst_t
+                    self.tensors["regen_src_n"][...] = int(d.size)
+                else:
+                    self.tensors["regen_src_list"][e] = lst_t
+                    self.tensors["regen_src_n"][e] = int(d.size)
             if "regen_source_count" in self.tensors:
                 # bookkeeping the reset kernel derives from the layout (source blocks per regeneration window,
                 # csrc/aie_layout.h: regen_conv): a layout injected here needs the same counts

@@ -573,6 +573,69 @@ def test_dense_source_layouts_take_the_row_by_row_regeneration():
             _compare_all(be, oracle, "dense layout second reset")
 
 
+def _expected_src_list(flags_row, cap):
+    """Source doubles of one replica from its flag bytes: Wood cells ascending, then Stone cells (+ H W)."""
+    hw = flags_row.size
+    d = np.concatenate([np.flatnonzero(flags_row & 4), hw + np.flatnonzero(flags_row & 2)])
+    lst = np.zeros(cap, np.int64)
+    lst[: min(cap, d.size)] = d[:cap]
+    return d.size, lst
+
+
+@pytest.mark.parametrize("case", ["fixed_shared", "uniform_per_replica", "dense"])
+def test_record_source_list_follows_the_flags(case):
+    """Round 6: the regeneration's source doubles are a record field (`regen_src_n`, `regen_src_list`) the reset kernel
+    derives from the cells' flag bytes -- and aie_set_layout / aie_upload / load_state wherever the flags change without
+    a reset -- instead of a scan inside every step.  The list equals the flags' after create, after resets with fresh
+    layouts and after a state injection; a step leaves it alone."""
+    import torch
+
+    cfg = {"fixed_shared": dict(C2),
+           "uniform_per_replica": dict(scenario_name="uniform/simple_wood_and_stone", n_agents=4, world_size=[15, 15],
+                                       episode_length=6, components=[["Build", {}], ["Gather", {}]],
+                                       starting_stone_coverage=0.1, starting_wood_coverage=0.1),
+           "dense": dict(scenario_name="uniform/simple_wood_and_stone", n_agents=5, world_size=[20, 20], episode_length=6,
+                         components=[["Build", {}], ["Gather", {}]], starting_stone_coverage=0.22,
+                         starting_wood_coverage=0.22)}[case]
+    E = 12
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    be = env.backend
+    cap = int(be.tensors["regen_src_list"].shape[-1])
+
+    def check(where):
+        torch.cuda.synchronize()
+        flags = be.tensors["cell_flags"].reshape(E, -1).cpu().numpy()
+        got_n = be.tensors["regen_src_n"].cpu().numpy()
+        got = be.tensors["regen_src_list"].cpu().numpy().view(np.uint16).astype(np.int64)
+        for e in range(E):
+            n, lst = _expected_src_list(flags[e], cap)
+            assert got_n[e] == n, (where, e, got_n[e], n)
+            assert np.array_equal(got[e], lst), (where, e)
+        return got_n
+
+    if case == "fixed_shared":
+        check("after create (aie_set_layout)")
+    env.seed(3)
+    env.reset()
+    n0 = check("after reset")
+    assert (n0 > 0).all() and ((n0 > cap).all() if case == "dense" else (n0 <= cap).all())
+    for t in range(8):  # crosses an episode end for the generated layouts (auto reset off: explicit masked reset)
+        a, p = be.sample_random_actions(seed=9)
+        env.step({"a": a, "p": p})
+        if t == 5 and case != "fixed_shared":
+            env.reset(be.tensors["done"])
+    check("after steps and a second reset")
+    if case == "fixed_shared":
+        # a state injection with another layout into one replica (load_state derives the list on the host)
+        st = {k: v[0].cpu().numpy() for k, v in be.tensors.items() if k in ("stone", "wood")}
+        rs = np.random.RandomState(1)
+        st["stone_src"] = (rs.rand(25, 25) < 0.04).astype(np.uint8)
+        st["wood_src"] = (rs.rand(25, 25) < 0.04).astype(np.uint8)
+        st["water"] = np.zeros((25, 25), np.uint8)
+        be.load_state(st, e=2)
+        check("after load_state")
+
+
 @pytest.mark.parametrize("variant", sorted(OSE_VARIANTS))
 def test_hip_matches_oracle_one_step_economy(variant):
     """BASELINE configs[4] family: one-step-economy + SimpleLabor + PeriodicBracketTax."""

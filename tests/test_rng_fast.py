@@ -116,6 +116,8 @@ def test_fast_and_numpy_modes_differ_only_in_the_stream():
     _, om = _oracle(C2, 3, 5)
     assert of.t["mt"].shape == (3, 4) and om.t["mt"].shape == (3, 624)
     for k in om.t:
+        if k in ("regen_src_n", "regen_src_list"):  # (the record's own source list: the counter stream shares the batch's)
+            continue
         if k != "mt":
             assert of.t[k].shape == om.t[k].shape, k
     z_a, z_p = np.zeros((3, 4), np.int32), np.zeros((3, 7), np.int32)
