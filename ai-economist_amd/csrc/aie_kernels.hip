@@ -403,6 +403,36 @@ __device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__
   for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
   if (c.tid < 48) key[576 + c.tid] = m.r[9];
 }
+__device__ __forceinline__ uint16_t* dirty_list(const Ctx& c);
+// The step's way out (round 6).  A step changes a handful of the H W map cells -- the ones its change log lists for the
+// in-place map observations (dirty_*: every cell whose word or occupant changed) -- so the 16-byte units that hold
+// nothing but cells stay as they are in HBM and the listed cells go out one word per lane: 2.4 of the 4.2 KB image of
+// BASELINE configs[1] are not written.  A log overflow writes everything.  (The generator's rows left right behind the
+// regeneration: store_generator_rows.)
+__device__ __forceinline__ void store_record_step(const Ctx& c, uint8_t* __restrict__ arena, int wave, int nwaves) {
+  uint8_t* g = arena + (int64_t)c.e * c.P.rec_bytes;
+  uint4* dst = reinterpret_cast<uint4*>(g);
+  const uint4* src = reinterpret_cast<const uint4*>(c.rec);
+  const int nq = (c.P.o_src_list ? c.P.o_src_n : rec_lds_bytes(c.P)) >> 4;
+  const int cnt = uni(c.dirty[0]);
+  const int q0 = (c.P.o_cells == 0 && cnt <= AIE_DIRTY_CAP) ? (4 * c.P.HW) >> 4 : 0;  // units [0, q0): cells only
+  for (int q = q0 + wave * AIE_NT + c.tid; q < nq; q += nwaves * AIE_NT) dst[q] = src[q];
+  if (wave == nwaves - 1) {
+    if (q0 > 0 && c.tid < cnt) {
+      const int cell = (int)dirty_list(c)[c.tid];
+      reinterpret_cast<uint32_t*>(g + c.P.o_cells)[cell] = R_CELLS(c)[cell];
+    }
+    if (c.P.o_src_list && rng_fast(c.P) && c.tid == 0)  // the counter stream's state lies behind the list
+      reinterpret_cast<uint4*>(g + c.P.o_mt)[0] = reinterpret_cast<const uint4*>(c.rec + c.P.o_mt)[0];
+  }
+}
+__device__ __forceinline__ void store_generator_rows(const Ctx& c, uint8_t* __restrict__ arena, const MT& m) {
+  if (rng_fast(c.P)) return;
+  uint32_t* key = reinterpret_cast<uint32_t*>(arena + (int64_t)c.e * c.P.rec_bytes + c.P.o_mt);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) key[64 * j + c.tid] = m.r[j];
+  if (c.tid < 48) key[576 + c.tid] = m.r[9];
+}
 
 // ------------------------------------------------------------------------------------
 // NumPy legacy RandomState stream (MT19937), one per replica.
@@ -2751,7 +2781,9 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   if (wid == 0) {
     // ---------------- first wave: actions, components, flat vectors, rewards ----------------
     Agents A;
-    const int act_err = decode_actions(c, A, act_a, act_p);  // (the loads ride beside the record's; c.act_p is LDS scratch)
+    int act_err = 0;
+    if (!(skip & (1 << 18))) act_err = decode_actions(c, A, act_a, act_p);  // (the loads ride beside the record's; c.act_p is LDS scratch)
+    else A.act = 0;
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x] = wall_clock64();
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
     MT none;
@@ -2805,7 +2837,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     if (!REW_ON_W1) step_rewards_and_done(c, arena, next, skip);
     if (w0_tail_prio) __builtin_amdgcn_s_setprio(0);
     __syncthreads();  // (5)
-    if (!(skip & 32)) store_record(c, arena, none, 0, NW, /*key_wave=*/NW - 1);
+    if (!(skip & 32)) store_record_step(c, arena, 0, NW);
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 7] = wall_clock64();
   } else {
     // ---------------- second wave: generator, occupancy map, regeneration, map observations, masks ----------------
@@ -2815,7 +2847,8 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     load_record(c, arena, m, 1, NW, /*key_wave=*/-1);
     // behind its share of the copy: the words the components will draw -> the LDS draw window (two or three rows of the
     // generator's state, fetched from HBM; the state itself follows while the components run)
-    if (FAST) draw_window_publish_fast(draw_w, draw_cap, (uint32_t)uni((int)gkey[0]), (uint32_t)uni((int)gkey[1]), (uint32_t)uni((int)gkey[2]), uni(gpos), c.tid);
+    if (skip & (1 << 16)) {}  // (development: the load phase without the draw window)
+    else if (FAST) draw_window_publish_fast(draw_w, draw_cap, (uint32_t)uni((int)gkey[0]), (uint32_t)uni((int)gkey[1]), (uint32_t)uni((int)gkey[2]), uni(gpos), c.tid);
     else draw_window_publish_from_hbm(draw_w, draw_cap, gkey, uni(gpos), c.tid);
     if (SPEC >= 0 && const_tables_in_lds(P)) {
       // the small constant tables (Ctx.rtab / mtab) -> LDS, published by the barrier below
@@ -2824,7 +2857,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       for (int q = c.tid; q < P.MA; q += AIE_NT) const_cast<uint32_t*>(c.mtab)[q] = P.mask_test[q];
     }
     __syncthreads();  // (2)
-    rebuild_locmap(c);
+    if (!(skip & (1 << 17))) rebuild_locmap(c);
     __syncthreads();  // (3)
     // nothing to do until the components are done but the next step's random actions
     SrcList src;
@@ -2832,7 +2865,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) src.d[k] = 0;
     if (SHL) src = src_list_from_arena(c, arena);  // (the loads ride under the first wave's dynamics)
-    if (!FAST) {  // the generator's rows -> registers (re-read after the barrier if the components twisted the state)
+    if (!FAST && !(skip & (1 << 19))) {  // the generator's rows -> registers (re-read after the barrier if the components twisted the state)
 #pragma unroll
       for (int j = 0; j < 9; ++j) m.r[j] = gkey[64 * j + c.tid];
       m.r[9] = c.tid < 48 ? gkey[576 + c.tid] : 0u;
@@ -2862,6 +2895,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       *R_I32(c, o_mt_pos) = m.pos;
       if (FAST) R_U32(c, o_mt)[1] = m.fblk;
     }
+    if (!(skip & 32)) store_generator_rows(c, arena, m);  // (the rows' registers are free from here on)
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
     AIE_WSYNC();
     if (!(skip & 4)) {
@@ -2880,7 +2914,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     if (REW_ON_W1) step_rewards_and_done(c, arena, next, skip);
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();  // (5)
-    if (!(skip & 32)) store_record(c, arena, m, 1, NW, /*key_wave=*/1);
+    if (!(skip & 32)) store_record_step(c, arena, 1, NW);
   }
 }
 

@@ -20,13 +20,20 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from helpers import make_env  # noqa: E402
 
-MASKS = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 8 | 16, 2 | 4 | 512, 31 | 512, 63 | 512, 0]
+SK = 63 | 512  # the skeleton: record in, decode, occupancy map (nothing else, no record store)
+MASKS = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 8 | 16, 2 | 4 | 512, 31 | 512, SK,
+         SK | 1 << 16, SK | 1 << 17, SK | 1 << 18, SK | 1 << 19, SK | 15 << 16, 0]
+if os.environ.get("ABLATE_SKELETON"):
+    MASKS = [0, 31 | 512, SK, SK | 1 << 16, SK | 1 << 17, SK | 1 << 18, SK | 1 << 19, SK | 15 << 16, 0]
+SK = 63 | 512
 NAMES = {0: "full", 1: "-components", 2: "-regen", 4: "-map observations", 8: "-flat vectors -masks", 16: "-rewards",
          31 | 512: "record in, decode, occupancy map, record out only", 63 | 512: "record in, decode, occupancy map only",
          32: "-record store", 64: "-flat stage A", 128: "-flat cda", 256: "-flat tax", 512: "-masks",
          1024: "-planner copy-out", 2048: "-build", 4096: "-cda", 8192: "-gather", 16384: "-tax",
          32768: "full map rewrite instead of in-place", 24: "-flat -rewards (wave 0 tail)",
-         2 | 4 | 512: "-regen -map obs -masks (wave 1 tail)"}
+         2 | 4 | 512: "-regen -map obs -masks (wave 1 tail)",
+         SK | 1 << 16: "skeleton - draw window", SK | 1 << 17: "skeleton - occupancy map", SK | 1 << 18: "skeleton - action decode",
+         SK | 1 << 19: "skeleton - generator rows to registers", SK | 15 << 16: "skeleton - all four"}
 LAUNCHES = 30
 E = 4096
 
