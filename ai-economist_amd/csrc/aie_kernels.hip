@@ -64,8 +64,7 @@ struct Ctx {
   uint8_t* locmap;   // LDS [HW] 0 = empty, i+1 = agent i
   double* fscr;      // LDS f64 scratch
   float* stage;      // LDS staging of the small observation vectors (also: MT word dump during regen)
-  uint16_t* srcl;    // LDS [AIE_SRC_CAP] regen doubles that target a source block: the record's own list (o_src_list), nullptr
-                     // where the batch shares one (shared_src_list)
+  uint16_t* srcl;    // (unused since round 6: the source list is a record field read straight into registers, src_list_from_record)
   int32_t* srcn;     // LDS [4] scratch words ([2]: the dense log's event rows of this step)
   int32_t* mflags;   // LDS [n] per-agent mask bits
   int32_t* dirty;    // LDS [4 + AIE_DIRTY_CAP/2]: count, moved-agent mask (2 words), pad, uint16 cell list
@@ -199,7 +198,7 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R
   q += fscr_doubles(P) * 8;
   float* stage = reinterpret_cast<float*>(q);
   q += stage_bytes(P);
-  uint16_t* srcl = P.o_src_list ? reinterpret_cast<uint16_t*>(lds + P.o_src_list) : nullptr;
+  uint16_t* srcl = nullptr;
   int32_t* srcn = reinterpret_cast<int32_t*>(q);
   q += 16;
   int32_t* mflags = reinterpret_cast<int32_t*>(q);
@@ -388,15 +387,12 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
   m.r[9] = c.tid < 48 ? key[576 + c.tid] : 0u;
 }
 __device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m, int wave = 0,
-                                             int nwaves = 1, int key_wave = 0, bool with_src_list = false) {
+                                             int nwaves = 1, int key_wave = 0) {
   uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
   uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
-  // (the source list -- the image's last fields -- only changes where a kernel rebuilds it: `with_src_list`)
-  const int nq = (with_src_list || !c.P.o_src_list ? rec_lds_bytes(c.P) : c.P.o_src_n) >> 4;
+  const int nq = rec_lds_bytes(c.P) >> 4;
   for (int q = wave * AIE_NT + c.tid; q < nq; q += nwaves * AIE_NT) dst[q] = src[q];
-  if (!with_src_list && c.P.o_src_list && rng_fast(c.P) && wave == 0 && c.tid == 0)  // the counter stream's state lies behind the list
-    reinterpret_cast<uint4*>(g + c.P.o_mt)[0] = reinterpret_cast<const uint4*>(c.rec + c.P.o_mt)[0];
   if (wave != key_wave || rng_fast(c.P)) return;  // the generator's rows are in that wave's registers
   uint32_t* key = reinterpret_cast<uint32_t*>(g + c.P.o_mt);
 #pragma unroll
@@ -413,17 +409,13 @@ __device__ __forceinline__ void store_record_step(const Ctx& c, uint8_t* __restr
   uint8_t* g = arena + (int64_t)c.e * c.P.rec_bytes;
   uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
-  const int nq = (c.P.o_src_list ? c.P.o_src_n : rec_lds_bytes(c.P)) >> 4;
+  const int nq = rec_lds_bytes(c.P) >> 4;
   const int cnt = uni(c.dirty[0]);
   const int q0 = (c.P.o_cells == 0 && cnt <= AIE_DIRTY_CAP) ? (4 * c.P.HW) >> 4 : 0;  // units [0, q0): cells only
   for (int q = q0 + wave * AIE_NT + c.tid; q < nq; q += nwaves * AIE_NT) dst[q] = src[q];
-  if (wave == nwaves - 1) {
-    if (q0 > 0 && c.tid < cnt) {
-      const int cell = (int)dirty_list(c)[c.tid];
-      reinterpret_cast<uint32_t*>(g + c.P.o_cells)[cell] = R_CELLS(c)[cell];
-    }
-    if (c.P.o_src_list && rng_fast(c.P) && c.tid == 0)  // the counter stream's state lies behind the list
-      reinterpret_cast<uint4*>(g + c.P.o_mt)[0] = reinterpret_cast<const uint4*>(c.rec + c.P.o_mt)[0];
+  if (wave == nwaves - 1 && q0 > 0 && c.tid < cnt) {
+    const int cell = (int)dirty_list(c)[c.tid];
+    reinterpret_cast<uint32_t*>(g + c.P.o_cells)[cell] = R_CELLS(c)[cell];
   }
 }
 __device__ __forceinline__ void store_generator_rows(const Ctx& c, uint8_t* __restrict__ arena, const MT& m) {
@@ -1935,11 +1927,13 @@ struct SrcList {
   int S;                            // number of source doubles (may exceed AIE_SRC_CAP: row-by-row regeneration)
   int d[AIE_SRC_CAP / AIE_NT];      // this lane's entries
 };
-__device__ __forceinline__ SrcList src_list_from_lds(const Ctx& c) {
+__device__ __forceinline__ SrcList src_list_from_record(const Ctx& c, const uint8_t* __restrict__ arena) {
   SrcList L;
-  L.S = uni(*R_I32(c, o_src_n));
+  const uint8_t* g = arena + (int64_t)c.e * c.P.rec_bytes;
+  L.S = uni(*reinterpret_cast<const int32_t*>(g + c.P.o_src_n));
+  const uint16_t* lst = reinterpret_cast<const uint16_t*>(g + c.P.o_src_list);
 #pragma unroll
-  for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) L.d[k] = (int)c.srcl[k * AIE_NT + c.tid];  // (entries past the count are zero)
+  for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) L.d[k] = (int)lst[k * AIE_NT + c.tid];  // (entries past the count are zero)
   return L;
 }
 __device__ __forceinline__ SrcList src_list_from_arena(const Ctx& c, const uint8_t* __restrict__ arena) {
@@ -2634,13 +2628,15 @@ __device__ __forceinline__ void rebuild_locmap(const Ctx& c) {
 }
 
 // The replica's source doubles from the cells' flag bytes (LDS image), ascending: Wood cells, then Stone cells
-// (layout_from_file.py:394-403: np.random.rand(2, H, W) is consumed for Wood first).  One wave; count and list land in
-// the record image (o_src_n, o_src_list; a count above AIE_SRC_CAP selects the row-by-row regeneration).
-__device__ __forceinline__ void build_src_list(const Ctx& c) {
+// (layout_from_file.py:394-403: np.random.rand(2, H, W) is consumed for Wood first).  One wave; count and list go to
+// the record in HBM (o_src_n, o_src_list; a count above AIE_SRC_CAP selects the row-by-row regeneration).
+__device__ __forceinline__ void build_src_list(const Ctx& c, uint8_t* __restrict__ arena) {
   if (!c.P.o_src_list) return;
   const int HW = c.P.HW;
+  uint8_t* g = arena + (int64_t)c.e * c.P.rec_bytes;
+  uint16_t* lst = reinterpret_cast<uint16_t*>(g + c.P.o_src_list);
   const uint8_t* cb = reinterpret_cast<const uint8_t*>(R_CELLS(c));
-  for (int k = c.tid; k < AIE_SRC_CAP; k += AIE_NT) c.srcl[k] = 0;
+  for (int k = c.tid; k < AIE_SRC_CAP; k += AIE_NT) lst[k] = 0;
   int base = 0;
   for (int rs = 0; rs < 2; ++rs) {
     const uint32_t bit = rs == 0 ? AIE_CELL_WOOD_SRC : AIE_CELL_STONE_SRC;
@@ -2649,12 +2645,11 @@ __device__ __forceinline__ void build_src_list(const Ctx& c) {
       const bool on = q < HW && (cb[4 * q + 3] & bit);
       const uint64_t mask = __ballot(on);
       const int slot = base + __popcll(mask & lanemask_lt(c.tid));
-      if (on && slot < AIE_SRC_CAP) c.srcl[slot] = (uint16_t)(rs * HW + q);
+      if (on && slot < AIE_SRC_CAP) lst[slot] = (uint16_t)(rs * HW + q);
       base += __popcll(mask);
     }
   }
-  if (c.tid == 0) *R_I32(c, o_src_n) = base;
-  AIE_WSYNC();
+  if (c.tid == 0) *reinterpret_cast<int32_t*>(g + c.P.o_src_n) = base;
 }
 
 }  // namespace aie
@@ -2864,7 +2859,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     src.S = 0;
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) src.d[k] = 0;
-    if (SHL) src = src_list_from_arena(c, arena);  // (the loads ride under the first wave's dynamics)
+    src = SHL ? src_list_from_arena(c, arena) : src_list_from_record(c, arena);  // (the loads ride under the first wave's dynamics)
     if (!FAST && !(skip & (1 << 19))) {  // the generator's rows -> registers (re-read after the barrier if the components twisted the state)
 #pragma unroll
       for (int j = 0; j < 9; ++j) m.r[j] = gkey[64 * j + c.tid];
@@ -2889,7 +2884,6 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       mt_rows_from_hbm(m, gkey, c.tid);
     }
     m.pos = uni(*R_I32(c, o_mt_pos));
-    if (!SHL) src = src_list_from_lds(c);
     if (!(skip & 2)) scenario_step_regen(c, m, src);
     if (c.tid == 0) {
       *R_I32(c, o_mt_pos) = m.pos;
@@ -3523,7 +3517,7 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
     }
   }
   __syncthreads();
-  build_src_list(c);  // the regeneration's source doubles of this episode's layout
+  build_src_list(c, arena);  // the regeneration's source doubles of this episode's layout
   if (P.regen_conv) {  // source blocks per d x d window, zero-padded ("same"), once per episode
     const uint8_t* cb = reinterpret_cast<const uint8_t*>(R_CELLS(c));
     for (int q = tid; q < AIE_N_RES * HW; q += AIE_NT) {
@@ -3673,7 +3667,7 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
     }
   }
   __syncthreads();
-  store_record(c, arena, m, 0, 1, 0, /*with_src_list=*/true);
+  store_record(c, arena, m);
 }
 }  // namespace aie
 

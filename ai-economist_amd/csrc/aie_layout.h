@@ -98,8 +98,9 @@ typedef struct aie_params {
                           * ascending -- double d of a step's 2 H W np.random.rand values targets Wood cell d (d < H W) or Stone
                           * cell d - H W, and only source-block cells can respawn.  Derived from the cells' flag bytes by the
                           * reset kernel (and by aie_set_layout / aie_upload of the cells; load_state on the host), read by every
-                          * step instead of a scan of the flags.  The LAST fields of the record's LDS image, never stored back by
-                          * the step (aie_rec_store_bytes).  Absent (0) where the batch shares one list (a_src_list). */
+                          * step -- straight into the registers of the wave that regenerates, while the components run -- instead
+                          * of a scan of the flags.  Behind the generator's state, i.e. outside the record's LDS image.  Absent
+                          * (0) where the batch shares one list (a_src_list). */
   int32_t o_obs_valid;   /* 1: the map observation tensors hold this replica's current state (the step
                           * kernel then only rewrites what a step changes); cleared by anything that
                           * edits state from outside the kernels                                     */
@@ -1156,12 +1157,12 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->o_mt_gauss = aie__rec(&cur, 8, 8);
   p->o_mt_pos = aie__rec(&cur, 4, 4);
   p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
+  p->o_mt = aie__rec(&cur, 4 * aie__rng_state_words(c), 16);
   p->o_src_n = p->o_src_list = 0;
-  if (aie__record_src_list(c)) {  /* (16-byte aligned: the step stores the image up to here, aie_rec_store_bytes) */
+  if (aie__record_src_list(c)) {  /* behind the generator's state: not part of the LDS image (everything before o_mt) */
     p->o_src_n = aie__rec(&cur, 16, 16);
     p->o_src_list = aie__rec(&cur, 2 * AIE_SRC_CAP, 16);
   }
-  p->o_mt = aie__rec(&cur, 4 * aie__rng_state_words(c), 16);
   p->rec_bytes = (int32_t)aie__align(cur, 16);
 
   /* ---- arena ------------------------------------------------------------------- */
