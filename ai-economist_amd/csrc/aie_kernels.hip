@@ -2761,7 +2761,11 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   // With many agents the first wave's tail (flat vectors of every agent, utilities) is the longer one: it then keeps a
   // priority above the waves that are still loading (measured at 10 agents: 42.3 -> 41.9 us; at 4 agents any
   // priority above 0 costs 0.8-1.4 us)
+#ifdef AIE_W0_TAIL_PRIO  // (A/B builds)
+  const int w0_tail_prio = AIE_W0_TAIL_PRIO;
+#else
   const int w0_tail_prio = P.n >= 8 ? 2 : 0;
+#endif
   // Where the rewards run.  With MT19937 the second wave's tail (four twists of regeneration, map observations, masks) is
   // as long as the first wave's (flat vectors, rewards); with the counter stream the regeneration shrinks to a few Philox
   // blocks and the first wave's tail is the long pole (tools/block_trace.py: 7.1 us against 3.7 us), so the rewards move
@@ -2874,7 +2878,11 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     __syncthreads();  // (4)
     // resource regeneration (the generator's rows are in this wave's registers), then what depends on the map:
     // incremental map observations, action masks
+#ifdef AIE_W1_TAIL_PRIO  // (A/B builds)
+    __builtin_amdgcn_s_setprio(AIE_W1_TAIL_PRIO);
+#else
     __builtin_amdgcn_s_setprio(2);  // from here on this wave is the critical one (the first has slack)
+#endif
     if (FAST) {  // the stream's state is in the LDS image (the components may have moved it to the next block)
       const uint32_t* st = R_U32(c, o_mt);
       m.fkey = (uint32_t)uni((int)st[0]);
