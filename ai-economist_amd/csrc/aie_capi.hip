@@ -535,6 +535,16 @@ int aie_set_reward_log(aie_env* env, float* d_log, int32_t n_slots) {
   env->rew_log = d_log;
   env->rew_log_slots = d_log ? n_slots : 0;
   env->rew_log_epoch += 1;  // (the arena starts zeroed and this starts at 1: never equal to a fresh record's epoch)
+  // the kernels read the log's descriptor from the device-side parameter block: launches already captured in a hipGraph
+  // follow this call too (the copy is ordered behind whatever the device is running)
+  env->P.rew_log = env->rew_log;
+  env->P.rew_slots = env->rew_log_slots;
+  env->P.rew_epoch = env->rew_log_epoch;
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  AIE_HIP_CHECK(env, hipDeviceSynchronize());
+  AIE_HIP_CHECK(env, hipMemcpy(reinterpret_cast<uint8_t*>(env->d_params) + offsetof(aie_params, rew_log), &env->P.rew_log,
+                               offsetof(aie_params, rew_epoch) + sizeof(int32_t) - offsetof(aie_params, rew_log),
+                               hipMemcpyHostToDevice));
   return AIE_OK;
 }
 
@@ -582,11 +592,6 @@ static int aie_step_impl(aie_env* env, const int32_t* d_actions_a, const int32_t
   if (!env) return AIE_E_INVALID;
   NextActions next = next_in;
   next.E = (int32_t)env->P.E;
-  if (env->rew_log) {  // reward log (aie_set_reward_log): the replicas pick and advance their slot themselves
-    next.rew_log = env->rew_log;
-    next.rew_slots = env->rew_log_slots;
-    next.rew_epoch = env->rew_log_epoch;
-  }
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
   if (env->P.saez_stride)  // tax_model "saez": the period-start formula runs ahead of the step (aie_kernels_saez.hip)
     hipLaunchKernelGGL(aie_saez_kernel, dim3((unsigned)env->P.E), dim3(AIE_NT), 0, static_cast<hipStream_t>(stream),

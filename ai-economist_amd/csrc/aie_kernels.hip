@@ -2682,12 +2682,6 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
   int32_t* p;
   uint64_t seed;
   int64_t env_offset;  // (the draw index `t` of the counter RNG is the replica's own record field o_sample_t)
-  // aie_set_reward_log: the caller's reward log, f32 [rew_slots][E][n + 2] = agents' rewards, the planner's reward, done
-  // -- or nullptr.  The slot a step fills is the replica's record field o_rew_slot (advanced by the step itself,
-  // restarted at 0 when rew_epoch differs from the record's o_rew_epoch, i.e. after a new aie_set_reward_log call):
-  // nothing here changes from step to step, so a captured launch can be replayed.
-  float* rew_log;
-  int32_t rew_slots, rew_epoch;
   // replicas this launch steps: [e_lo, e_hi), or all of them when e_hi == 0.  An environment with dense-log replicas
   // whose current episode is being logged steps those replicas with aie_step_kernel_log and the rest with its fast
   // kernel (aie_capi.hip: aie_step_impl)
@@ -2700,22 +2694,26 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
 };
 // This step's slot of the reward log: the replica's slot counter selects it and moves on (`writer`: the one lane that
 // stores the counter back; every lane of the wave calls this with the same fields).
-__device__ __forceinline__ float* rew_log_claim(const NextActions& next, int32_t* slot_field, int32_t* epoch_field, int E,
+// (`R`: the run-time parameter block in device memory, where aie_set_reward_log keeps the log's address, slot count and
+// epoch -- nothing of it travels by value, so a captured launch follows a later aie_set_reward_log call)
+__device__ __forceinline__ float* rew_log_claim(const aie_params& R, int32_t* slot_field, int32_t* epoch_field, int E,
                                                 int n, bool writer) {
-  if (!next.rew_log) return nullptr;
+  float* const log = R.rew_log;
+  if (!log) return nullptr;
+  const int epoch = R.rew_epoch;
   int slot = __builtin_amdgcn_readfirstlane(*slot_field);
-  if (__builtin_amdgcn_readfirstlane(*epoch_field) != next.rew_epoch) slot = 0;
+  if (__builtin_amdgcn_readfirstlane(*epoch_field) != epoch) slot = 0;
   if (writer) {
-    *epoch_field = next.rew_epoch;
-    *slot_field = slot + 1 >= next.rew_slots ? 0 : slot + 1;
+    *epoch_field = epoch;
+    *slot_field = slot + 1 >= R.rew_slots ? 0 : slot + 1;
   }
-  return next.rew_log + (int64_t)slot * E * (n + 2);
+  return log + (int64_t)slot * E * (n + 2);
 }
 // rewards of the step (compute_reward, layout_from_file.py:519-559), the reward log's slot, `done` and the completed-episode
 // count: one wave
 __device__ __forceinline__ void step_rewards_and_done(const aie::Ctx& c, uint8_t* __restrict__ arena, const NextActions& next, int skip) {
   using namespace aie;
-  float* const rew_log = rew_log_claim(next, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), c.R.E, c.P.n, c.tid == 0);
+  float* const rew_log = rew_log_claim(c.R, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), c.R.E, c.P.n, c.tid == 0);
   if (!(skip & 16)) compute_rewards(c, arena, rew_log);
   AIE_WSYNC();
   if (c.tid == 0) {

@@ -502,12 +502,18 @@ __device__ __forceinline__ void cv_step_body(const aie_params* __restrict__ para
   uint8_t* hist = cv_hist_base(P, arena, e);
   const int T = P.c.episode_length;
   const int t = uni(*reinterpret_cast<const int32_t*>(rec + P.o_timestep)) + 1;
-  if (t > T) return;  // episode over: the caller has to reset (the reference would index past its arrays)
   // the replica's call counters (beside the timestep in the record): the draw index of the synthetic random policy and
   // this step's slot of the reward log (aie_set_reward_log; nullptr = off).  Lane 0 stores them back at the end.
   const int sample_t = uni(*reinterpret_cast<const int32_t*>(rec + P.o_sample_t));
-  float* __restrict__ rew_log = rew_log_claim(next, reinterpret_cast<int32_t*>(rec + P.o_rew_slot),
+  float* __restrict__ rew_log = rew_log_claim(P, reinterpret_cast<int32_t*>(rec + P.o_rew_slot),
                                               reinterpret_cast<int32_t*>(rec + P.o_rew_epoch), P.E, n, s == 0);
+  if (t > T) {
+    // episode over: the caller has to reset (the reference would index past its arrays).  The call counters still move
+    // with the batch's: a replica that sat a launch out writes the same reward-log slot as its peers, and
+    // draws with the same index, once it is reset.
+    if (s == 0 && (next.a || next.p)) *reinterpret_cast<int32_t*>(rec + P.o_sample_t) = sample_t + 1;
+    return;
+  }
   // Every load of the replica's record is issued here, before anything waits: a replica is one wavefront whose whole
   // step is a dependent chain (timestep -> history bytes -> state -> stores), and all 8192 of BASELINE configs[3] are
   // resident at once, so a launch lasts as long as that chain.  What does not depend on the timestep travels beside

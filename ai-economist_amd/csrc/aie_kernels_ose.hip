@@ -823,7 +823,7 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
   OSE_STAMP(c, 9);
   // this step's slot of aie_set_reward_log (or nullptr): every thread reads the replica's slot counter, thread 0 advances
   // it behind the barrier below
-  float* __restrict__ rew_log = rew_log_claim(next, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), R.E, n, false);
+  float* __restrict__ rew_log = rew_log_claim(R, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), R.E, n, false);
   {
     double* util = R_F64(c, o_util);
     for (int i = tid; i <= n; i += OSE_NT) {
@@ -839,7 +839,7 @@ __device__ __forceinline__ void ose_step_body(const aie_params* __restrict__ par
     (arena + c.R.a_done)[c.e] = (uint8_t)done;
     if (rew_log) {
       rew_log[(int64_t)c.e * (n + 2) + n + 1] = done ? 1.0f : 0.0f;
-      (void)rew_log_claim(next, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), R.E, n, true);
+      (void)rew_log_claim(R, R_I32(c, o_rew_slot), R_I32(c, o_rew_epoch), R.E, n, true);
     }
     if (done) *R_I32(c, o_completions) += 1;
   }

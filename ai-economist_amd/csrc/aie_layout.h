@@ -168,6 +168,12 @@ typedef struct aie_params {
   uint32_t mask_test[AIE_MAX_MASK];
   int32_t dev_skip_mask;
   uint64_t* dev_trace;   /* development: 8 clock stamps per workgroup (start, components.., regen, end), or NULL */
+  /* aie_set_reward_log: the caller's reward log, f32 [rew_slots][E][n + 2] = agents' rewards, the planner's reward, done --
+   * or NULL.  In the device-side block (not a kernel argument) so that a launch captured in a hipGraph sees a later
+   * aie_set_reward_log call (round 6).  rew_epoch: bumped by every such call, restarts the replicas' slot
+   * counters (record fields o_rew_slot / o_rew_epoch). */
+  float* rew_log;
+  int32_t rew_slots, rew_epoch;
 
   /* ---- COVID-19 scenario (aie__build_covid) ---- */
   int32_t cv_L;          /* filter_len                                                     */
@@ -262,6 +268,8 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->a_src_list = 0;
   p->dev_skip_mask = 0;
   p->dev_trace = 0;
+  p->rew_log = 0;
+  p->rew_slots = p->rew_epoch = 0;
   p->dev_draw_window = 0;
   p->auto_reset = 0;
   p->ev_replicas = p->ev_cap = p->ev_stride = 0;  /* dense-log replicas: the fast kernels never record events */

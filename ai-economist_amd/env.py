@@ -61,14 +61,18 @@ class DeviceBackend:
         try:
             self._finish_init(cfg, layout_planes, lib_owned, nbytes)
         except BaseException:
-            # nothing else knows the handle yet: destroy it (and a library-owned arena with it) instead of leaking it
+            # nothing else knows the handle yet: destroy it (and a library-owned arena with it) instead of leaking it.
+            # Exactly once: an owner object, once it exists, destroys the handle in its __del__ -- which may
+            # run right here or later, when the last view of the arena goes -- so it is disarmed first and the one
+            # aie_destroy call is this one.
+            owner = getattr(self, "_arena_owner", None)
+            if owner is not None:
+                owner.handle = None
             self._arena_owner = None
             self.tensors = {}
+            self.arena = None
             try:
-                if lib_owned and getattr(self, "arena", None) is not None:
-                    self.arena = None  # (drops the owner object, whose __del__ destroys the handle)
-                else:
-                    self.lib.aie_destroy(self.handle)
+                self.lib.aie_destroy(self.handle)
             finally:
                 self.handle = None
             raise

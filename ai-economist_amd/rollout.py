@@ -34,6 +34,10 @@ class GraphedStep:
         be = self.be
         if auto_reset:
             be.set_auto_reset(True)
+        # The capture records whichever step kernel is current and replays it forever, and auto-reset restarts replicas
+        # without passing through aie_reset (where a finished background specialisation is adopted otherwise): wait for
+        # the configuration's specialised kernels here, best effort (the generic kernel gives the same results)
+        self.specialised = bool(be.specialize(required=False))
         self.actions_a, self.actions_p = be._action_buffers(0)
         self.graph = None
         self._capture(warmup)

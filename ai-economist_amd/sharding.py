@@ -139,7 +139,8 @@ class RewardLogGather:
     (`g.received_obs`: one {name: [W * E, ...]} dict per block on `dst`, ObservationGather).
     """
 
-    def __init__(self, backend, steps_per_gather=64, dst=0, keep=False, force_collective=False, gather_obs=None):
+    def __init__(self, backend, steps_per_gather=64, dst=0, keep=False, force_collective=False, gather_obs=None,
+                 host_staged=None):
         import torch
         import torch.distributed as dist
 
@@ -149,6 +150,16 @@ class RewardLogGather:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.backend = backend
         self.log = backend.set_reward_log(2 * self.K)  # [2K, E, n + 2]
+        # host_staged: the block travels through pinned host memory and the group's CPU collective (gloo gathers CPU
+        # tensors only).  That is the exchange of several ranks that SHARE one device -- RCCL refuses two ranks on one
+        # GPU -- i.e. of the two-ranks-on-one-GPU test and of `bench.py --oversubscribe-one-gpu`; default: whenever the
+        # group's backend is gloo and the log lives on a GPU.
+        if host_staged is None:
+            host_staged = bool(dist.is_initialized() and dist.get_backend() == "gloo" and self.log.is_cuda)
+        self.host_staged = bool(host_staged)
+        self.stage = None
+        if self.host_staged:
+            self.stage = [torch.empty(self.log[: self.K].shape, dtype=self.log.dtype).pin_memory() for _ in range(2)]
         self.filled = 0   # steps written into the current block
         self.block = 0    # block being written (0 / 1)
         self.pending = [None, None]  # outstanding collective per block
@@ -156,8 +167,11 @@ class RewardLogGather:
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self.recv = None
         if self.rank == dst and self.collective:
-            self.recv = [[torch.empty_like(self.log[: self.K]) for _ in range(self.world)] for _ in range(2)]
+            like = self.stage[0] if self.host_staged else self.log[: self.K]
+            self.recv = [[torch.empty_like(like) for _ in range(self.world)] for _ in range(2)]
         self.received = []
+        if gather_obs and self.host_staged:
+            raise NotImplementedError("RewardLogGather: gather_obs travels over the device collective only (not host-staged)")
         self.obs_gather = ObservationGather(backend, gather_obs, dst) if gather_obs else None
         self.obs_pending = [None, None]  # observation gathers started with a block, waited for with it
         self.received_obs = []
@@ -168,6 +182,8 @@ class RewardLogGather:
             # the communicator is created by the first collective (hundreds of milliseconds): here, not inside
             # somebody's rollout
             warm = self.log[:1, :1].clone()
+            if self.host_staged:
+                warm = warm.cpu()
             self.dist.gather(warm, [torch.empty_like(warm) for _ in range(self.world)] if self.rank == dst else None,
                              dst=dst)
 
@@ -181,7 +197,7 @@ class RewardLogGather:
         if self.collective:
             # async_op: the backend orders the collective behind the steps already enqueued (RCCL runs it on its
             # own stream), and wait() below orders later steps behind it -- the steps in between overlap it
-            self.pending[b] = self.dist.gather(view, self.recv[b] if self.rank == self.dst else None,
+            self.pending[b] = self.dist.gather(self._staged(view, b), self.recv[b] if self.rank == self.dst else None,
                                                dst=self.dst, async_op=True)
             self.n_collectives += 1
         elif self.keep:
@@ -194,6 +210,16 @@ class RewardLogGather:
         self.block ^= 1
         self._wait(self.block)  # the block about to be overwritten must have left
         return True
+
+    def _staged(self, view, b):
+        """The block as the collective takes it: itself, or -- host_staged -- its copy in pinned host memory (a device ->
+        host copy on the step stream, waited for here: the CPU collective reads it as soon as it is started)."""
+        if not self.host_staged:
+            return view
+        dst = self.stage[b][: view.shape[0]]
+        dst.copy_(view, non_blocking=True)
+        self.torch.cuda.current_stream(view.device).synchronize()
+        return dst
 
     def _wait(self, b):
         import time
@@ -225,7 +251,7 @@ class RewardLogGather:
                 self.obs_pending[b] = self.obs_gather.start(b)
             view = self.log[b * self.K: b * self.K + f]
             if self.collective:
-                w = self.dist.gather(view, [r[:f] for r in self.recv[b]] if self.rank == self.dst else None,
+                w = self.dist.gather(self._staged(view, b), [r[:f] for r in self.recv[b]] if self.rank == self.dst else None,
                                      dst=self.dst, async_op=True)
                 self.n_collectives += 1
                 import time

@@ -611,7 +611,7 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
     elapsed = elapsed_local
     per_rank = [elapsed_local]
     if world > 1:
-        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed_local], dtype=torch.float64, device="cpu" if args.oversubscribe_one_gpu else device)
         allt = [torch.zeros_like(tt) for _ in range(world)]
         torch.distributed.all_gather(allt, tt)
         per_rank = [float(x.item()) for x in allt]
@@ -625,7 +625,7 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
     avg_ms = (region_ms - reset_ms) / launches_in_region
     per_rank_launch_ms = [avg_ms]
     if world > 1:  # every rank's own kernel time (HIP events on its launch stream): separates it from the gather's wait
-        tt = torch.tensor([avg_ms], dtype=torch.float64, device=device)
+        tt = torch.tensor([avg_ms], dtype=torch.float64, device="cpu" if args.oversubscribe_one_gpu else device)
         allt = [torch.zeros_like(tt) for _ in range(world)]
         torch.distributed.all_gather(allt, tt)
         per_rank_launch_ms = [float(x.item()) for x in allt]
@@ -723,8 +723,11 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
             "config": {
                 "workload": "%s: %s; uniform random policy; mobile agents counted (planner excluded)" % (wl, W["desc"]),
                 "workload_short": "%s %s, %s random policy, planner not counted" % (wl, W["short"], "mask-respecting" if roll.masked else "uniform"),
-                "parallelism_short": ("replica sharding x%d, RCCL (reward,done) gather to rank 0" % world) if world > 1
+                "parallelism_short": (("replica sharding x%d on ONE GPU, gloo host-staged (reward,done) gather to rank 0"
+                                       if args.oversubscribe_one_gpu else
+                                       "replica sharding x%d, RCCL (reward,done) gather to rank 0") % world) if world > 1
                 else "single GPU",
+                "oversubscribed_one_gpu": bool(args.oversubscribe_one_gpu) or None,
                 "envs_per_gpu": E, "global_envs": world * E, "n_agents": n,
                 "policy_short": "masked" if roll.masked else "unmasked",
                 "rng": ("per-replica counter-based stream, Philox2x32-10 (rng_mode='fast': NOT NumPy's stream; bit-exact "
@@ -797,6 +800,8 @@ def compact_line(out):
     line["config"] = {"workload": cfg["workload_short"], "envs_per_gpu": cfg["envs_per_gpu"],
                       "global_envs": cfg["global_envs"], "n_agents": cfg["n_agents"],
                       "kernel_specialisation": cfg["kernel_specialisation"], "parallelism": cfg["parallelism_short"]}
+    if cfg.get("oversubscribed_one_gpu"):
+        line["config"]["oversubscribed_one_gpu"] = True  # (N ranks on one device: the N > 1 path, not a scaling figure)
     line["roofline"] = {k: out["roofline"].get(k) for k in ROOF_KEYS}
     line["gpu_region_seconds"] = out["gpu_region_seconds"]
     if out["n_gpus"] > 1 or out.get("gather"):
@@ -991,6 +996,10 @@ def main():
                     help="run the N > 1 reward-log gather in a 1-rank group (exercises the RCCL path on one GPU)")
     ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"),
                     help="where the full (uncompacted) result goes; the last stdout line is the <= 4 KB driver line")
+    ap.add_argument("--oversubscribe-one-gpu", action="store_true",
+                    help="development / tests: all N ranks share HIP device 0 (a gloo group and the host-staged reward-log "
+                         "gather: RCCL refuses two ranks on one device) -- the N > 1 path with real kernels on a 1-GPU box; "
+                         "the line says so (config.oversubscribed_one_gpu) and is no scaling measurement")
     ap.add_argument("--launcher", choices=["auto", "torchrun"], default="auto",
                     help="torchrun: re-execute under torch.distributed.run even with --gpus 1 (the N > 1 launch path on one GPU)")
     args = ap.parse_args()
@@ -1000,7 +1009,7 @@ def main():
             import torch
 
             have = torch.cuda.device_count()
-            if args.gpus > have:
+            if args.gpus > have and not args.oversubscribe_one_gpu:
                 sys.exit("bench.py: --gpus %d, but only %d HIP device(s) are visible on this node" % (args.gpus, have))
         sys.exit(self_launch(args))
 
@@ -1013,6 +1022,8 @@ def main():
         sys.exit("bench.py refuses to run with development switches set: %s" % dev_env)
 
     rank, local_rank, world = dist_info()
+    if args.oversubscribe_one_gpu:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         sys.exit("bench.py: rank %d wants HIP device %d, but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
     if args.gpus > 1 or world > 1 or args.force_gather or args.launcher == "torchrun":
@@ -1020,7 +1031,10 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.oversubscribe_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         assert world == max(1, args.gpus), "world size %d != --gpus %d" % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)

@@ -423,7 +423,11 @@ int aie_step_sample_next_masked(aie_env* env, const int32_t* d_actions_a, const 
  * d_log[((slot * n_envs) + e) * (n_agents + 2) + ...], slot = 0, 1, ... n_slots - 1, 0, ... advancing by one per
  * step (this call resets it to 0).  The caller owns d_log (n_slots * n_envs * (n_agents + 2) floats) and ships
  * whole ranges of slots to the learner rank with one collective per many steps instead of one per step
- * (ai_economist_amd/sharding.py).  d_log == NULL switches the log off.  All scenarios. */
+ * (ai_economist_amd/sharding.py).  d_log == NULL switches the log off.  All scenarios.
+ * The log's address, slot count and restart live in device memory, not in the step's kernel arguments: step launches
+ * captured in a hipGraph BEFORE this call write to the log this call names when they are replayed after it, and a
+ * replica that sits a launch out (COVID: stepped past its episode's end without a reset) still moves its slot with the
+ * batch's.  The call waits for the device to go idle (call it between steps, not under stream capture). */
 int aie_set_reward_log(aie_env* env, float* d_log, int32_t n_slots);
 
 /* Auto-reset (the vectorised-trainer convention, reference analogue: F/env_wrapper.py:341-353 reset_only_done_envs):

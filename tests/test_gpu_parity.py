@@ -834,6 +834,81 @@ def test_reward_log_slots_follow_the_steps(case):
     assert torch.equal(log, before)
 
 
+def test_covid_replica_past_its_episode_end_keeps_its_call_counters_with_the_batch():
+    """a COVID replica stepped past its episode's end without a reset does nothing -- but its reward-log slot
+    and its draw index still advance with every launch, so that after its reset it writes the slot (and draws with the
+    index) its peers do."""
+    cfg = _reward_log_cases()["covid"]
+    E = 6
+    env = make_env(cfg, n_envs=E, device="cuda:0")
+    env.reset()
+    be = env.backend
+    be.set_reward_log(4)
+    T = int(env.episode_length)
+    # put replicas 0..2 at the end of their episode (the state a rollout reaches after T steps), leave 3..5 at the start
+    be.tensors["timestep"][:3] = T
+    cur = be.sample_random_actions(7, 0, slot=0)
+    slot = 0
+    for t in range(3):
+        cur = be.step_sample_next(cur[0], cur[1], 7, 0, next_slot=slot ^ 1)
+        slot ^= 1
+    assert be.tensors["timestep"].cpu().tolist() == [T] * 3 + [3] * 3  # the first three sat the launches out ...
+    assert be.tensors["rew_log_slot"].cpu().tolist() == [3] * E      # ... and kept their slot
+    assert be.tensors["sample_t"].cpu().tolist() == [int(be.tensors["sample_t"][5])] * E  # ... and their draw index
+
+
+def test_captured_step_follows_a_later_set_reward_log_call():
+    """the reward log's address, slot count and restart live in the device-side parameter block, so a step
+    launch captured in a hipGraph writes to the log that the LATEST aie_set_reward_log call named (RewardLogGather.finish
+    rewinds the log after the capture): replays after a rewind restart at slot 0 and equal an eager twin's log."""
+    import torch
+
+    E = 24
+    envs = []
+    for _ in range(2):
+        env = make_env(C2, n_envs=E, device="cuda:0")
+        env.seed(5)
+        env.reset()
+        envs.append(env)
+    (eg, ee) = envs
+    bg, bee = eg.backend, ee.backend
+    n = bg.n
+    log_g, log_e = bg.set_reward_log(4), bee.set_reward_log(4)
+    acts = [bg.sample_random_actions(31 + k, 0, slot=0) for k in range(1)][0]
+    a, p = acts[0].clone(), acts[1].clone()
+    for be in (bg, bee):  # two steps each: the slot counters stand at 2
+        be.step(a, p)
+        be.step(a, p)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        bg.step(a, p)
+    torch.cuda.current_stream().wait_stream(side)
+    bee.step(a, p)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        bg.step(a, p)
+    # after the capture: rewind both logs (a new epoch: the next step fills slot 0) -- the graph must follow
+    bg.rewind_reward_log()
+    bee.rewind_reward_log()
+    log_g.zero_()
+    log_e.zero_()
+    for _ in range(3):
+        graph.replay()
+        bee.step(a, p)
+    torch.cuda.synchronize()
+    assert bg.tensors["rew_log_slot"].cpu().tolist() == [3] * E
+    assert torch.equal(log_g, log_e)
+    assert float(log_g[:3].abs().sum()) > 0 and float(log_g[3].abs().sum()) == 0
+    # and a log somewhere else entirely
+    new_g, new_e = bg.set_reward_log(2), bee.set_reward_log(2)
+    graph.replay()
+    bee.step(a, p)
+    torch.cuda.synchronize()
+    assert torch.equal(new_g, new_e) and float(new_g[0].abs().sum()) > 0
+
+
 def test_reward_log_gather_over_rccl():
     """sharding.RewardLogGather on the real collective backend: an RCCL ("nccl") process group over whatever GPUs
     this process sees (one rank here; the multi-rank logic is covered by the gloo tests): blocks of 4 steps travel
