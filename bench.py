@@ -251,6 +251,30 @@ def measured_traffic(wl, envs_per_gpu, max_round=None):
     return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
+def summary_provenance(path):
+    """(round, stale) of a committed counter summary: the round from its file name (profiles/rNN_...), stale = it was
+    collected on kernels other than the ones this library was built from -- its `source_hash` (tools/pmc_summary.py,
+    tools/sq_passes.sh; absent before round 6) is not the hash of the sources in this tree."""
+    import re
+
+    if not path:
+        return None, None
+    m = re.match(r"^r(\d+)_", os.path.basename(path))
+    rnd = int(m.group(1)) if m else None
+    try:
+        have = json.load(open(os.path.join(ROOT, path))).get("source_hash")
+    except (OSError, ValueError):
+        have = None
+    try:
+        import ai_economist_amd  # noqa: F401
+        from ai_economist_amd import _build
+
+        now = _build._source_hash()
+    except Exception:
+        now = None
+    return rnd, (have is None or now is None or have != now)
+
+
 def usable_cores():
     try:
         n = len(os.sched_getaffinity(0))
@@ -678,6 +702,9 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
             arena_allocator=arena["allocator"], arena_piece_mib=arena["piece_mib"],
             bound=bound, roof="hbm", kernel=kernel_name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, hbm_traffic_frac=traffic_frac,
+            frac_moved=traffic_frac,  # = hbm_traffic_frac: MEASURED bytes / time / peak (what `frac` > 1 has to be read against)
+            traffic_round=summary_provenance(traffic_src)[0], traffic_stale=summary_provenance(traffic_src)[1],
+            counters_round=summary_provenance(insts_src)[0], counters_stale=summary_provenance(insts_src)[1],
             issue_frac=issue_frac, wave_instructions_per_launch=insts, issue_source=insts_src,
             valu_frac=valu_frac, valu_instructions_per_launch=valu_insts,
             valu_roof="a wave64 VALU instruction occupies its SIMD for 4 clocks: %d SIMDs x %.1f GHz / 4" % (N_SIMDS, SM_CLOCK_HZ / 1e9),
@@ -772,10 +799,11 @@ LINE_LIMIT = 4096
 # frac = SURVEY 8(d)'s algorithmic bytes / launch time / peak; frac_final_layout = the same with the bytes of the layouts
 # actually used (COVID: SURVEY's figure assumes the 601-day window is streamed every step, which neither kernel does any
 # more -- the sums over the window are the same float64, the bytes are not)
-ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_final_layout", "traffic", "hbm_traffic_frac",
-             "valu_frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "arena_bytes", "fits_infinity_cache")
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_final_layout", "traffic", "frac_moved",
+             "valu_frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "arena_bytes", "fits_infinity_cache",
+             "traffic_round", "traffic_stale", "counters_round", "counters_stale")
 # (side entries: no kernel names -- the detail file has them -- so that thirteen of them fit the 4 KB line)
-SIDE_KEYS = ("value", "ms_per_step", "avg_launch_ms", "frac", "hbm_traffic_frac", "valu_frac", "bound")  # (frac_final_layout: detail file)
+SIDE_KEYS = ("bound", "value", "avg_launch_ms", "frac", "frac_moved", "valu_frac")  # (ms_per_step, frac_final_layout: detail file)
 
 
 def _sig(x, digits=5):
@@ -826,6 +854,10 @@ def compact_line(out):
                 continue
             flat = dict(r.get("roofline") or {}, **{k: r.get(k) for k in ("value", "ms_per_step", "gpu_region_seconds")})
             sides[name] = {k: flat.get(k) for k in SIDE_KEYS if flat.get(k) is not None}
+            if flat.get("counters_stale") or flat.get("traffic_stale"):
+                # a counter-derived field of this entry (valu_frac / bound, frac_moved) comes from a committed summary that
+                # was collected on other kernels than this tree's; which round's: the detail file
+                sides[name]["stale"] = True
             if name.startswith("C4"):
                 sides[name]["policy"] = (r.get("config") or {}).get("policy_short")
             if not flat.get("fits_infinity_cache", True):
@@ -844,7 +876,7 @@ def compact_line(out):
     text = json.dumps(line, separators=(",", ":"))
     if len(text) > LINE_LIMIT:  # cannot happen with the key sets above (tests/test_bench_accounting.py); never truncate JSON
         for name in list(line.get("workloads", {})):
-            line["workloads"][name] = {k: line["workloads"][name].get(k) for k in ("value", "ms_per_step", "frac")}
+            line["workloads"][name] = {k: line["workloads"][name].get(k) for k in ("value", "avg_launch_ms", "frac")}
         text = json.dumps(line, separators=(",", ":"))
     assert len(text) <= LINE_LIMIT, len(text)
     return text

@@ -63,7 +63,8 @@ def _synthetic_full_result(n_gpus=1, long_strings=400):
     prose = "x" * long_strings
     roof = dict(bound="latency", roof="hbm", kernel="aie_step_kernel_spec<0>" + "k" * 40, achieved=7225.123456789,
                 peak=8000.0, unit="GB/s", frac=0.903140432, traffic=83412345.678, traffic_source=prose,
-                hbm_traffic_frac=0.4187654321, issue_frac=0.2987654321, wave_instructions_per_launch=123456789,
+                hbm_traffic_frac=0.4187654321, frac_moved=0.4187654321, traffic_round=6, traffic_stale=False, counters_round=4,
+                counters_stale=True, issue_frac=0.2987654321, wave_instructions_per_launch=123456789,
                 issue_source=prose, valu_frac=0.6087654321, valu_instructions_per_launch=98765432, valu_roof=prose,
                 issue_roof=prose, algorithmic_bytes_per_launch=179961856.0, algorithmic_bytes_per_unit=10984.0,
                 unit_of_work=prose, achieved_final_layout=8281.123, frac_final_layout=1.035,
@@ -106,6 +107,14 @@ def test_driver_line_stays_under_4_kb_and_keeps_the_contract(n_gpus):
     assert line["config"]["global_envs"] == n_gpus * line["config"]["envs_per_gpu"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in line["roofline"]
+    assert list(line["roofline"])[0] == "bound"  # what limits the kernel comes first: a `frac` above 1 is read against it
+    # provenance of the counter-derived fields: which round's committed summaries, and whether they were
+    # collected on the kernels of this tree
+    assert line["roofline"]["frac_moved"] == pytest.approx(full["roofline"]["hbm_traffic_frac"], rel=1e-4)
+    assert line["roofline"]["counters_round"] == 4 and line["roofline"]["counters_stale"] is True
+    assert line["roofline"]["traffic_round"] == 6 and line["roofline"]["traffic_stale"] is False
+    for name, _, _ in bench.SIDE_WORKLOADS:
+        assert line["workloads"][name]["stale"] is True and list(line["workloads"][name])[0] == "bound"
     assert line["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4)
     assert line["value"] == pytest.approx(full["value"], rel=1e-4)
     assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
@@ -124,3 +133,21 @@ def test_emit_prints_the_compact_line_last(tmp_path, capsys):
     assert len(lines) == 2 and len(lines[-1]) < 4096
     assert json.loads(lines[0]) == json.loads(open(tmp_path / "detail.json").read())
     assert json.loads(lines[-1])["detail"] == "bench_detail.json"
+
+
+def test_summary_provenance_flags_summaries_of_other_kernels(tmp_path, monkeypatch):
+    """bench.summary_provenance: the round comes from the file name; a summary without a source hash (rounds 1 - 5) or with
+    another tree's hash is stale, one that carries this tree's hash is not."""
+    import ai_economist_amd  # noqa: F401
+    from ai_economist_amd import _build
+
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    now = _build._source_hash()
+    for name, payload in (("r04_c2_sq_counters.json", {}), ("r06_c2_pmc.json", {"source_hash": now}),
+                          ("r06_c3_pmc.json", {"source_hash": "0" * 64})):
+        (tmp_path / "profiles" / name).write_text(json.dumps(payload))
+    assert bench.summary_provenance("profiles/r04_c2_sq_counters.json") == (4, True)
+    assert bench.summary_provenance("profiles/r06_c2_pmc.json") == (6, False)
+    assert bench.summary_provenance("profiles/r06_c3_pmc.json") == (6, True)
+    assert bench.summary_provenance(None) == (None, None)

@@ -40,5 +40,14 @@ res = {
     "calibration_arena_fill_WRITE_SIZE_KiB": fill[0] if fill else None,
     "notes": "separate --pmc passes; KiB units; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md",
 }
+# which kernels were measured: the content hash of the library's sources (ai_economist_amd/_build.py) -- bench.py flags a
+# summary whose hash is not the running library's as stale (round 6)
+try:
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res["source_hash"] = open(os.path.join(root, "ai-economist_amd", "csrc", "libaie_hip.so.srchash")).read().strip()
+except OSError:
+    res["source_hash"] = None
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

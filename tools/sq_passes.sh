@@ -49,5 +49,9 @@ for k, d in acc.items():
     print(k)
     for name, v in c.items():
         print("   %-26s mean %.4g" % (name, v))
+try:  # which kernels were measured (bench.py flags a summary whose hash is not the running library's as stale)
+    out["source_hash"] = open("$R/ai-economist_amd/csrc/libaie_hip.so.srchash").read().strip()
+except OSError:
+    out["source_hash"] = None
 json.dump(out, open("$R/gpurun_out/r04_${WL}_sq_counters.json", "w"), indent=1)
 PY
