@@ -200,6 +200,8 @@ def bind(lib):
     lib.aie_sample_random_actions.argtypes = [vp, C.c_uint64, C.c_int64, vp, vp, vp]
     lib.aie_set_reward_log.restype = C.c_int
     lib.aie_set_reward_log.argtypes = [vp, vp, C.c_int32]
+    lib.aie_step_range.restype = C.c_int
+    lib.aie_step_range.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.aie_step_sample_next.restype = C.c_int
     lib.aie_step_sample_next.argtypes = [vp, vp, vp, C.c_uint64, C.c_int64, vp, vp, vp]
     lib.aie_step_sample_next_masked.restype = C.c_int
@@ -229,8 +231,9 @@ EXPORTED_SYMBOLS = [
     "aie_seed", "aie_seed_fast", "aie_set_rng_state", "aie_reset", "aie_step", "aie_sample_random_actions",
     "aie_sample_masked_actions", "aie_sample_policy_actions", "aie_step_sample_next", "aie_step_sample_next_masked", "aie_set_reward_log", "aie_set_auto_reset",
     "aie_set_dense_log_active", "aie_step_kernel_instance", "aie_select_step_kernel", "aie_specialize", "aie_set_global_saez_buffer", "aie_sizeof_config",
-    "aie_arena_info",
+    "aie_arena_info", "aie_step_range",
 ]
+STEP_HEAD, STEP_TAIL, STEP_OBSERVE, STEP_REBASE, STEP_RETAX = 1, 2, 4, 8, 16  # AIE_STEP_*
 ARENA_ALLOCATORS = ["caller", "hipMalloc", "vmm"]  # AIE_ARENA_*
 KERNEL_AUTO, KERNEL_GENERIC = 0, 1
 KERNEL_INSTANCE_JIT = 1000

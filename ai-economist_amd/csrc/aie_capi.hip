@@ -552,6 +552,35 @@ int aie_step(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_
   return aie_step_impl(env, d_actions_a, d_actions_p, stream, NextActions{});
 }
 
+int aie_step_range(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, int32_t comp_lo, int32_t comp_hi,
+                   int32_t phases, void* stream) {
+  if (!env) return AIE_E_INVALID;
+  const aie_params& P = env->P;
+  if (P.c.scenario != AIE_SCN_GTB || P.saez_stride || (P.ev_replicas > 0 && env->log_active)) {
+    snprintf(env->err, sizeof(env->err), "aie_step_range: gather-trade-build scenarios without tax_model \"saez\", and not while a "
+             "dense-log replica records");
+    return AIE_E_UNSUPPORTED;
+  }
+  if (comp_lo < 0 || comp_hi < comp_lo || comp_hi > P.c.n_components || phases < 0 || phases > 31 ||
+      ((phases & AIE_STEP_OBSERVE) && (phases & ~(AIE_STEP_OBSERVE | AIE_STEP_REBASE | AIE_STEP_RETAX))) ||
+      ((phases & (AIE_STEP_REBASE | AIE_STEP_RETAX)) && !(phases & AIE_STEP_OBSERVE))) {
+    snprintf(env->err, sizeof(env->err), "aie_step_range: components [%d, %d) of %d, phases %d", comp_lo, comp_hi, P.c.n_components, phases);
+    return AIE_E_INVALID;
+  }
+  AIE_HIP_CHECK(env, hipSetDevice(env->device));
+  NextActions next{};
+  next.E = (int32_t)P.E;
+  next.comp_lo = comp_lo;
+  next.comp_hi = comp_hi;
+  next.phase = phases | 32;  // (never 0 = "a whole step": bit 5 marks a ranged launch)
+  hipLaunchKernelGGL(aie_step_kernel_log, dim3((unsigned)P.E), dim3(2 * AIE_NT), env->lds, static_cast<hipStream_t>(stream),
+                     env->d_params, env->arena, d_actions_a, d_actions_p, next);
+  if ((phases & AIE_STEP_TAIL) && P.auto_reset)  // as behind aie_step: the replicas this step finished restart right behind it
+    aie_launch_gtb_reset(env, env->arena + P.a_done, 1, stream);
+  AIE_HIP_CHECK(env, hipGetLastError());
+  return AIE_OK;
+}
+
 int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, uint64_t seed,
                          int64_t global_env_offset, int32_t* d_next_a, int32_t* d_next_p, void* stream) {
   if (!env) return AIE_E_INVALID;

@@ -632,12 +632,7 @@ __device__ __forceinline__ double np_seq_elem(const double* a, int n, int mode, 
   const int r = (int)(((uint32_t)idx * M) >> 16);
   return fabs(a[r] - a[idx - r * n]);
 }
-#ifdef AIE_EXP_NOSCRATCH
-__device__ __forceinline__ double np_sum_leaf(
-#else
-__device__ __attribute__((noinline)) double np_sum_leaf(
-#endif
-const double* a, int n, int mode, uint32_t M, int o, int m,
+__device__ __attribute__((noinline)) double np_sum_leaf(const double* a, int n, int mode, uint32_t M, int o, int m,
                                                         int lane) {
   if (m < 8) {
     double res = -0.0;
@@ -807,12 +802,7 @@ __device__ __attribute__((noinline, cold)) Refill rng_refill_fast(uint32_t* st, 
   return Refill{pos, avail, twisted};
 }
 __device__ __forceinline__ uint32_t rng_u32(MTL& l, int lane) {
-#ifdef AIE_EXP_NOSCRATCH  // (timing experiment only: no refill, wrong numbers past the window)
-  if (l.pos >= l.base + l.avail) { l.pos += 1; return (uint32_t)l.pos * 2654435761u; }
-  if (false) {
-#else
   if (__builtin_expect(l.pos >= l.base + l.avail, 0)) {
-#endif
     const Refill r = l.fast ? rng_refill_fast(l.gkey, l.w, l.cap, l.pos, lane) : rng_refill(l.gkey, l.w, l.cap, l.pos, lane);
     l.pos = uni(r.pos);  // (a function's results come back in vector registers: keep the bookkeeping scalar)
     l.base = l.pos;
@@ -1958,11 +1948,7 @@ __device__ __forceinline__ void scenario_step_regen(const Ctx& c, MT& m, const S
     AIE_WSYNC();
   }
   const int S = src.S;
-#ifdef AIE_EXP_NOSCRATCH
-  if (false) {
-#else
   if (S > AIE_SRC_CAP) {
-#endif
     if (m.fast && m.pos < AIE_MT_N) mt_fast_rows(m, c.tid);  // (the counter stream keeps no rows between steps)
     scenario_step_regen_rows(c, m);
     return;
@@ -2687,6 +2673,11 @@ struct NextActions {  // aie_step_sample_next: where and how to sample the next 
   // kernel (aie_capi.hip: aie_step_impl)
   int32_t e_lo, e_hi;
   int32_t masked;  // aie_step_sample_next_masked (COVID): the next actions are drawn among what the new masks allow
+  // aie_step_range (custom host components, include/aie.h): the built-in components [comp_lo, comp_hi) of the list and
+  // the parts of a step this launch performs -- AIE_STEP_HEAD (timestep += 1), AIE_STEP_TAIL (regeneration, observations,
+  // masks, rewards, done), AIE_STEP_OBSERVE (observations and masks of the state as it stands, nothing else); phase == 0:
+  // a whole step.  Honoured by the full-featured kernel only (aie_step_kernel_log); everybody else steps whole steps.
+  int32_t comp_lo, comp_hi, phase;
   // The replica count, by value: a workgroup needs it for its very first decision (which replica it is), and as a
   // kernel argument it arrives with the argument segment instead of behind a second, dependent round trip to the
   // parameter block (round 6: the caches are cold at every launch, a first touch from the far XCDs takes ~1 us).
@@ -2771,6 +2762,12 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   // ten agents the utilities' n^2 gini terms make them the longer piece: C3f 35.3 -> 37.4 us, so they stay where they
   // were).  They share no scratch slot with the flat-vector writer (current_metrics).
   const bool REW_ON_W1 = FAST && P.n < 8;
+  // partial steps (aie_step_range): compile-time "whole step" everywhere but in the full-featured kernel
+  const int ph = LOG ? next.phase : 0;
+  const bool HEAD = ph == 0 || (ph & 1), TAIL = ph == 0 || (ph & 2), OBSERVE = ph != 0 && (ph & 4) && !(ph & 2);
+  const bool REBASE = OBSERVE && (ph & 8);  // utilities := current (the reward baseline a reset leaves, layout_from_file.py:347-349)
+  const bool RETAX = OBSERVE && (ph & 16);  // PeriodicBracketTax's reset-time snapshot of the agents' coin (redistribution.py:1106-1110)
+  const int c_lo = ph ? next.comp_lo : 0, c_hi = ph ? next.comp_hi : P.c.n_components;
   // The two waves run two separate ARMS from here to the end, each with its own copy of the four workgroup barriers
   // (the branch is wave-uniform, every wave passes the same number of them): a value that only one wave carries --
   // the agents' registers and the draw cache of the first, the generator's ten rows of the second -- is then live in
@@ -2796,14 +2793,17 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     }
     agents_load(c, A);
     if (act_err && c.tid == 0) *R_I32(c, o_error_flags) |= act_err;
-    if (P.has_cda && !(skip & 1)) cda_decay_price_history(c);
+    bool cda_in_range = ph == 0;  // (the decay opens ContinuousDoubleAuction.component_step: with the component)
+    if (ph != 0)
+      for (int k = c_lo; k < c_hi; ++k) cda_in_range |= P.c.components[k] == AIE_COMP_CDA;
+    if (P.has_cda && !(skip & 1) && cda_in_range) cda_decay_price_history(c);
     __syncthreads();  // (3) occupancy map rebuilt
-    if (c.tid == 0) *R_I32(c, o_timestep) += 1;
+    if (c.tid == 0 && HEAD) *R_I32(c, o_timestep) += 1;
     if (c.ev && c.tid == 0) c.srcn[2] = 0;
     __builtin_amdgcn_s_setprio(3);  // the serial dynamics are the replica's critical path
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 1] = wall_clock64();
     if (!(skip & 1)) {
-      for (int k = 0; k < P.c.n_components; ++k) {
+      for (int k = c_lo; k < c_hi; ++k) {
         switch (P.c.components[k]) {
           case AIE_COMP_BUILD: if (!(skip & 2048)) build_component_step(c, ml, A); break;
           case AIE_COMP_CDA: if (!(skip & 4096)) cda_component_step(c, A); break;
@@ -2829,9 +2829,18 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     __syncthreads();  // (4) components done; the generator's position (and, after a refill that twisted, its state in HBM) is final
     // flat observation vectors and rewards: neither looks at the map
     if (w0_tail_prio) __builtin_amdgcn_s_setprio(2);
-    if (!(skip & 8)) write_flat_observations(c, arena);
+    if (!(skip & 8) && (TAIL || OBSERVE)) write_flat_observations(c, arena);
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 10] = wall_clock64();
-    if (!REW_ON_W1) step_rewards_and_done(c, arena, next, skip);
+    if (!REW_ON_W1 && TAIL) step_rewards_and_done(c, arena, next, skip);
+    if (RETAX && P.has_tax && c.tid < P.n)
+      R_F64(c, o_tax_last_coin)[c.tid] = R_F64(c, o_inv_coin)[c.tid] + R_F64(c, o_esc_coin)[c.tid];
+    if (REBASE) {  // (reset_body's last lines: the metrics of the state as the host's reset hooks left it)
+      AIE_WSYNC();
+      current_metrics(c);
+      AIE_WSYNC();
+      if (c.tid <= P.n) R_F64(c, o_util)[c.tid] = scr_part(c)[c.tid];
+      AIE_WSYNC();
+    }
     if (w0_tail_prio) __builtin_amdgcn_s_setprio(0);
     __syncthreads();  // (5)
     if (!(skip & 32)) store_record_step(c, arena, 0, NW);
@@ -2867,7 +2876,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       for (int j = 0; j < 9; ++j) m.r[j] = gkey[64 * j + c.tid];
       m.r[9] = c.tid < 48 ? gkey[576 + c.tid] : 0u;
     }
-    if (next.a || next.p) {
+    if ((next.a || next.p) && TAIL) {
       const int per_env = P.n * P.act_a_width + P.act_p_width;
       const int st = uni(*R_I32(c, o_sample_t));  // (the first wave does not touch this field)
       for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, (int64_t)st, c.e, j, next.a, next.p);
@@ -2890,28 +2899,28 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       mt_rows_from_hbm(m, gkey, c.tid);
     }
     m.pos = uni(*R_I32(c, o_mt_pos));
-    if (!(skip & 2)) scenario_step_regen(c, m, src);
-    if (c.tid == 0) {
-      *R_I32(c, o_mt_pos) = m.pos;
-      if (FAST) R_U32(c, o_mt)[1] = m.fblk;
+    if (TAIL) {
+      if (!(skip & 2)) scenario_step_regen(c, m, src);
+      if (c.tid == 0) {
+        *R_I32(c, o_mt_pos) = m.pos;
+        if (FAST) R_U32(c, o_mt)[1] = m.fblk;
+      }
+      if (!(skip & 32)) store_generator_rows(c, arena, m);  // (the rows' registers are free from here on)
     }
-    if (!(skip & 32)) store_generator_rows(c, arena, m);  // (the rows' registers are free from here on)
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
     AIE_WSYNC();
-    if (!(skip & 4)) {
+    if (!(skip & 4) && (TAIL || OBSERVE)) {
       // the map observations of the previous step are still in the arena: update them in place,
-      // unless something outside the kernels touched the state (obs_valid == 0)
-#ifdef AIE_EXP_NOSCRATCH
-      update_spatial_observations(c, arena);
-#else
-      if (uni(*R_I32(c, o_obs_valid)) && !(skip & 32768)) update_spatial_observations(c, arena);
+      // unless something outside the kernels touched the state (obs_valid == 0; an AIE_STEP_OBSERVE launch: always)
+      if (uni(*R_I32(c, o_obs_valid)) && !(skip & 32768) && !OBSERVE) update_spatial_observations(c, arena);
       else write_spatial_observations(c, arena);
-#endif
       if (c.tid == 0) *R_I32(c, o_obs_valid) = 1;
+    } else if (!TAIL && !OBSERVE && c.tid == 0) {
+      *R_I32(c, o_obs_valid) = 0;  // a partial step changed the state and wrote no observations: the launch that does starts over
     }
-    if (!(skip & 8)) write_action_masks(c, arena);
+    if (!(skip & 8) && (TAIL || OBSERVE)) write_action_masks(c, arena);
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
-    if (REW_ON_W1) step_rewards_and_done(c, arena, next, skip);
+    if (REW_ON_W1 && TAIL) step_rewards_and_done(c, arena, next, skip);
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();  // (5)
     if (!(skip & 32)) store_record_step(c, arena, 1, NW);
@@ -2941,11 +2950,7 @@ aie_step_kernel_log(const aie_params* __restrict__ params, uint8_t* __restrict__
   step_body<2, true>(params, arena, act_a, act_p, lds, next);
 }
 // compile-time instances for the configurations listed in ai-economist_amd/_specs.py (BASELINE configs[1], [2], ...)
-#ifdef AIE_EXP_WAVES  // (timing experiment: another register budget for the instances)
-#define AIE_SPEC_WAVES(S) AIE_EXP_WAVES
-#else
 #define AIE_SPEC_WAVES(S) aie_spec_image<S>::waves
-#endif
 template <int SPEC>
 __global__ void __launch_bounds__(2 * AIE_NT)
 __attribute__((amdgpu_waves_per_eu(AIE_SPEC_WAVES(SPEC), AIE_SPEC_WAVES(SPEC))))

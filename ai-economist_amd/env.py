@@ -198,6 +198,14 @@ class DeviceBackend:
         p = self._ptr(actions_p, torch.int32, "actions_p", self.act_p_numel)
         self._check(self.lib.aie_step(self.handle, a, p, self._stream()))
 
+    def step_range(self, actions_a, actions_p, comp_lo, comp_hi, phases):
+        """aie_step_range: the built-in components [comp_lo, comp_hi) and the named parts of a step (_cabi.STEP_HEAD /
+        STEP_TAIL / STEP_OBSERVE) -- what foundation.BatchedComponent hooks run between."""
+        torch = _torch()
+        a = self._ptr(actions_a, torch.int32, "actions_a", self.act_a_numel)
+        p = self._ptr(actions_p, torch.int32, "actions_p", self.act_p_numel)
+        self._check(self.lib.aie_step_range(self.handle, a, p, int(comp_lo), int(comp_hi), int(phases), self._stream()))
+
     def set_reward_log(self, n_slots):
         """Allocates a reward log of `n_slots` step slots, f32 [n_slots, E, n_agents + 2] = (agent rewards,
         planner reward, done), and makes every following step fill the next slot (slot 0 first, wrapping).

@@ -11,6 +11,7 @@ Same entry points as the reference package (F/__init__.py:7-18):
 are the registries; register your own Scenario/Component spec classes with
 `@foundation.scenarios.add` / `@foundation.components.add`.
 """
+from .components import BaseComponent, BatchedComponent  # noqa: F401  (base classes of user-registered components)
 from .components import component_registry as components
 from .entities import agent_registry as agents
 from .entities import endogenous_registry as endogenous

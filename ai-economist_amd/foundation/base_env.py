@@ -30,6 +30,8 @@ class BaseEnvironment:
     # scenarios whose observations are already per-key arrays (COVID) accept
     # flatten_observations=False, which is how the reference's run config sets it
     supports_unflattened_observations = False
+    # host components (foundation.BatchedComponent) run between launches of aie_step_range: gather-trade-build scenarios
+    supports_batched_components = False
 
     def __init__(self, components=None, n_agents=None, world_size=None, episode_length=1000,
                  multi_action_mode_agents=False, multi_action_mode_planner=True,
@@ -108,15 +110,23 @@ class BaseEnvironment:
             else:
                 cname, ckw = list(spec.keys())[0], list(spec.values())[0]
             ccls = component_registry.get(cname)
-            if not int(getattr(ccls, "comp_id", 0)):
+            if getattr(ccls, "is_batched_host_component", False):
+                if not self.supports_batched_components:
+                    raise NotImplementedError("host components (foundation.BatchedComponent) run in the gather-trade-build "
+                                              "scenarios only; {!r} is listed in a {} environment".format(cname, self.name))
+                if dense_log_frequency is not None:
+                    raise NotImplementedError("host components and dense logs do not combine yet (the logged replica's "
+                                              "event rows are per launch)")
+            elif not int(getattr(ccls, "comp_id", 0)):
                 # The registry is open like the reference's (base_component.py:378, registrar.py:48-66), but a component's
                 # dynamics are a device kernel here: Python component_step / generate_observations code cannot run
                 # inside a batched launch.  Said at construction, not as "unknown component id 0" at the first reset.
                 raise NotImplementedError(
                     "component {!r} ({}) has no device kernel: this backend runs the reference's built-in components only "
                     "(Build, ContinuousDoubleAuction, Gather, PeriodicBracketTax, WealthRedistribution, SimpleLabor, "
-                    "ControlUSStateOpenCloseStatus, FederalGovernmentSubsidy, VaccinationCampaign); a registered class "
-                    "needs a `comp_id` the kernels know (include/aie.h: AIE_COMP_*)".format(cname, ccls.__name__))
+                    "ControlUSStateOpenCloseStatus, FederalGovernmentSubsidy, VaccinationCampaign) on the device; a "
+                    "component of your own subclasses foundation.BatchedComponent (its component_step runs as torch code "
+                    "on the state tensors between two launches)".format(cname, ccls.__name__))
             self._register_entities(ccls.required_entities)
             obj = ccls(self.n_agents, self._episode_length, inventory_scale=self.inv_scale, **ckw)
             if obj.name in self._components_dict:
@@ -125,6 +135,19 @@ class BaseEnvironment:
             self._components.append(obj)
             self._components_dict[obj.name] = obj
             self._shorthand_lookup[obj.shorthand] = obj
+        # host components: (built-in components listed before it, component), in list order
+        self._host_components = []
+        n_builtin = 0
+        for obj in self._components:
+            if getattr(obj, "is_batched_host_component", False):
+                if obj.get_n_actions("BasicMobileAgent") or obj.get_n_actions("BasicPlanner"):
+                    raise NotImplementedError("host component {!r}: action subspaces are the kernels' (get_n_actions must "
+                                              "return None)".format(obj.name))
+                self._host_components.append((n_builtin, obj))
+            else:
+                n_builtin += 1
+        self._n_builtin_components = n_builtin
+        self._host_obs_tables = None
 
         self._completions = 0
         self._last_ep_metrics = None
@@ -211,10 +234,11 @@ class BaseEnvironment:
         cfg.allow_observation_scaling = int(self._allow_observation_scaling)
         cfg.dense_log_replicas = 1 if self._create_dense_log_every is not None else 0
         cfg.rng_mode = _cabi.RNG_FAST if self.rng_mode == "fast" else _cabi.RNG_NUMPY
-        if len(self._components) > _cabi.MAX_COMPONENTS:
+        builtin = [c for c in self._components if not getattr(c, "is_batched_host_component", False)]
+        if len(builtin) > _cabi.MAX_COMPONENTS:
             raise ValueError("too many components")
-        cfg.n_components = len(self._components)
-        for i, c in enumerate(self._components):
+        cfg.n_components = len(builtin)
+        for i, c in enumerate(builtin):
             cfg.components[i] = c.comp_id
             c.fill_config(cfg)
         self.fill_scenario_config(cfg)
@@ -266,8 +290,17 @@ class BaseEnvironment:
 
     def _obs(self):
         obs = self._obs_raw()
+        host = None
+        if self._host_components:
+            merged = self._host_observations(obs)
+            host = {who: merged[who].pop("_host_keys", {}) for who in ("a", "p")}
+            if self._flatten_observations or self.supports_unflattened_observations:
+                obs = merged
         if not self._flatten_observations and not self.supports_unflattened_observations:
             obs = self._unflatten(obs)
+            if host:  # the unflattened form: every key on its own
+                for who in ("a", "p"):
+                    obs[who].update(host[who])
         if not self._flatten_masks:
             obs = self._unflatten_masks(obs)
         return obs
@@ -394,7 +427,28 @@ class BaseEnvironment:
             self._replay_log = {"reset": dict(seed_state=self.rng_state(0) if self._dense_log_this_episode else None),
                                 "step": []}
         self.host_pre_reset(env_mask)
+        if self._host_components and env_mask is not None:
+            env_mask = env_mask.clone()  # (often the live `done` tensor, which the reset clears; the hooks need it afterwards)
         self.backend.reset(env_mask)
+        if self._host_components:
+            # The reference resets the components in list order, then the scenario (base_env.py:905-911).  The built-in
+            # components' resets all ran inside the reset kernel; the one of them that looks at what a host component may
+            # have edited -- PeriodicBracketTax snapshots the agents' coin (redistribution.py:1106-1110) -- takes its
+            # snapshot again between the hooks listed ahead of it and those behind it; the utilities the first rewards are
+            # measured from and the observations follow at the end (the scenario's own reset steps come last there too).
+            tax_at = next((k for k, c in enumerate(b for b in self._components if not getattr(b, "is_batched_host_component", False))
+                           if c.name == "PeriodicBracketTax"), None)
+            edited_ahead = edited_behind = retaken = False
+            for n_before, comp in self._host_components:
+                ahead = tax_at is None or n_before <= tax_at  # listed ahead of the tax component (or there is none)
+                if not ahead and edited_ahead and not retaken:
+                    self.backend.step_range(None, None, 0, 0, _cabi.STEP_OBSERVE | _cabi.STEP_RETAX)
+                    retaken = True
+                e = bool(comp.additional_reset_steps(self.backend.tensors, env_mask))
+                edited_ahead, edited_behind = edited_ahead or (e and ahead), edited_behind or (e and not ahead)
+            if edited_ahead or edited_behind:  # the reset kernel's observations no longer show the state: rewrite them
+                retax = _cabi.STEP_RETAX if (tax_at is not None and edited_ahead and not retaken) else 0
+                self.backend.step_range(None, None, 0, 0, _cabi.STEP_OBSERVE | _cabi.STEP_REBASE | retax)
         if log_replica_resets:
             self._dense_log = {"world": [], "states": [], "actions": [], "rewards": []}
             if self._dense_log_this_episode:
@@ -487,7 +541,10 @@ class BaseEnvironment:
             self._dense_logger.before_step(a, p)
             self._replay_log["step"].append(dict(actions=self._dense_logger.reference_actions(a, p),
                                                  seed_state=self.rng_state(0)))
-        self.backend.step(a, p)
+        if self._host_components:
+            self._step_with_host_components(a, p)
+        else:
+            self.backend.step(a, p)
         t = self.backend.tensors
         if logging:
             self._dense_logger.after_step()
@@ -499,6 +556,68 @@ class BaseEnvironment:
         done = {"__all__": t["done"]}
         info = {"a": {}, "p": {}}
         return self._obs(), rew, done, info
+
+    def _step_with_host_components(self, a, p):
+        """One step with foundation.BatchedComponent hooks: the built-in components in stretches (aie_step_range), the
+        hooks between them in list order (base_env.py:985-987), the end of the step in the last launch."""
+        be = self.backend
+        if a is None or p is None:  # every launch of the step decodes the same buffers
+            za, zp = be._action_buffers(0)
+            a = za.zero_() if a is None else a
+            p = zp.zero_() if p is None else p
+        lo, first = 0, True
+        for hi, comp in self._host_components:
+            if first or hi > lo:
+                be.step_range(a, p, lo, hi, _cabi.STEP_HEAD if first else 0)  # (0: a plain middle stretch)
+            first = False
+            comp.component_step(be.tensors)
+            lo = hi
+        be.step_range(a, p, lo, self._n_builtin_components, _cabi.STEP_TAIL | (_cabi.STEP_HEAD if first else 0))
+
+    def _host_observations(self, obs):
+        """Adds the host components' observations to the raw observation dict: under "<Component>-<key>" and, with
+        flatten_observations, merged into the flat vectors at their sorted-key position (base_env.py:561-612, 644-673:
+        scalars and vectors of an actor are concatenated in sorted key order)."""
+        import torch
+
+        be = self.backend
+        extra = {"a": {}, "p": {}}
+        for _, comp in self._host_components:
+            o = comp.generate_observations(be.tensors) or {}
+            for who in ("a", "p"):
+                for k, v in (o.get(who) or {}).items():
+                    extra[who]["%s-%s" % (comp.name, k)] = v
+        if not extra["a"] and not extra["p"]:
+            return obs
+        if self._host_obs_tables is None:
+            from .obs_keys import flat_keys
+
+            base = flat_keys(self)
+            tables = {}
+            for who, lead in (("a", 2), ("p", 1)):  # leading dims: [E, n] / [E]
+                items = [(key, size, ("k", off)) for key, off, size, _ in base[who]]
+                col = base["sizes"][who]
+                for key in sorted(extra[who]):
+                    v = extra[who][key]
+                    size = 1 if v.dim() == lead else int(v.shape[-1])
+                    items.append((key, size, ("x", col)))
+                    col += size
+                perm = []
+                for key, size, (_src, off) in sorted(items, key=lambda it: it[0]):
+                    perm.extend(range(off, off + size))
+                tables[who] = torch.as_tensor(perm, dtype=torch.int64, device=be.device)
+            self._host_obs_tables = tables
+        out = {who: dict(d) for who, d in obs.items()}
+        for who, lead in (("a", 2), ("p", 1)):
+            if not extra[who]:
+                continue
+            parts = [obs[who]["flat"]]
+            for key in sorted(extra[who]):
+                v = extra[who][key].to(torch.float32)
+                parts.append(v.unsqueeze(-1) if v.dim() == lead else v)
+            out[who]["flat"] = torch.cat(parts, dim=-1).index_select(-1, self._host_obs_tables[who])
+            out[who]["_host_keys"] = {k: extra[who][k] for k in extra[who]}
+        return out
 
     def check_errors(self):
         """Raises what the reference raises from inside step() / reset() for conditions a batched launch can only

@@ -37,6 +37,7 @@ def parse_layout_string(text):
 
 @scenario_registry.add
 class LayoutFromFile(BaseEnvironment):
+    supports_batched_components = True  # (and every scenario derived from it: uniform/, quadrant/, multi_zone/, split_layout/)
     name = "layout_from_file/simple_wood_and_stone"
     agent_subclasses = ["BasicMobileAgent", "BasicPlanner"]
     required_entities = ["Wood", "Stone", "Water"]

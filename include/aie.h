@@ -418,6 +418,30 @@ int aie_step_sample_next(aie_env* env, const int32_t* d_actions_a, const int32_t
 int aie_step_sample_next_masked(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, uint64_t seed,
                                 int64_t global_env_offset, int32_t* d_next_a, int32_t* d_next_p, void* stream);
 
+/* Part of a step, for components that live on the HOST (round 6: ai_economist_amd.foundation.BatchedComponent -- a user's
+ * registered component whose component_step runs as torch code on the state tensors between two launches; the
+ * reference's registries are open, F/base/base_component.py:378, F/base/registrar.py:48-66).  Runs the built-in components
+ * [comp_lo, comp_hi) of aie_config.components, in order, and of the rest of a step what `phases` names:
+ *   AIE_STEP_HEAD     timestep += 1 (base_env.py:981: before the first component of a step)
+ *   AIE_STEP_TAIL     scenario_step (regeneration), observations, masks, rewards, done (+ auto-reset) -- the end of a step
+ *   AIE_STEP_OBSERVE  observations and masks of the state as it stands, nothing else (after a host-side edit, e.g. a
+ *                     component's additional_reset_steps); with AIE_STEP_REBASE also the utilities the next rewards are
+ *                     measured from, as a reset leaves them (layout_from_file.py:347-349 runs behind the components' resets)
+ * (phases == 0: components only, a stretch in the middle of a step.)
+ * One step = any sequence of calls whose first carries HEAD, whose last carries TAIL and whose ranges tile the list;
+ * aie_step(a, p) == aie_step_range(a, p, 0, n_components, HEAD | TAIL).  Every call takes the same action buffers.
+ * Between two calls of a step the caller may edit state tensors; the TAIL call rewrites all observations.  Always the
+ * full-featured kernel (no compile-time / run-time instance).  Gather-trade-build scenarios; AIE_E_UNSUPPORTED elsewhere,
+ * with tax_model "saez" and while a dense-log replica records. */
+#define AIE_STEP_HEAD 1
+#define AIE_STEP_TAIL 2
+#define AIE_STEP_OBSERVE 4
+#define AIE_STEP_REBASE 8
+#define AIE_STEP_RETAX 16 /* with OBSERVE: PeriodicBracketTax's reset-time snapshot of the agents' coin (redistribution.py:1106-1110) taken
+                           * again -- a host component listed AHEAD of the tax component edited coin in its reset hook */
+int aie_step_range(aie_env* env, const int32_t* d_actions_a, const int32_t* d_actions_p, int32_t comp_lo, int32_t comp_hi,
+                   int32_t phases, void* stream);
+
 /* Reward log for learners on another device: every following aie_step / aie_step_sample_next ALSO
  * writes replica e's (agent rewards [n_agents], planner reward, done as 0/1) as n_agents + 2 floats to
  * d_log[((slot * n_envs) + e) * (n_agents + 2) + ...], slot = 0, 1, ... n_slots - 1, 0, ... advancing by one per

@@ -22,7 +22,12 @@ F64_FIELDS = ["inv_coin", "esc_coin", "labor", "build_payment", "build_skill",
 def golden_names():
     """Gather-trade-build / one-step-economy fixtures (the COVID ones have their own format)."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    return [n for n in names if not n.startswith("c4_covid")]
+    return [n for n in names if not n.startswith("c4_covid") and not n.startswith("custom_")]
+
+
+def custom_golden_names():
+    """Fixtures with user-registered components (oracle/gen_golden_custom.py)."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "custom_*.npz")))
 
 
 def covid_golden_names():
