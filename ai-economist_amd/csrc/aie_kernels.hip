@@ -2534,11 +2534,16 @@ __device__ __forceinline__ void write_flat_observations(const Ctx& c, uint8_t* _
 
 // Action masks (own staging slots, own per-agent mask bits): independent of the flat vectors
 // above, so the second wave of a replica builds them while the first one does those.
-__device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __restrict__ arena) {
+// `all` == false (a step whose observation tensors still show the previous step): only what changed is rewritten -- the
+// rows of the agents whose mask bits differ from the ones the tensor shows (record field o_mask_bits), the planner's when
+// its "rates may be set today" flag flips (o_mask_p_open; which rates are visible only changes at a reset, and a reset
+// writes everything).  Round 6: 1.4 KB of stores and ~100 vector instructions per replica-step less on BASELINE configs[1].
+__device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __restrict__ arena, bool all = true) {
   const aie_params& P = c.P;
   const int n = P.n, tid = c.tid, Pp = P.P;
   const int skip = c.skipm;
   if (skip & 512) return;
+  if (!P.o_mask_bits) all = true;
   if (tid < n) {
     const int i = tid;
     const double coin = R_F64(c, o_inv_coin)[i];
@@ -2562,7 +2567,10 @@ __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __rest
         if (quota) mf |= (uint32_t)(kmax + 1) << (8 + 8 * r);
       }
     }
-    c.mflags[i] = (int32_t)mf;
+    // bit 31 of the staged word: this agent's row has to be written
+    const bool changed = all || (int32_t)mf != R_I32(c, o_mask_bits)[i];
+    if (P.o_mask_bits) R_I32(c, o_mask_bits)[i] = (int32_t)mf;
+    c.mflags[i] = (int32_t)(mf | (changed ? 0x80000000u : 0u));
   }
   AIE_WSYNC();
   // ---- masks: _generate_masks base_env.py:706-756 + flatten_masks base_agent.py:440-460,
@@ -2579,15 +2587,24 @@ __device__ __forceinline__ void write_action_masks(const Ctx& c, uint8_t* __rest
       const uint32_t sh = t & 31u, msk = (t >> 8) & 0xffu, thr = t >> 16;
       return (((uint32_t)c.mflags[i] >> sh) & msk) >= thr ? 1.0f : 0.0f;
     };
+    auto dirty = [&](int idx) -> bool { return c.mflags[udiv(idx, P.MA, P.mg_MA)] < 0; };  // (bit 31)
     const int n4 = count >> 2;
     for (int q = tid; q < n4; q += AIE_NT) {
+      if (!all && !dirty(4 * q) && !dirty(4 * q + 3)) continue;  // (a quad spans at most two agents' rows)
       f32x4_a4 o = {elem(4 * q), elem(4 * q + 1), elem(4 * q + 2), elem(4 * q + 3)};
       reinterpret_cast<f32x4_a4*>(dst)[q] = o;
     }
-    for (int q = 4 * n4 + tid; q < count; q += AIE_NT) dst[q] = elem(q);
+    for (int q = 4 * n4 + tid; q < count; q += AIE_NT)
+      if (all || dirty(q)) dst[q] = elem(q);
     float* pdst = reinterpret_cast<float*>(arena + c.R.a_obs_p_mask) + (int64_t)c.e * P.MP;
     const bool pmulti = P.c.multi_action_mode_planner != 0;
     const float open = (P.n_sub_p && *R_I32(c, o_tax_cycle_pos) == 1) ? 1.0f : 0.0f;
+    if (P.o_mask_bits) {
+      const int was = uni(*R_I32(c, o_mask_p_open));
+      AIE_WSYNC();
+      if (tid == 0) *R_I32(c, o_mask_p_open) = open != 0.0f ? 1 : 0;
+      if (!all && was == (open != 0.0f ? 1 : 0)) return;
+    }
     for (int q = tid; q < P.MP; q += AIE_NT) {
       float v;
       int j = -1;  // index of the discretised rate this entry stands for (-1: a NO-OP entry)
@@ -2871,6 +2888,8 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) src.d[k] = 0;
     src = SHL ? src_list_from_arena(c, arena) : src_list_from_record(c, arena);  // (the loads ride under the first wave's dynamics)
+    // (tried in round 6: all ten rows with the record burst and the window from the registers -- one dependent round trip
+    // and 768 redundant bytes less, but 1.7 KB more in the burst every workgroup starts with: C2 23.0 -> 23.5 us)
     if (!FAST && !(skip & (1 << 19))) {  // the generator's rows -> registers (re-read after the barrier if the components twisted the state)
 #pragma unroll
       for (int j = 0; j < 9; ++j) m.r[j] = gkey[64 * j + c.tid];
@@ -2909,6 +2928,8 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     }
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 6] = wall_clock64();
     AIE_WSYNC();
+    // (the masks follow the map observations' rule: in place unless something outside the kernels touched the state)
+    const bool masks_all = OBSERVE || !uni(*R_I32(c, o_obs_valid)) || (skip & (4 | 32768)) != 0;
     if (!(skip & 4) && (TAIL || OBSERVE)) {
       // the map observations of the previous step are still in the arena: update them in place,
       // unless something outside the kernels touched the state (obs_valid == 0; an AIE_STEP_OBSERVE launch: always)
@@ -2918,7 +2939,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     } else if (!TAIL && !OBSERVE && c.tid == 0) {
       *R_I32(c, o_obs_valid) = 0;  // a partial step changed the state and wrote no observations: the launch that does starts over
     }
-    if (!(skip & 8) && (TAIL || OBSERVE)) write_action_masks(c, arena);
+    if (!(skip & 8) && (TAIL || OBSERVE)) write_action_masks(c, arena, /*all=*/masks_all);
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 11] = wall_clock64();
     if (REW_ON_W1 && TAIL) step_rewards_and_done(c, arena, next, skip);
     __builtin_amdgcn_s_setprio(0);

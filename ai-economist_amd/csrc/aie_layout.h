@@ -90,6 +90,9 @@ typedef struct aie_params {
   int32_t o_tax_cycle_pos, o_tax_rate_idx, o_tax_last_coin, o_tax_last_income;
   int32_t o_tax_last_marginal_rate, o_tax_total_collected;
   int32_t o_timestep, o_completions, o_auto_warmup;
+  int32_t o_mask_bits, o_mask_p_open; /* gather-trade-build: the per-agent mask bits (int32 [n]) and the planner's "rates may be
+                          * set today" flag the action-mask tensors currently show -- a step rewrites only the masks of agents
+                          * whose bits changed and the planner's when the flag flips (round 6); 0 = fields absent */
   int32_t o_skill, o_production, o_first_step; /* one-step-economy / SimpleLabor           */
   int32_t o_mt, o_mt_pos, o_mt_has_gauss, o_mt_gauss;
   int32_t o_tax_last_completions; /* PeriodicBracketTax._last_completions (tax annealing)     */
@@ -1162,6 +1165,8 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   p->o_sample_t = aie__rec(&cur, 4, 4);
   p->o_rew_slot = aie__rec(&cur, 4, 4);
   p->o_rew_epoch = aie__rec(&cur, 4, 4);
+  p->o_mask_bits = aie__rec(&cur, 4 * n, 4);
+  p->o_mask_p_open = aie__rec(&cur, 4, 4);
   p->o_mt_gauss = aie__rec(&cur, 8, 8);
   p->o_mt_pos = aie__rec(&cur, 4, 4);
   p->o_mt_has_gauss = aie__rec(&cur, 4, 4);
