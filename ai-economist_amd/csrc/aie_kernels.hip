@@ -725,7 +725,7 @@ __device__ __forceinline__ int draw_window_publish(uint32_t* w, int cap, const M
 #pragma unroll
     for (int j = 1; j < 10; ++j) v = (r == j) ? rr[j] : v;
     const int slot = 64 * r + lane - pos;
-    if (slot >= 0 && slot < avail) w[slot] = mt_word(m, v);
+    if (slot >= 0 && slot < avail) w[slot] = v;  // (raw state words: the reader tempers the 64 it caches, rng_u32)
   }
   AIE_WSYNC();
   return avail;
@@ -740,7 +740,7 @@ __device__ __forceinline__ int draw_window_publish_from_hbm(uint32_t* w, int cap
     const int r = r0 + d, i = 64 * r + lane;
     if (r > 9) break;
     const int slot = i - pos;
-    if (slot >= 0 && slot < avail) w[slot] = mt_temper(gkey[i]);  // (slot < avail implies i < 624)
+    if (slot >= 0 && slot < avail) w[slot] = gkey[i];  // (slot < avail implies i < 624; raw: see draw_window_publish)
   }
   return avail;
 }
@@ -813,7 +813,10 @@ __device__ __forceinline__ uint32_t rng_u32(MTL& l, int lane) {
   int k = l.pos - l.cbase;
   if ((unsigned)k >= (unsigned)AIE_NT) {  // the next (up to) 64 words of the draw window
     const int idx = l.pos - l.base + lane;
-    l.cache = l.w[idx < l.avail ? idx : l.avail - 1];
+    // MT19937's window holds RAW state words (round 6): a step draws one or two dozen of the 128+ the window offers, so the
+    // tempering happens here, once per 64 cached words, instead of over the whole window on the way in
+    const uint32_t raw = l.w[idx < l.avail ? idx : l.avail - 1];
+    l.cache = l.fast ? raw : mt_temper(raw);
     l.cbase = l.pos;
     k = 0;
   }
@@ -2680,6 +2683,23 @@ __device__ __forceinline__ void build_src_list(const Ctx& c, uint8_t* __restrict
 // (Tried and dropped: writing the map observations speculatively during the dynamics and
 // repairing the changed cells afterwards -- parity-clean, but the co-resident second waves'
 // instruction stream slows the serial dynamics of the first waves by as much as it saves.)
+// The three libm tables behind the utilities (aie_glibc_math.h: pow's log and exp tables, log's: 7 KB) touched once per
+// workgroup, 64 bytes apart: the step's second wave calls this while the first one runs the components, so that the
+// utilities' dependent table look-ups at the end of the step (two or three per pow, each a round trip to wherever the
+// streaming traffic has pushed the tables) find them in this CU's vector cache.  Returns a value to keep alive.
+__device__ __forceinline__ uint32_t glibc_tables_touch(int lane) {
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int line = 2 * lane + k;  // 112 lines of 64 bytes
+    const uint8_t* p = line < 48 ? reinterpret_cast<const uint8_t*>(aie_glibc_powlog_tab) + 64 * line
+                     : line < 80 ? reinterpret_cast<const uint8_t*>(aie_glibc_exp_tab) + 64 * (line - 48)
+                                 : reinterpret_cast<const uint8_t*>(aie_glibc_log_tab) + 64 * (line - 80);
+    if (line < 112) v ^= *reinterpret_cast<const volatile uint32_t*>(p);
+  }
+  return v;
+}
+
 struct NextActions {  // aie_step_sample_next: where and how to sample the next step's random actions
   int32_t* a;
   int32_t* p;
@@ -2888,6 +2908,11 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) src.d[k] = 0;
     src = SHL ? src_list_from_arena(c, arena) : src_list_from_record(c, arena);  // (the loads ride under the first wave's dynamics)
+#ifndef AIE_NO_TABLE_TOUCH  // (A/B builds)
+    const uint32_t warm = glibc_tables_touch(c.tid);
+#else
+    const uint32_t warm = 0;
+#endif
     // (tried in round 6: all ten rows with the record burst and the window from the registers -- one dependent round trip
     // and 768 redundant bytes less, but 1.7 KB more in the burst every workgroup starts with: C2 23.0 -> 23.5 us)
     if (!FAST && !(skip & (1 << 19))) {  // the generator's rows -> registers (re-read after the barrier if the components twisted the state)
@@ -2901,6 +2926,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
       for (int j = c.tid; j < per_env; j += AIE_NT) sample_action_slot(P, next.seed, next.env_offset, (int64_t)st, c.e, j, next.a, next.p);
       if (c.tid == 0) *R_I32(c, o_sample_t) = st + 1;
     }
+    asm volatile("" ::"v"(warm));
     __syncthreads();  // (4)
     // resource regeneration (the generator's rows are in this wave's registers), then what depends on the map:
     // incremental map observations, action masks
