@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(64) pingpong(int* mail, long long* out, int* x
   }
 }
 
-__global__ void __launch_bounds__(128) stamp(long long* start, int* xcc, int spin) {
+__global__ void __launch_bounds__(1024) stamp(long long* start, int* xcc, int spin) {
   if (threadIdx.x == 0) {
     start[blockIdx.x] = wall_clock64();
     unsigned id;
@@ -220,6 +220,17 @@ int main() {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("200 back-to-back stamp launches (4096 x 128 threads, 9680 B LDS, spin %d ticks): %.2f us per launch\n", spin, ms * 5.0);
+  }
+  // dispatch cost against the workgroup shape: the same 8192 waves and the same LDS per wave as 4096 x 128, in fewer and
+  // larger workgroups (would several replicas per workgroup launch faster?)
+  for (int wpw : {2, 4, 8, 16}) {
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(stamp, dim3(8192 / wpw), dim3(64 * wpw), 4840 * wpw, 0, start, xcc, 0);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("empty kernel, %4d workgroups x %4d threads, %6d B LDS each: %.2f us per launch\n", 8192 / wpw, 64 * wpw, 4840 * wpw, ms * 5.0);
   }
   Params hp;
   hp.E = 4096;
