@@ -289,7 +289,7 @@ def usable_cores():
     return n
 
 
-def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64, policy="unmasked"):
+def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64, policy="unmasked", episodes=0):
     """The reference's own env.step (oracle/_ref or the live tree, through oracle/ref_harness.py): P = usable cores
     processes, one environment each, pinned, stepped concurrently with uniform random actions."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -307,12 +307,17 @@ def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64, policy="unmasked"):
         cores = sorted(os.sched_getaffinity(0))
     except AttributeError:
         cores = list(range(P))
-    start = time.time() + 6.0 + 0.05 * P
+    # episodes > 0: SURVEY 8(d)'s protocol (1 warm-up episode + `episodes` timed whole episodes incl. resets) instead of the
+    # free-running window; the warm-up episode runs ahead of the common start
+    warm = 6.0 + 0.05 * P
+    if episodes:
+        warm += 1.3 * float(cfg.get("episode_length", 1000)) / 1500.0 + 5.0  # (a reference episode: ~0.5 ms per step and worker)
+    start = time.time() + warm
     procs = []
     for k in range(P):
         cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_worker.py"), "--cfg-json", json.dumps(cfg),
                "--core", str(cores[k % len(cores)]), "--start", repr(start), "--seconds", repr(seconds),
-               "--seed", str(1 + k), "--policy", policy]
+               "--seed", str(1 + k), "--policy", policy, "--episodes", str(int(episodes))]
         procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
                                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")))
     rate, steps, late, n_agents, ok, resets = 0.0, 0, 0, None, 0, 0
@@ -331,6 +336,16 @@ def cpu_reference_baseline(cfg, seconds=10.0, max_procs=64, policy="unmasked"):
         resets += int(d.get("resets", 0))
     if not ok:
         return None
+    if episodes:
+        return dict(value=rate, unit="agent-steps/s", cores=ok, kind="reference", per_core=rate / ok, steps=steps, resets=resets,
+                    policy=policy, episodes=episodes,
+                    sample_short="%d pinned procs x 1 env, unmodified reference env.step, %s uniform policy, SURVEY 8(d): 1 warm-up + "
+                                 "%d timed whole episodes incl. resets (%d steps)" % (ok, policy, episodes, steps),
+                    sample="%d pinned processes x one environment each, the unmodified reference env.step (base_env.py:929-1032) "
+                           "with uniform random actions (%s): one warm-up episode, then %d timed whole episodes including "
+                           "their env.reset() per process, started on a common clock (SURVEY.md 8(d)'s protocol): %d steps in "
+                           "total, %d agents each; host reports %d usable cores%s"
+                           % (ok, policy, episodes, steps, n_agents, ncores, ", %d workers started late" % late if late else ""))
     return dict(value=rate, unit="agent-steps/s", cores=ok, kind="reference", per_core=rate / ok,
                 steps=steps, resets=resets, seconds=seconds, policy=policy,
                 sample_short="%d pinned procs x 1 env, unmodified reference env.step, %s uniform policy, free-running %.0f s "
@@ -1012,6 +1027,10 @@ def main():
                     help="C2pi: configs[1] with a torch MLP policy in the loop, alone (one JSON line; no CPU legs)")
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-episodes", type=int, default=0,
+                    help="time the headline's cpu_baseline on SURVEY 8(d)'s protocol -- 1 warm-up + N timed WHOLE episodes incl. "
+                         "resets per process -- instead of the default free-running 10 s window (3 = the survey's figure; takes "
+                         "~4 x episode_length x 0.5 ms per process)")
     ap.add_argument("--no-workloads", action="store_true",
                     help="headline workload only (default: a 1-GPU C2 run also times C1, C3, C4, C4x, C5 in short windows)")
     ap.add_argument("--generic-kernel", action="store_true",
@@ -1122,7 +1141,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             ref = None
             try:
-                ref = cpu_reference_baseline(cfg)
+                ref = cpu_reference_baseline(cfg, episodes=args.cpu_baseline_episodes)
             except Exception as exc:  # the reference leg must not take the GPU line down
                 out["cpu_baseline_error"] = repr(exc)
             if wl in ("C1", "C2", "C3"):

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--start", type=float, default=0.0)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--episodes", type=int, default=0,
+                    help="SURVEY 8(d)'s protocol instead of the free-running window: one warm-up episode from a fresh reset, "
+                         "then this many timed WHOLE episodes including their resets (--seconds is ignored)")
     ap.add_argument("--policy", choices=["unmasked", "masked"], default="unmasked",
                     help="unmasked: i.i.d. uniform over the full action range (SURVEY 8(d)); masked: uniform over the entries "
                          "the current `action_mask` observation allows (what bench.py's mask-respecting GPU legs draw)")
@@ -92,6 +95,24 @@ def main():
             obs[0] = env.reset()
             resets[0] += 1
 
+    if args.episodes > 0:
+        # 1 warm-up episode + N timed whole episodes incl. resets; every worker starts on the common clock
+        obs[0] = env.reset()
+        resets[0] = 0
+        while resets[0] < 1:
+            one_step()
+        late = time.time() > args.start
+        while time.time() < args.start:
+            time.sleep(0.001)
+        t0 = time.time()
+        resets[0] = 0
+        steps = 0
+        while resets[0] < args.episodes:
+            one_step()
+            steps += 1
+        print(json.dumps({"steps": steps, "elapsed": time.time() - t0, "n_agents": n, "late": bool(late),
+                          "resets": resets[0], "policy": args.policy, "episodes": args.episodes}))
+        return
     for _ in range(20):
         one_step()
     late = time.time() > args.start
