@@ -814,18 +814,30 @@ int aie_sample_policy_actions(aie_env* env, const float* d_logits_a, const float
     snprintf(env->err, sizeof(env->err), "aie_sample_policy_actions: an action buffer without its logits");
     return AIE_E_INVALID;
   }
-  {  // (score, entry) travel as one 64-bit key with 11 bits of entry index (aie_layout.h: aie_sampler_key)
-    const aie_params& P = env->P;
-    const int wa = P.c.scenario == AIE_SCN_COVID ? 1 + P.cv_NL : P.MA;
-    const int wp = P.c.multi_action_mode_planner ? 1 + P.sub_p_dim : P.MP;
-    if (wa > 2048 || wp > 2048) {
-      snprintf(env->err, sizeof(env->err), "aie_sample_policy_actions: action rows of more than 2048 entries (%d / %d)", wa, wp);
-      return AIE_E_UNSUPPORTED;
-    }
-  }
   AIE_HIP_CHECK(env, hipSetDevice(env->device));
-  hipLaunchKernelGGL(aie_sample_policy_actions_kernel, dim3((unsigned)env->P.E), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     env->P, env->arena, d_logits_a, d_logits_p, seed, global_env_offset, d_actions_a, d_actions_p);
+  // waves per replica (1, 2 or 4 of a workgroup's four); AIE_SAMPLER_WAVES_LOG2 in the environment is a development knob
+  static const int wpr_log2 = [] {
+    const char* v = getenv("AIE_SAMPLER_WAVES_LOG2");
+    const int k = v ? atoi(v) : 1;
+    int r = k < 0 ? 0 : (k > 2 ? 2 : k);
+#ifdef AIE_DEV
+    if (const char* sk = getenv("AIE_SAMPLER_DEV_SKIP")) r |= atoi(sk) << 8;
+#endif
+    return r;
+  }();
+  const int rpb = 4 >> (wpr_log2 & 255);
+  const aie_sampler_args S = aie_sampler_args_of(&env->P, env->d_params);
+  using sampler_fn = void (*)(const aie_sampler_args, uint8_t*, const float*, const float*, uint64_t, int64_t, int32_t*, int32_t*, int);
+  sampler_fn fn = aie_sample_policy_actions_kernel;  // rows of any shape
+  if (!S.ragged && S.agents.len <= 64 && S.planner.len <= 64) {  // every row one aligned lane segment: the fast instances
+    static const sampler_fn fast[3][3] = {
+        {aie_sample_policy_fast_kernel<4, 4>, aie_sample_policy_fast_kernel<4, 5>, aie_sample_policy_fast_kernel<4, 6>},
+        {aie_sample_policy_fast_kernel<5, 4>, aie_sample_policy_fast_kernel<5, 5>, aie_sample_policy_fast_kernel<5, 6>},
+        {aie_sample_policy_fast_kernel<6, 4>, aie_sample_policy_fast_kernel<6, 5>, aie_sample_policy_fast_kernel<6, 6>}};
+    fn = fast[S.agents.lsh - 4][S.planner.lsh - 4];
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)((env->P.E + rpb - 1) / rpb)), dim3(256), 0, static_cast<hipStream_t>(stream), S,
+                     env->arena, d_logits_a, d_logits_p, seed, global_env_offset, d_actions_a, d_actions_p, wpr_log2);
   AIE_HIP_CHECK(env, hipGetLastError());
   return AIE_OK;
 }

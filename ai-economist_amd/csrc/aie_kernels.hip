@@ -3864,114 +3864,418 @@ extern "C" __global__ void aie_sample_masked_actions_kernel(const aie_params P, 
 }
 
 // Categorical sampling from the caller's policy logits under the current action masks (include/aie.h:
-// aie_sample_policy_actions): Gumbel-max, entry k of a slot scores logit_k - log(-log(u_k)) with u_k from a counter hash
-// keyed (seed, global replica, the replica's draw index t, slot, k); the allowed entry with the highest score wins (lowest
-// index on ties; NaN logits count as masked; nothing allowed: NO-OP).  Scores are float64 and the logarithm is a fixed
-// sequence of IEEE operations (aie_layout.h: aie_sampler_log), so the CPU restatement picks the same entries.
-// One workgroup of four waves per replica; a wave takes every fourth WORK ITEM: one action slot, or -- where the rows of
-// a group are equally long and at most 32 entries (the planner's tax brackets: 22, COVID's states: 11) -- as many whole
-// rows as fit its 64 lanes; a lane takes one entry (every 64th of a longer row).  The kernel is bound by its vector
-// arithmetic (a wave per slot instead of four waves per replica made it slower: 25 -> 40 us on BASELINE configs[1]), hence
-// one 64-bit hash per replica and a 32-bit finaliser per slot and per entry, two short logarithms, (score, entry) as one
-// ordered 64-bit key and ONE LDS atomic max per lane for the row's arg-max.  Thread 0 advances the draw index behind a
-// barrier: one launch, nothing by value from a host counter (replayable from a hipGraph).
-struct SamplerRow {
-  const float* mask;
-  const float* lg;
-  int lo, len, stride;
-};
-__device__ __forceinline__ SamplerRow sampler_row(const aie_params& P, const uint8_t* __restrict__ arena, const float* __restrict__ logits_a,
-                                                  const float* __restrict__ logits_p, int e, int j, int na, int wa, bool covid) {
-  SamplerRow r;
-  r.stride = 1;
-  if (j < na) {
-    const int i = j / P.act_a_width, s = j - i * P.act_a_width;
-    if (covid) {
-      r.mask = reinterpret_cast<const float*>(arena + P.a_cv_obs_a) + ((int64_t)e * P.cv_nrow_obs + AIE_CV_OB_MASK) * P.n + i;
-      r.stride = P.n;
-    } else {
-      r.mask = reinterpret_cast<const float*>(arena + P.a_obs_a_mask) + ((int64_t)e * P.n + i) * P.MA;
-    }
-    r.lg = logits_a + ((int64_t)e * P.n + i) * wa;
-    r.lo = 0;
-    r.len = wa;
-    if (P.c.multi_action_mode_agents) {
-      for (int k = 0; k < s; ++k) r.lo += 1 + P.sub_a_dim[k];
-      r.len = P.n_sub_a ? 1 + P.sub_a_dim[s] : 1;
-    }
-  } else {
-    const int s = j - na;
-    if (covid) r.mask = reinterpret_cast<const float*>(arena + P.a_cv_obs_p) + (int64_t)e * (4 + P.MP) + 4;
-    else r.mask = reinterpret_cast<const float*>(arena + P.a_obs_p_mask) + (int64_t)e * P.MP;
-    r.lg = logits_p + (int64_t)e * P.MP;
-    r.lo = 0;
-    r.len = P.MP;
-    if (P.c.multi_action_mode_planner) {
-      r.lo = s * (1 + P.sub_p_dim);
-      r.len = P.n_sub_p ? 1 + P.sub_p_dim : 1;
-    }
-  }
+// aie_sample_policy_actions): inverse-CDF sampling (round 6; round 5: Gumbel-max) -- a slot's allowed entries get the
+// weights exp(logit_k - max), their prefix sums run in a fixed order, one uniform u per slot from a counter hash keyed
+// (seed, global replica, the replica's draw index t, slot) picks the first entry whose sum passes u times the total (NaN
+// logits count as masked; nothing allowed: NO-OP).  float32 throughout, every operation a plain IEEE add / multiply / fma
+// in a fixed order (aie_layout.h: aie_sampler_expf and the scan's definition), so the CPU restatement picks the same
+// entries.  The kernel is bound by the vector instructions it issues (round 6 counters: 530 per wave and 16 waves per
+// SIMD were 14 of its 19.7 us), so everything that is the same for a row runs on the scalar unit (the row's addresses,
+// its hash, the pick from the ballot) and the cross-lane steps are single DPP instructions: a WORK ITEM is one action
+// slot, or -- where the rows of a group are equally long and at most 32 entries (the planner's tax brackets: 22, COVID's
+// states: 11) -- as many whole rows as fit the wave's 64 lanes, each in its own aligned segment of 16 or 32 lanes; a lane
+// takes one entry (every 64th of a longer row).  `wpr` waves share a replica's items (a workgroup of four waves holds
+// 4 / wpr replicas).  The first wave of a replica advances the draw index behind the workgroup's barrier: one launch,
+// nothing by value from a host counter (replayable from a hipGraph).
+//
+// Cross-lane steps, written as instructions because the compiler wraps a float max in two canonicalising copies and does
+// not fold a row-masked broadcast into the add (s_nop 4: a DPP source needs 5 wait states after a write of EXEC and 2
+// after the VALU write of its source; the assembler text is invisible to the hazard recogniser).
+__device__ __forceinline__ float sampler_row16_max(float m) {  // every lane: the maximum over its row of 16 lanes
+  asm("s_nop 4\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+      : "+v"(m));
+  return m;
+}
+__device__ __forceinline__ float sampler_max_raw(float a, float b) {  // (no NaN reaches the sampler's maxima)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-extern "C" __global__ void __launch_bounds__(256)
-aie_sample_policy_actions_kernel(const aie_params P, uint8_t* __restrict__ arena, const float* __restrict__ logits_a,
-                                 const float* __restrict__ logits_p, uint64_t seed, int64_t env_offset,
-                                 int32_t* __restrict__ act_a, int32_t* __restrict__ act_p) {
-  const int e = (int)blockIdx.x;
-  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-  const int na = P.n * P.act_a_width, per_env = na + P.act_p_width;
-  int32_t* tfield = reinterpret_cast<int32_t*>(arena + P.a_records + (int64_t)e * P.rec_bytes + P.o_sample_t);
-  const int64_t t = aie::uni(*tfield);
-  const bool covid = P.c.scenario == AIE_SCN_COVID;
-  const int wa = covid ? 1 + P.cv_NL : P.MA;  // logits per agent, in the mask's own (flattened) layout
-  __shared__ unsigned long long cell[4][64];
-  // work items: groups of equally long rows are packed several to a wave
-  const bool have_a = act_a && logits_a, have_p = act_p && logits_p;
-  const int len_a = P.c.multi_action_mode_agents ? 0 : wa;  // (0: rows differ in length)
-  const int rpw_a = (len_a > 0 && len_a <= 32) ? 64 / len_a : 1;
-  const int items_a = have_a ? (na + rpw_a - 1) / rpw_a : 0;
-  const int len_p = P.c.multi_action_mode_planner ? (P.n_sub_p ? 1 + P.sub_p_dim : 1) : P.MP;
-  const int rpw_p = len_p <= 32 ? 64 / len_p : 1;
-  const int items_p = have_p ? (P.act_p_width + rpw_p - 1) / rpw_p : 0;
-  const uint32_t base_lo = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)per_env);
-  for (int it = wave; it < items_a + items_p; it += 4) {
-    const bool ag = it < items_a;
-    const int rpw = ag ? rpw_a : rpw_p;
-    const int j0 = ag ? it * rpw : na + (it - items_a) * rpw, jend = ag ? na : per_env;
-    const int len_u = ag ? len_a : len_p;
-    int sub = 0, kk = lane;
-    if (rpw > 1) {
-      sub = lane / len_u;
-      kk = lane - sub * len_u;
+__device__ __forceinline__ float sampler_segment_max(float m, int seg) {
+  m = sampler_row16_max(m);
+  if (seg >= 32) {  // odd rows of one copy <-> even rows of the other: both copies together hold both rows of a pair
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    m = sampler_max_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  if (seg >= 64) {  // the upper half of one copy <-> the lower half of the other
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    m = sampler_max_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  return m;
+}
+// Inclusive prefix sums of one 64-entry chunk in the sampler's fixed order (aie_layout.h).
+__device__ __forceinline__ float sampler_scan(float v, int seg) {
+  asm("s_nop 4\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1"
+      : "+v"(v));
+  if (seg >= 32) asm("s_nop 4\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+  if (seg >= 64) asm("s_nop 4\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+  return v;
+}
+// One work item in scalars: its first row; the other rows of a packed item follow at fixed strides.
+struct SamplerItem {
+  const float *lg, *mk;  // the first row's logits and mask entries
+  int32_t* dst;          // its action
+  int len, lrs, mrs, mks;  // entries; logits / mask stride from row to row; mask stride from entry to entry
+  int rows, lsh;           // rows of the item that exist; log2 of the lanes per row
+  uint32_t j0;             // the first row's slot in the replica
+};
+// A replica's agent rows and its planner rows: everything an item's addresses need (aie_sampler_args: filled by the host
+// from the parameter block, a few dozen bytes of kernel arguments -- with the 8 KB block itself as the argument its fields
+// arrived in a dozen dependent scalar-cache misses, most of the launch's 18 us whatever the arithmetic cost).
+struct SamplerGroup {
+  const float *lg, *mk;
+  int32_t* dst;
+  int len, lrs, mrs, mks, rpw, lsh, rows, items, slot0;
+};
+__device__ __forceinline__ SamplerGroup sampler_group(const aie_sampler_group& g, const uint8_t* __restrict__ arena,
+                                                      const float* __restrict__ logits, int32_t* __restrict__ act, int e, int slot0) {
+  SamplerGroup G;
+  G.lg = logits + (uint64_t)(uint32_t)e * g.lg_estride;
+  G.mk = reinterpret_cast<const float*>(arena + g.mk_off) + (uint64_t)(uint32_t)e * g.mk_estride;
+  G.dst = act + (uint64_t)(uint32_t)e * (uint32_t)g.rows;
+  G.len = g.len;
+  G.lrs = g.lrs;
+  G.mrs = g.mrs;
+  G.mks = g.mks;
+  G.lsh = g.lsh;
+  G.rpw = 64 >> g.lsh;
+  G.rows = g.rows;
+  G.items = (act && logits) ? (g.rows + G.rpw - 1) >> (6 - g.lsh) : 0;
+  G.slot0 = slot0;
+  return G;
+}
+__device__ __forceinline__ SamplerItem sampler_item(const aie_sampler_args& S, const SamplerGroup& A, const SamplerGroup& Q, int it) {
+  SamplerItem d;
+  const bool ag = it < A.items;
+  const int rpw = ag ? A.rpw : Q.rpw, r0 = (ag ? it : it - A.items) * rpw, rows = ag ? A.rows : Q.rows;
+  const float* lg = ag ? A.lg : Q.lg;
+  const float* mk = ag ? A.mk : Q.mk;
+  d.lrs = ag ? A.lrs : Q.lrs;
+  d.mrs = ag ? A.mrs : Q.mrs;
+  d.mks = ag ? A.mks : Q.mks;
+  d.lsh = ag ? A.lsh : Q.lsh;
+  d.len = ag ? A.len : Q.len;
+  d.dst = (ag ? A.dst : Q.dst) + r0;
+  d.j0 = (uint32_t)(r0 + (ag ? A.slot0 : Q.slot0));
+  d.rows = rows - r0 < rpw ? rows - r0 : rpw;
+  if (ag && S.ragged) {  // multi-action agents: an agent's rows differ in length (lrs / mrs: the strides from agent to agent)
+    const int i = r0 / S.act_a_width, s = r0 - i * S.act_a_width;
+    int lo = 0;
+    for (int k = 0; k < s; ++k) lo += 1 + S.params->sub_a_dim[k];
+    d.len = S.params->n_sub_a ? 1 + S.params->sub_a_dim[s] : 1;
+    d.lg = lg + (int64_t)i * d.lrs + lo;
+    d.mk = mk + (int64_t)i * d.mrs + lo;
+  } else {
+    d.lg = lg + (int64_t)r0 * d.lrs;
+    d.mk = mk + (int64_t)r0 * d.mrs;
+  }
+  return d;
+}
+// the lane's entry of the item's first 64-entry chunk: logit and mask value.  No branch and no use here: a lane without
+// an entry reads the row's first one and sampler_item_run ignores it -- the loads of a whole group of items must issue
+// back to back (a compare on the loaded value next to the load makes the wave wait right there).
+__device__ __forceinline__ void sampler_item_load(const SamplerItem& d, int lane, float& x, float& mv) {
+  const int sub = lane >> d.lsh, kk = lane & ((1 << d.lsh) - 1);
+  const bool inb = sub < d.rows && kk < d.len;
+  x = d.lg[inb ? __mul24(sub, d.lrs) + kk : 0];
+  mv = d.mk[inb ? __mul24(sub, d.mrs) + __mul24(kk, d.mks) : 0];
+}
+__device__ __forceinline__ void sampler_item_run(const SamplerItem& d, int lane, const float x0, const float mv0, uint32_t base) {
+  const int lsh = d.lsh, segw = 1 << lsh, rpw = 64 >> lsh, len = d.len;
+  const int sub = lane >> lsh, kk = lane & (segw - 1);
+  // a lone row's length may differ from row to row (multi-action agents) and exceed 64 (chunks); packed rows fit their segment
+  const int nch = rpw > 1 ? 1 : (len + 63) >> 6;
+  const int seg = rpw > 1 ? segw : (len > 32 ? 64 : aie_sampler_segment(len));
+  const int lgo = __mul24(sub, d.lrs) + kk, mko = __mul24(sub, d.mrs) + __mul24(kk, d.mks);
+  // ---- the row maximum over the allowed entries ----
+  const bool ok0 = sub < d.rows && kk < len && mv0 > 0.5f && x0 == x0;
+  float m = ok0 ? x0 : -INFINITY;
+  for (int ch = 1; ch < nch; ++ch)
+    if (64 * ch + kk < len) {
+      const float x = d.lg[lgo + 64 * ch];
+      if (d.mk[mko + 64 * ch * d.mks] > 0.5f && x > m) m = x;  // (x > m: not a NaN)
     }
-    const int j = j0 + sub;
-    cell[wave][lane] = 0ull;
-    AIE_WSYNC();
-    if (sub < rpw && j < jend) {
-      const SamplerRow r = sampler_row(P, arena, logits_a, logits_p, e, j, na, wa, covid);
-      const uint32_t slot_word = aie_sampler_entry_rng(base_lo, 0x40000000u + (uint32_t)j);
-      for (int k = kk; k < r.len; k += 64) {  // (packed rows: one pass)
-        const float x = r.lg[r.lo + k];
-        if (!(r.mask[(r.lo + k) * r.stride] > 0.5f) || x != x) continue;
-        const uint32_t rnd = aie_sampler_entry_rng(slot_word, (uint32_t)k);
-        const double u = ((double)rnd + 0.5) * (1.0 / 4294967296.0);
-        const double sc = (double)x - aie_sampler_log(-aie_sampler_log(u));
-        atomicMax(&cell[wave][sub], (unsigned long long)aie_sampler_key(sc, k));
+  const float M = sampler_segment_max(m, seg);
+  // ---- one uniform per row (scalar hashes, selected into the row's lanes) ----
+  uint32_t rnd = 0u;
+  for (int s = 0; s < rpw; ++s) {
+    const uint32_t h = aie_sampler_entry_rng(base, d.j0 + (uint32_t)s);
+    rnd = sub == s ? h : rnd;
+  }
+  const float u = aie_sampler_uniform(rnd);
+  // ---- weights, prefix sums, the first entry whose sum passes u T ----
+  int choice = -1, last_ok = -1, outv = 0;
+  float T = 0.0f;
+  for (int pass = (nch > 1 ? 0 : 1); pass < 2; ++pass) {  // (rows of more than 64 entries: a first pass for T)
+    float carry = 0.0f;
+    for (int ch = 0; ch < nch; ++ch) {
+      float x = x0;
+      bool ok = ok0;
+      if (ch > 0) {
+        ok = false;
+        if (64 * ch + kk < len) {
+          x = d.lg[lgo + 64 * ch];
+          ok = d.mk[mko + 64 * ch * d.mks] > 0.5f && x == x;
+        }
+      }
+      const float w = ok ? aie_sampler_expf(x - M) : 0.0f;
+      const float c = carry + sampler_scan(w, seg);
+      if (rpw == 1) {
+        const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), seg - 1));
+        if (pass == 0) {
+          carry = tot;
+          continue;
+        }
+        if (nch == 1) T = tot;
+        const uint64_t oks = __ballot(ok), hits = __ballot(ok && c > u * T);
+        if (choice < 0 && hits) choice = 64 * ch + (__ffsll((unsigned long long)hits) - 1);
+        if (oks) last_ok = 64 * ch + (63 - __clzll((long long)oks));
+        carry = tot;
+      } else {  // packed rows: one chunk, a total and a pick per segment
+        float Ts = 0.0f;
+        for (int s = 0; s < rpw; ++s) {
+          const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), (s << lsh) + segw - 1));
+          Ts = sub == s ? tot : Ts;
+        }
+        const uint64_t oks = __ballot(ok), hits = __ballot(ok && c > u * Ts);
+        const uint64_t sm = (1ull << segw) - 1ull;
+        for (int s = 0; s < rpw; ++s) {
+          const uint64_t h = (hits >> (s << lsh)) & sm, o = (oks >> (s << lsh)) & sm;
+          const int pick = h ? __ffsll((unsigned long long)h) - 1 : (o ? 63 - __clzll((long long)o) : 0);
+          outv = sub == s ? pick : outv;
+        }
       }
     }
-    AIE_WSYNC();
-    if (lane < rpw && j0 + lane < jend) {  // lane s reports row j0 + s
-      const unsigned long long best = cell[wave][lane];
-      const int choice = best ? 2047 - (int)(best & 0x7ffull) : 0;
-      const int jr = j0 + lane;
-      if (jr < na) act_a[(int64_t)e * na + jr] = choice;
-      else act_p[(int64_t)e * P.act_p_width + (jr - na)] = choice;
-    }
-    AIE_WSYNC();
+    if (pass == 0) T = carry;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) *tfield = (int32_t)t + 1;
+  if (rpw == 1) outv = choice < 0 ? (last_ok < 0 ? 0 : last_ok) : choice;
+  if (sub < d.rows && kk == 0) d.dst[sub] = outv;
 }
+#define AIE_SAMPLER_GROUP 4  // items whose loads a wave has in flight together
+extern "C" __global__ void __launch_bounds__(256)
+aie_sample_policy_actions_kernel(const aie_sampler_args S, uint8_t* __restrict__ arena, const float* __restrict__ logits_a,
+                                 const float* __restrict__ logits_p, uint64_t seed, int64_t env_offset,
+                                 int32_t* __restrict__ act_a, int32_t* __restrict__ act_p, int wpr_log2) {
+  const int lane = (int)threadIdx.x & 63, wave = aie::uni((int)threadIdx.x >> 6);
+#ifdef AIE_DEV  // development: bits 8.. of the argument switch parts of the kernel off (what is the launch made of?)
+  const int dev_skip = wpr_log2 >> 8;
+  wpr_log2 &= 255;
+  if (dev_skip & 8) return;
+#else
+  constexpr int dev_skip = 0;
+#endif
+  const int wpr = 1 << wpr_log2;
+  const int e = (int)blockIdx.x * (4 >> wpr_log2) + (wave >> wpr_log2), w_in = wave & (wpr - 1);
+  if (e < S.E) {
+    // work items: equally long short rows share a wave, each in its own ALIGNED lane segment of 16 or 32 lanes
+    const SamplerGroup A = sampler_group(S.agents, arena, logits_a, act_a, e, 0);
+    const SamplerGroup Q = sampler_group(S.planner, arena, logits_p, act_p, e, S.agents.rows);
+    const int items = A.items + Q.items, per_env = S.agents.rows + S.planner.rows;
+    // the kernel waits on memory, not on arithmetic (a wave's items one after the other: 18 us however few instructions):
+    // the draw index and a whole group of items' entries are requested before anything is computed
+    const int32_t* tfield = reinterpret_cast<const int32_t*>(arena + S.t_off + (int64_t)e * S.rec_bytes);
+    const int32_t t_lane = (dev_skip & 2) ? 0 : *tfield;
+    uint32_t base = 0u;
+    for (int it0 = w_in; it0 < items; it0 += AIE_SAMPLER_GROUP * wpr) {
+      SamplerItem d[AIE_SAMPLER_GROUP];
+      float x0[AIE_SAMPLER_GROUP], mv0[AIE_SAMPLER_GROUP];
+#pragma unroll
+      for (int g = 0; g < AIE_SAMPLER_GROUP; ++g) {
+        const int it = it0 + g * wpr;
+        if (it < items) {
+          d[g] = sampler_item(S, A, Q, it);
+          if (dev_skip & 1) {
+            x0[g] = (float)(lane & 7);
+            mv0[g] = 1.0f;
+          } else {
+            sampler_item_load(d[g], lane, x0[g], mv0[g]);
+          }
+        }
+      }
+      if (it0 == w_in) base = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)(int64_t)aie::uni(t_lane), (uint64_t)per_env);
+#pragma unroll
+      for (int g = 0; g < AIE_SAMPLER_GROUP; ++g)
+        if (it0 + g * wpr < items) {
+          if (dev_skip & 4) {
+            if (x0[g] + mv0[g] == 12345.0f) d[g].dst[0] = 1;
+          } else {
+            sampler_item_run(d[g], lane, x0[g], mv0[g], base);
+          }
+        }
+    }
+  }
+  __syncthreads();  // every wave of the replica has read the draw index: its first wave advances it
+  if (e < S.E && w_in == 0 && lane == 0 && !(dev_skip & 2)) {
+    int32_t* tfield = reinterpret_cast<int32_t*>(arena + S.t_off + (int64_t)e * S.rec_bytes);
+    *tfield = *tfield + 1;
+  }
+}
+// ---- the sampler's fast instances: every row of both groups is one aligned lane segment --------------------------------
+// (no rows of more than 64 entries, no multi-action agents: every BASELINE configuration and COVID.)  A SIMD issues one
+// scalar and one vector instruction every fourth clock whichever of its waves they come from, so the launch costs what the
+// LONGER of the two instruction streams costs (round 6: 530 vector + 420 scalar instructions per wave and 16 waves per
+// SIMD were 14 of the generic kernel's 19.7 us; dropping the vector count to a third moved nothing -- the scalar stream of
+// its run-time row shapes, 1500 instructions for four items, had become the longer one).  Here the lanes per row are
+// compile-time (LA agents, LQ planner: 16, 32 or 64 = 1 << 4 .. 6): no loops over the rows of an item, no branches on the
+// segment size, lane constants per group instead of per item, the pick stored by the segment's first lane above u T, and
+// the rows that need a second look (nothing allowed; rounding left no entry above u T) found by one population count.
+template <int LSH>
+struct SamplerFast {
+  const float *lg, *mk;
+  int32_t* dst;
+  int lrs, mrs, rows, items, slot0;
+  uint64_t kkmask;              // lanes whose entry exists (kk < len)
+  uint32_t lgo, mko;            // the lane's entry inside an item: byte offsets from the item's first logit / mask entry
+  uint32_t below_lo, below_hi;  // the lanes of my segment below me
+  int sub, kk;
+};
+template <int LSH>
+__device__ __forceinline__ SamplerFast<LSH> sampler_fast_group(const aie_sampler_group& g, const uint8_t* __restrict__ arena,
+                                                               const float* __restrict__ logits, int32_t* __restrict__ act,
+                                                               int e, int slot0, int lane) {
+  SamplerFast<LSH> G;
+  constexpr int SEGW = 1 << LSH;
+  G.lg = logits + (uint64_t)(uint32_t)e * g.lg_estride;  // (32 x 32 -> 64 bits: two scalar instructions)
+  G.mk = reinterpret_cast<const float*>(arena + g.mk_off) + (uint64_t)(uint32_t)e * g.mk_estride;
+  G.dst = act + (uint64_t)(uint32_t)e * (uint32_t)g.rows;
+  G.lrs = g.lrs;
+  G.mrs = g.mrs;
+  G.rows = g.rows;
+  G.items = (act && logits) ? (g.rows + (64 >> LSH) - 1) >> (6 - LSH) : 0;
+  G.slot0 = slot0;
+  G.sub = lane >> LSH;
+  G.kk = lane & (SEGW - 1);
+  G.kkmask = __ballot(G.kk < g.len);
+  G.lgo = 4u * (uint32_t)(__mul24(G.sub, g.lrs) + G.kk);
+  G.mko = 4u * (uint32_t)(__mul24(G.sub, g.mrs) + __mul24(G.kk, g.mks));
+  const uint64_t below = ((1ull << lane) - 1ull) & ~((1ull << (lane & ~(SEGW - 1))) - 1ull);
+  G.below_lo = (uint32_t)below;
+  G.below_hi = (uint32_t)(below >> 32);
+  return G;
+}
+template <int LSH>
+__device__ __forceinline__ uint64_t sampler_fast_lanes(const SamplerFast<LSH>& G, int it) {  // the lanes of item `it` that hold an entry
+  const int rows = G.rows - (it << (6 - LSH));
+  return rows >= (64 >> LSH) ? G.kkmask : G.kkmask & ((1ull << (rows << LSH)) - 1ull);
+}
+// no use of the loaded values here (sampler_item_load); a lane without an entry reads the item's first one
+template <int LSH>
+__device__ __forceinline__ void sampler_fast_load(const SamplerFast<LSH>& G, int it, float& x, float& mv) {
+  const bool in = __builtin_amdgcn_inverse_ballot_w64(sampler_fast_lanes(G, it));
+  // (32-bit byte offsets from the replica's first row: one scalar base per group, the rest in the lane's offset register)
+  const uint32_t r0 = (uint32_t)it << (6 - LSH), lg0 = 4u * r0 * (uint32_t)G.lrs, mk0 = 4u * r0 * (uint32_t)G.mrs;
+  x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(G.lg) + (lg0 + (in ? G.lgo : 0u)));
+  mv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(G.mk) + (mk0 + (in ? G.mko : 0u)));
+}
+template <int LSH>
+__device__ __forceinline__ void sampler_fast_run(const SamplerFast<LSH>& G, int it, int lane, const float x, const float mv, uint32_t base) {
+  constexpr int SEG = 1 << LSH, RPW = 64 >> LSH;
+  const int r0 = it << (6 - LSH);
+  const int rows = G.rows - r0 < RPW ? G.rows - r0 : RPW;
+  const bool ok = __builtin_amdgcn_inverse_ballot_w64(sampler_fast_lanes(G, it)) && mv > 0.5f && x == x;
+  const float M = sampler_segment_max(ok ? x : -INFINITY, SEG);
+  const float w = ok ? aie_sampler_expf(x - M) : 0.0f;
+  const float c = sampler_scan(w, SEG);
+  const uint32_t slot = (uint32_t)(G.slot0 + r0);
+  float thr;
+  if (LSH == 6) {  // one row: its uniform and its total are scalars
+    const float T = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
+    thr = aie_sampler_uniform(aie_sampler_entry_rng(base, slot)) * T;
+  } else {         // the segment's last lane to all of it: a swizzle through the LDS crossbar, no memory
+    const float T = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, c), LSH == 5 ? 0x3E0 : 0x1F0));
+    thr = aie_sampler_uniform(aie_sampler_entry_rng(base, slot + (uint32_t)G.sub)) * T;
+  }
+  const bool hit = ok && c > thr;
+  const uint64_t hits = __ballot(hit);
+  const bool first = hit && (((uint32_t)hits & G.below_lo) | ((uint32_t)(hits >> 32) & G.below_hi)) == 0u;
+  if (first) *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(G.dst) + 4u * (uint32_t)(r0 + G.sub)) = G.kk;
+  if (__popcll(__ballot(first)) != rows) {  // rows without a pick: nothing allowed (NO-OP), or no sum above u T (the last allowed entry)
+    const uint64_t oks = __ballot(ok), sm = LSH == 6 ? ~0ull : (1ull << SEG) - 1ull;
+    for (int s = 0; s < rows; ++s)
+      if (((hits >> (s << LSH)) & sm) == 0ull) {
+        const uint64_t o = (oks >> (s << LSH)) & sm;
+        if (lane == 0) G.dst[r0 + s] = o ? 63 - __clzll((long long)o) : 0;
+      }
+  }
+}
+template <int LA, int LQ>
+__global__ void __launch_bounds__(256)
+aie_sample_policy_fast_kernel(const aie_sampler_args S, uint8_t* __restrict__ arena, const float* __restrict__ logits_a,
+                              const float* __restrict__ logits_p, uint64_t seed, int64_t env_offset,
+                              int32_t* __restrict__ act_a, int32_t* __restrict__ act_p, int wpr_log2) {
+  const int lane = (int)threadIdx.x & 63, wave = aie::uni((int)threadIdx.x >> 6);
+  // every kernel argument is requested here, in one batch: fetched where first used (behind branches) they arrived in
+  // four to five dependent trips to the scalar cache, cold at the start of a launch
+  asm volatile("" ::"s"(S.agents.mk_off), "s"(S.agents.mk_estride), "s"(S.agents.lg_estride), "s"(S.agents.len), "s"(S.agents.lrs),
+               "s"(S.agents.mrs), "s"(S.agents.mks), "s"(S.agents.rows), "s"(S.planner.mk_off), "s"(S.planner.mk_estride),
+               "s"(S.planner.lg_estride), "s"(S.planner.len), "s"(S.planner.lrs), "s"(S.planner.mrs), "s"(S.planner.mks),
+               "s"(S.planner.rows), "s"(S.t_off), "s"(S.rec_bytes), "s"(S.E), "s"(arena), "s"(logits_a), "s"(logits_p), "s"(seed),
+               "s"(env_offset), "s"(act_a), "s"(act_p), "s"(wpr_log2));
+#ifdef AIE_DEV  // development: bits 8.. of the argument switch parts of the kernel off (what is the launch made of?)
+  const int dev_skip = wpr_log2 >> 8;
+  wpr_log2 &= 255;
+  if (dev_skip & 8) return;
+#else
+  constexpr int dev_skip = 0;
+#endif
+  const int wpr = 1 << wpr_log2;
+  const int e = (int)blockIdx.x * (4 >> wpr_log2) + (wave >> wpr_log2), w_in = wave & (wpr - 1);
+  if (e < S.E) {
+    const SamplerFast<LA> A = sampler_fast_group<LA>(S.agents, arena, logits_a, act_a, e, 0, lane);
+    const SamplerFast<LQ> Q = sampler_fast_group<LQ>(S.planner, arena, logits_p, act_p, e, S.agents.rows, lane);
+    const int per_env = S.agents.rows + S.planner.rows;
+    // the draw index and a whole turn's entries are requested before anything is computed
+    const int32_t* tfield = reinterpret_cast<const int32_t*>(arena + S.t_off + (int64_t)e * S.rec_bytes);
+    const int32_t t_lane = (dev_skip & 2) ? 0 : *tfield;
+    // (per turn: two agent items and two planner items of this wave, all their loads ahead of the arithmetic)
+    uint32_t base = 0u;
+    for (int it_ = w_in; it_ < A.items || it_ < Q.items; it_ += 2 * wpr) {
+      int it = it_;
+      asm volatile("" : "+s"(it));  // (opaque: no induction variables derived from it -- the loop's one or two turns
+                                    //  do not repay two dozen of them set up in every wave's prologue)
+      float xa[2], ma[2], xq[2], mq[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if (dev_skip & 1) {
+          xa[g] = xq[g] = (float)(lane & 7);
+          ma[g] = mq[g] = 1.0f;
+        } else {
+          if (it + g * wpr < A.items) sampler_fast_load<LA>(A, it + g * wpr, xa[g], ma[g]);
+          if (it + g * wpr < Q.items) sampler_fast_load<LQ>(Q, it + g * wpr, xq[g], mq[g]);
+        }
+      }
+      if (it_ == w_in) base = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)(int64_t)aie::uni(t_lane), (uint64_t)per_env);
+      if (dev_skip & 4) {
+        if (xa[0] + ma[0] + xa[1] + ma[1] + xq[0] + mq[0] + xq[1] + mq[1] == 12345.0f) A.dst[0] = 1;
+        continue;
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if (it + g * wpr < A.items) sampler_fast_run<LA>(A, it + g * wpr, lane, xa[g], ma[g], base);
+        if (it + g * wpr < Q.items) sampler_fast_run<LQ>(Q, it + g * wpr, lane, xq[g], mq[g], base);
+      }
+    }
+  }
+  __syncthreads();  // every wave of the replica has read the draw index: its first wave advances it
+  if (e < S.E && w_in == 0 && lane == 0 && !(dev_skip & 2)) {
+    int32_t* tfield = reinterpret_cast<int32_t*>(arena + S.t_off + (int64_t)e * S.rec_bytes);
+    *tfield = *tfield + 1;
+  }
+}
+#define AIE_SAMPLER_FAST(LA, LQ) \
+  template __global__ void aie_sample_policy_fast_kernel<LA, LQ>(const aie_sampler_args, uint8_t*, const float*, const float*, \
+                                                                 uint64_t, int64_t, int32_t*, int32_t*, int);
+AIE_SAMPLER_FAST(4, 4) AIE_SAMPLER_FAST(4, 5) AIE_SAMPLER_FAST(4, 6)
+AIE_SAMPLER_FAST(5, 4) AIE_SAMPLER_FAST(5, 5) AIE_SAMPLER_FAST(5, 6)
+AIE_SAMPLER_FAST(6, 4) AIE_SAMPLER_FAST(6, 5) AIE_SAMPLER_FAST(6, 6)
 #endif  // !AIE_JIT
 
 #if defined(AIE_JIT) && !defined(AIE_JIT_OSE)

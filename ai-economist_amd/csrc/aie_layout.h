@@ -23,6 +23,7 @@
 #ifndef AIE_LAYOUT_H_
 #define AIE_LAYOUT_H_
 
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -1325,18 +1326,31 @@ AIE_HD static inline double aie_annealed_tax_limit(int completions, double warmu
   return pv * final_max;
 }
 
-/* The logarithm of the policy sampler's Gumbel scores (aie_sample_policy_actions): log(v) for a normal double v > 0 as a
- * FIXED sequence of IEEE double operations -- no fma, no libm, no table -- so that the kernel, the CPU restatement
- * (oracle/) and a NumPy / Python transcription produce the same bits: v = m 2^e with m in [sqrt(1/2), sqrt(2)),
- * log v = e ln 2 + 2 atanh(s), s = (m - 1) / (m + 1), atanh by its odd series through s^13 (|s| <= 0.1716: the first
- * dropped term is below 3e-13 of the leading one) -- far more than a sampler needs; what it needs is that everybody
- * computes the SAME score.  (libm's log restated operation by operation, aie_glibc_math.h, cost
- * the sampler 26 us per launch on BASELINE configs[1]: two table-driven logarithms per entry.) */
-/* The policy sampler's per-entry random word: one 64-bit counter hash per action slot (aie_counter_rng, keyed seed /
- * global replica / draw index / slot), then a 32-bit finaliser per entry (two multiplies; "lowbias32" of C. Wellons'
- * hash prospector) -- the 64-bit hash per ENTRY was a third of the sampler's vector work. */
-AIE_HD static inline uint32_t aie_sampler_entry_rng(uint32_t slot_word, uint32_t k) {
-  uint32_t h = slot_word + k * 0x9E3779B1u;
+/* ---- the policy sampler (aie_sample_policy_actions; round 6: inverse CDF in float32) ---------------------------------
+ * A row (one action slot: `len` entries k = 0 .. len - 1 with logits x_k, of which some are allowed: mask > 0.5 and x_k
+ * not a NaN) is sampled as
+ *     M = max of the allowed x_k;  w_k = aie_sampler_expf(x_k - M) for allowed k, 0 otherwise (and for k >= len);
+ *     c_k = inclusive prefix sums of w in the FIXED order below;  T = the total in that order;
+ *     u = aie_sampler_uniform(aie_sampler_entry_rng(base, slot)) in (0, 1), 23 bits;
+ *     choice = the first allowed k with c_k > u T  (the last allowed k if rounding leaves none; NO-OP if nothing is allowed),
+ * base = one 64-bit counter hash per replica and call (aie_counter_rng), slot = the row's index in the replica.  Every
+ * operation is an IEEE float32 add / multiply / fused multiply-add (fmaf: exact, rounded once) in a fixed order -- no
+ * libm exponential, no table -- so the kernel, the CPU restatement (oracle/) and a Python transcription pick the same entry:
+ *   * prefix sums: rows are cut into chunks of 64 entries; inside a chunk, over the entry's index r in its chunk and the
+ *     row's segment size seg = aie_sampler_segment(len) (16, 32 or 64: what the kernel's cross-lane primitives span; 64
+ *     for every chunk of a row of more than 64 entries):
+ *     steps d = 1, 2, 4, 8: v_r <- v_r + v_{r-d} for (r mod 16) >= d (all r at once, inputs = the previous step's values);
+ *     seg >= 32: v_r <- v_r + v_{16 (r div 16) - 1} for r div 16 odd;  seg = 64: v_r <- v_r + v_31 for r >= 32;
+ *     c_k = carry + v_r;  the chunk's total = carry + v_{seg-1};  carry = 0 for the first chunk, then the previous total;
+ *   * aie_sampler_expf(y), y <= 0: 0 at or below -80; n = rint(y log2(e)); r = fma(n, -ln2_lo, fma(n, -ln2_hi, y)); the
+ *     Taylor polynomial of e^r through r^6 by Horner in fma (|r| <= 0.35: the first dropped term is 1.3e-7 of the sum);
+ *     times 2^n (ldexp: exact, n >= -116).
+ * Per entry: one exponential of 14 vector instructions, a row maximum and a prefix sum of 6 - 10 data-parallel-primitive
+ * instructions each (DPP row rotates / shifts / broadcasts and gfx950's permlane swaps: no LDS), one comparison -- where
+ * round 5's Gumbel-max spent two float64 logarithms (each with an IEEE division) and a 64-bit key per entry.  float32
+ * resolves a probability to 2^-24 of the row's total; u itself has 23 bits. */
+AIE_HD static inline uint32_t aie_sampler_entry_rng(uint32_t base, uint32_t k) {  /* "lowbias32", C. Wellons' hash prospector */
+  uint32_t h = base + k * 0x9E3779B1u;
   h ^= h >> 16;
   h *= 0x7feb352du;
   h ^= h >> 15;
@@ -1344,40 +1358,79 @@ AIE_HD static inline uint32_t aie_sampler_entry_rng(uint32_t slot_word, uint32_t
   h ^= h >> 16;
   return h;
 }
-/* (score, entry) as ONE unsigned 64-bit key whose order is "higher score first, lower entry index on ties": the double's
- * bits made monotone (sign flip), its lowest 11 mantissa bits replaced by 2047 - k (k < 2048; scores that agree in all
- * but those bits -- 2.4e-13 relative -- count as tied).  0 = nothing allowed.  The arg-max of a slot is then one LDS
- * atomic max per lane instead of a six-step shuffle tree of (double, int) pairs. */
-AIE_HD static inline uint64_t aie_sampler_key(double score, int k) {
-  union { double d; uint64_t u; } c;
-  c.d = score;
-  uint64_t b = c.u;
-  b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-  return (b & ~0x7ffull) | (uint64_t)(2047 - k);
+AIE_HD static inline float aie_sampler_uniform(uint32_t rnd) {  /* ((rnd >> 9) + 1/2) / 2^23: exact in float32 */
+  return (float)(rnd >> 9) * 0x1p-23f + 0x1p-24f;
 }
-AIE_HD static inline double aie_sampler_log(double v) {
-#if defined(__HIPCC__)
-  _Pragma("clang fp contract(off)")
-#endif
-  union { double d; uint64_t u; } c;
-  c.d = v;
-  int e = (int)((c.u >> 52) & 0x7ffu) - 1023;
-  c.u = (c.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
-  double m = c.d; /* [1, 2) */
-  if (m > 1.4142135623730951) {
-    m = m * 0.5;
-    e += 1;
+AIE_HD static inline float aie_sampler_expf(float y) {
+  /* (the guard is a select at the end: one straight line of 14 instructions on the device) */
+  const float n = rintf(y * 0x1.715476p+0f);      /* round half to even */
+  float r = fmaf(n, -0x1.62e4p-1f, y);            /* ln 2 = 0x1.62e4p-1 + 0x1.7f7d1cp-20: the first product is exact */
+  r = fmaf(n, -0x1.7f7d1cp-20f, r);
+  float p = 0x1.6c16c2p-10f;                      /* 1/6! */
+  p = fmaf(p, r, 0x1.111112p-7f);                 /* 1/5! */
+  p = fmaf(p, r, 0x1.555556p-5f);                 /* 1/4! */
+  p = fmaf(p, r, 0x1.555556p-3f);                 /* 1/3! */
+  p = fmaf(p, r, 0.5f);
+  p = fmaf(p, r, 1.0f);
+  p = fmaf(p, r, 1.0f);
+  const int ni = y > -80.0f ? (int)n : 0;
+  return y > -80.0f ? ldexpf(p, ni) : 0.0f;
+}
+/* the aligned lane segment a row of `len` entries is scanned in, and how many such rows share a wavefront */
+AIE_HD static inline int aie_sampler_segment(int len) { return len <= 16 ? 16 : len <= 32 ? 32 : 64; }
+AIE_HD static inline int aie_sampler_rows_per_wave(int len) { return 64 / aie_sampler_segment(len); }
+/* What the sampler kernel needs of the parameter block, as its kernel argument (aie_sampler_args_of fills it).  A group
+ * is a replica's agent rows or its planner rows: row r's entry k has its logit at logits[e lg_estride + r lrs + k] and its
+ * mask at the arena's float mk_off / 4 + e mk_estride + r mrs + k mks (COVID's collated agent masks: mrs 1, mks n). */
+typedef struct aie_sampler_group {
+  int64_t mk_off;
+  uint32_t mk_estride, lg_estride;       /* (32 bits: a replica's rows x entries) */
+  int32_t len, lrs, mrs, mks, lsh, rows; /* entries per row; strides; log2 of the lanes a row takes; rows per replica */
+} aie_sampler_group;
+typedef struct aie_sampler_args {
+  aie_sampler_group agents, planner;
+  int64_t t_off, rec_bytes;   /* replica e's draw index: the arena's int32 at t_off + e rec_bytes */
+  const aie_params* params;   /* the device copy: read for multi-action agents only (rows of different lengths) */
+  int32_t E, ragged, act_a_width, pad_;
+} aie_sampler_args;
+static inline aie_sampler_args aie_sampler_args_of(const aie_params* p, const aie_params* d_params) {
+  aie_sampler_args S;
+  memset(&S, 0, sizeof(S));
+  const int covid = p->c.scenario == AIE_SCN_COVID;
+  const int wa = covid ? 1 + p->cv_NL : p->MA; /* logits per agent, in the mask's own (flattened) layout */
+  aie_sampler_group* A = &S.agents;
+  aie_sampler_group* Q = &S.planner;
+  S.ragged = p->c.multi_action_mode_agents != 0;
+  A->len = wa;
+  A->lsh = S.ragged ? 6 : (aie_sampler_segment(wa) == 16 ? 4 : aie_sampler_segment(wa) == 32 ? 5 : 6);
+  A->rows = p->n * p->act_a_width;
+  A->lrs = wa;
+  A->lg_estride = (uint32_t)(p->n * wa);
+  if (covid) {
+    A->mk_off = p->a_cv_obs_a + 4 * (int64_t)AIE_CV_OB_MASK * p->n;
+    A->mk_estride = (uint32_t)(p->cv_nrow_obs * p->n);
+    A->mks = p->n;
+    A->mrs = 1;
+  } else {
+    A->mk_off = p->a_obs_a_mask;
+    A->mk_estride = (uint32_t)(p->n * p->MA);
+    A->mks = 1;
+    A->mrs = p->MA;
   }
-  const double s = (m - 1.0) / (m + 1.0);
-  const double z = s * s;
-  double p = 0.076923076923076927;   /* 1/13 */
-  p = p * z + 0.090909090909090912;  /* 1/11 */
-  p = p * z + 0.1111111111111111;    /* 1/9 */
-  p = p * z + 0.14285714285714285;   /* 1/7 */
-  p = p * z + 0.2;                   /* 1/5 */
-  p = p * z + 0.33333333333333331;   /* 1/3 */
-  p = p * z + 1.0;
-  return (double)e * 0.69314718055994529 + (2.0 * s) * p;
+  Q->len = p->c.multi_action_mode_planner ? (p->n_sub_p ? 1 + p->sub_p_dim : 1) : p->MP;
+  Q->lsh = aie_sampler_segment(Q->len) == 16 ? 4 : aie_sampler_segment(Q->len) == 32 ? 5 : 6;
+  Q->rows = p->act_p_width;
+  Q->lrs = Q->mrs = p->c.multi_action_mode_planner ? 1 + p->sub_p_dim : p->MP; /* (a multi-action planner's rows: 1 + sub_p_dim apart) */
+  Q->mks = 1;
+  Q->lg_estride = (uint32_t)p->MP;
+  Q->mk_off = covid ? p->a_cv_obs_p + 16 : p->a_obs_p_mask;
+  Q->mk_estride = (uint32_t)(covid ? 4 + p->MP : p->MP);
+  S.t_off = p->a_records + p->o_sample_t;
+  S.rec_bytes = p->rec_bytes;
+  S.params = d_params;
+  S.E = p->E;
+  S.act_a_width = p->act_a_width;
+  return S;
 }
 AIE_HD static inline uint32_t aie_counter_rng(uint64_t seed, uint64_t env, uint64_t t, uint64_t slot) {
   uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env + 1ull);

@@ -530,12 +530,14 @@ int aie_specialize(aie_env* env);
  *   d_logits_a  float32 [E, n, MA]  in the layout of obs_a_action_mask (single-action agents: one row of MA entries,
  *               entry 0 = NO-OP; multi-action: the subspaces' (1 + dim) entries back to back; COVID: [E, n, 1 + levels])
  *   d_logits_p  float32 [E, MP]     in the layout of obs_p_action_mask
- * Sub-action = argmax over the allowed entries k of logit_k - log(-log(u_k)) (Gumbel-max: a draw from softmax(logits)
- * restricted to the mask), u_k from a counter hash keyed (seed, global env id, the replica's draw index, slot, k); scores
- * that agree to 2.4e-13 relative count as tied and take the lower index, NaN logits count as masked, NO-OP if nothing is
- * allowed.  Scores are float64 and `log` is a fixed sequence of IEEE operations (csrc/aie_layout.h: aie_sampler_log,
- * aie_sampler_entry_rng, aie_sampler_key), so the CPU restatement (oracle/: aie_oracle_sample_policy_actions) picks the
- * same entries.  One launch; the
+ * Sub-action = a draw from softmax(logits) restricted to the mask by inverse CDF: weights exp(logit_k - max) of the allowed
+ * entries, their prefix sums in a fixed order, the first entry whose sum passes u x total, u in (0, 1) from a counter hash
+ * keyed (seed, global env id, the replica's draw index, slot); NaN logits count as masked, NO-OP if nothing is allowed.
+ * Everything is float32 and a fixed sequence of IEEE add / multiply / fused multiply-add operations (csrc/aie_layout.h:
+ * aie_sampler_expf, aie_sampler_uniform, aie_sampler_entry_rng, the scan's order), so the CPU restatement (oracle/:
+ * aie_oracle_sample_policy_actions) picks the same entries; a probability is resolved to 2^-24 of its row's total and u
+ * has 23 bits.  Rows of up to 64 entries with single-action agents (every BASELINE configuration, COVID) run on
+ * instances with compile-time row shapes, anything else on a generic kernel with the same results.  One launch; the
  * draw index is the replica's record field `sample_t`, advanced by the kernel (replayable from a hipGraph).  Either pair
  * (logits, actions) may be NULL. */
 int aie_sample_policy_actions(aie_env* env, const float* d_logits_a, const float* d_logits_p, uint64_t seed,

@@ -1845,12 +1845,67 @@ void aie_oracle_seed64(const aie_params* p, uint8_t* arena, uint64_t base_seed) 
   }
 }
 void aie_oracle_seed(const aie_params* p, uint8_t* arena, uint32_t base_seed) { aie_oracle_seed64(p, arena, (uint64_t)base_seed); }
-/* aie_sample_policy_actions (include/aie.h) restated: Gumbel-max over the allowed entries of every action slot, float64
- * scores logit - log(-log(u)) with the sampler's fixed-operation log (aie_layout.h: aie_sampler_log; tests compare it with
- * libm's), u from the counter RNG keyed (seed, global replica, draw index, slot, k);
- * ties take the lower index, NaN logits count as masked, NO-OP if nothing is allowed; advances `sample_t`.  Not part of
- * the reference (its trainers sample in their own framework, training_script.py:88-133): this pins the PRODUCT's
- * sampler.  Gather-trade-build and one-step-economy layouts (COVID's collated masks: covid_oracle.py). */
+/* aie_sample_policy_actions (include/aie.h) restated: inverse-CDF sampling over the allowed entries of every action slot,
+ * float64 weights exp(logit - max) with the sampler's fixed-operation exp and prefix-sum order (aie_layout.h), one uniform
+ * per slot from the counter RNG keyed (seed, global replica, draw index, slot); NaN logits count as masked, NO-OP if nothing
+ * is allowed; advances `sample_t`.  Not part of the reference (its trainers sample in their own framework,
+ * training_script.py:88-133): this pins the PRODUCT's sampler.  Gather-trade-build and one-step-economy layouts (COVID's
+ * collated masks: a Python transcription in tests/test_gpu_parity.py). */
+/* One row of the inverse-CDF sampler (aie_layout.h: the sampler's definition): chunks of 64 entries, the fixed-order scan
+ * inside a chunk, a running carry from chunk to chunk. */
+int32_t aie_oracle_sample_row(const float* lg, const float* mask, int mask_stride, int len, uint32_t rnd) {
+  int any = 0;
+  float M = 0.0f;
+  for (int k = 0; k < len; ++k) {
+    const float x = lg[k];
+    if (!(mask[k * mask_stride] > 0.5f) || x != x) continue;
+    if (!any || x > M) M = x;
+    any = 1;
+  }
+  if (!any) return 0;
+  const float u = aie_sampler_uniform(rnd);
+  const int nch = (len + 63) / 64, seg = nch > 1 ? 64 : aie_sampler_segment(len);
+  float T = 0.0f;
+  int choice = -1, last_ok = -1;
+  for (int pass = (nch > 1 ? 0 : 1); pass < 2; ++pass) {
+    float carry = 0.0f;
+    for (int ch = 0; ch < nch; ++ch) {
+      float v[64];
+      int ok[64];
+      for (int r = 0; r < 64; ++r) {
+        const int k = 64 * ch + r;
+        v[r] = 0.0f;
+        ok[r] = 0;
+        if (k < len) {
+          const float x = lg[k];
+          ok[r] = mask[k * mask_stride] > 0.5f && x == x;
+          if (ok[r]) v[r] = aie_sampler_expf(x - M);
+        }
+      }
+      for (int d = 1; d < 16; d <<= 1)
+        for (int r = 63; r >= 0; --r) v[r] = v[r] + ((r & 15) >= d ? v[r - d] : 0.0f); /* (descending r: v[r - d] is still the previous step's) */
+      if (seg >= 32)
+        for (int r = 0; r < 64; ++r)
+          if ((r >> 4) & 1) v[r] = v[r] + v[(r & ~15) - 1];
+      if (seg >= 64)
+        for (int r = 32; r < 64; ++r) v[r] = v[r] + v[31];
+      const float tot = carry + v[seg - 1];
+      if (pass == 0) {
+        carry = tot;
+        continue;
+      }
+      if (nch == 1) T = tot;
+      for (int r = 0; r < 64; ++r) {
+        if (!ok[r]) continue;
+        last_ok = 64 * ch + r;
+        if (choice < 0 && carry + v[r] > u * T) choice = 64 * ch + r;
+      }
+      carry = tot;
+    }
+    if (pass == 0) T = carry;
+  }
+  return choice < 0 ? last_ok : choice;
+}
 void aie_oracle_sample_policy_actions(const aie_params* p, uint8_t* arena, const float* logits_a, const float* logits_p,
                                       uint64_t seed, int64_t env_offset, int32_t* act_a, int32_t* act_p) {
   const int na = p->n * p->act_a_width, per_env = na + p->act_p_width;
@@ -1887,27 +1942,15 @@ void aie_oracle_sample_policy_actions(const aie_params* p, uint8_t* arena, const
         dst = act_p + (int64_t)e * p->act_p_width + s;
       }
       const uint32_t base = aie_counter_rng(seed, (uint64_t)(env_offset + e), (uint64_t)t, (uint64_t)per_env); /* per replica and call */
-      const uint32_t slot_word = aie_sampler_entry_rng(base, 0x40000000u + (uint32_t)j);
-      uint64_t best = 0; /* (score, entry) as one ordered key: aie_layout.h */
-      for (int k = 0; k < len; ++k) {
-        const float x = lg[lo + k];
-        if (!(mask[lo + k] > 0.5f) || x != x) continue;
-        const uint32_t r = aie_sampler_entry_rng(slot_word, (uint32_t)k);
-        const double u = ((double)r + 0.5) * (1.0 / 4294967296.0);
-        const double sc = (double)x - aie_sampler_log(-aie_sampler_log(u)); /* (the product's own log: aie_layout.h) */
-        const uint64_t key = aie_sampler_key(sc, k);
-        if (key > best) best = key;
-      }
-      const int best_k = best ? 2047 - (int)(best & 0x7ffu) : -1;
-      *dst = best_k < 0 ? 0 : best_k;
+      *dst = aie_oracle_sample_row(lg + lo, mask + lo, 1, len, aie_sampler_entry_rng(base, (uint32_t)j));
     }
     *tf = (int32_t)t + 1;
   }
 }
 /* the sampler's building blocks (aie_layout.h), exported so that a CPU test can hold them to their Python transcription
  * and to libm */
-double aie_oracle_sampler_log(double v) { return aie_sampler_log(v); }
-uint64_t aie_oracle_sampler_key(double score, int k) { return aie_sampler_key(score, k); }
+float aie_oracle_sampler_expf(float y) { return aie_sampler_expf(y); }
+float aie_oracle_sampler_uniform(uint32_t rnd) { return aie_sampler_uniform(rnd); }
 uint32_t aie_oracle_sampler_entry_rng(uint32_t slot_word, uint32_t k) { return aie_sampler_entry_rng(slot_word, k); }
 /* multi-threaded step for the cpu_baseline leg of bench.py */
 void aie_oracle_step_mt(const aie_params* p, uint8_t* arena, const int32_t* aa, const int32_t* ap, int nthreads) {

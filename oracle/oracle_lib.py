@@ -56,10 +56,12 @@ def lib():
         L.aie_oracle_philox2x32_10.restype = None
         L.aie_oracle_sample_policy_actions.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int64, vp, vp]
         L.aie_oracle_sample_policy_actions.restype = None
-        L.aie_oracle_sampler_log.argtypes = [C.c_double]
-        L.aie_oracle_sampler_log.restype = C.c_double
-        L.aie_oracle_sampler_key.argtypes = [C.c_double, C.c_int]
-        L.aie_oracle_sampler_key.restype = C.c_uint64
+        L.aie_oracle_sampler_expf.argtypes = [C.c_float]
+        L.aie_oracle_sampler_expf.restype = C.c_float
+        L.aie_oracle_sampler_uniform.argtypes = [C.c_uint32]
+        L.aie_oracle_sampler_uniform.restype = C.c_float
+        L.aie_oracle_sample_row.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]
+        L.aie_oracle_sample_row.restype = C.c_int32
         L.aie_oracle_sampler_entry_rng.argtypes = [C.c_uint32, C.c_uint32]
         L.aie_oracle_sampler_entry_rng.restype = C.c_uint32
         _LIB = L

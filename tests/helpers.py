@@ -347,3 +347,108 @@ FAMILY_CASES = {
     # and so does anything structural
     "c2_six_orders": (dict(C2, components=_components_with(GTB, ContinuousDoubleAuction=dict(max_num_orders=6))), False),
 }
+
+
+# ---- the policy sampler (csrc/aie_layout.h: aie_sampler_exp, aie_sampler_entry_rng, the scan's order), transcribed in
+# plain Python: IEEE double multiplies and adds in the header's order, nothing else ----
+def _f32_nearest(fr):
+    """The float32 nearest to the exact rational `fr`, ties to even (one rounding, as a hardware fma rounds)."""
+    from fractions import Fraction
+
+    f = np.float32(float(fr))  # within one unit of the answer (float(fr) is itself correctly rounded to float64)
+    best = None
+    for c in (np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))):
+        if not np.isfinite(c):
+            continue
+        key = (abs(Fraction(float(c)) - fr), int(np.float32(c).view(np.uint32)) & 1)
+        if best is None or key < best[0]:
+            best = (key, np.float32(c))
+    return best[1]
+
+
+def fmaf(a, b, c):
+    """a * b + c in float32 with ONE rounding (C's fmaf / v_fma_f32), through exact rational arithmetic."""
+    from fractions import Fraction
+
+    return _f32_nearest(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+
+
+def sampler_expf(y):
+    f32 = np.float32
+    y = f32(y)
+    if not (y > f32(-80.0)):
+        return f32(0.0)
+    n = np.rint(y * f32(float.fromhex("0x1.715476p+0")))  # float32 product, round half to even
+    r = fmaf(n, f32(-float.fromhex("0x1.62e4p-1")), y)
+    r = fmaf(n, f32(-float.fromhex("0x1.7f7d1cp-20")), r)
+    p = f32(float.fromhex("0x1.6c16c2p-10"))
+    for c in ("0x1.111112p-7", "0x1.555556p-5", "0x1.555556p-3", "0x1p-1", "0x1p+0", "0x1p+0"):
+        p = fmaf(p, r, f32(float.fromhex(c)))
+    return f32(np.ldexp(p, int(n)))
+
+
+def sampler_uniform(rnd):
+    return np.float32(rnd >> 9) * np.float32(2.0 ** -23) + np.float32(2.0 ** -24)
+
+
+def sampler_entry_rng(slot_word, k):
+    h = (slot_word + k * 0x9E3779B1) & 0xffffffff
+    h ^= h >> 16
+    h = (h * 0x7feb352d) & 0xffffffff
+    h ^= h >> 15
+    h = (h * 0x846ca68b) & 0xffffffff
+    return h ^ (h >> 16)
+
+
+def counter_rng(seed, env_id, t, slot):
+    M64 = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * (env_id + 1)) & M64
+    z ^= ((t + 1) * 0xBF58476D1CE4E5B9) & M64
+    z ^= ((slot + 1) * 0x94D049BB133111EB) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    z ^= z >> 31
+    return z >> 32
+
+
+def sampler_pick_row(logits, mask, rnd):
+    """One action slot: float32 logits, mask (> 0.5 = allowed), the slot's 32-bit word -> the entry
+    aie_sample_policy_actions picks (float32 arithmetic, operation for operation)."""
+    f32 = np.float32
+    n = len(logits)
+    lg = [f32(v) for v in logits]
+    ok = [bool(mask[k] > 0.5) and bool(lg[k] == lg[k]) for k in range(n)]
+    if not any(ok):
+        return 0
+    M = max(lg[k] for k in range(n) if ok[k])
+    u = sampler_uniform(rnd)
+    nch = (n + 63) // 64
+    seg = 64 if nch > 1 else (16 if n <= 16 else 32 if n <= 32 else 64)  # aie_sampler_segment
+    zero = f32(0.0)
+    T, choice, last_ok = zero, -1, -1
+    for pas in ((0, 1) if nch > 1 else (1,)):
+        carry = zero
+        for ch in range(nch):
+            v = [sampler_expf(lg[64 * ch + r] - M) if 64 * ch + r < n and ok[64 * ch + r] else zero for r in range(64)]
+            for d in (1, 2, 4, 8):
+                v = [v[r] + (v[r - d] if (r & 15) >= d else zero) for r in range(64)]
+            if seg >= 32:
+                v = [v[r] + v[(r & ~15) - 1] if (r >> 4) & 1 else v[r] for r in range(64)]
+            if seg >= 64:
+                v = [v[r] + v[31] if r >= 32 else v[r] for r in range(64)]
+            tot = carry + v[seg - 1]
+            if pas == 0:
+                carry = tot
+                continue
+            if nch == 1:
+                T = tot
+            for r in range(64):
+                k = 64 * ch + r
+                if k < n and ok[k]:
+                    last_ok = k
+                    if choice < 0 and carry + v[r] > u * T:
+                        choice = k
+            carry = tot
+        if pas == 0:
+            T = carry
+    return last_ok if choice < 0 else choice

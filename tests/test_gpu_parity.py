@@ -1398,17 +1398,27 @@ def _graph_env(cfg, E, seed, reward_log):
     return env, log
 
 
-@pytest.mark.parametrize("case", ["gtb_c2", "gtb_multi_action", "one_step_economy"])
+@pytest.mark.parametrize("case", ["gtb_c2", "gtb_multi_action", "one_step_economy", "rows_22_12", "rows_6_52", "rows_6_12_five_agents"])
 def test_policy_sampler_equals_its_cpu_restatement(case):
-    """aie_sample_policy_actions (Gumbel-max over the caller's logits under the action masks, one launch) against
+    """aie_sample_policy_actions (inverse-CDF sampling from the caller's logits under the action masks, one launch) against
     oracle/'s restatement: the same sub-action in every slot of every replica, over steps whose masks change (inventory-
     dependent trades, the planner's tax days), with NaN logits, ties and fully masked rows thrown in; the draw index
-    advances once per call."""
+    advances once per call.  The cases cover the kernel's instances: rows of 50 + 22 entries (BASELINE configs[1]: 64- and
+    32-lane segments), multi-action agents and a one-row planner of 148 entries / the one-step economy (the generic kernel:
+    rows of different lengths, chunks of 64), and rows of 22 + 12, 6 + 52 and 6 + 12 entries (32 + 16, 16 + 64 and 16 + 16
+    lanes per row; five agents: a last item with one row of four)."""
     import torch
     from oracle_lib import OracleEnv
 
     if case == "one_step_economy":
         cfg = _auto_reset_cases()["one_step_economy"]
+    elif case.startswith("rows_"):
+        def tax(disc):
+            return ["PeriodicBracketTax", {"rate_disc": disc, "period": 10}]
+        comps = {"rows_22_12": [["Build", {}], ["ContinuousDoubleAuction", {"max_num_orders": 5, "max_bid_ask": 3}], ["Gather", {}], tax(0.1)],
+                 "rows_6_52": [["Build", {}], ["Gather", {}], tax(0.02)],
+                 "rows_6_12_five_agents": [["Build", {}], ["Gather", {}], tax(0.1)]}[case]
+        cfg = dict(C2, episode_length=30, components=comps, n_agents=5 if case.endswith("five_agents") else 4)
     else:
         cfg = dict(C2, episode_length=30, multi_action_mode_agents=(case == "gtb_multi_action"),
                    multi_action_mode_planner=(case != "gtb_multi_action"))
@@ -1490,12 +1500,10 @@ def test_backend_lifecycle_free_now_and_failed_construction(monkeypatch):
 
 def test_policy_sampler_covid_collated_masks():
     """aie_sample_policy_actions on the COVID scenario's collated masks ([1 + levels][states] rows per replica, stride n):
-    against a NumPy restatement of the sampler written out here (counter hash, Gumbel-max with libm's log, lowest index on
-    ties) -- every state's and the planner's sub-action, over steps whose masks change with the cool-downs."""
-    import math
-
+    against the Python transcription of the sampler (tests/helpers.py: counter hash, fixed-operation exp, the prefix sums'
+    order) -- every state's and the planner's sub-action, over steps whose masks change with the cool-downs."""
     import torch
-    from helpers import load_covid_golden
+    from helpers import counter_rng, load_covid_golden, sampler_entry_rng, sampler_pick_row
 
     cfg = dict(load_covid_golden("c4_covid_variant")["cfg"], scenario_name="CovidAndEconomySimulation")
     E = 6
@@ -1507,57 +1515,9 @@ def test_policy_sampler_covid_collated_masks():
     mp = be.tensors["obs_p_action_mask"]   # [E, MP]
     NL1, MP = ma.shape[1], mp.shape[-1]
     per_env = n + 1
-    M64 = (1 << 64) - 1
-
-    def counter_rng(seed, env_id, t, slot):
-        z = (seed + 0x9E3779B97F4A7C15 * (env_id + 1)) & M64
-        z ^= ((t + 1) * 0xBF58476D1CE4E5B9) & M64
-        z ^= ((slot + 1) * 0x94D049BB133111EB) & M64
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
-        z ^= z >> 31
-        return z >> 32
-
-    def slog(v):  # csrc/aie_layout.h: aie_sampler_log, transcribed (plain IEEE multiplies, adds and one division)
-        m, ex = math.frexp(v)
-        m, ex = m * 2.0, ex - 1
-        if m > 1.4142135623730951:
-            m, ex = m * 0.5, ex + 1
-        sv = (m - 1.0) / (m + 1.0)
-        z = sv * sv
-        pl = 0.076923076923076927
-        for cst in (0.090909090909090912, 0.1111111111111111, 0.14285714285714285, 0.2, 0.33333333333333331, 1.0):
-            pl = pl * z + cst
-        return float(ex) * 0.69314718055994529 + (2.0 * sv) * pl
-
-    for v in (1e-10, 0.3, 0.9999999, 1.0, 2.5, 22.0):
-        assert abs(slog(v) - math.log(v)) <= 1e-12 * max(1.0, abs(math.log(v)))
-
-    def entry_rng(slot_word, k):  # aie_sampler_entry_rng
-        h = (slot_word + k * 0x9E3779B1) & 0xffffffff
-        h ^= h >> 16
-        h = (h * 0x7feb352d) & 0xffffffff
-        h ^= h >> 15
-        h = (h * 0x846ca68b) & 0xffffffff
-        return h ^ (h >> 16)
-
-    def key(score, k):  # aie_sampler_key
-        import struct
-
-        b = struct.unpack("<Q", struct.pack("<d", score))[0]
-        b = (~b & M64) if b >> 63 else (b | (1 << 63))
-        return (b & ~0x7ff) | (2047 - k)
 
     def pick(logits, mask, e, t, j):
-        slot_word = entry_rng(counter_rng(31, 50 + e, t, per_env), 0x40000000 + j)
-        best = 0
-        for k in range(len(logits)):
-            x = float(logits[k])
-            if not (mask[k] > 0.5) or x != x:
-                continue
-            u = (entry_rng(slot_word, k) + 0.5) / 4294967296.0
-            best = max(best, key(x - slog(-slog(u)), k))
-        return 2047 - (best & 0x7ff) if best else 0
+        return sampler_pick_row(logits, mask, sampler_entry_rng(counter_rng(31, 50 + e, t, per_env), j))
 
     g = torch.Generator(device="cpu").manual_seed(5)
     changed = 0

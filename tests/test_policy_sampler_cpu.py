@@ -1,14 +1,16 @@
-"""aie_sample_policy_actions, CPU side: the sampler's building blocks (csrc/aie_layout.h: aie_sampler_log,
-aie_sampler_key, aie_sampler_entry_rng) against their Python transcription and libm, and -- through oracle/'s restatement,
-which the -m gpu tests hold the kernel to entry for entry -- that the sampler draws from softmax(logits) restricted to the
-action mask (what a trainer expects of it: base_env.py:141-145, tutorials/rllib/env_wrapper.py:50-211)."""
+"""aie_sample_policy_actions, CPU side: the sampler's building blocks (csrc/aie_layout.h: aie_sampler_expf,
+aie_sampler_entry_rng, the fixed prefix-sum order) against their Python transcription (tests/helpers.py) and libm, and --
+through oracle/'s restatement, which the -m gpu tests hold the kernel to entry for entry -- that the sampler draws from
+softmax(logits) restricted to the action mask (what a trainer expects of it: base_env.py:141-145,
+tutorials/rllib/env_wrapper.py:50-211)."""
+import ctypes as C
 import math
 import struct
 
 import numpy as np
 import pytest
 
-from helpers import make_env
+from helpers import make_env, sampler_entry_rng, sampler_expf, sampler_pick_row, sampler_uniform
 
 GTB = [["Build", {}], ["ContinuousDoubleAuction", {"max_num_orders": 5}], ["Gather", {}], ["PeriodicBracketTax", {}]]
 C2 = dict(scenario_name="layout_from_file/simple_wood_and_stone", n_agents=4, world_size=[25, 25],
@@ -16,46 +18,74 @@ C2 = dict(scenario_name="layout_from_file/simple_wood_and_stone", n_agents=4, wo
           env_layout_file="quadrant_25x25_20each_30clump.txt")
 
 
-def _slog(v):
-    m, ex = math.frexp(v)
-    m, ex = m * 2.0, ex - 1
-    if m > 1.4142135623730951:
-        m, ex = m * 0.5, ex + 1
-    s = (m - 1.0) / (m + 1.0)
-    z = s * s
-    p = 0.076923076923076927
-    for c in (0.090909090909090912, 0.1111111111111111, 0.14285714285714285, 0.2, 0.33333333333333331, 1.0):
-        p = p * z + c
-    return float(ex) * 0.69314718055994529 + (2.0 * s) * p
-
-
-def test_sampler_log_is_the_same_bits_everywhere_and_close_to_libm():
+def test_sampler_exp_is_the_same_bits_everywhere_and_close_to_libm():
     from oracle_lib import lib
 
     L = lib()
     rs = np.random.RandomState(0)
     worst = 0.0
-    vals = list(np.exp(rs.uniform(-23, 4, size=20000))) + [1.0, 2.0, 0.5, 1.4142135623730951, 1.4142135623730954, 1e-10, 22.18]
-    for v in vals:
-        got = L.aie_oracle_sampler_log(float(v))
-        assert struct.pack("<d", got) == struct.pack("<d", _slog(float(v))), v
-        worst = max(worst, abs(got - math.log(v)) / max(1.0, abs(math.log(v))))
-    assert worst < 1e-12, worst
+    vals = list(-rs.uniform(0, 60, size=3000)) + list(-np.exp(rs.uniform(-30, 4.4, size=2000))) + [0.0, -0.0, -0.34657359, -0.346573591,
+                                                                                                  -79.9, -80.0, -80.1, -1e30, -87.5]
+    for y in vals:
+        y = np.float32(y)
+        got = L.aie_oracle_sampler_expf(float(y))
+        assert struct.pack("<f", got) == struct.pack("<f", sampler_expf(y)), y
+        if y > -80.0:
+            worst = max(worst, abs(got - math.exp(float(y))) / math.exp(float(y)))
+        else:
+            assert got == 0.0
+    assert worst < 4e-7, worst
+    assert L.aie_oracle_sampler_expf(0.0) == 1.0
+    for rnd in (0, 1, 511, 512, 0x7fffffff, 0xffffffff, 0x12345678):
+        got = L.aie_oracle_sampler_uniform(rnd)
+        assert got == float(sampler_uniform(rnd)) == ((rnd >> 9) + 0.5) / 2.0 ** 23 and 0.0 < got < 1.0
 
 
-def test_sampler_key_orders_scores_then_prefers_the_lower_entry():
+def test_fmaf_transcription_rounds_once():
+    """helpers.fmaf (exact rational arithmetic) where rounding the float64 result a second time would go wrong."""
+    from helpers import fmaf
+
+    f32 = np.float32
+    a, b = f32(1.0 + 2.0 ** -12), f32(1.0 + 2.0 ** -12)  # a b = 1 + 2^-11 + 2^-24: half a unit above 1 + 2^-11 ...
+    assert fmaf(a, b, f32(2.0 ** -60)) == f32(1.0 + 2.0 ** -11 + 2.0 ** -23)  # ... plus a sliver float64 cannot hold: up
+    assert fmaf(a, b, f32(-2.0 ** -60)) == f32(1.0 + 2.0 ** -11)  # minus the sliver: down
+    assert fmaf(a, b, f32(0.0)) == f32(1.0 + 2.0 ** -11)  # the exact tie: to even
+    rs = np.random.RandomState(1)
+    for _ in range(300):  # where float64 holds the sum exactly, one more rounding is the answer
+        x, y, z = f32(rs.randn()), f32(rs.randn()), f32(rs.randn())
+        d = float(x) * float(y) + float(z)
+        from fractions import Fraction
+        if Fraction(float(x)) * Fraction(float(y)) + Fraction(float(z)) == Fraction(d):
+            assert fmaf(x, y, z) == f32(d)
+
+
+def test_sampler_row_equals_its_python_transcription():
+    """oracle/'s row sampler (the kernel's twin) against the transcription: rows of 1 .. 150 entries (one, two and three
+    64-entry chunks), masks, NaN and hopeless logits, fully masked rows."""
     from oracle_lib import lib
 
     L = lib()
-    rs = np.random.RandomState(1)
-    sc = np.concatenate([rs.randn(2000) * 5, [-1e30, 1e30, 0.0, -0.0, 1e-300, -1e-300]])
-    for a, b in zip(sc[:-1], sc[1:]):
-        ka, kb = L.aie_oracle_sampler_key(float(a), 7), L.aie_oracle_sampler_key(float(b), 7)
-        if abs(a - b) > 1e-9 * max(1.0, abs(a), abs(b)):  # (scores closer than the 11 dropped bits count as tied)
-            assert (ka > kb) == (a > b), (a, b)
-    assert L.aie_oracle_sampler_key(1.5, 3) > L.aie_oracle_sampler_key(1.5, 4) > 0
-    assert L.aie_oracle_sampler_key(-1e30, 2047) > 0  # 0 is reserved for "nothing allowed"
-    assert (L.aie_oracle_sampler_key(2.25, 1234) & 0x7ff) == 2047 - 1234
+    rs = np.random.RandomState(2)
+    seen = set()
+    for trial in range(400):
+        n = int(rs.choice([1, 2, 7, 11, 22, 50, 63, 64, 65, 101, 128, 150]))
+        lg = (rs.randn(n) * rs.choice([0.5, 3.0, 30.0])).astype(np.float32)
+        mask = (rs.rand(n) < rs.choice([0.2, 0.7, 1.0])).astype(np.float32)
+        if trial % 9 == 0:
+            lg[rs.randint(n)] = np.nan
+        if trial % 11 == 0:
+            lg[:] = -1e30
+        if trial % 13 == 0:
+            mask[:] = 0.0
+        if trial % 17 == 0:
+            lg[:] = 0.25
+        word = int(rs.randint(0, 2 ** 32, dtype=np.uint64))
+        want = sampler_pick_row(lg, mask, word)
+        got = L.aie_oracle_sample_row(lg.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p), 1, n, word)
+        assert got == want, (trial, n, got, want)
+        assert want == 0 or (mask[want] > 0.5 and lg[want] == lg[want])
+        seen.add(want)
+    assert len(seen) > 40
 
 
 def test_sampler_entry_hash_is_uniform():
@@ -63,6 +93,7 @@ def test_sampler_entry_hash_is_uniform():
 
     L = lib()
     words = np.array([L.aie_oracle_sampler_entry_rng(0x1234567 + 977 * s, k) for s in range(256) for k in range(256)], np.uint32)
+    assert int(words[5 * 256 + 9]) == sampler_entry_rng(0x1234567 + 977 * 5, 9)
     h = np.bincount(words.view(np.uint8), minlength=256).astype(np.float64)
     exp = words.size * 4 / 256.0
     assert float(((h - exp) ** 2 / exp).sum()) < 330.5  # 255 degrees of freedom, 99.9 %
