@@ -14,7 +14,7 @@ MAX_RATES = 64
 N_RES = 2
 MT_N = 624
 RNG_NUMPY, RNG_FAST = 0, 1  # aie_config.rng_mode (AIE_RNG_*)
-RNG_FAST_STATE_WORDS = 4     # tensor "mt" in fast mode: key32, block number, salt, 0
+RNG_FAST_STATE_WORDS = 4     # tensor "mt" in fast mode: key32, block number, salt, resets so far
 
 COMP_BUILD, COMP_CDA, COMP_GATHER, COMP_TAX, COMP_SIMPLE_LABOR = 1, 2, 3, 4, 5
 COMP_COVID_CONTROL, COMP_COVID_SUBSIDY, COMP_COVID_VACCINE = 6, 7, 8

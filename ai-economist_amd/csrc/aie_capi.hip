@@ -472,7 +472,18 @@ int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos) {
 }
 
 // gather-trade-build reset: the compile-time instance of the environment's configuration if it has one
+static void aie_launch_gtb_reset_only(aie_env* env, const uint8_t* d_mask, int keep_rewards, void* stream);
 static void aie_launch_gtb_reset(aie_env* env, const uint8_t* d_mask, int keep_rewards, void* stream) {
+  aie_launch_gtb_reset_only(env, d_mask, keep_rewards, stream);
+  if (aie__layout_staged(&env->P.c)) {  // generated layouts in the counter-stream mode: drawn ahead of their resets
+    const int threshold = env->P.E >= 4 ? (int)(env->P.E / 4) : 1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(aie_layout_decide_kernel, dim3(1), dim3(1), 0, st, env->d_params, env->arena, threshold);
+    hipLaunchKernelGGL(aie_layout_refill_kernel, dim3((unsigned)env->P.E), dim3(LG_NW * AIE_NT),
+                       env->lds + aie::layout_gen_lds_bytes(env->P), st, env->d_params, env->arena);
+  }
+}
+static void aie_launch_gtb_reset_only(aie_env* env, const uint8_t* d_mask, int keep_rewards, void* stream) {
   // LG_NW wavefronts per replica when the reset draws a new source layout (aie_kernels.hip: layout_generate), else one
   const dim3 g((unsigned)env->P.E), b(env->P.c.layout_gen != AIE_LAYOUT_FIXED ? LG_NW * AIE_NT : AIE_NT);
   const size_t lds = env->lds + aie::layout_gen_lds_bytes(env->P);

@@ -3149,12 +3149,18 @@ struct LgShared {      // cross-wave scratch in LDS (behind the planes)
   uint32_t am[2][LG_NW][2]; // gauss: per-wave accept masks, two parities
   int32_t thr[32];          // threshold search: cells on after iteration k of the current block
   uint32_t kbits[2];        // growth kernel: sign bits of the 49 randn values
+  double lcache;            // legacy_gauss's one-value cache of a layout stream of its own (aie_layout_stream): the
+  int32_t lhas, lpad_;      //   replica's own cache, a record field, belongs to the replica's stream
 };
 __host__ __device__ inline size_t layout_gen_lds_bytes(const aie_params& P) {
   if (P.c.layout_gen == AIE_LAYOUT_FIXED) return 0;
   const size_t hwp = ((size_t)P.HW + 15) / 16 * 16;
   // tmp, x (f64), two byte planes, the multi_zone grid, the cross-wave scratch
   return 2 * hwp * 8 + 2 * hwp + 256 * 4 + ((sizeof(LgShared) + 15) / 16 * 16);
+}
+__device__ __forceinline__ LgShared* lg_shared(uint8_t* extra, const aie_params& P) {  // (layout_generate's carve-up of `extra`)
+  const size_t hwp = ((size_t)P.HW + 15) / 16 * 16;
+  return reinterpret_cast<LgShared*>(extra + 2 * hwp * 8 + 2 * hwp + 256 * 4);
 }
 // number of lanes of the whole workgroup for which `on` holds (every wave calls it; one barrier)
 __device__ __forceinline__ int lg_block_count(bool on, LgShared* sh, int& par, int wave, int lane) {
@@ -3178,9 +3184,8 @@ __device__ __forceinline__ int lg_kth_bit(uint64_t mask, int k, int lane) {
 // called once for k = 0 .. count - 1 by the lane that owns the value.  LG_NW x 64 attempts per pass: attempt a reads
 // the four words at pos + 4 a.  Called by all waves; contains barriers.
 template <typename Emit>
-__device__ __forceinline__ void lg_gauss(const Ctx& c, MT3& s, int count, LgShared* sh, int& par, int wave, int lane, Emit emit) {
-  int32_t* has = R_I32(c, o_mt_has_gauss);
-  double* cache = R_F64(c, o_mt_gauss);
+__device__ __forceinline__ void lg_gauss(MT3& s, int count, LgShared* sh, int& par, int wave, int lane, int32_t* has,
+                                         double* cache, Emit emit) {
   int produced = 0;
   const bool cached = count > 0 && uni(*has) != 0;
   __syncthreads();  // every wave has looked at the cache flag before anybody changes it
@@ -3242,7 +3247,27 @@ __device__ __forceinline__ void lg_gauss(const Ctx& c, MT3& s, int count, LgShar
 // MultiZone's per-reset zone shuffle (:778-872), Quadrant's empty water lines (:992-1024).  Called by all LG_NW waves
 // of the replica's workgroup (gtid = 0 .. LG_NW * 64 - 1); `m` is every wave's copy of the generator, advanced
 // identically.  c.tid is the lane.
-__device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8_t* __restrict__ arena, uint8_t* extra, int gtid) {
+// (cell flags of the record image <- the two source planes, with the checker / water-line cuts of the scenario)
+template <typename Planes>
+__device__ __forceinline__ void layout_install(const Ctx& c, int gtid, int nthreads, Planes planes) {
+  const aie_params& P = c.P;
+  const aie_config& g = P.c;
+  const int H = P.H, W = P.W, HW = P.HW;
+  uint8_t* cb = reinterpret_cast<uint8_t*>(R_CELLS(c));
+  for (int cell = gtid; cell < HW; cell += nthreads) {
+    const int r = cell / W, col = cell - r * W;
+    const uint32_t bits = planes(cell);  // bit 0 Stone, bit 1 Wood
+    bool st = (bits & 1u) != 0, wd = (bits & 2u) != 0;
+    if (g.layout_checker && ((r & 1) + (col & 1)) != 1) st = wd = false;
+    if (g.layout_gen == AIE_LAYOUT_QUADRANT && (col == H / 2 || r == W / 2)) st = wd = false;  // nothing on the water lines
+    cb[4 * cell + 3] = (uint8_t)((cb[4 * cell + 3] & AIE_CELL_WATER) | (st ? AIE_CELL_STONE_SRC : 0) | (wd ? AIE_CELL_WOOD_SRC : 0));
+  }
+}
+// `ghas` / `gcache`: legacy_gauss's cache of the stream the layout is drawn from (the record's for the replica's own
+// stream, LgShared's for a layout stream).  `stage_out` != nullptr: the planes go to the staging area (one byte per cell:
+// bit 0 Stone, bit 1 Wood) instead of into the record image's cell flags.
+__device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8_t* __restrict__ arena, uint8_t* extra, int gtid,
+                                                int32_t* ghas, double* gcache, uint8_t* __restrict__ stage_out = nullptr) {
   const aie_params& P = c.P;
   const aie_config& g = P.c;
   const int H = P.H, W = P.W, HW = P.HW, lane = gtid & 63, wave = gtid >> 6;
@@ -3433,7 +3458,7 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
         LG_CNT(6);
         if (gtid < 2) sh->kbits[gtid] = 0;
         { LG_T0();
-        lg_gauss(c, s3, 49 + HW, sh, gpar, wave, lane, [&](int k, double gs) {
+        lg_gauss(s3, 49 + HW, sh, gpar, wave, lane, ghas, gcache, [&](int k, double gs) {
           if (k < 49) {
             if (gs > 0) atomicOr(&sh->kbits[k >> 5], 1u << (k & 31));
           } else {
@@ -3496,13 +3521,10 @@ __device__ __forceinline__ void layout_generate(const Ctx& c, MT& m, const uint8
   }
   mt_copy(m, s3.w[0]);
   m.pos = s3.pos;
-  uint8_t* cb = reinterpret_cast<uint8_t*>(R_CELLS(c));
-  for (int cell = gtid; cell < HW; cell += NT) {
-    const int r = cell / W, col = cell - r * W;
-    bool st = mbp[0][cell] != 0, wd = mbp[1][cell] != 0;
-    if (g.layout_checker && ((r & 1) + (col & 1)) != 1) st = wd = false;
-    if (g.layout_gen == AIE_LAYOUT_QUADRANT && (col == H / 2 || r == W / 2)) st = wd = false;  // nothing on the water lines
-    cb[4 * cell + 3] = (uint8_t)((cb[4 * cell + 3] & AIE_CELL_WATER) | (st ? AIE_CELL_STONE_SRC : 0) | (wd ? AIE_CELL_WOOD_SRC : 0));
+  if (stage_out) {
+    for (int cell = gtid; cell < HW; cell += NT) stage_out[cell] = (uint8_t)((mbp[0][cell] ? 1u : 0u) | (mbp[1][cell] ? 2u : 0u));
+  } else {
+    layout_install(c, gtid, NT, [&](int cell) -> uint32_t { return (mbp[0][cell] ? 1u : 0u) | (mbp[1][cell] ? 2u : 0u); });
   }
   __syncthreads();
 #ifdef AIE_DEV
@@ -3544,7 +3566,47 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
   m.pos = uni(*R_I32(c, o_mt_pos));
   mt_fast_attach(c, m);
   if (LAYOUT && P.c.layout_gen != AIE_LAYOUT_FIXED) {  // a fresh source layout, drawn before anything else of the reset
-    layout_generate(c, m, arena, lds + lds_bytes(P), gtid);
+    if (aie__layout_staged(&P.c)) {
+      // the counter-stream mode: this reset's layout is a function of (the replica's stream, resets so far) alone
+      // (aie_layout.h: aie_layout_stream) -- already in the staging area if a refill launch came by since the last
+      // reset, else drawn here from the same stream; the replica's own stream is not touched either way
+      uint32_t st[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) st[k] = (uint32_t)uni((int)R_U32(c, o_mt)[k]);
+      const uint64_t tag = aie_layout_tag(st);
+      const uint64_t* tags = reinterpret_cast<const uint64_t*>(arena + R.a_layout_tag);
+      int32_t* ctl = reinterpret_cast<int32_t*>(arena + R.a_layout_ctl);
+      const uint64_t have = tags[e];
+      const bool staged = (uint32_t)uni((int)(uint32_t)have) == (uint32_t)tag && (uint32_t)uni((int)(uint32_t)(have >> 32)) == (uint32_t)(tag >> 32);
+      __syncthreads();  // (every wave has read the state words before the first one counts the reset)
+      if (staged) {
+        const uint8_t* sp = arena + R.a_layout_stage + (int64_t)e * R.layout_stage_stride;
+        layout_install(c, gtid, LG_NW * AIE_NT, [&](int cell) -> uint32_t { return sp[cell]; });
+        __syncthreads();
+      } else {
+        LgShared* sh = lg_shared(lds + lds_bytes(P), P);
+        if (gtid == 0) {
+          sh->lhas = 0;
+          sh->lcache = 0.0;
+        }
+        __syncthreads();
+        uint32_t ks[2];
+        aie_layout_stream(st, ks);
+        MT ml;
+        mt_init(ml, P);
+        ml.fkey = ks[0];
+        ml.fblk = 0xffffffffu;
+        ml.fsalt = ks[1];
+        layout_generate(c, ml, arena, lds + lds_bytes(P), gtid, &sh->lhas, &sh->lcache);
+      }
+      if (gtid == 0) {
+        R_U32(c, o_mt)[3] = st[3] + 1u;  // resets so far
+        atomicAdd(&ctl[0], 1);           // one more replica without a staged layout for its coming reset
+        atomicAdd(&ctl[staged ? 2 : 3], 1);
+      }
+    } else {
+      layout_generate(c, m, arena, lds + lds_bytes(P), gtid, R_I32(c, o_mt_has_gauss), R_F64(c, o_mt_gauss));
+    }
     if (wave != 0) return;
   }
   {  // layout_from_file.py:323-334: resources back on every source block, no houses
@@ -3742,6 +3804,52 @@ aie_reset_kernel_layout(const aie_params* __restrict__ params, uint8_t* __restri
                         const uint8_t* __restrict__ mask, int keep_rewards) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   aie::reset_body<-1, true>(params, arena, mask, keep_rewards, lds);
+}
+// Generated layouts in the counter-stream mode, ahead of their resets (aie_layout.h: a_layout_stage).  Behind every reset
+// launch: one thread decides whether a refill pays -- a refill launch lasts as long as its slowest replica (0.3 ms at
+// BASELINE configs[0]'s scenario, 1 - 10 tries of the coverage check) however many layouts it draws, so it waits until
+// `threshold` replicas have used theirs up (a de-phased rollout resets 2 % of the replicas per launch: one 0.3 ms
+// chain per ~12 reset launches instead of one in each) -- then every replica whose coming reset has no staged layout
+// yet draws it.  Replicas that reset twice between two refills draw the second layout inside the reset, as before:
+// the layout is the same function of (stream, resets so far) wherever it is drawn.
+extern "C" __global__ void aie_layout_decide_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena, int threshold) {
+  int32_t* ctl = reinterpret_cast<int32_t*>(arena + params->a_layout_ctl);
+  const bool go = ctl[0] >= threshold;
+  ctl[1] = go ? 1 : 0;
+  if (go) ctl[0] = 0;
+}
+extern "C" __global__ void __launch_bounds__(LG_NW * AIE_NT)
+aie_layout_refill_kernel(const aie_params* __restrict__ params, uint8_t* __restrict__ arena) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const aie_params& P = *params;
+  const int32_t* ctl = reinterpret_cast<const int32_t*>(arena + P.a_layout_ctl);
+  if (!ctl[1]) return;
+  const int e = (int)blockIdx.x, gtid = (int)threadIdx.x;
+  const uint32_t* stg = reinterpret_cast<const uint32_t*>(arena + P.a_records + (int64_t)e * P.rec_bytes + P.o_mt);
+  uint32_t st[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) st[k] = (uint32_t)aie::uni((int)stg[k]);
+  const uint64_t tag = aie_layout_tag(st);
+  uint64_t* tags = reinterpret_cast<uint64_t*>(arena + P.a_layout_tag);
+  const uint64_t have = tags[e];
+  if ((uint32_t)aie::uni((int)(uint32_t)have) == (uint32_t)tag && (uint32_t)aie::uni((int)(uint32_t)(have >> 32)) == (uint32_t)(tag >> 32)) return;
+  const aie::Ctx c = aie::make_ctx(P, P, lds, e, gtid & 63, arena);
+  aie::LgShared* sh = aie::lg_shared(lds + aie::lds_bytes(P), P);
+  if (gtid == 0) {
+    sh->lhas = 0;
+    sh->lcache = 0.0;
+  }
+  __syncthreads();
+  uint32_t ks[2];
+  aie_layout_stream(st, ks);
+  aie::MT ml;
+  aie::mt_init(ml, P);
+  ml.fkey = ks[0];
+  ml.fblk = 0xffffffffu;
+  ml.fsalt = ks[1];
+  aie::layout_generate(c, ml, arena, lds + aie::lds_bytes(P), gtid, &sh->lhas, &sh->lcache,
+                       arena + P.a_layout_stage + (int64_t)e * P.layout_stage_stride);
+  if (gtid == 0) tags[e] = tag;  // (behind layout_generate's closing barrier: the staged bytes are written)
 }
 // compile-time instances (aie_spec_generated.h), as for the step kernel
 template <int SPEC>

@@ -29,6 +29,12 @@
 
 #include "aie.h"
 
+#if defined(__HIPCC__)
+#define AIE_HD __host__ __device__
+#else
+#define AIE_HD
+#endif
+
 #define AIE_MAX_TENSORS 160
 #define AIE_MAX_MASK 544   /* entries of one agent's flattened action mask (4 x 127 prices + ...) */
 
@@ -146,6 +152,19 @@ typedef struct aie_params {
   int32_t saez_global_cap, saez_pad_;
   int64_t a_layout_prob; /* shared f64 [AIE_N_RES][H*W]: source probability maps of the generated layouts (layout_gen
                           * UNIFORM / QUADRANT: uploaded once by the host, tensor "layout_source_prob") */
+  /* Generated layouts under AIE_RNG_FAST (aie__layout_staged): a replica's k-th reset draws its source layout from a
+   * stream of its own (aie_layout_stream: keyed by the replica's stream and k, the record's fourth state word), so the
+   * layout does not depend on what the episode's steps drew and can be made AHEAD of the reset.  Staging area:
+   *   a_layout_stage  u8 [E][layout_stage_stride]: bit 0 Stone source, bit 1 Wood source per cell (before the checker /
+   *                   water-line cuts), valid iff the tag equals the tag of the replica's coming reset;
+   *   a_layout_tag    u64 [E]: aie_layout_tag of the staged layout (0: none);
+   *   a_layout_ctl    int32 [4]: staged layouts consumed since the last refill, the refill's go flag, installs from the
+   *                   staging area, layouts drawn inside a reset (development counters).
+   * A reset installs the staged layout when the tag matches and draws the layout itself otherwise (same stream, same
+   * result); behind every reset launch a one-thread kernel decides whether enough layouts were consumed for a refill
+   * launch to pay (its duration is that of the slowest replica, however many it draws). */
+  int64_t a_layout_stage, a_layout_tag, a_layout_ctl;
+  int32_t layout_stage_stride, layout_pad_;
   int64_t a_src_list;    /* shared, fixed layouts with shared_layout only (aie__shared_src_list): int32 count (16 B), then
                           * uint16 [AIE_SRC_CAP]: the regeneration draws that target a source block (double d of a step's
                           * 2 H W np.random.rand values: Wood cell d, or Stone cell d - H W), derived once by
@@ -269,6 +288,7 @@ static inline void aie_spec_normalize(aie_params* p) {
   p->a_cv_events = p->a_cv_ev0 = 0;
   p->a_cv_replay_a = p->a_cv_replay_p = p->a_cv_replay_state = 0;
   p->a_layout_prob = 0;
+  p->a_layout_stage = p->a_layout_tag = p->a_layout_ctl = 0;
   p->a_src_list = 0;
   p->dev_skip_mask = 0;
   p->dev_trace = 0;
@@ -348,6 +368,23 @@ static inline int aie__record_src_list(const aie_config* c) {
 /* words of generator state in a replica's record ("mt"): MT19937's key, or (key32, block number, salt, 0) of the
  * counter stream (include/aie.h: AIE_RNG_FAST) */
 static inline int32_t aie__rng_state_words(const aie_config* c) { return c->rng_mode == AIE_RNG_FAST ? 4 : AIE_MT_N; }
+/* generated layouts come from a stream of their own, drawn ahead of the reset (aie_params: a_layout_stage) */
+AIE_HD static inline int aie__layout_staged(const aie_config* c) {
+  return c->scenario == AIE_SCN_GTB && c->layout_gen != AIE_LAYOUT_FIXED && c->rng_mode == AIE_RNG_FAST;
+}
+/* The layout stream of a replica's k-th reset, k = st[3], from its stream's state st = (key, block, salt, k): the same
+ * Philox function with key + 0x9E3779B9 (k >> 15) and the counter's high word salt | 0x8000 | (k & 0x7fff) -- bit 15 is
+ * never set in the replica's own stream (its pair index stays below 2^47).  out = (key, salt); the stream starts at its
+ * block 0 (state block 0xffffffff, position 624: the first draw opens block 0). */
+AIE_HD static inline void aie_layout_stream(const uint32_t st[4], uint32_t out[2]) {
+  out[0] = st[0] + 0x9E3779B9u * (st[3] >> 15);
+  out[1] = st[2] | 0x8000u | (st[3] & 0x7fffu);
+}
+AIE_HD static inline uint64_t aie_layout_tag(const uint32_t st[4]) {  /* never 0: bit 15 */
+  uint32_t ks[2];
+  aie_layout_stream(st, ks);
+  return ((uint64_t)ks[0] << 32) | (uint64_t)ks[1];
+}
 
 /* record field allocator */
 static inline int32_t aie__rec(int32_t* cur, int32_t bytes, int32_t align) {
@@ -1208,6 +1245,14 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   aie__alloc_saez(c, p, &a);
   p->a_layout_prob = a;
   if (c->layout_gen != AIE_LAYOUT_FIXED) a = aie__align(a + (int64_t)AIE_N_RES * HW * 8, 256);
+  p->layout_stage_stride = (HW + 15) / 16 * 16;
+  p->layout_pad_ = 0;
+  p->a_layout_stage = p->a_layout_tag = p->a_layout_ctl = a;
+  if (aie__layout_staged(c)) {
+    p->a_layout_stage = a; a = aie__align(a + E * p->layout_stage_stride, 256);
+    p->a_layout_tag = a;   a = aie__align(a + E * 8, 256);
+    p->a_layout_ctl = a;   a = aie__align(a + 16, 256);
+  }
   p->a_src_list = a;
   if (aie__shared_src_list(c)) a = aie__align(a + 16 + 2 * AIE_SRC_CAP, 256);
   p->arena_bytes = a;
@@ -1306,6 +1351,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
     aie__add_saez_tensors(p, tt);
     if (c->layout_gen != AIE_LAYOUT_FIXED)
       aie__add_shared(tt, "layout_source_prob", AIE_F64, p->a_layout_prob, 2, AIE_N_RES, HW);
+    if (aie__layout_staged(c)) aie__add_shared(tt, "layout_stage_ctl", AIE_I32, p->a_layout_ctl, 1, 4, 0);
 #undef DENSE
   }
   return AIE_OK;
@@ -1313,11 +1359,6 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
 
 /* Counter-based RNG of the benchmark's synthetic uniform random policy
  * (SURVEY.md 8(d)): splitmix64 finaliser over (seed, global replica id, t, slot). */
-#if defined(__HIPCC__)
-#define AIE_HD __host__ __device__
-#else
-#define AIE_HD
-#endif
 /* annealed_tax_limit, F/components/utils.py:10-56 */
 AIE_HD static inline double aie_annealed_tax_limit(int completions, double warmup, double slope, double final_max) {
   double pv = slope * ((double)completions - warmup);

@@ -133,6 +133,12 @@ WORKLOADS = {
                      "oracle's restatement of the same generator (tests/test_rng_fast.py); never the headline",
                 cfg=lambda: dict(C2_CFG, rng_mode="fast"), envs=4096, survey_bytes=10984.0, kernel="aie_step_kernel",
                 rng="fast"),
+    "C1f": dict(short="configs[0] scenario batched with rng_mode='fast': layouts from a stream of their own, drawn ahead of the resets",
+                desc="C1 in the throughput mode rng_mode='fast' (see C2f): a replica's k-th reset draws its source layout from "
+                     "a counter stream keyed by the replica and k (csrc/aie_layout.h: aie_layout_stream), so the library draws "
+                     "layouts ahead of their resets -- one refill launch per quarter of the replicas instead of one 0.3 ms "
+                     "chain inside every masked reset",
+                cfg=lambda: dict(C1_CFG, rng_mode="fast"), envs=4096, survey_bytes=5303.0, kernel="aie_step_kernel", rng="fast"),
     "C3f": dict(short="configs[2] one GPU share with rng_mode='fast' (counter-based stream; NOT NumPy's stream)",
                 desc="BASELINE configs[2], one GPU's share, in the throughput mode rng_mode='fast' (see C2f)",
                 cfg=lambda: dict(C2_CFG, n_agents=10, rng_mode="fast"), envs=4096, survey_bytes=7666.0,
@@ -748,6 +754,7 @@ def run_workload(wl, args, steps, warmup, rank, local_rank, world, device):
                                                 "C2v": "gather-trade-build 25x25 4-agent batched envs, other scalars",
                                                 "C2f": "gather-trade-build 25x25 4-agent batched envs, counter-based RNG (not NumPy's stream)",
                                                 "C3f": "gather-trade-build 25x25 10-agent batched envs, counter-based RNG (not NumPy's stream)",
+                                                "C1f": "simple_wood_and_stone 15x15 4-agent Gather+Build batched envs, counter-based RNG (not NumPy's stream)",
                                                 "P2": "gather-trade-build 25x25 4-agent batched envs, phase-2 YAML",
                                                 "C3": "gather-trade-build 25x25 10-agent batched envs",
                                                 "C4": "covid19_env 51 US-state agents + planner",
@@ -916,7 +923,7 @@ def emit(out, detail_file):
     print(compact_line(out), flush=True)
 
 
-SIDE_WORKLOADS = [("C1", 200, 20), ("C2v", 200, 20), ("C2f", 200, 20), ("P2", 200, 20), ("C3", 200, 20), ("C3f", 200, 20),
+SIDE_WORKLOADS = [("C1", 200, 20), ("C1f", 200, 20), ("C2v", 200, 20), ("C2f", 200, 20), ("P2", 200, 20), ("C3", 200, 20), ("C3f", 200, 20),
                   ("C4", 200, 20), ("C4x", 100, 10),
                   ("C4xu", 100, 10), ("C2@16384", 100, 20), ("C2@65536", 60, 10), ("C5", 60, 20)]
 

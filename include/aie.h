@@ -72,8 +72,14 @@ extern "C" {
  *                  uses (the resource regeneration addresses the words of its source cells directly instead of
  *                  advancing MT19937 through all 4 H W of them).  Checked bit for bit against oracle/'s restatement of
  *                  the same generator; not stream-compatible with NumPy.  COVID draws no random numbers: ignored there.
+ *                  Scenarios that draw a new source layout at every reset (uniform/, quadrant/, multi_zone/) take the
+ *                  layout of a replica's k-th reset (k = 0, 1, ... since seeding) from a stream of its own -- the same
+ *                  function with key32 + 0x9E3779B9 (k >> 15) and the counter's high word salt | 0x8000 | (k & 0x7fff),
+ *                  from its word 0 -- so the layout does not depend on what the episode's steps drew, and the library
+ *                  draws layouts AHEAD of their resets (one refill launch behind a reset once a quarter of the
+ *                  replicas have used theirs up; a reset whose layout is not there yet draws it itself: same result).
  * The position bookkeeping is shared: the stream is consumed in blocks of AIE_MT_N words ("mt_pos" counts inside the
- * block, 624 = block exhausted); in fast mode tensor "mt" is uint32 [E, 4] = key32, block number, salt, 0. */
+ * block, 624 = block exhausted); in fast mode tensor "mt" is uint32 [E, 4] = key32, block number, salt, resets so far. */
 #define AIE_RNG_NUMPY 0
 #define AIE_RNG_FAST 1
 #define AIE_COVID_MAX_FILTERS 8 /* unemployment filter bank size (covid19_env.py:242)    */
@@ -384,7 +390,7 @@ int aie_seed(aie_env* env, uint32_t base_seed, void* stream);
  * seed + global_env_offset + e (48 bits are used); aie_seed(env, s, ...) is aie_seed_fast(env, s, 0, ...) there. */
 int aie_seed_fast(aie_env* env, uint64_t seed, int64_t global_env_offset, void* stream);
 /* Raw legacy-MT19937 state per replica: key[E][624], pos[E] (np.random.get_state()); rng_mode == AIE_RNG_FAST:
- * key[E][4] (key32, block number, salt, 0), pos[E]. */
+ * key[E][4] (key32, block number, salt, resets so far), pos[E]. */
 int aie_set_rng_state(aie_env* env, const uint32_t* key, const int32_t* pos);
 
 /* Resets the replicas whose env_mask byte is non-zero (NULL = all); env_mask is a

@@ -1426,7 +1426,30 @@ static void reset_one(const aie_params* p, uint8_t* arena, int e) {
   *I32(&c, o_timestep) = 0;
   memset(MET(&c), 0, (size_t)p->met_bytes); /* component resets clear their episode logs */
   if (EV(&c)) EV(&c)[0] = 0;
-  if (p->c.layout_gen != AIE_LAYOUT_FIXED) layout_generate(&c); /* a fresh source layout from this replica's stream */
+  if (p->c.layout_gen != AIE_LAYOUT_FIXED) {
+    if (aie__layout_staged(&p->c)) {
+      /* the counter-stream mode: the k-th reset's layout comes from a stream of its own (aie_layout.h: aie_layout_stream;
+       * the device may have drawn it ahead of the reset), the replica's stream and its Gauss cache stay as they are */
+      uint32_t* st = (uint32_t*)(c.rec + p->o_mt);
+      uint32_t keep[4], ks[2];
+      memcpy(keep, st, sizeof(keep));
+      const int32_t keep_pos = *I32(&c, o_mt_pos), keep_has = *I32(&c, o_mt_has_gauss);
+      const double keep_gauss = *F64(&c, o_mt_gauss);
+      aie_layout_stream(keep, ks);
+      st[0] = ks[0]; st[1] = 0xffffffffu; st[2] = ks[1];
+      *I32(&c, o_mt_pos) = 624;
+      *I32(&c, o_mt_has_gauss) = 0;
+      *F64(&c, o_mt_gauss) = 0.0;
+      layout_generate(&c);
+      memcpy(st, keep, sizeof(keep));
+      st[3] = keep[3] + 1u;
+      *I32(&c, o_mt_pos) = keep_pos;
+      *I32(&c, o_mt_has_gauss) = keep_has;
+      *F64(&c, o_mt_gauss) = keep_gauss;
+    } else {
+      layout_generate(&c); /* a fresh source layout from this replica's stream */
+    }
+  }
   for (int cell = 0; cell < HW; ++cell) { /* layout_from_file.py:323-334 */
     unsigned fl = C_FLAGS(&c, cell);
     CELLS(&c)[cell] = AIE_CELL_PACK((fl & AIE_CELL_STONE_SRC) ? 1 : 0, (fl & AIE_CELL_WOOD_SRC) ? 1 : 0, -1, fl);

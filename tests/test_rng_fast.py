@@ -351,6 +351,51 @@ def test_hip_fast_mode_dynamic_layouts():
 
 
 @pytest.mark.gpu
+def test_hip_fast_mode_layouts_drawn_ahead_of_their_resets():
+    """Generated layouts in the counter-stream mode come from a stream of their own, keyed by the replica's stream and its
+    number of resets (csrc/aie_layout.h: aie_layout_stream), so the library draws them AHEAD of the reset once a quarter of
+    the replicas have used theirs up.  A de-phased pattern of masked resets -- some replicas twice between two refills --
+    takes both roads (installed from the staging area; drawn inside the reset) and equals the oracle, which draws every
+    layout at its reset, field for field."""
+    import torch
+    from oracle_lib import OracleEnv
+    from test_gpu_parity import _compare_all
+
+    E = 96
+    env = make_env(dict(C1, episode_length=1000), n_envs=E, device="cuda:0", rng_mode="fast")
+    be = env.backend
+    env.seed(33)
+    env.reset()
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(33)
+    oracle.reset()
+    ctl = be.tensors["layout_stage_ctl"]
+    torch.cuda.synchronize()
+    base = ctl.cpu().reshape(-1).tolist()  # (layouts consumed since the last refill, the refill's go flag, installs, draws inside a reset)
+    assert base[:2] == [0, 1] and base[2] + base[3] > 0 and (base[2] + base[3]) % E == 0, base  # the refill behind the reset ran
+    _compare_all(be, oracle, "after reset")
+    rs = np.random.RandomState(5)
+    groups = [list(range(0, 8)), list(range(0, 8)), list(range(8, 40)), list(range(4, 12)), list(range(40, 96)), list(range(0, 96)),
+              list(rs.choice(E, 20, replace=False)), list(rs.choice(E, 30, replace=False)), list(range(0, 8))]
+    for k, grp in enumerate(groups):
+        for _ in range(3):
+            a, p = be.sample_random_actions(seed=99)
+            env.step({"a": a, "p": p})
+            oracle.step(a.cpu().numpy(), p.cpu().numpy(), nthreads=4)
+        mask = np.zeros(E, np.uint8)
+        mask[grp] = 1
+        env.reset(torch.from_numpy(mask).to("cuda:0"))
+        oracle.reset(mask)
+        torch.cuda.synchronize()
+        _compare_all(be, oracle, "masked reset %d" % k)
+    n_empty, go, staged, inside = ctl.cpu().reshape(-1).tolist()
+    staged, inside = staged - base[2], inside - base[3]
+    assert staged + inside == sum(len(g) for g in groups)
+    assert staged > 150 and inside >= 8, (staged, inside)  # (the second reset of replicas 0 - 7 found nothing staged)
+    assert int(be.tensors["mt"][:, 3].min()) >= 2  # resets so far, the stream's fourth state word
+
+
+@pytest.mark.gpu
 def test_hip_fast_mode_one_step_economy():
     """one-step-economy: the agent-order permutation SimpleLabor draws and discards (the stream's position is state)."""
     _gpu_case(_ose_cfg(12, 3), 64, 20, seed=6, check_every=1, reset_at=(3, 6, 9, 12, 15, 18))
