@@ -69,7 +69,8 @@ struct Ctx {
   int32_t* mflags;   // LDS [n] per-agent mask bits
   int32_t* dirty;    // LDS [4 + AIE_DIRTY_CAP/2]: count, moved-agent mask (2 words), pad, uint16 cell list
   uint8_t* snap;     // LDS [2][HW]: pre-step max(map, source block) per resource (P.regen_general only), else nullptr
-  uint8_t* met;      // GLOBAL: this replica's episode accumulators (aie_layout.h: a_metrics), or nullptr
+  uint8_t* met;      // (one-step-economy: this replica's episode accumulators; everybody else: C_MET)
+  uint8_t* met_arena;  // GLOBAL: the arena where the replica has episode accumulators (aie_layout.h: a_metrics), else nullptr
   int32_t* ev;       // GLOBAL: this replica's dense-log event rows (a_events), or nullptr (not logged)
   bool saez;         // tax_model == "saez" (compile-time false in the common step kernel, like ev == nullptr)
   bool full;         // compile-time: false in the common step kernel (aie_step_kernel), which leaves out what
@@ -185,6 +186,9 @@ __host__ __device__ inline size_t lds_bytes(const aie_params& P) {
   return (b + 15) / 16 * 16;
 }
 
+// the accumulators' address where it is used (rarely: a trade, a tax day) instead of in every prologue: a_metrics was a
+// scalar load ahead of the step kernel's first record load (0.2 us of the launch, round 6)
+#define C_MET(c) ((c).met_arena ? (c).met_arena + (c).R.a_metrics + (int64_t)(c).e * (c).P.met_bytes : nullptr)
 __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R, uint8_t* lds, int e, int tid,
                                         uint8_t* arena = nullptr, bool with_events = true, int skipm = 0,
                                         bool lds_tables = false) {
@@ -220,13 +224,13 @@ __device__ __forceinline__ Ctx make_ctx(const aie_params& P, const aie_params& R
   uint32_t* mtwin = mt_window_in_lds(P) ? reinterpret_cast<uint32_t*>(q) : nullptr;
   if (mt_window_in_lds(P)) q += AIE_MT_WINDOW_LDS_BYTES;
   uint8_t* snap = P.regen_general ? q : nullptr;
-  uint8_t* met = arena ? arena + R.a_metrics + (int64_t)e * P.met_bytes : nullptr;
+  uint8_t* met = nullptr;  // (C_MET)
   // with_events == false is a compile-time constant in the common step kernel: every `if (c.ev)` / `if (c.saez)`
   // folds away (environments with dense-log replicas or tax_model "saez" run aie_step_kernel_log)
   int32_t* ev = (with_events && arena && e < R.ev_replicas)  // (the event buffer is a property of the batch, not of an
                     ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * R.ev_stride) : nullptr;  // instance's family)
   const bool saez = with_events && P.c.tax_model == AIE_TAX_SAEZ;
-  return Ctx{P, R, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, snap, met, ev, saez, with_events, tid, e, rtab, mtab, mtwin, skipm};
+  return Ctx{P, R, lds, act_p, locmap, fscr, stage, srcl, srcn, mflags, dirty, snap, met, arena, ev, saez, with_events, tid, e, rtab, mtab, mtwin, skipm};
 }
 
 // ------------------------------------------------------------------------------------
@@ -375,7 +379,9 @@ __device__ __forceinline__ void fast_pair(uint32_t key, uint32_t blk, uint32_t s
 // `wave` of `nwaves` copies every nwaves-th 16-byte unit; wave `key_wave` also takes the MT19937 key (registers).
 __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restrict__ arena, MT& m, int wave = 0,
                                             int nwaves = 1, int key_wave = 0) {
-  const uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
+  // (a_records == 0: the records open the arena, aie_layout.h -- not read from the parameter block: every scalar load a
+  // workgroup needs before its first record load costs the launch 0.2 - 0.3 us, round 6)
+  const uint8_t* g = arena + (int64_t)c.e * c.P.rec_bytes;
   const uint4* src = reinterpret_cast<const uint4*>(g);
   uint4* dst = reinterpret_cast<uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
@@ -388,7 +394,7 @@ __device__ __forceinline__ void load_record(const Ctx& c, const uint8_t* __restr
 }
 __device__ __forceinline__ void store_record(const Ctx& c, uint8_t* __restrict__ arena, const MT& m, int wave = 0,
                                              int nwaves = 1, int key_wave = 0) {
-  uint8_t* g = arena + c.R.a_records + (int64_t)c.e * c.P.rec_bytes;
+  uint8_t* g = arena + (int64_t)c.e * c.P.rec_bytes;  // (a_records == 0, see load_record)
   uint4* dst = reinterpret_cast<uint4*>(g);
   const uint4* src = reinterpret_cast<const uint4*>(c.rec);
   const int nq = rec_lds_bytes(c.P) >> 4;
@@ -1438,8 +1444,8 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
         atomicSub(reinterpret_cast<uint32_t*>(bid_hist + (bi & ~3)), 1u << (8 * (bi & 3)));
         atomicSub(reinterpret_cast<uint32_t*>(ask_hist + (ai & ~3)), 1u << (8 * (ai & 3)));
         unsafeAtomicAdd(R_F64(c, o_cda_price_history) + (r * n + seller) * P + price, 1.0);
-        if (c.met) {  // get_metrics :585-641: fire-and-forget integer atomics
-          int32_t* tm = reinterpret_cast<int32_t*>(c.met + c.P.mo_cda);
+        if (C_MET(c)) {  // get_metrics :585-641: fire-and-forget integer atomics
+          int32_t* tm = reinterpret_cast<int32_t*>(C_MET(c) + c.P.mo_cda);
           int32_t* sell = tm + ((0 * AIE_N_RES + r) * n + seller) * 2;
           int32_t* buy = tm + ((1 * AIE_N_RES + r) * n + buyer) * 2;
           atomicAdd(sell, 1); atomicAdd(sell + 1, price);
@@ -1481,8 +1487,8 @@ __device__ __forceinline__ void cda_component_step(const Ctx& c, Agents& A) {
       bid_hist[(r * n + buyer) * P + bprice] -= 1;
       ask_hist[(r * n + seller) * P + aprice] -= 1;
       R_F64(c, o_cda_price_history)[(r * n + seller) * P + price] += 1.0;
-      if (lane == 0 && c.met) {  // get_metrics :585-641: fire-and-forget integer atomics
-        int32_t* tm = reinterpret_cast<int32_t*>(c.met + c.P.mo_cda);
+      if (lane == 0 && C_MET(c)) {  // get_metrics :585-641: fire-and-forget integer atomics
+        int32_t* tm = reinterpret_cast<int32_t*>(C_MET(c) + c.P.mo_cda);
         int32_t* sell = tm + ((0 * AIE_N_RES + r) * n + seller) * 2;
         int32_t* buy = tm + ((1 * AIE_N_RES + r) * n + buyer) * 2;
         atomicAdd(sell, 1); atomicAdd(sell + 1, price);
@@ -1613,7 +1619,7 @@ __device__ __forceinline__ double tax_curr_rate_max(const Ctx& c) {
 }
 // this replica's Saez block (tax_model "saez", aie_layout.h: a_saez); step / reset kernels only (c.met set)
 __device__ __forceinline__ uint8_t* saez_block(const Ctx& c) {
-  return c.met - c.R.a_metrics - (int64_t)c.e * c.P.met_bytes + c.R.a_saez + (int64_t)c.e * c.P.saez_stride;
+  return C_MET(c) - c.R.a_metrics - (int64_t)c.e * c.P.met_bytes + c.R.a_saez + (int64_t)c.e * c.P.saez_stride;
 }
 __device__ __forceinline__ double tax_rate(const Ctx& c, int b) {  // curr_marginal_rates :396-417
   if (c.P.c.tax_model == AIE_TAX_MODEL_WRAPPER) return c.rtab[R_I32(c, o_tax_rate_idx)[b]];
@@ -1695,23 +1701,23 @@ __device__ __forceinline__ void tax_enact(const Ctx& c, Agents& A) {
     R_F64(c, o_tax_last_income)[i] = income;
     A.coin -= eff;
     eff_rate = eff / (income > 0.000001 ? income : 0.000001);  // :880
-    if (c.met) {  // episode accumulators for get_metrics :1141-1186 (no-return atomics)
-      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_income) + i, income > 0 ? income : 0.0);
-      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_paid) + i, eff);
+    if (C_MET(c)) {  // episode accumulators for get_metrics :1141-1186 (no-return atomics)
+      unsafeAtomicAdd(reinterpret_cast<double*>(C_MET(c) + c.P.mo_tax_income) + i, income > 0 ? income : 0.0);
+      unsafeAtomicAdd(reinterpret_cast<double*>(C_MET(c) + c.P.mo_tax_paid) + i, eff);
       int bin = 0;  // income_bin :828-835
       if (income >= 0)
         for (int b = 0; b < c.P.NB; ++b)
           if (income >= c.R.c.tax_bracket_cutoffs[b] && (b + 1 == c.P.NB || income < c.R.c.tax_bracket_cutoffs[b + 1])) { bin = b; break; }
-      atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_occ) + bin, 1);
+      atomicAdd(reinterpret_cast<int32_t*>(C_MET(c) + c.P.mo_tax_occ) + bin, 1);
     }
   }
-  if (c.met) {
-    if (i < c.P.NB) unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_sched) + i, tax_rate(c, i));
+  if (C_MET(c)) {
+    if (i < c.P.NB) unsafeAtomicAdd(reinterpret_cast<double*>(C_MET(c) + c.P.mo_tax_sched) + i, tax_rate(c, i));
     double day = 0;
     for (int j = 0; j < n; ++j) day += bcast(eff_rate, j);
     if (i == 0) {
-      unsafeAtomicAdd(reinterpret_cast<double*>(c.met + c.P.mo_tax_eff), day);
-      atomicAdd(reinterpret_cast<int32_t*>(c.met + c.P.mo_tax_days), 1);
+      unsafeAtomicAdd(reinterpret_cast<double*>(C_MET(c) + c.P.mo_tax_eff), day);
+      atomicAdd(reinterpret_cast<int32_t*>(C_MET(c) + c.P.mo_tax_days), 1);
     }
   }
   if (c.ev) {
@@ -2701,24 +2707,25 @@ __device__ __forceinline__ uint32_t glibc_tables_touch(int lane) {
 }
 
 struct NextActions {  // aie_step_sample_next: where and how to sample the next step's random actions
-  int32_t* a;
-  int32_t* p;
-  uint64_t seed;
-  int64_t env_offset;  // (the draw index `t` of the counter RNG is the replica's own record field o_sample_t)
+  // The replica count (and the replica range) FIRST: a workgroup needs them for its very first decision (which replica it
+  // is), and here they share the argument segment's first 64 bytes with the parameter block's and the arena's pointers
+  // -- one scalar-cache miss instead of two at the head of every workgroup (round 6; as a field of the parameter block
+  // the count had been a second, dependent round trip: the caches are cold at every launch).
+  int32_t E;
   // replicas this launch steps: [e_lo, e_hi), or all of them when e_hi == 0.  An environment with dense-log replicas
   // whose current episode is being logged steps those replicas with aie_step_kernel_log and the rest with its fast
   // kernel (aie_capi.hip: aie_step_impl)
   int32_t e_lo, e_hi;
   int32_t masked;  // aie_step_sample_next_masked (COVID): the next actions are drawn among what the new masks allow
+  int32_t* a;
+  int32_t* p;
+  uint64_t seed;
+  int64_t env_offset;  // (the draw index `t` of the counter RNG is the replica's own record field o_sample_t)
   // aie_step_range (custom host components, include/aie.h): the built-in components [comp_lo, comp_hi) of the list and
   // the parts of a step this launch performs -- AIE_STEP_HEAD (timestep += 1), AIE_STEP_TAIL (regeneration, observations,
   // masks, rewards, done), AIE_STEP_OBSERVE (observations and masks of the state as it stands, nothing else); phase == 0:
   // a whole step.  Honoured by the full-featured kernel only (aie_step_kernel_log); everybody else steps whole steps.
   int32_t comp_lo, comp_hi, phase;
-  // The replica count, by value: a workgroup needs it for its very first decision (which replica it is), and as a
-  // kernel argument it arrives with the argument segment instead of behind a second, dependent round trip to the
-  // parameter block (round 6: the caches are cold at every launch, a first touch from the far XCDs takes ~1 us).
-  int32_t E;
 };
 // This step's slot of the reward log: the replica's slot counter selects it and moves on (`writer`: the one lane that
 // stores the counter back; every lane of the wave calls this with the same fields).
@@ -2762,6 +2769,8 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
   using namespace aie;
   // The parameter block lives in device memory (uniform scalar loads).  Passing the 2.7 KB
   // struct by value made the compiler copy it to scratch on every launch (5x slower).
+  // (round 6: requesting every kernel argument in one batch up here cost 2 us -- scalar-cache misses are served one at a
+  // time, and most arguments are not needed before the record is on its way; see the sampler for the opposite case)
   const aie_params& R = *params;
   const aie_params& P = aie_spec_params<SPEC>(params);
   const int wid = NW == 1 ? 0 : uni((int)(threadIdx.x >> 6));
@@ -2813,10 +2822,15 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     // ---------------- first wave: actions, components, flat vectors, rewards ----------------
     Agents A;
     int act_err = 0;
-    if (!(skip & (1 << 18))) act_err = decode_actions(c, A, act_a, act_p);  // (the loads ride beside the record's; c.act_p is LDS scratch)
+    if (!(skip & (1 << 18))) act_err = decode_actions(c, A, act_a, act_p);  // (c.act_p is LDS scratch)
     else A.act = 0;
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x] = wall_clock64();
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 9] = wall_clock64();
+    // (round 6, tools/ab2.sh: requesting the action words and the wave's whole share of the image before anything waits
+    // -- the loop below comes out as load, wait, LDS write per unit, behind decode_actions' two load-wait-decode rounds --
+    // made the launch SLOWER, 22.5 -> 23.5 us, and so did milder orders (both action loads first: 22.7; the record ahead of
+    // the decode: 22.9): 4096 workgroups start together, and what their first microseconds are short of is the memory
+    // system's capacity for requests, not patience -- the loop's own pace spreads them)
     MT none;
     load_record(c, arena, none, 0, NW, /*key_wave=*/-1);
     __syncthreads();  // (2) the record is in LDS
@@ -2893,6 +2907,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     if (skip & (1 << 16)) {}  // (development: the load phase without the draw window)
     else if (FAST) draw_window_publish_fast(draw_w, draw_cap, (uint32_t)uni((int)gkey[0]), (uint32_t)uni((int)gkey[1]), (uint32_t)uni((int)gkey[2]), uni(gpos), c.tid);
     else draw_window_publish_from_hbm(draw_w, draw_cap, gkey, uni(gpos), c.tid);
+
     if (SPEC >= 0 && const_tables_in_lds(P)) {
       // the small constant tables (Ctx.rtab / mtab) -> LDS, published by the barrier below
       if (P.has_tax && P.c.tax_model == AIE_TAX_MODEL_WRAPPER)
@@ -2908,6 +2923,9 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
 #pragma unroll
     for (int k = 0; k < AIE_SRC_CAP / AIE_NT; ++k) src.d[k] = 0;
     src = SHL ? src_list_from_arena(c, arena) : src_list_from_record(c, arena);  // (the loads ride under the first wave's dynamics)
+    // (round 6: six scalar touches here, for the parameter-block lines the two tails read, cost 1.2 us -- this wave is not
+    // idle enough to absorb six misses served one at a time; removing a_records / a_metrics from the prologue and sharing
+    // one argument line gave 0.2 - 0.3 us each)
 #ifndef AIE_NO_TABLE_TOUCH  // (A/B builds)
     const uint32_t warm = glibc_tables_touch(c.tid);
 #else
@@ -3556,7 +3574,7 @@ __device__ __forceinline__ void reset_body(const aie_params* __restrict__ params
   const Ctx c = make_ctx(P, R, lds, e, gtid & 63, arena);
   const int n = P.n, HW = P.HW, tid = c.tid;
   if (wave == 0) {
-    for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(c.met)[q] = 0u;  // new episode
+    for (int q = tid; q < (P.met_bytes >> 2); q += AIE_NT) reinterpret_cast<uint32_t*>(C_MET(c))[q] = 0u;  // new episode
     if (c.ev && tid == 0) c.ev[0] = 0;
   }
   MT m;

@@ -85,7 +85,7 @@ __device__ __forceinline__ Ctx ose_make_ctx(const aie_params& P, const aie_param
   s.tmpl_p = s.tmpl_a + pad4(P.FA > P.MA ? P.FA : P.MA);
   uint8_t* met = arena + R.a_metrics + (int64_t)e * P.met_bytes;
   int32_t* ev = e < R.ev_replicas ? reinterpret_cast<int32_t*>(arena + R.a_events + (int64_t)e * R.ev_stride) : nullptr;
-  return Ctx{P, R, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e,
+  return Ctx{P, R, lds, act_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, met, arena, ev, P.c.tax_model == AIE_TAX_SAEZ, true, tid, e,
              /*rtab=*/R.c.tax_disc_rates, /*mtab=*/P.mask_test, /*mtwin=*/nullptr, /*skipm=*/0};
 }
 

@@ -1219,7 +1219,7 @@ static inline int aie_build_params(const aie_config* c, aie_params* p, aie_tenso
   /* ---- arena ------------------------------------------------------------------- */
   const int64_t E = p->E;
   int64_t a = 0;
-  p->a_records = a; a = aie__align(a + E * (int64_t)p->rec_bytes, 256);
+  p->a_records = a; a = aie__align(a + E * (int64_t)p->rec_bytes, 256); /* (0: the step kernel's record copies rely on it) */
   p->am_ch = c->full_observability ? p->CM : p->CM + 1;
   p->am_h = c->full_observability ? p->H : p->WV;
   p->am_w = c->full_observability ? p->W : p->WV;

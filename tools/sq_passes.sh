@@ -24,12 +24,12 @@ dur = collections.defaultdict(list)
 for f in sorted(glob.glob("$R/gpurun_out/sq_${WL}_*/s_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "step_kernel" in k or "window_kernel" in k:
+        if "step_kernel" in k or "window_kernel" in k or "aie_jit_step" in k:
             acc[k.split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in sorted(glob.glob("$R/gpurun_out/sq_${WL}_*/s_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "step_kernel" in k or "window_kernel" in k:
+        if "step_kernel" in k or "window_kernel" in k or "aie_jit_step" in k:
             dur[k.split("(")[0][:60]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 out = {}
 for k, d in acc.items():
