@@ -71,6 +71,10 @@ SPECS = [
     # AIE_RNG_FAST) of the two headline configurations -- never the headline itself
     ("C2f: C2 with rng_mode='fast'", "layout_from_file/simple_wood_and_stone", dict(_BASE, n_agents=4, rng_mode="fast"), "gtb", 8),
     ("C3f: C3 with rng_mode='fast'", "layout_from_file/simple_wood_and_stone", dict(_BASE, n_agents=10, rng_mode="fast"), "gtb", 8),
+    # C1's scenario in the throughput mode: layouts from a stream of their own, drawn ahead of their resets
+    ("C1f: C1 with rng_mode='fast'", "uniform/simple_wood_and_stone",
+     dict(n_agents=4, world_size=[15, 15], episode_length=1000, components=[("Build", {}), ("Gather", {})],
+          starting_agent_coin=10, starting_stone_coverage=0.10, starting_wood_coverage=0.10, rng_mode="fast"), "gtb", 8),
 ]
 
 

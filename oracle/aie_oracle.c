@@ -1972,6 +1972,13 @@ void aie_oracle_sample_policy_actions(const aie_params* p, uint8_t* arena, const
 }
 /* the sampler's building blocks (aie_layout.h), exported so that a CPU test can hold them to their Python transcription
  * and to libm */
+/* the layout stream of a replica's k-th reset in the counter-stream mode (aie_layout.h): out = (key, counter high word, tag lo, tag hi) */
+void aie_oracle_layout_stream(const uint32_t* st, uint32_t* out) {
+  aie_layout_stream(st, out);
+  const uint64_t tag = aie_layout_tag(st);
+  out[2] = (uint32_t)tag;
+  out[3] = (uint32_t)(tag >> 32);
+}
 float aie_oracle_sampler_expf(float y) { return aie_sampler_expf(y); }
 float aie_oracle_sampler_uniform(uint32_t rnd) { return aie_sampler_uniform(rnd); }
 uint32_t aie_oracle_sampler_entry_rng(uint32_t slot_word, uint32_t k) { return aie_sampler_entry_rng(slot_word, k); }

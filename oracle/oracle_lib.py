@@ -54,6 +54,8 @@ def lib():
         L.aie_oracle_seed64.restype = None
         L.aie_oracle_philox2x32_10.argtypes = [vp, C.c_uint32, vp]
         L.aie_oracle_philox2x32_10.restype = None
+        L.aie_oracle_layout_stream.argtypes = [vp, vp]
+        L.aie_oracle_layout_stream.restype = None
         L.aie_oracle_sample_policy_actions.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int64, vp, vp]
         L.aie_oracle_sample_policy_actions.restype = None
         L.aie_oracle_sampler_expf.argtypes = [C.c_float]

@@ -109,6 +109,49 @@ def test_fast_mode_is_deterministic_and_keyed_by_global_replica():
         assert np.array_equal(big.t[k][4:], shard.t[k]), k
 
 
+def test_generated_layouts_have_a_stream_of_their_own_in_fast_mode():
+    """uniform/ in the counter-stream mode: the source layout of a replica's k-th reset is a function of (its stream's key
+    and salt, k) alone -- the same whatever the episode's steps drew in between (which is what lets the device draw it
+    ahead of the reset) -- and a different one for every k; the fourth state word counts the resets.  In the parity mode
+    the layout comes out of the replica's NumPy stream at the reset, so it DOES depend on the draws before it."""
+    from oracle_lib import lib
+
+    rs = np.random.RandomState(3)
+    flags = {}
+    for mode in ("fast", "numpy"):
+        for steps in (0, 7):
+            _, o = _oracle(dict(C1, episode_length=50), 5, 19, rng_mode=mode)
+            first = o.t["cell_flags"].copy()
+            for _ in range(steps):
+                o.step(rs.randint(0, 6, size=(5, 4)).astype(np.int32), np.zeros((5, 1), np.int32))
+            o.reset(np.ones(5, np.uint8))
+            flags[mode, steps] = (first, o.t["cell_flags"].copy(), o.t["mt"].copy(), o.t["mt_pos"].copy())
+    f0, f7 = flags["fast", 0], flags["fast", 7]
+    assert np.array_equal(f0[0], f7[0]) and np.array_equal(f0[1], f7[1])      # layouts 0 and 1: the same with or without steps
+    assert not np.array_equal(f0[0], f0[1])                                   # ... and different from each other
+    assert (f0[2][:, 3] == 2).all() and (f7[2][:, 3] == 2).all()              # resets so far
+    assert np.array_equal(f0[2][:, [0, 2]], f7[2][:, [0, 2]])                 # key and salt: the stream's identity
+    assert not np.array_equal(f0[3], f7[3]) or not np.array_equal(f0[2][:, 1], f7[2][:, 1])  # the replica's own stream did move
+    n0, n7 = flags["numpy", 0], flags["numpy", 7]
+    assert np.array_equal(n0[0], n7[0]) and not np.array_equal(n0[1], n7[1])  # parity mode: the second layout follows the draws
+    # the stream's definition (csrc/aie_layout.h: aie_layout_stream), word for word
+    L = lib()
+    for st in ([5, 9, 0x12340000, 0], [5, 9, 0x12340000, 1], [0xffffffff, 0, 0, 32767], [7, 3, 0xffff0000, 32768], [7, 3, 0, 98305]):
+        buf = (C.c_uint32 * 4)(*st)
+        out = (C.c_uint32 * 4)()
+        L.aie_oracle_layout_stream(buf, out)
+        k = st[3]
+        assert out[0] == (st[0] + 0x9E3779B9 * (k >> 15)) & 0xffffffff
+        assert out[1] == st[2] | 0x8000 | (k & 0x7fff)
+        assert (out[3] << 32 | out[2]) == (out[0] << 32 | out[1]) != 0
+    # the first words of layout stream 1 of replica 2 are Philox words of that key / counter (block 0, pairs 0, 1, ...)
+    st = [int(v) for v in f0[2][2]]
+    st[3] = 1
+    out = (C.c_uint32 * 4)()
+    L.aie_oracle_layout_stream((C.c_uint32 * 4)(*st), out)
+    assert _philox(0, out[1], out[0]) != _philox(0, st[2], st[0])  # not the replica's own block 0
+
+
 def test_fast_and_numpy_modes_differ_only_in_the_stream():
     """Same configuration: the two modes share every tensor's shape except the generator state, and where no draw
     decides anything (NO-OP actions, nothing to regenerate) their trajectories coincide."""

@@ -10,7 +10,7 @@ mkdir -p $R/gpurun_out/summ
 cd /tmp && export TMPDIR=/tmp
 for WL in "$@"; do
   case $WL in C5) STEPS=100; WARM=20;; C4*) STEPS=300; WARM=30;; C2@65536) STEPS=90; WARM=10;; C2@16384) STEPS=300; WARM=30;; *) STEPS=600; WARM=50;; esac
-  case $WL in C5) KN=aie_ose_step_kernel;; C4x*) KN=aie_covid_step_kernel+aie_covid_window_kernel;; C4) KN=aie_covid_step_kernel;; C1f) KN=aie_jit_step;; *) KN=aie_step_kernel;; esac  # (C1f: a run-time instance)
+  case $WL in C5) KN=aie_ose_step_kernel;; C4x*) KN=aie_covid_step_kernel+aie_covid_window_kernel;; C4) KN=aie_covid_step_kernel;; *) KN=aie_step_kernel;; esac
   w=$(echo $WL | tr 'A-Z' 'a-z' | sed 's/@/_e/')
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r06_$w -o s -- \
     python $R/bench.py --workload $WL --no-workloads --no-cpu-baseline --steps $STEPS --warmup $WARM > $R/gpurun_out/prof_r06_$w.json 2> $R/gpurun_out/prof_r06_$w.err
