@@ -2851,7 +2851,7 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
     __syncthreads();  // (3) occupancy map rebuilt
     if (c.tid == 0 && HEAD) *R_I32(c, o_timestep) += 1;
     if (c.ev && c.tid == 0) c.srcn[2] = 0;
-    __builtin_amdgcn_s_setprio(3);  // the serial dynamics are the replica's critical path
+    __builtin_amdgcn_s_setprio(3);  // the serial dynamics are the replica's critical path (at any batch size: round 6 A/B)
     if (TRACE && R.dev_trace && c.tid == 0) R.dev_trace[12 * blockIdx.x + 1] = wall_clock64();
     if (!(skip & 1)) {
       for (int k = c_lo; k < c_hi; ++k) {
@@ -2951,7 +2951,13 @@ __device__ __forceinline__ void step_body(const aie_params* __restrict__ params,
 #ifdef AIE_W1_TAIL_PRIO  // (A/B builds)
     __builtin_amdgcn_s_setprio(AIE_W1_TAIL_PRIO);
 #else
-    __builtin_amdgcn_s_setprio(2);  // from here on this wave is the critical one (the first has slack)
+    // A batch that fits the device in one go (4096 workgroups at 8 waves per SIMD) is a race to the last workgroup's end:
+    // from here on this wave is the critical one (the first has slack) and goes ahead of the waves still loading.  A
+    // larger batch is a stream of workgroups, bound by the vector pipes: there a raised tail only delays the next
+    // workgroups' start (tools/ab2.sh, round 6: 16 384 replicas 74.5 -> 72.8 us without it, 65 536: 318 -> 314 us;
+    // 4096: 22.5 -> 23.0 us WITHOUT it).
+    if (next.E > 6144) __builtin_amdgcn_s_setprio(0);
+    else __builtin_amdgcn_s_setprio(2);
 #endif
     if (FAST) {  // the stream's state is in the LDS image (the components may have moved it to the next block)
       const uint32_t* st = R_U32(c, o_mt);

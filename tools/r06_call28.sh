@@ -6,6 +6,9 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06_final_driver_win
 tail -1 gpurun_out/r06_final_driver_window.txt > gpurun_out/r06_final_bench.json
 cp bench_detail.json gpurun_out/r06_final_bench_detail.json
 python bench.py --gpus 1 --no-workloads --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r06_c2_long_window.json
-cut -c1-400 gpurun_out/r06_final_bench.json
+cut -c1-200 gpurun_out/r06_final_bench.json
 echo
-cut -c1-300 gpurun_out/r06_c2_long_window.json
+cut -c1-200 gpurun_out/r06_c2_long_window.json
+echo
+timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed" > gpurun_out/r06_final_gpu_tests.txt
+cat gpurun_out/r06_final_gpu_tests.txt
