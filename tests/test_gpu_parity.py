@@ -1465,6 +1465,34 @@ def test_policy_sampler_equals_its_cpu_restatement(case):
     assert be.lib.aie_sample_policy_actions(be.handle, None, None, 77, 1000, a.data_ptr(), None, None) != 0
 
 
+@pytest.mark.parametrize("E", [1, 5])
+def test_policy_sampler_odd_batches(E):
+    """A workgroup of the sampler holds two replicas: batches of one and of five replicas (a half-empty last workgroup)
+    against the oracle, agents' and planner's rows, the draw index advancing."""
+    import torch
+    from oracle_lib import OracleEnv
+
+    env = make_env(dict(C2, episode_length=30), n_envs=E, device="cuda:0", env_offset=7)
+    env.seed(4)
+    env.reset()
+    be = env.backend
+    oracle = OracleEnv(env.build_config(), env.layout_planes())
+    oracle.seed(4 + 7)
+    oracle.reset()
+    MA, MP = be.tensors["obs_a_action_mask"].shape[-1], be.tensors["obs_p_action_mask"].shape[-1]
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for t in range(6):
+        la = (torch.randn(E, be.n, MA, generator=g) * 2).float()
+        lp = (torch.randn(E, MP, generator=g) * 2).float()
+        a, p = be.sample_policy_actions(la.to("cuda:0"), lp.to("cuda:0"), seed=9, env_offset=7)
+        torch.cuda.synchronize()
+        wa, wp = oracle.sample_policy_actions(la.numpy(), lp.numpy(), 9, 7, width_a=a.shape[-1], width_p=p.shape[-1])
+        assert np.array_equal(a.cpu().numpy(), wa) and np.array_equal(p.cpu().numpy(), wp), t
+        assert np.array_equal(be.tensors["sample_t"].cpu().numpy(), oracle.t["sample_t"])
+        env.step({"a": a, "p": p})
+        oracle.step(wa.reshape(E, -1), wp, nthreads=1)
+
+
 def test_backend_lifecycle_free_now_and_failed_construction(monkeypatch):
     """A library-owned arena (forced here for a small environment) goes back to the device at free_now(), not when the
     garbage collector finds the last view; a constructor that fails after aie_create destroys the handle it made."""
