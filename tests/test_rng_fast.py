@@ -439,6 +439,39 @@ def test_hip_fast_mode_layouts_drawn_ahead_of_their_resets():
 
 
 @pytest.mark.gpu
+def test_hip_fast_mode_staged_layout_follows_an_injected_stream():
+    """A replica that receives another replica's whole state (tensor writes: the staging area knows nothing of it) is that
+    replica's clone from then on -- its next reset must draw the CLONED stream's layout, although the staging area holds one
+    for its old stream: the stage is keyed by the stream's identity and the reset count, so the clone draws inside the
+    reset what the original installs from the staging area, and both get the same layout."""
+    import torch
+
+    E = 8
+    env = make_env(dict(C1, episode_length=1000), n_envs=E, device="cuda:0", rng_mode="fast")
+    be = env.backend
+    env.seed(5)
+    env.reset()
+    for _ in range(3):
+        a, p = be.sample_random_actions(seed=1)
+        env.step({"a": a, "p": p})
+    torch.cuda.synchronize()
+    ctl0 = be.tensors["layout_stage_ctl"].cpu().reshape(-1).tolist()
+    for k, t in be.tensors.items():  # replica 5 := replica 1, every per-replica tensor (incl. the generator's four words)
+        if t.dim() >= 1 and t.shape[0] == E:
+            t[5] = t[1]
+    mask = torch.zeros(E, dtype=torch.uint8, device="cuda:0")
+    mask[1] = mask[5] = 1
+    env.reset(mask)
+    torch.cuda.synchronize()
+    ctl1 = be.tensors["layout_stage_ctl"].cpu().reshape(-1).tolist()
+    assert ctl1[2] - ctl0[2] == 1 and ctl1[3] - ctl0[3] == 1  # one installed from the staging area, one drawn inside the reset
+    for k in ("cell_flags", "stone", "wood", "loc_r", "loc_c", "mt", "mt_pos", "build_skill"):
+        if k in be.tensors:
+            assert torch.equal(be.tensors[k][5], be.tensors[k][1]), k
+    assert not torch.equal(be.tensors["cell_flags"][5], be.tensors["cell_flags"][4])
+
+
+@pytest.mark.gpu
 def test_hip_fast_mode_one_step_economy():
     """one-step-economy: the agent-order permutation SimpleLabor draws and discards (the stream's position is state)."""
     _gpu_case(_ose_cfg(12, 3), 64, 20, seed=6, check_every=1, reset_at=(3, 6, 9, 12, 15, 18))
